@@ -1,0 +1,184 @@
+/*
+ * mccnn.h -- C-ABI of the MI355X-native Monte-Carlo convolution library
+ * (libmccnn_hip.so, built from mccnn_amd/csrc/ by hipcc for gfx950).
+ *
+ * This is the drop-in boundary for the reference's tf_ops operators
+ * (viscom-ulm/MCCNN, tf_ops .cc/.cu files behind tf_ops/MCConvModuleSrc). One entry
+ * point (or a count/fill pair where the output size is data dependent) replaces
+ * one registered TF op; each declaration cites the reference interface it
+ * replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _host;
+ *  - the library never allocates, frees or synchronises, except where a
+ *    function documents a host read-back (num_cells with scale_inv == 0);
+ *    scratch memory is caller-provided (`ws`, size from the matching
+ *    *_workspace_bytes query) -- the reference instead cudaMalloc/cudaFree'd
+ *    inside its launchers (find_neighbors.cu:298-309, sort_gpu.cu:410-418,
+ *    poisson_sampling.cu:202-223);
+ *  - every launch goes to the explicit `stream` (a hipStream_t passed as void*;
+ *    the reference used the legacy default stream);
+ *  - return value: 0 = ok, < 0 = argument error (MCCNN_E_*), > 0 = hipError_t.
+ *    The reference aborted the process on CUDA errors (cuda_kernel_utils.h:17-24);
+ *    this library never does;
+ *  - data layout is the reference's flattened ragged batch:
+ *    points [N,3] f32, batch ids [N] i32 (the [N,1] tensor, flat), features
+ *    [N,F] f32 row-major, aabb [B,3] f32, cell table [B,nc,nc,nc,2] i32,
+ *    start indices [M] i32, packed neighbours [E,2] i32 rows (j, i);
+ *  - kernel-MLP weights are addressed FLAT exactly like the reference kernels
+ *    (spatial_conv.cu:172): w1[nu*3+d], b1[nu], w2[q*64+n*8+m], b2[nu],
+ *    w3[q*64+n*8+m], b3[nu], nu = 8q+n -- although the Python variables are
+ *    declared [3,8nb] / [8,8nb] (MCConvBuilder.py:407-419) there is no transpose.
+ *  - canonical order: inside a grid cell points keep ascending original index;
+ *    Poisson samples are emitted batch -> phase -> cell (launch-linear) -> point.
+ *    Both are one valid outcome of the reference's atomics (sort_gpu.cu:170,
+ *    poisson_sampling.cu:115) and are reproducible.
+ */
+#ifndef MCCNN_H_
+#define MCCNN_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mccnn_stream_t; /* hipStream_t */
+
+#define MCCNN_OK 0
+#define MCCNN_E_BADARG (-1)     /* null pointer / non-positive size            */
+#define MCCNN_E_BATCHID (-2)    /* reserved (batch id outside [0,B))           */
+#define MCCNN_E_TOOLARGE (-3)   /* B*nc^3 or E does not fit int32              */
+#define MCCNN_E_WORKSPACE (-4)  /* workspace smaller than *_workspace_bytes    */
+#define MCCNN_E_SHAPE (-5)      /* MLP shape rules of spatial_conv.cc:258-300  */
+
+/* generated get_block_size(), genCompileScript.py:46-47 (BLOCK_MLP_SIZE = 8) */
+int mccnn_block_size(void);
+/* library/ABI version, arch string ("gfx950") */
+int mccnn_abi_version(void);
+const char* mccnn_arch(void);
+const char* mccnn_error_string(int code);
+
+/* ComputeAabb -- aabb_gpu.cc:22-86, aabb_gpu.cu:57-140.
+ * scale_inv == 0: every row receives the whole-batch box (aabb_gpu.cu:104-114). */
+size_t mccnn_compute_aabb_workspace_bytes(int batch_size);
+int mccnn_compute_aabb(const float* pts, const int* batch_ids, int n, int batch_size, int scale_inv,
+                       float* aabb_min, float* aabb_max, void* ws, size_t ws_bytes,
+                       mccnn_stream_t stream);
+
+/* determineNumCells -- sort_gpu.cu:374-420. scale_inv != 0: pure host arithmetic.
+ * scale_inv == 0: reads the box of batch 0 back to the host (one stream sync,
+ * like the reference's cudaMemcpy D2H at sort_gpu.cu:417). */
+int mccnn_num_cells(const float* aabb_min, const float* aabb_max, int batch_size, float cell_size,
+                    int scale_inv, int* num_cells_host, mccnn_stream_t stream);
+
+/* SortPointsStep1 -- sort_gpu.cc:23,184-268, sort_gpu.cu:35-174,436-471.
+ * keys[i] = b*nc^3 + x*nc^2 + y*nc + z; new_idx[i] = destination of point i in
+ * the cell-sorted list (stable: ascending i inside a cell). */
+size_t mccnn_sort_step1_workspace_bytes(int n, int batch_size, int num_cells);
+int mccnn_sort_step1(const float* pts, const int* batch_ids, const float* aabb_min,
+                     const float* aabb_max, int n, int batch_size, int num_cells, int* keys,
+                     int* new_idx, void* ws, size_t ws_bytes, mccnn_stream_t stream);
+
+/* SortPointsStep2 -- sort_gpu.cc:40,270-378, sort_gpu.cu:192-248,473-497.
+ * Applies the permutation and builds the (first,last+1) cell table; empty cell = (0,0). */
+size_t mccnn_sort_step2_workspace_bytes(int n);
+int mccnn_sort_step2(const float* pts, const int* batch_ids, const float* feats, const int* keys,
+                     const int* new_idx, int n, int num_feats, int batch_size, int num_cells,
+                     float* out_pts, int* out_batch_ids, float* out_feats, int* cell_indexs, void* ws,
+                     size_t ws_bytes, mccnn_stream_t stream);
+
+/* out[i,:] = in[idx[i],:], i < n_idx.  Replaces SortPointsStep2Grad (sort_gpu.cu:260),
+ * SortFeaturesBack (:288) and GetSampledFeatures (poisson_sampling.cu:135). */
+int mccnn_permute_gather(const float* in, const int* idx, int n_idx, int num_feats, float* out,
+                         mccnn_stream_t stream);
+/* out[idx[i],:] = in[i,:], i < n_idx; zero_fill != 0 first clears out[0:n_out,:].
+ * Replaces SortFeaturesBackGrad (sort_gpu.cu:311; this is Python's sort_features(),
+ * MCConvModuleSrc:35-36) and GetSampledFeaturesGrad (poisson_sampling.cu:158,262-274). */
+int mccnn_permute_scatter(const float* in, const int* idx, int n_idx, int num_feats, float* out,
+                          int n_out, int zero_fill, mccnn_stream_t stream);
+
+/* TransformIndexs -- sort_gpu.cc:96,496-533, sort_gpu.cu:332-362.
+ * out[s] = inv[in_idx[s]] with inv[new_idx[i]] = i.  ws: n ints. */
+size_t mccnn_transform_indexs_workspace_bytes(int n);
+int mccnn_transform_indexs(const int* in_idx, int s, const int* new_idx, int n, int* out_idx,
+                           void* ws, size_t ws_bytes, mccnn_stream_t stream);
+
+/* FindNeighbors -- find_neighbors.cc:25,80-185, find_neighbors.cu:40-372.
+ * count: start_idx[i] = exclusive prefix of the per-centre neighbour counts and
+ * *total_dev (device int) = E.  The caller reads E, allocates packed[E,2] and
+ * calls fill with the same arguments.  Row order: centre ascending; inside a
+ * centre the 27-cell table order of find_neighbors.cu:282-291, then ascending j. */
+size_t mccnn_find_neighbors_workspace_bytes(int m);
+int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids, int m,
+                               const float* sorted_pts, const int* cell_indexs,
+                               const float* aabb_min, const float* aabb_max, int batch_size,
+                               int num_cells, float radius, int scale_inv, int* start_idx,
+                               int* total_dev, void* ws, size_t ws_bytes, mccnn_stream_t stream);
+int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m,
+                              const float* sorted_pts, const int* cell_indexs,
+                              const float* aabb_min, const float* aabb_max, int batch_size,
+                              int num_cells, float radius, int scale_inv, const int* start_idx,
+                              int e, int* packed, mccnn_stream_t stream);
+
+/* ComputePDF -- compute_pdf.cc:25,57-142, compute_pdf.cu:40-119.
+ * mode 0: the reference's arithmetic (double exp per axis, float rounding per
+ *         statement, compute_pdf.cu:72-92);
+ * mode 1: single-precision evaluation (one expf per pair); agrees with mode 0 to
+ *         ~1e-6 relative, inside the 1e-4 tolerance of the feature path. */
+int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx,
+                      int m, const int* packed, int e, const float* aabb_min, const float* aabb_max,
+                      int batch_size, float window, float radius, int scale_inv, int mode,
+                      float* pdfs, mccnn_stream_t stream);
+
+/* PoissonSampling -- poisson_sampling.cc:26,109-211, poisson_sampling.cu:51-230.
+ * count: runs the 27 colour phases, leaves the selection in ws and writes the
+ * number of samples S to *total_dev.  fill: emits pts[S,3], batch ids[S] and
+ * indices[S] (into the SORTED list) in canonical order.  ws must be preserved
+ * between the two calls. */
+size_t mccnn_poisson_sampling_workspace_bytes(int n, int batch_size, int num_cells);
+int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batch_ids, int n,
+                                 const int* cell_indexs, const float* aabb_min,
+                                 const float* aabb_max, int batch_size, int num_cells, float radius,
+                                 int scale_inv, int* total_dev, void* ws, size_t ws_bytes,
+                                 mccnn_stream_t stream);
+int mccnn_poisson_sampling_fill(const float* sorted_pts, int n, const int* cell_indexs,
+                                int batch_size, int num_cells, int s, float* out_pts,
+                                int* out_batch_ids, int* out_indexs, void* ws, size_t ws_bytes,
+                                mccnn_stream_t stream);
+
+/* SpatialConv -- spatial_conv.cc:24,159-321, spatial_conv.cu:24-325,796-871.
+ * out[M, combin ? num_out_feats : num_in_feats].  Every output row is written
+ * (no pre-zeroing needed). */
+size_t mccnn_spatial_conv_fwd_workspace_bytes(int m, int e, int num_in_feats, int num_out_feats,
+                                              int combin);
+int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats,
+                           const int* sorted_batch_ids, const float* pdfs, const float* samples,
+                           const int* start_idx, const int* packed, const float* aabb_min,
+                           const float* aabb_max, const float* w1, const float* b1, const float* w2,
+                           const float* b2, const float* w3, const float* b3, int n, int m, int e,
+                           int num_in_feats, int num_out_feats, int combin, int batch_size,
+                           float radius, int scale_inv, int avg, float* out, void* ws,
+                           size_t ws_bytes, mccnn_stream_t stream);
+
+/* SpatialConvGrad -- spatial_conv.cc:56,323-519, spatial_conv.cu:327-792,873-966.
+ * Gradients w.r.t. the features and the six MLP tensors only
+ * (MCConvModuleSrc:74-81).  All seven outputs are fully written; gradients of
+ * padded output neurons (nu >= neuronsOut), which the reference leaves
+ * uninitialised (spatial_conv.cu:921,924), are zero. */
+size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_feats,
+                                              int num_out_feats, int combin);
+int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats,
+                           const int* sorted_batch_ids, const float* pdfs, const float* samples,
+                           const int* start_idx, const int* packed, const float* aabb_min,
+                           const float* aabb_max, const float* w1, const float* b1, const float* w2,
+                           const float* b2, const float* w3, const float* b3, const float* out_grad,
+                           int n, int m, int e, int num_in_feats, int num_out_feats, int combin,
+                           int batch_size, float radius, int scale_inv, int avg, float* feat_grad,
+                           float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
+                           void* ws, size_t ws_bytes, mccnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCCNN_H_ */

@@ -1,0 +1,450 @@
+"""Python op surface of the Monte-Carlo convolution layer.
+
+Same function names, argument orders and gradient wiring as the reference's
+tf_ops/MCConvModuleSrc (generated into MCConvModule.py, genCompileScript.py:40-48), with
+torch CUDA tensors instead of TF tensors. Every op calls the C-ABI of include/mccnn.h
+(libmccnn_hip.so, hand-written HIP for gfx950) on the current torch stream; there is no
+CPU or PyTorch fallback -- a missing library raises.
+
+Shape / attribute validation mirrors the OP_REQUIRES blocks of the reference wrappers and
+raises InvalidArgumentError (the analogue of tf.errors.InvalidArgumentError).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_handle
+
+
+class InvalidArgumentError(ValueError):
+    pass
+
+
+def _req(cond, msg):
+    if not cond:
+        raise InvalidArgumentError(msg)
+
+
+def _f32(t, name):
+    _req(isinstance(t, torch.Tensor) and t.is_cuda, "%s must be a CUDA tensor" % name)
+    _req(t.dtype == torch.float32, "%s must be float32" % name)
+    return t.contiguous()
+
+
+def _i32(t, name):
+    _req(isinstance(t, torch.Tensor) and t.is_cuda, "%s must be a CUDA tensor" % name)
+    _req(t.dtype == torch.int32, "%s must be int32" % name)
+    return t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _check_points(pts, name, op):
+    _req(pts.dim() == 2, "%s expects %s with the following dimensions (numPoints, pointComponents)" % (op, name))
+    _req(pts.shape[1] == 3, "%s expects %s with three components" % (op, name))
+
+
+def _check_batch_ids(bids, n, op):
+    _req(bids.dim() == 2 and bids.shape[0] == n and bids.shape[1] == 1,
+         "%s expects as batch ids input the following dimensions (numPoints, 1)" % op)
+
+
+def _check_aabb(mn, mx, batchSize, op):
+    for t in (mn, mx):
+        _req(t.dim() == 2 and t.shape[0] == batchSize and t.shape[1] == 3,
+             "%s expects bounding box points with shape (batchSize, 3)" % op)
+
+
+def get_block_size():
+    """genCompileScript.py:46-47"""
+    return int(_lib.load().mccnn_block_size())
+
+
+# ---------------------------------------------------------------------------------------------
+_NUM_CELLS_CACHE = {}
+
+
+def _num_cells(aabbMin, aabbMax, batchSize, cellSize, scaleInv):
+    """determineNumCells (sort_gpu.cu:397-420). scaleInv=False costs one 24-byte read-back, cached
+    per (box tensor, version, cell size) so step1/step2 of the same grid pay it once."""
+    lib = _lib.load()
+    out = C.c_int(0)
+    if scaleInv:
+        check(lib.mccnn_num_cells(None, None, batchSize, float(cellSize), 1, C.byref(out), None), "num_cells")
+        return out.value
+    key = (aabbMin.data_ptr(), aabbMin._version, aabbMax.data_ptr(), aabbMax._version, float(cellSize))
+    hit = _NUM_CELLS_CACHE.get(key)
+    if hit is not None:
+        return hit
+    check(lib.mccnn_num_cells(ptr(aabbMin), ptr(aabbMax), batchSize, float(cellSize), 0, C.byref(out),
+                              stream_handle()), "num_cells")
+    if len(_NUM_CELLS_CACHE) > 256:
+        _NUM_CELLS_CACHE.clear()
+    _NUM_CELLS_CACHE[key] = out.value
+    return out.value
+
+
+# ---------------------------------------------------------------------------------------------
+def compute_aabb(inPts, inBatchIds, batchSize, scaleInv=True):
+    """ComputeAabb (MCConvModuleSrc:20, aabb_gpu.cc:22-86). Non differentiable."""
+    op = "ComputeAabbOp"
+    _req(batchSize > 0, op + " expects a positive batch size")
+    pts, bids = _f32(inPts.detach(), "points"), _i32(inBatchIds, "batch_ids")
+    _check_points(pts, "points", op)
+    _check_batch_ids(bids, pts.shape[0], op)
+    lib = _lib.load()
+    mn = torch.empty((batchSize, 3), dtype=torch.float32, device=pts.device)
+    mx = torch.empty_like(mn)
+    ws = _ws(lib.mccnn_compute_aabb_workspace_bytes(batchSize), pts.device)
+    check(lib.mccnn_compute_aabb(ptr(pts), ptr(bids), pts.shape[0], batchSize, int(bool(scaleInv)), ptr(mn), ptr(mx),
+                                 ptr(ws), ws.numel(), stream_handle()), "compute_aabb")
+    return mn, mx
+
+
+def sort_points_step1(inPts, inBatchIds, aabbMin, aabbMax, batchSize, cellSize, scaleInv):
+    """SortPointsStep1 (MCConvModuleSrc:24, sort_gpu.cc:184-268) -> (keys, indexs). Non differentiable."""
+    op = "SortPointsStep1Op"
+    _req(batchSize > 0, op + " expects a positive batch size")
+    _req(cellSize > 0, op + " expects a positive cell size")
+    pts, bids = _f32(inPts.detach(), "points"), _i32(inBatchIds, "batch_ids")
+    mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
+    _check_points(pts, "points", op)
+    _check_batch_ids(bids, pts.shape[0], op)
+    _check_aabb(mn, mx, batchSize, op)
+    lib = _lib.load()
+    n = pts.shape[0]
+    nc = _num_cells(mn, mx, batchSize, cellSize, scaleInv)
+    keys = torch.empty(n, dtype=torch.int32, device=pts.device)
+    idx = torch.empty(n, dtype=torch.int32, device=pts.device)
+    wsb = lib.mccnn_sort_step1_workspace_bytes(n, batchSize, nc)
+    _req(wsb > 0, op + ": batch_size * num_cells^3 does not fit 32-bit keys")
+    ws = _ws(wsb, pts.device)
+    check(lib.mccnn_sort_step1(ptr(pts), ptr(bids), ptr(mn), ptr(mx), n, batchSize, nc, ptr(keys), ptr(idx), ptr(ws),
+                               ws.numel(), stream_handle()), "sort_points_step1")
+    return keys, idx
+
+
+def _gather_rows(src, idx, n_rows):
+    lib = _lib.load()
+    out = torch.empty((n_rows, src.shape[1]), dtype=torch.float32, device=src.device)
+    check(lib.mccnn_permute_gather(ptr(src), ptr(idx), n_rows, src.shape[1], ptr(out), stream_handle()),
+          "permute_gather")
+    return out
+
+
+def _scatter_rows(src, idx, n_out, zero_fill):
+    lib = _lib.load()
+    out = torch.empty((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
+    check(lib.mccnn_permute_scatter(ptr(src), ptr(idx), src.shape[0], src.shape[1], ptr(out), n_out,
+                                    int(zero_fill), stream_handle()), "permute_scatter")
+    return out
+
+
+class _SortPointsStep2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inPts, inBatchIds, inFeatures, keys, indexs, aabbMin, aabbMax, batchSize, cellSize, scaleInv):
+        op = "SortPointsStep2Op"
+        _req(batchSize > 0, op + " expects a positive batch size")
+        pts, bids = _f32(inPts, "points"), _i32(inBatchIds, "batch_ids")
+        feats = _f32(inFeatures, "features")
+        keys, indexs = _i32(keys, "keys"), _i32(indexs, "index_new_pos")
+        mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
+        _check_points(pts, "points", op)
+        n = pts.shape[0]
+        _check_batch_ids(bids, n, op)
+        _req(feats.dim() == 2 and feats.shape[0] == n, op + " expects features with dimensions (numPoints, numFeatures)")
+        _req(feats.shape[1] > 0, op + " expects features with at least one component")
+        _req(keys.dim() == 1 and keys.shape[0] == n, op + " expects the same number of keys and points")
+        _req(indexs.dim() == 1 and indexs.shape[0] == n, op + " expects the same number of indexs and points")
+        _check_aabb(mn, mx, batchSize, op)
+        lib = _lib.load()
+        nc = _num_cells(mn, mx, batchSize, cellSize, scaleInv)
+        oP = torch.empty_like(pts)
+        oB = torch.empty_like(bids)
+        oF = torch.empty_like(feats)
+        cells = torch.empty((batchSize, nc, nc, nc, 2), dtype=torch.int32, device=pts.device)
+        ws = _ws(lib.mccnn_sort_step2_workspace_bytes(n), pts.device)
+        check(lib.mccnn_sort_step2(ptr(pts), ptr(bids), ptr(feats), ptr(keys), ptr(indexs), n, feats.shape[1],
+                                   batchSize, nc, ptr(oP), ptr(oB), ptr(oF), ptr(cells), ptr(ws), ws.numel(),
+                                   stream_handle()), "sort_points_step2")
+        ctx.save_for_backward(indexs)
+        ctx.mark_non_differentiable(oB, cells)
+        return oP, oB, oF, cells
+
+    @staticmethod
+    def backward(ctx, gPts, gBids, gFeats, gCells):
+        # _sort_points_step2_grad (MCConvModuleSrc:30-33): in[i] = out[index_new_pos[i]]
+        (indexs,) = ctx.saved_tensors
+        n = indexs.shape[0]
+        dPts = _gather_rows(_f32(gPts, "grad"), indexs, n) if gPts is not None else None
+        dFeats = _gather_rows(_f32(gFeats, "grad"), indexs, n) if gFeats is not None else None
+        return dPts, None, dFeats, None, None, None, None, None, None, None
+
+
+def sort_points_step2(inPts, inBatchIds, inFeatures, keys, indexs, aabbMin, aabbMax, batchSize, cellSize, scaleInv):
+    """SortPointsStep2 (MCConvModuleSrc:28-33) -> (sortPts, sortBatchs, sortFeatures, cellIndexs)."""
+    return _SortPointsStep2.apply(inPts, inBatchIds, inFeatures, keys, indexs, aabbMin, aabbMax, batchSize, cellSize,
+                                  scaleInv)
+
+
+class _SortFeatures(torch.autograd.Function):
+    """sort_features == SortFeaturesBackGrad: out[idx[i]] = in[i] (MCConvModuleSrc:35-39)."""
+
+    @staticmethod
+    def forward(ctx, inFeatures, indexs):
+        f, idx = _f32(inFeatures, "features"), _i32(indexs, "index_new_pos")
+        _req(idx.dim() == 1, "SortFeaturesBackGradOp expects indexs with the following dimensions (numPoints)")
+        _req(f.dim() == 2 and f.shape[1] > 0 and f.shape[0] == idx.shape[0],
+             "SortFeaturesBackGradOp expects features with dimensions (numPoints, numFeatures)")
+        ctx.save_for_backward(idx)
+        return _scatter_rows(f, idx, f.shape[0], False)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return _gather_rows(_f32(g, "grad"), idx, idx.shape[0]), None
+
+
+def sort_features(inFeatures, indexs):
+    return _SortFeatures.apply(inFeatures, indexs)
+
+
+class _SortFeaturesBack(torch.autograd.Function):
+    """SortFeaturesBack: out[i] = in[idx[i]] (MCConvModuleSrc:41-45)."""
+
+    @staticmethod
+    def forward(ctx, inFeatures, indexs):
+        f, idx = _f32(inFeatures, "features"), _i32(indexs, "index_new_pos")
+        _req(idx.dim() == 1, "SortFeaturesBackOp expects indexs with the following dimensions (numPoints)")
+        _req(f.dim() == 2 and f.shape[1] > 0 and f.shape[0] == idx.shape[0],
+             "SortFeaturesBackOp expects features with dimensions (numPoints, numFeatures)")
+        ctx.save_for_backward(idx)
+        return _gather_rows(f, idx, idx.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return _scatter_rows(_f32(g, "grad"), idx, idx.shape[0], False), None
+
+
+def sort_features_back(inFeatures, indexs):
+    return _SortFeaturesBack.apply(inFeatures, indexs)
+
+
+def transform_indexs(inIndexs, inNewPositions):
+    """TransformIndexs (MCConvModuleSrc:47, sort_gpu.cc:496-533). Non differentiable."""
+    a, b = _i32(inIndexs, "curr_indexs"), _i32(inNewPositions, "index_new_pos")
+    _req(a.dim() == 1 and b.dim() == 1, "TransformIndexsOp expects indexs with the following dimensions (numPoints)")
+    lib = _lib.load()
+    out = torch.empty_like(a)
+    ws = _ws(lib.mccnn_transform_indexs_workspace_bytes(b.shape[0]), a.device)
+    check(lib.mccnn_transform_indexs(ptr(a), a.shape[0], ptr(b), b.shape[0], ptr(out), ptr(ws), ws.numel(),
+                                     stream_handle()), "transform_indexs")
+    return out
+
+
+def find_neighbors(inPts, inBatchIds, inPts2, cellIndexs, aabbMin, aabbMax, radius, batchSize, scaleInv):
+    """FindNeighbors (MCConvModuleSrc:51, find_neighbors.cc:80-185) -> (startIndexs [M,1], packedNeighs [E,2]).
+    Reads E back to the host to size the second output, like the reference (find_neighbors.cu:307-309)."""
+    op = "FindNeighborsOp"
+    _req(radius > 0.0, op + " expects a positive radius")
+    _req(batchSize > 0, op + " expects a positive batch size")
+    c, cb = _f32(inPts.detach(), "points"), _i32(inBatchIds, "batch_ids")
+    p2, cells = _f32(inPts2.detach(), "points2"), _i32(cellIndexs, "cell_indexs")
+    mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
+    _check_points(c, "points", op)
+    _check_batch_ids(cb, c.shape[0], op)
+    _check_points(p2, "points2", op)
+    _req(cells.dim() == 5 and cells.shape[0] == batchSize, op + " expects a five dimension tensor for the cell indices")
+    _check_aabb(mn, mx, batchSize, op)
+    lib = _lib.load()
+    m, nc = c.shape[0], cells.shape[1]
+    start = torch.empty((m, 1), dtype=torch.int32, device=c.device)
+    total = torch.empty(1, dtype=torch.int32, device=c.device)
+    ws = _ws(lib.mccnn_find_neighbors_workspace_bytes(m), c.device)
+    args = (ptr(c), ptr(cb), m, ptr(p2), ptr(cells), ptr(mn), ptr(mx), batchSize, nc, float(radius),
+            int(bool(scaleInv)))
+    check(lib.mccnn_find_neighbors_count(*args, ptr(start), ptr(total), ptr(ws), ws.numel(), stream_handle()),
+          "find_neighbors(count)")
+    e = int(total.item())
+    packed = torch.empty((e, 2), dtype=torch.int32, device=c.device)
+    check(lib.mccnn_find_neighbors_fill(*args, ptr(start), e, ptr(packed), stream_handle()), "find_neighbors(fill)")
+    return start, packed
+
+
+#: 0 = the reference's double-precision-exp arithmetic, 1 = single-precision (default; ~1e-6 rel. apart)
+PDF_MODE = 1
+
+
+def compute_pdf(inPts, inBatchIds, aabbMin, aabbMax, startIndexs, neighbors, window, radius, batchSize, scaleInv,
+                mode=None):
+    """ComputePDF (MCConvModuleSrc:55, compute_pdf.cc:57-142) -> pdfs [E,1]. Non differentiable."""
+    op = "ComputePDFOp"
+    _req(radius > 0.0, op + " expects a positive radius")
+    _req(window > 0.0, op + " expects a positive window")
+    _req(batchSize > 0, op + " expects a positive batch size")
+    p, b = _f32(inPts.detach(), "points"), _i32(inBatchIds, "batch_ids")
+    mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
+    st, pk = _i32(startIndexs, "start_indexs"), _i32(neighbors, "neighbors")
+    _check_points(p, "points", op)
+    _check_batch_ids(b, p.shape[0], op)
+    _req(st.dim() == 2 and st.shape[1] == 1, op + " expects start indexs with dimensions (numSamples, 1)")
+    _req(pk.dim() == 2 and pk.shape[1] == 2, op + " expects a neighbor list with dimensions (numNeighbors, 2)")
+    _check_aabb(mn, mx, batchSize, op)
+    lib = _lib.load()
+    e = pk.shape[0]
+    pdfs = torch.empty((e, 1), dtype=torch.float32, device=p.device)
+    check(lib.mccnn_compute_pdf(ptr(p), ptr(b), ptr(st), st.shape[0], ptr(pk), e, ptr(mn), ptr(mx), batchSize,
+                                float(window), float(radius), int(bool(scaleInv)),
+                                int(PDF_MODE if mode is None else mode), ptr(pdfs), stream_handle()), "compute_pdf")
+    return pdfs
+
+
+def poisson_sampling(inPts, inBatchIds, cellIndexs, aabbMin, aabbMax, radius, batchSize, scaleInv):
+    """PoissonSampling (MCConvModuleSrc:59, poisson_sampling.cc:109-211) -> (pts [S,3], batchIds [S,1], indexs [S]).
+    indexs point into the SORTED input list. Non differentiable."""
+    op = "PoissonSamplingOp"
+    _req(radius > 0.0, op + " expects a positive radius")
+    _req(batchSize > 0, op + " expects a positive batch size")
+    p, b = _f32(inPts.detach(), "points"), _i32(inBatchIds, "batch_ids")
+    cells = _i32(cellIndexs, "cell_indexs")
+    mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
+    _check_points(p, "points", op)
+    _check_batch_ids(b, p.shape[0], op)
+    _req(cells.dim() == 5 and cells.shape[0] == batchSize, op + " expects a five dimension tensor for the cell indices")
+    _check_aabb(mn, mx, batchSize, op)
+    lib = _lib.load()
+    n, nc = p.shape[0], cells.shape[1]
+    wsb = lib.mccnn_poisson_sampling_workspace_bytes(n, batchSize, nc)
+    _req(wsb > 0, op + ": grid too large")
+    ws = _ws(wsb, p.device)
+    total = torch.empty(1, dtype=torch.int32, device=p.device)
+    check(lib.mccnn_poisson_sampling_count(ptr(p), ptr(b), n, ptr(cells), ptr(mn), ptr(mx), batchSize, nc,
+                                           float(radius), int(bool(scaleInv)), ptr(total), ptr(ws), ws.numel(),
+                                           stream_handle()), "poisson_sampling(count)")
+    s = int(total.item())
+    oP = torch.empty((s, 3), dtype=torch.float32, device=p.device)
+    oB = torch.empty((s, 1), dtype=torch.int32, device=p.device)
+    oI = torch.empty(s, dtype=torch.int32, device=p.device)
+    check(lib.mccnn_poisson_sampling_fill(ptr(p), n, ptr(cells), batchSize, nc, s, ptr(oP), ptr(oB), ptr(oI), ptr(ws),
+                                          ws.numel(), stream_handle()), "poisson_sampling(fill)")
+    return oP, oB, oI
+
+
+class _GetSampledFeatures(torch.autograd.Function):
+    """GetSampledFeatures (+Grad: scatter with zero fill), MCConvModuleSrc:63-68."""
+
+    @staticmethod
+    def forward(ctx, inSampledIndexs, pInFeatures):
+        idx, f = _i32(inSampledIndexs, "sampled_indexs"), _f32(pInFeatures, "features")
+        _req(idx.dim() == 1, "GetSampledFeaturesOp expects indexs with the following dimensions (numSamples)")
+        _req(f.dim() == 2 and f.shape[1] > 0, "GetSampledFeaturesOp expects features with dimensions (numPoints, numFeatures)")
+        ctx.save_for_backward(idx)
+        ctx.n = f.shape[0]
+        return _gather_rows(f, idx, idx.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return None, _scatter_rows(_f32(g, "grad"), idx, ctx.n, True)
+
+
+def get_sampled_features(inSampledIndexs, pInFeatures):
+    return _GetSampledFeatures.apply(inSampledIndexs, pInFeatures)
+
+
+# ---------------------------------------------------------------------------------------------
+def _conv_checks(op, pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3, numOutFeatures, combin,
+                 batchSize, radius):
+    bs = get_block_size()
+    _req(numOutFeatures > 0, op + " expects a positive number of output features")
+    _req(radius > 0.0, op + " expects a positive radius")
+    _req(batchSize > 0, op + " expects a positive batch size")
+    _check_points(pts, "points", op)
+    n = pts.shape[0]
+    _req(feats.dim() == 2 and feats.shape[0] == n, op + " expects as feature inputs the following dimensions (numPoints, numFeatures)")
+    _check_batch_ids(bids, n, op)
+    _req(pdfs.dim() == 2 and pdfs.shape[1] == 1, op + " expects as pdfs the following dimensions (numNeighbors, 1)")
+    e = pdfs.shape[0]
+    _check_points(smp, "sample points", op)
+    m = smp.shape[0]
+    _req(st.dim() == 2 and st.shape[1] == 1 and st.shape[0] == m, op + " expects start indexs with dimensions (numSamples, 1)")
+    _req(pk.dim() == 2 and pk.shape[0] == e and pk.shape[1] == 2, op + " expects a neighbor list with dimensions (numNeighbors, 2)")
+    _check_aabb(mn, mx, batchSize, op)
+    _req(w1.dim() == 2 and w1.shape[0] == 3 and b1.dim() == 1 and w1.shape[1] == b1.shape[0] and w1.shape[1] % bs == 0,
+         op + " expects a correct first hidden layer")
+    _req(w2.dim() == 2 and w2.shape[0] == bs and b2.dim() == 1 and w2.shape[1] == b2.shape[0] and w2.shape[1] == w1.shape[1],
+         op + " expects a correct second hidden layer")
+    _req(w3.dim() == 2 and w3.shape[0] == bs and b3.dim() == 1 and w3.shape[1] == b3.shape[0],
+         op + " expects a correct output layer")
+    fin = feats.shape[1]
+    _req(w3.shape[1] % fin == 0, op + " expects a number of output neurons multiple of the number of features.")
+    if not combin:
+        _req(w3.shape[1] == fin, op + " expects the same number of features in the input and the output")
+    neurons = fin * numOutFeatures if combin else fin
+    nb = (neurons + bs - 1) // bs
+    _req(w1.shape[1] == nb * bs and w3.shape[1] == nb * bs, op + " expects %d neurons per layer" % (nb * bs))
+    return n, m, e, fin
+
+
+class _SpatialConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inPts, inFeatures, inBatchIds, inPDFs, inSamplePts, neighStartIndexs, packedNeighs, aabbMin,
+                aabbMax, weights1, biases1, weights2, biases2, weightsOut, biasesOut, numOutFeatures, combin,
+                batchSize, radius, scaleInv, avg):
+        op = "SpatialConvOp"
+        pts, feats, bids = _f32(inPts, "points"), _f32(inFeatures, "features"), _i32(inBatchIds, "batch_ids")
+        pdfs, smp = _f32(inPDFs, "pdfs"), _f32(inSamplePts, "sample_pts")
+        st, pk = _i32(neighStartIndexs, "start_neighs_indexs"), _i32(packedNeighs, "neighs_indexs")
+        mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
+        w1, b1 = _f32(weights1, "weight_hidden_1"), _f32(biases1, "bias_hidden_1")
+        w2, b2 = _f32(weights2, "weight_hidden_2"), _f32(biases2, "bias_hidden_2")
+        w3, b3 = _f32(weightsOut, "weight_out_layer"), _f32(biasesOut, "bias_out_layer")
+        n, m, e, fin = _conv_checks(op, pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3,
+                                    numOutFeatures, combin, batchSize, radius)
+        lib = _lib.load()
+        outF = numOutFeatures if combin else fin
+        out = torch.empty((m, outF), dtype=torch.float32, device=pts.device)
+        ws = _ws(lib.mccnn_spatial_conv_fwd_workspace_bytes(m, e, fin, numOutFeatures, int(bool(combin))), pts.device)
+        check(lib.mccnn_spatial_conv_fwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
+                                         ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), n, m,
+                                         e, fin, numOutFeatures, int(bool(combin)), batchSize, float(radius),
+                                         int(bool(scaleInv)), int(bool(avg)), ptr(out), ptr(ws), ws.numel(),
+                                         stream_handle()), "spatial_conv")
+        ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3)
+        ctx.attrs = (numOutFeatures, bool(combin), batchSize, float(radius), bool(scaleInv), bool(avg))
+        return out
+
+    @staticmethod
+    def backward(ctx, outGrad):
+        # _spatial_conv_grad (MCConvModuleSrc:74-81): grads for features and the 6 MLP tensors only
+        pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
+        numOutFeatures, combin, batchSize, radius, scaleInv, avg = ctx.attrs
+        og = _f32(outGrad, "out_features_grad")
+        lib = _lib.load()
+        n, fin = feats.shape
+        m, e = smp.shape[0], pk.shape[0]
+        fg = torch.empty_like(feats)
+        dw1, db1, dw2, db2, dw3, db3 = (torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3))
+        ws = _ws(lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, numOutFeatures, int(combin)), pts.device)
+        check(lib.mccnn_spatial_conv_bwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
+                                         ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
+                                         ptr(og), n, m, e, fin, numOutFeatures, int(combin), batchSize, radius,
+                                         int(scaleInv), int(avg), ptr(fg), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2),
+                                         ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
+              "spatial_conv_grad")
+        return (None, fg, None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
+                None, None, None, None, None, None)
+
+
+def spatial_conv(inPts, inFeatures, inBatchIds, inPDFs, inSamplePts, neighStartIndexs, packedNeighs, aabbMin, aabbMax,
+                 weights1, weights2, weightsOut, biases1, biases2, biasesOut, numOutFeatures, combin, batchSize, radius,
+                 scaleInv, avg):
+    """SpatialConv (MCConvModuleSrc:70-81). Note the reference's argument order (weights first, then biases);
+    the op itself takes (w1, b1, w2, b2, w3, b3)."""
+    return _SpatialConv.apply(inPts, inFeatures, inBatchIds, inPDFs, inSamplePts, neighStartIndexs, packedNeighs,
+                              aabbMin, aabbMax, weights1, biases1, weights2, biases2, weightsOut, biasesOut,
+                              numOutFeatures, combin, batchSize, radius, scaleInv, avg)

@@ -1,0 +1,85 @@
+"""ctypes binding of the C-ABI in include/mccnn.h (libmccnn_hip.so).
+
+The product path has NO fallback: if the HIP library is missing or cannot be loaded this
+module raises, and every op in MCConvModule fails loudly.
+"""
+import ctypes as C
+import os
+
+import torch  # must be imported first: libmccnn_hip.so binds to the HIP runtime torch already loaded
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmccnn_hip.so")
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mccnn.h declaration by declaration
+SIGNATURES = {
+    "mccnn_block_size": (_i, []),
+    "mccnn_abi_version": (_i, []),
+    "mccnn_arch": (C.c_char_p, []),
+    "mccnn_error_string": (C.c_char_p, [_i]),
+    "mccnn_compute_aabb_workspace_bytes": (_sz, [_i]),
+    "mccnn_compute_aabb": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_num_cells": (_i, [_vp, _vp, _i, _f, _i, C.POINTER(_i), _vp]),
+    "mccnn_sort_step1_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mccnn_sort_step1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_sort_step2_workspace_bytes": (_sz, [_i]),
+    "mccnn_sort_step2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_permute_gather": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "mccnn_permute_scatter": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "mccnn_transform_indexs_workspace_bytes": (_sz, [_i]),
+    "mccnn_transform_indexs": (_i, [_vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "mccnn_find_neighbors_workspace_bytes": (_sz, [_i]),
+    "mccnn_find_neighbors_count": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_find_neighbors_fill": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _i, _vp, _vp]),
+    "mccnn_compute_pdf": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _f, _f, _i, _i, _vp, _vp]),
+    "mccnn_poisson_sampling_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mccnn_poisson_sampling_count": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
+    "mccnn_poisson_sampling_fill": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_spatial_conv_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "mccnn_spatial_conv_fwd": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
+    "mccnn_spatial_conv_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "mccnn_spatial_conv_bwd": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _i, _i, _f, _i, _i] + [_vp] * 7 + [_vp, _sz, _vp]),
+}
+
+
+class MCCNNError(RuntimeError):
+    """Raised for any non-zero return code of the C-ABI (the reference raised
+    errors::InvalidArgument for shape errors and exit()ed on CUDA errors)."""
+
+
+_lib = None
+
+
+def load():
+    """Load libmccnn_hip.so and type every exported symbol. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MCCNNError(
+            "libmccnn_hip.so not found at %s -- build it with `python -m mccnn_amd.build` "
+            "(there is no CPU / PyTorch fallback for the MC-convolution ops)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mccnn_error_string(rc).decode()
+        raise MCCNNError("%s failed: %s (code %d)" % (what, msg, rc))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_handle():
+    return torch.cuda.current_stream().cuda_stream

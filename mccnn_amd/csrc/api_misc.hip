@@ -1,0 +1,24 @@
+// Version / diagnostics entry points of libmccnn_hip.
+#include "common.h"
+
+extern "C" {
+
+int mccnn_block_size(void) { return MCCNN_MLP; }
+int mccnn_abi_version(void) { return 1; }
+const char* mccnn_arch(void) { return "gfx950"; }
+
+const char* mccnn_error_string(int code) {
+    switch (code) {
+        case MCCNN_OK: return "ok";
+        case MCCNN_E_BADARG: return "invalid argument (null pointer or non-positive size/attribute)";
+        case MCCNN_E_BATCHID: return "batch id outside [0, batch_size)";
+        case MCCNN_E_TOOLARGE: return "problem does not fit 32-bit indexing (B*nc^3, E or LDS tile)";
+        case MCCNN_E_WORKSPACE: return "workspace missing or smaller than the *_workspace_bytes query";
+        case MCCNN_E_SHAPE: return "kernel-MLP shape rule violated (spatial_conv.cc:258-300)";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "unknown mccnn error";
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// Shared host/device helpers of libmccnn_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+#include "mccnn.h"
+
+#define MCCNN_MLP 8        // BLOCK_MLP_SIZE (genCompileScript.py:20)
+#define MCCNN_WAVE 64      // CDNA wavefront
+
+#define MCCNN_HIP(call)                         \
+    do {                                        \
+        hipError_t e__ = (call);                \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+#define MCCNN_LAUNCHED()                        \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+namespace mccnn {
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace.
+struct Arena {
+    char* base;
+    size_t cap, off;
+    Arena(void* p, size_t n) : base((char*)p), cap(n), off(0) {}
+    template <typename T>
+    T* take(size_t count) {
+        size_t bytes = align_up(count * sizeof(T));
+        if (off + bytes > cap) return nullptr;
+        T* r = (T*)(base + off);
+        off += bytes;
+        return r;
+    }
+};
+
+// Exclusive prefix sum of n int32 (out may alias in). If total != nullptr the grand
+// total is written there. ws must hold scan_workspace_bytes(n). Defined in scan.hip.
+size_t scan_workspace_bytes(int n);
+int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Geometry helpers. The library is compiled with -ffp-contract=off, so each expression
+// below rounds exactly like the oracle's (and the reference source's) f32 expression:
+// correctly rounded divide / sqrt (-fhip-fp32-correctly-rounded-divide-sqrt), no FMA.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float max_extent(const float* __restrict__ mn, const float* __restrict__ mx, int b) {
+    // sort_gpu.cu:50-52
+    return fmaxf(fmaxf(mx[b * 3] - mn[b * 3], mx[b * 3 + 1] - mn[b * 3 + 1]), mx[b * 3 + 2] - mn[b * 3 + 2]);
+}
+__device__ __forceinline__ int cell_coord(float p, float mn, float cs, int nc) {
+    // sort_gpu.cu:55
+    return max(min((int)floorf((p - mn) / cs), nc - 1), 0);
+}
+__device__ __forceinline__ float point_dist(float ax, float ay, float az, float cx, float cy, float cz) {
+    // find_neighbors.cu:95-96
+    float dx = ax - cx, dy = ay - cy, dz = az - cz;
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+// find_neighbors.cu:282-291 : entry o = (1 - o%3, 1 - (o/3)%3, 1 - o/9)
+__device__ __forceinline__ void neigh_offset(int o, int& dx, int& dy, int& dz) {
+    dx = 1 - (o % 3);
+    dy = 1 - ((o / 3) % 3);
+    dz = 1 - (o / 9);
+}
+
+// poisson_sampling.cu:192-196 packed as (dx+1) | (dy+1)<<2 | (dz+1)<<4
+__device__ __constant__ const unsigned char kPoolOffsets[27] = {
+    2 | (2 << 2) | (0 << 4), 1 | (0 << 2) | (2 << 4), 1 | (2 << 2) | (2 << 4), 1 | (2 << 2) | (1 << 4),
+    1 | (1 << 2) | (2 << 4), 1 | (0 << 2) | (1 << 4), 0 | (2 << 2) | (0 << 4), 1 | (0 << 2) | (0 << 4),
+    2 | (1 << 2) | (1 << 4), 2 | (0 << 2) | (2 << 4), 2 | (1 << 2) | (2 << 4), 0 | (2 << 2) | (2 << 4),
+    0 | (1 << 2) | (1 << 4), 2 | (0 << 2) | (0 << 4), 1 | (2 << 2) | (0 << 4), 0 | (0 << 2) | (1 << 4),
+    0 | (2 << 2) | (1 << 4), 1 | (1 << 2) | (1 << 4), 1 | (1 << 2) | (0 << 4), 2 | (2 << 2) | (1 << 4),
+    2 | (1 << 2) | (0 << 4), 2 | (0 << 2) | (1 << 4), 0 | (1 << 2) | (2 << 4), 2 | (2 << 2) | (2 << 4),
+    0 | (1 << 2) | (0 << 4), 0 | (0 << 2) | (0 << 4), 0 | (0 << 2) | (2 << 4)};
+__device__ __forceinline__ void pool_offset(int o, int& dx, int& dy, int& dz) {
+    unsigned v = kPoolOffsets[o];
+    dx = (int)(v & 3) - 1;
+    dy = (int)((v >> 2) & 3) - 1;
+    dz = (int)((v >> 4) & 3) - 1;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// wave64 inclusive scan (int)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane_id() >= d) v += t;
+    }
+    return v;
+}
+
+}  // namespace mccnn

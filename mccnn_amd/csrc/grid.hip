@@ -1,0 +1,366 @@
+// Bounding boxes, grid-hash keys, stable counting sort into cells, cell table, row
+// permutations. Replaces tf_ops/aabb_gpu.cu and tf_ops/sort_gpu.cu.
+#include "common.h"
+
+namespace mccnn {
+
+// ------------------------------------------------------------------ AABB (aabb_gpu.cu:57-140)
+// Floats are mapped to order-preserving uint32 so that plain integer atomics give min/max
+// (the reference hand-rolled CAS loops, aabb_gpu.cu:23-45).
+__device__ __forceinline__ unsigned f2ord(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ void aabb_init(unsigned* __restrict__ enc, int B) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 3 * B) {
+        enc[t] = f2ord(FLT_MAX);            // running min
+        enc[3 * B + t] = f2ord(-FLT_MAX);   // running max
+    }
+}
+
+__global__ __launch_bounds__(256) void aabb_reduce(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                   int n, int B, unsigned* __restrict__ enc) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool act = i < n;
+    int b = act ? bids[i] : -1;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (act) {
+        x = pts[(size_t)i * 3];
+        y = pts[(size_t)i * 3 + 1];
+        z = pts[(size_t)i * 3 + 2];
+    }
+    // Clouds are stored contiguously (utils/DataSet.py:816-823), so a wave almost always sees
+    // one batch id: reduce in-wave and issue 6 atomics per wave instead of 6 per point.
+    int b0 = __shfl(b, 0, 64);
+    bool uniform = __all(b == b0 || !act) && __any(act) && (__shfl(act ? 1 : 0, 0, 64) != 0);
+    if (uniform) {
+        float mnx = act ? x : FLT_MAX, mny = act ? y : FLT_MAX, mnz = act ? z : FLT_MAX;
+        float mxx = act ? x : -FLT_MAX, mxy = act ? y : -FLT_MAX, mxz = act ? z : -FLT_MAX;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mnx = fminf(mnx, __shfl_xor(mnx, d, 64));
+            mny = fminf(mny, __shfl_xor(mny, d, 64));
+            mnz = fminf(mnz, __shfl_xor(mnz, d, 64));
+            mxx = fmaxf(mxx, __shfl_xor(mxx, d, 64));
+            mxy = fmaxf(mxy, __shfl_xor(mxy, d, 64));
+            mxz = fmaxf(mxz, __shfl_xor(mxz, d, 64));
+        }
+        if (lane_id() == 0 && b0 >= 0 && b0 < B) {
+            atomicMin(&enc[b0 * 3], f2ord(mnx));
+            atomicMin(&enc[b0 * 3 + 1], f2ord(mny));
+            atomicMin(&enc[b0 * 3 + 2], f2ord(mnz));
+            atomicMax(&enc[3 * B + b0 * 3], f2ord(mxx));
+            atomicMax(&enc[3 * B + b0 * 3 + 1], f2ord(mxy));
+            atomicMax(&enc[3 * B + b0 * 3 + 2], f2ord(mxz));
+        }
+    } else if (act && b >= 0 && b < B) {
+        atomicMin(&enc[b * 3], f2ord(x));
+        atomicMin(&enc[b * 3 + 1], f2ord(y));
+        atomicMin(&enc[b * 3 + 2], f2ord(z));
+        atomicMax(&enc[3 * B + b * 3], f2ord(x));
+        atomicMax(&enc[3 * B + b * 3 + 1], f2ord(y));
+        atomicMax(&enc[3 * B + b * 3 + 2], f2ord(z));
+    }
+}
+
+// One block. scale_inv == 0: every row gets the whole-batch box (aabb_gpu.cu:104-114).
+__global__ __launch_bounds__(256) void aabb_finalize(const unsigned* __restrict__ enc, int B, int scaleInv,
+                                                     float* __restrict__ mn, float* __restrict__ mx) {
+    if (scaleInv) {
+        for (int t = threadIdx.x; t < 3 * B; t += blockDim.x) {
+            mn[t] = ord2f(enc[t]);
+            mx[t] = ord2f(enc[3 * B + t]);
+        }
+        return;
+    }
+    __shared__ unsigned g[6];
+    if (threadIdx.x < 3) g[threadIdx.x] = 0xffffffffu;
+    if (threadIdx.x >= 3 && threadIdx.x < 6) g[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int t = threadIdx.x; t < 3 * B; t += blockDim.x) {
+        atomicMin(&g[t % 3], enc[t]);
+        atomicMax(&g[3 + t % 3], enc[3 * B + t]);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 3 * B; t += blockDim.x) {
+        mn[t] = ord2f(g[t % 3]);
+        mx[t] = ord2f(g[3 + t % 3]);
+    }
+}
+
+__global__ void num_cells_dev(const float* __restrict__ mn, const float* __restrict__ mx, float cellSize,
+                              int* __restrict__ out) {
+    // determine_cell_size, sort_gpu.cu:374-391 (batch 0 only)
+    float ext = max_extent(mn, mx, 0);
+    int nc = (int)(ext / cellSize);
+    *out = nc == 0 ? 1 : nc;
+}
+
+// ------------------------------------------------------------------ keys + histogram
+// calc_key + update_counters fused (sort_gpu.cu:35-80). arrival[i] = rank in atomic arrival
+// order; it is only used to park point ids in their cell segment, the final order is fixed
+// by rank_in_cell below.
+__global__ __launch_bounds__(256) void keys_hist(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                 const float* __restrict__ mn, const float* __restrict__ mx,
+                                                 int n, int nc, int* __restrict__ keys, int* __restrict__ cnt,
+                                                 int* __restrict__ arrival) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int b = bids[i];
+    float cs = max_extent(mn, mx, b) / (float)nc;
+    int x = cell_coord(pts[(size_t)i * 3], mn[b * 3], cs, nc);
+    int y = cell_coord(pts[(size_t)i * 3 + 1], mn[b * 3 + 1], cs, nc);
+    int z = cell_coord(pts[(size_t)i * 3 + 2], mn[b * 3 + 2], cs, nc);
+    int key = b * nc * nc * nc + x * nc * nc + y * nc + z;  // sort_gpu.cu:59
+    keys[i] = key;
+    arrival[i] = atomicAdd(&cnt[key], 1);
+}
+
+__global__ __launch_bounds__(256) void park_ids(const int* __restrict__ keys, const int* __restrict__ start,
+                                                const int* __restrict__ arrival, int n, int* __restrict__ slot) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slot[start[keys[i]] + arrival[i]] = i;
+}
+
+// new_idx[i] = cellStart + #{ids in my cell smaller than i}: the stable (sequential) order.
+__global__ __launch_bounds__(256) void rank_in_cell(const int* __restrict__ keys, const int* __restrict__ start,
+                                                    const int* __restrict__ slot, int n, int* __restrict__ newIdx) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int k = keys[i];
+    int s0 = start[k], s1 = start[k + 1];
+    int r = 0;
+    for (int p = s0; p < s1; ++p) r += (slot[p] < i) ? 1 : 0;
+    newIdx[i] = s0 + r;
+}
+
+// ------------------------------------------------------------------ step 2
+__global__ __launch_bounds__(256) void move_points(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                   const int* __restrict__ keys, const int* __restrict__ newIdx,
+                                                   int n, float* __restrict__ oPts, int* __restrict__ oBids,
+                                                   int* __restrict__ sKeys) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int p = newIdx[i];
+    oPts[(size_t)p * 3] = pts[(size_t)i * 3];
+    oPts[(size_t)p * 3 + 1] = pts[(size_t)i * 3 + 1];
+    oPts[(size_t)p * 3 + 2] = pts[(size_t)i * 3 + 2];
+    oBids[p] = bids[i];
+    sKeys[p] = keys[i];
+}
+
+// save_indexs, sort_gpu.cu:225-248
+__global__ __launch_bounds__(256) void cell_table(const int* __restrict__ sKeys, int n, int* __restrict__ cells) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int k = sKeys[p];
+    if (p == 0 || sKeys[p - 1] != k) cells[2 * (size_t)k] = p;
+    if (p == n - 1 || sKeys[p + 1] != k) cells[2 * (size_t)k + 1] = p + 1;
+}
+
+// ------------------------------------------------------------------ row permutations
+// One thread per VEC floats of a row; rows are F floats. GATHER: out[i] = in[idx[i]],
+// else out[idx[i]] = in[i].
+template <int VEC, bool GATHER>
+__global__ __launch_bounds__(256) void permute_rows(const float* __restrict__ in, const int* __restrict__ idx,
+                                                    long long total /* n*F/VEC */, int fv /* F/VEC */,
+                                                    float* __restrict__ out) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    long long row = t / fv;
+    int c = (int)(t - row * fv);
+    long long other = idx[row];
+    long long src = GATHER ? other * fv + c : t;
+    long long dst = GATHER ? t : other * fv + c;
+    if (VEC == 4) {
+        reinterpret_cast<float4*>(out)[dst] = reinterpret_cast<const float4*>(in)[src];
+    } else if (VEC == 2) {
+        reinterpret_cast<float2*>(out)[dst] = reinterpret_cast<const float2*>(in)[src];
+    } else {
+        out[dst] = in[src];
+    }
+}
+
+template <bool GATHER>
+static int launch_permute(const float* in, const int* idx, int n, int F, float* out, hipStream_t s) {
+    if (n <= 0) return 0;
+    bool a16 = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    bool a8 = (((uintptr_t)in | (uintptr_t)out) & 7) == 0;
+    if (F % 4 == 0 && a16) {
+        long long total = (long long)n * (F / 4);
+        permute_rows<4, GATHER><<<ceil_div(total, 256), 256, 0, s>>>(in, idx, total, F / 4, out);
+    } else if (F % 2 == 0 && a8) {
+        long long total = (long long)n * (F / 2);
+        permute_rows<2, GATHER><<<ceil_div(total, 256), 256, 0, s>>>(in, idx, total, F / 2, out);
+    } else {
+        long long total = (long long)n * F;
+        permute_rows<1, GATHER><<<ceil_div(total, 256), 256, 0, s>>>(in, idx, total, F, out);
+    }
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void invert_perm(const int* __restrict__ newIdx, int n, int* __restrict__ inv) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[newIdx[i]] = i;
+}
+__global__ __launch_bounds__(256) void map_indexs(const int* __restrict__ in, int s, const int* __restrict__ inv,
+                                                  int* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < s) out[i] = inv[in[i]];
+}
+
+}  // namespace mccnn
+
+using namespace mccnn;
+
+extern "C" {
+
+size_t mccnn_compute_aabb_workspace_bytes(int batch_size) {
+    return align_up((size_t)(batch_size > 0 ? batch_size : 1) * 6 * sizeof(unsigned));
+}
+
+int mccnn_compute_aabb(const float* pts, const int* batch_ids, int n, int batch_size, int scale_inv,
+                       float* aabb_min, float* aabb_max, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    if (!aabb_min || !aabb_max || batch_size <= 0 || n < 0 || (n > 0 && (!pts || !batch_ids))) return MCCNN_E_BADARG;
+    if (!ws || ws_bytes < mccnn_compute_aabb_workspace_bytes(batch_size)) return MCCNN_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* enc = (unsigned*)ws;
+    aabb_init<<<ceil_div(3 * batch_size, 256), 256, 0, s>>>(enc, batch_size);
+    MCCNN_LAUNCHED();
+    if (n > 0) {
+        aabb_reduce<<<ceil_div(n, 256), 256, 0, s>>>(pts, batch_ids, n, batch_size, enc);
+        MCCNN_LAUNCHED();
+    }
+    aabb_finalize<<<1, 256, 0, s>>>(enc, batch_size, scale_inv, aabb_min, aabb_max);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+int mccnn_num_cells(const float* aabb_min, const float* aabb_max, int batch_size, float cell_size, int scale_inv,
+                    int* num_cells_host, mccnn_stream_t stream) {
+    if (!num_cells_host || batch_size <= 0 || !(cell_size > 0.0f)) return MCCNN_E_BADARG;
+    if (scale_inv) {  // sort_gpu.cu:404-408
+        int nc = (int)(1.0f / cell_size);
+        *num_cells_host = nc == 0 ? 1 : nc;
+        return 0;
+    }
+    if (!aabb_min || !aabb_max) return MCCNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    float h[6];
+    MCCNN_HIP(hipMemcpyAsync(h, aabb_min, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    MCCNN_HIP(hipMemcpyAsync(h + 3, aabb_max, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    MCCNN_HIP(hipStreamSynchronize(s));
+    float ext = fmaxf(fmaxf(h[3] - h[0], h[4] - h[1]), h[5] - h[2]);
+    int nc = (int)(ext / cell_size);
+    *num_cells_host = nc == 0 ? 1 : nc;
+    return 0;
+}
+
+static long long total_cells(int B, int nc) { return (long long)B * nc * nc * nc; }
+
+size_t mccnn_sort_step1_workspace_bytes(int n, int batch_size, int num_cells) {
+    long long C = total_cells(batch_size, num_cells);
+    if (C <= 0 || C >= 0x7fffffffLL) return 0;
+    return align_up((size_t)C * 4) + align_up((size_t)(C + 1) * 4) + align_up((size_t)(n > 0 ? n : 1) * 4) +
+           scan_workspace_bytes((int)C) + 256;
+}
+
+int mccnn_sort_step1(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n,
+                     int batch_size, int num_cells, int* keys, int* new_idx, void* ws, size_t ws_bytes,
+                     mccnn_stream_t stream) {
+    if (n < 0 || batch_size <= 0 || num_cells <= 0 || !aabb_min || !aabb_max) return MCCNN_E_BADARG;
+    if (n == 0) return 0;
+    if (!pts || !batch_ids || !keys || !new_idx) return MCCNN_E_BADARG;
+    long long C = total_cells(batch_size, num_cells);
+    if (C >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
+    if (!ws || ws_bytes < mccnn_sort_step1_workspace_bytes(n, batch_size, num_cells)) return MCCNN_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    Arena a(ws, ws_bytes);
+    int* cnt = a.take<int>((size_t)C);
+    int* start = a.take<int>((size_t)C + 1);
+    int* slot = a.take<int>((size_t)n);
+    void* scanws = a.take<char>(scan_workspace_bytes((int)C));
+    if (!cnt || !start || !slot || !scanws) return MCCNN_E_WORKSPACE;
+    MCCNN_HIP(hipMemsetAsync(cnt, 0, (size_t)C * sizeof(int), s));
+    int blocks = ceil_div(n, 256);
+    keys_hist<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, num_cells, keys, cnt, new_idx);
+    MCCNN_LAUNCHED();
+    int rc = exclusive_scan_i32(cnt, start, (int)C, start + C, scanws, s);
+    if (rc) return rc;
+    park_ids<<<blocks, 256, 0, s>>>(keys, start, new_idx, n, slot);
+    MCCNN_LAUNCHED();
+    rank_in_cell<<<blocks, 256, 0, s>>>(keys, start, slot, n, new_idx);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+size_t mccnn_sort_step2_workspace_bytes(int n) { return align_up((size_t)(n > 0 ? n : 1) * 4); }
+
+int mccnn_sort_step2(const float* pts, const int* batch_ids, const float* feats, const int* keys, const int* new_idx,
+                     int n, int num_feats, int batch_size, int num_cells, float* out_pts, int* out_batch_ids,
+                     float* out_feats, int* cell_indexs, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    if (n < 0 || batch_size <= 0 || num_cells <= 0 || num_feats <= 0 || !cell_indexs) return MCCNN_E_BADARG;
+    long long C = total_cells(batch_size, num_cells);
+    if (C >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
+    hipStream_t s = (hipStream_t)stream;
+    MCCNN_HIP(hipMemsetAsync(cell_indexs, 0, (size_t)C * 2 * sizeof(int), s));  // sort_gpu.cu:492
+    if (n == 0) return 0;
+    if (!pts || !batch_ids || !feats || !keys || !new_idx || !out_pts || !out_batch_ids || !out_feats)
+        return MCCNN_E_BADARG;
+    if (!ws || ws_bytes < mccnn_sort_step2_workspace_bytes(n)) return MCCNN_E_WORKSPACE;
+    int* skeys = (int*)ws;
+    int blocks = ceil_div(n, 256);
+    move_points<<<blocks, 256, 0, s>>>(pts, batch_ids, keys, new_idx, n, out_pts, out_batch_ids, skeys);
+    MCCNN_LAUNCHED();
+    int rc = launch_permute<false>(feats, new_idx, n, num_feats, out_feats, s);
+    if (rc) return rc;
+    cell_table<<<blocks, 256, 0, s>>>(skeys, n, cell_indexs);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+int mccnn_permute_gather(const float* in, const int* idx, int n_idx, int num_feats, float* out,
+                         mccnn_stream_t stream) {
+    if (n_idx < 0 || num_feats <= 0) return MCCNN_E_BADARG;
+    if (n_idx == 0) return 0;
+    if (!in || !idx || !out) return MCCNN_E_BADARG;
+    return launch_permute<true>(in, idx, n_idx, num_feats, out, (hipStream_t)stream);
+}
+
+int mccnn_permute_scatter(const float* in, const int* idx, int n_idx, int num_feats, float* out, int n_out,
+                          int zero_fill, mccnn_stream_t stream) {
+    if (n_idx < 0 || num_feats <= 0 || n_out < 0) return MCCNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (zero_fill && n_out > 0) {
+        if (!out) return MCCNN_E_BADARG;
+        MCCNN_HIP(hipMemsetAsync(out, 0, (size_t)n_out * num_feats * sizeof(float), s));
+    }
+    if (n_idx == 0) return 0;
+    if (!in || !idx || !out) return MCCNN_E_BADARG;
+    return launch_permute<false>(in, idx, n_idx, num_feats, out, s);
+}
+
+size_t mccnn_transform_indexs_workspace_bytes(int n) { return align_up((size_t)(n > 0 ? n : 1) * 4); }
+
+int mccnn_transform_indexs(const int* in_idx, int s_count, const int* new_idx, int n, int* out_idx, void* ws,
+                           size_t ws_bytes, mccnn_stream_t stream) {
+    if (s_count < 0 || n < 0) return MCCNN_E_BADARG;
+    if (s_count == 0) return 0;
+    if (!in_idx || !new_idx || !out_idx || n == 0) return MCCNN_E_BADARG;
+    if (!ws || ws_bytes < mccnn_transform_indexs_workspace_bytes(n)) return MCCNN_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    int* inv = (int*)ws;
+    invert_perm<<<ceil_div(n, 256), 256, 0, s>>>(new_idx, n, inv);
+    MCCNN_LAUNCHED();
+    map_indexs<<<ceil_div(s_count, 256), 256, 0, s>>>(in_idx, s_count, inv, out_idx);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+}  // extern "C"

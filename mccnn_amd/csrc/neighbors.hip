@@ -1,0 +1,177 @@
+// Fixed-radius neighbour search over the 27-cell window and the per-edge kernel density
+// estimate. Replaces tf_ops/find_neighbors.cu and tf_ops/compute_pdf.cu.
+#include "common.h"
+
+namespace mccnn {
+
+struct CentreCtx {
+    float cx, cy, cz, R;
+    int b, x, y, z;
+};
+
+__device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centres, const int* __restrict__ cb,
+                                                const float* __restrict__ mn, const float* __restrict__ mx,
+                                                int i, int nc, float radius, int scaleInv) {
+    CentreCtx c;
+    c.b = cb[i];
+    c.cx = centres[(size_t)i * 3];
+    c.cy = centres[(size_t)i * 3 + 1];
+    c.cz = centres[(size_t)i * 3 + 2];
+    float ext = max_extent(mn, mx, c.b);
+    float cs = ext / (float)nc;
+    c.R = scaleInv ? radius * ext : radius;  // find_neighbors.cu:73
+    c.x = cell_coord(c.cx, mn[c.b * 3], cs, nc);
+    c.y = cell_coord(c.cy, mn[c.b * 3 + 1], cs, nc);
+    c.z = cell_coord(c.cz, mn[c.b * 3 + 2], cs, nc);
+    return c;
+}
+
+// One thread per centre; FILL == false counts, FILL == true writes (j, i) rows.
+// Traversal order = cellOffsets order (find_neighbors.cu:282-291), then ascending j.
+template <bool FILL>
+__global__ __launch_bounds__(128) void neigh_walk(const float* __restrict__ centres, const int* __restrict__ cb, int m,
+                                                  const float* __restrict__ pts2, const int* __restrict__ cells,
+                                                  const float* __restrict__ mn, const float* __restrict__ mx, int nc,
+                                                  float radius, int scaleInv, int* __restrict__ counts,
+                                                  const int* __restrict__ startIdx, int* __restrict__ packed) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    CentreCtx c = centre_ctx(centres, cb, mn, mx, i, nc, radius, scaleInv);
+    int k = 0;
+    int2* dst = FILL ? reinterpret_cast<int2*>(packed) + startIdx[i] : nullptr;
+    size_t cellBase = (size_t)c.b * nc * nc * nc;
+    for (int o = 0; o < 27; ++o) {
+        int dx, dy, dz;
+        neigh_offset(o, dx, dy, dz);
+        int X = c.x + dx, Y = c.y + dy, Z = c.z + dz;
+        if (X < 0 || X >= nc || Y < 0 || Y >= nc || Z < 0 || Z >= nc) continue;
+        size_t flat = cellBase + (size_t)X * nc * nc + (size_t)Y * nc + Z;
+        int2 r = reinterpret_cast<const int2*>(cells)[flat];
+        for (int j = r.x; j < r.y; ++j) {
+            float d = point_dist(pts2[(size_t)j * 3], pts2[(size_t)j * 3 + 1], pts2[(size_t)j * 3 + 2], c.cx, c.cy, c.cz);
+            if (d < c.R) {
+                if (FILL) dst[k] = make_int2(j, i);
+                ++k;
+            }
+        }
+    }
+    if (!FILL) counts[i] = k;
+}
+
+// ------------------------------------------------------------------ compute_pdf.cu:40-94
+// One thread per edge (j, i): KDE of p_j against every neighbour of centre i.
+template <int MODE>
+__global__ __launch_bounds__(256) void pdf_edges(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                 const int* __restrict__ startIdx, int m,
+                                                 const int2* __restrict__ packed, int e, const float* __restrict__ mn,
+                                                 const float* __restrict__ mx, float window, float radius,
+                                                 int scaleInv, float* __restrict__ pdfs) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= e) return;
+    int2 pr = packed[t];
+    int cur = pr.x, centre = pr.y;
+    float cx = pts[(size_t)cur * 3], cy = pts[(size_t)cur * 3 + 1], cz = pts[(size_t)cur * 3 + 2];
+    int b = bids[cur];
+    float ext = max_extent(mn, mx, b);
+    float R = scaleInv ? radius * ext : radius;
+    int i0 = startIdx[centre];
+    int i1 = (centre < m - 1) ? startIdx[centre + 1] : e;
+    const float h = window;
+    const float invH = 1 / h;
+    const float invRadH = (float)(1.0 / (double)(R * h));  // compute_pdf.cu:74
+    float pdf = 0.0f;
+    if (MODE == 0) {
+        for (int it = i0; it < i1; ++it) {
+            size_t q = (size_t)packed[it].x * 3;
+            float d0 = (pts[q] - cx) * invRadH;
+            float d1 = (pts[q + 1] - cy) * invRadH;
+            float d2 = (pts[q + 2] - cz) * invRadH;
+            // compute_pdf.cu:85-88, double sub-expressions rounded to float per statement
+            float g = (float)((double)invH * ((0.39894228) * exp((-0.5) * (double)d0 * (double)d0)));
+            g = (float)((double)(g * invH) * ((0.39894228) * exp((-0.5) * (double)d1 * (double)d1)));
+            g = (float)((double)(g * invH) * ((0.39894228) * exp((-0.5) * (double)d2 * (double)d2)));
+            pdf += g;
+        }
+    } else {
+        const float k3 = (invH * 0.39894228f) * (invH * 0.39894228f) * (invH * 0.39894228f);
+        for (int it = i0; it < i1; ++it) {
+            size_t q = (size_t)packed[it].x * 3;
+            float d0 = (pts[q] - cx) * invRadH;
+            float d1 = (pts[q + 1] - cy) * invRadH;
+            float d2 = (pts[q + 2] - cz) * invRadH;
+            float s = d0 * d0 + d1 * d1 + d2 * d2;
+            pdf += k3 * __expf(-0.5f * s);
+        }
+    }
+    pdfs[t] = pdf / ((float)i1 - i0);  // compute_pdf.cu:92
+}
+
+}  // namespace mccnn
+
+using namespace mccnn;
+
+extern "C" {
+
+size_t mccnn_find_neighbors_workspace_bytes(int m) {
+    return align_up((size_t)(m > 0 ? m : 1) * 4) + scan_workspace_bytes(m > 0 ? m : 1) + 256;
+}
+
+int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
+                               const int* cell_indexs, const float* aabb_min, const float* aabb_max, int batch_size,
+                               int num_cells, float radius, int scale_inv, int* start_idx, int* total_dev, void* ws,
+                               size_t ws_bytes, mccnn_stream_t stream) {
+    if (m < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (m == 0) {
+        MCCNN_HIP(hipMemsetAsync(total_dev, 0, sizeof(int), s));
+        return 0;
+    }
+    if (!centres || !centre_batch_ids || !cell_indexs || !aabb_min || !aabb_max || !start_idx) return MCCNN_E_BADARG;
+    if (!ws || ws_bytes < mccnn_find_neighbors_workspace_bytes(m)) return MCCNN_E_WORKSPACE;
+    Arena a(ws, ws_bytes);
+    int* counts = a.take<int>((size_t)m);
+    void* scanws = a.take<char>(scan_workspace_bytes(m));
+    if (!counts || !scanws) return MCCNN_E_WORKSPACE;
+    neigh_walk<false><<<ceil_div(m, 128), 128, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
+                                                       aabb_max, num_cells, radius, scale_inv, counts, nullptr,
+                                                       nullptr);
+    MCCNN_LAUNCHED();
+    return exclusive_scan_i32(counts, start_idx, m, total_dev, scanws, s);
+}
+
+int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
+                              const int* cell_indexs, const float* aabb_min, const float* aabb_max, int batch_size,
+                              int num_cells, float radius, int scale_inv, const int* start_idx, int e, int* packed,
+                              mccnn_stream_t stream) {
+    if (m < 0 || e < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f)) return MCCNN_E_BADARG;
+    if (m == 0 || e == 0) return 0;
+    if (!centres || !centre_batch_ids || !sorted_pts || !cell_indexs || !aabb_min || !aabb_max || !start_idx || !packed)
+        return MCCNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    neigh_walk<true><<<ceil_div(m, 128), 128, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
+                                                      aabb_max, num_cells, radius, scale_inv, nullptr, start_idx,
+                                                      packed);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx, int m,
+                      const int* packed, int e, const float* aabb_min, const float* aabb_max, int batch_size,
+                      float window, float radius, int scale_inv, int mode, float* pdfs, mccnn_stream_t stream) {
+    if (m < 0 || e < 0 || batch_size <= 0 || !(radius > 0.0f) || !(window > 0.0f)) return MCCNN_E_BADARG;
+    if (e == 0) return 0;
+    if (!sorted_pts || !sorted_batch_ids || !start_idx || !packed || !aabb_min || !aabb_max || !pdfs || m == 0)
+        return MCCNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int2* pk = reinterpret_cast<const int2*>(packed);
+    if (mode == 0)
+        pdf_edges<0><<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, start_idx, m, pk, e, aabb_min,
+                                                      aabb_max, window, radius, scale_inv, pdfs);
+    else
+        pdf_edges<1><<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, start_idx, m, pk, e, aabb_min,
+                                                      aabb_max, window, radius, scale_inv, pdfs);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+// Parallel Poisson-disk subsampling on the point grid. Replaces tf_ops/poisson_sampling.cu.
+//
+// The reference runs 27*B serial launches (poisson_sampling.cu:210-219), one per batch and
+// colour phase, and appends samples through a global atomic counter, so its output ORDER is
+// nondeterministic while the selected SET is not (cells handled in one phase are >= 3 cells
+// apart, their 27-windows never overlap). Here: one launch per colour phase over all batches
+// (27 launches), each cell records how many samples it kept in a slot indexed by the
+// canonical sequential order, an exclusive scan of the slots gives every cell its output
+// base, and a fill pass emits the samples -- deterministic, no atomics.
+#include "common.h"
+
+namespace mccnn {
+
+struct PoissonDims {
+    int nc, G, nB, D;  // cells/axis, phase groups/axis, 4-wide blocks/axis, nB*4
+};
+__host__ __device__ inline PoissonDims poisson_dims(int nc) {
+    PoissonDims d;
+    d.nc = nc;
+    d.G = nc / 3 + ((nc % 3 != 0) ? 1 : 0);      // poisson_sampling.cu:206-207
+    d.nB = d.G / 4 + ((d.G % 4 != 0) ? 1 : 0);   // :208-209
+    d.D = d.nB * 4;
+    return d;
+}
+// Position of group (gx,gy,gz) of batch b, phase ph in the reference's sequential launch order:
+// batch, phase, blockIdx z,y,x, threadIdx z,y,x (x fastest).
+__device__ __forceinline__ long long poisson_slot(const PoissonDims& d, int b, int ph, int gx, int gy, int gz) {
+    int bx = gx >> 2, by = gy >> 2, bz = gz >> 2, tx = gx & 3, ty = gy & 3, tz = gz & 3;
+    long long lin = ((long long)((bz * d.nB + by) * d.nB + bx)) * 64 + (tz * 4 + ty) * 4 + tx;
+    return ((long long)b * 27 + ph) * ((long long)d.D * d.D * d.D) + lin;
+}
+
+// selectSamples (poisson_sampling.cu:51-124) for one phase, all batches.
+__global__ __launch_bounds__(64) void poisson_phase(const float* __restrict__ pts, const int* __restrict__ cells,
+                                                    const float* __restrict__ mn, const float* __restrict__ mx, int B,
+                                                    PoissonDims d, int ph, float radius, int scaleInv,
+                                                    unsigned char* __restrict__ sel, int* __restrict__ slotCount) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long perBatch = (long long)d.G * d.G * d.G;
+    if (t >= perBatch * B) return;
+    int b = (int)(t / perBatch);
+    int r = (int)(t - (long long)b * perBatch);
+    int gx = r % d.G, gy = (r / d.G) % d.G, gz = r / (d.G * d.G);
+    int ox, oy, oz;
+    pool_offset(ph, ox, oy, oz);
+    int nc = d.nc;
+    int xC = gx * 3 + 1 + ox, yC = gy * 3 + 1 + oy, zC = gz * 3 + 1 + oz;
+    if (!(xC < nc && yC < nc && zC < nc)) return;  // poisson_sampling.cu:74
+    float ext = max_extent(mn, mx, b);
+    float R = scaleInv ? radius * ext : radius;
+    size_t cellBase = (size_t)b * nc * nc * nc;
+    const int2* ct = reinterpret_cast<const int2*>(cells);
+    int2 me = ct[cellBase + (size_t)xC * nc * nc + (size_t)yC * nc + zC];
+    int kept = 0;
+    for (int i = me.x; i < me.y; ++i) {
+        float c0 = pts[(size_t)i * 3], c1 = pts[(size_t)i * 3 + 1], c2 = pts[(size_t)i * 3 + 2];
+        bool collision = false;
+        for (int o = 0; o < 27 && !collision; ++o) {
+            int dx, dy, dz;
+            pool_offset(o, dx, dy, dz);
+            int X = xC + dx, Y = yC + dy, Z = zC + dz;
+            if (X < 0 || X >= nc || Y < 0 || Y >= nc || Z < 0 || Z >= nc) continue;
+            int2 rr = ct[cellBase + (size_t)X * nc * nc + (size_t)Y * nc + Z];
+            for (int j = rr.x; j < rr.y && !collision; ++j) {
+                // a point of my own cell selected earlier in this very loop is visible: same thread
+                if (!sel[j]) continue;
+                float dd = point_dist(pts[(size_t)j * 3], pts[(size_t)j * 3 + 1], pts[(size_t)j * 3 + 2], c0, c1, c2);
+                if (dd < R) collision = true;
+            }
+        }
+        if (!collision) {
+            sel[i] = 1;
+            ++kept;
+        }
+    }
+    slotCount[poisson_slot(d, b, ph, gx, gy, gz)] = kept;
+}
+
+// phase index of an (ox,oy,oz) offset triple = inverse of the table at poisson_sampling.cu:192-196
+__device__ __forceinline__ int pool_phase_of(int ox, int oy, int oz) {
+    for (int p = 0; p < 27; ++p) {
+        int dx, dy, dz;
+        pool_offset(p, dx, dy, dz);
+        if (dx == ox && dy == oy && dz == oz) return p;
+    }
+    return -1;
+}
+
+// One thread per grid cell: emit its kept points at the cell's canonical output base.
+__global__ __launch_bounds__(256) void poisson_emit(const float* __restrict__ pts, const int* __restrict__ cells,
+                                                    int B, PoissonDims d, const unsigned char* __restrict__ sel,
+                                                    const int* __restrict__ slotBase, float* __restrict__ oPts,
+                                                    int* __restrict__ oBids, int* __restrict__ oIdx) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int nc = d.nc;
+    long long perBatch = (long long)nc * nc * nc;
+    if (t >= perBatch * B) return;
+    int b = (int)(t / perBatch);
+    int r = (int)(t - (long long)b * perBatch);
+    int z = r % nc, y = (r / nc) % nc, x = r / (nc * nc);
+    int2 me = reinterpret_cast<const int2*>(cells)[t];
+    if (me.y <= me.x) return;
+    // cell = 3g + 1 + off, off in {-1,0,1}  =>  g = cell / 3, off = cell % 3 - 1
+    int ph = pool_phase_of(x % 3 - 1, y % 3 - 1, z % 3 - 1);
+    int o = slotBase[poisson_slot(d, b, ph, x / 3, y / 3, z / 3)];
+    for (int i = me.x; i < me.y; ++i) {
+        if (!sel[i]) continue;
+        oPts[(size_t)o * 3] = pts[(size_t)i * 3];
+        oPts[(size_t)o * 3 + 1] = pts[(size_t)i * 3 + 1];
+        oPts[(size_t)o * 3 + 2] = pts[(size_t)i * 3 + 2];
+        oBids[o] = b;
+        oIdx[o] = i;
+        ++o;
+    }
+}
+
+static long long poisson_slots(int B, int nc) {
+    PoissonDims d = poisson_dims(nc);
+    return (long long)B * 27 * d.D * d.D * d.D;
+}
+
+}  // namespace mccnn
+
+using namespace mccnn;
+
+extern "C" {
+
+size_t mccnn_poisson_sampling_workspace_bytes(int n, int batch_size, int num_cells) {
+    if (batch_size <= 0 || num_cells <= 0) return 0;
+    long long S = poisson_slots(batch_size, num_cells);
+    if (S >= 0x7fffffffLL) return 0;
+    return align_up((size_t)(n > 0 ? n : 1)) + align_up((size_t)S * 4) + scan_workspace_bytes((int)S) + 256;
+}
+
+int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batch_ids, int n, const int* cell_indexs,
+                                 const float* aabb_min, const float* aabb_max, int batch_size, int num_cells,
+                                 float radius, int scale_inv, int* total_dev, void* ws, size_t ws_bytes,
+                                 mccnn_stream_t stream) {
+    (void)sorted_batch_ids;
+    if (n < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        MCCNN_HIP(hipMemsetAsync(total_dev, 0, sizeof(int), s));
+        return 0;
+    }
+    if (!sorted_pts || !cell_indexs || !aabb_min || !aabb_max) return MCCNN_E_BADARG;
+    long long S = poisson_slots(batch_size, num_cells);
+    if (S >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
+    if (!ws || ws_bytes < mccnn_poisson_sampling_workspace_bytes(n, batch_size, num_cells)) return MCCNN_E_WORKSPACE;
+    Arena a(ws, ws_bytes);
+    unsigned char* sel = a.take<unsigned char>((size_t)n);
+    int* slots = a.take<int>((size_t)S);
+    void* scanws = a.take<char>(scan_workspace_bytes((int)S));
+    if (!sel || !slots || !scanws) return MCCNN_E_WORKSPACE;
+    MCCNN_HIP(hipMemsetAsync(sel, 0, (size_t)n, s));
+    MCCNN_HIP(hipMemsetAsync(slots, 0, (size_t)S * sizeof(int), s));
+    PoissonDims d = poisson_dims(num_cells);
+    long long threads = (long long)batch_size * d.G * d.G * d.G;
+    for (int ph = 0; ph < 27; ++ph) {
+        poisson_phase<<<ceil_div(threads, 64), 64, 0, s>>>(sorted_pts, cell_indexs, aabb_min, aabb_max, batch_size, d,
+                                                           ph, radius, scale_inv, sel, slots);
+        MCCNN_LAUNCHED();
+    }
+    return exclusive_scan_i32(slots, slots, (int)S, total_dev, scanws, s);
+}
+
+int mccnn_poisson_sampling_fill(const float* sorted_pts, int n, const int* cell_indexs, int batch_size, int num_cells,
+                                int s_count, float* out_pts, int* out_batch_ids, int* out_indexs, void* ws,
+                                size_t ws_bytes, mccnn_stream_t stream) {
+    if (n < 0 || s_count < 0 || batch_size <= 0 || num_cells <= 0) return MCCNN_E_BADARG;
+    if (n == 0 || s_count == 0) return 0;
+    if (!sorted_pts || !cell_indexs || !out_pts || !out_batch_ids || !out_indexs) return MCCNN_E_BADARG;
+    long long S = poisson_slots(batch_size, num_cells);
+    if (!ws || ws_bytes < mccnn_poisson_sampling_workspace_bytes(n, batch_size, num_cells)) return MCCNN_E_WORKSPACE;
+    Arena a(ws, ws_bytes);
+    unsigned char* sel = a.take<unsigned char>((size_t)n);
+    int* slots = a.take<int>((size_t)S);
+    if (!sel || !slots) return MCCNN_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    PoissonDims d = poisson_dims(num_cells);
+    long long cellsTotal = (long long)batch_size * num_cells * num_cells * num_cells;
+    poisson_emit<<<ceil_div(cellsTotal, 256), 256, 0, s>>>(sorted_pts, cell_indexs, batch_size, d, sel, slots, out_pts,
+                                                           out_batch_ids, out_indexs);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+}  // extern "C"

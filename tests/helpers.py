@@ -1,0 +1,112 @@
+"""Shared input generators and the op-chain driver used by both the oracle and the GPU tests."""
+import numpy as np
+
+
+def make_cloud(n_per, B, seed, kind="uniform", ragged=False):
+    """Flattened ragged batch: points [N,3] f32, batch ids [N,1] i32, clouds concatenated."""
+    rng = np.random.default_rng(seed)
+    pts, bids = [], []
+    for b in range(B):
+        n = n_per if not ragged else max(1, int(n_per * (0.3 + 0.7 * rng.random())))
+        if kind == "uniform":
+            p = rng.random((n, 3), dtype=np.float32)
+        elif kind == "sphere":
+            v = rng.normal(size=(n, 3))
+            p = (v / np.linalg.norm(v, axis=1, keepdims=True) * (0.5 + 0.1 * b)).astype(np.float32)
+        elif kind == "clustered":  # strongly non-uniform: dense blobs + sparse background
+            k = n // 2
+            c = rng.random((4, 3))
+            blob = c[rng.integers(0, 4, k)] + 0.03 * rng.normal(size=(k, 3))
+            p = np.concatenate([blob, rng.random((n - k, 3))]).astype(np.float32)
+            rng.shuffle(p)
+        else:
+            raise ValueError(kind)
+        pts.append(p + np.float32(0.25 * b))
+        bids.append(np.full((len(p), 1), b, np.int32))
+    return np.concatenate(pts).astype(np.float32), np.concatenate(bids).astype(np.int32)
+
+
+def make_room(n, seed, oversample=3.0):
+    """Synthetic ScanNet-like room: surfaces of a 6.0 x 4.0 x 2.8 m box (floor + 4 walls)
+    plus 6 axis-aligned furniture boxes, sampled uniformly by area, then thinned to n points with the
+    reference's *gradient* protocol along the longest axis (utils/DataSet.py:431-492:
+    keep-prob = sqrt(clip((x - 0.2 L) / (0.6 L), 0.01, 1)))."""
+    rng = np.random.default_rng(seed)
+    L, W, H = 6.0, 4.0, 2.8
+    rects = []  # (origin, edge u, edge v)
+    rects.append(((0, 0, 0), (L, 0, 0), (0, W, 0)))  # floor
+    rects.append(((0, 0, 0), (L, 0, 0), (0, 0, H)))
+    rects.append(((0, W, 0), (L, 0, 0), (0, 0, H)))
+    rects.append(((0, 0, 0), (0, W, 0), (0, 0, H)))
+    rects.append(((L, 0, 0), (0, W, 0), (0, 0, H)))
+    frng = np.random.default_rng(20180601)  # furniture layout is fixed across rooms
+    for _ in range(6):
+        sx, sy, sz = 0.4 + 1.2 * frng.random(), 0.4 + 0.8 * frng.random(), 0.3 + 0.9 * frng.random()
+        ox, oy = (L - sx) * frng.random(), (W - sy) * frng.random()
+        o = np.array([ox, oy, 0.0])
+        for (a, u, v) in (((0, 0, sz), (sx, 0, 0), (0, sy, 0)), ((0, 0, 0), (sx, 0, 0), (0, 0, sz)),
+                          ((0, sy, 0), (sx, 0, 0), (0, 0, sz)), ((0, 0, 0), (0, sy, 0), (0, 0, sz)),
+                          ((sx, 0, 0), (0, sy, 0), (0, 0, sz))):
+            rects.append((tuple(o + np.array(a)), u, v))
+    areas = np.array([np.linalg.norm(np.cross(u, v)) for (_, u, v) in rects])
+    total = int(n * oversample)
+    which = rng.choice(len(rects), size=total, p=areas / areas.sum())
+    uv = rng.random((total, 2))
+    org = np.array([r[0] for r in rects], dtype=np.float64)[which]
+    eu = np.array([r[1] for r in rects], dtype=np.float64)[which]
+    ev = np.array([r[2] for r in rects], dtype=np.float64)[which]
+    p = org + eu * uv[:, :1] + ev * uv[:, 1:]
+    prob = np.sqrt(np.clip((p[:, 0] - 0.2 * L) / (0.6 * L), 0.01, 1.0))
+    keep = rng.random(total) < prob
+    p = p[keep]
+    if len(p) < n:
+        return make_room(n, seed, oversample * 1.6)
+    sel = rng.choice(len(p), size=n, replace=False)
+    return p[sel].astype(np.float32)
+
+
+def make_mlp(nb, seed, scale=0.5, bias=0.1):
+    """Kernel-MLP tensors in the reference's declared shapes (MCConvBuilder.py:407-419)."""
+    rng = np.random.default_rng(seed)
+    nn = 8 * nb
+    u = lambda *s: (scale * (2 * rng.random(s) - 1)).astype(np.float32)
+    return dict(w1=u(3, nn), b1=(bias * u(nn)), w2=u(8, nn), b2=(bias * u(nn)), w3=u(8, nn), b3=(bias * u(nn)))
+
+
+def conv_nb(fin, fout, combin):
+    neurons = fin * fout if combin else fin
+    return (neurons + 7) // 8
+
+
+def run_chain(ops, wrap, unwrap, pts, bids, feats, B, radius, scaleInv, window=0.2, fout=8, combin=True, avg=True,
+              seed=7, poisson_radius=None, centres=None, centre_bids=None, pdf_kwargs=None):
+    """compute_aabb -> sort_step1/2 -> find_neighbors -> compute_pdf -> spatial_conv (+grad) [-> poisson ...],
+    i.e. ConvolutionBuilder.create_convolution's op sequence (MCConvBuilder.py:349-427).
+    `ops` is a module/object exposing the reference's op names; wrap/unwrap convert numpy<->backend tensors."""
+    r = {}
+    P, Bi, F = wrap(pts), wrap(bids), wrap(feats)
+    mn, mx = ops.compute_aabb(P, Bi, B, scaleInv)
+    keys, idx = ops.sort_points_step1(P, Bi, mn, mx, B, radius, scaleInv)
+    sP, sB, sF, cells = ops.sort_points_step2(P, Bi, F, keys, idx, mn, mx, B, radius, scaleInv)
+    C = P if centres is None else wrap(centres)
+    Cb = Bi if centres is None else wrap(centre_bids)
+    start, packed = ops.find_neighbors(C, Cb, sP, cells, mn, mx, radius, B, scaleInv)
+    pdfs = ops.compute_pdf(sP, sB, mn, mx, start, packed, window, radius, B, scaleInv, **(pdf_kwargs or {}))
+    r.update(aabbMin=unwrap(mn), aabbMax=unwrap(mx), keys=unwrap(keys), indexs=unwrap(idx), sortPts=unwrap(sP),
+             sortBatchs=unwrap(sB), sortFeatures=unwrap(sF), cellIndexs=unwrap(cells), startIndexs=unwrap(start),
+             packedNeighs=unwrap(packed), pdfs=unwrap(pdfs))
+    fin = feats.shape[1]
+    w = make_mlp(conv_nb(fin, fout, combin), seed)
+    r["mlp"] = w
+    r["_handles"] = dict(sP=sP, sB=sB, sF=sF, cells=cells, mn=mn, mx=mx, start=start, packed=packed, pdfs=pdfs, C=C,
+                         idx=idx)
+    if poisson_radius is not None:
+        # a second grid at the Poisson radius, like PointHierarchy.__init__ (MCConvBuilder.py:101-116)
+        k2, i2 = ops.sort_points_step1(P, Bi, mn, mx, B, poisson_radius, scaleInv)
+        p2, b2, f2, c2 = ops.sort_points_step2(P, Bi, F, k2, i2, mn, mx, B, poisson_radius, scaleInv)
+        sp, sb, si = ops.poisson_sampling(p2, b2, c2, mn, mx, poisson_radius, B, scaleInv)
+        sf = ops.get_sampled_features(si, f2)
+        ti = ops.transform_indexs(si, i2)
+        r.update(samplePts=unwrap(sp), sampleBatchs=unwrap(sb), sampleIndexs=unwrap(si), sampleFeatures=unwrap(sf),
+                 transformedIndexs=unwrap(ti), poissonSortPts=unwrap(p2), poissonCells=unwrap(c2))
+    return r

@@ -1,0 +1,213 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): integer / index outputs bit-exact (sort keys and order, cell table,
+neighbour lists, Poisson samples); float outputs within 1e-4 relative.
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import make_cloud, make_room, make_mlp, conv_nb, run_chain
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4  # north_star: "fp32 features within 1e-4 rel"
+
+
+def _wrap(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def _unwrap(t):
+    return t.detach().cpu().numpy()
+
+
+def _ident(x):
+    return x
+
+
+def assert_close(got, ref, rtol=RTOL, what=""):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-30) if ref.size else 1.0
+    err = np.abs(got - ref).max() / scale if ref.size else 0.0
+    assert err <= rtol, "%s: max |diff| / max |ref| = %.3e > %.1e" % (what, err, rtol)
+
+
+INT_KEYS = ["keys", "indexs", "sortBatchs", "cellIndexs", "startIndexs", "packedNeighs"]
+EXACT_FLOAT_KEYS = ["aabbMin", "aabbMax", "sortPts", "sortFeatures"]  # pure copies / min / max
+
+
+def compare_chain(g, o, pdf_rtol=RTOL):
+    for k in INT_KEYS + EXACT_FLOAT_KEYS:
+        assert g[k].shape == o[k].shape, (k, g[k].shape, o[k].shape)
+        assert np.array_equal(g[k], o[k]), "%s differs (%d mismatches)" % (k, int((g[k] != o[k]).sum()))
+    assert_close(g["pdfs"], o["pdfs"], pdf_rtol, "pdfs")
+    for k in ("samplePts", "sampleBatchs", "sampleIndexs", "sampleFeatures", "transformedIndexs"):
+        if k in o:
+            assert g[k].shape == o[k].shape, (k, g[k].shape, o[k].shape)
+            assert np.array_equal(g[k], o[k]), k
+
+
+CASES = [
+    # name, n_per, B, kind, ragged, radius, scaleInv, Fin, poisson_radius
+    ("cfg0_uniform4096", 4096, 1, "uniform", False, 0.1, True, 3, 0.1),
+    ("batched_sphere", 1024, 8, "sphere", False, 0.2, True, 1, 0.1),
+    ("ragged_clustered", 700, 5, "clustered", True, 0.15, True, 4, 0.05),
+    ("abs_radius_batched", 1500, 3, "uniform", True, 0.12, False, 3, 0.2),
+    ("single_cell", 300, 4, "uniform", False, 1.2, True, 2, 1.3),
+    ("tiny", 3, 2, "uniform", False, 0.5, True, 1, 0.5),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_grid_neighbors_pdf_poisson(mc, oracle, case):
+    _, n_per, B, kind, ragged, radius, scaleInv, fin, prad = case
+    pts, bids = make_cloud(n_per, B, 11, kind, ragged)
+    feats = np.random.default_rng(3).random((len(pts), fin), dtype=np.float32)
+    g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, B, radius, scaleInv, poisson_radius=prad,
+                  pdf_kwargs=dict(mode=0))
+    o = run_chain(oracle, _ident, _ident, pts, bids, feats, B, radius, scaleInv, poisson_radius=prad)
+    compare_chain(g, o, pdf_rtol=2e-6)  # mode 0 replays the reference arithmetic
+    # mode 1 (single precision KDE) stays inside the feature-path tolerance
+    h = g["_handles"]
+    fast = mc.compute_pdf(h["sP"], h["sB"], h["mn"], h["mx"], h["start"], h["packed"], 0.2, radius, B, scaleInv, mode=1)
+    assert_close(_unwrap(fast), o["pdfs"], RTOL, "pdfs(mode 1)")
+
+
+def test_room_absolute_radius(mc, oracle):
+    """Headline-like input: non-uniform room, absolute radius 0.1 (whole-batch box), 2 rooms x 20k points."""
+    B = 2
+    pts = np.concatenate([make_room(20000, 20180601), make_room(20000, 20180602)])
+    bids = np.repeat(np.arange(B, dtype=np.int32), 20000).reshape(-1, 1)
+    feats = np.random.default_rng(7).random((len(pts), 3), dtype=np.float32)
+    g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, B, 0.1, False, poisson_radius=0.2, pdf_kwargs=dict(mode=0))
+    o = run_chain(oracle, _ident, _ident, pts, bids, feats, B, 0.1, False, poisson_radius=0.2)
+    compare_chain(g, o, pdf_rtol=2e-6)
+
+
+def test_pooling_centres_differ_from_points(mc, oracle):
+    """Pool-style search: centres are a different (smaller, unsorted) point set than the gridded points."""
+    pts, bids = make_cloud(2000, 3, 5, "uniform")
+    rng = np.random.default_rng(9)
+    sel = np.sort(rng.choice(len(pts), 500, replace=False))
+    centres = (pts[sel] + 0.01 * rng.normal(size=(500, 3))).astype(np.float32)  # may leave the box: clamped cells
+    cb = bids[sel]
+    feats = rng.random((len(pts), 2), dtype=np.float32)
+    g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, 3, 0.2, True, centres=centres, centre_bids=cb,
+                  pdf_kwargs=dict(mode=0))
+    o = run_chain(oracle, _ident, _ident, pts, bids, feats, 3, 0.2, True, centres=centres, centre_bids=cb)
+    compare_chain(g, o, pdf_rtol=2e-6)
+
+
+CONV_CASES = [
+    # name, Fin, Fout, combin, avg, scaleInv, radius
+    ("cfg0_3to8_combin", 3, 8, True, True, True, 0.1),
+    ("1to16_combin", 1, 16, True, True, True, 0.15),
+    ("dw32", 32, 32, False, True, True, 0.15),
+    ("dw8_noavg_abs", 8, 8, False, False, False, 0.12),
+    ("2to5_combin_padded", 2, 5, True, True, True, 0.15),  # 10 neurons -> nb=2, 6 padded neurons... 16 % 2 == 0
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_spatial_conv_fwd_bwd(mc, oracle, case):
+    import torch
+    _, fin, fout, combin, avg, scaleInv, radius = case
+    B = 2
+    pts, bids = make_cloud(1500, B, 21, "clustered", True)
+    rng = np.random.default_rng(7)
+    feats = (2 * rng.random((len(pts), fin)) - 1).astype(np.float32)
+    o = run_chain(oracle, _ident, _ident, pts, bids, feats, B, radius, scaleInv, fout=fout, combin=combin)
+    g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, B, radius, scaleInv, fout=fout, combin=combin)
+    for k in INT_KEYS:
+        assert np.array_equal(g[k], o[k]), k
+    w = o["mlp"]
+    outF = fout if combin else fin
+    og = (2 * np.random.default_rng(11).random((len(pts), outF)) - 1).astype(np.float32)
+    # oracle
+    args = (o["sortPts"], o["sortFeatures"], o["sortBatchs"], o["pdfs"], pts, o["startIndexs"], o["packedNeighs"],
+            o["aabbMin"], o["aabbMax"], w["w1"], w["w2"], w["w3"], w["b1"], w["b2"], w["b3"])
+    ref = oracle.spatial_conv(*args, fout, combin, B, radius, scaleInv, avg)
+    rg = oracle.spatial_conv_grad(*args, og, fout, combin, B, radius, scaleInv, avg)
+    # GPU through autograd (same pdfs as the oracle so that only the conv is compared)
+    h = g["_handles"]
+    tw = {k: _wrap(v).requires_grad_(True) for k, v in w.items()}
+    sF = h["sF"].detach().clone().requires_grad_(True)
+    out = mc.spatial_conv(h["sP"], sF, h["sB"], _wrap(o["pdfs"]), h["C"], h["start"], h["packed"], h["mn"], h["mx"],
+                          tw["w1"], tw["w2"], tw["w3"], tw["b1"], tw["b2"], tw["b3"], fout, combin, B, radius,
+                          scaleInv, avg)
+    assert_close(_unwrap(out), ref, RTOL, "spatial_conv")
+    out.backward(_wrap(og))
+    torch.cuda.synchronize()
+    neurons = fin * fout if combin else fin
+    got = [sF.grad, tw["w1"].grad, tw["b1"].grad, tw["w2"].grad, tw["b2"].grad, tw["w3"].grad, tw["b3"].grad]
+    names = ["featGrad", "dw1", "db1", "dw2", "db2", "dw3", "db3"]
+    for nm, a, b in zip(names, got, rg):
+        assert_close(_unwrap(a), b, RTOL, nm)
+    # padded output neurons: the library writes zeros (reference leaves them uninitialised)
+    dw3 = _unwrap(tw["w3"].grad).reshape(-1)
+    assert np.all(dw3[neurons * 8:] == 0)
+
+
+def test_permutation_ops_and_adjoints(mc, oracle):
+    import torch
+    rng = np.random.default_rng(2)
+    n, F = 1000, 5
+    perm = rng.permutation(n).astype(np.int32)
+    f = rng.random((n, F), dtype=np.float32)
+    assert np.array_equal(_unwrap(mc.sort_features(_wrap(f), _wrap(perm))), oracle.sort_features(f, perm))
+    assert np.array_equal(_unwrap(mc.sort_features_back(_wrap(f), _wrap(perm))), oracle.sort_features_back(f, perm))
+    # mutual adjoints (MCConvModuleSrc:37-45)
+    x = _wrap(f).requires_grad_(True)
+    y = mc.sort_features(x, _wrap(perm))
+    gy = rng.random((n, F), dtype=np.float32)
+    y.backward(_wrap(gy))
+    assert np.array_equal(_unwrap(x.grad), oracle.sort_features_back(gy, perm))
+    # sampled features + scatter-with-zero-fill gradient (MCConvModuleSrc:63-68)
+    idx = np.sort(rng.choice(n, 100, replace=False)).astype(np.int32)
+    x2 = _wrap(f).requires_grad_(True)
+    s = mc.get_sampled_features(_wrap(idx), x2)
+    assert np.array_equal(_unwrap(s), oracle.get_sampled_features(idx, f))
+    gs = rng.random((100, F), dtype=np.float32)
+    s.backward(_wrap(gs))
+    assert np.array_equal(_unwrap(x2.grad), oracle.get_sampled_features_grad(idx, f, gs))
+    assert np.array_equal(_unwrap(mc.transform_indexs(_wrap(idx), _wrap(perm))), oracle.transform_indexs(idx, perm))
+
+
+def test_sort_step2_gradient_routing(mc, oracle):
+    pts, bids = make_cloud(500, 2, 4, "uniform")
+    feats = np.random.default_rng(1).random((len(pts), 3), dtype=np.float32)
+    P, Bi = _wrap(pts).requires_grad_(True), _wrap(bids)
+    F = _wrap(feats).requires_grad_(True)
+    mn, mx = mc.compute_aabb(P, Bi, 2, True)
+    k, i = mc.sort_points_step1(P, Bi, mn, mx, 2, 0.2, True)
+    sP, sB, sF, cells = mc.sort_points_step2(P, Bi, F, k, i, mn, mx, 2, 0.2, True)
+    gp = np.random.default_rng(5).random(pts.shape, dtype=np.float32)
+    gf = np.random.default_rng(6).random(feats.shape, dtype=np.float32)
+    (sP * _wrap(gp)).sum().backward(retain_graph=True)
+    (sF * _wrap(gf)).sum().backward()
+    idx = _unwrap(i)
+    rp, rf = oracle.sort_points_step2_grad(idx, gp, gf)
+    assert np.array_equal(_unwrap(P.grad), rp) and np.array_equal(_unwrap(F.grad), rf)
+
+
+def test_invalid_arguments_raise(mc):
+    import torch
+    pts, bids = make_cloud(64, 1, 0)
+    P, Bi = _wrap(pts), _wrap(bids)
+    with pytest.raises(mc.InvalidArgumentError):
+        mc.compute_aabb(P[:, :2].contiguous(), Bi, 1, True)  # not 3 components (aabb_gpu.cc:53-58)
+    with pytest.raises(mc.InvalidArgumentError):
+        mc.compute_aabb(P, Bi.reshape(-1), 1, True)          # batch ids must be [N,1]
+    mn, mx = mc.compute_aabb(P, Bi, 1, True)
+    with pytest.raises(mc.InvalidArgumentError):
+        mc.find_neighbors(P, Bi, P, torch.zeros((1, 2, 2, 2, 2), dtype=torch.int32).cuda(), mn, mx, -1.0, 1, True)
+
+
+def test_empty_inputs(mc):
+    import torch
+    P = torch.zeros((0, 3), dtype=torch.float32).cuda()
+    Bi = torch.zeros((0, 1), dtype=torch.int32).cuda()
+    mn, mx = mc.compute_aabb(P, Bi, 2, True)
+    assert np.all(_unwrap(mn) == np.finfo(np.float32).max) and np.all(_unwrap(mx) == -np.finfo(np.float32).max)
