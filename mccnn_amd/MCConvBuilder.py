@@ -1,0 +1,257 @@
+"""PointHierarchy / ConvolutionBuilder -- the builder API of the reference's utils/MCConvBuilder.py
+on top of the HIP op surface (mccnn_amd.MCConvModule).
+
+Same constructor / create_convolution signatures, cache keys (MCConvBuilder.py:203-238) and variable
+names / shapes (MCConvBuilder.py:394-419). The reference builds a TF1 graph once; here the builder
+is called every forward pass (eager), so:
+  * the kernel-MLP variables live in the builder (`ConvolutionBuilder.parameters()`), are created on
+    first use of a `convName` and re-used afterwards (tf.get_variable semantics);
+  * `reset()` (MCConvBuilder.py:241) drops the per-forward caches (grids, neighbours, pdfs) -- call it
+    (or build a new PointHierarchy) at the start of each forward pass.
+"""
+import math
+
+import torch
+
+from .MCConvModule import (compute_aabb, sort_points_step1, sort_points_step2, sort_features, sort_features_back,
+                           compute_pdf, poisson_sampling, get_sampled_features, spatial_conv, get_block_size,
+                           transform_indexs, find_neighbors)
+
+_VERBOSE = False
+
+
+def _log(msg):
+    if _VERBOSE:
+        print(msg)
+
+
+class PointHierarchy:
+    """Point hierarchy built by successive Poisson-disk sampling (MCConvBuilder.py:24-131).
+
+    Attributes (same names as the reference): points_, features_, batchIds_, sampledIndexs_,
+    radiusList_, batchSize_, relativeRadius_, hierarchyName_, aabbMin_, aabbMax_.
+    """
+
+    def __init__(self, inPoints, inFeatures, inBatchIds, radiusList, hierarchyName="Point_Hierarchy", batchSize=32,
+                 relativeRadius=True):
+        self.points_ = [inPoints]
+        self.features_ = [inFeatures]
+        self.batchIds_ = [inBatchIds]
+        self.sampledIndexs_ = []
+        self.radiusList_ = [0.0]
+        self.batchSize_ = batchSize
+        self.relativeRadius_ = relativeRadius
+        self.hierarchyName_ = hierarchyName
+
+        aabbMin, aabbMax = compute_aabb(inPoints, inBatchIds, batchSize, self.relativeRadius_)
+        self.aabbMin_ = aabbMin
+        self.aabbMax_ = aabbMax
+        _log("########## Point Hierarchy: %s (Rel: %s)" % (hierarchyName, relativeRadius))
+
+        currPts, currFeatures, currBatchIds = inPoints, inFeatures, inBatchIds
+        for level, currRadius in enumerate(radiusList):
+            _log("Level: %d | Poisson Disk Radius: %s" % (level + 1, currRadius))
+            keys, indexs = sort_points_step1(currPts, currBatchIds, self.aabbMin_, self.aabbMax_, self.batchSize_,
+                                             currRadius, self.relativeRadius_)
+            sortPts, sortBatchs, sortFeatures, cellIndexs = sort_points_step2(
+                currPts, currBatchIds, currFeatures, keys, indexs, self.aabbMin_, self.aabbMax_, self.batchSize_,
+                currRadius, self.relativeRadius_)
+            sampledPts, sampledBatchsIds, sampledIndexs = poisson_sampling(
+                sortPts, sortBatchs, cellIndexs, aabbMin, aabbMax, currRadius, batchSize, self.relativeRadius_)
+            sampledFeatures = get_sampled_features(sampledIndexs, sortFeatures)
+            transformedIndexs = transform_indexs(sampledIndexs, indexs)
+
+            self.points_.append(sampledPts)
+            self.batchIds_.append(sampledBatchsIds)
+            self.features_.append(sampledFeatures)
+            self.sampledIndexs_.append(transformedIndexs)
+            self.radiusList_.append(currRadius)
+            currPts, currBatchIds, currFeatures = sampledPts, sampledBatchsIds, sampledFeatures
+
+
+def _fan_avg_uniform_(t, fan_in, fan_out):
+    """tf.contrib.layers.variance_scaling_initializer(factor=1.0, mode='FAN_AVG', uniform=True)
+    (MCConvBuilder.py:394): U(-l, l), l = sqrt(3 * factor / ((fan_in + fan_out) / 2))."""
+    limit = math.sqrt(3.0 / ((fan_in + fan_out) / 2.0))
+    with torch.no_grad():
+        t.uniform_(-limit, limit)
+    return t
+
+
+class ConvolutionBuilder:
+    """Creates MC convolutions on point hierarchies, caching grids / neighbours / pdfs
+    (MCConvBuilder.py:133-427)."""
+
+    def __init__(self, multiFeatureConvs=False, KDEWindow=0.25, relativeRadius=True, usePDF=True, useAVG=True,
+                 decayLossCollection='weight_decay_loss', device=None):
+        self.cacheGrids_ = {}
+        self.cacheNeighs_ = {}
+        self.cachePDFs_ = {}
+        self.multiFeatureConvs_ = multiFeatureConvs
+        self.KDEWindow_ = KDEWindow
+        self.relativeRadius_ = relativeRadius
+        self.usePDF_ = usePDF
+        self.useAVG_ = useAVG
+        self.decayLossCollection_ = decayLossCollection
+        self.device_ = device
+        self.variables_ = {}        # name -> torch.nn.Parameter (tf.get_variable store)
+        self.collections_ = {}      # collection name -> list of parameters (tf.add_to_collection)
+        self.opTrace_ = None        # optional list the builder appends (op, key) records to (tests)
+
+    # ------------------------------------------------------------------ variable store
+    def parameters(self):
+        return list(self.variables_.values())
+
+    def named_parameters(self):
+        return list(self.variables_.items())
+
+    def get_collection(self, name):
+        return list(self.collections_.get(name, []))
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.variables_.items()}
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            if k in self.variables_:
+                with torch.no_grad():
+                    self.variables_[k].copy_(v)
+            else:
+                self.variables_[k] = torch.nn.Parameter(v.detach().clone())
+
+    def _get_variable(self, name, shape, device, init):
+        p = self.variables_.get(name)
+        if p is None:
+            p = torch.nn.Parameter(init(torch.empty(shape, dtype=torch.float32, device=device)))
+            self.variables_[name] = p
+        elif tuple(p.shape) != tuple(shape):
+            raise RuntimeError("variable %s exists with shape %s, requested %s" % (name, tuple(p.shape), shape))
+        return p
+
+    def _add_to_collection(self, name, p):
+        lst = self.collections_.setdefault(name, [])
+        if not any(q is p for q in lst):
+            lst.append(p)
+
+    # ------------------------------------------------------------------ caches
+    def __compute_dic_keys__(self, inPointHierarchy, outPointHierarchy, inPointLevel, outPointLevel, convRadius,
+                             KDEWindow, relativeRadius, usePDF):
+        # MCConvBuilder.py:203-238
+        keyGrid = inPointHierarchy.hierarchyName_ + '|' + str(inPointLevel) + '|' + str(convRadius) + '|' + \
+            str(relativeRadius)
+        keyNeighs = keyGrid + '|' + outPointHierarchy.hierarchyName_ + '|' + str(outPointLevel)
+        keyPDF = keyNeighs + '|' + str(KDEWindow) + '|' + str(usePDF)
+        return keyGrid, keyNeighs, keyPDF
+
+    def reset(self):
+        """Drop the operation caches (MCConvBuilder.py:241-246). Variables are kept."""
+        self.cacheGrids_ = {}
+        self.cacheNeighs_ = {}
+        self.cachePDFs_ = {}
+
+    def _trace(self, *rec):
+        if self.opTrace_ is not None:
+            self.opTrace_.append(rec)
+
+    # ------------------------------------------------------------------ create_convolution
+    def create_convolution(self, convName, inPointHierarchy, inPointLevel, inFeatures, inNumFeatures, convRadius,
+                           outPointHierarchy=None, outPointLevel=None, multiFeatureConv=None, outNumFeatures=None,
+                           KDEWindow=None, relativeRadius=None, usePDF=None, useAVG=None):
+        # defaults: MCConvBuilder.py:299-325
+        currMultiFeatureConv = self.multiFeatureConvs_ if multiFeatureConv is None else multiFeatureConv
+        currNumOutFeatures = inNumFeatures if outNumFeatures is None else outNumFeatures
+        currKDEWindow = self.KDEWindow_ if KDEWindow is None else KDEWindow
+        currRelativeRadius = self.relativeRadius_ if relativeRadius is None else relativeRadius
+        currUsePDF = self.usePDF_ if usePDF is None else usePDF
+        currUseAVG = self.useAVG_ if useAVG is None else useAVG
+        currOutPointHierarchy = inPointHierarchy if outPointHierarchy is None else outPointHierarchy
+        currOutPointLevel = inPointLevel if outPointLevel is None else outPointLevel
+
+        if currOutPointHierarchy.batchSize_ != inPointHierarchy.batchSize_:
+            raise RuntimeError('Different batch size in the input and output point hierarchy')
+        if (currMultiFeatureConv == False) and (currNumOutFeatures != inNumFeatures):
+            raise RuntimeError('The number of input and output features should be the same '
+                               'for multi feature convolutions.')
+
+        keyGrid, keyNeighs, keyPDF = self.__compute_dic_keys__(
+            inPointHierarchy, currOutPointHierarchy, inPointLevel, currOutPointLevel, convRadius, currKDEWindow,
+            currRelativeRadius, currUsePDF)
+        _log("Convolution: %s (KDE: %s | MF: %s | Rel: %s | PDF: %s)" % (convName, currKDEWindow,
+                                                                       currMultiFeatureConv, currRelativeRadius,
+                                                                       currUsePDF))
+
+        # grid (MCConvBuilder.py:349-363)
+        if keyGrid in self.cacheGrids_:
+            currGridTuple = self.cacheGrids_[keyGrid]
+            sortFeatures = sort_features(inFeatures, currGridTuple[3])
+            self._trace("sort_features", keyGrid)
+        else:
+            keys, indexs = sort_points_step1(
+                inPointHierarchy.points_[inPointLevel], inPointHierarchy.batchIds_[inPointLevel],
+                inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, inPointHierarchy.batchSize_, convRadius,
+                currRelativeRadius)
+            sortPts, sortBatchs, sortFeatures, cellIndexs = sort_points_step2(
+                inPointHierarchy.points_[inPointLevel], inPointHierarchy.batchIds_[inPointLevel], inFeatures, keys,
+                indexs, inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, inPointHierarchy.batchSize_,
+                convRadius, currRelativeRadius)
+            currGridTuple = (sortPts, sortBatchs, cellIndexs, indexs)
+            self.cacheGrids_[keyGrid] = currGridTuple
+            self._trace("sort_points_step1", keyGrid)
+            self._trace("sort_points_step2", keyGrid)
+
+        # neighbours (MCConvBuilder.py:366-376)
+        if keyNeighs in self.cacheNeighs_:
+            currNeighTuple = self.cacheNeighs_[keyNeighs]
+        else:
+            startIndexs, packedNeighs = find_neighbors(
+                currOutPointHierarchy.points_[currOutPointLevel], currOutPointHierarchy.batchIds_[currOutPointLevel],
+                currGridTuple[0], currGridTuple[2], inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, convRadius,
+                inPointHierarchy.batchSize_, currRelativeRadius)
+            currNeighTuple = (startIndexs, packedNeighs)
+            self.cacheNeighs_[keyNeighs] = currNeighTuple
+            self._trace("find_neighbors", keyNeighs)
+
+        # pdf (MCConvBuilder.py:379-391)
+        if keyPDF in self.cachePDFs_:
+            currPDFs = self.cachePDFs_[keyPDF]
+        else:
+            if currUsePDF:
+                currPDFs = compute_pdf(currGridTuple[0], currGridTuple[1], inPointHierarchy.aabbMin_,
+                                       inPointHierarchy.aabbMax_, currNeighTuple[0], currNeighTuple[1], currKDEWindow,
+                                       convRadius, inPointHierarchy.batchSize_, currRelativeRadius)
+                self._trace("compute_pdf", keyPDF)
+            else:
+                currPDFs = torch.ones((currNeighTuple[1].shape[0], 1), dtype=torch.float32,
+                                      device=currNeighTuple[1].device)
+            self.cachePDFs_[keyPDF] = currPDFs
+
+        # variables (MCConvBuilder.py:394-419)
+        blockSize = get_block_size()
+        numOutNeurons = inNumFeatures * currNumOutFeatures if currMultiFeatureConv else inNumFeatures
+        numBlocks = int(numOutNeurons / blockSize)
+        if numOutNeurons % blockSize != 0:
+            numBlocks = numBlocks + 1
+        dev = self.device_ or inFeatures.device
+        zeros = lambda t: t.zero_()
+        nn = blockSize * numBlocks
+        weights = self._get_variable(convName + '_weights', (3, nn), dev, lambda t: _fan_avg_uniform_(t, 3, nn))
+        self._add_to_collection(self.decayLossCollection_, weights)
+        biases = self._get_variable(convName + '_biases', (nn,), dev, zeros)
+        # TF fans for a rank-3 variable [numBlocks, bs, bs]: receptive field = numBlocks, fan_in = fan_out = bs*numBlocks
+        weights2v = self._get_variable(convName + '_weights2', (numBlocks, blockSize, blockSize), dev,
+                                       lambda t: _fan_avg_uniform_(t, numBlocks * blockSize, numBlocks * blockSize))
+        weights2 = weights2v.reshape(blockSize, numBlocks * blockSize)
+        self._add_to_collection(self.decayLossCollection_, weights2v)
+        biases2 = self._get_variable(convName + '_biases2', (numBlocks, blockSize), dev, zeros).reshape(nn)
+        weights3v = self._get_variable(convName + '_weights3', (numBlocks, blockSize, blockSize), dev,
+                                       lambda t: _fan_avg_uniform_(t, numBlocks * blockSize, numBlocks * blockSize))
+        weights3 = weights3v.reshape(blockSize, numBlocks * blockSize)
+        self._add_to_collection(self.decayLossCollection_, weights3v)
+        biases3 = self._get_variable(convName + '_biases3', (numBlocks, blockSize), dev, zeros).reshape(nn)
+
+        self._trace("spatial_conv", convName, (3, nn), currNumOutFeatures, bool(currMultiFeatureConv))
+        return spatial_conv(currGridTuple[0], sortFeatures, currGridTuple[1], currPDFs,
+                            currOutPointHierarchy.points_[currOutPointLevel], currNeighTuple[0], currNeighTuple[1],
+                            inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, weights, weights2, weights3, biases,
+                            biases2, biases3, currNumOutFeatures, currMultiFeatureConv, inPointHierarchy.batchSize_,
+                            convRadius, currRelativeRadius, currUseAVG)

@@ -1,0 +1,87 @@
+"""Per-cloud data parallelism for the MC-convolution layer.
+
+Independent units are whole clouds (batch ids): every op keys on the batch id and there is no
+halo between clouds, so a batch shards cloud-per-rank with NO data-path collective. The only
+exchanges are
+  * one bucketed all-reduce(SUM) of the flattened kernel-MLP weight gradients per step
+    (176*nb floats per conv layer -- latency-bound on xGMI, so ONE flat bucket, not per tensor);
+  * when relativeRadius=False the reference uses ONE bounding box for the whole batch
+    (aabb_gpu.cu:104-114); to stay bit-identical to a single-device batch the shards all-reduce
+    (MIN, MAX) their 2x3 box floats before sorting.
+One process per GPU, torch.distributed backend "nccl" (= RCCL on ROCm); "gloo" on CPU tensors in tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def cloud_partition(batchSize, world_size):
+    """Contiguous, balanced assignment of cloud ids to ranks: list of (first, last+1)."""
+    base, rem = divmod(batchSize, world_size)
+    out, first = [], 0
+    for r in range(world_size):
+        cnt = base + (1 if r < rem else 0)
+        out.append((first, first + cnt))
+        first += cnt
+    return out
+
+
+def shard_clouds(points, batchIds, features, batchSize, rank, world_size):
+    """Keep the clouds owned by `rank`; batch ids are re-based to 0..B_local-1.
+    Returns (points, batchIds, features, localBatchSize, (firstCloud, lastCloud+1))."""
+    first, last = cloud_partition(batchSize, world_size)[rank]
+    ids = batchIds.reshape(-1)
+    mask = (ids >= first) & (ids < last)
+    lp = points[mask]
+    lb = (batchIds[mask] - first).to(batchIds.dtype)
+    lf = features[mask]
+    return lp, lb, lf, last - first, (first, last)
+
+
+def allreduce_aabb(aabbMin, aabbMax, group=None):
+    """Whole-batch box across shards (needed only for relativeRadius=False). In place."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return aabbMin, aabbMax
+    dist.all_reduce(aabbMin, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(aabbMax, op=dist.ReduceOp.MAX, group=group)
+    return aabbMin, aabbMax
+
+
+class GradBucket:
+    """One flat buffer for all kernel-MLP gradients -> a single all-reduce per step."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = None
+
+    def allreduce(self, group=None, average=False):
+        if not self.params:
+            return
+        p0 = self.params[0]
+        if self.flat is None or self.flat.device != p0.device:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                self.flat.div_(dist.get_world_size(group))
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            g = self.flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+
+
+def allreduce_mlp_grads(params, group=None, average=False):
+    GradBucket(list(params)).allreduce(group, average)
