@@ -19,6 +19,8 @@ FLAGS = [
     # bit-exact geometry: no FMA contraction, correctly rounded f32 divide / sqrt (see csrc/common.h)
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall", "-Wno-unused-function",
+    # MFMA results straight into VGPRs (no v_accvgpr_read per value): gfx950 has a unified register file
+    "-mllvm", "-amdgpu-mfma-vgpr-form=1",
 ]
 
 

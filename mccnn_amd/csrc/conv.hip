@@ -12,6 +12,7 @@
 // centre's edges is a segmented wave scan, and every output row is written exactly once from
 // an LDS tile: no atomics, no pre-zeroing, bit-reproducible.
 #include "common.h"
+#include <cstdlib>
 
 namespace mccnn {
 
@@ -27,11 +28,16 @@ struct ConvArgs {
     const float* mx;
     const float *w1, *b1, *w2, *b2, *w3, *b3;
     int n, m, e, Fin, Fout, nb, neuronsOut, outF;
-    float radius;
+    float radius, invRadius;
     int scaleInv, avg, G;
 };
 
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.0f); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
 
 struct EdgeCtx {
     int j, i;
@@ -170,18 +176,443 @@ __global__ __launch_bounds__(256) void conv_fwd_valu(ConvArgs a, float* __restri
 }
 
 // ---------------------------------------------------------------------------------------
+// MFMA kernels (nb <= MCCNN_LDS_MAX_NB).
+//
+// v_mfma_f32_4x4x1_16b_f32 computes 16 independent 4x4 rank-1 updates per wave:
+//     D[lane 4b+j][reg r] += A(lane 4b+r) * B(lane 4b+j)          (layout probed on gfx950, profiles/)
+// With lane = edge and reg = neuron this is exactly one k-step of an 8x8 block of the kernel MLP
+// for 64 edges at once and with ZERO block-diagonal waste (a 16x16x4 tiling wastes half of every
+// MFMA on the off-diagonal zeros): A = the weight W[r][k] (same for every quad), B = the lane's
+// own activation h[k]. Two accumulators (neurons 0-3 / 4-7) x 8 k-steps = 16 MFMAs per layer, the
+// accumulator is initialised with the bias straight from LDS, numerics == the fmaf chain of v1.
+// The transposed products of the backward pass (t3 = W3^T (g f), t4 = W2^T t3) use the same form
+// with the transposed weight copies staged in LDS.
+// ---------------------------------------------------------------------------------------
+#define MCCNN_LDS_MAX_NB 64
+// floats per MLP block in LDS: W1[8][4] b1[8] W2[8][8] b2[8] W3[8][8] b3[8] (+ W2^T[8][8] W3^T[8][8] for bwd)
+#define MCCNN_WQ_FWD 184
+#define MCCNN_WQ_BWD 312
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_SHL(n) (0x100 + (n))
+
+// max(x, 0) as ONE instruction (v_med3_f32); fmaxf() costs an extra canonicalising v_max on MFMA results
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()); }
+
+// Stage the MLP tensors of all nb blocks into LDS in the per-block layout above.
+template <int WQ>
+__device__ __forceinline__ void stage_weights(const ConvArgs& a, float* wl) {
+    for (int t = threadIdx.x; t < a.nb * WQ; t += blockDim.x) {
+        int q = t / WQ, r = t - q * WQ;
+        float v;
+        if (r < 32) { int row = r >> 2, c = r & 3; v = (c < 3) ? a.w1[(q * 8 + row) * 3 + c] : 0.0f; }
+        else if (r < 40) v = a.b1[q * 8 + r - 32];
+        else if (r < 104) v = a.w2[q * 64 + r - 40];
+        else if (r < 112) v = a.b2[q * 8 + r - 104];
+        else if (r < 176) v = a.w3[q * 64 + r - 112];
+        else if (r < 184) v = a.b3[q * 8 + r - 176];
+        else if (r < 248) { int k = r - 184; v = a.w2[q * 64 + (k & 7) * 8 + (k >> 3)]; }   // W2^T[l][m] = W2[m][l]
+        else { int k = r - 248; v = a.w3[q * 64 + (k & 7) * 8 + (k >> 3)]; }                  // W3^T[m][n] = W3[n][m]
+        wl[t] = v;
+    }
+}
+
+// One 8x8 layer for 64 edges: acc(lo,hi) = bias; acc += W[row][k] * x[k], rows i4 / 4+i4 supplied by this lane.
+__device__ __forceinline__ void layer8(const f32x4* __restrict__ wrows /* 16 x f32x4: row r at [2r],[2r+1] */,
+                                       f32x4 lo, f32x4 hi, int i4, const float* x, float* y) {
+    f32x4 al0 = wrows[2 * i4], al1 = wrows[2 * i4 + 1];
+    f32x4 ah0 = wrows[2 * (4 + i4)], ah1 = wrows[2 * (4 + i4) + 1];
+    float al[8] = {al0.x, al0.y, al0.z, al0.w, al1.x, al1.y, al1.z, al1.w};
+    float ah[8] = {ah0.x, ah0.y, ah0.z, ah0.w, ah1.x, ah1.y, ah1.z, ah1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        lo = MFMA4(al[k], x[k], lo);
+        hi = MFMA4(ah[k], x[k], hi);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { y[r] = lo[r]; y[4 + r] = hi[r]; }
+}
+
+// Kernel MLP of block q (weights at wq in LDS) for the 64 edges of a wave.
+// a1 = relu(pre1), a2 = relu(pre2) are returned because backward needs them.
+__device__ __forceinline__ void mlp_block_mfma(const float* __restrict__ wq, int i4, float d0, float d1, float d2,
+                                               float* pre1, float* a1, float* pre2, float* a2, float* o) {
+    const f32x4* w = reinterpret_cast<const f32x4*>(wq);
+    f32x4 a1lo = w[i4], a1hi = w[4 + i4];
+    f32x4 lo = w[8], hi = w[9];  // b1
+    lo = MFMA4(a1lo.x, d0, lo);
+    hi = MFMA4(a1hi.x, d0, hi);
+    lo = MFMA4(a1lo.y, d1, lo);
+    hi = MFMA4(a1hi.y, d1, hi);
+    lo = MFMA4(a1lo.z, d2, lo);
+    hi = MFMA4(a1hi.z, d2, hi);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pre1[r] = lo[r]; pre1[4 + r] = hi[r]; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a1[r] = relu1(pre1[r]);
+    layer8(w + 10, w[26], w[27], i4, a1, pre2);  // W2, b2
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a2[r] = relu1(pre2[r]);
+    layer8(w + 28, w[44], w[45], i4, a2, o);     // W3, b3
+}
+
+// Per-wave view of G consecutive centres = one contiguous edge range; sL = LDS copy of start[c0..c1].
+struct WaveRange {
+    int c0, c1, eBeg, eEnd;
+};
+__device__ __forceinline__ WaveRange wave_range(const ConvArgs& a, int waveGlobal, int* sL, int lane) {
+    WaveRange r;
+    r.c0 = waveGlobal * a.G;
+    r.c1 = min(r.c0 + a.G, a.m);
+    r.eBeg = r.eEnd = 0;
+    if (r.c0 < a.m) {
+        for (int k = lane; k <= r.c1 - r.c0; k += 64) sL[k] = (r.c0 + k < a.m) ? a.start[r.c0 + k] : a.e;
+        r.eBeg = a.start[r.c0];
+        r.eEnd = (r.c1 < a.m) ? a.start[r.c1] : a.e;
+    }
+    return r;
+}
+
+struct Edge {
+    int j, il;  // neighbour (sorted list) index, centre index relative to the wave's c0
+    float d0, d1, d2, inv;
+};
+// delta = (p_j - c_i) / R_b is evaluated as (p_j - c_i) * (1/R_b) and 1/(pdf K) with v_rcp_f32: <= 2 ulp
+// from the reference's divisions (spatial_conv.cu:155-163), far inside the 1e-4 feature tolerance.
+__device__ __forceinline__ Edge load_edge2(const ConvArgs& a, const WaveRange& wr, const int* sL, int t, bool act) {
+    Edge e;
+    int2 pr = act ? a.packed[t] : make_int2(0, wr.c0);
+    float pdf = act ? a.pdfs[t] : 1.0f;
+    e.j = pr.x;
+    e.il = pr.y - wr.c0;
+    float invR = a.invRadius;
+    if (a.scaleInv) {
+        int b = a.bids[e.j];
+        invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, b));
+    }
+    const float* p = a.pts + (size_t)e.j * 3;
+    const float* c = a.samples + (size_t)pr.y * 3;
+    e.d0 = (p[0] - c[0]) * invR;
+    e.d1 = (p[1] - c[1]) * invR;
+    e.d2 = (p[2] - c[2]) * invR;
+    float K = a.avg ? (float)(sL[e.il + 1] - sL[e.il]) : 1.0f;
+    e.inv = act ? __builtin_amdgcn_rcpf(pdf * K) : 0.0f;
+    return e;
+}
+
+// Forward. The reduction over a centre's edges: DPP row_shr segmented scan inside each 16-lane row, then the
+// row-segment tails add into the wave's LDS output tile (ds_add_f32). Output rows are written exactly once.
+template <bool COMBIN, int FEAT>
+__global__ __launch_bounds__(256) void conv_fwd_mfma(ConvArgs a, float* __restrict__ out) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
+    const int G = a.G, outF = a.outF;
+    float* wl = lds;
+    float* tile = lds + a.nb * MCCNN_WQ_FWD + (size_t)wave * (G * outF + G + 4);
+    int* sL = reinterpret_cast<int*>(tile + G * outF);
+    stage_weights<MCCNN_WQ_FWD>(a, wl);
+    WaveRange wr = wave_range(a, blockIdx.x * 4 + wave, sL, lane);
+    if (wr.c0 < a.m)
+        for (int k = lane; k < G * outF; k += 64) tile[k] = 0.0f;
+    __syncthreads();
+    if (wr.c0 >= a.m) return;
+
+    for (int base = wr.eBeg; base < wr.eEnd; base += 64) {
+        const int t = base + lane;
+        const bool act = t < wr.eEnd;
+        Edge ec = load_edge2(a, wr, sL, t, act);
+        const int key1 = act ? (ec.il + 1) : 0;  // 0 = no edge
+        // same-centre masks for the in-row segmented scan (row = 16 lanes)
+        const float m1 = (key1 != 0 && dpp_i<DPP_ROW_SHR(1)>(key1) == key1) ? 1.f : 0.f;
+        const float m2 = (key1 != 0 && dpp_i<DPP_ROW_SHR(2)>(key1) == key1) ? 1.f : 0.f;
+        const float m4 = (key1 != 0 && dpp_i<DPP_ROW_SHR(4)>(key1) == key1) ? 1.f : 0.f;
+        const float m8 = (key1 != 0 && dpp_i<DPP_ROW_SHR(8)>(key1) == key1) ? 1.f : 0.f;
+        const bool tail = act && (dpp_i<DPP_ROW_SHL(1)>(key1) != key1);  // last lane of a row reads 0 -> tail
+        float* row = tile + (size_t)ec.il * outF;
+        float f1 = 0.f;
+        if (FEAT == 1) f1 = act ? a.feats[ec.j] * ec.inv : 0.f;
+
+        for (int q = 0; q < a.nb; ++q) {
+            float pre1[8], a1[8], pre2[8], a2[8], o[8], c[8];
+            mlp_block_mfma(wl + q * MCCNN_WQ_FWD, i4, ec.d0, ec.d1, ec.d2, pre1, a1, pre2, a2, o);
+            const bool full = (q * 8 + 8 <= a.neuronsOut);
+            if (FEAT == 2) {
+                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)ec.j * a.Fin + q * 8);
+                float4 fa = fp[0], fb = fp[1];
+                float f[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+#pragma unroll
+                for (int n = 0; n < 8; ++n) c[n] = (f[n] * ec.inv) * o[n];
+            } else if (FEAT == 1) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) c[n] = f1 * o[n];
+            } else {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    int nu = q * 8 + n;
+                    int fin = nu % a.Fin;
+                    c[n] = (nu < a.neuronsOut) ? a.feats[(size_t)ec.j * a.Fin + fin] * o[n] * ec.inv : 0.f;
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                float v = c[n];
+                v = fmaf(m1, dpp_f<DPP_ROW_SHR(1)>(v), v);
+                v = fmaf(m2, dpp_f<DPP_ROW_SHR(2)>(v), v);
+                v = fmaf(m4, dpp_f<DPP_ROW_SHR(4)>(v), v);
+                v = fmaf(m8, dpp_f<DPP_ROW_SHR(8)>(v), v);
+                c[n] = v;
+            }
+            if (tail) {
+                if (!COMBIN || a.Fin == 1) {
+                    float* dst = row + q * 8;
+                    if (full) {
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) atomicAdd(&dst[n], c[n]);  // ds_add_f32, wave-private tile
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < 8; ++n)
+                            if (q * 8 + n < a.neuronsOut) atomicAdd(&dst[n], c[n]);
+                    }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) {
+                        int nu = q * 8 + n;
+                        if (nu < a.neuronsOut) atomicAdd(&row[nu / a.Fin], c[n]);
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int cnt = (wr.c1 - wr.c0) * outF;
+    float* dst = out + (size_t)wr.c0 * outF;
+    for (int k = lane; k < cnt; k += 64) dst[k] = tile[k];
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward, MFMA version. q-outer: for one MLP block the wave sweeps all its edges keeping the block's
+// 176 weight-gradient partial sums in VGPRs (VALU FMAs run beside the MFMA chains), reduces them across the
+// wave once per (wave, q) and stores them to a per-wave partial row; reduce_partials sums the rows in a fixed
+// order (deterministic, no float atomics on the parameters). Feature gradients: for combin layers with
+// Fin <= 4 they are accumulated per edge in LDS across all blocks and flushed with ONE atomic per (edge, fin);
+// otherwise one atomic per (edge, neuron).
+// ---------------------------------------------------------------------------------------
+#define MCCNN_DF_CAP 2048  // floats of per-wave LDS for the per-edge feature-gradient accumulators
+
+template <bool COMBIN, int FEAT>
+__global__ __launch_bounds__(256, 2) void conv_bwd_mfma(ConvArgs a, const float* __restrict__ outGrad,
+                                                        float* __restrict__ featGrad, float* __restrict__ partials) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
+    const int G = a.G, outF = a.outF;
+    float* wl = lds;
+    float* mine = lds + a.nb * MCCNN_WQ_BWD + (size_t)wave * (MCCNN_DF_CAP + 192 + G + 4);
+    float* dfL = mine;                  // [edge_local][Fin] feature-gradient accumulators (FEAT 0/1 with Fin <= 4)
+    float* red = mine + MCCNN_DF_CAP;   // 176 reduced sums of one block
+    int* sL = reinterpret_cast<int*>(red + 192);
+    stage_weights<MCCNN_WQ_BWD>(a, wl);
+    const int waveGlobal = blockIdx.x * 4 + wave;
+    WaveRange wr = wave_range(a, waveGlobal, sL, lane);
+    const bool useDfL = COMBIN && a.Fin <= 4;
+    const int dfCapEdges = MCCNN_DF_CAP / a.Fin;
+    if (useDfL)
+        for (int k = lane; k < MCCNN_DF_CAP; k += 64) dfL[k] = 0.0f;
+    __syncthreads();
+    float* prow = partials + (size_t)waveGlobal * a.nb * 176;
+
+    for (int q = 0; q < a.nb; ++q) {
+        float gw3[64], gb3[8], gw2[64], gb2[8], gw1[24], gb1[8];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) { gw3[k] = 0.f; gw2[k] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { gb3[k] = 0.f; gb2[k] = 0.f; gb1[k] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 24; ++k) gw1[k] = 0.f;
+        const float* wq = wl + q * MCCNN_WQ_BWD;
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(wq);
+        const int numOuts = min(a.neuronsOut - q * 8, 8);
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+        for (int base = wr.eBeg; base < wr.eEnd; base += 64) {
+            const int t = base + lane;
+            const bool act = t < wr.eEnd;
+            Edge ec = load_edge2(a, wr, sL, t, act);
+            float a1[8], a2[8], o[8];
+            bool p1[8], p2[8];  // pre-activation >= 0 (ReLU' of the reference: spatial_conv.cu:404,429), kept as lane masks
+            {
+                float pre1[8], pre2[8];
+                mlp_block_mfma(wq, i4, ec.d0, ec.d1, ec.d2, pre1, a1, pre2, a2, o);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { p1[k] = pre1[k] >= 0.0f; p2[k] = pre2[k] >= 0.0f; }
+            }
+            // g_n * f_n and the feature gradient
+            float gf[8];
+            {
+                float g[8];
+                const float* grow = outGrad + (size_t)(wr.c0 + ec.il) * outF;
+                if (FEAT == 2) {
+                    const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
+                    const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)ec.j * a.Fin + q * 8);
+                    float4 ga = gp[0], gb = gp[1], fa = fp[0], fb = fp[1];
+                    float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+                    float ff[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; gf[n] = g[n] * ff[n]; }
+                } else if (FEAT == 1) {
+                    float f = a.feats[ec.j];
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) {
+                        g[n] = (act && n < numOuts) ? grow[q * 8 + n] : 0.f;
+                        gf[n] = g[n] * f;
+                    }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) {
+                        int nu = q * 8 + n;
+                        int fin = COMBIN ? nu % a.Fin : nu;
+                        int fo = COMBIN ? nu / a.Fin : nu;
+                        bool ok = act && n < numOuts;
+                        g[n] = ok ? grow[fo] : 0.f;
+                        gf[n] = ok ? g[n] * a.feats[(size_t)ec.j * a.Fin + fin] : 0.f;
+                    }
+                }
+                // feature gradient: og * o / (pdf K)   (spatial_conv.cu:400)
+                if (FEAT == 1) {
+                    float sfg = 0.f;
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) sfg = fmaf(g[n], o[n], sfg);
+                    sfg *= ec.inv;
+                    if (act) {
+                        int el = t - wr.eBeg;
+                        if (el < dfCapEdges) dfL[el] += sfg;  // this lane is the only writer of edge el
+                        else atomicAdd(&featGrad[ec.j], sfg);
+                    }
+                } else if (FEAT == 2) {
+                    if (act) {
+                        float* fgp = featGrad + (size_t)ec.j * a.Fin + q * 8;
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) atomicAdd(&fgp[n], g[n] * o[n] * ec.inv);
+                    }
+                } else if (act) {
+                    int el = t - wr.eBeg;
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) {
+                        int nu = q * 8 + n;
+                        if (n < numOuts) {
+                            int fin = COMBIN ? nu % a.Fin : nu;
+                            float v = g[n] * o[n] * ec.inv;
+                            if (useDfL && el < dfCapEdges) dfL[el * a.Fin + fin] += v;
+                            else atomicAdd(&featGrad[(size_t)ec.j * a.Fin + fin], v);
+                        }
+                    }
+                }
+            }
+            // dW3 += u a2^T, db3 += u, u = g f / (pdf K)          (spatial_conv.cu:383-399)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                float u = gf[n] * ec.inv;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) gw3[n * 8 + k] = fmaf(u, a2[k], gw3[n * 8 + k]);
+                gb3[n] += u;
+            }
+            // t3 = 1[pre2 >= 0] * W3^T (g f) / (pdf K)             (:403-414)
+            float t3[8];
+            layer8(w4 + 62, zero4, zero4, i4, gf, t3);  // W3^T rows at float 248 -> f32x4 index 62
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t3[k] = p2[k] ? t3[k] * ec.inv : 0.f;
+            // dW2 += t3 a1^T, db2 += t3                            (:419-425)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int l = 0; l < 8; ++l) gw2[k * 8 + l] = fmaf(t3[k], a1[l], gw2[k * 8 + l]);
+                gb2[k] += t3[k];
+            }
+            // t4 = 1[pre1 >= 0] * W2^T t3                          (:428-434)
+            float t4[8];
+            layer8(w4 + 46, zero4, zero4, i4, t3, t4);  // W2^T rows at float 184 -> f32x4 index 46
+            // dW1 += t4 delta^T, db1 += t4                         (:439-444)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                float v = p1[l] ? t4[l] : 0.f;
+                gw1[l * 3] = fmaf(v, ec.d0, gw1[l * 3]);
+                gw1[l * 3 + 1] = fmaf(v, ec.d1, gw1[l * 3 + 1]);
+                gw1[l * 3 + 2] = fmaf(v, ec.d2, gw1[l * 3 + 2]);
+                gb1[l] += v;
+            }
+        }
+        // wave reduction -> LDS (layout: w1[24] b1[8] w2[64] b2[8] w3[64] b3[8]) -> this wave's partial row
+#pragma unroll
+        for (int k = 0; k < 24; ++k) { float v = wave_sum(gw1[k]); if (lane == 0) red[k] = v; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { float v = wave_sum(gb1[k]); if (lane == 0) red[24 + k] = v; }
+#pragma unroll
+        for (int k = 0; k < 64; ++k) { float v = wave_sum(gw2[k]); if (lane == 0) red[32 + k] = v; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { float v = wave_sum(gb2[k]); if (lane == 0) red[96 + k] = v; }
+#pragma unroll
+        for (int k = 0; k < 64; ++k) { float v = wave_sum(gw3[k]); if (lane == 0) red[104 + k] = v; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { float v = wave_sum(gb3[k]); if (lane == 0) red[168 + k] = v; }
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < 176; k += 64) prow[q * 176 + k] = red[k];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (useDfL) {
+        __builtin_amdgcn_wave_barrier();
+        int nE = min(wr.eEnd - wr.eBeg, dfCapEdges);
+        for (int el = lane; el < nE; el += 64) {
+            int j = a.packed[wr.eBeg + el].x;
+            for (int f = 0; f < a.Fin; ++f) atomicAdd(&featGrad[(size_t)j * a.Fin + f], dfL[el * a.Fin + f]);
+        }
+    }
+}
+
+// Sums the per-wave partial rows in a fixed order and scatters them to the six gradient tensors.
+__global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ partials, int numWaves, int nb,
+                                                       float* __restrict__ dw1, float* __restrict__ db1,
+                                                       float* __restrict__ dw2, float* __restrict__ db2,
+                                                       float* __restrict__ dw3, float* __restrict__ db3) {
+    __shared__ float acc[16][17];
+    const int K = nb * 176;
+    const int kk = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + kk;
+    float s = 0.f;
+    if (k < K)
+        for (int w = sl; w < numWaves; w += 16) s += partials[(size_t)w * K + k];
+    acc[sl][kk] = s;
+    __syncthreads();
+    if (sl == 0 && k < K) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += acc[i][kk];
+        int q = k / 176, r = k - q * 176;
+        if (r < 24) dw1[q * 24 + r] = v;
+        else if (r < 32) db1[q * 8 + r - 24] = v;
+        else if (r < 96) dw2[q * 64 + r - 32] = v;
+        else if (r < 104) db2[q * 8 + r - 96] = v;
+        else if (r < 168) dw3[q * 64 + r - 104] = v;
+        else db3[q * 8 + r - 168] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Backward (spatial_conv.cu:327-445 / :563-680). A wave owns GB consecutive centres; for each
 // block q it sweeps its edges keeping the 176 weight-gradient partial sums of that block in
 // registers, reduces them across the wave once per (wave, q), combines the 4 waves of the
 // workgroup in LDS and issues one global atomic per (workgroup, parameter). Feature gradients
 // are scattered with float atomics (rows of different centres share j).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-
 template <bool COMBIN>
 __global__ __launch_bounds__(256) void conv_bwd_valu(ConvArgs a, const float* __restrict__ outGrad,
                                                      float* __restrict__ featGrad, float* __restrict__ dw1,
@@ -311,7 +742,7 @@ static int fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_f
     a.pts = sorted_pts; a.feats = sorted_feats; a.bids = sorted_batch_ids; a.pdfs = pdfs; a.samples = samples;
     a.start = start_idx; a.packed = reinterpret_cast<const int2*>(packed); a.mn = aabb_min; a.mx = aabb_max;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3;
-    a.n = n; a.m = m; a.e = e; a.Fin = Fin; a.Fout = Fout; a.radius = radius; a.scaleInv = scale_inv; a.avg = avg;
+    a.n = n; a.m = m; a.e = e; a.Fin = Fin; a.Fout = Fout; a.radius = radius; a.invRadius = 1.0f / radius; a.scaleInv = scale_inv; a.avg = avg;
     if (m > 0 && (!samples || !start_idx || !aabb_min || !aabb_max || !w1 || !b1 || !w2 || !b2 || !w3 || !b3))
         return MCCNN_E_BADARG;
     if (e > 0 && (!sorted_pts || !sorted_feats || !sorted_batch_ids || !pdfs || !packed)) return MCCNN_E_BADARG;
@@ -325,6 +756,8 @@ using namespace mccnn;
 extern "C" {
 
 size_t mccnn_spatial_conv_fwd_workspace_bytes(int, int, int, int, int) { return 0; }
+
+static bool use_mfma(const ConvArgs& a) { return a.nb <= MCCNN_LDS_MAX_NB && !getenv("MCCNN_FORCE_VALU"); }
 
 int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
                            const float* pdfs, const float* samples, const int* start_idx, const int* packed,
@@ -341,6 +774,27 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     if (m == 0) return 0;
     if (!out) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
+    bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats) & 15) == 0);
+    if (use_mfma(a)) {
+        // G centres per wave: LDS tile of G*outF floats per wave, <= 4 KB
+        int G = 1024 / a.outF;
+        if (G > 16) G = 16;
+        if (G < 1) G = 1;
+        a.G = G;
+        size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * ((size_t)G * a.outF + G + 4)) * sizeof(float);
+        if (lds <= 64 * 1024) {
+            int blocks = ceil_div(m, 4 * G);
+            if (combin) {
+                if (a.Fin == 1) conv_fwd_mfma<true, 1><<<blocks, 256, lds, s>>>(a, out);
+                else conv_fwd_mfma<true, 0><<<blocks, 256, lds, s>>>(a, out);
+            } else {
+                if (vec) conv_fwd_mfma<false, 2><<<blocks, 256, lds, s>>>(a, out);
+                else conv_fwd_mfma<false, 0><<<blocks, 256, lds, s>>>(a, out);
+            }
+            MCCNN_LAUNCHED();
+            return 0;
+        }
+    }
     int G = 2048 / a.outF;
     if (G > 32) G = 32;
     if (G < 1) G = 1;
@@ -348,7 +802,6 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     size_t lds = (size_t)4 * G * a.outF * sizeof(float);
     if (lds > 64 * 1024) return MCCNN_E_TOOLARGE;
     int blocks = ceil_div(m, 4 * G);
-    bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats) & 15) == 0);
     if (combin) {
         if (a.Fin == 1) conv_fwd_valu<true, 1><<<blocks, 256, lds, s>>>(a, out);
         else conv_fwd_valu<true, 0><<<blocks, 256, lds, s>>>(a, out);
@@ -360,7 +813,16 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     return 0;
 }
 
-size_t mccnn_spatial_conv_bwd_workspace_bytes(int, int, int, int, int, int) { return 0; }
+#define MCCNN_BWD_G 64  // centres per wave in the MFMA backward
+
+size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_feats, int num_out_feats, int combin) {
+    (void)n; (void)e;
+    if (m <= 0 || num_in_feats <= 0 || num_out_feats <= 0) return 256;
+    long long neurons = combin ? (long long)num_in_feats * num_out_feats : num_in_feats;
+    long long nb = (neurons + 7) / 8;
+    long long waves = (long long)ceil_div(m, 4 * MCCNN_BWD_G) * 4;
+    return align_up((size_t)(waves * nb * 176) * sizeof(float)) + 256;
+}
 
 int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
                            const float* pdfs, const float* samples, const int* start_idx, const int* packed,
@@ -369,7 +831,6 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
                            int n, int m, int e, int num_in_feats, int num_out_feats, int combin, int batch_size,
                            float radius, int scale_inv, int avg, float* feat_grad, float* dw1, float* db1, float* dw2,
                            float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
-    (void)ws; (void)ws_bytes;
     ConvArgs a;
     int rc = fill_args(a, sorted_pts, sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min,
                        aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_in_feats, num_out_feats, combin, batch_size,
@@ -379,14 +840,38 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
     hipStream_t s = (hipStream_t)stream;
     size_t nn = (size_t)a.nb * 8;
     if (n > 0) MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * sizeof(float), s));
-    MCCNN_HIP(hipMemsetAsync(dw1, 0, 3 * nn * sizeof(float), s));
-    MCCNN_HIP(hipMemsetAsync(db1, 0, nn * sizeof(float), s));
-    MCCNN_HIP(hipMemsetAsync(dw2, 0, 8 * nn * sizeof(float), s));
-    MCCNN_HIP(hipMemsetAsync(db2, 0, nn * sizeof(float), s));
-    MCCNN_HIP(hipMemsetAsync(dw3, 0, 8 * nn * sizeof(float), s));
-    MCCNN_HIP(hipMemsetAsync(db3, 0, nn * sizeof(float), s));
+    bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats | (uintptr_t)out_grad) & 15) == 0);
+    size_t lds = ((size_t)a.nb * MCCNN_WQ_BWD + 4 * ((size_t)MCCNN_DF_CAP + 192 + MCCNN_BWD_G + 4)) * sizeof(float);
+    bool mfma = use_mfma(a) && lds <= 64 * 1024 && m > 0 && e > 0;
+    if (!mfma || m == 0 || e == 0) {
+        MCCNN_HIP(hipMemsetAsync(dw1, 0, 3 * nn * sizeof(float), s));
+        MCCNN_HIP(hipMemsetAsync(db1, 0, nn * sizeof(float), s));
+        MCCNN_HIP(hipMemsetAsync(dw2, 0, 8 * nn * sizeof(float), s));
+        MCCNN_HIP(hipMemsetAsync(db2, 0, nn * sizeof(float), s));
+        MCCNN_HIP(hipMemsetAsync(dw3, 0, 8 * nn * sizeof(float), s));
+        MCCNN_HIP(hipMemsetAsync(db3, 0, nn * sizeof(float), s));
+    }
     if (m == 0 || e == 0) return 0;
     if (!out_grad) return MCCNN_E_BADARG;
+    if (mfma) {
+        if (!ws || ws_bytes < mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, num_in_feats, num_out_feats, combin))
+            return MCCNN_E_WORKSPACE;
+        a.G = MCCNN_BWD_G;
+        int blocks = ceil_div(m, 4 * a.G);
+        float* partials = (float*)ws;
+        if (combin) {
+            if (a.Fin == 1) conv_bwd_mfma<true, 1><<<blocks, 256, lds, s>>>(a, out_grad, feat_grad, partials);
+            else conv_bwd_mfma<true, 0><<<blocks, 256, lds, s>>>(a, out_grad, feat_grad, partials);
+        } else {
+            if (vec) conv_bwd_mfma<false, 2><<<blocks, 256, lds, s>>>(a, out_grad, feat_grad, partials);
+            else conv_bwd_mfma<false, 0><<<blocks, 256, lds, s>>>(a, out_grad, feat_grad, partials);
+        }
+        MCCNN_LAUNCHED();
+        reduce_partials<<<ceil_div((long long)a.nb * 176, 16), 256, 0, s>>>(partials, blocks * 4, a.nb, dw1, db1, dw2,
+                                                                            db2, dw3, db3);
+        MCCNN_LAUNCHED();
+        return 0;
+    }
     a.G = 32;
     int blocks = ceil_div(m, 4 * a.G);
     if (combin) conv_bwd_valu<true><<<blocks, 256, 0, s>>>(a, out_grad, feat_grad, dw1, db1, dw2, db2, dw3, db3);
