@@ -108,18 +108,25 @@ int mccnn_transform_indexs(const int* in_idx, int s, const int* new_idx, int n, 
  * count: start_idx[i] = exclusive prefix of the per-centre neighbour counts and
  * *total_dev (device int) = E.  The caller reads E, allocates packed[E,2] and
  * calls fill with the same arguments.  Row order: centre ascending; inside a
- * centre the 27-cell table order of find_neighbors.cu:282-291, then ascending j. */
+ * centre the 27-cell table order of find_neighbors.cu:282-291, then ascending j.
+ * centre_order (optional, may be NULL): a permutation of 0..m-1 giving the order in
+ * which threads visit the centres. It never changes the result; a spatially coherent
+ * order (e.g. the inverse of new_idx when the centres are the gridded points) makes
+ * neighbouring lanes walk the same cells, which is several times faster. */
 size_t mccnn_find_neighbors_workspace_bytes(int m);
 int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids, int m,
                                const float* sorted_pts, const int* cell_indexs,
                                const float* aabb_min, const float* aabb_max, int batch_size,
-                               int num_cells, float radius, int scale_inv, int* start_idx,
-                               int* total_dev, void* ws, size_t ws_bytes, mccnn_stream_t stream);
+                               int num_cells, float radius, int scale_inv, const int* centre_order,
+                               int* start_idx, int* total_dev, void* ws, size_t ws_bytes,
+                               mccnn_stream_t stream);
 int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m,
                               const float* sorted_pts, const int* cell_indexs,
                               const float* aabb_min, const float* aabb_max, int batch_size,
-                              int num_cells, float radius, int scale_inv, const int* start_idx,
-                              int e, int* packed, mccnn_stream_t stream);
+                              int num_cells, float radius, int scale_inv, const int* centre_order,
+                              const int* start_idx, int e, int* packed, mccnn_stream_t stream);
+/* inv[new_idx[i]] = i -- the visiting order above for same-level searches (sort_gpu.cu:332-345). */
+int mccnn_invert_permutation(const int* new_idx, int n, int* inv, mccnn_stream_t stream);
 
 /* ComputePDF -- compute_pdf.cc:25,57-142, compute_pdf.cu:40-119.
  * mode 0: the reference's arithmetic (double exp per axis, float rounding per

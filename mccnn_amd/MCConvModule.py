@@ -64,6 +64,39 @@ def get_block_size():
 
 
 # ---------------------------------------------------------------------------------------------
+# Visiting-order hints for find_neighbors. The op surface of the reference has no such argument, so the shim
+# remembers, per point tensor, a permutation that walks the points cell by cell: for the points a grid was built
+# from it is the inverse of index_new_pos, for Poisson samples the argsort of their indices in the sorted list.
+# A hint only changes the order in which GPU threads visit the centres (speed), never the result.
+_ORDER_HINTS = {}
+
+
+def _tensor_key(t):
+    return (t.data_ptr(), t._version, t.shape[0])
+
+
+def _remember_order(points, kind, payload):
+    if len(_ORDER_HINTS) > 64:
+        _ORDER_HINTS.clear()
+    _ORDER_HINTS[_tensor_key(points)] = [kind, payload, None]
+
+
+def _order_hint(points):
+    ent = _ORDER_HINTS.get(_tensor_key(points))
+    if ent is None:
+        return None
+    if ent[2] is None:
+        kind, payload = ent[0], ent[1]
+        if kind == "new_idx":
+            inv = torch.empty_like(payload)
+            check(_lib.load().mccnn_invert_permutation(ptr(payload), payload.shape[0], ptr(inv), stream_handle()),
+                  "invert_permutation")
+            ent[2] = inv
+        else:  # "sorted_pos": position of every point in some cell-sorted list
+            ent[2] = torch.argsort(payload).to(torch.int32)
+    return ent[2]
+
+
 _NUM_CELLS_CACHE = {}
 
 
@@ -172,6 +205,7 @@ class _SortPointsStep2(torch.autograd.Function):
                                    stream_handle()), "sort_points_step2")
         ctx.save_for_backward(indexs)
         ctx.mark_non_differentiable(oB, cells)
+        _remember_order(inPts, "new_idx", indexs)
         return oP, oB, oF, cells
 
     @staticmethod
@@ -265,8 +299,11 @@ def find_neighbors(inPts, inBatchIds, inPts2, cellIndexs, aabbMin, aabbMax, radi
     start = torch.empty((m, 1), dtype=torch.int32, device=c.device)
     total = torch.empty(1, dtype=torch.int32, device=c.device)
     ws = _ws(lib.mccnn_find_neighbors_workspace_bytes(m), c.device)
+    order = _order_hint(inPts)
+    if order is not None and order.shape[0] != m:
+        order = None
     args = (ptr(c), ptr(cb), m, ptr(p2), ptr(cells), ptr(mn), ptr(mx), batchSize, nc, float(radius),
-            int(bool(scaleInv)))
+            int(bool(scaleInv)), ptr(order))
     check(lib.mccnn_find_neighbors_count(*args, ptr(start), ptr(total), ptr(ws), ws.numel(), stream_handle()),
           "find_neighbors(count)")
     e = int(total.item())
@@ -331,6 +368,7 @@ def poisson_sampling(inPts, inBatchIds, cellIndexs, aabbMin, aabbMax, radius, ba
     oI = torch.empty(s, dtype=torch.int32, device=p.device)
     check(lib.mccnn_poisson_sampling_fill(ptr(p), n, ptr(cells), batchSize, nc, s, ptr(oP), ptr(oB), ptr(oI), ptr(ws),
                                           ws.numel(), stream_handle()), "poisson_sampling(fill)")
+    _remember_order(oP, "sorted_pos", oI)
     return oP, oB, oI
 
 

@@ -9,7 +9,7 @@ import os
 import torch  # must be imported first: libmccnn_hip.so binds to the HIP runtime torch already loaded
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmccnn_hip.so")
+LIB_PATH = os.path.join(_PKG, "lib", os.environ.get("MCCNN_LIB_NAME", "libmccnn_hip.so"))  # override only for A/B experiments
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -31,8 +31,9 @@ SIGNATURES = {
     "mccnn_transform_indexs_workspace_bytes": (_sz, [_i]),
     "mccnn_transform_indexs": (_i, [_vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "mccnn_find_neighbors_workspace_bytes": (_sz, [_i]),
-    "mccnn_find_neighbors_count": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _sz, _vp]),
-    "mccnn_find_neighbors_fill": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _i, _vp, _vp]),
+    "mccnn_find_neighbors_count": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_find_neighbors_fill": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp]),
+    "mccnn_invert_permutation": (_i, [_vp, _i, _vp, _vp]),
     "mccnn_compute_pdf": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _f, _f, _i, _i, _vp, _vp]),
     "mccnn_poisson_sampling_workspace_bytes": (_sz, [_i, _i, _i]),
     "mccnn_poisson_sampling_count": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),

@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
-LIB = os.path.join(LIB_DIR, "libmccnn_hip.so")
+LIB = os.path.join(LIB_DIR, os.environ.get("MCCNN_LIB_NAME", "libmccnn_hip.so"))  # override only for A/B experiments
 SOURCES = ["api_misc.hip", "scan.hip", "grid.hip", "neighbors.hip", "poisson.hip", "conv.hip"]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -51,8 +51,8 @@ def build(force=False, verbose=False):
     objs = []
     procs = []
     for src in sources():
-        obj = os.path.join(LIB_DIR, os.path.basename(src) + ".o")
-        cmd = [hipcc] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", src, "-o", obj]
+        obj = os.path.join(LIB_DIR, os.path.basename(LIB) + "." + os.path.basename(src) + ".o")
+        cmd = [hipcc] + FLAGS + os.environ.get("MCCNN_EXTRA_FLAGS", "").split() + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -290,10 +290,14 @@ struct Edge {
 };
 // delta = (p_j - c_i) / R_b is evaluated as (p_j - c_i) * (1/R_b) and 1/(pdf K) with v_rcp_f32: <= 2 ulp
 // from the reference's divisions (spatial_conv.cu:155-163), far inside the 1e-4 feature tolerance.
+__device__ __forceinline__ Edge make_edge(const ConvArgs& a, const WaveRange& wr, const int* sL, int2 pr, float pdf, bool act);
 __device__ __forceinline__ Edge load_edge2(const ConvArgs& a, const WaveRange& wr, const int* sL, int t, bool act) {
-    Edge e;
     int2 pr = act ? a.packed[t] : make_int2(0, wr.c0);
     float pdf = act ? a.pdfs[t] : 1.0f;
+    return make_edge(a, wr, sL, pr, pdf, act);
+}
+__device__ __forceinline__ Edge make_edge(const ConvArgs& a, const WaveRange& wr, const int* sL, int2 pr, float pdf, bool act) {
+    Edge e;
     e.j = pr.x;
     e.il = pr.y - wr.c0;
     float invR = a.invRadius;
@@ -328,10 +332,18 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(ConvArgs a, float* __restri
     __syncthreads();
     if (wr.c0 >= a.m) return;
 
+    int2 prN = make_int2(0, wr.c0);
+    float pdfN = 1.0f;
+    if (wr.eBeg + lane < wr.eEnd) { prN = a.packed[wr.eBeg + lane]; pdfN = a.pdfs[wr.eBeg + lane]; }
     for (int base = wr.eBeg; base < wr.eEnd; base += 64) {
         const int t = base + lane;
         const bool act = t < wr.eEnd;
-        Edge ec = load_edge2(a, wr, sL, t, act);
+        const int2 prC = act ? prN : make_int2(0, wr.c0);
+        const float pdfC = act ? pdfN : 1.0f;
+        Edge ec = make_edge(a, wr, sL, prC, pdfC, act);
+        float f1 = 0.f;
+        if (FEAT == 1) f1 = act ? a.feats[ec.j] * ec.inv : 0.f;
+        if (t + 64 < wr.eEnd) { prN = a.packed[t + 64]; pdfN = a.pdfs[t + 64]; }  // prefetch (after this chunk's gathers)
         const int key1 = act ? (ec.il + 1) : 0;  // 0 = no edge
         // same-centre masks for the in-row segmented scan (row = 16 lanes)
         const float m1 = (key1 != 0 && dpp_i<DPP_ROW_SHR(1)>(key1) == key1) ? 1.f : 0.f;
@@ -340,8 +352,6 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(ConvArgs a, float* __restri
         const float m8 = (key1 != 0 && dpp_i<DPP_ROW_SHR(8)>(key1) == key1) ? 1.f : 0.f;
         const bool tail = act && (dpp_i<DPP_ROW_SHL(1)>(key1) != key1);  // last lane of a row reads 0 -> tail
         float* row = tile + (size_t)ec.il * outF;
-        float f1 = 0.f;
-        if (FEAT == 1) f1 = act ? a.feats[ec.j] * ec.inv : 0.f;
 
         for (int q = 0; q < a.nb; ++q) {
             float pre1[8], a1[8], pre2[8], a2[8], o[8], c[8];
@@ -408,27 +418,71 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(ConvArgs a, float* __restri
 // Fin <= 4 they are accumulated per edge in LDS across all blocks and flushed with ONE atomic per (edge, fin);
 // otherwise one atomic per (edge, neuron).
 // ---------------------------------------------------------------------------------------
-#define MCCNN_DF_CAP 2048  // floats of per-wave LDS for the per-edge feature-gradient accumulators
 
+// Transposing butterfly: 64 per-lane values -> lane l ends with sum over all lanes of v[l].
+// 63 exchanges instead of the 64 x 6 of a per-value wave_sum. (Template recursion keeps every index static:
+// a runtime-indexed register array would be demoted to scratch.)
+template <int S>
+__device__ __forceinline__ void butterfly_step(float* v, int lane) {
+    const bool upper = (lane & S) != 0;
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        float send = upper ? v[k] : v[k + S];
+        float keep = upper ? v[k + S] : v[k];
+        v[k] = keep + __shfl_xor(send, S, 64);
+    }
+}
+__device__ __forceinline__ float wave_reduce64(float* v, int lane) {
+    butterfly_step<32>(v, lane);
+    butterfly_step<16>(v, lane);
+    butterfly_step<8>(v, lane);
+    butterfly_step<4>(v, lane);
+    butterfly_step<2>(v, lane);
+    butterfly_step<1>(v, lane);
+    return v[0];
+}
+
+// Per-edge record (delta0, delta1, delta2, 1/(pdf K)) written once per backward call: the q-outer sweep re-reads
+// every edge nb times, so the dependent gathers (packed -> pts/samples/start/pdf) and the set-up arithmetic are
+// paid once and the sweep itself only issues coalesced, prefetchable loads.
+__global__ __launch_bounds__(256) void edge_records(ConvArgs a, float4* __restrict__ rec) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.e) return;
+    int2 pr = a.packed[t];
+    float invR = a.invRadius;
+    if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, a.bids[pr.x]));
+    const float* p = a.pts + (size_t)pr.x * 3;
+    const float* c = a.samples + (size_t)pr.y * 3;
+    int e0 = a.start[pr.y];
+    int e1 = (pr.y < a.m - 1) ? a.start[pr.y + 1] : a.e;
+    float K = a.avg ? (float)(e1 - e0) : 1.0f;
+    rec[t] = make_float4((p[0] - c[0]) * invR, (p[1] - c[1]) * invR, (p[2] - c[2]) * invR,
+                         __builtin_amdgcn_rcpf(a.pdfs[t] * K));
+}
+
+#ifndef MCCNN_BWD_OCC
+#define MCCNN_BWD_OCC 2
+#endif
+// Waves own equal, contiguous EDGE ranges (cpw chunks of 64 edges each): nothing in the backward pass needs
+// centre alignment, and equal edge counts remove the tail that centre-aligned ranges show on non-uniform clouds.
 template <bool COMBIN, int FEAT>
-__global__ __launch_bounds__(256, 2) void conv_bwd_mfma(ConvArgs a, const float* __restrict__ outGrad,
-                                                        float* __restrict__ featGrad, float* __restrict__ partials) {
+__global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, const float4* __restrict__ rec,
+                                                                    const float* __restrict__ outGrad,
+                                                                    float* __restrict__ featGrad,
+                                                                    float* __restrict__ dfE, int cpw,
+                                                                    float* __restrict__ partials) {
     extern __shared__ float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
-    const int G = a.G, outF = a.outF;
+    const int outF = a.outF;
     float* wl = lds;
-    float* mine = lds + a.nb * MCCNN_WQ_BWD + (size_t)wave * (MCCNN_DF_CAP + 192 + G + 4);
-    float* dfL = mine;                  // [edge_local][Fin] feature-gradient accumulators (FEAT 0/1 with Fin <= 4)
-    float* red = mine + MCCNN_DF_CAP;   // 176 reduced sums of one block
-    int* sL = reinterpret_cast<int*>(red + 192);
+    float* red = lds + a.nb * MCCNN_WQ_BWD + wave * 192;  // 176 reduced sums of one block
     stage_weights<MCCNN_WQ_BWD>(a, wl);
-    const int waveGlobal = blockIdx.x * 4 + wave;
-    WaveRange wr = wave_range(a, waveGlobal, sL, lane);
-    const bool useDfL = COMBIN && a.Fin <= 4;
-    const int dfCapEdges = MCCNN_DF_CAP / a.Fin;
-    if (useDfL)
-        for (int k = lane; k < MCCNN_DF_CAP; k += 64) dfL[k] = 0.0f;
     __syncthreads();
+    const int waveGlobal = blockIdx.x * 4 + wave;
+    const long long eBegL = (long long)waveGlobal * cpw * 64;
+    if (eBegL >= a.e) return;
+    const int eBeg = (int)eBegL;
+    const int eEnd = (int)min((long long)a.e, eBegL + (long long)cpw * 64);
     float* prow = partials + (size_t)waveGlobal * a.nb * 176;
 
     for (int q = 0; q < a.nb; ++q) {
@@ -439,89 +493,125 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_mfma(ConvArgs a, const float*
         for (int k = 0; k < 8; ++k) { gb3[k] = 0.f; gb2[k] = 0.f; gb1[k] = 0.f; }
 #pragma unroll
         for (int k = 0; k < 24; ++k) gw1[k] = 0.f;
-        const float* wq = wl + q * MCCNN_WQ_BWD;
-        const f32x4* w4 = reinterpret_cast<const f32x4*>(wq);
         const int numOuts = min(a.neuronsOut - q * 8, 8);
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-        for (int base = wr.eBeg; base < wr.eEnd; base += 64) {
+        int2 prN = make_int2(0, 0);
+        float4 rcN = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (eBeg + lane < eEnd) { prN = a.packed[eBeg + lane]; rcN = rec[eBeg + lane]; }
+        for (int base = eBeg; base < eEnd; base += 64) {
             const int t = base + lane;
-            const bool act = t < wr.eEnd;
-            Edge ec = load_edge2(a, wr, sL, t, act);
+            const bool act = t < eEnd;
+            const int2 pr = prN;
+            const float4 rc = rcN;
+            const int j = pr.x;
+            const float inv = act ? rc.w : 0.f;
+            // g_n and f_n first: the gathers fly while the MFMA chains run
+            float g[8], ff[8];
+            const float* grow = outGrad + (size_t)pr.y * outF;
+            if (FEAT == 2) {
+                const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
+                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)j * a.Fin + q * 8);
+                float4 ga = gp[0], gb = gp[1], fa = fp[0], fb = fp[1];
+                float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+                float f8[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+#pragma unroll
+                for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; ff[n] = f8[n]; }
+            } else if (FEAT == 1) {
+#ifdef ABL_NOGATHER
+                float f = rc.x;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) { g[n] = act ? rc.y + n : 0.f; ff[n] = f; }
+                if (false) {
+#else
+                float f = a.feats[j];
+                if (numOuts == 8 && (outF & 3) == 0) {
+#endif
+                    const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
+                    float4 ga = gp[0], gb = gp[1];
+                    float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; ff[n] = f; }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) { g[n] = (act && n < numOuts) ? grow[q * 8 + n] : 0.f; ff[n] = f; }
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    int nu = q * 8 + n;
+                    int fin = COMBIN ? nu % a.Fin : nu;
+                    int fo = COMBIN ? nu / a.Fin : nu;
+                    bool ok = act && n < numOuts;
+                    g[n] = ok ? grow[fo] : 0.f;
+                    ff[n] = ok ? a.feats[(size_t)j * a.Fin + fin] : 0.f;
+                }
+            }
+            float dfOld = 0.f;
+#ifndef ABL_NODFE
+            if (COMBIN && FEAT == 1 && act && q > 0) dfOld = dfE[t];
+#endif
+            // prefetch the next chunk AFTER this chunk's gathers: vmcnt retires in order, so the waits for g / f
+            // leave these two loads in flight across the whole iteration
+            if (t + 64 < eEnd) { prN = a.packed[t + 64]; rcN = rec[t + 64]; }
             float a1[8], a2[8], o[8];
             bool p1[8], p2[8];  // pre-activation >= 0 (ReLU' of the reference: spatial_conv.cu:404,429), kept as lane masks
+            // keep the LDS weight reads inside the chunk loop: hoisted, they would pin ~100 VGPRs and spill the
+            // 176 accumulators (the LDS pipe is idle here, re-reading is free)
+            int woff = q * MCCNN_WQ_BWD;
+            asm volatile("" : "+s"(woff));
+            const float* wq = wl + woff;
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(wq);
             {
                 float pre1[8], pre2[8];
-                mlp_block_mfma(wq, i4, ec.d0, ec.d1, ec.d2, pre1, a1, pre2, a2, o);
+                mlp_block_mfma(wq, i4, rc.x, rc.y, rc.z, pre1, a1, pre2, a2, o);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { p1[k] = pre1[k] >= 0.0f; p2[k] = pre2[k] >= 0.0f; }
             }
-            // g_n * f_n and the feature gradient
-            float gf[8];
-            {
-                float g[8];
-                const float* grow = outGrad + (size_t)(wr.c0 + ec.il) * outF;
-                if (FEAT == 2) {
-                    const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
-                    const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)ec.j * a.Fin + q * 8);
-                    float4 ga = gp[0], gb = gp[1], fa = fp[0], fb = fp[1];
-                    float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-                    float ff[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; gf[n] = g[n] * ff[n]; }
-                } else if (FEAT == 1) {
-                    float f = a.feats[ec.j];
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) {
-                        g[n] = (act && n < numOuts) ? grow[q * 8 + n] : 0.f;
-                        gf[n] = g[n] * f;
-                    }
-                } else {
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) {
-                        int nu = q * 8 + n;
-                        int fin = COMBIN ? nu % a.Fin : nu;
-                        int fo = COMBIN ? nu / a.Fin : nu;
-                        bool ok = act && n < numOuts;
-                        g[n] = ok ? grow[fo] : 0.f;
-                        gf[n] = ok ? g[n] * a.feats[(size_t)ec.j * a.Fin + fin] : 0.f;
-                    }
-                }
-                // feature gradient: og * o / (pdf K)   (spatial_conv.cu:400)
+            // feature gradient: og * o / (pdf K)   (spatial_conv.cu:400)
+            if (COMBIN) {
                 if (FEAT == 1) {
                     float sfg = 0.f;
 #pragma unroll
                     for (int n = 0; n < 8; ++n) sfg = fmaf(g[n], o[n], sfg);
-                    sfg *= ec.inv;
-                    if (act) {
-                        int el = t - wr.eBeg;
-                        if (el < dfCapEdges) dfL[el] += sfg;  // this lane is the only writer of edge el
-                        else atomicAdd(&featGrad[ec.j], sfg);
-                    }
-                } else if (FEAT == 2) {
-                    if (act) {
-                        float* fgp = featGrad + (size_t)ec.j * a.Fin + q * 8;
-#pragma unroll
-                        for (int n = 0; n < 8; ++n) atomicAdd(&fgp[n], g[n] * o[n] * ec.inv);
-                    }
+                    sfg *= inv;
+#ifndef ABL_NODFE
+                    if (act) dfE[t] = dfOld + sfg;  // this lane owns edge t: plain RMW, no atomics
+#else
+                    asm volatile("" ::"v"(sfg + dfOld));
+#endif
                 } else if (act) {
-                    int el = t - wr.eBeg;
+                    // several neurons of a block may share fin: fold them in registers first
+                    for (int f = 0; f < a.Fin; ++f) {
+                        float sfg = 0.f;
+                        bool any = false;
 #pragma unroll
-                    for (int n = 0; n < 8; ++n) {
-                        int nu = q * 8 + n;
-                        if (n < numOuts) {
-                            int fin = COMBIN ? nu % a.Fin : nu;
-                            float v = g[n] * o[n] * ec.inv;
-                            if (useDfL && el < dfCapEdges) dfL[el * a.Fin + fin] += v;
-                            else atomicAdd(&featGrad[(size_t)ec.j * a.Fin + fin], v);
+                        for (int n = 0; n < 8; ++n) {
+                            int nu = q * 8 + n;
+                            if (n < numOuts && nu % a.Fin == f) { sfg = fmaf(g[n], o[n], sfg); any = true; }
+                        }
+                        if (any) {
+                            float* d = dfE + (size_t)t * a.Fin + f;
+                            float old = (q * 8 >= a.Fin || q > 0) ? *d : 0.f;
+                            if (q == 0) old = 0.f;
+                            // first touch of (t, f) happens in the block where nu == f, i.e. q == f / 8
+                            *d = ((q == f / 8) ? 0.f : old) + sfg * inv;
                         }
                     }
                 }
+            } else if (act) {
+                float* fgp = featGrad + (size_t)j * a.Fin + q * 8;
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    if (n < numOuts) atomicAdd(&fgp[n], g[n] * o[n] * inv);
             }
+            float gf[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) gf[n] = g[n] * ff[n];
             // dW3 += u a2^T, db3 += u, u = g f / (pdf K)          (spatial_conv.cu:383-399)
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
-                float u = gf[n] * ec.inv;
+                float u = gf[n] * inv;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) gw3[n * 8 + k] = fmaf(u, a2[k], gw3[n * 8 + k]);
                 gb3[n] += u;
@@ -530,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_mfma(ConvArgs a, const float*
             float t3[8];
             layer8(w4 + 62, zero4, zero4, i4, gf, t3);  // W3^T rows at float 248 -> f32x4 index 62
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t3[k] = p2[k] ? t3[k] * ec.inv : 0.f;
+            for (int k = 0; k < 8; ++k) t3[k] = p2[k] ? t3[k] * inv : 0.f;
             // dW2 += t3 a1^T, db2 += t3                            (:419-425)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -545,37 +635,42 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_mfma(ConvArgs a, const float*
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
                 float v = p1[l] ? t4[l] : 0.f;
-                gw1[l * 3] = fmaf(v, ec.d0, gw1[l * 3]);
-                gw1[l * 3 + 1] = fmaf(v, ec.d1, gw1[l * 3 + 1]);
-                gw1[l * 3 + 2] = fmaf(v, ec.d2, gw1[l * 3 + 2]);
+                gw1[l * 3] = fmaf(v, rc.x, gw1[l * 3]);
+                gw1[l * 3 + 1] = fmaf(v, rc.y, gw1[l * 3 + 1]);
+                gw1[l * 3 + 2] = fmaf(v, rc.z, gw1[l * 3 + 2]);
                 gb1[l] += v;
             }
         }
-        // wave reduction -> LDS (layout: w1[24] b1[8] w2[64] b2[8] w3[64] b3[8]) -> this wave's partial row
+        // transposing wave reduction; partial row layout: w1[24] b1[8] w2[64] b2[8] w3[64] b3[8]
+        {
+            float r2 = wave_reduce64(gw2, lane);
+            float r3 = wave_reduce64(gw3, lane);
+            float misc[64];
 #pragma unroll
-        for (int k = 0; k < 24; ++k) { float v = wave_sum(gw1[k]); if (lane == 0) red[k] = v; }
+            for (int k = 0; k < 24; ++k) misc[k] = gw1[k];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { float v = wave_sum(gb1[k]); if (lane == 0) red[24 + k] = v; }
+            for (int k = 0; k < 8; ++k) { misc[24 + k] = gb1[k]; misc[32 + k] = gb2[k]; misc[40 + k] = gb3[k]; }
 #pragma unroll
-        for (int k = 0; k < 64; ++k) { float v = wave_sum(gw2[k]); if (lane == 0) red[32 + k] = v; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { float v = wave_sum(gb2[k]); if (lane == 0) red[96 + k] = v; }
-#pragma unroll
-        for (int k = 0; k < 64; ++k) { float v = wave_sum(gw3[k]); if (lane == 0) red[104 + k] = v; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { float v = wave_sum(gb3[k]); if (lane == 0) red[168 + k] = v; }
-        __builtin_amdgcn_wave_barrier();
-        for (int k = lane; k < 176; k += 64) prow[q * 176 + k] = red[k];
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (useDfL) {
-        __builtin_amdgcn_wave_barrier();
-        int nE = min(wr.eEnd - wr.eBeg, dfCapEdges);
-        for (int el = lane; el < nE; el += 64) {
-            int j = a.packed[wr.eBeg + el].x;
-            for (int f = 0; f < a.Fin; ++f) atomicAdd(&featGrad[(size_t)j * a.Fin + f], dfL[el * a.Fin + f]);
+            for (int k = 48; k < 64; ++k) misc[k] = 0.f;
+            float rm = wave_reduce64(misc, lane);
+            float* pq = prow + q * 176;
+            pq[32 + lane] = r2;
+            pq[104 + lane] = r3;
+            if (lane < 32) pq[lane] = rm;                 // w1, b1
+            else if (lane < 40) pq[96 + lane - 32] = rm;  // b2
+            else if (lane < 48) pq[168 + lane - 40] = rm; // b3
         }
     }
+}
+
+// combin layers: featGrad[j, f] += dfE[e, f] (one atomic per edge and input feature)
+__global__ __launch_bounds__(256) void scatter_edge_featgrad(const int2* __restrict__ packed, const float* __restrict__ dfE,
+                                                             long long total, int Fin, float* __restrict__ featGrad) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    long long e = t / Fin;
+    int f = (int)(t - e * Fin);
+    atomicAdd(&featGrad[(size_t)packed[e].x * Fin + f], dfE[t]);
 }
 
 // Sums the per-wave partial rows in a fixed order and scatters them to the six gradient tensors.
@@ -813,15 +908,28 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     return 0;
 }
 
-#define MCCNN_BWD_G 64  // centres per wave in the MFMA backward
+#define MCCNN_BWD_WAVES 2048    // 256 CUs x 4 SIMDs x 2 resident waves
+#define MCCNN_BWD_MIN_CHUNKS 8  // amortises the per-(wave, block) reduction of the 176 partial sums
+
+static void bwd_partition(int e, int& cpw, int& waves) {
+    long long chunks = ((long long)e + 63) / 64;
+    cpw = (int)((chunks + MCCNN_BWD_WAVES - 1) / MCCNN_BWD_WAVES);
+    if (cpw < MCCNN_BWD_MIN_CHUNKS) cpw = MCCNN_BWD_MIN_CHUNKS;
+    waves = (int)((chunks + cpw - 1) / cpw);
+    if (waves < 1) waves = 1;
+}
 
 size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_feats, int num_out_feats, int combin) {
-    (void)n; (void)e;
-    if (m <= 0 || num_in_feats <= 0 || num_out_feats <= 0) return 256;
+    (void)n; (void)m;
+    if (e <= 0 || num_in_feats <= 0 || num_out_feats <= 0) return 256;
     long long neurons = combin ? (long long)num_in_feats * num_out_feats : num_in_feats;
     long long nb = (neurons + 7) / 8;
-    long long waves = (long long)ceil_div(m, 4 * MCCNN_BWD_G) * 4;
-    return align_up((size_t)(waves * nb * 176) * sizeof(float)) + 256;
+    int cpw, waves;
+    bwd_partition(e, cpw, waves);
+    size_t bytes = align_up((size_t)(((long long)waves + 3) / 4 * 4 * nb * 176) * sizeof(float));  // partial rows
+    bytes += align_up((size_t)e * sizeof(float4));                                                // edge records
+    if (combin) bytes += align_up((size_t)e * num_in_feats * sizeof(float));                      // per-edge dFeat
+    return bytes + 256;
 }
 
 int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
@@ -841,7 +949,7 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
     size_t nn = (size_t)a.nb * 8;
     if (n > 0) MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * sizeof(float), s));
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats | (uintptr_t)out_grad) & 15) == 0);
-    size_t lds = ((size_t)a.nb * MCCNN_WQ_BWD + 4 * ((size_t)MCCNN_DF_CAP + 192 + MCCNN_BWD_G + 4)) * sizeof(float);
+    size_t lds = ((size_t)a.nb * MCCNN_WQ_BWD + 4 * 192) * sizeof(float);
     bool mfma = use_mfma(a) && lds <= 64 * 1024 && m > 0 && e > 0;
     if (!mfma || m == 0 || e == 0) {
         MCCNN_HIP(hipMemsetAsync(dw1, 0, 3 * nn * sizeof(float), s));
@@ -856,20 +964,33 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
     if (mfma) {
         if (!ws || ws_bytes < mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, num_in_feats, num_out_feats, combin))
             return MCCNN_E_WORKSPACE;
-        a.G = MCCNN_BWD_G;
-        int blocks = ceil_div(m, 4 * a.G);
-        float* partials = (float*)ws;
+        int cpw, waves;
+        bwd_partition(e, cpw, waves);
+        int blocks = (waves + 3) / 4;
+        Arena ar(ws, ws_bytes);
+        float* partials = ar.take<float>((size_t)blocks * 4 * a.nb * 176);
+        float4* rec = ar.take<float4>((size_t)e);
+        float* dfE = combin ? ar.take<float>((size_t)e * a.Fin) : nullptr;
+        if (!partials || !rec || (combin && !dfE)) return MCCNN_E_WORKSPACE;
+        a.G = 0;
+        edge_records<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
+        MCCNN_LAUNCHED();
         if (combin) {
-            if (a.Fin == 1) conv_bwd_mfma<true, 1><<<blocks, 256, lds, s>>>(a, out_grad, feat_grad, partials);
-            else conv_bwd_mfma<true, 0><<<blocks, 256, lds, s>>>(a, out_grad, feat_grad, partials);
+            if (a.Fin == 1) conv_bwd_mfma<true, 1><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+            else conv_bwd_mfma<true, 0><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
         } else {
-            if (vec) conv_bwd_mfma<false, 2><<<blocks, 256, lds, s>>>(a, out_grad, feat_grad, partials);
-            else conv_bwd_mfma<false, 0><<<blocks, 256, lds, s>>>(a, out_grad, feat_grad, partials);
+            if (vec) conv_bwd_mfma<false, 2><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+            else conv_bwd_mfma<false, 0><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
         }
         MCCNN_LAUNCHED();
-        reduce_partials<<<ceil_div((long long)a.nb * 176, 16), 256, 0, s>>>(partials, blocks * 4, a.nb, dw1, db1, dw2,
-                                                                            db2, dw3, db3);
+        reduce_partials<<<ceil_div((long long)a.nb * 176, 16), 256, 0, s>>>(partials, waves, a.nb, dw1, db1, dw2, db2,
+                                                                            dw3, db3);
         MCCNN_LAUNCHED();
+        if (combin) {
+            long long total = (long long)e * a.Fin;
+            scatter_edge_featgrad<<<ceil_div(total, 256), 256, 0, s>>>(a.packed, dfE, total, a.Fin, feat_grad);
+            MCCNN_LAUNCHED();
+        }
         return 0;
     }
     a.G = 32;

@@ -26,36 +26,64 @@ __device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centre
     return c;
 }
 
-// One thread per centre; FILL == false counts, FILL == true writes (j, i) rows.
-// Traversal order = cellOffsets order (find_neighbors.cu:282-291), then ascending j.
+// One thread per centre, visited in `order` (identity when null); FILL == false counts, FILL == true writes
+// (j, i) rows. Traversal order = cellOffsets order (find_neighbors.cu:282-291), then ascending j.
+// The reference walks the window twice with one dependent load chain per candidate; here the 27 cell ranges
+// are fetched 9 at a time (one z-slab, independent loads) and the candidates of a cell 4 at a time, so a lane
+// keeps several loads in flight, and with a cell-coherent visiting order the lanes of a wave read the same
+// cells (broadcast loads, equal trip counts).
 template <bool FILL>
 __global__ __launch_bounds__(128) void neigh_walk(const float* __restrict__ centres, const int* __restrict__ cb, int m,
                                                   const float* __restrict__ pts2, const int* __restrict__ cells,
                                                   const float* __restrict__ mn, const float* __restrict__ mx, int nc,
-                                                  float radius, int scaleInv, int* __restrict__ counts,
-                                                  const int* __restrict__ startIdx, int* __restrict__ packed) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
+                                                  float radius, int scaleInv, const int* __restrict__ order,
+                                                  int* __restrict__ counts, const int* __restrict__ startIdx,
+                                                  int* __restrict__ packed) {
+    int tix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tix >= m) return;
+    const int i = order ? order[tix] : tix;
     CentreCtx c = centre_ctx(centres, cb, mn, mx, i, nc, radius, scaleInv);
     int k = 0;
     int2* dst = FILL ? reinterpret_cast<int2*>(packed) + startIdx[i] : nullptr;
-    size_t cellBase = (size_t)c.b * nc * nc * nc;
-    for (int o = 0; o < 27; ++o) {
-        int dx, dy, dz;
-        neigh_offset(o, dx, dy, dz);
-        int X = c.x + dx, Y = c.y + dy, Z = c.z + dz;
-        if (X < 0 || X >= nc || Y < 0 || Y >= nc || Z < 0 || Z >= nc) continue;
-        size_t flat = cellBase + (size_t)X * nc * nc + (size_t)Y * nc + Z;
-        int2 r = reinterpret_cast<const int2*>(cells)[flat];
-        for (int j = r.x; j < r.y; ++j) {
-            float d = point_dist(pts2[(size_t)j * 3], pts2[(size_t)j * 3 + 1], pts2[(size_t)j * 3 + 2], c.cx, c.cy, c.cz);
-            if (d < c.R) {
-                if (FILL) dst[k] = make_int2(j, i);
-                ++k;
+    const size_t cellBase = (size_t)c.b * nc * nc * nc;
+    const int2* ct = reinterpret_cast<const int2*>(cells);
+#pragma unroll 1
+    for (int slab = 0; slab < 3; ++slab) {
+        const int Z = c.z + 1 - slab;  // offsets o = 9*slab .. 9*slab+8 share dz = 1 - slab
+        int2 rng[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            int X = c.x + 1 - (u % 3), Y = c.y + 1 - (u / 3);
+            bool ok = X >= 0 && X < nc && Y >= 0 && Y < nc && Z >= 0 && Z < nc;
+            rng[u] = ok ? ct[cellBase + (size_t)X * nc * nc + (size_t)Y * nc + Z] : make_int2(0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int j0 = rng[u].x, j1 = rng[u].y;
+            for (int j = j0; j < j1; j += 4) {
+                float d[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    int jj = min(j + v, j1 - 1);
+                    const float* p = pts2 + (size_t)jj * 3;
+                    d[v] = point_dist(p[0], p[1], p[2], c.cx, c.cy, c.cz);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    if (j + v < j1 && d[v] < c.R) {
+                        if (FILL) dst[k] = make_int2(j + v, i);
+                        ++k;
+                    }
+                }
             }
         }
     }
     if (!FILL) counts[i] = k;
+}
+
+__global__ __launch_bounds__(256) void invert_perm_k(const int* __restrict__ newIdx, int n, int* __restrict__ inv) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[newIdx[i]] = i;
 }
 
 // ------------------------------------------------------------------ compute_pdf.cu:40-94
@@ -118,8 +146,8 @@ size_t mccnn_find_neighbors_workspace_bytes(int m) {
 
 int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
                                const int* cell_indexs, const float* aabb_min, const float* aabb_max, int batch_size,
-                               int num_cells, float radius, int scale_inv, int* start_idx, int* total_dev, void* ws,
-                               size_t ws_bytes, mccnn_stream_t stream) {
+                               int num_cells, float radius, int scale_inv, const int* centre_order, int* start_idx,
+                               int* total_dev, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
     if (m < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (m == 0) {
@@ -133,24 +161,33 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
     void* scanws = a.take<char>(scan_workspace_bytes(m));
     if (!counts || !scanws) return MCCNN_E_WORKSPACE;
     neigh_walk<false><<<ceil_div(m, 128), 128, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
-                                                       aabb_max, num_cells, radius, scale_inv, counts, nullptr,
-                                                       nullptr);
+                                                       aabb_max, num_cells, radius, scale_inv, centre_order, counts,
+                                                       nullptr, nullptr);
     MCCNN_LAUNCHED();
     return exclusive_scan_i32(counts, start_idx, m, total_dev, scanws, s);
 }
 
 int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
                               const int* cell_indexs, const float* aabb_min, const float* aabb_max, int batch_size,
-                              int num_cells, float radius, int scale_inv, const int* start_idx, int e, int* packed,
-                              mccnn_stream_t stream) {
+                              int num_cells, float radius, int scale_inv, const int* centre_order, const int* start_idx,
+                              int e, int* packed, mccnn_stream_t stream) {
     if (m < 0 || e < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f)) return MCCNN_E_BADARG;
     if (m == 0 || e == 0) return 0;
     if (!centres || !centre_batch_ids || !sorted_pts || !cell_indexs || !aabb_min || !aabb_max || !start_idx || !packed)
         return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     neigh_walk<true><<<ceil_div(m, 128), 128, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
-                                                      aabb_max, num_cells, radius, scale_inv, nullptr, start_idx,
-                                                      packed);
+                                                      aabb_max, num_cells, radius, scale_inv, centre_order, nullptr,
+                                                      start_idx, packed);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+int mccnn_invert_permutation(const int* new_idx, int n, int* inv, mccnn_stream_t stream) {
+    if (n < 0) return MCCNN_E_BADARG;
+    if (n == 0) return 0;
+    if (!new_idx || !inv) return MCCNN_E_BADARG;
+    invert_perm_k<<<ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(new_idx, n, inv);
     MCCNN_LAUNCHED();
     return 0;
 }
