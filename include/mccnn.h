@@ -133,10 +133,11 @@ int mccnn_invert_permutation(const int* new_idx, int n, int* inv, mccnn_stream_t
  *         statement, compute_pdf.cu:72-92);
  * mode 1: single-precision evaluation (one expf per pair); agrees with mode 0 to
  *         ~1e-6 relative, inside the 1e-4 tolerance of the feature path. */
+size_t mccnn_compute_pdf_workspace_bytes(int e, int mode);
 int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx,
                       int m, const int* packed, int e, const float* aabb_min, const float* aabb_max,
                       int batch_size, float window, float radius, int scale_inv, int mode,
-                      float* pdfs, mccnn_stream_t stream);
+                      float* pdfs, void* ws, size_t ws_bytes, mccnn_stream_t stream);
 
 /* PoissonSampling -- poisson_sampling.cc:26,109-211, poisson_sampling.cu:51-230.
  * count: runs the 27 colour phases, leaves the selection in ws and writes the

@@ -334,9 +334,11 @@ def compute_pdf(inPts, inBatchIds, aabbMin, aabbMax, startIndexs, neighbors, win
     lib = _lib.load()
     e = pk.shape[0]
     pdfs = torch.empty((e, 1), dtype=torch.float32, device=p.device)
+    md = int(PDF_MODE if mode is None else mode)
+    ws = _ws(lib.mccnn_compute_pdf_workspace_bytes(e, md), p.device)
     check(lib.mccnn_compute_pdf(ptr(p), ptr(b), ptr(st), st.shape[0], ptr(pk), e, ptr(mn), ptr(mx), batchSize,
-                                float(window), float(radius), int(bool(scaleInv)),
-                                int(PDF_MODE if mode is None else mode), ptr(pdfs), stream_handle()), "compute_pdf")
+                                float(window), float(radius), int(bool(scaleInv)), md, ptr(pdfs), ptr(ws), ws.numel(),
+                                stream_handle()), "compute_pdf")
     return pdfs
 
 

@@ -134,6 +134,57 @@ __global__ __launch_bounds__(256) void pdf_edges(const float* __restrict__ pts, 
     pdfs[t] = pdf / ((float)i1 - i0);  // compute_pdf.cu:92
 }
 
+// ---- single-precision KDE (mode 1) ------------------------------------------------------------------
+// Pre-pass: one float4 per edge with the neighbour's coordinates already scaled by 1/(R_b h); the pair loop
+// then costs one (wave-broadcast) 16-byte load and ~9 VALU instructions per pair.
+__global__ __launch_bounds__(256) void pdf_scaled_coords(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                         const int2* __restrict__ packed, int e,
+                                                         const float* __restrict__ mn, const float* __restrict__ mx,
+                                                         float window, float radius, int scaleInv,
+                                                         float4* __restrict__ sc) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= e) return;
+    int j = packed[t].x;
+    float R = scaleInv ? radius * max_extent(mn, mx, bids[j]) : radius;
+    float s = (float)(1.0 / (double)(R * window));
+    const float* p = pts + (size_t)j * 3;
+    sc[t] = make_float4(p[0] * s, p[1] * s, p[2] * s, 0.f);
+}
+
+__global__ __launch_bounds__(256) void pdf_edges_fast(const float4* __restrict__ sc, const int* __restrict__ startIdx,
+                                                      int m, const int2* __restrict__ packed, int e, float window,
+                                                      float* __restrict__ pdfs) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= e) return;
+    int centre = packed[t].y;
+    int i0 = startIdx[centre];
+    int i1 = (centre < m - 1) ? startIdx[centre + 1] : e;
+    float4 me = sc[t];
+    const float c = -0.5f * 1.44269504088896f;  // exp(-x/2) = exp2(c x)
+    float acc = 0.f;
+    int it = i0;
+    for (; it + 4 <= i1; it += 4) {
+        float4 q0 = sc[it], q1 = sc[it + 1], q2 = sc[it + 2], q3 = sc[it + 3];
+        float dx, dy, dz;
+        dx = q0.x - me.x; dy = q0.y - me.y; dz = q0.z - me.z;
+        acc += __builtin_amdgcn_exp2f(c * fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        dx = q1.x - me.x; dy = q1.y - me.y; dz = q1.z - me.z;
+        acc += __builtin_amdgcn_exp2f(c * fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        dx = q2.x - me.x; dy = q2.y - me.y; dz = q2.z - me.z;
+        acc += __builtin_amdgcn_exp2f(c * fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        dx = q3.x - me.x; dy = q3.y - me.y; dz = q3.z - me.z;
+        acc += __builtin_amdgcn_exp2f(c * fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    }
+    for (; it < i1; ++it) {
+        float4 q0 = sc[it];
+        float dx = q0.x - me.x, dy = q0.y - me.y, dz = q0.z - me.z;
+        acc += __builtin_amdgcn_exp2f(c * fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    }
+    const float invH = 1.0f / window;
+    const float g1 = invH * 0.39894228f;
+    pdfs[t] = (acc * (g1 * g1 * g1)) / ((float)i1 - i0);
+}
+
 }  // namespace mccnn
 
 using namespace mccnn;
@@ -192,9 +243,14 @@ int mccnn_invert_permutation(const int* new_idx, int n, int* inv, mccnn_stream_t
     return 0;
 }
 
+size_t mccnn_compute_pdf_workspace_bytes(int e, int mode) {
+    return (mode != 0 && e > 0) ? align_up((size_t)e * sizeof(float4)) : 256;
+}
+
 int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx, int m,
                       const int* packed, int e, const float* aabb_min, const float* aabb_max, int batch_size,
-                      float window, float radius, int scale_inv, int mode, float* pdfs, mccnn_stream_t stream) {
+                      float window, float radius, int scale_inv, int mode, float* pdfs, void* ws, size_t ws_bytes,
+                      mccnn_stream_t stream) {
     if (m < 0 || e < 0 || batch_size <= 0 || !(radius > 0.0f) || !(window > 0.0f)) return MCCNN_E_BADARG;
     if (e == 0) return 0;
     if (!sorted_pts || !sorted_batch_ids || !start_idx || !packed || !aabb_min || !aabb_max || !pdfs || m == 0)
@@ -204,9 +260,14 @@ int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, cons
     if (mode == 0)
         pdf_edges<0><<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, start_idx, m, pk, e, aabb_min,
                                                       aabb_max, window, radius, scale_inv, pdfs);
-    else
-        pdf_edges<1><<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, start_idx, m, pk, e, aabb_min,
-                                                      aabb_max, window, radius, scale_inv, pdfs);
+    else {
+        if (!ws || ws_bytes < mccnn_compute_pdf_workspace_bytes(e, mode)) return MCCNN_E_WORKSPACE;
+        float4* sc = (float4*)ws;
+        pdf_scaled_coords<<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, e, aabb_min, aabb_max,
+                                                          window, radius, scale_inv, sc);
+        MCCNN_LAUNCHED();
+        pdf_edges_fast<<<ceil_div(e, 256), 256, 0, s>>>(sc, start_idx, m, pk, e, window, pdfs);
+    }
     MCCNN_LAUNCHED();
     return 0;
 }

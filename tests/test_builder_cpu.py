@@ -1,0 +1,97 @@
+"""The builder counterpart (mccnn_amd.MCConvBuilder) must emit the op sequence, cache behaviour and variable
+shapes of the reference's utils/MCConvBuilder.py. The expected trace (tests/golden/builder_trace.json) was recorded
+from the REFERENCE code itself running MCClassS's graph builder against recording stubs (tests/golden/make_golden.py).
+Here the HIP ops are replaced by oracle-backed CPU shims (test infrastructure) so the test runs without a GPU."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture()
+def shimmed_builder(oracle, monkeypatch):
+    import mccnn_amd.MCConvBuilder as MB
+    calls = []
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    n = lambda x: x.detach().numpy() if isinstance(x, torch.Tensor) else x
+
+    def shim(name):
+        fn = getattr(oracle, name)
+
+        def f(*args):
+            calls.append(name)
+            out = fn(*[n(a) for a in args])
+            return tuple(t(o) for o in out) if isinstance(out, tuple) else t(out)
+        return f
+
+    for nm in ("compute_aabb", "sort_points_step1", "sort_points_step2", "sort_features", "sort_features_back",
+               "compute_pdf", "poisson_sampling", "get_sampled_features", "spatial_conv", "transform_indexs",
+               "find_neighbors"):
+        monkeypatch.setattr(MB, nm, shim(nm))
+    monkeypatch.setattr(MB, "get_block_size", lambda: 8)
+    return MB, calls
+
+
+def test_builder_matches_reference_trace(shimmed_builder):
+    MB, calls = shimmed_builder
+    ref = json.load(open(os.path.join(GOLD, "builder_trace.json")))
+    ref_ops = [c[0] for c in ref["calls"] if c[0] not in ("get_variable", "add_to_collection")]
+    B, k = 4, 16
+    rng = np.random.default_rng(0)
+    pts = torch.from_numpy(rng.random((B * 64, 3), dtype=np.float32))
+    bids = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), 64).reshape(-1, 1))
+    feats = torch.ones((B * 64, 1), dtype=torch.float32)
+    # models/MCClassS.py:29-71 with the dense layers between the convolutions left out
+    ph = MB.PointHierarchy(pts, feats, bids, [0.1, 0.4, math.sqrt(3.0) + 0.1], "MCClassS_PH", B)
+    cb = MB.ConvolutionBuilder(KDEWindow=0.2)
+    f1 = cb.create_convolution(convName="Conv_1", inPointHierarchy=ph, inPointLevel=0, outPointLevel=1, inFeatures=feats,
+                               inNumFeatures=1, outNumFeatures=k, convRadius=0.2, multiFeatureConv=True)
+    f1 = torch.cat([f1, f1], 1)  # stands in for conv_1x1(k -> 2k)
+    f2 = cb.create_convolution(convName="Conv_2", inPointHierarchy=ph, inPointLevel=1, outPointLevel=2, inFeatures=f1,
+                               inNumFeatures=k * 2, convRadius=0.8)
+    f2 = torch.cat([f2, f2], 1)
+    f3 = cb.create_convolution(convName="Conv_3", inPointHierarchy=ph, inPointLevel=2, outPointLevel=3, inFeatures=f2,
+                               inNumFeatures=k * 4, convRadius=math.sqrt(3.0) + 0.1)
+    assert calls == ref_ops
+    got_vars = {n: list(p.shape) for n, p in cb.named_parameters()}
+    assert got_vars == ref["variables"]
+    # weight-decay collection: weights, weights2, weights3 of every conv (MCConvBuilder.py:408-416)
+    ref_coll = [c[2] for c in ref["calls"] if c[0] == "add_to_collection"]
+    assert len(cb.get_collection("weight_decay_loss")) == len(ref_coll) == 9
+    assert f3.shape == (ph.points_[3].shape[0], k * 4)
+    assert len(ph.points_) == 4 and len(ph.sampledIndexs_) == 3 and ph.radiusList_[0] == 0.0
+
+
+def test_builder_caches_and_errors(shimmed_builder):
+    MB, calls = shimmed_builder
+    rng = np.random.default_rng(1)
+    pts = torch.from_numpy(rng.random((128, 3), dtype=np.float32))
+    bids = torch.zeros((128, 1), dtype=torch.int32)
+    feats = torch.from_numpy(rng.random((128, 8), dtype=np.float32))
+    ph = MB.PointHierarchy(pts, feats, bids, [], "PH", 1)
+    cb = MB.ConvolutionBuilder(KDEWindow=0.2)
+    del calls[:]
+    a = cb.create_convolution("A", ph, 0, feats, 8, 0.3)
+    first = list(calls)
+    b = cb.create_convolution("B", ph, 0, a, 8, 0.3)  # same grid / neighbours / pdf -> only sort_features + conv
+    assert first == ["sort_points_step1", "sort_points_step2", "find_neighbors", "compute_pdf", "spatial_conv"]
+    assert calls[len(first):] == ["sort_features", "spatial_conv"]
+    keyGrid = "PH|0|0.3|True"
+    assert list(cb.cacheGrids_) == [keyGrid] and list(cb.cacheNeighs_) == [keyGrid + "|PH|0"]
+    assert list(cb.cachePDFs_) == [keyGrid + "|PH|0|0.2|True"]
+    p_before = dict(cb.named_parameters())
+    cb.reset()
+    assert not cb.cacheGrids_ and not cb.cacheNeighs_ and not cb.cachePDFs_
+    cb.create_convolution("A", ph, 0, feats, 8, 0.3)
+    assert all(p_before[k] is v for k, v in cb.named_parameters())  # variables survive reset (get_variable reuse)
+    with pytest.raises(RuntimeError):
+        cb.create_convolution("C", ph, 0, feats, 8, 0.3, outNumFeatures=4)  # single-feature conv needs Fin == Fout
+    ph2 = MB.PointHierarchy(pts, feats, bids, [], "PH2", 2)
+    with pytest.raises(RuntimeError):
+        cb.create_convolution("D", ph, 0, feats, 8, 0.3, outPointHierarchy=ph2)
+    assert b.shape == (128, 8)

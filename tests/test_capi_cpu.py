@@ -1,0 +1,77 @@
+"""The C-ABI library must build for gfx950 without a GPU, load, and export every symbol include/mccnn.h declares
+(no compute calls here -- there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mccnn.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mccnn_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from mccnn_amd import build
+    return build.build()
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_symbols()
+    for must in ("mccnn_compute_aabb", "mccnn_num_cells", "mccnn_sort_step1", "mccnn_sort_step2", "mccnn_permute_gather",
+                 "mccnn_permute_scatter", "mccnn_transform_indexs", "mccnn_find_neighbors_count",
+                 "mccnn_find_neighbors_fill", "mccnn_compute_pdf", "mccnn_poisson_sampling_count",
+                 "mccnn_poisson_sampling_fill", "mccnn_spatial_conv_fwd", "mccnn_spatial_conv_bwd", "mccnn_block_size"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib_path], text=True)
+    exported = set(re.findall(r" T (mccnn_[a-z0-9_]+)", out))
+    missing = [n for n in declared_symbols() if n not in exported]
+    assert not missing, missing
+
+
+def test_binding_covers_header_and_loads(lib_path):
+    from mccnn_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    lib = _lib.load()
+    assert lib.mccnn_block_size() == 8            # genCompileScript.py:20
+    assert lib.mccnn_arch() == b"gfx950"
+    assert lib.mccnn_abi_version() >= 1
+    assert b"workspace" in lib.mccnn_error_string(-4)
+    # host-only entry points (no device access): numCells(scale_inv) known answers, workspace queries
+    n = ctypes.c_int(0)
+    for r, nc in ((0.1, 10), (0.2, 5), (0.03, 33), (1.9, 1)):
+        assert lib.mccnn_num_cells(None, None, 1, r, 1, ctypes.byref(n), None) == 0 and n.value == nc
+    assert lib.mccnn_num_cells(None, None, 1, -1.0, 1, ctypes.byref(n), None) == -1
+    assert lib.mccnn_sort_step1_workspace_bytes(1000, 2, 10) >= 2 * 1000 * 4 + 1000 * 4
+    assert lib.mccnn_sort_step1_workspace_bytes(10, 1 << 20, 1 << 10) == 0     # keys would overflow int32
+    assert lib.mccnn_spatial_conv_bwd_workspace_bytes(1000, 1000, 50000, 1, 64, 1) > 50000 * 16
+
+
+def test_code_object_is_gfx950_only(lib_path):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", lib_path], capture_output=True, text=True)
+    txt = out.stdout + out.stderr
+    if "gfx" not in txt:
+        out = subprocess.check_output(["strings", lib_path], text=True)
+        txt = "\n".join(l for l in out.splitlines() if "amdgcn-amd-amdhsa" in l)
+    archs = set(re.findall(r"gfx[0-9a-f]+", txt))
+    assert archs == {"gfx950"}, archs
+
+
+def test_product_package_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the oracle."""
+    pkg = os.path.join(ROOT, "mccnn_amd")
+    bad = re.compile(r"(^|\s)(import\s+oracle|from\s+oracle)|liboracle|orc_[a-z]|oracle/|oracle\.oracle")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not bad.search(src), os.path.join(dp, f)
