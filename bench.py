@@ -194,8 +194,9 @@ def main():
         gws = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]
         bwd_ws = torch.empty(max(256, lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, fout, int(combin))),
                              dtype=torch.uint8, device=device)
+        # start_t / perm_t = NULL: the call builds the transposed list itself (worst case: no sharing across layers)
         t_bwd, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_bwd(*conv_args, ptr(OG), n, m, e, fin, fout, int(combin), B,
-                                                                    r, 0, 1, ptr(fg), *[ptr(g) for g in gws],
+                                                                    r, 0, 1, None, None, ptr(fg), *[ptr(g) for g in gws],
                                                                     ptr(bwd_ws), bwd_ws.numel(), stream_handle()),
                                          "conv_bwd"))
         t_s2g, _ = ev_time(lambda: M._gather_rows(fg, idx, n))

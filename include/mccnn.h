@@ -173,7 +173,8 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats,
  * Gradients w.r.t. the features and the six MLP tensors only
  * (MCConvModuleSrc:74-81).  All seven outputs are fully written; gradients of
  * padded output neurons (nu >= neuronsOut), which the reference leaves
- * uninitialised (spatial_conv.cu:921,924), are zero. */
+ * uninitialised (spatial_conv.cu:921,924), are zero. start_t / perm_t: optional transposed
+ * neighbour list (see mccnn_transpose_neighbors), used by depth-wise layers only. */
 size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_feats,
                                               int num_out_feats, int combin);
 int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats,
@@ -182,9 +183,19 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats,
                            const float* aabb_max, const float* w1, const float* b1, const float* w2,
                            const float* b2, const float* w3, const float* b3, const float* out_grad,
                            int n, int m, int e, int num_in_feats, int num_out_feats, int combin,
-                           int batch_size, float radius, int scale_inv, int avg, float* feat_grad,
-                           float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
-                           void* ws, size_t ws_bytes, mccnn_stream_t stream);
+                           int batch_size, float radius, int scale_inv, int avg, const int* start_t,
+                           const int* perm_t, float* feat_grad, float* dw1, float* db1, float* dw2,
+                           float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes,
+                           mccnn_stream_t stream);
+
+/* Transposed neighbour list (CSR by neighbour index j): start_t[n+1] and perm_t[e] = edge ids
+ * grouped by j, ascending inside a row. Depth-wise SpatialConvGrad needs it to compute the
+ * feature gradient without float atomics; pass the pair to mccnn_spatial_conv_bwd (start_t /
+ * perm_t, both may be NULL -> built internally on every call) to amortise it over the layers
+ * that share one neighbour list, as ConvolutionBuilder's caches do (MCConvBuilder.py:366-376). */
+size_t mccnn_transpose_neighbors_workspace_bytes(int n, int e);
+int mccnn_transpose_neighbors(const int* packed, int e, int n, int* start_t, int* perm_t, void* ws,
+                              size_t ws_bytes, mccnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@ Shape / attribute validation mirrors the OP_REQUIRES blocks of the reference wra
 raises InvalidArgumentError (the analogue of tf.errors.InvalidArgumentError).
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -72,6 +73,9 @@ _ORDER_HINTS = {}
 
 
 def _tensor_key(t):
+    # storage address + version: autograd hands the op a different tensor OBJECT over the same storage, so object
+    # identity cannot be used here. A recycled address can only yield a stale permutation of the same length,
+    # which is still a valid visiting order (results do not depend on it).
     return (t.data_ptr(), t._version, t.shape[0])
 
 
@@ -98,25 +102,49 @@ def _order_hint(points):
 
 
 _NUM_CELLS_CACHE = {}
+# Transposed neighbour lists (CSR by neighbour index), shared by every depth-wise layer that convolves over the same
+# neighbour list -- the counterpart of ConvolutionBuilder's cacheNeighs_ for the backward pass.
+_TRANSPOSE_CACHE = {}
+
+
+def _transposed_neighbors(packed, n):
+    key = (packed.data_ptr(), packed._version, packed.shape[0], n)
+    hit = _TRANSPOSE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    lib = _lib.load()
+    e = packed.shape[0]
+    start_t = torch.empty(n + 1, dtype=torch.int32, device=packed.device)
+    perm_t = torch.empty(max(e, 1), dtype=torch.int32, device=packed.device)
+    ws = _ws(lib.mccnn_transpose_neighbors_workspace_bytes(n, e), packed.device)
+    check(lib.mccnn_transpose_neighbors(ptr(packed), e, n, ptr(start_t), ptr(perm_t), ptr(ws), ws.numel(),
+                                        stream_handle()), "transpose_neighbors")
+    if len(_TRANSPOSE_CACHE) > 16:
+        _TRANSPOSE_CACHE.clear()
+    _TRANSPOSE_CACHE[key] = (start_t, perm_t, packed)  # keep `packed` alive: the key is its address
+    return _TRANSPOSE_CACHE[key]
 
 
 def _num_cells(aabbMin, aabbMax, batchSize, cellSize, scaleInv):
-    """determineNumCells (sort_gpu.cu:397-420). scaleInv=False costs one 24-byte read-back, cached
-    per (box tensor, version, cell size) so step1/step2 of the same grid pay it once."""
+    """determineNumCells (sort_gpu.cu:397-420). scaleInv=False costs one 24-byte read-back; it is cached per box
+    tensor OBJECT (weak reference + version counter -- never by address, the allocator recycles addresses) so that
+    step1/step2 and later grids over the same hierarchy pay it once."""
     lib = _lib.load()
     out = C.c_int(0)
     if scaleInv:
         check(lib.mccnn_num_cells(None, None, batchSize, float(cellSize), 1, C.byref(out), None), "num_cells")
         return out.value
-    key = (aabbMin.data_ptr(), aabbMin._version, aabbMax.data_ptr(), aabbMax._version, float(cellSize))
+    key = (id(aabbMin), id(aabbMax), float(cellSize))
     hit = _NUM_CELLS_CACHE.get(key)
     if hit is not None:
-        return hit
+        rmin, rmax, vmin, vmax, val = hit
+        if rmin() is aabbMin and rmax() is aabbMax and vmin == aabbMin._version and vmax == aabbMax._version:
+            return val
     check(lib.mccnn_num_cells(ptr(aabbMin), ptr(aabbMax), batchSize, float(cellSize), 0, C.byref(out),
                               stream_handle()), "num_cells")
     if len(_NUM_CELLS_CACHE) > 256:
         _NUM_CELLS_CACHE.clear()
-    _NUM_CELLS_CACHE[key] = out.value
+    _NUM_CELLS_CACHE[key] = (weakref.ref(aabbMin), weakref.ref(aabbMax), aabbMin._version, aabbMax._version, out.value)
     return out.value
 
 
@@ -470,10 +498,14 @@ class _SpatialConv(torch.autograd.Function):
         fg = torch.empty_like(feats)
         dw1, db1, dw2, db2, dw3, db3 = (torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3))
         ws = _ws(lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, numOutFeatures, int(combin)), pts.device)
+        start_t = perm_t = None
+        if not combin and e > 0:
+            start_t, perm_t, _ = _transposed_neighbors(pk, n)
         check(lib.mccnn_spatial_conv_bwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                          ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
                                          ptr(og), n, m, e, fin, numOutFeatures, int(combin), batchSize, radius,
-                                         int(scaleInv), int(avg), ptr(fg), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2),
+                                         int(scaleInv), int(avg), ptr(start_t), ptr(perm_t), ptr(fg), ptr(dw1),
+                                         ptr(db1), ptr(dw2), ptr(db2),
                                          ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
               "spatial_conv_grad")
         return (None, fg, None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,

@@ -355,7 +355,12 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(ConvArgs a, float* __restri
 
         for (int q = 0; q < a.nb; ++q) {
             float pre1[8], a1[8], pre2[8], a2[8], o[8], c[8];
+#ifdef ABL_NOMLP
+#pragma unroll
+            for (int n = 0; n < 8; ++n) o[n] = ec.d0 + n * ec.d1 + q;
+#else
             mlp_block_mfma(wl + q * MCCNN_WQ_FWD, i4, ec.d0, ec.d1, ec.d2, pre1, a1, pre2, a2, o);
+#endif
             const bool full = (q * 8 + 8 <= a.neuronsOut);
             if (FEAT == 2) {
                 const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)ec.j * a.Fin + q * 8);
@@ -374,6 +379,7 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(ConvArgs a, float* __restri
                     c[n] = (nu < a.neuronsOut) ? a.feats[(size_t)ec.j * a.Fin + fin] * o[n] * ec.inv : 0.f;
                 }
             }
+#ifndef ABL_NOSCAN
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
                 float v = c[n];
@@ -383,7 +389,13 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(ConvArgs a, float* __restri
                 v = fmaf(m8, dpp_f<DPP_ROW_SHR(8)>(v), v);
                 c[n] = v;
             }
+#endif
+#ifdef ABL_NOTAIL
+            asm volatile("" ::"v"(c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7]));
+            if (false) {
+#else
             if (tail) {
+#endif
                 if (!COMBIN || a.Fin == 1) {
                     float* dst = row + q * 8;
                     if (full) {
@@ -458,6 +470,157 @@ __global__ __launch_bounds__(256) void edge_records(ConvArgs a, float4* __restri
     float K = a.avg ? (float)(e1 - e0) : 1.0f;
     rec[t] = make_float4((p[0] - c[0]) * invR, (p[1] - c[1]) * invR, (p[2] - c[2]) * invR,
                          __builtin_amdgcn_rcpf(a.pdfs[t] * K));
+}
+
+// Forward, q-outer sweep (the default MFMA forward). The chunk-outer kernel above re-reads every weight operand
+// from LDS for every 64-edge chunk (16 ds_read_b128 per chunk and block -- the LDS pipe, not the MFMA pipe, was its
+// limiter); here one MLP block's operands are read ONCE per (wave, block) and stay in VGPRs while the wave sweeps
+// its edges, which arrive as coalesced, prefetched per-edge records (edge_records). Same centre-aligned ranges,
+// same LDS output tile, same segmented DPP reduction.
+struct BlockWeights {
+    f32x4 a1lo, a1hi, b1lo, b1hi;
+    f32x4 w2l0, w2l1, w2h0, w2h1, b2lo, b2hi;
+    f32x4 w3l0, w3l1, w3h0, w3h1, b3lo, b3hi;
+};
+__device__ __forceinline__ BlockWeights load_block_weights(const float* wq, int i4) {
+    const f32x4* w = reinterpret_cast<const f32x4*>(wq);
+    BlockWeights r;
+    r.a1lo = w[i4]; r.a1hi = w[4 + i4]; r.b1lo = w[8]; r.b1hi = w[9];
+    r.w2l0 = w[10 + 2 * i4]; r.w2l1 = w[11 + 2 * i4]; r.w2h0 = w[10 + 2 * (4 + i4)]; r.w2h1 = w[11 + 2 * (4 + i4)];
+    r.b2lo = w[26]; r.b2hi = w[27];
+    r.w3l0 = w[28 + 2 * i4]; r.w3l1 = w[29 + 2 * i4]; r.w3h0 = w[28 + 2 * (4 + i4)]; r.w3h1 = w[29 + 2 * (4 + i4)];
+    r.b3lo = w[44]; r.b3hi = w[45];
+    return r;
+}
+__device__ __forceinline__ void layer8r(f32x4 al0, f32x4 al1, f32x4 ah0, f32x4 ah1, f32x4 lo, f32x4 hi, const float* x,
+                                        float* y) {
+    float al[8] = {al0.x, al0.y, al0.z, al0.w, al1.x, al1.y, al1.z, al1.w};
+    float ah[8] = {ah0.x, ah0.y, ah0.z, ah0.w, ah1.x, ah1.y, ah1.z, ah1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        lo = MFMA4(al[k], x[k], lo);
+        hi = MFMA4(ah[k], x[k], hi);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { y[r] = lo[r]; y[4 + r] = hi[r]; }
+}
+__device__ __forceinline__ void mlp_block_regs(const BlockWeights& W, float d0, float d1, float d2, float* o) {
+    f32x4 lo = W.b1lo, hi = W.b1hi;
+    lo = MFMA4(W.a1lo.x, d0, lo);
+    hi = MFMA4(W.a1hi.x, d0, hi);
+    lo = MFMA4(W.a1lo.y, d1, lo);
+    hi = MFMA4(W.a1hi.y, d1, hi);
+    lo = MFMA4(W.a1lo.z, d2, lo);
+    hi = MFMA4(W.a1hi.z, d2, hi);
+    float a1[8], pre2[8], a2[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { a1[r] = relu1(lo[r]); a1[4 + r] = relu1(hi[r]); }
+    layer8r(W.w2l0, W.w2l1, W.w2h0, W.w2h1, W.b2lo, W.b2hi, a1, pre2);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a2[r] = relu1(pre2[r]);
+    layer8r(W.w3l0, W.w3l1, W.w3h0, W.w3h1, W.b3lo, W.b3hi, a2, o);
+}
+
+template <bool COMBIN, int FEAT>
+__global__ __launch_bounds__(256) void conv_fwd_sweep(ConvArgs a, const float4* __restrict__ rec, float* __restrict__ out) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
+    const int G = a.G, outF = a.outF;
+    float* wl = lds;
+    float* tile = lds + a.nb * MCCNN_WQ_FWD + (size_t)wave * (G * outF);
+    stage_weights<MCCNN_WQ_FWD>(a, wl);
+    const int c0 = (blockIdx.x * 4 + wave) * G;
+    const int c1 = min(c0 + G, a.m);
+    if (c0 < a.m)
+        for (int k = lane; k < G * outF; k += 64) tile[k] = 0.0f;
+    __syncthreads();
+    if (c0 >= a.m) return;
+    const int eBeg = a.start[c0];
+    const int eEnd = (c1 < a.m) ? a.start[c1] : a.e;
+
+    for (int q = 0; q < a.nb; ++q) {
+        const BlockWeights W = load_block_weights(wl + q * MCCNN_WQ_FWD, i4);
+        const bool full = (q * 8 + 8 <= a.neuronsOut);
+        int2 prN = make_int2(0, c0);
+        float4 rcN = make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            int t0 = min(eBeg + lane, a.e - 1);
+            prN = a.packed[t0];
+            rcN = rec[t0];
+        }
+        for (int base = eBeg; base < eEnd; base += 64) {
+            const int t = base + lane;
+            const bool act = t < eEnd;
+            const int2 pr = prN;
+            const float4 rc = rcN;
+            const int j = pr.x;
+            const float inv = act ? rc.w : 0.f;
+            // this chunk's gathers first, then the prefetch (vmcnt retires in order)
+            float s[8];
+            if (FEAT == 1) {
+                float f1 = a.feats[j] * inv;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) s[n] = f1;
+            } else if (FEAT == 2) {
+                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)j * a.Fin + q * 8);
+                float4 fa = fp[0], fb = fp[1];
+                s[0] = fa.x * inv; s[1] = fa.y * inv; s[2] = fa.z * inv; s[3] = fa.w * inv;
+                s[4] = fb.x * inv; s[5] = fb.y * inv; s[6] = fb.z * inv; s[7] = fb.w * inv;
+            } else {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    int nu = q * 8 + n;
+                    s[n] = (nu < a.neuronsOut) ? a.feats[(size_t)j * a.Fin + nu % a.Fin] * inv : 0.f;
+                }
+            }
+            {
+                int tn = min(t + 64, a.e - 1);  // clamped: keeps the prefetch branch-free
+                prN = a.packed[tn];
+                rcN = rec[tn];
+            }
+            const int key1 = act ? (pr.y - c0 + 1) : 0;  // 0 = no edge
+            const float m1 = (key1 != 0 && dpp_i<DPP_ROW_SHR(1)>(key1) == key1) ? 1.f : 0.f;
+            const float m2 = (key1 != 0 && dpp_i<DPP_ROW_SHR(2)>(key1) == key1) ? 1.f : 0.f;
+            const float m4 = (key1 != 0 && dpp_i<DPP_ROW_SHR(4)>(key1) == key1) ? 1.f : 0.f;
+            const float m8 = (key1 != 0 && dpp_i<DPP_ROW_SHR(8)>(key1) == key1) ? 1.f : 0.f;
+            const bool tail = act && (dpp_i<DPP_ROW_SHL(1)>(key1) != key1);
+            float o[8], c[8];
+            mlp_block_regs(W, rc.x, rc.y, rc.z, o);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                float v = s[n] * o[n];
+                v = fmaf(m1, dpp_f<DPP_ROW_SHR(1)>(v), v);
+                v = fmaf(m2, dpp_f<DPP_ROW_SHR(2)>(v), v);
+                v = fmaf(m4, dpp_f<DPP_ROW_SHR(4)>(v), v);
+                v = fmaf(m8, dpp_f<DPP_ROW_SHR(8)>(v), v);
+                c[n] = v;
+            }
+            if (tail) {
+                float* row = tile + (size_t)(key1 - 1) * outF;
+                if (!COMBIN || a.Fin == 1) {
+                    float* dst = row + q * 8;
+                    if (full) {
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) atomicAdd(&dst[n], c[n]);  // ds_add_f32, wave-private tile
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < 8; ++n)
+                            if (q * 8 + n < a.neuronsOut) atomicAdd(&dst[n], c[n]);
+                    }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) {
+                        int nu = q * 8 + n;
+                        if (nu < a.neuronsOut) atomicAdd(&row[nu / a.Fin], c[n]);
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int cnt = (c1 - c0) * outF;
+    float* dst = out + (size_t)c0 * outF;
+    for (int k = lane; k < cnt; k += 64) dst[k] = tile[k];
 }
 
 #ifndef MCCNN_BWD_OCC
@@ -564,7 +727,12 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
             const f32x4* w4 = reinterpret_cast<const f32x4*>(wq);
             {
                 float pre1[8], pre2[8];
+#ifdef ABL_NOMLPB
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { pre1[k] = rc.x + k; pre2[k] = rc.y - k; a1[k] = pre1[k]; a2[k] = pre2[k]; o[k] = rc.z * k; }
+#else
                 mlp_block_mfma(wq, i4, rc.x, rc.y, rc.z, pre1, a1, pre2, a2, o);
+#endif
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { p1[k] = pre1[k] >= 0.0f; p2[k] = pre2[k] >= 0.0f; }
             }
@@ -599,16 +767,12 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
                         }
                     }
                 }
-            } else if (act) {
-                float* fgp = featGrad + (size_t)j * a.Fin + q * 8;
-#pragma unroll
-                for (int n = 0; n < 8; ++n)
-                    if (n < numOuts) atomicAdd(&fgp[n], g[n] * o[n] * inv);
-            }
+            }  // depth-wise layers: the feature gradient is computed by conv_dfeat_dw on the transposed list
             float gf[8];
 #pragma unroll
             for (int n = 0; n < 8; ++n) gf[n] = g[n] * ff[n];
             // dW3 += u a2^T, db3 += u, u = g f / (pdf K)          (spatial_conv.cu:383-399)
+#ifndef ABL_NOWG
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
                 float u = gf[n] * inv;
@@ -616,21 +780,38 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
                 for (int k = 0; k < 8; ++k) gw3[n * 8 + k] = fmaf(u, a2[k], gw3[n * 8 + k]);
                 gb3[n] += u;
             }
+#else
+            gw3[0] += a2[0] + a2[1] + a2[2] + a2[3] + a2[4] + a2[5] + a2[6] + a2[7];
+#endif
             // t3 = 1[pre2 >= 0] * W3^T (g f) / (pdf K)             (:403-414)
             float t3[8];
+#ifdef ABL_NOT34
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t3[k] = gf[k];
+#else
             layer8(w4 + 62, zero4, zero4, i4, gf, t3);  // W3^T rows at float 248 -> f32x4 index 62
+#endif
 #pragma unroll
             for (int k = 0; k < 8; ++k) t3[k] = p2[k] ? t3[k] * inv : 0.f;
             // dW2 += t3 a1^T, db2 += t3                            (:419-425)
+#ifndef ABL_NOWG
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
 #pragma unroll
                 for (int l = 0; l < 8; ++l) gw2[k * 8 + l] = fmaf(t3[k], a1[l], gw2[k * 8 + l]);
                 gb2[k] += t3[k];
             }
+#else
+            gw2[0] += a1[0] + a1[1] + a1[2] + a1[3] + a1[4] + a1[5] + a1[6] + a1[7];
+#endif
             // t4 = 1[pre1 >= 0] * W2^T t3                          (:428-434)
             float t4[8];
+#ifdef ABL_NOT34
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t4[k] = t3[k];
+#else
             layer8(w4 + 46, zero4, zero4, i4, t3, t4);  // W2^T rows at float 184 -> f32x4 index 46
+#endif
             // dW1 += t4 delta^T, db1 += t4                         (:439-444)
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
@@ -663,6 +844,352 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Backward, all-MFMA version (default). Same sweep structure as conv_bwd_mfma, but the weight-gradient outer
+// products also run on the matrix pipe, so the 176 VGPR accumulators (and their spills / 2-wave occupancy)
+// disappear. In the MLP chains a lane is an edge; for the outer products a QUAD is an edge:
+//     D[lane 4b+j][reg r] += A(lane 4b+r) * B(lane 4b+j)
+// with A = u_e[r], B = a2_e[j] is exactly the 4x4 tile (rows r, cols j) of u_e a2_e^T for the edge e of quad b,
+// accumulated over time = over edges. The per-lane vectors (u, a2, t3, a1, t4, [delta,1]) go through a small
+// wave-private LDS buffer (32 edges at a time, row stride 12 floats: conflict-free for the b128 writes and the
+// quad-layout b32 reads) to change layout. 14 accumulator tiles per block:
+//   dW3 (4) db3 (2, B = 1) dW2 (4) db2 (2) [dW1 | db1] (2, B = [delta, 1])  -> 56 MFMAs per 64 edges.
+// Per (wave, block) the 16 quads' tiles are summed with 4 xor-shuffles per register.
+// ---------------------------------------------------------------------------------------
+#define MCCNN_XROW 12                    // floats per 8-vector row in the transposition buffer
+#define MCCNN_XBUF (32 * (5 * MCCNN_XROW + 4))  // floats per wave: 32 edges x (u, a2, t3, a1, t4 rows + [delta,1])
+
+template <bool COMBIN, int FEAT>
+__global__ __launch_bounds__(256) void conv_bwd_mfma2(ConvArgs a, const float4* __restrict__ rec,
+                                                      const float* __restrict__ outGrad, float* __restrict__ featGrad,
+                                                      float* __restrict__ dfE, int cpw, float* __restrict__ partials) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3, quad = lane >> 2;
+    const int outF = a.outF;
+    float* wl = lds;
+    float* xb = lds + a.nb * MCCNN_WQ_BWD + wave * MCCNN_XBUF;
+    stage_weights<MCCNN_WQ_BWD>(a, wl);
+    __syncthreads();
+    const int waveGlobal = blockIdx.x * 4 + wave;
+    const long long eBegL = (long long)waveGlobal * cpw * 64;
+    if (eBegL >= a.e) return;
+    const int eBeg = (int)eBegL;
+    const int eEnd = (int)min((long long)a.e, eBegL + (long long)cpw * 64);
+    float* prow = partials + (size_t)waveGlobal * a.nb * 176;
+    // transposition buffer addressing
+    float* xw = xb + (lane & 31) * MCCNN_XROW;           // my row when I write (edge = lane & 31)
+    float* xdw = xb + 5 * 32 * MCCNN_XROW + (lane & 31) * 4;
+    const int VEC = 32 * MCCNN_XROW;                     // floats between the 5 vector planes
+
+    for (int q = 0; q < a.nb; ++q) {
+        f32x4 acc[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int numOuts = min(a.neuronsOut - q * 8, 8);
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+        int2 prN;
+        float4 rcN;
+        {
+            int t0 = min(eBeg + lane, a.e - 1);
+            prN = a.packed[t0];
+            rcN = rec[t0];
+        }
+        for (int base = eBeg; base < eEnd; base += 64) {
+            const int t = base + lane;
+            const bool act = t < eEnd;
+            const int2 pr = prN;
+            const float4 rc = rcN;
+            const int j = pr.x;
+            const float inv = act ? rc.w : 0.f;
+            // g_n and f_n first: the gathers fly while the MFMA chains run
+            float g[8], ff[8];
+            const float* grow = outGrad + (size_t)pr.y * outF;
+            if (FEAT == 2) {
+                const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
+                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)j * a.Fin + q * 8);
+                float4 ga = gp[0], gb = gp[1], fa = fp[0], fb = fp[1];
+                float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+                float f8[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+#pragma unroll
+                for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; ff[n] = f8[n]; }
+            } else if (FEAT == 1) {
+                float f = a.feats[j];
+                if (numOuts == 8 && (outF & 3) == 0) {
+                    const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
+                    float4 ga = gp[0], gb = gp[1];
+                    float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; ff[n] = f; }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) { g[n] = (act && n < numOuts) ? grow[q * 8 + n] : 0.f; ff[n] = f; }
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    int nu = q * 8 + n;
+                    int fin = COMBIN ? nu % a.Fin : nu;
+                    int fo = COMBIN ? nu / a.Fin : nu;
+                    bool ok = act && n < numOuts;
+                    g[n] = ok ? grow[fo] : 0.f;
+                    ff[n] = ok ? a.feats[(size_t)j * a.Fin + fin] : 0.f;
+                }
+            }
+            float dfOld = 0.f;
+            if (COMBIN && FEAT == 1 && act && q > 0) dfOld = dfE[t];
+            {
+                int tn = min(t + 64, a.e - 1);  // clamped: the prefetch stays branch-free
+                prN = a.packed[tn];
+                rcN = rec[tn];
+            }
+            float a1[8], a2[8], o[8];
+            bool p1[8], p2[8];
+            // keep the LDS weight reads inside the chunk loop (hoisted they would pin ~100 VGPRs)
+            int woff = q * MCCNN_WQ_BWD;
+            asm volatile("" : "+s"(woff));
+            const float* wq = wl + woff;
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(wq);
+            {
+                float pre1[8], pre2[8];
+                mlp_block_mfma(wq, i4, rc.x, rc.y, rc.z, pre1, a1, pre2, a2, o);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { p1[k] = pre1[k] >= 0.0f; p2[k] = pre2[k] >= 0.0f; }
+            }
+            // feature gradient: og * o / (pdf K)   (spatial_conv.cu:400)
+            if (COMBIN) {
+                if (FEAT == 1) {
+                    float sfg = 0.f;
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) sfg = fmaf(g[n], o[n], sfg);
+                    if (act) dfE[t] = dfOld + sfg * inv;  // this lane owns edge t: plain RMW, no atomics
+                } else if (act) {
+                    for (int f = 0; f < a.Fin; ++f) {
+                        float sfg = 0.f;
+                        bool any = false;
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) {
+                            int nu = q * 8 + n;
+                            if (n < numOuts && nu % a.Fin == f) { sfg = fmaf(g[n], o[n], sfg); any = true; }
+                        }
+                        if (any) {
+                            float* d = dfE + (size_t)t * a.Fin + f;
+                            // first touch of (t, f) happens in the block that holds neuron nu == f, i.e. q == f / 8
+                            float old = (q == f / 8) ? 0.f : *d;
+                            *d = old + sfg * inv;
+                        }
+                    }
+                }
+            }  // depth-wise layers: the feature gradient is computed by conv_dfeat_dw on the transposed list
+            float gf[8], u[8], t3[8], t4[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) { gf[n] = g[n] * ff[n]; u[n] = gf[n] * inv; }
+            layer8(w4 + 62, zero4, zero4, i4, gf, t3);  // t3 = 1[pre2>=0] W3^T (g f) / (pdf K)   (:403-414)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t3[k] = p2[k] ? t3[k] * inv : 0.f;
+            layer8(w4 + 46, zero4, zero4, i4, t3, t4);  // t4 = 1[pre1>=0] W2^T t3                  (:428-434)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t4[k] = p1[k] ? t4[k] : 0.f;
+
+            // ---- outer products on the matrix pipe, 32 edges per pass through the transposition buffer
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if ((lane >> 5) == half) {
+                    f32x4* d = reinterpret_cast<f32x4*>(xw);
+                    d[0] = (f32x4){u[0], u[1], u[2], u[3]};
+                    d[1] = (f32x4){u[4], u[5], u[6], u[7]};
+                    d = reinterpret_cast<f32x4*>(xw + VEC);
+                    d[0] = (f32x4){a2[0], a2[1], a2[2], a2[3]};
+                    d[1] = (f32x4){a2[4], a2[5], a2[6], a2[7]};
+                    d = reinterpret_cast<f32x4*>(xw + 2 * VEC);
+                    d[0] = (f32x4){t3[0], t3[1], t3[2], t3[3]};
+                    d[1] = (f32x4){t3[4], t3[5], t3[6], t3[7]};
+                    d = reinterpret_cast<f32x4*>(xw + 3 * VEC);
+                    d[0] = (f32x4){a1[0], a1[1], a1[2], a1[3]};
+                    d[1] = (f32x4){a1[4], a1[5], a1[6], a1[7]};
+                    d = reinterpret_cast<f32x4*>(xw + 4 * VEC);
+                    d[0] = (f32x4){t4[0], t4[1], t4[2], t4[3]};
+                    d[1] = (f32x4){t4[4], t4[5], t4[6], t4[7]};
+                    *reinterpret_cast<f32x4*>(xdw) = (f32x4){rc.x, rc.y, rc.z, 1.0f};
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int sgrp = 0; sgrp < 2; ++sgrp) {
+                    const float* xr = xb + (sgrp * 16 + quad) * MCCNN_XROW + i4;  // row of my quad's edge, my component
+                    float ul = xr[0], uh = xr[4];
+                    float a2l = xr[VEC], a2h = xr[VEC + 4];
+                    float t3l = xr[2 * VEC], t3h = xr[2 * VEC + 4];
+                    float a1l = xr[3 * VEC], a1h = xr[3 * VEC + 4];
+                    float t4l = xr[4 * VEC], t4h = xr[4 * VEC + 4];
+                    float dl = xb[5 * 32 * MCCNN_XROW + (sgrp * 16 + quad) * 4 + i4];
+                    acc[0] = MFMA4(ul, a2l, acc[0]);
+                    acc[1] = MFMA4(ul, a2h, acc[1]);
+                    acc[2] = MFMA4(uh, a2l, acc[2]);
+                    acc[3] = MFMA4(uh, a2h, acc[3]);
+                    acc[4] = MFMA4(ul, 1.0f, acc[4]);
+                    acc[5] = MFMA4(uh, 1.0f, acc[5]);
+                    acc[6] = MFMA4(t3l, a1l, acc[6]);
+                    acc[7] = MFMA4(t3l, a1h, acc[7]);
+                    acc[8] = MFMA4(t3h, a1l, acc[8]);
+                    acc[9] = MFMA4(t3h, a1h, acc[9]);
+                    acc[10] = MFMA4(t3l, 1.0f, acc[10]);
+                    acc[11] = MFMA4(t3h, 1.0f, acc[11]);
+                    acc[12] = MFMA4(t4l, dl, acc[12]);
+                    acc[13] = MFMA4(t4h, dl, acc[13]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // sum the 16 quads' tiles; afterwards every quad holds the totals, lanes 0..3 store them
+#pragma unroll
+        for (int k = 0; k < 14; ++k) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[k][r];
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64);
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                acc[k][r] = v;
+            }
+        }
+        if (lane < 4) {
+            float* pq = prow + q * 176;  // w1[24] b1[8] w2[64] b2[8] w3[64] b3[8]
+            const int jc = lane;         // column index of the tiles
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pq[104 + r * 8 + jc] = acc[0][r];            // dW3[n=r][m=jc]
+                pq[104 + r * 8 + 4 + jc] = acc[1][r];        // dW3[r][4+jc]
+                pq[104 + (4 + r) * 8 + jc] = acc[2][r];      // dW3[4+r][jc]
+                pq[104 + (4 + r) * 8 + 4 + jc] = acc[3][r];  // dW3[4+r][4+jc]
+                pq[32 + r * 8 + jc] = acc[6][r];             // dW2[k=r][l=jc]
+                pq[32 + r * 8 + 4 + jc] = acc[7][r];
+                pq[32 + (4 + r) * 8 + jc] = acc[8][r];
+                pq[32 + (4 + r) * 8 + 4 + jc] = acc[9][r];
+                if (jc < 3) {
+                    pq[r * 3 + jc] = acc[12][r];             // dW1[l=r][d=jc]
+                    pq[(4 + r) * 3 + jc] = acc[13][r];
+                } else {
+                    pq[24 + r] = acc[12][r];                 // db1[l=r] (B column 3 is the constant 1)
+                    pq[24 + 4 + r] = acc[13][r];
+                }
+                if (jc == 0) {
+                    pq[168 + r] = acc[4][r];                 // db3
+                    pq[168 + 4 + r] = acc[5][r];
+                    pq[96 + r] = acc[10][r];                 // db2
+                    pq[96 + 4 + r] = acc[11][r];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Transposed neighbour list (CSR by neighbour j) and the depth-wise feature gradient.
+//   featGrad[j, nu] = sum over edges e=(j,i) of outGrad[i, nu] * o_e[nu] / (pdf_e K_i)     (spatial_conv.cu:400)
+// is the forward convolution with the roles of centres and neighbours swapped, so it runs through the same
+// MFMA + segmented-reduction machinery on the transposed list: rows are written once, no float atomics
+// (the reference -- and the first version here -- scatter one atomic per (edge, feature): E*Fin of them).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tr_count(const int2* __restrict__ packed, int e, int* __restrict__ cnt,
+                                                int* __restrict__ slot) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < e) slot[t] = atomicAdd(&cnt[packed[t].x], 1);
+}
+__global__ __launch_bounds__(256) void tr_fill(const int2* __restrict__ packed, int e, const int* __restrict__ startT,
+                                               const int* __restrict__ slot, int* __restrict__ tmp) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < e) tmp[startT[packed[t].x] + slot[t]] = t;
+}
+// stable order inside a row: ascending edge id (the arrival order above is arbitrary)
+__global__ __launch_bounds__(256) void tr_rank(const int2* __restrict__ packed, int e, const int* __restrict__ startT,
+                                               const int* __restrict__ tmp, int* __restrict__ permT) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= e) return;
+    int j = packed[t].x;
+    int s0 = startT[j], s1 = startT[j + 1];
+    int r = 0;
+    for (int p = s0; p < s1; ++p) r += (tmp[p] < t) ? 1 : 0;
+    permT[s0 + r] = t;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void conv_dfeat_dw(ConvArgs a, const float4* __restrict__ rec,
+                                                     const int* __restrict__ startT, const int* __restrict__ permT,
+                                                     const float* __restrict__ outGrad, float* __restrict__ featGrad) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
+    const int G = a.G, F = a.Fin;
+    float* wl = lds;
+    float* tile = lds + a.nb * MCCNN_WQ_FWD + (size_t)wave * (G * F);
+    stage_weights<MCCNN_WQ_FWD>(a, wl);
+    const int r0 = (blockIdx.x * 4 + wave) * G;
+    const int r1 = min(r0 + G, a.n);
+    if (r0 < a.n)
+        for (int k = lane; k < G * F; k += 64) tile[k] = 0.0f;
+    __syncthreads();
+    if (r0 >= a.n) return;
+    const int eBeg = startT[r0], eEnd = startT[r1];
+
+    int eN = permT[min(eBeg + lane, a.e - 1)];
+    for (int base = eBeg; base < eEnd; base += 64) {
+        const int t = base + lane;
+        const bool act = t < eEnd;
+        const int e = eN;
+        const float4 rc = rec[e];
+        const int2 pr = a.packed[e];
+        eN = permT[min(t + 64, a.e - 1)];
+        const float inv = act ? rc.w : 0.f;
+        const float* grow = outGrad + (size_t)pr.y * F;
+        const int key1 = act ? (pr.x - r0 + 1) : 0;
+        const float m1 = (key1 != 0 && dpp_i<DPP_ROW_SHR(1)>(key1) == key1) ? 1.f : 0.f;
+        const float m2 = (key1 != 0 && dpp_i<DPP_ROW_SHR(2)>(key1) == key1) ? 1.f : 0.f;
+        const float m4 = (key1 != 0 && dpp_i<DPP_ROW_SHR(4)>(key1) == key1) ? 1.f : 0.f;
+        const float m8 = (key1 != 0 && dpp_i<DPP_ROW_SHR(8)>(key1) == key1) ? 1.f : 0.f;
+        const bool tail = act && (dpp_i<DPP_ROW_SHL(1)>(key1) != key1);
+        float* row = tile + (size_t)(key1 - 1) * F;
+        for (int q = 0; q < a.nb; ++q) {
+            float pre1[8], a1[8], pre2[8], a2[8], o[8], c[8];
+            mlp_block_mfma(wl + q * MCCNN_WQ_FWD, i4, rc.x, rc.y, rc.z, pre1, a1, pre2, a2, o);
+            const bool full = (q * 8 + 8 <= F);
+            if (VEC) {
+                const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
+                float4 ga = gp[0], gb = gp[1];
+                float g[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+                for (int n = 0; n < 8; ++n) c[n] = (g[n] * inv) * o[n];
+            } else {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) c[n] = (q * 8 + n < F) ? grow[q * 8 + n] * inv * o[n] : 0.f;
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                float v = c[n];
+                v = fmaf(m1, dpp_f<DPP_ROW_SHR(1)>(v), v);
+                v = fmaf(m2, dpp_f<DPP_ROW_SHR(2)>(v), v);
+                v = fmaf(m4, dpp_f<DPP_ROW_SHR(4)>(v), v);
+                v = fmaf(m8, dpp_f<DPP_ROW_SHR(8)>(v), v);
+                c[n] = v;
+            }
+            if (tail) {
+                float* dst = row + q * 8;
+                if (full) {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) atomicAdd(&dst[n], c[n]);  // ds_add_f32, wave-private tile
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n)
+                        if (q * 8 + n < F) atomicAdd(&dst[n], c[n]);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int cnt = (r1 - r0) * F;
+    float* dst = featGrad + (size_t)r0 * F;
+    for (int k = lane; k < cnt; k += 64) dst[k] = tile[k];
+}
+
 // combin layers: featGrad[j, f] += dfE[e, f] (one atomic per edge and input feature)
 __global__ __launch_bounds__(256) void scatter_edge_featgrad(const int2* __restrict__ packed, const float* __restrict__ dfE,
                                                              long long total, int Fin, float* __restrict__ featGrad) {
@@ -678,14 +1205,23 @@ __global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__
                                                        float* __restrict__ dw1, float* __restrict__ db1,
                                                        float* __restrict__ dw2, float* __restrict__ db2,
                                                        float* __restrict__ dw3, float* __restrict__ db3) {
+    // 16 consecutive parameters x 16 row slices per workgroup; 4 independent accumulators keep loads in flight
     __shared__ float acc[16][17];
     const int K = nb * 176;
     const int kk = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int k = blockIdx.x * 16 + kk;
-    float s = 0.f;
-    if (k < K)
-        for (int w = sl; w < numWaves; w += 16) s += partials[(size_t)w * K + k];
-    acc[sl][kk] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (k < K) {
+        int w = sl;
+        for (; w + 48 < numWaves; w += 64) {
+            s0 += partials[(size_t)w * K + k];
+            s1 += partials[(size_t)(w + 16) * K + k];
+            s2 += partials[(size_t)(w + 32) * K + k];
+            s3 += partials[(size_t)(w + 48) * K + k];
+        }
+        for (; w < numWaves; w += 16) s0 += partials[(size_t)w * K + k];
+    }
+    acc[sl][kk] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sl == 0 && k < K) {
         float v = 0.f;
@@ -850,7 +1386,10 @@ using namespace mccnn;
 
 extern "C" {
 
-size_t mccnn_spatial_conv_fwd_workspace_bytes(int, int, int, int, int) { return 0; }
+size_t mccnn_spatial_conv_fwd_workspace_bytes(int m, int e, int num_in_feats, int num_out_feats, int combin) {
+    (void)m; (void)num_in_feats; (void)num_out_feats; (void)combin;
+    return e > 0 ? align_up((size_t)e * sizeof(float4)) + 256 : 256;  // per-edge records
+}
 
 static bool use_mfma(const ConvArgs& a) { return a.nb <= MCCNN_LDS_MAX_NB && !getenv("MCCNN_FORCE_VALU"); }
 
@@ -860,7 +1399,6 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
                            const float* w2, const float* b2, const float* w3, const float* b3, int n, int m, int e,
                            int num_in_feats, int num_out_feats, int combin, int batch_size, float radius,
                            int scale_inv, int avg, float* out, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
-    (void)ws; (void)ws_bytes;
     ConvArgs a;
     int rc = fill_args(a, sorted_pts, sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min,
                        aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_in_feats, num_out_feats, combin, batch_size,
@@ -870,6 +1408,30 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     if (!out) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats) & 15) == 0);
+    if (use_mfma(a) && e > 0 && getenv("MCCNN_FWD_SWEEP")) {  // experimental, slower for short per-wave ranges
+        int G = 1024 / a.outF;
+        if (G > 16) G = 16;
+        if (G < 1) G = 1;
+        a.G = G;
+        size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * ((size_t)G * a.outF)) * sizeof(float);
+        if (lds <= 64 * 1024) {
+            if (!ws || ws_bytes < mccnn_spatial_conv_fwd_workspace_bytes(m, e, num_in_feats, num_out_feats, combin))
+                return MCCNN_E_WORKSPACE;
+            float4* rec = (float4*)ws;
+            edge_records<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
+            MCCNN_LAUNCHED();
+            int blocks = ceil_div(m, 4 * G);
+            if (combin) {
+                if (a.Fin == 1) conv_fwd_sweep<true, 1><<<blocks, 256, lds, s>>>(a, rec, out);
+                else conv_fwd_sweep<true, 0><<<blocks, 256, lds, s>>>(a, rec, out);
+            } else {
+                if (vec) conv_fwd_sweep<false, 2><<<blocks, 256, lds, s>>>(a, rec, out);
+                else conv_fwd_sweep<false, 0><<<blocks, 256, lds, s>>>(a, rec, out);
+            }
+            MCCNN_LAUNCHED();
+            return 0;
+        }
+    }
     if (use_mfma(a)) {
         // G centres per wave: LDS tile of G*outF floats per wave, <= 4 KB
         int G = 1024 / a.outF;
@@ -908,7 +1470,9 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     return 0;
 }
 
+#ifndef MCCNN_BWD_WAVES
 #define MCCNN_BWD_WAVES 2048    // 256 CUs x 4 SIMDs x 2 resident waves
+#endif
 #define MCCNN_BWD_MIN_CHUNKS 8  // amortises the per-(wave, block) reduction of the 176 partial sums
 
 static void bwd_partition(int e, int& cpw, int& waves) {
@@ -919,8 +1483,42 @@ static void bwd_partition(int e, int& cpw, int& waves) {
     if (waves < 1) waves = 1;
 }
 
+size_t mccnn_transpose_neighbors_workspace_bytes(int n, int e) {
+    if (n <= 0 || e <= 0) return 256;
+    return align_up((size_t)n * 4) + 2 * align_up((size_t)e * 4) + scan_workspace_bytes(n) + 256;
+}
+
+int mccnn_transpose_neighbors(const int* packed, int e, int n, int* start_t, int* perm_t, void* ws, size_t ws_bytes,
+                              mccnn_stream_t stream) {
+    if (e < 0 || n < 0 || !start_t) return MCCNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (e == 0 || n == 0) {
+        MCCNN_HIP(hipMemsetAsync(start_t, 0, (size_t)(n + 1) * sizeof(int), s));
+        return 0;
+    }
+    if (!packed || !perm_t) return MCCNN_E_BADARG;
+    if (!ws || ws_bytes < mccnn_transpose_neighbors_workspace_bytes(n, e)) return MCCNN_E_WORKSPACE;
+    Arena ar(ws, ws_bytes);
+    int* cnt = ar.take<int>((size_t)n);
+    int* slot = ar.take<int>((size_t)e);
+    int* tmp = ar.take<int>((size_t)e);
+    void* scanws = ar.take<char>(scan_workspace_bytes(n));
+    if (!cnt || !slot || !tmp || !scanws) return MCCNN_E_WORKSPACE;
+    const int2* pk = reinterpret_cast<const int2*>(packed);
+    MCCNN_HIP(hipMemsetAsync(cnt, 0, (size_t)n * sizeof(int), s));
+    tr_count<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, cnt, slot);
+    MCCNN_LAUNCHED();
+    int rc = exclusive_scan_i32(cnt, start_t, n, start_t + n, scanws, s);
+    if (rc) return rc;
+    tr_fill<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, start_t, slot, tmp);
+    MCCNN_LAUNCHED();
+    tr_rank<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, start_t, tmp, perm_t);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
 size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_feats, int num_out_feats, int combin) {
-    (void)n; (void)m;
+    (void)m;
     if (e <= 0 || num_in_feats <= 0 || num_out_feats <= 0) return 256;
     long long neurons = combin ? (long long)num_in_feats * num_out_feats : num_in_feats;
     long long nb = (neurons + 7) / 8;
@@ -929,6 +1527,8 @@ size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_fe
     size_t bytes = align_up((size_t)(((long long)waves + 3) / 4 * 4 * nb * 176) * sizeof(float));  // partial rows
     bytes += align_up((size_t)e * sizeof(float4));                                                // edge records
     if (combin) bytes += align_up((size_t)e * num_in_feats * sizeof(float));                      // per-edge dFeat
+    else bytes += align_up((size_t)(n + 1) * 4) + align_up((size_t)e * 4) +                       // start_t, perm_t
+                  mccnn_transpose_neighbors_workspace_bytes(n, e);
     return bytes + 256;
 }
 
@@ -937,8 +1537,9 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
                            const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
                            const float* w2, const float* b2, const float* w3, const float* b3, const float* out_grad,
                            int n, int m, int e, int num_in_feats, int num_out_feats, int combin, int batch_size,
-                           float radius, int scale_inv, int avg, float* feat_grad, float* dw1, float* db1, float* dw2,
-                           float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+                           float radius, int scale_inv, int avg, const int* start_t, const int* perm_t,
+                           float* feat_grad, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
+                           void* ws, size_t ws_bytes, mccnn_stream_t stream) {
     ConvArgs a;
     int rc = fill_args(a, sorted_pts, sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min,
                        aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_in_feats, num_out_feats, combin, batch_size,
@@ -947,10 +1548,14 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
     if (!dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3 || (n > 0 && !feat_grad)) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     size_t nn = (size_t)a.nb * 8;
-    if (n > 0) MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * sizeof(float), s));
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats | (uintptr_t)out_grad) & 15) == 0);
     size_t lds = ((size_t)a.nb * MCCNN_WQ_BWD + 4 * 192) * sizeof(float);
     bool mfma = use_mfma(a) && lds <= 64 * 1024 && m > 0 && e > 0;
+    // depth-wise MFMA path writes every feat_grad row itself (conv_dfeat_dw); everything else accumulates into it
+    int Gd = 1024 / a.Fin; if (Gd > 16) Gd = 16; if (Gd < 1) Gd = 1;
+    size_t ldsD = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * ((size_t)Gd * a.Fin)) * sizeof(float);
+    bool dfeatT = mfma && !combin && ldsD <= 64 * 1024;
+    if (n > 0 && !dfeatT) MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * sizeof(float), s));
     if (!mfma || m == 0 || e == 0) {
         MCCNN_HIP(hipMemsetAsync(dw1, 0, 3 * nn * sizeof(float), s));
         MCCNN_HIP(hipMemsetAsync(db1, 0, nn * sizeof(float), s));
@@ -975,7 +1580,16 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
         a.G = 0;
         edge_records<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
         MCCNN_LAUNCHED();
-        if (combin) {
+        size_t lds2 = ((size_t)a.nb * MCCNN_WQ_BWD + 4 * MCCNN_XBUF) * sizeof(float);
+        if (lds2 <= 64 * 1024 && getenv("MCCNN_BWD_ALL_MFMA")) {  // experimental: outer products on the matrix pipe too
+            if (combin) {
+                if (a.Fin == 1) conv_bwd_mfma2<true, 1><<<blocks, 256, lds2, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+                else conv_bwd_mfma2<true, 0><<<blocks, 256, lds2, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+            } else {
+                if (vec) conv_bwd_mfma2<false, 2><<<blocks, 256, lds2, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+                else conv_bwd_mfma2<false, 0><<<blocks, 256, lds2, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+            }
+        } else if (combin) {
             if (a.Fin == 1) conv_bwd_mfma<true, 1><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
             else conv_bwd_mfma<true, 0><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
         } else {
@@ -990,6 +1604,26 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
             long long total = (long long)e * a.Fin;
             scatter_edge_featgrad<<<ceil_div(total, 256), 256, 0, s>>>(a.packed, dfE, total, a.Fin, feat_grad);
             MCCNN_LAUNCHED();
+        } else if (dfeatT) {
+            if (!start_t || !perm_t) {  // not supplied by the caller: build the transposed list here
+                int* st = ar.take<int>((size_t)n + 1);
+                int* pt = ar.take<int>((size_t)e);
+                size_t tb = mccnn_transpose_neighbors_workspace_bytes(n, e);
+                void* tws = ar.take<char>(tb);
+                if (!st || !pt || !tws) return MCCNN_E_WORKSPACE;
+                int rc2 = mccnn_transpose_neighbors(packed, e, n, st, pt, tws, tb, stream);
+                if (rc2) return rc2;
+                start_t = st;
+                perm_t = pt;
+            }
+            a.G = Gd;
+            int blocksD = ceil_div(n, 4 * Gd);
+            bool vecD = (a.Fin % 8 == 0) && ((((uintptr_t)out_grad) & 15) == 0);
+            if (vecD) conv_dfeat_dw<true><<<blocksD, 256, ldsD, s>>>(a, rec, start_t, perm_t, out_grad, feat_grad);
+            else conv_dfeat_dw<false><<<blocksD, 256, ldsD, s>>>(a, rec, start_t, perm_t, out_grad, feat_grad);
+            MCCNN_LAUNCHED();
+        } else {
+            return MCCNN_E_TOOLARGE;  // unreachable: the depth-wise tile always fits for nb <= MCCNN_LDS_MAX_NB
         }
         return 0;
     }
