@@ -92,11 +92,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU; MCCNN_BENCH_BACKEND=gloo lets several ranks share one GPU (single-GPU smoke test of the
+    # N > 1 code path only -- the real runs use nccl == RCCL over xGMI)
+    backend = os.environ.get("MCCNN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     if world != args.gpus:
         log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
 
@@ -123,6 +131,8 @@ def main():
     builder = ConvolutionBuilder(KDEWindow=args.window, relativeRadius=False)
     torch.manual_seed(1234)  # identical kernel-MLP weights on every rank
 
+    state = {"bucket": None}
+
     def step():
         builder.reset()
         F.grad = None
@@ -132,11 +142,12 @@ def main():
                                          multiFeatureConv=combin, KDEWindow=args.window)
         out.backward(OG)
         if world > 1:
-            bucket.allreduce()
+            if state["bucket"] is None:  # the variables exist after the first create_convolution
+                state["bucket"] = GradBucket(builder.parameters())
+            state["bucket"].allreduce()
         return out
 
     out = step()  # creates the variables
-    bucket = GradBucket(builder.parameters())
     e_local = int(next(iter(builder.cacheNeighs_.values()))[1].shape[0])
     for _ in range(max(args.warmup - 1, 0)):
         step()

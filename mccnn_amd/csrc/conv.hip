@@ -623,6 +623,176 @@ __global__ __launch_bounds__(256) void conv_fwd_sweep(ConvArgs a, const float4* 
     for (int k = lane; k < cnt; k += 64) dst[k] = tile[k];
 }
 
+// ---------------------------------------------------------------------------------------
+// "Slot" kernels: a LANE owns a whole output row (a centre, or a point j for the transposed pass) and walks that
+// row's edges one per step, so the sum over a row's edges is a plain per-lane accumulation -- no segmented scan,
+// no LDS tile, no atomics, rows written once, bit-reproducible. What makes it efficient is the row order: rows are
+// visited in DEGREE-SORTED order (counting sort of the row lengths, longest first), so the 64 rows of a wave have
+// (almost) the same length and the lanes stay busy together. q-outer: one MLP block's weight operands are loaded
+// once per (wave, block) and stay in VGPRs for the whole walk; per step only the per-edge record is fetched
+// (each lane streams through consecutive records -> L1-friendly), the kernel is bound by its 38 MFMAs per step.
+// ---------------------------------------------------------------------------------------
+#define MCCNN_DEG_BINS 2048
+
+__global__ __launch_bounds__(256) void deg_hist(const int* __restrict__ rowStart, int rows, int total,
+                                                int* __restrict__ hist) {
+    __shared__ int h[MCCNN_DEG_BINS];
+    for (int k = threadIdx.x; k < MCCNN_DEG_BINS; k += blockDim.x) h[k] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) {
+        int d = ((i + 1 < rows) ? rowStart[i + 1] : total) - rowStart[i];
+        atomicAdd(&h[min(d, MCCNN_DEG_BINS - 1)], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < MCCNN_DEG_BINS; k += blockDim.x)
+        if (h[k]) atomicAdd(&hist[k], h[k]);
+}
+// offsets for DESCENDING degree: off[k] = #rows with degree bin > k. One block.
+__global__ __launch_bounds__(256) void deg_offsets(const int* __restrict__ hist, int* __restrict__ off) {
+    __shared__ int part[256];
+    const int per = MCCNN_DEG_BINS / 256;  // 8 bins per thread, thread 0 owns the HIGHEST bins
+    int base = MCCNN_DEG_BINS - 1 - threadIdx.x * per;
+    int s = 0;
+    for (int k = 0; k < per; ++k) s += hist[base - k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    int pre = 0;
+    for (int t = 0; t < (int)threadIdx.x; ++t) pre += part[t];
+    for (int k = 0; k < per; ++k) {
+        off[base - k] = pre;
+        pre += hist[base - k];
+    }
+}
+__global__ __launch_bounds__(256) void deg_scatter(const int* __restrict__ rowStart, int rows, int total,
+                                                   int* __restrict__ cursor /* = offsets, consumed */,
+                                                   int* __restrict__ perm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    int d = ((i + 1 < rows) ? rowStart[i + 1] : total) - rowStart[i];
+    perm[atomicAdd(&cursor[min(d, MCCNN_DEG_BINS - 1)], 1)] = i;
+}
+
+struct SlotArgs {
+    const int* rowStart;   // CSR row starts (rows entries)
+    const int* rowPerm;    // rows in degree-sorted order
+    const int* edgePerm;   // edge id of CSR slot (nullptr = identity)
+    const float* gather;   // [*, F] rows multiplied into the MLP output (features / outGrad)
+    int rows, total, F;
+    int gatherByNeighbour; // 1: gather row = packed[e].x (forward), 0: packed[e].y (transposed pass)
+};
+
+// recW: per-edge (delta0, delta1, delta2, w). FEAT == 1: w already contains feature * 1/(pdf K).
+template <bool COMBIN, int FEAT>
+__global__ __launch_bounds__(256) void conv_slot(ConvArgs a, SlotArgs sa, const float4* __restrict__ rec,
+                                                 float* __restrict__ out) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
+    float* wl = lds;
+    stage_weights<MCCNN_WQ_FWD>(a, wl);
+    __syncthreads();
+    const int slot = (blockIdx.x * 4 + wave) * 64 + lane;
+    const bool live = slot < sa.rows;
+    const int row = live ? sa.rowPerm[slot] : 0;
+    const int s0 = live ? sa.rowStart[row] : 0;
+    const int deg = live ? (((row + 1 < sa.rows) ? sa.rowStart[row + 1] : sa.total) - s0) : 0;
+    int kmax = deg;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) kmax = max(kmax, __shfl_xor(kmax, d, 64));
+    if (kmax == 0) {  // rows without edges still have to be written (zeros)
+        if (live)
+            for (int f = 0; f < a.outF; ++f) out[(size_t)row * a.outF + f] = 0.f;
+        return;
+    }
+    const int F = sa.F;
+    float* orow = out + (size_t)row * a.outF;
+
+    for (int q = 0; q < a.nb; ++q) {
+        const BlockWeights W = load_block_weights(wl + q * MCCNN_WQ_FWD, i4);
+        float oacc[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) oacc[n] = 0.f;
+        // software pipeline: the record (and the gather index) of step t+1 is fetched during step t
+        int eN = (deg > 0) ? (sa.edgePerm ? sa.edgePerm[s0] : s0) : 0;
+        float4 rcN = rec[eN];
+        int gN = 0;
+        if (FEAT != 1) gN = sa.gatherByNeighbour ? a.packed[eN].x : a.packed[eN].y;
+        for (int t = 0; t < kmax; ++t) {
+            const bool act = t < deg;
+            const float4 rc = rcN;
+            const int gi = gN;
+            float s[8];
+            if (FEAT == 1) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) s[n] = act ? rc.w : 0.f;
+            } else if (FEAT == 2) {
+                const float4* fp = reinterpret_cast<const float4*>(sa.gather + (size_t)gi * F + q * 8);
+                float4 fa = fp[0], fb = fp[1];
+                const float w = act ? rc.w : 0.f;
+                s[0] = fa.x * w; s[1] = fa.y * w; s[2] = fa.z * w; s[3] = fa.w * w;
+                s[4] = fb.x * w; s[5] = fb.y * w; s[6] = fb.z * w; s[7] = fb.w * w;
+            } else {
+                const float w = act ? rc.w : 0.f;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    int nu = q * 8 + n;
+                    int col = COMBIN ? nu % F : nu;
+                    s[n] = (nu < a.neuronsOut) ? sa.gather[(size_t)gi * F + col] * w : 0.f;
+                }
+            }
+            {
+                int tn = min(t + 1, max(deg - 1, 0));
+                eN = sa.edgePerm ? sa.edgePerm[s0 + tn] : (s0 + tn);
+                if (deg == 0) eN = 0;
+                rcN = rec[eN];
+                if (FEAT != 1) gN = sa.gatherByNeighbour ? a.packed[eN].x : a.packed[eN].y;
+            }
+            float o[8];
+            mlp_block_regs(W, rc.x, rc.y, rc.z, o);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) oacc[n] = fmaf(s[n], o[n], oacc[n]);
+        }
+        if (live) {
+            if (!COMBIN || F == 1) {
+                if (q * 8 + 8 <= a.neuronsOut && (a.outF & 3) == 0) {
+                    float4* d4 = reinterpret_cast<float4*>(orow + q * 8);
+                    d4[0] = make_float4(oacc[0], oacc[1], oacc[2], oacc[3]);
+                    d4[1] = make_float4(oacc[4], oacc[5], oacc[6], oacc[7]);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n)
+                        if (q * 8 + n < a.neuronsOut) orow[q * 8 + n] = oacc[n];
+                }
+            } else {
+                // several neurons share an output feature (fo = nu / Fin); this lane owns the row: plain RMW
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    int nu = q * 8 + n;
+                    if (nu < a.neuronsOut) {
+                        int fo = nu / F;
+                        orow[fo] = (nu % F == 0) ? oacc[n] : orow[fo] + oacc[n];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// edge records with the feature folded in (Fin == 1 combin): w = feats[j] / (pdf K)
+__global__ __launch_bounds__(256) void edge_records_f1(ConvArgs a, float4* __restrict__ rec) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.e) return;
+    int2 pr = a.packed[t];
+    float invR = a.invRadius;
+    if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, a.bids[pr.x]));
+    const float* p = a.pts + (size_t)pr.x * 3;
+    const float* c = a.samples + (size_t)pr.y * 3;
+    int e0 = a.start[pr.y];
+    int e1 = (pr.y < a.m - 1) ? a.start[pr.y + 1] : a.e;
+    float K = a.avg ? (float)(e1 - e0) : 1.0f;
+    rec[t] = make_float4((p[0] - c[0]) * invR, (p[1] - c[1]) * invR, (p[2] - c[2]) * invR,
+                         a.feats[pr.x] * __builtin_amdgcn_rcpf(a.pdfs[t] * K));
+}
+
 #ifndef MCCNN_BWD_OCC
 #define MCCNN_BWD_OCC 2
 #endif
@@ -1101,16 +1271,24 @@ __global__ __launch_bounds__(256) void tr_fill(const int2* __restrict__ packed, 
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < e) tmp[startT[packed[t].x] + slot[t]] = t;
 }
-// stable order inside a row: ascending edge id (the arrival order above is arbitrary)
+// stable order inside a row: ascending edge id (the arrival order above is arbitrary). One thread per POSITION of
+// the row-grouped list, so neighbouring lanes belong to the same row and scan the same addresses (broadcast loads);
+// a thread per edge id would make every lane scan a different row (64 cache lines per load).
 __global__ __launch_bounds__(256) void tr_rank(const int2* __restrict__ packed, int e, const int* __restrict__ startT,
                                                const int* __restrict__ tmp, int* __restrict__ permT) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= e) return;
-    int j = packed[t].x;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= e) return;
+    int v = tmp[p];
+    int j = packed[v].x;
     int s0 = startT[j], s1 = startT[j + 1];
     int r = 0;
-    for (int p = s0; p < s1; ++p) r += (tmp[p] < t) ? 1 : 0;
-    permT[s0 + r] = t;
+    int q = s0;
+    for (; q + 4 <= s1; q += 4) {
+        int a0 = tmp[q], a1 = tmp[q + 1], a2 = tmp[q + 2], a3 = tmp[q + 3];
+        r += (a0 < v) + (a1 < v) + (a2 < v) + (a3 < v);
+    }
+    for (; q < s1; ++q) r += (tmp[q] < v) ? 1 : 0;
+    permT[s0 + r] = v;
 }
 
 template <bool VEC>
@@ -1357,6 +1535,21 @@ __global__ __launch_bounds__(256) void conv_bwd_valu(ConvArgs a, const float* __
     }
 }
 
+// rows in descending-degree order -> perm[rows]; hist / off: MCCNN_DEG_BINS ints each
+static int degree_sort(const int* rowStart, int rows, int total, int* hist, int* off, int* perm, hipStream_t s) {
+    MCCNN_HIP(hipMemsetAsync(hist, 0, MCCNN_DEG_BINS * sizeof(int), s));
+    int hb = ceil_div(rows, 256);
+    if (hb > 512) hb = 512;
+    deg_hist<<<hb, 256, 0, s>>>(rowStart, rows, total, hist);
+    MCCNN_LAUNCHED();
+    deg_offsets<<<1, 256, 0, s>>>(hist, off);
+    MCCNN_LAUNCHED();
+    deg_scatter<<<ceil_div(rows, 256), 256, 0, s>>>(rowStart, rows, total, off, perm);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+static size_t degree_sort_bytes(int rows) { return 2 * align_up(MCCNN_DEG_BINS * sizeof(int)) + align_up((size_t)(rows > 0 ? rows : 1) * 4); }
+
 static int fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
                      const float* pdfs, const float* samples, const int* start_idx, const int* packed,
                      const float* aabb_min, const float* aabb_max, const float* w1, const float* b1, const float* w2,
@@ -1387,8 +1580,9 @@ using namespace mccnn;
 extern "C" {
 
 size_t mccnn_spatial_conv_fwd_workspace_bytes(int m, int e, int num_in_feats, int num_out_feats, int combin) {
-    (void)m; (void)num_in_feats; (void)num_out_feats; (void)combin;
-    return e > 0 ? align_up((size_t)e * sizeof(float4)) + 256 : 256;  // per-edge records
+    (void)num_in_feats; (void)num_out_feats; (void)combin;
+    if (e <= 0) return 256;
+    return align_up((size_t)e * sizeof(float4)) + degree_sort_bytes(m) + 256;  // edge records + degree order
 }
 
 static bool use_mfma(const ConvArgs& a) { return a.nb <= MCCNN_LDS_MAX_NB && !getenv("MCCNN_FORCE_VALU"); }
@@ -1408,6 +1602,38 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     if (!out) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats) & 15) == 0);
+    if (use_mfma(a) && e > 0 && getenv("MCCNN_FWD_SLOT") && (size_t)a.nb * MCCNN_WQ_FWD * sizeof(float) <= 64 * 1024) {
+        // default: degree-sorted slot kernel (a lane owns a centre)
+        if (!ws || ws_bytes < mccnn_spatial_conv_fwd_workspace_bytes(m, e, num_in_feats, num_out_feats, combin))
+            return MCCNN_E_WORKSPACE;
+        Arena ar(ws, ws_bytes);
+        float4* rec = ar.take<float4>((size_t)e);
+        int* hist = ar.take<int>(MCCNN_DEG_BINS);
+        int* off = ar.take<int>(MCCNN_DEG_BINS);
+        int* perm = ar.take<int>((size_t)m);
+        if (!rec || !hist || !off || !perm) return MCCNN_E_WORKSPACE;
+        a.G = 0;
+        const bool f1 = combin && a.Fin == 1;
+        if (f1) edge_records_f1<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
+        else edge_records<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
+        MCCNN_LAUNCHED();
+        int rc2 = degree_sort(start_idx, m, e, hist, off, perm, s);
+        if (rc2) return rc2;
+        SlotArgs sa;
+        sa.rowStart = start_idx; sa.rowPerm = perm; sa.edgePerm = nullptr; sa.gather = sorted_feats;
+        sa.rows = m; sa.total = e; sa.F = a.Fin; sa.gatherByNeighbour = 1;
+        size_t lds = (size_t)a.nb * MCCNN_WQ_FWD * sizeof(float);
+        int blocks = ceil_div(m, 256);
+        if (combin) {
+            if (f1) conv_slot<true, 1><<<blocks, 256, lds, s>>>(a, sa, rec, out);
+            else conv_slot<true, 0><<<blocks, 256, lds, s>>>(a, sa, rec, out);
+        } else {
+            if (vec) conv_slot<false, 2><<<blocks, 256, lds, s>>>(a, sa, rec, out);
+            else conv_slot<false, 0><<<blocks, 256, lds, s>>>(a, sa, rec, out);
+        }
+        MCCNN_LAUNCHED();
+        return 0;
+    }
     if (use_mfma(a) && e > 0 && getenv("MCCNN_FWD_SWEEP")) {  // experimental, slower for short per-wave ranges
         int G = 1024 / a.outF;
         if (G > 16) G = 16;
@@ -1528,7 +1754,7 @@ size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_fe
     bytes += align_up((size_t)e * sizeof(float4));                                                // edge records
     if (combin) bytes += align_up((size_t)e * num_in_feats * sizeof(float));                      // per-edge dFeat
     else bytes += align_up((size_t)(n + 1) * 4) + align_up((size_t)e * 4) +                       // start_t, perm_t
-                  mccnn_transpose_neighbors_workspace_bytes(n, e);
+                  mccnn_transpose_neighbors_workspace_bytes(n, e) + degree_sort_bytes(n);
     return bytes + 256;
 }
 
@@ -1616,11 +1842,26 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
                 start_t = st;
                 perm_t = pt;
             }
-            a.G = Gd;
-            int blocksD = ceil_div(n, 4 * Gd);
             bool vecD = (a.Fin % 8 == 0) && ((((uintptr_t)out_grad) & 15) == 0);
-            if (vecD) conv_dfeat_dw<true><<<blocksD, 256, ldsD, s>>>(a, rec, start_t, perm_t, out_grad, feat_grad);
-            else conv_dfeat_dw<false><<<blocksD, 256, ldsD, s>>>(a, rec, start_t, perm_t, out_grad, feat_grad);
+            if (!getenv("MCCNN_FWD_SLOT")) {
+                a.G = Gd;
+                int blocksD = ceil_div(n, 4 * Gd);
+                if (vecD) conv_dfeat_dw<true><<<blocksD, 256, ldsD, s>>>(a, rec, start_t, perm_t, out_grad, feat_grad);
+                else conv_dfeat_dw<false><<<blocksD, 256, ldsD, s>>>(a, rec, start_t, perm_t, out_grad, feat_grad);
+            } else {
+                int* hist = ar.take<int>(MCCNN_DEG_BINS);
+                int* off = ar.take<int>(MCCNN_DEG_BINS);
+                int* permR = ar.take<int>((size_t)n);
+                if (!hist || !off || !permR) return MCCNN_E_WORKSPACE;
+                int rc3 = degree_sort(start_t, n, e, hist, off, permR, s);
+                if (rc3) return rc3;
+                SlotArgs sa;
+                sa.rowStart = start_t; sa.rowPerm = permR; sa.edgePerm = perm_t; sa.gather = out_grad;
+                sa.rows = n; sa.total = e; sa.F = a.Fin; sa.gatherByNeighbour = 0;
+                size_t ldsS = (size_t)a.nb * MCCNN_WQ_FWD * sizeof(float);
+                if (vecD) conv_slot<false, 2><<<ceil_div(n, 256), 256, ldsS, s>>>(a, sa, rec, feat_grad);
+                else conv_slot<false, 0><<<ceil_div(n, 256), 256, ldsS, s>>>(a, sa, rec, feat_grad);
+            }
             MCCNN_LAUNCHED();
         } else {
             return MCCNN_E_TOOLARGE;  // unreachable: the depth-wise tile always fits for nb <= MCCNN_LDS_MAX_NB
