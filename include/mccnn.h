@@ -113,18 +113,20 @@ int mccnn_transform_indexs(const int* in_idx, int s, const int* new_idx, int n, 
  * which threads visit the centres. It never changes the result; a spatially coherent
  * order (e.g. the inverse of new_idx when the centres are the gridded points) makes
  * neighbouring lanes walk the same cells, which is several times faster. */
-size_t mccnn_find_neighbors_workspace_bytes(int m);
+size_t mccnn_find_neighbors_workspace_bytes(int m, int n);
 int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids, int m,
-                               const float* sorted_pts, const int* cell_indexs,
+                               const float* sorted_pts, int n, const int* cell_indexs,
                                const float* aabb_min, const float* aabb_max, int batch_size,
                                int num_cells, float radius, int scale_inv, const int* centre_order,
                                int* start_idx, int* total_dev, void* ws, size_t ws_bytes,
                                mccnn_stream_t stream);
+/* ws: the SAME workspace the count call used (it holds the 16-byte padded copy of sorted_pts). */
 int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m,
-                              const float* sorted_pts, const int* cell_indexs,
+                              const float* sorted_pts, int n, const int* cell_indexs,
                               const float* aabb_min, const float* aabb_max, int batch_size,
                               int num_cells, float radius, int scale_inv, const int* centre_order,
-                              const int* start_idx, int e, int* packed, mccnn_stream_t stream);
+                              const int* start_idx, int e, int* packed, void* ws, size_t ws_bytes,
+                              mccnn_stream_t stream);
 /* inv[new_idx[i]] = i -- the visiting order above for same-level searches (sort_gpu.cu:332-345). */
 int mccnn_invert_permutation(const int* new_idx, int n, int* inv, mccnn_stream_t stream);
 

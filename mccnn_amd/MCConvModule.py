@@ -326,17 +326,19 @@ def find_neighbors(inPts, inBatchIds, inPts2, cellIndexs, aabbMin, aabbMax, radi
     m, nc = c.shape[0], cells.shape[1]
     start = torch.empty((m, 1), dtype=torch.int32, device=c.device)
     total = torch.empty(1, dtype=torch.int32, device=c.device)
-    ws = _ws(lib.mccnn_find_neighbors_workspace_bytes(m), c.device)
+    n2 = p2.shape[0]
+    ws = _ws(lib.mccnn_find_neighbors_workspace_bytes(m, n2), c.device)
     order = _order_hint(inPts)
     if order is not None and order.shape[0] != m:
         order = None
-    args = (ptr(c), ptr(cb), m, ptr(p2), ptr(cells), ptr(mn), ptr(mx), batchSize, nc, float(radius),
+    args = (ptr(c), ptr(cb), m, ptr(p2), n2, ptr(cells), ptr(mn), ptr(mx), batchSize, nc, float(radius),
             int(bool(scaleInv)), ptr(order))
     check(lib.mccnn_find_neighbors_count(*args, ptr(start), ptr(total), ptr(ws), ws.numel(), stream_handle()),
           "find_neighbors(count)")
     e = int(total.item())
     packed = torch.empty((e, 2), dtype=torch.int32, device=c.device)
-    check(lib.mccnn_find_neighbors_fill(*args, ptr(start), e, ptr(packed), stream_handle()), "find_neighbors(fill)")
+    check(lib.mccnn_find_neighbors_fill(*args, ptr(start), e, ptr(packed), ptr(ws), ws.numel(), stream_handle()),
+          "find_neighbors(fill)")
     return start, packed
 
 

@@ -30,9 +30,9 @@ SIGNATURES = {
     "mccnn_permute_scatter": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     "mccnn_transform_indexs_workspace_bytes": (_sz, [_i]),
     "mccnn_transform_indexs": (_i, [_vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
-    "mccnn_find_neighbors_workspace_bytes": (_sz, [_i]),
-    "mccnn_find_neighbors_count": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "mccnn_find_neighbors_fill": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp]),
+    "mccnn_find_neighbors_workspace_bytes": (_sz, [_i, _i]),
+    "mccnn_find_neighbors_count": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_find_neighbors_fill": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "mccnn_invert_permutation": (_i, [_vp, _i, _vp, _vp]),
     "mccnn_compute_pdf_workspace_bytes": (_sz, [_i, _i]),
     "mccnn_compute_pdf": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _f, _f, _i, _i, _vp, _vp, _sz, _vp]),

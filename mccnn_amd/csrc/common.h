@@ -63,6 +63,23 @@ __device__ __forceinline__ float point_dist(float ax, float ay, float az, float 
     return sqrtf(dx * dx + dy * dy + dz * dz);
 }
 
+// dx*dx + dy*dy + dz*dz exactly as the reference spells it (left to right, no FMA: -ffp-contract=off)
+__device__ __forceinline__ float point_dist2(float ax, float ay, float az, float cx, float cy, float cz) {
+    float dx = ax - cx, dy = ay - cy, dz = az - cz;
+    return dx * dx + dy * dy + dz * dz;
+}
+// The reference tests sqrt(d2) < R (find_neighbors.cu:96-97). sqrt is monotone and correctly rounded, so the test is
+// EXACTLY equivalent to d2 < T with T = the smallest float whose rounded square root reaches R. Computing T once per
+// centre removes a correctly-rounded sqrt (~10 instructions) from every candidate test.
+__device__ __forceinline__ float sqrt_threshold(float R) {
+    float t = R * R;
+    // walk to the boundary: at most a couple of ulps away from R*R
+    for (int it = 0; it < 8 && t > 0.0f && sqrtf(__uint_as_float(__float_as_uint(t) - 1)) >= R; ++it)
+        t = __uint_as_float(__float_as_uint(t) - 1);
+    for (int it = 0; it < 8 && sqrtf(t) < R; ++it) t = __uint_as_float(__float_as_uint(t) + 1);
+    return t;
+}
+
 // find_neighbors.cu:282-291 : entry o = (1 - o%3, 1 - (o/3)%3, 1 - o/9)
 __device__ __forceinline__ void neigh_offset(int o, int& dx, int& dy, int& dz) {
     dx = 1 - (o % 3);

@@ -210,6 +210,25 @@ __device__ __forceinline__ int dpp_i(int v) {
 // max(x, 0) as ONE instruction (v_med3_f32); fmaxf() costs an extra canonicalising v_max on MFMA results
 __device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()); }
 
+
+#ifdef MCCNN_TIMING
+__device__ unsigned long long g_timing[16];
+#define TSTART() unsigned long long t__ = __builtin_readcyclecounter(); (void)t__
+#define TSTAMP(k)                                                                      \
+    do {                                                                               \
+        unsigned long long n__ = __builtin_readcyclecounter();                         \
+        if (blockIdx.x == 7 && threadIdx.x == 0) g_timing[k] += n__ - t__;             \
+        t__ = n__;                                                                     \
+    } while (0)
+extern "C" int mccnn_debug_timing(unsigned long long* host16, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timing), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_timing), 16 * sizeof(unsigned long long));
+}
+#else
+#define TSTART()
+#define TSTAMP(k)
+#endif
+
 // Stage the MLP tensors of all nb blocks into LDS in the per-block layout above.
 template <int WQ>
 __device__ __forceinline__ void stage_weights(const ConvArgs& a, float* wl) {
@@ -228,20 +247,43 @@ __device__ __forceinline__ void stage_weights(const ConvArgs& a, float* wl) {
     }
 }
 
-// One 8x8 layer for 64 edges: acc(lo,hi) = bias; acc += W[row][k] * x[k], rows i4 / 4+i4 supplied by this lane.
+// One 8x8 layer for 64 edges: y = bias + W x, rows i4 / 4+i4 of W supplied by this lane.
+// A dependent v_mfma_f32_4x4x1 chain advances only every ~38 cycles (measured with s_memtime: the 8-deep chains of
+// the first version cost 38-43 cycles per MFMA although the pipe is busy 8), so the K = 8 sum is split into
+// MCCNN_KSPLIT independent partial chains per accumulator (bias in the first, zeros in the others) that are added
+// at the end: dependent depth 8 / KSPLIT instead of 8.
+#ifndef MCCNN_KSPLIT
+#define MCCNN_KSPLIT 1
+#endif
 __device__ __forceinline__ void layer8(const f32x4* __restrict__ wrows /* 16 x f32x4: row r at [2r],[2r+1] */,
-                                       f32x4 lo, f32x4 hi, int i4, const float* x, float* y) {
+                                       f32x4 blo, f32x4 bhi, int i4, const float* x, float* y) {
     f32x4 al0 = wrows[2 * i4], al1 = wrows[2 * i4 + 1];
     f32x4 ah0 = wrows[2 * (4 + i4)], ah1 = wrows[2 * (4 + i4) + 1];
     float al[8] = {al0.x, al0.y, al0.z, al0.w, al1.x, al1.y, al1.z, al1.w};
     float ah[8] = {ah0.x, ah0.y, ah0.z, ah0.w, ah1.x, ah1.y, ah1.z, ah1.w};
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 lo[MCCNN_KSPLIT], hi[MCCNN_KSPLIT];
+    lo[0] = blo;
+    hi[0] = bhi;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        lo = MFMA4(al[k], x[k], lo);
-        hi = MFMA4(ah[k], x[k], hi);
+    for (int c = 1; c < MCCNN_KSPLIT; ++c) { lo[c] = z; hi[c] = z; }
+    constexpr int PER = 8 / MCCNN_KSPLIT;
+#pragma unroll
+    for (int kk = 0; kk < PER; ++kk) {
+#pragma unroll
+        for (int c = 0; c < MCCNN_KSPLIT; ++c) {
+            const int k = c * PER + kk;
+            lo[c] = MFMA4(al[k], x[k], lo[c]);
+            hi[c] = MFMA4(ah[k], x[k], hi[c]);
+        }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { y[r] = lo[r]; y[4 + r] = hi[r]; }
+    for (int st = MCCNN_KSPLIT / 2; st >= 1; st >>= 1) {
+#pragma unroll
+        for (int c = 0; c < st; ++c) { lo[c] += lo[c + st]; hi[c] += hi[c + st]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { y[r] = lo[0][r]; y[4 + r] = hi[0][r]; }
 }
 
 // Kernel MLP of block q (weights at wq in LDS) for the 64 edges of a wave.
@@ -250,13 +292,15 @@ __device__ __forceinline__ void mlp_block_mfma(const float* __restrict__ wq, int
                                                float* pre1, float* a1, float* pre2, float* a2, float* o) {
     const f32x4* w = reinterpret_cast<const f32x4*>(wq);
     f32x4 a1lo = w[i4], a1hi = w[4 + i4];
-    f32x4 lo = w[8], hi = w[9];  // b1
-    lo = MFMA4(a1lo.x, d0, lo);
-    hi = MFMA4(a1hi.x, d0, hi);
-    lo = MFMA4(a1lo.y, d1, lo);
-    hi = MFMA4(a1hi.y, d1, hi);
-    lo = MFMA4(a1lo.z, d2, lo);
-    hi = MFMA4(a1hi.z, d2, hi);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    // layer 1 (K = 3): three independent rank-1 updates per accumulator, summed afterwards
+    f32x4 l0 = MFMA4(a1lo.x, d0, w[8]);  // + b1
+    f32x4 h0 = MFMA4(a1hi.x, d0, w[9]);
+    f32x4 l1 = MFMA4(a1lo.y, d1, z);
+    f32x4 h1 = MFMA4(a1hi.y, d1, z);
+    f32x4 l2 = MFMA4(a1lo.z, d2, z);
+    f32x4 h2 = MFMA4(a1hi.z, d2, z);
+    f32x4 lo = (l0 + l1) + l2, hi = (h0 + h1) + h2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { pre1[r] = lo[r]; pre1[4 + r] = hi[r]; }
 #pragma unroll
@@ -829,12 +873,17 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
         const int numOuts = min(a.neuronsOut - q * 8, 8);
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-        int2 prN = make_int2(0, 0);
-        float4 rcN = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (eBeg + lane < eEnd) { prN = a.packed[eBeg + lane]; rcN = rec[eBeg + lane]; }
+        int2 prN;
+        float4 rcN;
+        {
+            int t0 = min(eBeg + lane, a.e - 1);
+            prN = a.packed[t0];
+            rcN = rec[t0];
+        }
         for (int base = eBeg; base < eEnd; base += 64) {
             const int t = base + lane;
             const bool act = t < eEnd;
+            TSTART();
             const int2 pr = prN;
             const float4 rc = rcN;
             const int j = pr.x;
@@ -886,7 +935,12 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #endif
             // prefetch the next chunk AFTER this chunk's gathers: vmcnt retires in order, so the waits for g / f
             // leave these two loads in flight across the whole iteration
-            if (t + 64 < eEnd) { prN = a.packed[t + 64]; rcN = rec[t + 64]; }
+            {
+                int tn = min(t + 64, a.e - 1);  // clamped: the prefetch stays branch-free (counted vmcnt, not vmcnt(0))
+                prN = a.packed[tn];
+                rcN = rec[tn];
+            }
+            TSTAMP(1);
             float a1[8], a2[8], o[8];
             bool p1[8], p2[8];  // pre-activation >= 0 (ReLU' of the reference: spatial_conv.cu:404,429), kept as lane masks
             // keep the LDS weight reads inside the chunk loop: hoisted, they would pin ~100 VGPRs and spill the
@@ -906,6 +960,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { p1[k] = pre1[k] >= 0.0f; p2[k] = pre2[k] >= 0.0f; }
             }
+            TSTAMP(2);
             // feature gradient: og * o / (pdf K)   (spatial_conv.cu:400)
             if (COMBIN) {
                 if (FEAT == 1) {
@@ -941,6 +996,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
             float gf[8];
 #pragma unroll
             for (int n = 0; n < 8; ++n) gf[n] = g[n] * ff[n];
+            TSTAMP(3);
             // dW3 += u a2^T, db3 += u, u = g f / (pdf K)          (spatial_conv.cu:383-399)
 #ifndef ABL_NOWG
 #pragma unroll
@@ -953,6 +1009,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #else
             gw3[0] += a2[0] + a2[1] + a2[2] + a2[3] + a2[4] + a2[5] + a2[6] + a2[7];
 #endif
+            TSTAMP(4);
             // t3 = 1[pre2 >= 0] * W3^T (g f) / (pdf K)             (:403-414)
             float t3[8];
 #ifdef ABL_NOT34
@@ -963,6 +1020,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #endif
 #pragma unroll
             for (int k = 0; k < 8; ++k) t3[k] = p2[k] ? t3[k] * inv : 0.f;
+            TSTAMP(5);
             // dW2 += t3 a1^T, db2 += t3                            (:419-425)
 #ifndef ABL_NOWG
 #pragma unroll
@@ -974,6 +1032,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #else
             gw2[0] += a1[0] + a1[1] + a1[2] + a1[3] + a1[4] + a1[5] + a1[6] + a1[7];
 #endif
+            TSTAMP(6);
             // t4 = 1[pre1 >= 0] * W2^T t3                          (:428-434)
             float t4[8];
 #ifdef ABL_NOT34
@@ -982,6 +1041,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #else
             layer8(w4 + 46, zero4, zero4, i4, t3, t4);  // W2^T rows at float 184 -> f32x4 index 46
 #endif
+            TSTAMP(7);
             // dW1 += t4 delta^T, db1 += t4                         (:439-444)
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
@@ -991,6 +1051,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
                 gw1[l * 3 + 2] = fmaf(v, rc.z, gw1[l * 3 + 2]);
                 gb1[l] += v;
             }
+            TSTAMP(8);
         }
         // transposing wave reduction; partial row layout: w1[24] b1[8] w2[64] b2[8] w3[64] b3[8]
         {
@@ -1661,8 +1722,9 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     if (use_mfma(a)) {
         // G centres per wave: LDS tile of G*outF floats per wave, <= 4 KB
         int G = 1024 / a.outF;
-        if (G > 16) G = 16;
+        if (G > 8) G = 8;   // measured: 4-8 centres per wave beats 16+ (more, shorter waves hide latency better)
         if (G < 1) G = 1;
+        if (const char* gs = getenv("MCCNN_FWD_G")) G = atoi(gs);  // tuning knob
         a.G = G;
         size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * ((size_t)G * a.outF + G + 4)) * sizeof(float);
         if (lds <= 64 * 1024) {

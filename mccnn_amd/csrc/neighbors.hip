@@ -5,7 +5,7 @@
 namespace mccnn {
 
 struct CentreCtx {
-    float cx, cy, cz, R;
+    float cx, cy, cz, R, T;  // T: squared-distance threshold equivalent to sqrt(d2) < R (common.h)
     int b, x, y, z;
 };
 
@@ -20,6 +20,7 @@ __device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centre
     float ext = max_extent(mn, mx, c.b);
     float cs = ext / (float)nc;
     c.R = scaleInv ? radius * ext : radius;  // find_neighbors.cu:73
+    c.T = sqrt_threshold(c.R);
     c.x = cell_coord(c.cx, mn[c.b * 3], cs, nc);
     c.y = cell_coord(c.cy, mn[c.b * 3 + 1], cs, nc);
     c.z = cell_coord(c.cz, mn[c.b * 3 + 2], cs, nc);
@@ -34,7 +35,7 @@ __device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centre
 // cells (broadcast loads, equal trip counts).
 template <bool FILL>
 __global__ __launch_bounds__(128) void neigh_walk(const float* __restrict__ centres, const int* __restrict__ cb, int m,
-                                                  const float* __restrict__ pts2, const int* __restrict__ cells,
+                                                  const float4* __restrict__ pts4, const int* __restrict__ cells,
                                                   const float* __restrict__ mn, const float* __restrict__ mx, int nc,
                                                   float radius, int scaleInv, const int* __restrict__ order,
                                                   int* __restrict__ counts, const int* __restrict__ startIdx,
@@ -65,12 +66,12 @@ __global__ __launch_bounds__(128) void neigh_walk(const float* __restrict__ cent
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     int jj = min(j + v, j1 - 1);
-                    const float* p = pts2 + (size_t)jj * 3;
-                    d[v] = point_dist(p[0], p[1], p[2], c.cx, c.cy, c.cz);
+                    float4 p = pts4[jj];
+                    d[v] = point_dist2(p.x, p.y, p.z, c.cx, c.cy, c.cz);
                 }
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    if (j + v < j1 && d[v] < c.R) {
+                    if (j + v < j1 && d[v] < c.T) {
                         if (FILL) dst[k] = make_int2(j + v, i);
                         ++k;
                     }
@@ -79,6 +80,12 @@ __global__ __launch_bounds__(128) void neigh_walk(const float* __restrict__ cent
         }
     }
     if (!FILL) counts[i] = k;
+}
+
+// [N,3] -> [N] float4: one 16-byte load per candidate instead of three 4-byte loads at a 12-byte stride
+__global__ __launch_bounds__(256) void pad_points(const float* __restrict__ pts, int n, float4* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_float4(pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2], 0.f);
 }
 
 __global__ __launch_bounds__(256) void invert_perm_k(const int* __restrict__ newIdx, int n, int* __restrict__ inv) {
@@ -191,43 +198,63 @@ using namespace mccnn;
 
 extern "C" {
 
-size_t mccnn_find_neighbors_workspace_bytes(int m) {
-    return align_up((size_t)(m > 0 ? m : 1) * 4) + scan_workspace_bytes(m > 0 ? m : 1) + 256;
+size_t mccnn_find_neighbors_workspace_bytes(int m, int n) {
+    return align_up((size_t)(m > 0 ? m : 1) * 4) + scan_workspace_bytes(m > 0 ? m : 1) +
+           align_up((size_t)(n > 0 ? n : 1) * sizeof(float4)) + 256;
+}
+
+struct NeighWs {
+    int* counts;
+    void* scanws;
+    float4* pts4;
+};
+static bool neigh_ws(void* ws, size_t ws_bytes, int m, int n, NeighWs& w) {
+    if (!ws || ws_bytes < mccnn_find_neighbors_workspace_bytes(m, n)) return false;
+    Arena a(ws, ws_bytes);
+    w.counts = a.take<int>((size_t)(m > 0 ? m : 1));
+    w.scanws = a.take<char>(scan_workspace_bytes(m > 0 ? m : 1));
+    w.pts4 = a.take<float4>((size_t)(n > 0 ? n : 1));
+    return w.counts && w.scanws && w.pts4;
 }
 
 int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
-                               const int* cell_indexs, const float* aabb_min, const float* aabb_max, int batch_size,
-                               int num_cells, float radius, int scale_inv, const int* centre_order, int* start_idx,
-                               int* total_dev, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
-    if (m < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
+                               int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max,
+                               int batch_size, int num_cells, float radius, int scale_inv, const int* centre_order,
+                               int* start_idx, int* total_dev, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    if (m < 0 || n < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (m == 0) {
         MCCNN_HIP(hipMemsetAsync(total_dev, 0, sizeof(int), s));
         return 0;
     }
-    if (!centres || !centre_batch_ids || !cell_indexs || !aabb_min || !aabb_max || !start_idx) return MCCNN_E_BADARG;
-    if (!ws || ws_bytes < mccnn_find_neighbors_workspace_bytes(m)) return MCCNN_E_WORKSPACE;
-    Arena a(ws, ws_bytes);
-    int* counts = a.take<int>((size_t)m);
-    void* scanws = a.take<char>(scan_workspace_bytes(m));
-    if (!counts || !scanws) return MCCNN_E_WORKSPACE;
-    neigh_walk<false><<<ceil_div(m, 128), 128, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
-                                                       aabb_max, num_cells, radius, scale_inv, centre_order, counts,
+    if (!centres || !centre_batch_ids || !cell_indexs || !aabb_min || !aabb_max || !start_idx || (n > 0 && !sorted_pts))
+        return MCCNN_E_BADARG;
+    NeighWs w;
+    if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
+    if (n > 0) {
+        pad_points<<<ceil_div(n, 256), 256, 0, s>>>(sorted_pts, n, w.pts4);
+        MCCNN_LAUNCHED();
+    }
+    neigh_walk<false><<<ceil_div(m, 128), 128, 0, s>>>(centres, centre_batch_ids, m, w.pts4, cell_indexs, aabb_min,
+                                                       aabb_max, num_cells, radius, scale_inv, centre_order, w.counts,
                                                        nullptr, nullptr);
     MCCNN_LAUNCHED();
-    return exclusive_scan_i32(counts, start_idx, m, total_dev, scanws, s);
+    return exclusive_scan_i32(w.counts, start_idx, m, total_dev, w.scanws, s);
 }
 
 int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
-                              const int* cell_indexs, const float* aabb_min, const float* aabb_max, int batch_size,
-                              int num_cells, float radius, int scale_inv, const int* centre_order, const int* start_idx,
-                              int e, int* packed, mccnn_stream_t stream) {
-    if (m < 0 || e < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f)) return MCCNN_E_BADARG;
+                              int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max,
+                              int batch_size, int num_cells, float radius, int scale_inv, const int* centre_order,
+                              const int* start_idx, int e, int* packed, void* ws, size_t ws_bytes,
+                              mccnn_stream_t stream) {
+    if (m < 0 || n < 0 || e < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f)) return MCCNN_E_BADARG;
     if (m == 0 || e == 0) return 0;
     if (!centres || !centre_batch_ids || !sorted_pts || !cell_indexs || !aabb_min || !aabb_max || !start_idx || !packed)
         return MCCNN_E_BADARG;
+    NeighWs w;
+    if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;  // same workspace as the count call (holds pts4)
     hipStream_t s = (hipStream_t)stream;
-    neigh_walk<true><<<ceil_div(m, 128), 128, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
+    neigh_walk<true><<<ceil_div(m, 128), 128, 0, s>>>(centres, centre_batch_ids, m, w.pts4, cell_indexs, aabb_min,
                                                       aabb_max, num_cells, radius, scale_inv, centre_order, nullptr,
                                                       start_idx, packed);
     MCCNN_LAUNCHED();

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(64) void poisson_phase(const float* __restrict__ pt
     if (!(xC < nc && yC < nc && zC < nc)) return;  // poisson_sampling.cu:74
     float ext = max_extent(mn, mx, b);
     float R = scaleInv ? radius * ext : radius;
+    const float T = sqrt_threshold(R);  // sqrt(d2) < R  <=>  d2 < T (exact, see common.h)
     size_t cellBase = (size_t)b * nc * nc * nc;
     const int2* ct = reinterpret_cast<const int2*>(cells);
     int2 me = ct[cellBase + (size_t)xC * nc * nc + (size_t)yC * nc + zC];
@@ -64,8 +65,8 @@ __global__ __launch_bounds__(64) void poisson_phase(const float* __restrict__ pt
             for (int j = rr.x; j < rr.y && !collision; ++j) {
                 // a point of my own cell selected earlier in this very loop is visible: same thread
                 if (!sel[j]) continue;
-                float dd = point_dist(pts[(size_t)j * 3], pts[(size_t)j * 3 + 1], pts[(size_t)j * 3 + 2], c0, c1, c2);
-                if (dd < R) collision = true;
+                float dd = point_dist2(pts[(size_t)j * 3], pts[(size_t)j * 3 + 1], pts[(size_t)j * 3 + 2], c0, c1, c2);
+                if (dd < T) collision = true;
             }
         }
         if (!collision) {
