@@ -28,7 +28,7 @@ for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), r
 if rows:
     allc = pd.concat(rows)
     piv = allc.pivot_table(index="Kernel_Name", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
-    keep = [k for k in piv.index if "conv_" in k or "neigh" in k or "pdf" in k or "rank" in k or "keys" in k]
+    keep = [k for k in piv.index if any(t in k for t in ("conv_", "neigh", "pdf_edges", "edge_rec", "scatter_edge", "keys_hist"))]
     pd.set_option("display.width", 250)
     pd.set_option("display.max_columns", 50)
     print("== PMC (mean per dispatch)")
