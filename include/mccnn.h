@@ -120,7 +120,8 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
                                int num_cells, float radius, int scale_inv, const int* centre_order,
                                int* start_idx, int* total_dev, void* ws, size_t ws_bytes,
                                mccnn_stream_t stream);
-/* ws: the SAME workspace the count call used (it holds the 16-byte padded copy of sorted_pts). */
+/* ws: the SAME workspace the count call used, untouched in between (it holds the 16-byte padded copy
+ * of sorted_pts and the scanned per-slab output offsets). */
 int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m,
                               const float* sorted_pts, int n, const int* cell_indexs,
                               const float* aabb_min, const float* aabb_max, int batch_size,

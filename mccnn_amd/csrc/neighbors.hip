@@ -27,59 +27,64 @@ __device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centre
     return c;
 }
 
-// One thread per centre, visited in `order` (identity when null); FILL == false counts, FILL == true writes
-// (j, i) rows. Traversal order = cellOffsets order (find_neighbors.cu:282-291), then ascending j.
-// The reference walks the window twice with one dependent load chain per candidate; here the 27 cell ranges
-// are fetched 9 at a time (one z-slab, independent loads) and the candidates of a cell 4 at a time, so a lane
-// keeps several loads in flight, and with a cell-coherent visiting order the lanes of a wave read the same
-// cells (broadcast loads, equal trip counts).
+// THREE threads per centre -- one per z-slab of the 27-cell window (table entries 9*slab .. 9*slab+8, so slab order is
+// the table order of find_neighbors.cu:282-291) -- visited in `order` (identity when null). FILL == false counts per
+// (centre, slab), FILL == true writes (j, i) rows at the scanned per-slab offsets; inside a slab: table order, then
+// ascending j. One thread per centre left the chip three quarters empty at 100k centres (1.5 waves per SIMD) and
+// latency-bound; a slab per thread triples the parallelism and shortens every serial walk by three.
+// The 9 cell ranges of a slab are fetched with independent loads and the candidates of a cell 4 at a time; with a
+// cell-coherent visiting order the lanes of a wave read the same cells (broadcast loads, equal trip counts).
 template <bool FILL>
-__global__ __launch_bounds__(128) void neigh_walk(const float* __restrict__ centres, const int* __restrict__ cb, int m,
+__global__ __launch_bounds__(256) void neigh_walk(const float* __restrict__ centres, const int* __restrict__ cb, int m,
                                                   const float4* __restrict__ pts4, const int* __restrict__ cells,
                                                   const float* __restrict__ mn, const float* __restrict__ mx, int nc,
                                                   float radius, int scaleInv, const int* __restrict__ order,
-                                                  int* __restrict__ counts, const int* __restrict__ startIdx,
+                                                  int* __restrict__ counts3, const int* __restrict__ base3,
                                                   int* __restrict__ packed) {
     int tix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tix >= m) return;
-    const int i = order ? order[tix] : tix;
+    if (tix >= 3 * m) return;
+    const int ci = tix / 3, slab = tix - ci * 3;
+    const int i = order ? order[ci] : ci;
     CentreCtx c = centre_ctx(centres, cb, mn, mx, i, nc, radius, scaleInv);
     int k = 0;
-    int2* dst = FILL ? reinterpret_cast<int2*>(packed) + startIdx[i] : nullptr;
+    int2* dst = FILL ? reinterpret_cast<int2*>(packed) + base3[(size_t)i * 3 + slab] : nullptr;
     const size_t cellBase = (size_t)c.b * nc * nc * nc;
     const int2* ct = reinterpret_cast<const int2*>(cells);
-#pragma unroll 1
-    for (int slab = 0; slab < 3; ++slab) {
-        const int Z = c.z + 1 - slab;  // offsets o = 9*slab .. 9*slab+8 share dz = 1 - slab
-        int2 rng[9];
+    const int Z = c.z + 1 - slab;  // offsets o = 9*slab .. 9*slab+8 share dz = 1 - slab
+    int2 rng[9];
 #pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            int X = c.x + 1 - (u % 3), Y = c.y + 1 - (u / 3);
-            bool ok = X >= 0 && X < nc && Y >= 0 && Y < nc && Z >= 0 && Z < nc;
-            rng[u] = ok ? ct[cellBase + (size_t)X * nc * nc + (size_t)Y * nc + Z] : make_int2(0, 0);
-        }
+    for (int u = 0; u < 9; ++u) {
+        int X = c.x + 1 - (u % 3), Y = c.y + 1 - (u / 3);
+        bool ok = X >= 0 && X < nc && Y >= 0 && Y < nc && Z >= 0 && Z < nc;
+        rng[u] = ok ? ct[cellBase + (size_t)X * nc * nc + (size_t)Y * nc + Z] : make_int2(0, 0);
+    }
 #pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            const int j0 = rng[u].x, j1 = rng[u].y;
-            for (int j = j0; j < j1; j += 4) {
-                float d[4];
+    for (int u = 0; u < 9; ++u) {
+        const int j0 = rng[u].x, j1 = rng[u].y;
+        for (int j = j0; j < j1; j += 4) {
+            float d[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    int jj = min(j + v, j1 - 1);
-                    float4 p = pts4[jj];
-                    d[v] = point_dist2(p.x, p.y, p.z, c.cx, c.cy, c.cz);
-                }
+            for (int v = 0; v < 4; ++v) {
+                int jj = min(j + v, j1 - 1);
+                float4 p = pts4[jj];
+                d[v] = point_dist2(p.x, p.y, p.z, c.cx, c.cy, c.cz);
+            }
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    if (j + v < j1 && d[v] < c.T) {
-                        if (FILL) dst[k] = make_int2(j + v, i);
-                        ++k;
-                    }
+            for (int v = 0; v < 4; ++v) {
+                if (j + v < j1 && d[v] < c.T) {
+                    if (FILL) dst[k] = make_int2(j + v, i);
+                    ++k;
                 }
             }
         }
     }
-    if (!FILL) counts[i] = k;
+    if (!FILL) counts3[(size_t)i * 3 + slab] = k;
+}
+
+// start_idx[i] = offset of centre i's first slab
+__global__ __launch_bounds__(256) void slab_to_start(const int* __restrict__ base3, int m, int* __restrict__ startIdx) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) startIdx[i] = base3[(size_t)i * 3];
 }
 
 // [N,3] -> [N] float4: one 16-byte load per candidate instead of three 4-byte loads at a 12-byte stride
@@ -199,22 +204,23 @@ using namespace mccnn;
 extern "C" {
 
 size_t mccnn_find_neighbors_workspace_bytes(int m, int n) {
-    return align_up((size_t)(m > 0 ? m : 1) * 4) + scan_workspace_bytes(m > 0 ? m : 1) +
-           align_up((size_t)(n > 0 ? n : 1) * sizeof(float4)) + 256;
+    size_t m3 = 3 * (size_t)(m > 0 ? m : 1);
+    return align_up(m3 * 4) + scan_workspace_bytes((int)m3) + align_up((size_t)(n > 0 ? n : 1) * sizeof(float4)) + 256;
 }
 
 struct NeighWs {
-    int* counts;
+    int* counts3;  // per (centre, z-slab) hit counts, scanned in place to output offsets
     void* scanws;
     float4* pts4;
 };
 static bool neigh_ws(void* ws, size_t ws_bytes, int m, int n, NeighWs& w) {
     if (!ws || ws_bytes < mccnn_find_neighbors_workspace_bytes(m, n)) return false;
+    size_t m3 = 3 * (size_t)(m > 0 ? m : 1);
     Arena a(ws, ws_bytes);
-    w.counts = a.take<int>((size_t)(m > 0 ? m : 1));
-    w.scanws = a.take<char>(scan_workspace_bytes(m > 0 ? m : 1));
+    w.counts3 = a.take<int>(m3);
+    w.scanws = a.take<char>(scan_workspace_bytes((int)m3));
     w.pts4 = a.take<float4>((size_t)(n > 0 ? n : 1));
-    return w.counts && w.scanws && w.pts4;
+    return w.counts3 && w.scanws && w.pts4;
 }
 
 int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
@@ -222,6 +228,7 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
                                int batch_size, int num_cells, float radius, int scale_inv, const int* centre_order,
                                int* start_idx, int* total_dev, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
     if (m < 0 || n < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
+    if ((long long)m * 3 >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     hipStream_t s = (hipStream_t)stream;
     if (m == 0) {
         MCCNN_HIP(hipMemsetAsync(total_dev, 0, sizeof(int), s));
@@ -235,11 +242,15 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
         pad_points<<<ceil_div(n, 256), 256, 0, s>>>(sorted_pts, n, w.pts4);
         MCCNN_LAUNCHED();
     }
-    neigh_walk<false><<<ceil_div(m, 128), 128, 0, s>>>(centres, centre_batch_ids, m, w.pts4, cell_indexs, aabb_min,
-                                                       aabb_max, num_cells, radius, scale_inv, centre_order, w.counts,
-                                                       nullptr, nullptr);
+    neigh_walk<false><<<ceil_div(3LL * m, 256), 256, 0, s>>>(centres, centre_batch_ids, m, w.pts4, cell_indexs, aabb_min,
+                                                             aabb_max, num_cells, radius, scale_inv, centre_order,
+                                                             w.counts3, nullptr, nullptr);
     MCCNN_LAUNCHED();
-    return exclusive_scan_i32(w.counts, start_idx, m, total_dev, w.scanws, s);
+    int rc = exclusive_scan_i32(w.counts3, w.counts3, 3 * m, total_dev, w.scanws, s);
+    if (rc) return rc;
+    slab_to_start<<<ceil_div(m, 256), 256, 0, s>>>(w.counts3, m, start_idx);
+    MCCNN_LAUNCHED();
+    return 0;
 }
 
 int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
@@ -252,11 +263,12 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     if (!centres || !centre_batch_ids || !sorted_pts || !cell_indexs || !aabb_min || !aabb_max || !start_idx || !packed)
         return MCCNN_E_BADARG;
     NeighWs w;
-    if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;  // same workspace as the count call (holds pts4)
+    // same workspace as the count call: it holds the padded points and the scanned per-slab offsets
+    if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    neigh_walk<true><<<ceil_div(m, 128), 128, 0, s>>>(centres, centre_batch_ids, m, w.pts4, cell_indexs, aabb_min,
-                                                      aabb_max, num_cells, radius, scale_inv, centre_order, nullptr,
-                                                      start_idx, packed);
+    neigh_walk<true><<<ceil_div(3LL * m, 256), 256, 0, s>>>(centres, centre_batch_ids, m, w.pts4, cell_indexs, aabb_min,
+                                                            aabb_max, num_cells, radius, scale_inv, centre_order, nullptr,
+                                                            w.counts3, packed);
     MCCNN_LAUNCHED();
     return 0;
 }
