@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""End-to-end consumer of the drop-in path: the MCClassS and MCNormS graphs of the reference
+(models/MCClassS.py:25-77, models/MCNormS.py:25-58) written against mccnn_amd's builder and dense helpers, plus a
+tiny synthetic training loop. The graph builders keep the reference's structure line by line; only `tf.` is gone.
+
+    python examples/mcclass_s.py [--steps 20]
+"""
+import argparse
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+from mccnn_amd.MCNetworkUtils import (MLP_2_hidden, batch_norm_RELU_drop_out, conv_1x1, VariableStore)
+
+
+class MCClassS:
+    """models/MCClassS.py create_network(): 3 Poisson levels, 3 MC convolutions, global-feature MLP."""
+
+    def __init__(self, numInputFeatures, batchSize, k, numOutCat, device):
+        self.args = (numInputFeatures, batchSize, k, numOutCat)
+        self.store = VariableStore(device)
+        self.convBuilder = ConvolutionBuilder(KDEWindow=0.2, device=device)
+
+    def parameters(self):
+        return self.convBuilder.parameters() + self.store.parameters()
+
+    def __call__(self, points, batchIds, features, isTraining, keepProbConv=1.0, keepProbFull=0.5, useConvDropOut=False,
+                 useDropOutFull=True):
+        numInputFeatures, batchSize, k, numOutCat = self.args
+        st, mConvBuilder = self.store, self.convBuilder
+        mConvBuilder.reset()
+        mPointHierarchy = PointHierarchy(points, features, batchIds, [0.1, 0.4, math.sqrt(3.0) + 0.1], "MCClassS_PH",
+                                         batchSize)
+        convFeatures1 = mConvBuilder.create_convolution(
+            convName="Conv_1", inPointHierarchy=mPointHierarchy, inPointLevel=0, outPointLevel=1, inFeatures=features,
+            inNumFeatures=numInputFeatures, outNumFeatures=k, convRadius=0.2, multiFeatureConv=True)
+        convFeatures1 = batch_norm_RELU_drop_out("Reduce_1_In_BN", convFeatures1, isTraining, useConvDropOut, keepProbConv, st)
+        convFeatures1 = conv_1x1("Reduce_1", convFeatures1, k, k * 2, st)
+        convFeatures1 = batch_norm_RELU_drop_out("Reduce_1_Out_BN", convFeatures1, isTraining, useConvDropOut, keepProbConv, st)
+        convFeatures2 = mConvBuilder.create_convolution(
+            convName="Conv_2", inPointHierarchy=mPointHierarchy, inPointLevel=1, outPointLevel=2,
+            inFeatures=convFeatures1, inNumFeatures=k * 2, convRadius=0.8)
+        convFeatures2 = batch_norm_RELU_drop_out("Reduce_2_In_BN", convFeatures2, isTraining, useConvDropOut, keepProbConv, st)
+        convFeatures2 = conv_1x1("Reduce_2", convFeatures2, k * 2, k * 4, st)
+        convFeatures2 = batch_norm_RELU_drop_out("Reduce_2_Out_BN", convFeatures2, isTraining, useConvDropOut, keepProbConv, st)
+        convFeatures3 = mConvBuilder.create_convolution(
+            convName="Conv_3", inPointHierarchy=mPointHierarchy, inPointLevel=2, outPointLevel=3,
+            inFeatures=convFeatures2, inNumFeatures=k * 4, convRadius=math.sqrt(3.0) + 0.1)
+        finalInput = batch_norm_RELU_drop_out("BNRELUDROP_final", convFeatures3, isTraining, useConvDropOut, keepProbConv, st)
+        finalLogits = MLP_2_hidden(finalInput, k * 4, k * 2, k, numOutCat, "Final_Logits", keepProbFull, isTraining,
+                                   useDropOutFull, store=st)
+        self.lastHierarchy = mPointHierarchy
+        return finalLogits
+
+
+class MCNormS:
+    """models/MCNormS.py create_network(): two same-level multi-feature convolutions (normal estimation)."""
+
+    def __init__(self, numInputFeatures, batchSize, k, device):
+        self.args = (numInputFeatures, batchSize, k)
+        self.store = VariableStore(device)
+        self.convBuilder = ConvolutionBuilder(KDEWindow=0.2, device=device)
+
+    def parameters(self):
+        return self.convBuilder.parameters() + self.store.parameters()
+
+    def __call__(self, points, batchIds, features, isTraining):
+        numInputFeatures, batchSize, k = self.args
+        cb = self.convBuilder
+        cb.reset()
+        ph = PointHierarchy(points, features, batchIds, [], "MCNormS_PH", batchSize)
+        c1 = cb.create_convolution(convName="Conv_1", inPointHierarchy=ph, inPointLevel=0, inFeatures=features,
+                                   inNumFeatures=numInputFeatures, outNumFeatures=k, convRadius=0.15, multiFeatureConv=True)
+        c1 = batch_norm_RELU_drop_out("BN_RELU", c1, isTraining, False, False, self.store)
+        return cb.create_convolution(convName="Conv_2", inPointHierarchy=ph, inPointLevel=0, inFeatures=c1,
+                                     inNumFeatures=k, outNumFeatures=3, convRadius=0.15, multiFeatureConv=True)
+
+
+def synthetic_batch(batchSize, nPts, numCat, rng, device):
+    """Shapes whose class is a geometric property: ellipsoids with class-dependent axis ratios, unit-box normalised."""
+    pts, bids, labels = [], [], []
+    for b in range(batchSize):
+        c = int(rng.integers(0, numCat))
+        axes = np.array([1.0, 0.3 + 0.7 * c / max(numCat - 1, 1), 0.3 + 0.7 * ((c * 3) % numCat) / max(numCat - 1, 1)])
+        v = rng.normal(size=(nPts, 3))
+        p = v / np.linalg.norm(v, axis=1, keepdims=True) * axes
+        p = (p - p.min(0)) / (p.max(0) - p.min(0)).max()
+        pts.append(p.astype(np.float32))
+        bids.append(np.full((nPts, 1), b, np.int32))
+        labels.append(c)
+    t = lambda a: torch.from_numpy(a).to(device)
+    P, Bi = t(np.concatenate(pts)), t(np.concatenate(bids))
+    return P, Bi, torch.ones((P.shape[0], 1), dtype=torch.float32, device=device), t(np.array(labels, np.int64))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--points", type=int, default=1024)
+    args = ap.parse_args()
+    device = torch.device("cuda", 0)
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    net = MCClassS(1, args.batch, 16, 4, device)
+    P, Bi, F, y = synthetic_batch(args.batch, args.points, 4, rng, device)
+    net(P, Bi, F, True)  # creates the variables
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    for step in range(args.steps):
+        P, Bi, F, y = synthetic_batch(args.batch, args.points, 4, rng, device)
+        logits = net(P, Bi, F, True)
+        loss = torch.nn.functional.cross_entropy(logits, y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        if step % 5 == 0 or step == args.steps - 1:
+            print("step %3d  loss %.4f  acc %.2f  level sizes %s" % (
+                step, float(loss), float((logits.argmax(1) == y).float().mean()),
+                [int(p.shape[0]) for p in net.lastHierarchy.points_]))
+
+
+if __name__ == "__main__":
+    main()
