@@ -25,7 +25,12 @@ __global__ void aabb_init(unsigned* __restrict__ enc, int B) {
 
 __global__ __launch_bounds__(256) void aabb_reduce(const float* __restrict__ pts, const int* __restrict__ bids,
                                                    int n, int B, unsigned* __restrict__ enc) {
+    // Clouds are stored contiguously (utils/DataSet.py:816-823), so a wave -- and usually a whole workgroup -- sees
+    // one batch id: reduce in-wave with shuffles, combine the 4 waves in LDS and issue 6 global atomics per
+    // WORKGROUP (a single 100k-point cloud otherwise hammers the same 6 addresses from 1500 waves).
+    __shared__ unsigned sh[4][7];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int wave = threadIdx.x >> 6;
     bool act = i < n;
     int b = act ? bids[i] : -1;
     float x = 0.f, y = 0.f, z = 0.f;
@@ -34,10 +39,8 @@ __global__ __launch_bounds__(256) void aabb_reduce(const float* __restrict__ pts
         y = pts[(size_t)i * 3 + 1];
         z = pts[(size_t)i * 3 + 2];
     }
-    // Clouds are stored contiguously (utils/DataSet.py:816-823), so a wave almost always sees
-    // one batch id: reduce in-wave and issue 6 atomics per wave instead of 6 per point.
     int b0 = __shfl(b, 0, 64);
-    bool uniform = __all(b == b0 || !act) && __any(act) && (__shfl(act ? 1 : 0, 0, 64) != 0);
+    bool uniform = __all(b == b0 || !act) && (__shfl(act ? 1 : 0, 0, 64) != 0) && b0 >= 0 && b0 < B;
     if (uniform) {
         float mnx = act ? x : FLT_MAX, mny = act ? y : FLT_MAX, mnz = act ? z : FLT_MAX;
         float mxx = act ? x : -FLT_MAX, mxy = act ? y : -FLT_MAX, mxz = act ? z : -FLT_MAX;
@@ -50,21 +53,40 @@ __global__ __launch_bounds__(256) void aabb_reduce(const float* __restrict__ pts
             mxy = fmaxf(mxy, __shfl_xor(mxy, d, 64));
             mxz = fmaxf(mxz, __shfl_xor(mxz, d, 64));
         }
-        if (lane_id() == 0 && b0 >= 0 && b0 < B) {
-            atomicMin(&enc[b0 * 3], f2ord(mnx));
-            atomicMin(&enc[b0 * 3 + 1], f2ord(mny));
-            atomicMin(&enc[b0 * 3 + 2], f2ord(mnz));
-            atomicMax(&enc[3 * B + b0 * 3], f2ord(mxx));
-            atomicMax(&enc[3 * B + b0 * 3 + 1], f2ord(mxy));
-            atomicMax(&enc[3 * B + b0 * 3 + 2], f2ord(mxz));
+        if (lane_id() == 0) {
+            sh[wave][0] = f2ord(mnx); sh[wave][1] = f2ord(mny); sh[wave][2] = f2ord(mnz);
+            sh[wave][3] = f2ord(mxx); sh[wave][4] = f2ord(mxy); sh[wave][5] = f2ord(mxz);
+            sh[wave][6] = (unsigned)b0;
         }
-    } else if (act && b >= 0 && b < B) {
-        atomicMin(&enc[b * 3], f2ord(x));
-        atomicMin(&enc[b * 3 + 1], f2ord(y));
-        atomicMin(&enc[b * 3 + 2], f2ord(z));
-        atomicMax(&enc[3 * B + b * 3], f2ord(x));
-        atomicMax(&enc[3 * B + b * 3 + 1], f2ord(y));
-        atomicMax(&enc[3 * B + b * 3 + 2], f2ord(z));
+    } else {
+        if (lane_id() == 0) sh[wave][6] = 0xffffffffu;  // mixed / empty wave: handled per lane below
+        if (act && b >= 0 && b < B) {
+            atomicMin(&enc[b * 3], f2ord(x));
+            atomicMin(&enc[b * 3 + 1], f2ord(y));
+            atomicMin(&enc[b * 3 + 2], f2ord(z));
+            atomicMax(&enc[3 * B + b * 3], f2ord(x));
+            atomicMax(&enc[3 * B + b * 3 + 1], f2ord(y));
+            atomicMax(&enc[3 * B + b * 3 + 2], f2ord(z));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        // merge consecutive waves with the same batch id, one atomic per run
+        int w = 0;
+        while (w < 4) {
+            unsigned bb = sh[w][6];
+            if (bb == 0xffffffffu) { ++w; continue; }
+            unsigned v = sh[w][k];
+            int w2 = w + 1;
+            while (w2 < 4 && sh[w2][6] == bb) {
+                v = (k < 3) ? min(v, sh[w2][k]) : max(v, sh[w2][k]);
+                ++w2;
+            }
+            if (k < 3) atomicMin(&enc[bb * 3 + k], v);
+            else atomicMax(&enc[3 * B + bb * 3 + (k - 3)], v);
+            w = w2;
+        }
     }
 }
 

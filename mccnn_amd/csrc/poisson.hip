@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void poisson_phase(const float* __restrict__ pt
 // at once and `__any` decides. Selections made inside the cell during the walk are mirrored in the register copies.
 // A thread per cell (the reference's mapping, and this repo's first version) leaves 8000 threads with long dependent
 // load chains per launch: 29 ms for a 100k-point room; this kernel: well under 1 ms for the 27 phases.
-#define MCCNN_PS_ROUNDS 4
+#define MCCNN_PS_ROUNDS 12
 __global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restrict__ pts, const int* __restrict__ cells,
                                                           const float* __restrict__ mn, const float* __restrict__ mx,
                                                           int B, PoissonDims d, int ph, float radius, int scaleInv,
@@ -128,8 +128,11 @@ __global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restric
         float cx[MCCNN_PS_ROUNDS], cy[MCCNN_PS_ROUNDS], cz[MCCNN_PS_ROUNDS];
         int cj[MCCNN_PS_ROUNDS];
         bool cs[MCCNN_PS_ROUNDS];
+        const int nr = (total + 63) >> 6;  // rounds actually needed (wave-uniform): skip the rest
 #pragma unroll
         for (int rd = 0; rd < MCCNN_PS_ROUNDS; ++rd) {
+            cj[rd] = -1; cx[rd] = cy[rd] = cz[rd] = 0.f; cs[rd] = false;
+            if (rd >= nr) continue;
             const int c = rd * 64 + lane;
             // which of the 27 ranges holds flat candidate c: largest s with excl_s <= c
             int sidx = 0;
@@ -147,18 +150,31 @@ __global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restric
             cz[rd] = valid ? pts[(size_t)j * 3 + 2] : 0.f;
             cs[rd] = valid ? (sel[j] != 0) : false;
         }
+        // the cell's own points are candidates too (offset (0,0,0) is entry 17 of the table): fetch their coordinates
+        // from the register copies with shuffles instead of n dependent global loads
+        const int ownBase = __shfl(excl, 17, 64);
         for (int i = me.x; i < me.y; ++i) {
-            const float px = pts[(size_t)i * 3], py = pts[(size_t)i * 3 + 1], pz = pts[(size_t)i * 3 + 2];
+            const int c = ownBase + (i - me.x);
+            const int src = c & 63, rsel = c >> 6;
+            float px = 0.f, py = 0.f, pz = 0.f;
+#pragma unroll
+            for (int rd = 0; rd < MCCNN_PS_ROUNDS; ++rd) {
+                if (rd == rsel) {  // wave-uniform
+                    px = __shfl(cx[rd], src, 64);
+                    py = __shfl(cy[rd], src, 64);
+                    pz = __shfl(cz[rd], src, 64);
+                }
+            }
             bool coll = false;
 #pragma unroll
             for (int rd = 0; rd < MCCNN_PS_ROUNDS; ++rd)
-                coll |= cs[rd] && (point_dist2(cx[rd], cy[rd], cz[rd], px, py, pz) < T);
+                if (rd < nr) coll |= cs[rd] && (point_dist2(cx[rd], cy[rd], cz[rd], px, py, pz) < T);
             if (!__any(coll)) {
                 if (lane == 0) sel[i] = 1;
                 ++kept;
 #pragma unroll
                 for (int rd = 0; rd < MCCNN_PS_ROUNDS; ++rd)
-                    if (cj[rd] == i) cs[rd] = true;
+                    if (rd < nr && cj[rd] == i) cs[rd] = true;
             }
         }
     } else {
