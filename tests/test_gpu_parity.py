@@ -75,6 +75,22 @@ def test_grid_neighbors_pdf_poisson(mc, oracle, case):
     assert_close(_unwrap(fast), o["pdfs"], RTOL, "pdfs(mode 1)")
 
 
+def test_dense_cells(mc, oracle):
+    """A few very dense cells (>1000 points in one 27-window): exercises the streaming branch of the Poisson kernel,
+    long cell segments in the stable ranking and long CSR rows."""
+    rng = np.random.default_rng(13)
+    blob = (0.5 + 0.012 * rng.normal(size=(900, 3))).astype(np.float32)
+    rest = rng.random((400, 3), dtype=np.float32)
+    pts = np.concatenate([blob, rest]).astype(np.float32)
+    rng.shuffle(pts)
+    bids = np.zeros((len(pts), 1), np.int32)
+    feats = rng.random((len(pts), 2), dtype=np.float32)
+    g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, 1, 0.1, True, poisson_radius=0.1, pdf_kwargs=dict(mode=0))
+    o = run_chain(oracle, _ident, _ident, pts, bids, feats, 1, 0.1, True, poisson_radius=0.1)
+    assert np.diff(np.append(o["startIndexs"][:, 0], len(o["packedNeighs"]))).max() > 800
+    compare_chain(g, o, pdf_rtol=2e-6)
+
+
 def test_room_absolute_radius(mc, oracle):
     """Headline-like input: non-uniform room, absolute radius 0.1 (whole-batch box), 2 rooms x 20k points."""
     B = 2
