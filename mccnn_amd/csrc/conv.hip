@@ -210,25 +210,6 @@ __device__ __forceinline__ int dpp_i(int v) {
 // max(x, 0) as ONE instruction (v_med3_f32); fmaxf() costs an extra canonicalising v_max on MFMA results
 __device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()); }
 
-
-#ifdef MCCNN_TIMING
-__device__ unsigned long long g_timing[16];
-#define TSTART() unsigned long long t__ = __builtin_readcyclecounter(); (void)t__
-#define TSTAMP(k)                                                                      \
-    do {                                                                               \
-        unsigned long long n__ = __builtin_readcyclecounter();                         \
-        if (blockIdx.x == 7 && threadIdx.x == 0) g_timing[k] += n__ - t__;             \
-        t__ = n__;                                                                     \
-    } while (0)
-extern "C" int mccnn_debug_timing(unsigned long long* host16, int reset) {
-    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timing), z, sizeof(z)); }
-    return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_timing), 16 * sizeof(unsigned long long));
-}
-#else
-#define TSTART()
-#define TSTAMP(k)
-#endif
-
 // Stage the MLP tensors of all nb blocks into LDS in the per-block layout above.
 template <int WQ>
 __device__ __forceinline__ void stage_weights(const ConvArgs& a, float* wl) {
@@ -247,43 +228,23 @@ __device__ __forceinline__ void stage_weights(const ConvArgs& a, float* wl) {
     }
 }
 
-// One 8x8 layer for 64 edges: y = bias + W x, rows i4 / 4+i4 of W supplied by this lane.
-// A dependent v_mfma_f32_4x4x1 chain advances only every ~38 cycles (measured with s_memtime: the 8-deep chains of
-// the first version cost 38-43 cycles per MFMA although the pipe is busy 8), so the K = 8 sum is split into
-// MCCNN_KSPLIT independent partial chains per accumulator (bias in the first, zeros in the others) that are added
-// at the end: dependent depth 8 / KSPLIT instead of 8.
-#ifndef MCCNN_KSPLIT
-#define MCCNN_KSPLIT 1
-#endif
+// One 8x8 layer for 64 edges: y = bias + W x, rows i4 / 4+i4 of W supplied by this lane. Two interleaved
+// accumulation chains (neurons 0-3 / 4-7); splitting K into more independent chains was measured slower
+// (tools/issue_probe.hip: a single dependent 4x4x1 chain already issues every ~15 cycles and is hidden from 2 waves
+// per SIMD up).
 __device__ __forceinline__ void layer8(const f32x4* __restrict__ wrows /* 16 x f32x4: row r at [2r],[2r+1] */,
-                                       f32x4 blo, f32x4 bhi, int i4, const float* x, float* y) {
+                                       f32x4 lo, f32x4 hi, int i4, const float* x, float* y) {
     f32x4 al0 = wrows[2 * i4], al1 = wrows[2 * i4 + 1];
     f32x4 ah0 = wrows[2 * (4 + i4)], ah1 = wrows[2 * (4 + i4) + 1];
     float al[8] = {al0.x, al0.y, al0.z, al0.w, al1.x, al1.y, al1.z, al1.w};
     float ah[8] = {ah0.x, ah0.y, ah0.z, ah0.w, ah1.x, ah1.y, ah1.z, ah1.w};
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 lo[MCCNN_KSPLIT], hi[MCCNN_KSPLIT];
-    lo[0] = blo;
-    hi[0] = bhi;
 #pragma unroll
-    for (int c = 1; c < MCCNN_KSPLIT; ++c) { lo[c] = z; hi[c] = z; }
-    constexpr int PER = 8 / MCCNN_KSPLIT;
-#pragma unroll
-    for (int kk = 0; kk < PER; ++kk) {
-#pragma unroll
-        for (int c = 0; c < MCCNN_KSPLIT; ++c) {
-            const int k = c * PER + kk;
-            lo[c] = MFMA4(al[k], x[k], lo[c]);
-            hi[c] = MFMA4(ah[k], x[k], hi[c]);
-        }
+    for (int k = 0; k < 8; ++k) {
+        lo = MFMA4(al[k], x[k], lo);
+        hi = MFMA4(ah[k], x[k], hi);
     }
 #pragma unroll
-    for (int st = MCCNN_KSPLIT / 2; st >= 1; st >>= 1) {
-#pragma unroll
-        for (int c = 0; c < st; ++c) { lo[c] += lo[c + st]; hi[c] += hi[c + st]; }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { y[r] = lo[0][r]; y[4 + r] = hi[0][r]; }
+    for (int r = 0; r < 4; ++r) { y[r] = lo[r]; y[4 + r] = hi[r]; }
 }
 
 // Kernel MLP of block q (weights at wq in LDS) for the 64 edges of a wave.
@@ -292,15 +253,13 @@ __device__ __forceinline__ void mlp_block_mfma(const float* __restrict__ wq, int
                                                float* pre1, float* a1, float* pre2, float* a2, float* o) {
     const f32x4* w = reinterpret_cast<const f32x4*>(wq);
     f32x4 a1lo = w[i4], a1hi = w[4 + i4];
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    // layer 1 (K = 3): three independent rank-1 updates per accumulator, summed afterwards
-    f32x4 l0 = MFMA4(a1lo.x, d0, w[8]);  // + b1
-    f32x4 h0 = MFMA4(a1hi.x, d0, w[9]);
-    f32x4 l1 = MFMA4(a1lo.y, d1, z);
-    f32x4 h1 = MFMA4(a1hi.y, d1, z);
-    f32x4 l2 = MFMA4(a1lo.z, d2, z);
-    f32x4 h2 = MFMA4(a1hi.z, d2, z);
-    f32x4 lo = (l0 + l1) + l2, hi = (h0 + h1) + h2;
+    f32x4 lo = w[8], hi = w[9];  // b1
+    lo = MFMA4(a1lo.x, d0, lo);
+    hi = MFMA4(a1hi.x, d0, hi);
+    lo = MFMA4(a1lo.y, d1, lo);
+    hi = MFMA4(a1hi.y, d1, hi);
+    lo = MFMA4(a1lo.z, d2, lo);
+    hi = MFMA4(a1hi.z, d2, hi);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { pre1[r] = lo[r]; pre1[4 + r] = hi[r]; }
 #pragma unroll
@@ -399,12 +358,7 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(ConvArgs a, float* __restri
 
         for (int q = 0; q < a.nb; ++q) {
             float pre1[8], a1[8], pre2[8], a2[8], o[8], c[8];
-#ifdef ABL_NOMLP
-#pragma unroll
-            for (int n = 0; n < 8; ++n) o[n] = ec.d0 + n * ec.d1 + q;
-#else
             mlp_block_mfma(wl + q * MCCNN_WQ_FWD, i4, ec.d0, ec.d1, ec.d2, pre1, a1, pre2, a2, o);
-#endif
             const bool full = (q * 8 + 8 <= a.neuronsOut);
             if (FEAT == 2) {
                 const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)ec.j * a.Fin + q * 8);
@@ -423,7 +377,6 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(ConvArgs a, float* __restri
                     c[n] = (nu < a.neuronsOut) ? a.feats[(size_t)ec.j * a.Fin + fin] * o[n] * ec.inv : 0.f;
                 }
             }
-#ifndef ABL_NOSCAN
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
                 float v = c[n];
@@ -433,13 +386,7 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(ConvArgs a, float* __restri
                 v = fmaf(m8, dpp_f<DPP_ROW_SHR(8)>(v), v);
                 c[n] = v;
             }
-#endif
-#ifdef ABL_NOTAIL
-            asm volatile("" ::"v"(c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7]));
-            if (false) {
-#else
             if (tail) {
-#endif
                 if (!COMBIN || a.Fin == 1) {
                     float* dst = row + q * 8;
                     if (full) {
@@ -516,327 +463,6 @@ __global__ __launch_bounds__(256) void edge_records(ConvArgs a, float4* __restri
                          __builtin_amdgcn_rcpf(a.pdfs[t] * K));
 }
 
-// Forward, q-outer sweep (the default MFMA forward). The chunk-outer kernel above re-reads every weight operand
-// from LDS for every 64-edge chunk (16 ds_read_b128 per chunk and block -- the LDS pipe, not the MFMA pipe, was its
-// limiter); here one MLP block's operands are read ONCE per (wave, block) and stay in VGPRs while the wave sweeps
-// its edges, which arrive as coalesced, prefetched per-edge records (edge_records). Same centre-aligned ranges,
-// same LDS output tile, same segmented DPP reduction.
-struct BlockWeights {
-    f32x4 a1lo, a1hi, b1lo, b1hi;
-    f32x4 w2l0, w2l1, w2h0, w2h1, b2lo, b2hi;
-    f32x4 w3l0, w3l1, w3h0, w3h1, b3lo, b3hi;
-};
-__device__ __forceinline__ BlockWeights load_block_weights(const float* wq, int i4) {
-    const f32x4* w = reinterpret_cast<const f32x4*>(wq);
-    BlockWeights r;
-    r.a1lo = w[i4]; r.a1hi = w[4 + i4]; r.b1lo = w[8]; r.b1hi = w[9];
-    r.w2l0 = w[10 + 2 * i4]; r.w2l1 = w[11 + 2 * i4]; r.w2h0 = w[10 + 2 * (4 + i4)]; r.w2h1 = w[11 + 2 * (4 + i4)];
-    r.b2lo = w[26]; r.b2hi = w[27];
-    r.w3l0 = w[28 + 2 * i4]; r.w3l1 = w[29 + 2 * i4]; r.w3h0 = w[28 + 2 * (4 + i4)]; r.w3h1 = w[29 + 2 * (4 + i4)];
-    r.b3lo = w[44]; r.b3hi = w[45];
-    return r;
-}
-__device__ __forceinline__ void layer8r(f32x4 al0, f32x4 al1, f32x4 ah0, f32x4 ah1, f32x4 lo, f32x4 hi, const float* x,
-                                        float* y) {
-    float al[8] = {al0.x, al0.y, al0.z, al0.w, al1.x, al1.y, al1.z, al1.w};
-    float ah[8] = {ah0.x, ah0.y, ah0.z, ah0.w, ah1.x, ah1.y, ah1.z, ah1.w};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        lo = MFMA4(al[k], x[k], lo);
-        hi = MFMA4(ah[k], x[k], hi);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { y[r] = lo[r]; y[4 + r] = hi[r]; }
-}
-__device__ __forceinline__ void mlp_block_regs(const BlockWeights& W, float d0, float d1, float d2, float* o) {
-    f32x4 lo = W.b1lo, hi = W.b1hi;
-    lo = MFMA4(W.a1lo.x, d0, lo);
-    hi = MFMA4(W.a1hi.x, d0, hi);
-    lo = MFMA4(W.a1lo.y, d1, lo);
-    hi = MFMA4(W.a1hi.y, d1, hi);
-    lo = MFMA4(W.a1lo.z, d2, lo);
-    hi = MFMA4(W.a1hi.z, d2, hi);
-    float a1[8], pre2[8], a2[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { a1[r] = relu1(lo[r]); a1[4 + r] = relu1(hi[r]); }
-    layer8r(W.w2l0, W.w2l1, W.w2h0, W.w2h1, W.b2lo, W.b2hi, a1, pre2);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) a2[r] = relu1(pre2[r]);
-    layer8r(W.w3l0, W.w3l1, W.w3h0, W.w3h1, W.b3lo, W.b3hi, a2, o);
-}
-
-template <bool COMBIN, int FEAT>
-__global__ __launch_bounds__(256) void conv_fwd_sweep(ConvArgs a, const float4* __restrict__ rec, float* __restrict__ out) {
-    extern __shared__ float lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
-    const int G = a.G, outF = a.outF;
-    float* wl = lds;
-    float* tile = lds + a.nb * MCCNN_WQ_FWD + (size_t)wave * (G * outF);
-    stage_weights<MCCNN_WQ_FWD>(a, wl);
-    const int c0 = (blockIdx.x * 4 + wave) * G;
-    const int c1 = min(c0 + G, a.m);
-    if (c0 < a.m)
-        for (int k = lane; k < G * outF; k += 64) tile[k] = 0.0f;
-    __syncthreads();
-    if (c0 >= a.m) return;
-    const int eBeg = a.start[c0];
-    const int eEnd = (c1 < a.m) ? a.start[c1] : a.e;
-
-    for (int q = 0; q < a.nb; ++q) {
-        const BlockWeights W = load_block_weights(wl + q * MCCNN_WQ_FWD, i4);
-        const bool full = (q * 8 + 8 <= a.neuronsOut);
-        int2 prN = make_int2(0, c0);
-        float4 rcN = make_float4(0.f, 0.f, 0.f, 0.f);
-        {
-            int t0 = min(eBeg + lane, a.e - 1);
-            prN = a.packed[t0];
-            rcN = rec[t0];
-        }
-        for (int base = eBeg; base < eEnd; base += 64) {
-            const int t = base + lane;
-            const bool act = t < eEnd;
-            const int2 pr = prN;
-            const float4 rc = rcN;
-            const int j = pr.x;
-            const float inv = act ? rc.w : 0.f;
-            // this chunk's gathers first, then the prefetch (vmcnt retires in order)
-            float s[8];
-            if (FEAT == 1) {
-                float f1 = a.feats[j] * inv;
-#pragma unroll
-                for (int n = 0; n < 8; ++n) s[n] = f1;
-            } else if (FEAT == 2) {
-                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)j * a.Fin + q * 8);
-                float4 fa = fp[0], fb = fp[1];
-                s[0] = fa.x * inv; s[1] = fa.y * inv; s[2] = fa.z * inv; s[3] = fa.w * inv;
-                s[4] = fb.x * inv; s[5] = fb.y * inv; s[6] = fb.z * inv; s[7] = fb.w * inv;
-            } else {
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    int nu = q * 8 + n;
-                    s[n] = (nu < a.neuronsOut) ? a.feats[(size_t)j * a.Fin + nu % a.Fin] * inv : 0.f;
-                }
-            }
-            {
-                int tn = min(t + 64, a.e - 1);  // clamped: keeps the prefetch branch-free
-                prN = a.packed[tn];
-                rcN = rec[tn];
-            }
-            const int key1 = act ? (pr.y - c0 + 1) : 0;  // 0 = no edge
-            const float m1 = (key1 != 0 && dpp_i<DPP_ROW_SHR(1)>(key1) == key1) ? 1.f : 0.f;
-            const float m2 = (key1 != 0 && dpp_i<DPP_ROW_SHR(2)>(key1) == key1) ? 1.f : 0.f;
-            const float m4 = (key1 != 0 && dpp_i<DPP_ROW_SHR(4)>(key1) == key1) ? 1.f : 0.f;
-            const float m8 = (key1 != 0 && dpp_i<DPP_ROW_SHR(8)>(key1) == key1) ? 1.f : 0.f;
-            const bool tail = act && (dpp_i<DPP_ROW_SHL(1)>(key1) != key1);
-            float o[8], c[8];
-            mlp_block_regs(W, rc.x, rc.y, rc.z, o);
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                float v = s[n] * o[n];
-                v = fmaf(m1, dpp_f<DPP_ROW_SHR(1)>(v), v);
-                v = fmaf(m2, dpp_f<DPP_ROW_SHR(2)>(v), v);
-                v = fmaf(m4, dpp_f<DPP_ROW_SHR(4)>(v), v);
-                v = fmaf(m8, dpp_f<DPP_ROW_SHR(8)>(v), v);
-                c[n] = v;
-            }
-            if (tail) {
-                float* row = tile + (size_t)(key1 - 1) * outF;
-                if (!COMBIN || a.Fin == 1) {
-                    float* dst = row + q * 8;
-                    if (full) {
-#pragma unroll
-                        for (int n = 0; n < 8; ++n) atomicAdd(&dst[n], c[n]);  // ds_add_f32, wave-private tile
-                    } else {
-#pragma unroll
-                        for (int n = 0; n < 8; ++n)
-                            if (q * 8 + n < a.neuronsOut) atomicAdd(&dst[n], c[n]);
-                    }
-                } else {
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) {
-                        int nu = q * 8 + n;
-                        if (nu < a.neuronsOut) atomicAdd(&row[nu / a.Fin], c[n]);
-                    }
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int cnt = (c1 - c0) * outF;
-    float* dst = out + (size_t)c0 * outF;
-    for (int k = lane; k < cnt; k += 64) dst[k] = tile[k];
-}
-
-// ---------------------------------------------------------------------------------------
-// "Slot" kernels: a LANE owns a whole output row (a centre, or a point j for the transposed pass) and walks that
-// row's edges one per step, so the sum over a row's edges is a plain per-lane accumulation -- no segmented scan,
-// no LDS tile, no atomics, rows written once, bit-reproducible. What makes it efficient is the row order: rows are
-// visited in DEGREE-SORTED order (counting sort of the row lengths, longest first), so the 64 rows of a wave have
-// (almost) the same length and the lanes stay busy together. q-outer: one MLP block's weight operands are loaded
-// once per (wave, block) and stay in VGPRs for the whole walk; per step only the per-edge record is fetched
-// (each lane streams through consecutive records -> L1-friendly), the kernel is bound by its 38 MFMAs per step.
-// ---------------------------------------------------------------------------------------
-#define MCCNN_DEG_BINS 2048
-
-__global__ __launch_bounds__(256) void deg_hist(const int* __restrict__ rowStart, int rows, int total,
-                                                int* __restrict__ hist) {
-    __shared__ int h[MCCNN_DEG_BINS];
-    for (int k = threadIdx.x; k < MCCNN_DEG_BINS; k += blockDim.x) h[k] = 0;
-    __syncthreads();
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) {
-        int d = ((i + 1 < rows) ? rowStart[i + 1] : total) - rowStart[i];
-        atomicAdd(&h[min(d, MCCNN_DEG_BINS - 1)], 1);
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < MCCNN_DEG_BINS; k += blockDim.x)
-        if (h[k]) atomicAdd(&hist[k], h[k]);
-}
-// offsets for DESCENDING degree: off[k] = #rows with degree bin > k. One block.
-__global__ __launch_bounds__(256) void deg_offsets(const int* __restrict__ hist, int* __restrict__ off) {
-    __shared__ int part[256];
-    const int per = MCCNN_DEG_BINS / 256;  // 8 bins per thread, thread 0 owns the HIGHEST bins
-    int base = MCCNN_DEG_BINS - 1 - threadIdx.x * per;
-    int s = 0;
-    for (int k = 0; k < per; ++k) s += hist[base - k];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    int pre = 0;
-    for (int t = 0; t < (int)threadIdx.x; ++t) pre += part[t];
-    for (int k = 0; k < per; ++k) {
-        off[base - k] = pre;
-        pre += hist[base - k];
-    }
-}
-__global__ __launch_bounds__(256) void deg_scatter(const int* __restrict__ rowStart, int rows, int total,
-                                                   int* __restrict__ cursor /* = offsets, consumed */,
-                                                   int* __restrict__ perm) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
-    int d = ((i + 1 < rows) ? rowStart[i + 1] : total) - rowStart[i];
-    perm[atomicAdd(&cursor[min(d, MCCNN_DEG_BINS - 1)], 1)] = i;
-}
-
-struct SlotArgs {
-    const int* rowStart;   // CSR row starts (rows entries)
-    const int* rowPerm;    // rows in degree-sorted order
-    const int* edgePerm;   // edge id of CSR slot (nullptr = identity)
-    const float* gather;   // [*, F] rows multiplied into the MLP output (features / outGrad)
-    int rows, total, F;
-    int gatherByNeighbour; // 1: gather row = packed[e].x (forward), 0: packed[e].y (transposed pass)
-};
-
-// recW: per-edge (delta0, delta1, delta2, w). FEAT == 1: w already contains feature * 1/(pdf K).
-template <bool COMBIN, int FEAT>
-__global__ __launch_bounds__(256) void conv_slot(ConvArgs a, SlotArgs sa, const float4* __restrict__ rec,
-                                                 float* __restrict__ out) {
-    extern __shared__ float lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
-    float* wl = lds;
-    stage_weights<MCCNN_WQ_FWD>(a, wl);
-    __syncthreads();
-    const int slot = (blockIdx.x * 4 + wave) * 64 + lane;
-    const bool live = slot < sa.rows;
-    const int row = live ? sa.rowPerm[slot] : 0;
-    const int s0 = live ? sa.rowStart[row] : 0;
-    const int deg = live ? (((row + 1 < sa.rows) ? sa.rowStart[row + 1] : sa.total) - s0) : 0;
-    int kmax = deg;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) kmax = max(kmax, __shfl_xor(kmax, d, 64));
-    if (kmax == 0) {  // rows without edges still have to be written (zeros)
-        if (live)
-            for (int f = 0; f < a.outF; ++f) out[(size_t)row * a.outF + f] = 0.f;
-        return;
-    }
-    const int F = sa.F;
-    float* orow = out + (size_t)row * a.outF;
-
-    for (int q = 0; q < a.nb; ++q) {
-        const BlockWeights W = load_block_weights(wl + q * MCCNN_WQ_FWD, i4);
-        float oacc[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) oacc[n] = 0.f;
-        // software pipeline: the record (and the gather index) of step t+1 is fetched during step t
-        int eN = (deg > 0) ? (sa.edgePerm ? sa.edgePerm[s0] : s0) : 0;
-        float4 rcN = rec[eN];
-        int gN = 0;
-        if (FEAT != 1) gN = sa.gatherByNeighbour ? a.packed[eN].x : a.packed[eN].y;
-        for (int t = 0; t < kmax; ++t) {
-            const bool act = t < deg;
-            const float4 rc = rcN;
-            const int gi = gN;
-            float s[8];
-            if (FEAT == 1) {
-#pragma unroll
-                for (int n = 0; n < 8; ++n) s[n] = act ? rc.w : 0.f;
-            } else if (FEAT == 2) {
-                const float4* fp = reinterpret_cast<const float4*>(sa.gather + (size_t)gi * F + q * 8);
-                float4 fa = fp[0], fb = fp[1];
-                const float w = act ? rc.w : 0.f;
-                s[0] = fa.x * w; s[1] = fa.y * w; s[2] = fa.z * w; s[3] = fa.w * w;
-                s[4] = fb.x * w; s[5] = fb.y * w; s[6] = fb.z * w; s[7] = fb.w * w;
-            } else {
-                const float w = act ? rc.w : 0.f;
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    int nu = q * 8 + n;
-                    int col = COMBIN ? nu % F : nu;
-                    s[n] = (nu < a.neuronsOut) ? sa.gather[(size_t)gi * F + col] * w : 0.f;
-                }
-            }
-            {
-                int tn = min(t + 1, max(deg - 1, 0));
-                eN = sa.edgePerm ? sa.edgePerm[s0 + tn] : (s0 + tn);
-                if (deg == 0) eN = 0;
-                rcN = rec[eN];
-                if (FEAT != 1) gN = sa.gatherByNeighbour ? a.packed[eN].x : a.packed[eN].y;
-            }
-            float o[8];
-            mlp_block_regs(W, rc.x, rc.y, rc.z, o);
-#pragma unroll
-            for (int n = 0; n < 8; ++n) oacc[n] = fmaf(s[n], o[n], oacc[n]);
-        }
-        if (live) {
-            if (!COMBIN || F == 1) {
-                if (q * 8 + 8 <= a.neuronsOut && (a.outF & 3) == 0) {
-                    float4* d4 = reinterpret_cast<float4*>(orow + q * 8);
-                    d4[0] = make_float4(oacc[0], oacc[1], oacc[2], oacc[3]);
-                    d4[1] = make_float4(oacc[4], oacc[5], oacc[6], oacc[7]);
-                } else {
-#pragma unroll
-                    for (int n = 0; n < 8; ++n)
-                        if (q * 8 + n < a.neuronsOut) orow[q * 8 + n] = oacc[n];
-                }
-            } else {
-                // several neurons share an output feature (fo = nu / Fin); this lane owns the row: plain RMW
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    int nu = q * 8 + n;
-                    if (nu < a.neuronsOut) {
-                        int fo = nu / F;
-                        orow[fo] = (nu % F == 0) ? oacc[n] : orow[fo] + oacc[n];
-                    }
-                }
-            }
-        }
-    }
-}
-
-// edge records with the feature folded in (Fin == 1 combin): w = feats[j] / (pdf K)
-__global__ __launch_bounds__(256) void edge_records_f1(ConvArgs a, float4* __restrict__ rec) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.e) return;
-    int2 pr = a.packed[t];
-    float invR = a.invRadius;
-    if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, a.bids[pr.x]));
-    const float* p = a.pts + (size_t)pr.x * 3;
-    const float* c = a.samples + (size_t)pr.y * 3;
-    int e0 = a.start[pr.y];
-    int e1 = (pr.y < a.m - 1) ? a.start[pr.y + 1] : a.e;
-    float K = a.avg ? (float)(e1 - e0) : 1.0f;
-    rec[t] = make_float4((p[0] - c[0]) * invR, (p[1] - c[1]) * invR, (p[2] - c[2]) * invR,
-                         a.feats[pr.x] * __builtin_amdgcn_rcpf(a.pdfs[t] * K));
-}
-
 #ifndef MCCNN_BWD_OCC
 #define MCCNN_BWD_OCC 2
 #endif
@@ -883,7 +509,6 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
         for (int base = eBeg; base < eEnd; base += 64) {
             const int t = base + lane;
             const bool act = t < eEnd;
-            TSTART();
             const int2 pr = prN;
             const float4 rc = rcN;
             const int j = pr.x;
@@ -900,15 +525,8 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #pragma unroll
                 for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; ff[n] = f8[n]; }
             } else if (FEAT == 1) {
-#ifdef ABL_NOGATHER
-                float f = rc.x;
-#pragma unroll
-                for (int n = 0; n < 8; ++n) { g[n] = act ? rc.y + n : 0.f; ff[n] = f; }
-                if (false) {
-#else
                 float f = a.feats[j];
                 if (numOuts == 8 && (outF & 3) == 0) {
-#endif
                     const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
                     float4 ga = gp[0], gb = gp[1];
                     float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
@@ -930,9 +548,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
                 }
             }
             float dfOld = 0.f;
-#ifndef ABL_NODFE
             if (COMBIN && FEAT == 1 && act && q > 0) dfOld = dfE[t];
-#endif
             // prefetch the next chunk AFTER this chunk's gathers: vmcnt retires in order, so the waits for g / f
             // leave these two loads in flight across the whole iteration
             {
@@ -940,7 +556,6 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
                 prN = a.packed[tn];
                 rcN = rec[tn];
             }
-            TSTAMP(1);
             float a1[8], a2[8], o[8];
             bool p1[8], p2[8];  // pre-activation >= 0 (ReLU' of the reference: spatial_conv.cu:404,429), kept as lane masks
             // keep the LDS weight reads inside the chunk loop: hoisted, they would pin ~100 VGPRs and spill the
@@ -951,16 +566,10 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
             const f32x4* w4 = reinterpret_cast<const f32x4*>(wq);
             {
                 float pre1[8], pre2[8];
-#ifdef ABL_NOMLPB
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { pre1[k] = rc.x + k; pre2[k] = rc.y - k; a1[k] = pre1[k]; a2[k] = pre2[k]; o[k] = rc.z * k; }
-#else
                 mlp_block_mfma(wq, i4, rc.x, rc.y, rc.z, pre1, a1, pre2, a2, o);
-#endif
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { p1[k] = pre1[k] >= 0.0f; p2[k] = pre2[k] >= 0.0f; }
             }
-            TSTAMP(2);
             // feature gradient: og * o / (pdf K)   (spatial_conv.cu:400)
             if (COMBIN) {
                 if (FEAT == 1) {
@@ -968,11 +577,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #pragma unroll
                     for (int n = 0; n < 8; ++n) sfg = fmaf(g[n], o[n], sfg);
                     sfg *= inv;
-#ifndef ABL_NODFE
                     if (act) dfE[t] = dfOld + sfg;  // this lane owns edge t: plain RMW, no atomics
-#else
-                    asm volatile("" ::"v"(sfg + dfOld));
-#endif
                 } else if (act) {
                     // several neurons of a block may share fin: fold them in registers first
                     for (int f = 0; f < a.Fin; ++f) {
@@ -996,9 +601,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
             float gf[8];
 #pragma unroll
             for (int n = 0; n < 8; ++n) gf[n] = g[n] * ff[n];
-            TSTAMP(3);
             // dW3 += u a2^T, db3 += u, u = g f / (pdf K)          (spatial_conv.cu:383-399)
-#ifndef ABL_NOWG
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
                 float u = gf[n] * inv;
@@ -1006,42 +609,21 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
                 for (int k = 0; k < 8; ++k) gw3[n * 8 + k] = fmaf(u, a2[k], gw3[n * 8 + k]);
                 gb3[n] += u;
             }
-#else
-            gw3[0] += a2[0] + a2[1] + a2[2] + a2[3] + a2[4] + a2[5] + a2[6] + a2[7];
-#endif
-            TSTAMP(4);
             // t3 = 1[pre2 >= 0] * W3^T (g f) / (pdf K)             (:403-414)
             float t3[8];
-#ifdef ABL_NOT34
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t3[k] = gf[k];
-#else
             layer8(w4 + 62, zero4, zero4, i4, gf, t3);  // W3^T rows at float 248 -> f32x4 index 62
-#endif
 #pragma unroll
             for (int k = 0; k < 8; ++k) t3[k] = p2[k] ? t3[k] * inv : 0.f;
-            TSTAMP(5);
             // dW2 += t3 a1^T, db2 += t3                            (:419-425)
-#ifndef ABL_NOWG
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
 #pragma unroll
                 for (int l = 0; l < 8; ++l) gw2[k * 8 + l] = fmaf(t3[k], a1[l], gw2[k * 8 + l]);
                 gb2[k] += t3[k];
             }
-#else
-            gw2[0] += a1[0] + a1[1] + a1[2] + a1[3] + a1[4] + a1[5] + a1[6] + a1[7];
-#endif
-            TSTAMP(6);
             // t4 = 1[pre1 >= 0] * W2^T t3                          (:428-434)
             float t4[8];
-#ifdef ABL_NOT34
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t4[k] = t3[k];
-#else
             layer8(w4 + 46, zero4, zero4, i4, t3, t4);  // W2^T rows at float 184 -> f32x4 index 46
-#endif
-            TSTAMP(7);
             // dW1 += t4 delta^T, db1 += t4                         (:439-444)
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
@@ -1051,7 +633,6 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
                 gw1[l * 3 + 2] = fmaf(v, rc.z, gw1[l * 3 + 2]);
                 gb1[l] += v;
             }
-            TSTAMP(8);
         }
         // transposing wave reduction; partial row layout: w1[24] b1[8] w2[64] b2[8] w3[64] b3[8]
         {
@@ -1071,246 +652,6 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
             if (lane < 32) pq[lane] = rm;                 // w1, b1
             else if (lane < 40) pq[96 + lane - 32] = rm;  // b2
             else if (lane < 48) pq[168 + lane - 40] = rm; // b3
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Backward, all-MFMA version (default). Same sweep structure as conv_bwd_mfma, but the weight-gradient outer
-// products also run on the matrix pipe, so the 176 VGPR accumulators (and their spills / 2-wave occupancy)
-// disappear. In the MLP chains a lane is an edge; for the outer products a QUAD is an edge:
-//     D[lane 4b+j][reg r] += A(lane 4b+r) * B(lane 4b+j)
-// with A = u_e[r], B = a2_e[j] is exactly the 4x4 tile (rows r, cols j) of u_e a2_e^T for the edge e of quad b,
-// accumulated over time = over edges. The per-lane vectors (u, a2, t3, a1, t4, [delta,1]) go through a small
-// wave-private LDS buffer (32 edges at a time, row stride 12 floats: conflict-free for the b128 writes and the
-// quad-layout b32 reads) to change layout. 14 accumulator tiles per block:
-//   dW3 (4) db3 (2, B = 1) dW2 (4) db2 (2) [dW1 | db1] (2, B = [delta, 1])  -> 56 MFMAs per 64 edges.
-// Per (wave, block) the 16 quads' tiles are summed with 4 xor-shuffles per register.
-// ---------------------------------------------------------------------------------------
-#define MCCNN_XROW 12                    // floats per 8-vector row in the transposition buffer
-#define MCCNN_XBUF (32 * (5 * MCCNN_XROW + 4))  // floats per wave: 32 edges x (u, a2, t3, a1, t4 rows + [delta,1])
-
-template <bool COMBIN, int FEAT>
-__global__ __launch_bounds__(256) void conv_bwd_mfma2(ConvArgs a, const float4* __restrict__ rec,
-                                                      const float* __restrict__ outGrad, float* __restrict__ featGrad,
-                                                      float* __restrict__ dfE, int cpw, float* __restrict__ partials) {
-    extern __shared__ float lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3, quad = lane >> 2;
-    const int outF = a.outF;
-    float* wl = lds;
-    float* xb = lds + a.nb * MCCNN_WQ_BWD + wave * MCCNN_XBUF;
-    stage_weights<MCCNN_WQ_BWD>(a, wl);
-    __syncthreads();
-    const int waveGlobal = blockIdx.x * 4 + wave;
-    const long long eBegL = (long long)waveGlobal * cpw * 64;
-    if (eBegL >= a.e) return;
-    const int eBeg = (int)eBegL;
-    const int eEnd = (int)min((long long)a.e, eBegL + (long long)cpw * 64);
-    float* prow = partials + (size_t)waveGlobal * a.nb * 176;
-    // transposition buffer addressing
-    float* xw = xb + (lane & 31) * MCCNN_XROW;           // my row when I write (edge = lane & 31)
-    float* xdw = xb + 5 * 32 * MCCNN_XROW + (lane & 31) * 4;
-    const int VEC = 32 * MCCNN_XROW;                     // floats between the 5 vector planes
-
-    for (int q = 0; q < a.nb; ++q) {
-        f32x4 acc[14];
-#pragma unroll
-        for (int k = 0; k < 14; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int numOuts = min(a.neuronsOut - q * 8, 8);
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-        int2 prN;
-        float4 rcN;
-        {
-            int t0 = min(eBeg + lane, a.e - 1);
-            prN = a.packed[t0];
-            rcN = rec[t0];
-        }
-        for (int base = eBeg; base < eEnd; base += 64) {
-            const int t = base + lane;
-            const bool act = t < eEnd;
-            const int2 pr = prN;
-            const float4 rc = rcN;
-            const int j = pr.x;
-            const float inv = act ? rc.w : 0.f;
-            // g_n and f_n first: the gathers fly while the MFMA chains run
-            float g[8], ff[8];
-            const float* grow = outGrad + (size_t)pr.y * outF;
-            if (FEAT == 2) {
-                const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
-                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)j * a.Fin + q * 8);
-                float4 ga = gp[0], gb = gp[1], fa = fp[0], fb = fp[1];
-                float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-                float f8[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
-#pragma unroll
-                for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; ff[n] = f8[n]; }
-            } else if (FEAT == 1) {
-                float f = a.feats[j];
-                if (numOuts == 8 && (outF & 3) == 0) {
-                    const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
-                    float4 ga = gp[0], gb = gp[1];
-                    float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; ff[n] = f; }
-                } else {
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) { g[n] = (act && n < numOuts) ? grow[q * 8 + n] : 0.f; ff[n] = f; }
-                }
-            } else {
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    int nu = q * 8 + n;
-                    int fin = COMBIN ? nu % a.Fin : nu;
-                    int fo = COMBIN ? nu / a.Fin : nu;
-                    bool ok = act && n < numOuts;
-                    g[n] = ok ? grow[fo] : 0.f;
-                    ff[n] = ok ? a.feats[(size_t)j * a.Fin + fin] : 0.f;
-                }
-            }
-            float dfOld = 0.f;
-            if (COMBIN && FEAT == 1 && act && q > 0) dfOld = dfE[t];
-            {
-                int tn = min(t + 64, a.e - 1);  // clamped: the prefetch stays branch-free
-                prN = a.packed[tn];
-                rcN = rec[tn];
-            }
-            float a1[8], a2[8], o[8];
-            bool p1[8], p2[8];
-            // keep the LDS weight reads inside the chunk loop (hoisted they would pin ~100 VGPRs)
-            int woff = q * MCCNN_WQ_BWD;
-            asm volatile("" : "+s"(woff));
-            const float* wq = wl + woff;
-            const f32x4* w4 = reinterpret_cast<const f32x4*>(wq);
-            {
-                float pre1[8], pre2[8];
-                mlp_block_mfma(wq, i4, rc.x, rc.y, rc.z, pre1, a1, pre2, a2, o);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { p1[k] = pre1[k] >= 0.0f; p2[k] = pre2[k] >= 0.0f; }
-            }
-            // feature gradient: og * o / (pdf K)   (spatial_conv.cu:400)
-            if (COMBIN) {
-                if (FEAT == 1) {
-                    float sfg = 0.f;
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) sfg = fmaf(g[n], o[n], sfg);
-                    if (act) dfE[t] = dfOld + sfg * inv;  // this lane owns edge t: plain RMW, no atomics
-                } else if (act) {
-                    for (int f = 0; f < a.Fin; ++f) {
-                        float sfg = 0.f;
-                        bool any = false;
-#pragma unroll
-                        for (int n = 0; n < 8; ++n) {
-                            int nu = q * 8 + n;
-                            if (n < numOuts && nu % a.Fin == f) { sfg = fmaf(g[n], o[n], sfg); any = true; }
-                        }
-                        if (any) {
-                            float* d = dfE + (size_t)t * a.Fin + f;
-                            // first touch of (t, f) happens in the block that holds neuron nu == f, i.e. q == f / 8
-                            float old = (q == f / 8) ? 0.f : *d;
-                            *d = old + sfg * inv;
-                        }
-                    }
-                }
-            }  // depth-wise layers: the feature gradient is computed by conv_dfeat_dw on the transposed list
-            float gf[8], u[8], t3[8], t4[8];
-#pragma unroll
-            for (int n = 0; n < 8; ++n) { gf[n] = g[n] * ff[n]; u[n] = gf[n] * inv; }
-            layer8(w4 + 62, zero4, zero4, i4, gf, t3);  // t3 = 1[pre2>=0] W3^T (g f) / (pdf K)   (:403-414)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t3[k] = p2[k] ? t3[k] * inv : 0.f;
-            layer8(w4 + 46, zero4, zero4, i4, t3, t4);  // t4 = 1[pre1>=0] W2^T t3                  (:428-434)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t4[k] = p1[k] ? t4[k] : 0.f;
-
-            // ---- outer products on the matrix pipe, 32 edges per pass through the transposition buffer
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if ((lane >> 5) == half) {
-                    f32x4* d = reinterpret_cast<f32x4*>(xw);
-                    d[0] = (f32x4){u[0], u[1], u[2], u[3]};
-                    d[1] = (f32x4){u[4], u[5], u[6], u[7]};
-                    d = reinterpret_cast<f32x4*>(xw + VEC);
-                    d[0] = (f32x4){a2[0], a2[1], a2[2], a2[3]};
-                    d[1] = (f32x4){a2[4], a2[5], a2[6], a2[7]};
-                    d = reinterpret_cast<f32x4*>(xw + 2 * VEC);
-                    d[0] = (f32x4){t3[0], t3[1], t3[2], t3[3]};
-                    d[1] = (f32x4){t3[4], t3[5], t3[6], t3[7]};
-                    d = reinterpret_cast<f32x4*>(xw + 3 * VEC);
-                    d[0] = (f32x4){a1[0], a1[1], a1[2], a1[3]};
-                    d[1] = (f32x4){a1[4], a1[5], a1[6], a1[7]};
-                    d = reinterpret_cast<f32x4*>(xw + 4 * VEC);
-                    d[0] = (f32x4){t4[0], t4[1], t4[2], t4[3]};
-                    d[1] = (f32x4){t4[4], t4[5], t4[6], t4[7]};
-                    *reinterpret_cast<f32x4*>(xdw) = (f32x4){rc.x, rc.y, rc.z, 1.0f};
-                }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int sgrp = 0; sgrp < 2; ++sgrp) {
-                    const float* xr = xb + (sgrp * 16 + quad) * MCCNN_XROW + i4;  // row of my quad's edge, my component
-                    float ul = xr[0], uh = xr[4];
-                    float a2l = xr[VEC], a2h = xr[VEC + 4];
-                    float t3l = xr[2 * VEC], t3h = xr[2 * VEC + 4];
-                    float a1l = xr[3 * VEC], a1h = xr[3 * VEC + 4];
-                    float t4l = xr[4 * VEC], t4h = xr[4 * VEC + 4];
-                    float dl = xb[5 * 32 * MCCNN_XROW + (sgrp * 16 + quad) * 4 + i4];
-                    acc[0] = MFMA4(ul, a2l, acc[0]);
-                    acc[1] = MFMA4(ul, a2h, acc[1]);
-                    acc[2] = MFMA4(uh, a2l, acc[2]);
-                    acc[3] = MFMA4(uh, a2h, acc[3]);
-                    acc[4] = MFMA4(ul, 1.0f, acc[4]);
-                    acc[5] = MFMA4(uh, 1.0f, acc[5]);
-                    acc[6] = MFMA4(t3l, a1l, acc[6]);
-                    acc[7] = MFMA4(t3l, a1h, acc[7]);
-                    acc[8] = MFMA4(t3h, a1l, acc[8]);
-                    acc[9] = MFMA4(t3h, a1h, acc[9]);
-                    acc[10] = MFMA4(t3l, 1.0f, acc[10]);
-                    acc[11] = MFMA4(t3h, 1.0f, acc[11]);
-                    acc[12] = MFMA4(t4l, dl, acc[12]);
-                    acc[13] = MFMA4(t4h, dl, acc[13]);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        // sum the 16 quads' tiles; afterwards every quad holds the totals, lanes 0..3 store them
-#pragma unroll
-        for (int k = 0; k < 14; ++k) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[k][r];
-                v += __shfl_xor(v, 4, 64);
-                v += __shfl_xor(v, 8, 64);
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                acc[k][r] = v;
-            }
-        }
-        if (lane < 4) {
-            float* pq = prow + q * 176;  // w1[24] b1[8] w2[64] b2[8] w3[64] b3[8]
-            const int jc = lane;         // column index of the tiles
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pq[104 + r * 8 + jc] = acc[0][r];            // dW3[n=r][m=jc]
-                pq[104 + r * 8 + 4 + jc] = acc[1][r];        // dW3[r][4+jc]
-                pq[104 + (4 + r) * 8 + jc] = acc[2][r];      // dW3[4+r][jc]
-                pq[104 + (4 + r) * 8 + 4 + jc] = acc[3][r];  // dW3[4+r][4+jc]
-                pq[32 + r * 8 + jc] = acc[6][r];             // dW2[k=r][l=jc]
-                pq[32 + r * 8 + 4 + jc] = acc[7][r];
-                pq[32 + (4 + r) * 8 + jc] = acc[8][r];
-                pq[32 + (4 + r) * 8 + 4 + jc] = acc[9][r];
-                if (jc < 3) {
-                    pq[r * 3 + jc] = acc[12][r];             // dW1[l=r][d=jc]
-                    pq[(4 + r) * 3 + jc] = acc[13][r];
-                } else {
-                    pq[24 + r] = acc[12][r];                 // db1[l=r] (B column 3 is the constant 1)
-                    pq[24 + 4 + r] = acc[13][r];
-                }
-                if (jc == 0) {
-                    pq[168 + r] = acc[4][r];                 // db3
-                    pq[168 + 4 + r] = acc[5][r];
-                    pq[96 + r] = acc[10][r];                 // db2
-                    pq[96 + 4 + r] = acc[11][r];
-                }
-            }
         }
     }
 }
@@ -1596,21 +937,6 @@ __global__ __launch_bounds__(256) void conv_bwd_valu(ConvArgs a, const float* __
     }
 }
 
-// rows in descending-degree order -> perm[rows]; hist / off: MCCNN_DEG_BINS ints each
-static int degree_sort(const int* rowStart, int rows, int total, int* hist, int* off, int* perm, hipStream_t s) {
-    MCCNN_HIP(hipMemsetAsync(hist, 0, MCCNN_DEG_BINS * sizeof(int), s));
-    int hb = ceil_div(rows, 256);
-    if (hb > 512) hb = 512;
-    deg_hist<<<hb, 256, 0, s>>>(rowStart, rows, total, hist);
-    MCCNN_LAUNCHED();
-    deg_offsets<<<1, 256, 0, s>>>(hist, off);
-    MCCNN_LAUNCHED();
-    deg_scatter<<<ceil_div(rows, 256), 256, 0, s>>>(rowStart, rows, total, off, perm);
-    MCCNN_LAUNCHED();
-    return 0;
-}
-static size_t degree_sort_bytes(int rows) { return 2 * align_up(MCCNN_DEG_BINS * sizeof(int)) + align_up((size_t)(rows > 0 ? rows : 1) * 4); }
-
 static int fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
                      const float* pdfs, const float* samples, const int* start_idx, const int* packed,
                      const float* aabb_min, const float* aabb_max, const float* w1, const float* b1, const float* w2,
@@ -1640,11 +966,7 @@ using namespace mccnn;
 
 extern "C" {
 
-size_t mccnn_spatial_conv_fwd_workspace_bytes(int m, int e, int num_in_feats, int num_out_feats, int combin) {
-    (void)num_in_feats; (void)num_out_feats; (void)combin;
-    if (e <= 0) return 256;
-    return align_up((size_t)e * sizeof(float4)) + degree_sort_bytes(m) + 256;  // edge records + degree order
-}
+size_t mccnn_spatial_conv_fwd_workspace_bytes(int, int, int, int, int) { return 256; }  // none needed today
 
 static bool use_mfma(const ConvArgs& a) { return a.nb <= MCCNN_LDS_MAX_NB && !getenv("MCCNN_FORCE_VALU"); }
 
@@ -1654,6 +976,7 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
                            const float* w2, const float* b2, const float* w3, const float* b3, int n, int m, int e,
                            int num_in_feats, int num_out_feats, int combin, int batch_size, float radius,
                            int scale_inv, int avg, float* out, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    (void)ws; (void)ws_bytes;
     ConvArgs a;
     int rc = fill_args(a, sorted_pts, sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min,
                        aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_in_feats, num_out_feats, combin, batch_size,
@@ -1663,68 +986,11 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     if (!out) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats) & 15) == 0);
-    if (use_mfma(a) && e > 0 && getenv("MCCNN_FWD_SLOT") && (size_t)a.nb * MCCNN_WQ_FWD * sizeof(float) <= 64 * 1024) {
-        // default: degree-sorted slot kernel (a lane owns a centre)
-        if (!ws || ws_bytes < mccnn_spatial_conv_fwd_workspace_bytes(m, e, num_in_feats, num_out_feats, combin))
-            return MCCNN_E_WORKSPACE;
-        Arena ar(ws, ws_bytes);
-        float4* rec = ar.take<float4>((size_t)e);
-        int* hist = ar.take<int>(MCCNN_DEG_BINS);
-        int* off = ar.take<int>(MCCNN_DEG_BINS);
-        int* perm = ar.take<int>((size_t)m);
-        if (!rec || !hist || !off || !perm) return MCCNN_E_WORKSPACE;
-        a.G = 0;
-        const bool f1 = combin && a.Fin == 1;
-        if (f1) edge_records_f1<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
-        else edge_records<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
-        MCCNN_LAUNCHED();
-        int rc2 = degree_sort(start_idx, m, e, hist, off, perm, s);
-        if (rc2) return rc2;
-        SlotArgs sa;
-        sa.rowStart = start_idx; sa.rowPerm = perm; sa.edgePerm = nullptr; sa.gather = sorted_feats;
-        sa.rows = m; sa.total = e; sa.F = a.Fin; sa.gatherByNeighbour = 1;
-        size_t lds = (size_t)a.nb * MCCNN_WQ_FWD * sizeof(float);
-        int blocks = ceil_div(m, 256);
-        if (combin) {
-            if (f1) conv_slot<true, 1><<<blocks, 256, lds, s>>>(a, sa, rec, out);
-            else conv_slot<true, 0><<<blocks, 256, lds, s>>>(a, sa, rec, out);
-        } else {
-            if (vec) conv_slot<false, 2><<<blocks, 256, lds, s>>>(a, sa, rec, out);
-            else conv_slot<false, 0><<<blocks, 256, lds, s>>>(a, sa, rec, out);
-        }
-        MCCNN_LAUNCHED();
-        return 0;
-    }
-    if (use_mfma(a) && e > 0 && getenv("MCCNN_FWD_SWEEP")) {  // experimental, slower for short per-wave ranges
-        int G = 1024 / a.outF;
-        if (G > 16) G = 16;
-        if (G < 1) G = 1;
-        a.G = G;
-        size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * ((size_t)G * a.outF)) * sizeof(float);
-        if (lds <= 64 * 1024) {
-            if (!ws || ws_bytes < mccnn_spatial_conv_fwd_workspace_bytes(m, e, num_in_feats, num_out_feats, combin))
-                return MCCNN_E_WORKSPACE;
-            float4* rec = (float4*)ws;
-            edge_records<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
-            MCCNN_LAUNCHED();
-            int blocks = ceil_div(m, 4 * G);
-            if (combin) {
-                if (a.Fin == 1) conv_fwd_sweep<true, 1><<<blocks, 256, lds, s>>>(a, rec, out);
-                else conv_fwd_sweep<true, 0><<<blocks, 256, lds, s>>>(a, rec, out);
-            } else {
-                if (vec) conv_fwd_sweep<false, 2><<<blocks, 256, lds, s>>>(a, rec, out);
-                else conv_fwd_sweep<false, 0><<<blocks, 256, lds, s>>>(a, rec, out);
-            }
-            MCCNN_LAUNCHED();
-            return 0;
-        }
-    }
     if (use_mfma(a)) {
         // G centres per wave: LDS tile of G*outF floats per wave, <= 4 KB
         int G = 1024 / a.outF;
         if (G > 8) G = 8;   // measured: 4-8 centres per wave beats 16+ (more, shorter waves hide latency better)
         if (G < 1) G = 1;
-        if (const char* gs = getenv("MCCNN_FWD_G")) G = atoi(gs);  // tuning knob
         a.G = G;
         size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * ((size_t)G * a.outF + G + 4)) * sizeof(float);
         if (lds <= 64 * 1024) {
@@ -1740,6 +1006,7 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
             return 0;
         }
     }
+    // fallback for very wide layers (nb > MCCNN_LDS_MAX_NB): VALU kernel with scalar-loaded weights
     int G = 2048 / a.outF;
     if (G > 32) G = 32;
     if (G < 1) G = 1;
@@ -1816,7 +1083,7 @@ size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_fe
     bytes += align_up((size_t)e * sizeof(float4));                                                // edge records
     if (combin) bytes += align_up((size_t)e * num_in_feats * sizeof(float));                      // per-edge dFeat
     else bytes += align_up((size_t)(n + 1) * 4) + align_up((size_t)e * 4) +                       // start_t, perm_t
-                  mccnn_transpose_neighbors_workspace_bytes(n, e) + degree_sort_bytes(n);
+                  mccnn_transpose_neighbors_workspace_bytes(n, e);
     return bytes + 256;
 }
 
@@ -1840,7 +1107,7 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
     size_t lds = ((size_t)a.nb * MCCNN_WQ_BWD + 4 * 192) * sizeof(float);
     bool mfma = use_mfma(a) && lds <= 64 * 1024 && m > 0 && e > 0;
     // depth-wise MFMA path writes every feat_grad row itself (conv_dfeat_dw); everything else accumulates into it
-    int Gd = 1024 / a.Fin; if (Gd > 16) Gd = 16; if (Gd < 1) Gd = 1;
+    int Gd = 1024 / a.Fin; if (Gd > 8) Gd = 8; if (Gd < 1) Gd = 1;
     size_t ldsD = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * ((size_t)Gd * a.Fin)) * sizeof(float);
     bool dfeatT = mfma && !combin && ldsD <= 64 * 1024;
     if (n > 0 && !dfeatT) MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * sizeof(float), s));
@@ -1868,16 +1135,7 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
         a.G = 0;
         edge_records<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
         MCCNN_LAUNCHED();
-        size_t lds2 = ((size_t)a.nb * MCCNN_WQ_BWD + 4 * MCCNN_XBUF) * sizeof(float);
-        if (lds2 <= 64 * 1024 && getenv("MCCNN_BWD_ALL_MFMA")) {  // experimental: outer products on the matrix pipe too
-            if (combin) {
-                if (a.Fin == 1) conv_bwd_mfma2<true, 1><<<blocks, 256, lds2, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-                else conv_bwd_mfma2<true, 0><<<blocks, 256, lds2, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-            } else {
-                if (vec) conv_bwd_mfma2<false, 2><<<blocks, 256, lds2, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-                else conv_bwd_mfma2<false, 0><<<blocks, 256, lds2, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-            }
-        } else if (combin) {
+        if (combin) {
             if (a.Fin == 1) conv_bwd_mfma<true, 1><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
             else conv_bwd_mfma<true, 0><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
         } else {
@@ -1905,25 +1163,10 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
                 perm_t = pt;
             }
             bool vecD = (a.Fin % 8 == 0) && ((((uintptr_t)out_grad) & 15) == 0);
-            if (!getenv("MCCNN_FWD_SLOT")) {
-                a.G = Gd;
-                int blocksD = ceil_div(n, 4 * Gd);
-                if (vecD) conv_dfeat_dw<true><<<blocksD, 256, ldsD, s>>>(a, rec, start_t, perm_t, out_grad, feat_grad);
-                else conv_dfeat_dw<false><<<blocksD, 256, ldsD, s>>>(a, rec, start_t, perm_t, out_grad, feat_grad);
-            } else {
-                int* hist = ar.take<int>(MCCNN_DEG_BINS);
-                int* off = ar.take<int>(MCCNN_DEG_BINS);
-                int* permR = ar.take<int>((size_t)n);
-                if (!hist || !off || !permR) return MCCNN_E_WORKSPACE;
-                int rc3 = degree_sort(start_t, n, e, hist, off, permR, s);
-                if (rc3) return rc3;
-                SlotArgs sa;
-                sa.rowStart = start_t; sa.rowPerm = permR; sa.edgePerm = perm_t; sa.gather = out_grad;
-                sa.rows = n; sa.total = e; sa.F = a.Fin; sa.gatherByNeighbour = 0;
-                size_t ldsS = (size_t)a.nb * MCCNN_WQ_FWD * sizeof(float);
-                if (vecD) conv_slot<false, 2><<<ceil_div(n, 256), 256, ldsS, s>>>(a, sa, rec, feat_grad);
-                else conv_slot<false, 0><<<ceil_div(n, 256), 256, ldsS, s>>>(a, sa, rec, feat_grad);
-            }
+            a.G = Gd;
+            int blocksD = ceil_div(n, 4 * Gd);
+            if (vecD) conv_dfeat_dw<true><<<blocksD, 256, ldsD, s>>>(a, rec, start_t, perm_t, out_grad, feat_grad);
+            else conv_dfeat_dw<false><<<blocksD, 256, ldsD, s>>>(a, rec, start_t, perm_t, out_grad, feat_grad);
             MCCNN_LAUNCHED();
         } else {
             return MCCNN_E_TOOLARGE;  // unreachable: the depth-wise tile always fits for nb <= MCCNN_LDS_MAX_NB

@@ -99,9 +99,8 @@ __global__ __launch_bounds__(256) void invert_perm_k(const int* __restrict__ new
 }
 
 // ------------------------------------------------------------------ compute_pdf.cu:40-94
-// One thread per edge (j, i): KDE of p_j against every neighbour of centre i.
-template <int MODE>
-__global__ __launch_bounds__(256) void pdf_edges(const float* __restrict__ pts, const int* __restrict__ bids,
+// Mode 0: one thread per edge (j, i), the reference's arithmetic (3 double-precision exps per pair).
+__global__ __launch_bounds__(256) void pdf_edges_ref(const float* __restrict__ pts, const int* __restrict__ bids,
                                                  const int* __restrict__ startIdx, int m,
                                                  const int2* __restrict__ packed, int e, const float* __restrict__ mn,
                                                  const float* __restrict__ mx, float window, float radius,
@@ -120,28 +119,16 @@ __global__ __launch_bounds__(256) void pdf_edges(const float* __restrict__ pts, 
     const float invH = 1 / h;
     const float invRadH = (float)(1.0 / (double)(R * h));  // compute_pdf.cu:74
     float pdf = 0.0f;
-    if (MODE == 0) {
-        for (int it = i0; it < i1; ++it) {
-            size_t q = (size_t)packed[it].x * 3;
-            float d0 = (pts[q] - cx) * invRadH;
-            float d1 = (pts[q + 1] - cy) * invRadH;
-            float d2 = (pts[q + 2] - cz) * invRadH;
-            // compute_pdf.cu:85-88, double sub-expressions rounded to float per statement
-            float g = (float)((double)invH * ((0.39894228) * exp((-0.5) * (double)d0 * (double)d0)));
-            g = (float)((double)(g * invH) * ((0.39894228) * exp((-0.5) * (double)d1 * (double)d1)));
-            g = (float)((double)(g * invH) * ((0.39894228) * exp((-0.5) * (double)d2 * (double)d2)));
-            pdf += g;
-        }
-    } else {
-        const float k3 = (invH * 0.39894228f) * (invH * 0.39894228f) * (invH * 0.39894228f);
-        for (int it = i0; it < i1; ++it) {
-            size_t q = (size_t)packed[it].x * 3;
-            float d0 = (pts[q] - cx) * invRadH;
-            float d1 = (pts[q + 1] - cy) * invRadH;
-            float d2 = (pts[q + 2] - cz) * invRadH;
-            float s = d0 * d0 + d1 * d1 + d2 * d2;
-            pdf += k3 * __expf(-0.5f * s);
-        }
+    for (int it = i0; it < i1; ++it) {
+        size_t q = (size_t)packed[it].x * 3;
+        float d0 = (pts[q] - cx) * invRadH;
+        float d1 = (pts[q + 1] - cy) * invRadH;
+        float d2 = (pts[q + 2] - cz) * invRadH;
+        // compute_pdf.cu:85-88, double sub-expressions rounded to float per statement
+        float g = (float)((double)invH * ((0.39894228) * exp((-0.5) * (double)d0 * (double)d0)));
+        g = (float)((double)(g * invH) * ((0.39894228) * exp((-0.5) * (double)d1 * (double)d1)));
+        g = (float)((double)(g * invH) * ((0.39894228) * exp((-0.5) * (double)d2 * (double)d2)));
+        pdf += g;
     }
     pdfs[t] = pdf / ((float)i1 - i0);  // compute_pdf.cu:92
 }
@@ -297,7 +284,7 @@ int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, cons
     hipStream_t s = (hipStream_t)stream;
     const int2* pk = reinterpret_cast<const int2*>(packed);
     if (mode == 0)
-        pdf_edges<0><<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, start_idx, m, pk, e, aabb_min,
+        pdf_edges_ref<<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, start_idx, m, pk, e, aabb_min,
                                                       aabb_max, window, radius, scale_inv, pdfs);
     else {
         if (!ws || ws_bytes < mccnn_compute_pdf_workspace_bytes(e, mode)) return MCCNN_E_WORKSPACE;

@@ -8,7 +8,6 @@
 // canonical sequential order, an exclusive scan of the slots gives every cell its output
 // base, and a fill pass emits the samples -- deterministic, no atomics.
 #include "common.h"
-#include <cstdlib>
 
 namespace mccnn {
 
@@ -31,59 +30,12 @@ __device__ __forceinline__ long long poisson_slot(const PoissonDims& d, int b, i
     return ((long long)b * 27 + ph) * ((long long)d.D * d.D * d.D) + lin;
 }
 
-// selectSamples (poisson_sampling.cu:51-124) for one phase, all batches.
-__global__ __launch_bounds__(64) void poisson_phase(const float* __restrict__ pts, const int* __restrict__ cells,
-                                                    const float* __restrict__ mn, const float* __restrict__ mx, int B,
-                                                    PoissonDims d, int ph, float radius, int scaleInv,
-                                                    unsigned char* __restrict__ sel, int* __restrict__ slotCount) {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long perBatch = (long long)d.G * d.G * d.G;
-    if (t >= perBatch * B) return;
-    int b = (int)(t / perBatch);
-    int r = (int)(t - (long long)b * perBatch);
-    int gx = r % d.G, gy = (r / d.G) % d.G, gz = r / (d.G * d.G);
-    int ox, oy, oz;
-    pool_offset(ph, ox, oy, oz);
-    int nc = d.nc;
-    int xC = gx * 3 + 1 + ox, yC = gy * 3 + 1 + oy, zC = gz * 3 + 1 + oz;
-    if (!(xC < nc && yC < nc && zC < nc)) return;  // poisson_sampling.cu:74
-    float ext = max_extent(mn, mx, b);
-    float R = scaleInv ? radius * ext : radius;
-    const float T = sqrt_threshold(R);  // sqrt(d2) < R  <=>  d2 < T (exact, see common.h)
-    size_t cellBase = (size_t)b * nc * nc * nc;
-    const int2* ct = reinterpret_cast<const int2*>(cells);
-    int2 me = ct[cellBase + (size_t)xC * nc * nc + (size_t)yC * nc + zC];
-    int kept = 0;
-    for (int i = me.x; i < me.y; ++i) {
-        float c0 = pts[(size_t)i * 3], c1 = pts[(size_t)i * 3 + 1], c2 = pts[(size_t)i * 3 + 2];
-        bool collision = false;
-        for (int o = 0; o < 27 && !collision; ++o) {
-            int dx, dy, dz;
-            pool_offset(o, dx, dy, dz);
-            int X = xC + dx, Y = yC + dy, Z = zC + dz;
-            if (X < 0 || X >= nc || Y < 0 || Y >= nc || Z < 0 || Z >= nc) continue;
-            int2 rr = ct[cellBase + (size_t)X * nc * nc + (size_t)Y * nc + Z];
-            for (int j = rr.x; j < rr.y && !collision; ++j) {
-                // a point of my own cell selected earlier in this very loop is visible: same thread
-                if (!sel[j]) continue;
-                float dd = point_dist2(pts[(size_t)j * 3], pts[(size_t)j * 3 + 1], pts[(size_t)j * 3 + 2], c0, c1, c2);
-                if (dd < T) collision = true;
-            }
-        }
-        if (!collision) {
-            sel[i] = 1;
-            ++kept;
-        }
-    }
-    slotCount[poisson_slot(d, b, ph, gx, gy, gz)] = kept;
-}
-
-// selectSamples for one phase, one WAVE per cell. The greedy walk over a cell's points is inherently sequential, but
+// selectSamples (poisson_sampling.cu:51-124) for one phase over all batches, one WAVE per cell. The greedy walk over a cell's points is inherently sequential, but
 // the test of one point against the already selected points of its 27-window is not: the window's candidates (~150)
 // are loaded ONCE into registers (64 per round, up to 4 rounds), every point of the cell is then tested by all lanes
 // at once and `__any` decides. Selections made inside the cell during the walk are mirrored in the register copies.
 // A thread per cell (the reference's mapping, and this repo's first version) leaves 8000 threads with long dependent
-// load chains per launch: 29 ms for a 100k-point room; this kernel: well under 1 ms for the 27 phases.
+// load chains per launch: 29 ms for a 100k-point room; this kernel: 0.9 ms for the 27 phases.
 #define MCCNN_PS_ROUNDS 12
 __global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restrict__ pts, const int* __restrict__ cells,
                                                           const float* __restrict__ mn, const float* __restrict__ mx,
@@ -286,14 +238,9 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
     MCCNN_HIP(hipMemsetAsync(slots, 0, (size_t)S * sizeof(int), s));
     PoissonDims d = poisson_dims(num_cells);
     long long threads = (long long)batch_size * d.G * d.G * d.G;
-    const bool perThread = getenv("MCCNN_POISSON_THREAD_PER_CELL") != nullptr;  // first version, kept for A/B
     for (int ph = 0; ph < 27; ++ph) {
-        if (perThread)
-            poisson_phase<<<ceil_div(threads, 64), 64, 0, s>>>(sorted_pts, cell_indexs, aabb_min, aabb_max, batch_size, d,
-                                                               ph, radius, scale_inv, sel, slots);
-        else
-            poisson_phase_wave<<<ceil_div(threads, 4), 256, 0, s>>>(sorted_pts, cell_indexs, aabb_min, aabb_max,
-                                                                    batch_size, d, ph, radius, scale_inv, sel, slots);
+        poisson_phase_wave<<<ceil_div(threads, 4), 256, 0, s>>>(sorted_pts, cell_indexs, aabb_min, aabb_max, batch_size,
+                                                                d, ph, radius, scale_inv, sel, slots);
         MCCNN_LAUNCHED();
     }
     return exclusive_scan_i32(slots, slots, (int)S, total_dev, scanws, s);
