@@ -149,16 +149,26 @@ __global__ __launch_bounds__(256) void park_ids(const int* __restrict__ keys, co
     if (i < n) slot[start[keys[i]] + arrival[i]] = i;
 }
 
-// new_idx[i] = cellStart + #{ids in my cell smaller than i}: the stable (sequential) order.
+// new_idx[id] = cellStart + #{ids in the same cell smaller than id}: the stable (sequential) order.
+// One thread per POSITION of the parked list: neighbouring lanes sit in the same cell and scan the same
+// addresses (broadcast loads, equal trip counts); a thread per point id would make every lane of a wave scan a
+// different cell. Cost is quadratic in the cell occupancy -- fine for radius-sized cells (tens of points), slow
+// for degenerate grids that put >1e4 points into one cell.
 __global__ __launch_bounds__(256) void rank_in_cell(const int* __restrict__ keys, const int* __restrict__ start,
                                                     const int* __restrict__ slot, int n, int* __restrict__ newIdx) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int k = keys[i];
-    int s0 = start[k], s1 = start[k + 1];
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int id = slot[p];
+    const int k = keys[id];
+    const int s0 = start[k], s1 = start[k + 1];
     int r = 0;
-    for (int p = s0; p < s1; ++p) r += (slot[p] < i) ? 1 : 0;
-    newIdx[i] = s0 + r;
+    int q = s0;
+    for (; q + 4 <= s1; q += 4) {
+        int a0 = slot[q], a1 = slot[q + 1], a2 = slot[q + 2], a3 = slot[q + 3];
+        r += (a0 < id) + (a1 < id) + (a2 < id) + (a3 < id);
+    }
+    for (; q < s1; ++q) r += (slot[q] < id) ? 1 : 0;
+    newIdx[id] = s0 + r;
 }
 
 // ------------------------------------------------------------------ step 2
