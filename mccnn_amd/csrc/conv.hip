@@ -207,8 +207,22 @@ __device__ __forceinline__ int dpp_i(int v) {
 #define DPP_ROW_SHR(n) (0x110 + (n))
 #define DPP_ROW_SHL(n) (0x100 + (n))
 
-// max(x, 0) as ONE instruction (v_med3_f32); fmaxf() costs an extra canonicalising v_max on MFMA results
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()); }
+// MFMA and VALU instructions of one wave are kept in separate PHASES: tools/issue_probe.hip shows that a wave
+// alternating between the two pays ~7 extra cycles per switch (8 mfma + 16 fma cost 163 cycles interleaved, 108
+// grouped = the sum of the parts), and the scheduler's default is to interleave. SALU and memory ops may cross.
+#ifndef MCCNN_NO_PHASES
+#define MCCNN_PHASE() __builtin_amdgcn_sched_barrier(0x4 | 0x10 | 0x80)
+#else
+#define MCCNN_PHASE()
+#endif
+
+// max(x, 0) as ONE instruction: v_med3_f32(x, 0, +inf). fmaxf() costs an extra canonicalising v_max on MFMA results,
+// and med3 with a literal +inf is folded back into that pair -- so the +inf goes through an opaque SGPR.
+__device__ __forceinline__ float relu1(float x) {
+    float inf = __builtin_huge_valf();
+    asm("" : "+s"(inf));
+    return __builtin_amdgcn_fmed3f(x, 0.0f, inf);
+}
 
 // Stage the MLP tensors of all nb blocks into LDS in the per-block layout above.
 template <int WQ>
@@ -260,14 +274,19 @@ __device__ __forceinline__ void mlp_block_mfma(const float* __restrict__ wq, int
     hi = MFMA4(a1hi.y, d1, hi);
     lo = MFMA4(a1lo.z, d2, lo);
     hi = MFMA4(a1hi.z, d2, hi);
+    MCCNN_PHASE();
 #pragma unroll
     for (int r = 0; r < 4; ++r) { pre1[r] = lo[r]; pre1[4 + r] = hi[r]; }
 #pragma unroll
     for (int r = 0; r < 8; ++r) a1[r] = relu1(pre1[r]);
+    MCCNN_PHASE();
     layer8(w + 10, w[26], w[27], i4, a1, pre2);  // W2, b2
+    MCCNN_PHASE();
 #pragma unroll
     for (int r = 0; r < 8; ++r) a2[r] = relu1(pre2[r]);
+    MCCNN_PHASE();
     layer8(w + 28, w[44], w[45], i4, a2, o);     // W3, b3
+    MCCNN_PHASE();
 }
 
 // Per-wave view of G consecutive centres = one contiguous edge range; sL = LDS copy of start[c0..c1].
@@ -358,6 +377,7 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(ConvArgs a, float* __restri
 
         for (int q = 0; q < a.nb; ++q) {
             float pre1[8], a1[8], pre2[8], a2[8], o[8], c[8];
+            MCCNN_PHASE();
             mlp_block_mfma(wl + q * MCCNN_WQ_FWD, i4, ec.d0, ec.d1, ec.d2, pre1, a1, pre2, a2, o);
             const bool full = (q * 8 + 8 <= a.neuronsOut);
             if (FEAT == 2) {
@@ -525,10 +545,17 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #pragma unroll
                 for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; ff[n] = f8[n]; }
             } else if (FEAT == 1) {
+#ifdef ABL_NOMEM
+                float f = rc.x;
+                const float4* gp = reinterpret_cast<const float4*>(outGrad + (lane & 7) * 8);
+                float4 ga = gp[0], gb = gp[1];
+                if (true) {
+#else
                 float f = a.feats[j];
                 if (numOuts == 8 && (outF & 3) == 0) {
                     const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
                     float4 ga = gp[0], gb = gp[1];
+#endif
                     float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
 #pragma unroll
                     for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; ff[n] = f; }
@@ -548,7 +575,9 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
                 }
             }
             float dfOld = 0.f;
+#ifndef ABL_NODFE
             if (COMBIN && FEAT == 1 && act && q > 0) dfOld = dfE[t];
+#endif
             // prefetch the next chunk AFTER this chunk's gathers: vmcnt retires in order, so the waits for g / f
             // leave these two loads in flight across the whole iteration
             {
@@ -577,7 +606,11 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #pragma unroll
                     for (int n = 0; n < 8; ++n) sfg = fmaf(g[n], o[n], sfg);
                     sfg *= inv;
+#ifdef ABL_NODFE
+                    if (act && sfg == 123.f) dfE[t] = dfOld + sfg;
+#else
                     if (act) dfE[t] = dfOld + sfg;  // this lane owns edge t: plain RMW, no atomics
+#endif
                 } else if (act) {
                     // several neurons of a block may share fin: fold them in registers first
                     for (int f = 0; f < a.Fin; ++f) {
@@ -611,7 +644,9 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
             }
             // t3 = 1[pre2 >= 0] * W3^T (g f) / (pdf K)             (:403-414)
             float t3[8];
+            MCCNN_PHASE();
             layer8(w4 + 62, zero4, zero4, i4, gf, t3);  // W3^T rows at float 248 -> f32x4 index 62
+            MCCNN_PHASE();
 #pragma unroll
             for (int k = 0; k < 8; ++k) t3[k] = p2[k] ? t3[k] * inv : 0.f;
             // dW2 += t3 a1^T, db2 += t3                            (:419-425)
@@ -623,7 +658,9 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
             }
             // t4 = 1[pre1 >= 0] * W2^T t3                          (:428-434)
             float t4[8];
+            MCCNN_PHASE();
             layer8(w4 + 46, zero4, zero4, i4, t3, t4);  // W2^T rows at float 184 -> f32x4 index 46
+            MCCNN_PHASE();
             // dW1 += t4 delta^T, db1 += t4                         (:439-444)
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
