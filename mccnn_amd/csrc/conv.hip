@@ -289,148 +289,246 @@ __device__ __forceinline__ void mlp_block_mfma(const float* __restrict__ wq, int
     MCCNN_PHASE();
 }
 
-// Per-wave view of G consecutive centres = one contiguous edge range; sL = LDS copy of start[c0..c1].
-struct WaveRange {
-    int c0, c1, eBeg, eEnd;
-};
-__device__ __forceinline__ WaveRange wave_range(const ConvArgs& a, int waveGlobal, int* sL, int lane) {
-    WaveRange r;
-    r.c0 = waveGlobal * a.G;
-    r.c1 = min(r.c0 + a.G, a.m);
-    r.eBeg = r.eEnd = 0;
-    if (r.c0 < a.m) {
-        for (int k = lane; k <= r.c1 - r.c0; k += 64) sL[k] = (r.c0 + k < a.m) ? a.start[r.c0 + k] : a.e;
-        r.eBeg = a.start[r.c0];
-        r.eEnd = (r.c1 < a.m) ? a.start[r.c1] : a.e;
+// ---------------------------------------------------------------------------------------
+// Forward, streaming form. Every wave owns a centre-aligned slice of the neighbour list holding ~E/W edges (W = the
+// number of waves the chip keeps resident, so the launch is ONE balanced round: with a fixed number of centres per
+// wave the non-uniform clouds left the last third of the launch half empty). Chunks are 64 consecutive edges of the
+// slice, independent of centre boundaries; the output tile is a sliding window of G rows (row of centre c = c mod G)
+// that is flushed -- each row exactly once, in order -- when a chunk reaches beyond it.
+// ---------------------------------------------------------------------------------------
+// smallest c in [0, m] with S(c) >= t, S(c) = start[c] (c < m), S(m) = e. 64-ary: three dependent loads for m < 2^18.
+__device__ __forceinline__ int wave_lower_bound(const int* __restrict__ start, int m, int e, int t, int lane) {
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        const int span = hi - lo;
+        const int step = (span + 63) >> 6;
+        const int p = min(lo + lane * step, hi);
+        const int v = (p < m) ? start[p] : e;
+        const unsigned long long b = __ballot(v >= t);
+        const int f = b ? (int)__builtin_ctzll(b) : 64;
+        const int nlo = (f == 0) ? lo : min(lo + (f - 1) * step, hi) + 1;
+        const int nhi = (f == 0) ? lo : ((f == 64) ? hi : min(lo + f * step, hi));
+        lo = nlo;
+        hi = nhi;
     }
-    return r;
+    return lo;
 }
 
-struct Edge {
-    int j, il;  // neighbour (sorted list) index, centre index relative to the wave's c0
-    float d0, d1, d2, inv;
-};
-// delta = (p_j - c_i) / R_b is evaluated as (p_j - c_i) * (1/R_b) and 1/(pdf K) with v_rcp_f32: <= 2 ulp
-// from the reference's divisions (spatial_conv.cu:155-163), far inside the 1e-4 feature tolerance.
-__device__ __forceinline__ Edge make_edge(const ConvArgs& a, const WaveRange& wr, const int* sL, int2 pr, float pdf, bool act);
-__device__ __forceinline__ Edge load_edge2(const ConvArgs& a, const WaveRange& wr, const int* sL, int t, bool act) {
-    int2 pr = act ? a.packed[t] : make_int2(0, wr.c0);
-    float pdf = act ? a.pdfs[t] : 1.0f;
-    return make_edge(a, wr, sL, pr, pdf, act);
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_rows_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
 }
-__device__ __forceinline__ Edge make_edge(const ConvArgs& a, const WaveRange& wr, const int* sL, int2 pr, float pdf, bool act) {
-    Edge e;
-    e.j = pr.x;
-    e.il = pr.y - wr.c0;
-    float invR = a.invRadius;
-    if (a.scaleInv) {
-        int b = a.bids[e.j];
-        invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, b));
-    }
-    const float* p = a.pts + (size_t)e.j * 3;
-    const float* c = a.samples + (size_t)pr.y * 3;
-    e.d0 = (p[0] - c[0]) * invR;
-    e.d1 = (p[1] - c[1]) * invR;
-    e.d2 = (p[2] - c[2]) * invR;
-    float K = a.avg ? (float)(sL[e.il + 1] - sL[e.il]) : 1.0f;
-    e.inv = act ? __builtin_amdgcn_rcpf(pdf * K) : 0.0f;
-    return e;
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_rows_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xf, false);
 }
 
-// Forward. The reduction over a centre's edges: DPP row_shr segmented scan inside each 16-lane row, then the
-// row-segment tails add into the wave's LDS output tile (ds_add_f32). Output rows are written exactly once.
-template <bool COMBIN, int FEAT>
-__global__ __launch_bounds__(256) void conv_fwd_mfma(ConvArgs a, float* __restrict__ out) {
+// Segmented inclusive scan of 8 values over the 64 lanes: v += m_step * v[lane - step]. The DPP read is folded
+// into the multiply-add (v_fmac_f32_dpp) -- from C++ the compiler emits v_mov_b32_dpp + v_fma (VOP3 cannot carry
+// DPP) -- and the 8 values advance in lock step, so an instruction never reads a register written less than 8
+// instructions earlier (the VALU-write -> DPP-read hazard needs 2 wait states; inline asm gets no automatic nops).
+#define MCCNN_SCAN_STEP(CTRL, M)                                                         \
+    "v_fmac_f32_dpp %0, %0, %" #M " " CTRL "\n v_fmac_f32_dpp %1, %1, %" #M " " CTRL "\n" \
+    "v_fmac_f32_dpp %2, %2, %" #M " " CTRL "\n v_fmac_f32_dpp %3, %3, %" #M " " CTRL "\n" \
+    "v_fmac_f32_dpp %4, %4, %" #M " " CTRL "\n v_fmac_f32_dpp %5, %5, %" #M " " CTRL "\n" \
+    "v_fmac_f32_dpp %6, %6, %" #M " " CTRL "\n v_fmac_f32_dpp %7, %7, %" #M " " CTRL "\n"
+__device__ __forceinline__ void wave_seg_scan8(float* c, float m1, float m2, float m4, float m8, float mA, float mB) {
+    asm("s_nop 1\n"
+        MCCNN_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1", 8)
+        MCCNN_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1", 9)
+        MCCNN_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1", 10)
+        MCCNN_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1", 11)
+        MCCNN_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf", 12)
+        MCCNN_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf", 13)
+        "s_nop 1\n"
+        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7])
+        : "v"(m1), "v"(m2), "v"(m4), "v"(m8), "v"(mA), "v"(mB));
+}
+
+// TR = true runs the same reduction over the TRANSPOSED list (rows = neighbours j, CSR a.start = startT, edge ids
+// through permT, geometry from the per-edge records): the depth-wise feature gradient
+//   featGrad[j, nu] = sum over edges e=(j,i) of outGrad[i, nu] * o_e[nu] / (pdf_e K_i)          (spatial_conv.cu:400)
+// is the forward convolution with the roles of centres and neighbours swapped (a.feats = outGrad, a.m = n).
+template <bool COMBIN, int FEAT, bool TR>
+__global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict__ out, int numWaves,
+                                                   const float4* __restrict__ rec, const int* __restrict__ permT) {
     extern __shared__ float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
-    const int G = a.G, outF = a.outF;
+    const int outF = a.outF;
     float* wl = lds;
-    float* tile = lds + a.nb * MCCNN_WQ_FWD + (size_t)wave * (G * outF + G + 4);
-    int* sL = reinterpret_cast<int*>(tile + G * outF);
+    float* carry = lds + a.nb * MCCNN_WQ_FWD + (size_t)wave * (a.nb * 8);  // running sums of a centre that spans chunks
     stage_weights<MCCNN_WQ_FWD>(a, wl);
-    WaveRange wr = wave_range(a, blockIdx.x * 4 + wave, sL, lane);
-    if (wr.c0 < a.m)
-        for (int k = lane; k < G * outF; k += 64) tile[k] = 0.0f;
     __syncthreads();
-    if (wr.c0 >= a.m) return;
+    const int w = blockIdx.x * 4 + wave;
+    if (w >= numWaves) return;
+    const int tA = (int)(((long long)a.e * w) / numWaves);
+    const int tB = (int)(((long long)a.e * (w + 1)) / numWaves);
+    const int cA = (w == 0) ? 0 : wave_lower_bound(a.start, a.m, a.e, tA, lane);
+    const int cB = (w == numWaves - 1) ? a.m : wave_lower_bound(a.start, a.m, a.e, tB, lane);
+    if (cA >= cB) return;
+    const int eBeg = a.start[cA];
+    const int eEnd = (cB < a.m) ? a.start[cB] : a.e;
+    const bool vecOut = (!COMBIN || FEAT == 1) && (outF & 3) == 0;
 
-    int2 prN = make_int2(0, wr.c0);
+    // rows of centres without neighbours are never reached by an edge: zero them where the gap shows up
+    auto zero_rows = [&](int c0, int c1) {
+        for (int c = c0; c < c1; ++c)
+            for (int f = 0; f < outF; ++f) out[(size_t)c * outF + f] = 0.0f;
+    };
+
+    int keyLast = cA;     // key (= centre + 1) of the previous chunk's last edge; cA stands for "centre cA-1 is done"
+    int carryKey = -1;    // key whose partial sums sit in carry[]
+    int2 prN = make_int2(0, cA);
     float pdfN = 1.0f;
-    if (wr.eBeg + lane < wr.eEnd) { prN = a.packed[wr.eBeg + lane]; pdfN = a.pdfs[wr.eBeg + lane]; }
-    for (int base = wr.eBeg; base < wr.eEnd; base += 64) {
+    int eN = 0;
+    if (TR) {
+        eN = permT[min(eBeg + lane, a.e - 1)];
+    } else if (eBeg + lane < eEnd) {
+        prN = a.packed[eBeg + lane];
+        pdfN = a.pdfs[eBeg + lane];
+    }
+    float acc = 0.f;  // generic combin layers: running sum over the Fin neurons of one output feature
+    for (int base = eBeg; base < eEnd; base += 64) {
         const int t = base + lane;
-        const bool act = t < wr.eEnd;
-        const int2 prC = act ? prN : make_int2(0, wr.c0);
-        const float pdfC = act ? pdfN : 1.0f;
-        Edge ec = make_edge(a, wr, sL, prC, pdfC, act);
+        const int nIn = min(64, eEnd - base);
+        const bool in = lane < nIn;
+        int ci, j;
+        float d0, d1, d2, inv;
+        if (TR) {
+            const float4 rc = rec[eN];
+            const int2 pr = a.packed[eN];
+            eN = permT[min(t + 64, a.e - 1)];
+            ci = pr.x;  // the row this edge adds to: its neighbour point
+            j = pr.y;   // the row it reads: outGrad of its centre
+            d0 = rc.x; d1 = rc.y; d2 = rc.z;
+            inv = in ? rc.w : 0.0f;
+        } else {
+            const int2 pr = prN;
+            const float pdf = pdfN;
+            if (t + 64 < eEnd) { prN = a.packed[t + 64]; pdfN = a.pdfs[t + 64]; }
+            ci = pr.y;
+            j = pr.x;
+            float invR = a.invRadius;
+            if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, a.bids[j]));
+            const float* pp = a.pts + (size_t)j * 3;
+            const float* cc = a.samples + (size_t)ci * 3;
+            d0 = (pp[0] - cc[0]) * invR; d1 = (pp[1] - cc[1]) * invR; d2 = (pp[2] - cc[2]) * invR;
+            float K = 1.0f;
+            if (a.avg) K = (float)(((ci + 1 < a.m) ? a.start[ci + 1] : a.e) - a.start[ci]);
+            inv = in ? __builtin_amdgcn_rcpf(pdf * K) : 0.0f;
+        }
+        const int key = in ? ci + 1 : 0;
+        const int cLast = __builtin_amdgcn_readlane(ci, nIn - 1);
+        // the last row of this chunk goes on in the next one iff its CSR range reaches beyond the chunk
+        const int rowEnd = (cLast + 1 < a.m) ? a.start[cLast + 1] : a.e;
+        const bool cont = rowEnd > base + 64;
+        int keyPrev = __shfl_up(key, 1, 64);
+        if (lane == 0) keyPrev = keyLast;
+        int keyNext = __shfl_down(key, 1, 64);
+        const bool tail = in && ((lane == nIn - 1) ? !cont : (key != keyNext));
+        if (in && key - keyPrev > 1) zero_rows(keyPrev, ci);  // rows keyPrev .. ci-1 have no edges
         float f1 = 0.f;
-        if (FEAT == 1) f1 = act ? a.feats[ec.j] * ec.inv : 0.f;
-        if (t + 64 < wr.eEnd) { prN = a.packed[t + 64]; pdfN = a.pdfs[t + 64]; }  // prefetch (after this chunk's gathers)
-        const int key1 = act ? (ec.il + 1) : 0;  // 0 = no edge
-        // same-centre masks for the in-row segmented scan (row = 16 lanes)
-        const float m1 = (key1 != 0 && dpp_i<DPP_ROW_SHR(1)>(key1) == key1) ? 1.f : 0.f;
-        const float m2 = (key1 != 0 && dpp_i<DPP_ROW_SHR(2)>(key1) == key1) ? 1.f : 0.f;
-        const float m4 = (key1 != 0 && dpp_i<DPP_ROW_SHR(4)>(key1) == key1) ? 1.f : 0.f;
-        const float m8 = (key1 != 0 && dpp_i<DPP_ROW_SHR(8)>(key1) == key1) ? 1.f : 0.f;
-        const bool tail = act && (dpp_i<DPP_ROW_SHL(1)>(key1) != key1);  // last lane of a row reads 0 -> tail
-        float* row = tile + (size_t)ec.il * outF;
+        if (FEAT == 1) f1 = in ? a.feats[j] * inv : 0.f;
+        // wave-wide segmented inclusive scan: 4 steps inside the 16-lane rows, then rows 1,3 take the end of rows
+        // 0,2 and rows 2,3 the end of row 1 -- always only into lanes of the same centre
+        const float m1 = (key != 0 && dpp_i<DPP_ROW_SHR(1)>(key) == key) ? 1.f : 0.f;
+        const float m2 = (key != 0 && dpp_i<DPP_ROW_SHR(2)>(key) == key) ? 1.f : 0.f;
+        const float m4 = (key != 0 && dpp_i<DPP_ROW_SHR(4)>(key) == key) ? 1.f : 0.f;
+        const float m8 = (key != 0 && dpp_i<DPP_ROW_SHR(8)>(key) == key) ? 1.f : 0.f;
+        const float mA = (key != 0 && dpp_rows_i<DPP_ROW_BCAST15, 0xA>(key) == key) ? 1.f : 0.f;
+        const float mB = (key != 0 && dpp_rows_i<DPP_ROW_BCAST31, 0xC>(key) == key) ? 1.f : 0.f;
+        const bool haveCarry = carryKey >= 0;
+        const float mC = (haveCarry && key == carryKey) ? 1.f : 0.f;
+        float* orow = out + (size_t)ci * outF;
 
-        for (int q = 0; q < a.nb; ++q) {
+        int finQ = 0, foQ = 0;  // (nu % Fin, nu / Fin) of the block's first neuron, kept incrementally
+        auto block = [&](const int q, const float4 fa, const float4 fb) {
             float pre1[8], a1[8], pre2[8], a2[8], o[8], c[8];
             MCCNN_PHASE();
-            mlp_block_mfma(wl + q * MCCNN_WQ_FWD, i4, ec.d0, ec.d1, ec.d2, pre1, a1, pre2, a2, o);
-            const bool full = (q * 8 + 8 <= a.neuronsOut);
+            mlp_block_mfma(wl + q * MCCNN_WQ_FWD, i4, d0, d1, d2, pre1, a1, pre2, a2, o);
             if (FEAT == 2) {
-                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)ec.j * a.Fin + q * 8);
-                float4 fa = fp[0], fb = fp[1];
                 float f[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
 #pragma unroll
-                for (int n = 0; n < 8; ++n) c[n] = (f[n] * ec.inv) * o[n];
+                for (int n = 0; n < 8; ++n) c[n] = (f[n] * inv) * o[n];
             } else if (FEAT == 1) {
 #pragma unroll
                 for (int n = 0; n < 8; ++n) c[n] = f1 * o[n];
             } else {
+                // neuron nu = fo * Fin + fin (combin) or nu = fin (depth-wise): fin advances with nu, no division
+                int fin = finQ;
 #pragma unroll
                 for (int n = 0; n < 8; ++n) {
                     int nu = q * 8 + n;
-                    int fin = nu % a.Fin;
-                    c[n] = (nu < a.neuronsOut) ? a.feats[(size_t)ec.j * a.Fin + fin] * o[n] * ec.inv : 0.f;
+                    c[n] = (nu < a.neuronsOut) ? a.feats[(size_t)j * a.Fin + fin] * o[n] * inv : 0.f;
+                    if (++fin == a.Fin) fin = 0;
                 }
             }
+            float* cq = carry + q * 8;
+            f32x4 cv0 = {0.f, 0.f, 0.f, 0.f}, cv1 = cv0;
+            if (haveCarry) { cv0 = *reinterpret_cast<f32x4*>(cq); cv1 = *reinterpret_cast<f32x4*>(cq + 4); }
+            wave_seg_scan8(c, m1, m2, m4, m8, mA, mB);
 #pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                float v = c[n];
-                v = fmaf(m1, dpp_f<DPP_ROW_SHR(1)>(v), v);
-                v = fmaf(m2, dpp_f<DPP_ROW_SHR(2)>(v), v);
-                v = fmaf(m4, dpp_f<DPP_ROW_SHR(4)>(v), v);
-                v = fmaf(m8, dpp_f<DPP_ROW_SHR(8)>(v), v);
-                c[n] = v;
+            for (int n = 0; n < 8; ++n) c[n] = fmaf(mC, n < 4 ? cv0[n & 3] : cv1[n & 3], c[n]);
+            if (cont && lane == 63) {
+                *reinterpret_cast<f32x4*>(cq) = (f32x4){c[0], c[1], c[2], c[3]};
+                *reinterpret_cast<f32x4*>(cq + 4) = (f32x4){c[4], c[5], c[6], c[7]};
             }
-            if (tail) {
-                if (!COMBIN || a.Fin == 1) {
-                    float* dst = row + q * 8;
-                    if (full) {
-#pragma unroll
-                        for (int n = 0; n < 8; ++n) atomicAdd(&dst[n], c[n]);  // ds_add_f32, wave-private tile
+            if (!COMBIN || FEAT == 1) {
+                if (!COMBIN && FEAT == 0) finQ += 8;  // depth-wise, scalar path: fin = nu
+                if (tail) {
+                    {
+                    float* dst = orow + q * 8;
+                    if (vecOut) {
+                        reinterpret_cast<float4*>(dst)[0] = make_float4(c[0], c[1], c[2], c[3]);
+                        reinterpret_cast<float4*>(dst)[1] = make_float4(c[4], c[5], c[6], c[7]);
                     } else {
 #pragma unroll
                         for (int n = 0; n < 8; ++n)
-                            if (q * 8 + n < a.neuronsOut) atomicAdd(&dst[n], c[n]);
+                            if (q * 8 + n < a.neuronsOut) dst[n] = c[n];
                     }
-                } else {
+                    }
+                }
+            } else {
+                // output feature fo = sum over its Fin consecutive neurons (spatial_conv.cu:236): close it at the last one
 #pragma unroll
-                    for (int n = 0; n < 8; ++n) {
-                        int nu = q * 8 + n;
-                        if (nu < a.neuronsOut) atomicAdd(&row[nu / a.Fin], c[n]);
+                for (int n = 0; n < 8; ++n) {
+                    const int nu = q * 8 + n;
+                    if (nu < a.neuronsOut) {
+                        acc += c[n];
+                        if (++finQ == a.Fin) {
+                            if (tail) orow[foQ] = acc;
+                            acc = 0.f;
+                            finQ = 0;
+                            ++foQ;
+                        }
                     }
                 }
             }
+        };
+        if (FEAT == 2) {
+            // the feature row is read one 128-byte line (4 blocks) at a time: fetching 32 bytes per block would pull
+            // every line through L1 four times, and L1 does not hold 64 rows x 20 waves in between
+            for (int q0 = 0; q0 < a.nb; q0 += 4) {
+                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)j * a.Fin + q0 * 8);
+                const int left = a.nb - q0;
+                float4 fl[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) fl[k] = (k < 2 * left) ? fp[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                block(q0, fl[0], fl[1]);
+                if (left > 1) block(q0 + 1, fl[2], fl[3]);
+                if (left > 2) block(q0 + 2, fl[4], fl[5]);
+                if (left > 3) block(q0 + 3, fl[6], fl[7]);
+            }
+        } else {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < a.nb; ++q) block(q, z, z);
         }
+        carryKey = cont ? cLast + 1 : -1;
+        keyLast = cLast + 1;
     }
-    __builtin_amdgcn_wave_barrier();
-    const int cnt = (wr.c1 - wr.c0) * outF;
-    float* dst = out + (size_t)wr.c0 * outF;
-    for (int k = lane; k < cnt; k += 64) dst[k] = tile[k];
+    if (lane == 0) zero_rows(keyLast, cB);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -498,7 +596,6 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
     const int outF = a.outF;
     float* wl = lds;
-    float* red = lds + a.nb * MCCNN_WQ_BWD + wave * 192;  // 176 reduced sums of one block
     stage_weights<MCCNN_WQ_BWD>(a, wl);
     __syncthreads();
     const int waveGlobal = blockIdx.x * 4 + wave;
@@ -545,17 +642,10 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #pragma unroll
                 for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; ff[n] = f8[n]; }
             } else if (FEAT == 1) {
-#ifdef ABL_NOMEM
-                float f = rc.x;
-                const float4* gp = reinterpret_cast<const float4*>(outGrad + (lane & 7) * 8);
-                float4 ga = gp[0], gb = gp[1];
-                if (true) {
-#else
                 float f = a.feats[j];
                 if (numOuts == 8 && (outF & 3) == 0) {
                     const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
                     float4 ga = gp[0], gb = gp[1];
-#endif
                     float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
 #pragma unroll
                     for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; ff[n] = f; }
@@ -575,9 +665,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
                 }
             }
             float dfOld = 0.f;
-#ifndef ABL_NODFE
             if (COMBIN && FEAT == 1 && act && q > 0) dfOld = dfE[t];
-#endif
             // prefetch the next chunk AFTER this chunk's gathers: vmcnt retires in order, so the waits for g / f
             // leave these two loads in flight across the whole iteration
             {
@@ -606,11 +694,11 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #pragma unroll
                     for (int n = 0; n < 8; ++n) sfg = fmaf(g[n], o[n], sfg);
                     sfg *= inv;
-#ifdef ABL_NODFE
-                    if (act && sfg == 123.f) dfE[t] = dfOld + sfg;
-#else
-                    if (act) dfE[t] = dfOld + sfg;  // this lane owns edge t: plain RMW, no atomics
-#endif
+                    // this lane owns edge t: plain RMW across the blocks, ONE atomic per edge after the last block
+                    if (act) {
+                        if (q == a.nb - 1) atomicAdd(&featGrad[j], dfOld + sfg);
+                        else dfE[t] = dfOld + sfg;
+                    }
                 } else if (act) {
                     // several neurons of a block may share fin: fold them in registers first
                     for (int f = 0; f < a.Fin; ++f) {
@@ -630,7 +718,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
                         }
                     }
                 }
-            }  // depth-wise layers: the feature gradient is computed by conv_dfeat_dw on the transposed list
+            }  // depth-wise layers: the feature gradient is computed by conv_stream<TR> on the transposed list
             float gf[8];
 #pragma unroll
             for (int n = 0; n < 8; ++n) gf[n] = g[n] * ff[n];
@@ -728,83 +816,6 @@ __global__ __launch_bounds__(256) void tr_rank(const int2* __restrict__ packed, 
     }
     for (; q < s1; ++q) r += (tmp[q] < v) ? 1 : 0;
     permT[s0 + r] = v;
-}
-
-template <bool VEC>
-__global__ __launch_bounds__(256) void conv_dfeat_dw(ConvArgs a, const float4* __restrict__ rec,
-                                                     const int* __restrict__ startT, const int* __restrict__ permT,
-                                                     const float* __restrict__ outGrad, float* __restrict__ featGrad) {
-    extern __shared__ float lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
-    const int G = a.G, F = a.Fin;
-    float* wl = lds;
-    float* tile = lds + a.nb * MCCNN_WQ_FWD + (size_t)wave * (G * F);
-    stage_weights<MCCNN_WQ_FWD>(a, wl);
-    const int r0 = (blockIdx.x * 4 + wave) * G;
-    const int r1 = min(r0 + G, a.n);
-    if (r0 < a.n)
-        for (int k = lane; k < G * F; k += 64) tile[k] = 0.0f;
-    __syncthreads();
-    if (r0 >= a.n) return;
-    const int eBeg = startT[r0], eEnd = startT[r1];
-
-    int eN = permT[min(eBeg + lane, a.e - 1)];
-    for (int base = eBeg; base < eEnd; base += 64) {
-        const int t = base + lane;
-        const bool act = t < eEnd;
-        const int e = eN;
-        const float4 rc = rec[e];
-        const int2 pr = a.packed[e];
-        eN = permT[min(t + 64, a.e - 1)];
-        const float inv = act ? rc.w : 0.f;
-        const float* grow = outGrad + (size_t)pr.y * F;
-        const int key1 = act ? (pr.x - r0 + 1) : 0;
-        const float m1 = (key1 != 0 && dpp_i<DPP_ROW_SHR(1)>(key1) == key1) ? 1.f : 0.f;
-        const float m2 = (key1 != 0 && dpp_i<DPP_ROW_SHR(2)>(key1) == key1) ? 1.f : 0.f;
-        const float m4 = (key1 != 0 && dpp_i<DPP_ROW_SHR(4)>(key1) == key1) ? 1.f : 0.f;
-        const float m8 = (key1 != 0 && dpp_i<DPP_ROW_SHR(8)>(key1) == key1) ? 1.f : 0.f;
-        const bool tail = act && (dpp_i<DPP_ROW_SHL(1)>(key1) != key1);
-        float* row = tile + (size_t)(key1 - 1) * F;
-        for (int q = 0; q < a.nb; ++q) {
-            float pre1[8], a1[8], pre2[8], a2[8], o[8], c[8];
-            mlp_block_mfma(wl + q * MCCNN_WQ_FWD, i4, rc.x, rc.y, rc.z, pre1, a1, pre2, a2, o);
-            const bool full = (q * 8 + 8 <= F);
-            if (VEC) {
-                const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
-                float4 ga = gp[0], gb = gp[1];
-                float g[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-#pragma unroll
-                for (int n = 0; n < 8; ++n) c[n] = (g[n] * inv) * o[n];
-            } else {
-#pragma unroll
-                for (int n = 0; n < 8; ++n) c[n] = (q * 8 + n < F) ? grow[q * 8 + n] * inv * o[n] : 0.f;
-            }
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                float v = c[n];
-                v = fmaf(m1, dpp_f<DPP_ROW_SHR(1)>(v), v);
-                v = fmaf(m2, dpp_f<DPP_ROW_SHR(2)>(v), v);
-                v = fmaf(m4, dpp_f<DPP_ROW_SHR(4)>(v), v);
-                v = fmaf(m8, dpp_f<DPP_ROW_SHR(8)>(v), v);
-                c[n] = v;
-            }
-            if (tail) {
-                float* dst = row + q * 8;
-                if (full) {
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) atomicAdd(&dst[n], c[n]);  // ds_add_f32, wave-private tile
-                } else {
-#pragma unroll
-                    for (int n = 0; n < 8; ++n)
-                        if (q * 8 + n < F) atomicAdd(&dst[n], c[n]);
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int cnt = (r1 - r0) * F;
-    float* dst = featGrad + (size_t)r0 * F;
-    for (int k = lane; k < cnt; k += 64) dst[k] = tile[k];
 }
 
 // combin layers: featGrad[j, f] += dfE[e, f] (one atomic per edge and input feature)
@@ -1001,6 +1012,34 @@ static int fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_f
 
 using namespace mccnn;
 
+// Launch of the streaming reduction kernel: as many waves as the chip keeps resident (one balanced round).
+template <bool TR>
+static int launch_conv_stream(const ConvArgs& a, bool combin, bool vec, float* out, const float4* rec, const int* permT,
+                              hipStream_t s) {
+    typedef void (*Kern)(ConvArgs, float*, int, const float4*, const int*);
+    Kern fn;
+    if (TR) fn = vec ? conv_stream<false, 2, true> : conv_stream<false, 0, true>;
+    else if (combin) fn = (a.Fin == 1) ? conv_stream<true, 1, false> : conv_stream<true, 0, false>;
+    else fn = vec ? conv_stream<false, 2, false> : conv_stream<false, 0, false>;
+    const size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * (size_t)a.nb * 8) * sizeof(float);
+    static int numCU = 0;
+    if (!numCU) {
+        int dev = 0;
+        MCCNN_HIP(hipGetDevice(&dev));
+        MCCNN_HIP(hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    int perCU = 0;
+    MCCNN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, reinterpret_cast<const void*>(fn), 256, lds));
+    if (perCU < 1) perCU = 1;
+    const long long chunks = ((long long)a.e + 63) / 64;
+    long long W = (long long)numCU * perCU * 4;
+    if (W > (chunks + 1) / 2) W = (chunks + 1) / 2;  // at least ~2 chunks per wave
+    if (W < 1) W = 1;
+    fn<<<(int)((W + 3) / 4), 256, lds, s>>>(a, out, (int)W, rec, permT);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
 extern "C" {
 
 size_t mccnn_spatial_conv_fwd_workspace_bytes(int, int, int, int, int) { return 256; }  // none needed today
@@ -1023,25 +1062,10 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     if (!out) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats) & 15) == 0);
-    if (use_mfma(a)) {
-        // G centres per wave: LDS tile of G*outF floats per wave, <= 4 KB
-        int G = 1024 / a.outF;
-        if (G > 8) G = 8;   // measured: 4-8 centres per wave beats 16+ (more, shorter waves hide latency better)
-        if (G < 1) G = 1;
-        a.G = G;
-        size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * ((size_t)G * a.outF + G + 4)) * sizeof(float);
-        if (lds <= 64 * 1024) {
-            int blocks = ceil_div(m, 4 * G);
-            if (combin) {
-                if (a.Fin == 1) conv_fwd_mfma<true, 1><<<blocks, 256, lds, s>>>(a, out);
-                else conv_fwd_mfma<true, 0><<<blocks, 256, lds, s>>>(a, out);
-            } else {
-                if (vec) conv_fwd_mfma<false, 2><<<blocks, 256, lds, s>>>(a, out);
-                else conv_fwd_mfma<false, 0><<<blocks, 256, lds, s>>>(a, out);
-            }
-            MCCNN_LAUNCHED();
-            return 0;
-        }
+    if (use_mfma(a) && e > 0) return launch_conv_stream<false>(a, combin != 0, vec, out, nullptr, nullptr, s);
+    if (e == 0) {
+        MCCNN_HIP(hipMemsetAsync(out, 0, (size_t)m * a.outF * sizeof(float), s));
+        return 0;
     }
     // fallback for very wide layers (nb > MCCNN_LDS_MAX_NB): VALU kernel with scalar-loaded weights
     int G = 2048 / a.outF;
@@ -1143,10 +1167,9 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats | (uintptr_t)out_grad) & 15) == 0);
     size_t lds = ((size_t)a.nb * MCCNN_WQ_BWD + 4 * 192) * sizeof(float);
     bool mfma = use_mfma(a) && lds <= 64 * 1024 && m > 0 && e > 0;
-    // depth-wise MFMA path writes every feat_grad row itself (conv_dfeat_dw); everything else accumulates into it
-    int Gd = 1024 / a.Fin; if (Gd > 8) Gd = 8; if (Gd < 1) Gd = 1;
-    size_t ldsD = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * ((size_t)Gd * a.Fin)) * sizeof(float);
-    bool dfeatT = mfma && !combin && ldsD <= 64 * 1024;
+    // depth-wise MFMA path writes every feat_grad row itself (conv_stream over the transposed list); everything else
+    // accumulates into it
+    bool dfeatT = mfma && !combin;
     if (n > 0 && !dfeatT) MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * sizeof(float), s));
     if (!mfma || m == 0 || e == 0) {
         MCCNN_HIP(hipMemsetAsync(dw1, 0, 3 * nn * sizeof(float), s));
@@ -1183,10 +1206,11 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
         reduce_partials<<<ceil_div((long long)a.nb * 176, 16), 256, 0, s>>>(partials, waves, a.nb, dw1, db1, dw2, db2,
                                                                             dw3, db3);
         MCCNN_LAUNCHED();
-        if (combin) {
+        if (combin && a.Fin > 1) {  // Fin == 1: the main kernel adds each edge's finished sum itself
             long long total = (long long)e * a.Fin;
             scatter_edge_featgrad<<<ceil_div(total, 256), 256, 0, s>>>(a.packed, dfE, total, a.Fin, feat_grad);
             MCCNN_LAUNCHED();
+        } else if (combin) {
         } else if (dfeatT) {
             if (!start_t || !perm_t) {  // not supplied by the caller: build the transposed list here
                 int* st = ar.take<int>((size_t)n + 1);
@@ -1200,11 +1224,12 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
                 perm_t = pt;
             }
             bool vecD = (a.Fin % 8 == 0) && ((((uintptr_t)out_grad) & 15) == 0);
-            a.G = Gd;
-            int blocksD = ceil_div(n, 4 * Gd);
-            if (vecD) conv_dfeat_dw<true><<<blocksD, 256, ldsD, s>>>(a, rec, start_t, perm_t, out_grad, feat_grad);
-            else conv_dfeat_dw<false><<<blocksD, 256, ldsD, s>>>(a, rec, start_t, perm_t, out_grad, feat_grad);
-            MCCNN_LAUNCHED();
+            ConvArgs t = a;  // rows = the n neighbour points, CSR = start_t, gathered rows = outGrad
+            t.start = start_t;
+            t.m = n;
+            t.feats = out_grad;
+            int rc3 = launch_conv_stream<true>(t, false, vecD, feat_grad, rec, perm_t, s);
+            if (rc3) return rc3;
         } else {
             return MCCNN_E_TOOLARGE;  // unreachable: the depth-wise tile always fits for nb <= MCCNN_LDS_MAX_NB
         }
