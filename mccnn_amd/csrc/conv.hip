@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void edge_records(ConvArgs a, float4* __restri
 #endif
 // Waves own equal, contiguous EDGE ranges (cpw chunks of 64 edges each): nothing in the backward pass needs
 // centre alignment, and equal edge counts remove the tail that centre-aligned ranges show on non-uniform clouds.
-template <bool COMBIN, int FEAT>
+template <bool COMBIN, int FEAT, bool COOP>
 __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, const float4* __restrict__ rec,
                                                                     const float* __restrict__ outGrad,
                                                                     float* __restrict__ featGrad,
@@ -598,14 +598,19 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
     float* wl = lds;
     stage_weights<MCCNN_WQ_BWD>(a, wl);
     __syncthreads();
-    const int waveGlobal = blockIdx.x * 4 + wave;
-    const long long eBegL = (long long)waveGlobal * cpw * 64;
+    // COOP (depth-wise layers): the four waves of a workgroup share ONE slice of 4*cpw chunks and split the blocks
+    // (wave k takes q = k, k+4, ...). The 32-byte pieces of a feature / gradient row that four consecutive blocks
+    // read are one 128-byte line: fetched by one wave, it is still in L1/L2 when the other three want it, instead of
+    // crossing the fabric once per block sweep. Combin layers keep wave-private slices (per-edge dFeat RMW).
+    const int slice = COOP ? blockIdx.x : blockIdx.x * 4 + wave;
+    const int scpw = COOP ? 4 * cpw : cpw;
+    const long long eBegL = (long long)slice * scpw * 64;
     if (eBegL >= a.e) return;
     const int eBeg = (int)eBegL;
-    const int eEnd = (int)min((long long)a.e, eBegL + (long long)cpw * 64);
-    float* prow = partials + (size_t)waveGlobal * a.nb * 176;
+    const int eEnd = (int)min((long long)a.e, eBegL + (long long)scpw * 64);
+    float* prow = partials + (size_t)slice * a.nb * 176;
 
-    for (int q = 0; q < a.nb; ++q) {
+    for (int q = COOP ? __builtin_amdgcn_readfirstlane(wave) : 0; q < a.nb; q += COOP ? 4 : 1) {
         float gw3[64], gb3[8], gw2[64], gb2[8], gw1[24], gb1[8];
 #pragma unroll
         for (int k = 0; k < 64; ++k) { gw3[k] = 0.f; gw2[k] = 0.f; }
@@ -1195,15 +1200,20 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
         a.G = 0;
         edge_records<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
         MCCNN_LAUNCHED();
+        const bool coop = !combin && a.nb >= 4;
+        int rows = coop ? blocks : waves;  // partial rows to sum
         if (combin) {
-            if (a.Fin == 1) conv_bwd_mfma<true, 1><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-            else conv_bwd_mfma<true, 0><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+            if (a.Fin == 1) conv_bwd_mfma<true, 1, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+            else conv_bwd_mfma<true, 0, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+        } else if (coop) {
+            if (vec) conv_bwd_mfma<false, 2, true><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+            else conv_bwd_mfma<false, 0, true><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
         } else {
-            if (vec) conv_bwd_mfma<false, 2><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-            else conv_bwd_mfma<false, 0><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+            if (vec) conv_bwd_mfma<false, 2, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+            else conv_bwd_mfma<false, 0, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
         }
         MCCNN_LAUNCHED();
-        reduce_partials<<<ceil_div((long long)a.nb * 176, 16), 256, 0, s>>>(partials, waves, a.nb, dw1, db1, dw2, db2,
+        reduce_partials<<<ceil_div((long long)a.nb * 176, 16), 256, 0, s>>>(partials, rows, a.nb, dw1, db1, dw2, db2,
                                                                             dw3, db3);
         MCCNN_LAUNCHED();
         if (combin && a.Fin > 1) {  // Fin == 1: the main kernel adds each edge's finished sum itself
