@@ -234,6 +234,16 @@ def main():
         roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak,
                     "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                     "ms": round(ms, 4), "edges": e, "mlp_blocks": nb}
+        # HBM-side bytes per launch of the dominant kernel come from the separate rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE passes of THIS command (tools/prof.sh), committed under profiles/ -- bench.py cannot collect
+        # counters itself; null when the committed profile does not cover this workload.
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_%s.json" % args.layer)
+        if dom == "spatial_conv_bwd" and os.path.exists(tfile) and args.points == 100000 and args.rooms_per_gpu == 1:
+            with open(tfile) as fh:
+                for kname, tr in json.load(fh).items():
+                    if kname.startswith("conv_bwd_mfma"):
+                        roofline["traffic"] = int(tr["bytes"])
+                        roofline["traffic_source"] = "profiles/" + os.path.basename(tfile)
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N == 1)
     cpu = None

@@ -33,3 +33,16 @@ if rows:
     pd.set_option("display.max_columns", 50)
     print("== PMC (mean per dispatch)")
     print(piv.loc[keep].T.to_string(float_format=lambda x: "%.4g" % x))
+
+# HBM-side traffic per dispatch of the conv kernels, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for
+# gfx950 (FETCH_SIZE counts 64 B per 128-B request: doubled; both counters are in KB; WRITE_SIZE is uncalibrated).
+if rows:
+    import json
+    traffic = {}
+    for k in piv.index:
+        if "FETCH_SIZE" in piv.columns and "WRITE_SIZE" in piv.columns and ("conv_" in k or "neigh" in k or "pdf_edges" in k):
+            f, w = piv.loc[k].get("FETCH_SIZE"), piv.loc[k].get("WRITE_SIZE")
+            if f == f and w == w:
+                traffic[k] = {"fetch_bytes": float(f) * 1024 * 2, "write_bytes": float(w) * 1024,
+                              "bytes": float(f) * 1024 * 2 + float(w) * 1024}
+    json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
