@@ -198,8 +198,10 @@ def main():
                              dtype=torch.uint8, device=device)
         conv_args = (ptr(sP), ptr(sF), ptr(sB), ptr(pdfs), ptr(P), ptr(start), ptr(packed), ptr(mn), ptr(mx), ptr(w1),
                      ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3))
+        sbytes = lib.mccnn_spatial_conv_state_bytes(m, fin, fout, int(combin))
+        state = torch.empty(sbytes, dtype=torch.uint8, device=device) if sbytes else None  # kept fwd -> bwd, as autograd does
         t_fwd, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_fwd(*conv_args, n, m, e, fin, fout, int(combin), B, r, 0,
-                                                                    1, ptr(o), ptr(fwd_ws), fwd_ws.numel(),
+                                                                    1, ptr(o), ptr(state), ptr(fwd_ws), fwd_ws.numel(),
                                                                     stream_handle()), "conv_fwd"))
         fg = torch.empty_like(sF)
         gws = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]
@@ -207,7 +209,8 @@ def main():
                              dtype=torch.uint8, device=device)
         # start_t / perm_t = NULL: the call builds the transposed list itself (worst case: no sharing across layers)
         t_bwd, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_bwd(*conv_args, ptr(OG), n, m, e, fin, fout, int(combin), B,
-                                                                    r, 0, 1, None, None, ptr(fg), *[ptr(g) for g in gws],
+                                                                    r, 0, 1, ptr(state), None, None, ptr(fg),
+                                                                    *[ptr(g) for g in gws],
                                                                     ptr(bwd_ws), bwd_ws.numel(), stream_handle()),
                                          "conv_bwd"))
         t_s2g, _ = ev_time(lambda: M._gather_rows(fg, idx, n))

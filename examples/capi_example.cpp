@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     HK(hipMemcpy(dw3, w3.data(), w3.size() * 4, hipMemcpyHostToDevice)); HK(hipMemcpy(db3, b3.data(), b3.size() * 4, hipMemcpyHostToDevice));
     size_t wsc = mccnn_spatial_conv_fwd_workspace_bytes(n, E, Fin, Fout, 1); void* ws5 = dalloc<char>(wsc);
     CK(mccnn_spatial_conv_fwd(sP, sF, sB, pdfs, dP, start, packed, mn, mx, dw1, db1, dw2, db2, dw3, db3, n, n, E, Fin, Fout, 1, B,
-                              radius, scaleInv, 1, out, ws5, wsc, s));
+                              radius, scaleInv, 1, out, /*state=*/nullptr, ws5, wsc, s));
     std::vector<float> hout((size_t)n * Fout);
     HK(hipMemcpyAsync(hout.data(), out, hout.size() * 4, hipMemcpyDeviceToHost, s)); HK(hipStreamSynchronize(s));
     double sum = 0, asum = 0;

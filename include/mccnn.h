@@ -160,7 +160,12 @@ int mccnn_poisson_sampling_fill(const float* sorted_pts, int n, const int* cell_
 
 /* SpatialConv -- spatial_conv.cc:24,159-321, spatial_conv.cu:24-325,796-871.
  * out[M, combin ? num_out_feats : num_in_feats].  Every output row is written
- * (no pre-zeroing needed). */
+ * (no pre-zeroing needed).
+ * state: optional device buffer of mccnn_spatial_conv_state_bytes() bytes (0 = this layer shape
+ * keeps no state). Combin layers with one input feature leave their per-centre sums there; handing
+ * the same buffer to mccnn_spatial_conv_bwd saves it one pass over the edges. NULL is always
+ * allowed (the reference op has no such output: SpatialConvGrad then recomputes). */
+size_t mccnn_spatial_conv_state_bytes(int m, int num_in_feats, int num_out_feats, int combin);
 size_t mccnn_spatial_conv_fwd_workspace_bytes(int m, int e, int num_in_feats, int num_out_feats,
                                               int combin);
 int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats,
@@ -169,15 +174,16 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats,
                            const float* aabb_max, const float* w1, const float* b1, const float* w2,
                            const float* b2, const float* w3, const float* b3, int n, int m, int e,
                            int num_in_feats, int num_out_feats, int combin, int batch_size,
-                           float radius, int scale_inv, int avg, float* out, void* ws,
-                           size_t ws_bytes, mccnn_stream_t stream);
+                           float radius, int scale_inv, int avg, float* out, void* state,
+                           void* ws, size_t ws_bytes, mccnn_stream_t stream);
 
 /* SpatialConvGrad -- spatial_conv.cc:56,323-519, spatial_conv.cu:327-792,873-966.
  * Gradients w.r.t. the features and the six MLP tensors only
  * (MCConvModuleSrc:74-81).  All seven outputs are fully written; gradients of
  * padded output neurons (nu >= neuronsOut), which the reference leaves
- * uninitialised (spatial_conv.cu:921,924), are zero. start_t / perm_t: optional transposed
- * neighbour list (see mccnn_transpose_neighbors), used by depth-wise layers only. */
+ * uninitialised (spatial_conv.cu:921,924), are zero. state: the buffer the forward call of the
+ * SAME inputs filled, or NULL. start_t / perm_t: optional transposed neighbour list (see
+ * mccnn_transpose_neighbors), used by depth-wise layers only. */
 size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_feats,
                                               int num_out_feats, int combin);
 int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats,
@@ -186,8 +192,8 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats,
                            const float* aabb_max, const float* w1, const float* b1, const float* w2,
                            const float* b2, const float* w3, const float* b3, const float* out_grad,
                            int n, int m, int e, int num_in_feats, int num_out_feats, int combin,
-                           int batch_size, float radius, int scale_inv, int avg, const int* start_t,
-                           const int* perm_t, float* feat_grad, float* dw1, float* db1, float* dw2,
+                           int batch_size, float radius, int scale_inv, int avg, const void* state,
+                           const int* start_t, const int* perm_t, float* feat_grad, float* dw1, float* db1, float* dw2,
                            float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes,
                            mccnn_stream_t stream);
 

@@ -344,6 +344,9 @@ def find_neighbors(inPts, inBatchIds, inPts2, cellIndexs, aabbMin, aabbMax, radi
 
 #: 0 = the reference's double-precision-exp arithmetic, 1 = single-precision (default; ~1e-6 rel. apart)
 PDF_MODE = 1
+# keep the forward's per-centre sums for the backward pass (layers with one input feature); False = the backward
+# recomputes them, as a binding without an extra forward output has to
+KEEP_CONV_STATE = True
 
 
 def compute_pdf(inPts, inBatchIds, aabbMin, aabbMax, startIndexs, neighbors, window, radius, batchSize, scaleInv,
@@ -479,12 +482,19 @@ class _SpatialConv(torch.autograd.Function):
         outF = numOutFeatures if combin else fin
         out = torch.empty((m, outF), dtype=torch.float32, device=pts.device)
         ws = _ws(lib.mccnn_spatial_conv_fwd_workspace_bytes(m, e, fin, numOutFeatures, int(bool(combin))), pts.device)
+        # per-centre sums the backward pass can reuse (layers with one input feature); only kept when a gradient
+        # will be asked for
+        state = None
+        sbytes = lib.mccnn_spatial_conv_state_bytes(m, fin, numOutFeatures, int(bool(combin)))
+        if KEEP_CONV_STATE and sbytes and e > 0 and any(t.requires_grad for t in (feats, w1, b1, w2, b2, w3, b3)):
+            state = torch.empty(sbytes, dtype=torch.uint8, device=pts.device)
         check(lib.mccnn_spatial_conv_fwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                          ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), n, m,
                                          e, fin, numOutFeatures, int(bool(combin)), batchSize, float(radius),
-                                         int(bool(scaleInv)), int(bool(avg)), ptr(out), ptr(ws), ws.numel(),
+                                         int(bool(scaleInv)), int(bool(avg)), ptr(out), ptr(state), ptr(ws), ws.numel(),
                                          stream_handle()), "spatial_conv")
         ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3)
+        ctx.state = state
         ctx.attrs = (numOutFeatures, bool(combin), batchSize, float(radius), bool(scaleInv), bool(avg))
         return out
 
@@ -506,7 +516,8 @@ class _SpatialConv(torch.autograd.Function):
         check(lib.mccnn_spatial_conv_bwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                          ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
                                          ptr(og), n, m, e, fin, numOutFeatures, int(combin), batchSize, radius,
-                                         int(scaleInv), int(avg), ptr(start_t), ptr(perm_t), ptr(fg), ptr(dw1),
+                                         int(scaleInv), int(avg), ptr(ctx.state), ptr(start_t), ptr(perm_t), ptr(fg),
+                                         ptr(dw1),
                                          ptr(db1), ptr(dw2), ptr(db2),
                                          ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
               "spatial_conv_grad")

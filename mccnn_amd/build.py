@@ -13,7 +13,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, os.environ.get("MCCNN_LIB_NAME", "libmccnn_hip.so"))  # override only for A/B experiments
-SOURCES = ["api_misc.hip", "scan.hip", "grid.hip", "neighbors.hip", "poisson.hip", "conv.hip"]
+SOURCES = ["api_misc.hip", "scan.hip", "grid.hip", "neighbors.hip", "poisson.hip", "conv.hip", "conv_f1.hip"]
+HEADERS = ["common.h", "conv_mfma.h"]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # bit-exact geometry: no FMA contraction, correctly rounded f32 divide / sqrt (see csrc/common.h)
@@ -39,7 +40,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "mccnn.h")]
+    deps = sources() + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "mccnn.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -4,7 +4,7 @@
 extern "C" {
 
 int mccnn_block_size(void) { return MCCNN_MLP; }
-int mccnn_abi_version(void) { return 1; }
+int mccnn_abi_version(void) { return 2; }  // 2: optional forward state of spatial_conv
 const char* mccnn_arch(void) { return "gfx950"; }
 
 const char* mccnn_error_string(int code) {

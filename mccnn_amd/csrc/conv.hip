@@ -11,26 +11,10 @@
 // layers are explicit fmaf chains with wave-uniform weights (scalar loads), the sum over a
 // centre's edges is a segmented wave scan, and every output row is written exactly once from
 // an LDS tile: no atomics, no pre-zeroing, bit-reproducible.
-#include "common.h"
+#include "conv_mfma.h"
 #include <cstdlib>
 
 namespace mccnn {
-
-struct ConvArgs {
-    const float* pts;
-    const float* feats;
-    const int* bids;
-    const float* pdfs;
-    const float* samples;
-    const int* start;
-    const int2* packed;
-    const float* mn;
-    const float* mx;
-    const float *w1, *b1, *w2, *b2, *w3, *b3;
-    int n, m, e, Fin, Fout, nb, neuronsOut, outF;
-    float radius, invRadius;
-    int scaleInv, avg, G;
-};
 
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.0f); }
 __device__ __forceinline__ float wave_sum(float v) {
@@ -176,177 +160,12 @@ __global__ __launch_bounds__(256) void conv_fwd_valu(ConvArgs a, float* __restri
 }
 
 // ---------------------------------------------------------------------------------------
-// MFMA kernels (nb <= MCCNN_LDS_MAX_NB).
-//
-// v_mfma_f32_4x4x1_16b_f32 computes 16 independent 4x4 rank-1 updates per wave:
-//     D[lane 4b+j][reg r] += A(lane 4b+r) * B(lane 4b+j)          (layout probed on gfx950, profiles/)
-// With lane = edge and reg = neuron this is exactly one k-step of an 8x8 block of the kernel MLP
-// for 64 edges at once and with ZERO block-diagonal waste (a 16x16x4 tiling wastes half of every
-// MFMA on the off-diagonal zeros): A = the weight W[r][k] (same for every quad), B = the lane's
-// own activation h[k]. Two accumulators (neurons 0-3 / 4-7) x 8 k-steps = 16 MFMAs per layer, the
-// accumulator is initialised with the bias straight from LDS, numerics == the fmaf chain of v1.
-// The transposed products of the backward pass (t3 = W3^T (g f), t4 = W2^T t3) use the same form
-// with the transposed weight copies staged in LDS.
-// ---------------------------------------------------------------------------------------
-#define MCCNN_LDS_MAX_NB 64
-// floats per MLP block in LDS: W1[8][4] b1[8] W2[8][8] b2[8] W3[8][8] b3[8] (+ W2^T[8][8] W3^T[8][8] for bwd)
-#define MCCNN_WQ_FWD 184
-#define MCCNN_WQ_BWD 312
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
-}
-#define DPP_ROW_SHR(n) (0x110 + (n))
-#define DPP_ROW_SHL(n) (0x100 + (n))
-
-// MFMA and VALU instructions of one wave are kept in separate PHASES: tools/issue_probe.hip shows that a wave
-// alternating between the two pays ~7 extra cycles per switch (8 mfma + 16 fma cost 163 cycles interleaved, 108
-// grouped = the sum of the parts), and the scheduler's default is to interleave. SALU and memory ops may cross.
-#ifndef MCCNN_NO_PHASES
-#define MCCNN_PHASE() __builtin_amdgcn_sched_barrier(0x4 | 0x10 | 0x80)
-#else
-#define MCCNN_PHASE()
-#endif
-
-// max(x, 0) as ONE instruction: v_med3_f32(x, 0, +inf). fmaxf() costs an extra canonicalising v_max on MFMA results,
-// and med3 with a literal +inf is folded back into that pair -- so the +inf goes through an opaque SGPR.
-__device__ __forceinline__ float relu1(float x) {
-    float inf = __builtin_huge_valf();
-    asm("" : "+s"(inf));
-    return __builtin_amdgcn_fmed3f(x, 0.0f, inf);
-}
-
-// Stage the MLP tensors of all nb blocks into LDS in the per-block layout above.
-template <int WQ>
-__device__ __forceinline__ void stage_weights(const ConvArgs& a, float* wl) {
-    for (int t = threadIdx.x; t < a.nb * WQ; t += blockDim.x) {
-        int q = t / WQ, r = t - q * WQ;
-        float v;
-        if (r < 32) { int row = r >> 2, c = r & 3; v = (c < 3) ? a.w1[(q * 8 + row) * 3 + c] : 0.0f; }
-        else if (r < 40) v = a.b1[q * 8 + r - 32];
-        else if (r < 104) v = a.w2[q * 64 + r - 40];
-        else if (r < 112) v = a.b2[q * 8 + r - 104];
-        else if (r < 176) v = a.w3[q * 64 + r - 112];
-        else if (r < 184) v = a.b3[q * 8 + r - 176];
-        else if (r < 248) { int k = r - 184; v = a.w2[q * 64 + (k & 7) * 8 + (k >> 3)]; }   // W2^T[l][m] = W2[m][l]
-        else { int k = r - 248; v = a.w3[q * 64 + (k & 7) * 8 + (k >> 3)]; }                  // W3^T[m][n] = W3[n][m]
-        wl[t] = v;
-    }
-}
-
-// One 8x8 layer for 64 edges: y = bias + W x, rows i4 / 4+i4 of W supplied by this lane. Two interleaved
-// accumulation chains (neurons 0-3 / 4-7); splitting K into more independent chains was measured slower
-// (tools/issue_probe.hip: a single dependent 4x4x1 chain already issues every ~15 cycles and is hidden from 2 waves
-// per SIMD up).
-__device__ __forceinline__ void layer8(const f32x4* __restrict__ wrows /* 16 x f32x4: row r at [2r],[2r+1] */,
-                                       f32x4 lo, f32x4 hi, int i4, const float* x, float* y) {
-    f32x4 al0 = wrows[2 * i4], al1 = wrows[2 * i4 + 1];
-    f32x4 ah0 = wrows[2 * (4 + i4)], ah1 = wrows[2 * (4 + i4) + 1];
-    float al[8] = {al0.x, al0.y, al0.z, al0.w, al1.x, al1.y, al1.z, al1.w};
-    float ah[8] = {ah0.x, ah0.y, ah0.z, ah0.w, ah1.x, ah1.y, ah1.z, ah1.w};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        lo = MFMA4(al[k], x[k], lo);
-        hi = MFMA4(ah[k], x[k], hi);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { y[r] = lo[r]; y[4 + r] = hi[r]; }
-}
-
-// Kernel MLP of block q (weights at wq in LDS) for the 64 edges of a wave.
-// a1 = relu(pre1), a2 = relu(pre2) are returned because backward needs them.
-__device__ __forceinline__ void mlp_block_mfma(const float* __restrict__ wq, int i4, float d0, float d1, float d2,
-                                               float* pre1, float* a1, float* pre2, float* a2, float* o) {
-    const f32x4* w = reinterpret_cast<const f32x4*>(wq);
-    f32x4 a1lo = w[i4], a1hi = w[4 + i4];
-    f32x4 lo = w[8], hi = w[9];  // b1
-    lo = MFMA4(a1lo.x, d0, lo);
-    hi = MFMA4(a1hi.x, d0, hi);
-    lo = MFMA4(a1lo.y, d1, lo);
-    hi = MFMA4(a1hi.y, d1, hi);
-    lo = MFMA4(a1lo.z, d2, lo);
-    hi = MFMA4(a1hi.z, d2, hi);
-    MCCNN_PHASE();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { pre1[r] = lo[r]; pre1[4 + r] = hi[r]; }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) a1[r] = relu1(pre1[r]);
-    MCCNN_PHASE();
-    layer8(w + 10, w[26], w[27], i4, a1, pre2);  // W2, b2
-    MCCNN_PHASE();
-#pragma unroll
-    for (int r = 0; r < 8; ++r) a2[r] = relu1(pre2[r]);
-    MCCNN_PHASE();
-    layer8(w + 28, w[44], w[45], i4, a2, o);     // W3, b3
-    MCCNN_PHASE();
-}
-
-// ---------------------------------------------------------------------------------------
 // Forward, streaming form. Every wave owns a centre-aligned slice of the neighbour list holding ~E/W edges (W = the
 // number of waves the chip keeps resident, so the launch is ONE balanced round: with a fixed number of centres per
 // wave the non-uniform clouds left the last third of the launch half empty). Chunks are 64 consecutive edges of the
 // slice, independent of centre boundaries; the output tile is a sliding window of G rows (row of centre c = c mod G)
 // that is flushed -- each row exactly once, in order -- when a chunk reaches beyond it.
 // ---------------------------------------------------------------------------------------
-// smallest c in [0, m] with S(c) >= t, S(c) = start[c] (c < m), S(m) = e. 64-ary: three dependent loads for m < 2^18.
-__device__ __forceinline__ int wave_lower_bound(const int* __restrict__ start, int m, int e, int t, int lane) {
-    int lo = 0, hi = m;
-    while (lo < hi) {
-        const int span = hi - lo;
-        const int step = (span + 63) >> 6;
-        const int p = min(lo + lane * step, hi);
-        const int v = (p < m) ? start[p] : e;
-        const unsigned long long b = __ballot(v >= t);
-        const int f = b ? (int)__builtin_ctzll(b) : 64;
-        const int nlo = (f == 0) ? lo : min(lo + (f - 1) * step, hi) + 1;
-        const int nhi = (f == 0) ? lo : ((f == 64) ? hi : min(lo + f * step, hi));
-        lo = nlo;
-        hi = nhi;
-    }
-    return lo;
-}
-
-#define DPP_ROW_BCAST15 0x142
-#define DPP_ROW_BCAST31 0x143
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ float dpp_rows_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
-}
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ int dpp_rows_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xf, false);
-}
-
-// Segmented inclusive scan of 8 values over the 64 lanes: v += m_step * v[lane - step]. The DPP read is folded
-// into the multiply-add (v_fmac_f32_dpp) -- from C++ the compiler emits v_mov_b32_dpp + v_fma (VOP3 cannot carry
-// DPP) -- and the 8 values advance in lock step, so an instruction never reads a register written less than 8
-// instructions earlier (the VALU-write -> DPP-read hazard needs 2 wait states; inline asm gets no automatic nops).
-#define MCCNN_SCAN_STEP(CTRL, M)                                                         \
-    "v_fmac_f32_dpp %0, %0, %" #M " " CTRL "\n v_fmac_f32_dpp %1, %1, %" #M " " CTRL "\n" \
-    "v_fmac_f32_dpp %2, %2, %" #M " " CTRL "\n v_fmac_f32_dpp %3, %3, %" #M " " CTRL "\n" \
-    "v_fmac_f32_dpp %4, %4, %" #M " " CTRL "\n v_fmac_f32_dpp %5, %5, %" #M " " CTRL "\n" \
-    "v_fmac_f32_dpp %6, %6, %" #M " " CTRL "\n v_fmac_f32_dpp %7, %7, %" #M " " CTRL "\n"
-__device__ __forceinline__ void wave_seg_scan8(float* c, float m1, float m2, float m4, float m8, float mA, float mB) {
-    asm("s_nop 1\n"
-        MCCNN_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1", 8)
-        MCCNN_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1", 9)
-        MCCNN_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1", 10)
-        MCCNN_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1", 11)
-        MCCNN_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf", 12)
-        MCCNN_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf", 13)
-        "s_nop 1\n"
-        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7])
-        : "v"(m1), "v"(m2), "v"(m4), "v"(m8), "v"(mA), "v"(mB));
-}
-
 // TR = true runs the same reduction over the TRANSPOSED list (rows = neighbours j, CSR a.start = startT, edge ids
 // through permT, geometry from the per-edge records): the depth-wise feature gradient
 //   featGrad[j, nu] = sum over edges e=(j,i) of outGrad[i, nu] * o_e[nu] / (pdf_e K_i)          (spatial_conv.cu:400)
@@ -539,29 +358,6 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
 // Fin <= 4 they are accumulated per edge in LDS across all blocks and flushed with ONE atomic per (edge, fin);
 // otherwise one atomic per (edge, neuron).
 // ---------------------------------------------------------------------------------------
-
-// Transposing butterfly: 64 per-lane values -> lane l ends with sum over all lanes of v[l].
-// 63 exchanges instead of the 64 x 6 of a per-value wave_sum. (Template recursion keeps every index static:
-// a runtime-indexed register array would be demoted to scratch.)
-template <int S>
-__device__ __forceinline__ void butterfly_step(float* v, int lane) {
-    const bool upper = (lane & S) != 0;
-#pragma unroll
-    for (int k = 0; k < S; ++k) {
-        float send = upper ? v[k] : v[k + S];
-        float keep = upper ? v[k + S] : v[k];
-        v[k] = keep + __shfl_xor(send, S, 64);
-    }
-}
-__device__ __forceinline__ float wave_reduce64(float* v, int lane) {
-    butterfly_step<32>(v, lane);
-    butterfly_step<16>(v, lane);
-    butterfly_step<8>(v, lane);
-    butterfly_step<4>(v, lane);
-    butterfly_step<2>(v, lane);
-    butterfly_step<1>(v, lane);
-    return v[0];
-}
 
 // Per-edge record (delta0, delta1, delta2, 1/(pdf K)) written once per backward call: the q-outer sweep re-reads
 // every edge nb times, so the dependent gathers (packed -> pts/samples/start/pdf) and the set-up arithmetic are
@@ -1047,7 +843,22 @@ static int launch_conv_stream(const ConvArgs& a, bool combin, bool vec, float* o
 
 extern "C" {
 
-size_t mccnn_spatial_conv_fwd_workspace_bytes(int, int, int, int, int) { return 256; }  // none needed today
+// combin layers with one input feature take the factored path of conv_f1.hip (f1_*)
+static bool f1_shape(int num_in_feats, int num_out_feats, int combin) {
+    return combin && num_in_feats == 1 && num_out_feats > 0 && (num_out_feats + 7) / 8 <= MCCNN_LDS_MAX_NB &&
+           !getenv("MCCNN_FORCE_VALU") && !getenv("MCCNN_NO_F1");
+}
+
+size_t mccnn_spatial_conv_state_bytes(int m, int num_in_feats, int num_out_feats, int combin) {
+    if (m <= 0 || !f1_shape(num_in_feats, num_out_feats, combin)) return 0;
+    return f1_state_bytes(m, (num_out_feats + 7) / 8);
+}
+
+size_t mccnn_spatial_conv_fwd_workspace_bytes(int m, int e, int num_in_feats, int num_out_feats, int combin) {
+    (void)e;
+    if (m > 0 && f1_shape(num_in_feats, num_out_feats, combin)) return f1_fwd_workspace_bytes(m, (num_out_feats + 7) / 8);
+    return 256;
+}  // none needed today
 
 static bool use_mfma(const ConvArgs& a) { return a.nb <= MCCNN_LDS_MAX_NB && !getenv("MCCNN_FORCE_VALU"); }
 
@@ -1056,8 +867,8 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
                            const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
                            const float* w2, const float* b2, const float* w3, const float* b3, int n, int m, int e,
                            int num_in_feats, int num_out_feats, int combin, int batch_size, float radius,
-                           int scale_inv, int avg, float* out, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
-    (void)ws; (void)ws_bytes;
+                           int scale_inv, int avg, float* out, void* state, void* ws, size_t ws_bytes,
+                           mccnn_stream_t stream) {
     ConvArgs a;
     int rc = fill_args(a, sorted_pts, sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min,
                        aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_in_feats, num_out_feats, combin, batch_size,
@@ -1067,6 +878,7 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     if (!out) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats) & 15) == 0);
+    if (e > 0 && f1_shape(num_in_feats, num_out_feats, combin)) return f1_forward(a, out, state, ws, ws_bytes, s);
     if (use_mfma(a) && e > 0) return launch_conv_stream<false>(a, combin != 0, vec, out, nullptr, nullptr, s);
     if (e == 0) {
         MCCNN_HIP(hipMemsetAsync(out, 0, (size_t)m * a.outF * sizeof(float), s));
@@ -1139,10 +951,10 @@ int mccnn_transpose_neighbors(const int* packed, int e, int n, int* start_t, int
 }
 
 size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_feats, int num_out_feats, int combin) {
-    (void)m;
     if (e <= 0 || num_in_feats <= 0 || num_out_feats <= 0) return 256;
     long long neurons = combin ? (long long)num_in_feats * num_out_feats : num_in_feats;
     long long nb = (neurons + 7) / 8;
+    if (m > 0 && f1_shape(num_in_feats, num_out_feats, combin)) return f1_bwd_workspace_bytes(m, e, (int)nb);
     int cpw, waves;
     bwd_partition(e, cpw, waves);
     size_t bytes = align_up((size_t)(((long long)waves + 3) / 4 * 4 * nb * 176) * sizeof(float));  // partial rows
@@ -1158,8 +970,8 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
                            const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
                            const float* w2, const float* b2, const float* w3, const float* b3, const float* out_grad,
                            int n, int m, int e, int num_in_feats, int num_out_feats, int combin, int batch_size,
-                           float radius, int scale_inv, int avg, const int* start_t, const int* perm_t,
-                           float* feat_grad, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
+                           float radius, int scale_inv, int avg, const void* state, const int* start_t,
+                           const int* perm_t, float* feat_grad, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
                            void* ws, size_t ws_bytes, mccnn_stream_t stream) {
     ConvArgs a;
     int rc = fill_args(a, sorted_pts, sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min,
@@ -1186,6 +998,8 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
     }
     if (m == 0 || e == 0) return 0;
     if (!out_grad) return MCCNN_E_BADARG;
+    if (mfma && f1_shape(num_in_feats, num_out_feats, combin))
+        return f1_backward(a, out_grad, state, feat_grad, dw1, db1, dw2, db2, dw3, db3, ws, ws_bytes, s);
     if (mfma) {
         if (!ws || ws_bytes < mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, num_in_feats, num_out_feats, combin))
             return MCCNN_E_WORKSPACE;

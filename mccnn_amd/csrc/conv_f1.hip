@@ -1,0 +1,568 @@
+// Monte-Carlo convolution for combin layers with ONE input feature (the first layer of every MCCNN network: constant
+// or intensity input at the finest level -- the layer with the most points and edges). Same results as the general
+// kernels of conv.hip (spatial_conv.cu:24-79 forward, :327-445 backward) up to float summation order.
+//
+// With Fin = 1 the edge weight s_e = f_j / (pdf_e K_i) is a scalar, so the third MLP layer commutes with the sum over
+// a centre's edges (block q, 8 neurons, a2_e = second hidden layer of edge e):
+//     out_i[q]  = sum_e s_e (W3 a2_e + b3)   =  W3 A_i + b3 S_i,        A_i = sum_e s_e a2_e,   S_i = sum_e s_e
+//     dW3       = sum_i g_i (x) A_i,         db3 = sum_i g_i S_i
+//     t3_e      = 1[pre2_e >= 0] * (W3^T g_i) s_e  =  1[pre2_e >= 0] * G_i s_e
+//     dFeat_j  += (G_i . a2_e + g_i . b3) / (pdf_e K_i)
+// Layer 3 and everything that multiplies by it moves from the E edges to the M centres: per (64-edge chunk, block) the
+// forward issues 22 MFMAs instead of 38, the backward 38 instead of 70 and 104 accumulator FMAs instead of 176.
+// The forward leaves (A, S) in an optional state buffer for the backward; without it the backward recomputes them.
+#include "conv_mfma.h"
+
+namespace mccnn {
+
+// layers 1 and 2 of block q for the 64 edges of a wave (see mlp_block_mfma)
+__device__ __forceinline__ void mlp_block_l12(const float* __restrict__ wq, int i4, float d0, float d1, float d2,
+                                              float* pre1, float* a1, float* pre2, float* a2) {
+    const f32x4* w = reinterpret_cast<const f32x4*>(wq);
+    f32x4 a1lo = w[i4], a1hi = w[4 + i4];
+    f32x4 lo = w[8], hi = w[9];  // b1
+    lo = MFMA4(a1lo.x, d0, lo);
+    hi = MFMA4(a1hi.x, d0, hi);
+    lo = MFMA4(a1lo.y, d1, lo);
+    hi = MFMA4(a1hi.y, d1, hi);
+    lo = MFMA4(a1lo.z, d2, lo);
+    hi = MFMA4(a1hi.z, d2, hi);
+    MCCNN_PHASE();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pre1[r] = lo[r]; pre1[4 + r] = hi[r]; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a1[r] = relu1(pre1[r]);
+    MCCNN_PHASE();
+    layer8(w + 10, w[26], w[27], i4, a1, pre2);  // W2, b2
+    MCCNN_PHASE();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a2[r] = relu1(pre2[r]);
+    MCCNN_PHASE();
+}
+
+// segmented inclusive wave scan of ONE value (once per chunk: the nops cover the VALU-write -> DPP-read hazard)
+__device__ __forceinline__ float wave_seg_scan1(float v, float m1, float m2, float m4, float m8, float mA, float mB) {
+    asm("s_nop 1\n"
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n"
+        "v_fmac_f32_dpp %0, %0, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n"
+        "v_fmac_f32_dpp %0, %0, %3 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n"
+        "v_fmac_f32_dpp %0, %0, %4 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n"
+        "v_fmac_f32_dpp %0, %0, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
+        "v_fmac_f32_dpp %0, %0, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n s_nop 1\n"
+        : "+v"(v)
+        : "v"(m1), "v"(m2), "v"(m4), "v"(m8), "v"(mA), "v"(mB));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Forward, edge pass: A_i = sum_e s_e a2_e (nb*8 floats per centre), S_i = sum_e s_e. Same streaming structure as
+// conv_stream (conv.hip): edge-balanced centre-aligned slices, chunks of 64 consecutive edges, wave-wide segmented
+// scan with carry, the last lane of a centre stores its finished sums.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void f1_fwd_edges(ConvArgs a, float* __restrict__ A, float* __restrict__ S,
+                                                    int numWaves) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
+    const int rowA = a.nb * 8;
+    float* wl = lds;
+    float* carry = lds + a.nb * MCCNN_WQ_FWD + (size_t)wave * rowA;
+    stage_weights<MCCNN_WQ_FWD>(a, wl);
+    __syncthreads();
+    const int w = blockIdx.x * 4 + wave;
+    if (w >= numWaves) return;
+    const int tA = (int)(((long long)a.e * w) / numWaves);
+    const int tB = (int)(((long long)a.e * (w + 1)) / numWaves);
+    const int cA = (w == 0) ? 0 : wave_lower_bound(a.start, a.m, a.e, tA, lane);
+    const int cB = (w == numWaves - 1) ? a.m : wave_lower_bound(a.start, a.m, a.e, tB, lane);
+    if (cA >= cB) return;
+    const int eBeg = a.start[cA];
+    const int eEnd = (cB < a.m) ? a.start[cB] : a.e;
+
+    auto zero_rows = [&](int c0, int c1) {  // centres without neighbours
+        for (int c = c0; c < c1; ++c) {
+            for (int f = 0; f < rowA; ++f) A[(size_t)c * rowA + f] = 0.0f;
+            S[c] = 0.0f;
+        }
+    };
+
+    int keyLast = cA;
+    int carryKey = -1;
+    float carryS = 0.f;
+    int2 prN = make_int2(0, cA);
+    float pdfN = 1.0f;
+    if (eBeg + lane < eEnd) { prN = a.packed[eBeg + lane]; pdfN = a.pdfs[eBeg + lane]; }
+    for (int base = eBeg; base < eEnd; base += 64) {
+        const int t = base + lane;
+        const int nIn = min(64, eEnd - base);
+        const bool in = lane < nIn;
+        const int2 pr = prN;
+        const float pdf = pdfN;
+        if (t + 64 < eEnd) { prN = a.packed[t + 64]; pdfN = a.pdfs[t + 64]; }
+        const int ci = pr.y, j = pr.x;
+        float invR = a.invRadius;
+        if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, a.bids[j]));
+        const float* pp = a.pts + (size_t)j * 3;
+        const float* cc = a.samples + (size_t)ci * 3;
+        const float d0 = (pp[0] - cc[0]) * invR, d1 = (pp[1] - cc[1]) * invR, d2 = (pp[2] - cc[2]) * invR;
+        float K = 1.0f;
+        if (a.avg) K = (float)(((ci + 1 < a.m) ? a.start[ci + 1] : a.e) - a.start[ci]);
+        const float s = in ? a.feats[j] * __builtin_amdgcn_rcpf(pdf * K) : 0.0f;
+        const int key = in ? ci + 1 : 0;
+        const int cLast = __builtin_amdgcn_readlane(ci, nIn - 1);
+        const int rowEnd = (cLast + 1 < a.m) ? a.start[cLast + 1] : a.e;
+        const bool cont = rowEnd > base + 64;
+        int keyPrev = __shfl_up(key, 1, 64);
+        if (lane == 0) keyPrev = keyLast;
+        int keyNext = __shfl_down(key, 1, 64);
+        const bool tail = in && ((lane == nIn - 1) ? !cont : (key != keyNext));
+        if (in && key - keyPrev > 1) zero_rows(keyPrev, ci);
+        const float m1 = (key != 0 && dpp_i<DPP_ROW_SHR(1)>(key) == key) ? 1.f : 0.f;
+        const float m2 = (key != 0 && dpp_i<DPP_ROW_SHR(2)>(key) == key) ? 1.f : 0.f;
+        const float m4 = (key != 0 && dpp_i<DPP_ROW_SHR(4)>(key) == key) ? 1.f : 0.f;
+        const float m8 = (key != 0 && dpp_i<DPP_ROW_SHR(8)>(key) == key) ? 1.f : 0.f;
+        const float mA = (key != 0 && dpp_rows_i<DPP_ROW_BCAST15, 0xA>(key) == key) ? 1.f : 0.f;
+        const float mB = (key != 0 && dpp_rows_i<DPP_ROW_BCAST31, 0xC>(key) == key) ? 1.f : 0.f;
+        const bool haveCarry = carryKey >= 0;
+        const float mC = (haveCarry && key == carryKey) ? 1.f : 0.f;
+
+        float sv = wave_seg_scan1(s, m1, m2, m4, m8, mA, mB);
+        sv = fmaf(mC, carryS, sv);
+        if (tail) S[ci] = sv;
+        carryS = __shfl(sv, 63, 64);
+        float* arow = A + (size_t)ci * rowA;
+
+        for (int q = 0; q < a.nb; ++q) {
+            float pre1[8], a1[8], pre2[8], a2[8], c[8];
+            MCCNN_PHASE();
+            mlp_block_l12(wl + q * MCCNN_WQ_FWD, i4, d0, d1, d2, pre1, a1, pre2, a2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = s * a2[k];
+            float* cq = carry + q * 8;
+            f32x4 cv0 = {0.f, 0.f, 0.f, 0.f}, cv1 = cv0;
+            if (haveCarry) { cv0 = *reinterpret_cast<f32x4*>(cq); cv1 = *reinterpret_cast<f32x4*>(cq + 4); }
+            wave_seg_scan8(c, m1, m2, m4, m8, mA, mB);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = fmaf(mC, k < 4 ? cv0[k & 3] : cv1[k & 3], c[k]);
+            if (cont && lane == 63) {
+                *reinterpret_cast<f32x4*>(cq) = (f32x4){c[0], c[1], c[2], c[3]};
+                *reinterpret_cast<f32x4*>(cq + 4) = (f32x4){c[4], c[5], c[6], c[7]};
+            }
+            if (tail) {
+                float4* dst = reinterpret_cast<float4*>(arow + q * 8);
+                dst[0] = make_float4(c[0], c[1], c[2], c[3]);
+                dst[1] = make_float4(c[4], c[5], c[6], c[7]);
+            }
+        }
+        carryKey = cont ? cLast + 1 : -1;
+        keyLast = cLast + 1;
+    }
+    if (lane == 0) zero_rows(keyLast, cB);
+}
+
+// Forward, centre pass: out_i[8q+n] = W3_q[n] . A_i[q] + b3_q[n] S_i. One thread per (centre, block): consecutive lanes
+// read / write consecutive 32-byte pieces of a row; weights from LDS.
+__global__ __launch_bounds__(256) void f1_fwd_centres(ConvArgs a, const float* __restrict__ A,
+                                                      const float* __restrict__ S, float* __restrict__ out) {
+    extern __shared__ float lds[];  // per block: W3[8][8], b3[8]
+    for (int t = threadIdx.x; t < a.nb * 72; t += blockDim.x) {
+        int q = t / 72, r = t - q * 72;
+        lds[t] = (r < 64) ? a.w3[q * 64 + r] : a.b3[q * 8 + r - 64];
+    }
+    __syncthreads();
+    const long long tix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tix >= (long long)a.m * a.nb) return;
+    const int i = (int)(tix / a.nb), q = (int)(tix - (long long)i * a.nb);
+    const float Si = S[i];
+    const float4* ap = reinterpret_cast<const float4*>(A + tix * 8);
+    const float4 x0 = ap[0], x1 = ap[1];
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    const float* wq = lds + q * 72;
+    float o[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        float acc = wq[64 + n] * Si;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = fmaf(wq[n * 8 + k], x[k], acc);
+        o[n] = acc;
+    }
+    float* dst = out + (size_t)i * a.outF + q * 8;
+    if ((a.outF & 3) == 0 && q * 8 + 8 <= a.outF) {
+        reinterpret_cast<float4*>(dst)[0] = make_float4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<float4*>(dst)[1] = make_float4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            if (q * 8 + n < a.outF) dst[n] = o[n];
+    }
+}
+
+__global__ __launch_bounds__(256) void f1_edge_records(ConvArgs a, float4* __restrict__ rec) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.e) return;
+    int2 pr = a.packed[t];
+    float invR = a.invRadius;
+    if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, a.bids[pr.x]));
+    const float* p = a.pts + (size_t)pr.x * 3;
+    const float* c = a.samples + (size_t)pr.y * 3;
+    int e0 = a.start[pr.y];
+    int e1 = (pr.y < a.m - 1) ? a.start[pr.y + 1] : a.e;
+    float K = a.avg ? (float)(e1 - e0) : 1.0f;
+    rec[t] = make_float4((p[0] - c[0]) * invR, (p[1] - c[1]) * invR, (p[2] - c[2]) * invR,
+                         __builtin_amdgcn_rcpf(a.pdfs[t] * K));
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward, edge pass (q-outer, edge-balanced waves, see conv_bwd_mfma): dW2, db2, dW1, db1 partial sums in VGPRs
+// (104 accumulators), per-edge feature gradient accumulated across blocks with a plain read-modify-write and added to
+// featGrad by the last block. Partial row per (wave, block): w1[24] b1[8] w2[64] b2[8].
+// ---------------------------------------------------------------------------------------
+#define MCCNN_F1_ROW 104
+#ifndef MCCNN_F1_OCC
+#define MCCNN_F1_OCC 2
+#endif
+__global__ __launch_bounds__(256, MCCNN_F1_OCC) void f1_bwd_edges(ConvArgs a, const float4* __restrict__ rec,
+                                                       const float* __restrict__ G, const float* __restrict__ gb,
+                                                       float* __restrict__ featGrad, float* __restrict__ dfE, int cpw,
+                                                       float* __restrict__ partials) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
+    const int rowA = a.nb * 8;
+    float* wl = lds;
+    stage_weights<MCCNN_WQ_BWD>(a, wl);
+    __syncthreads();
+    const int waveGlobal = blockIdx.x * 4 + wave;
+    const long long eBegL = (long long)waveGlobal * cpw * 64;
+    if (eBegL >= a.e) return;
+    const int eBeg = (int)eBegL;
+    const int eEnd = (int)min((long long)a.e, eBegL + (long long)cpw * 64);
+    float* prow = partials + (size_t)waveGlobal * a.nb * MCCNN_F1_ROW;
+
+    for (int q = 0; q < a.nb; ++q) {
+        float gw2[64], gb2[8], gw1[24], gb1[8];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) gw2[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { gb2[k] = 0.f; gb1[k] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 24; ++k) gw1[k] = 0.f;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        const bool last = (q == a.nb - 1);
+
+        int2 prN;
+        float4 rcN;
+        {
+            int t0 = min(eBeg + lane, a.e - 1);
+            prN = a.packed[t0];
+            rcN = rec[t0];
+        }
+        for (int base = eBeg; base < eEnd; base += 64) {
+            const int t = base + lane;
+            const bool act = t < eEnd;
+            const int2 pr = prN;
+            const float4 rc = rcN;
+            const int j = pr.x, ci = pr.y;
+            const float inv = act ? rc.w : 0.f;
+            const float4* gp = reinterpret_cast<const float4*>(G + (size_t)ci * rowA + q * 8);
+            const float4 g0 = gp[0], g1 = gp[1];
+            const float f = a.feats[j];
+            float dfOld = 0.f, gbi = 0.f;
+            if (act && q > 0) dfOld = dfE[t];
+            if (last) gbi = gb[ci];
+            {
+                int tn = min(t + 64, a.e - 1);  // clamped: branch-free prefetch of the next chunk
+                prN = a.packed[tn];
+                rcN = rec[tn];
+            }
+            const float Gq[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float s = f * inv;
+            float a1[8], a2[8];
+            bool p1[8], p2[8];  // pre-activation >= 0 (ReLU' of the reference: spatial_conv.cu:404,429)
+            int woff = q * MCCNN_WQ_BWD;
+            asm volatile("" : "+s"(woff));  // keep the LDS weight reads inside the chunk loop (see conv_bwd_mfma)
+            const float* wq = wl + woff;
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(wq);
+            {
+                float pre1[8], pre2[8];
+                mlp_block_l12(wq, i4, rc.x, rc.y, rc.z, pre1, a1, pre2, a2);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { p1[k] = pre1[k] >= 0.0f; p2[k] = pre2[k] >= 0.0f; }
+            }
+            // feature gradient: (sum_q G_i[q] . a2_e[q] + g_i . b3) / (pdf K)
+            float sfg = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sfg = fmaf(Gq[k], a2[k], sfg);
+            if (act) {
+                if (last) atomicAdd(&featGrad[j], (dfOld + sfg + gbi) * inv);
+                else dfE[t] = dfOld + sfg;
+            }
+            // t3 = 1[pre2 >= 0] * G_i s_e ; dW2 += t3 a1^T, db2 += t3
+            float t3[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t3[k] = p2[k] ? Gq[k] * s : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int l = 0; l < 8; ++l) gw2[k * 8 + l] = fmaf(t3[k], a1[l], gw2[k * 8 + l]);
+                gb2[k] += t3[k];
+            }
+            // t4 = 1[pre1 >= 0] * W2^T t3 ; dW1 += t4 delta^T, db1 += t4
+            float t4[8];
+            MCCNN_PHASE();
+            layer8(w4 + 46, zero4, zero4, i4, t3, t4);  // W2^T rows at float 184 -> f32x4 index 46
+            MCCNN_PHASE();
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                float v = p1[l] ? t4[l] : 0.f;
+                gw1[l * 3] = fmaf(v, rc.x, gw1[l * 3]);
+                gw1[l * 3 + 1] = fmaf(v, rc.y, gw1[l * 3 + 1]);
+                gw1[l * 3 + 2] = fmaf(v, rc.z, gw1[l * 3 + 2]);
+                gb1[l] += v;
+            }
+        }
+        {
+            float r2 = wave_reduce64(gw2, lane);
+            float misc[64];
+#pragma unroll
+            for (int k = 0; k < 24; ++k) misc[k] = gw1[k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { misc[24 + k] = gb1[k]; misc[32 + k] = gb2[k]; }
+#pragma unroll
+            for (int k = 40; k < 64; ++k) misc[k] = 0.f;
+            float rm = wave_reduce64(misc, lane);
+            float* pq = prow + q * MCCNN_F1_ROW;
+            pq[32 + lane] = r2;
+            if (lane < 32) pq[lane] = rm;                 // w1, b1
+            else if (lane < 40) pq[96 + lane - 32] = rm;  // b2
+        }
+    }
+}
+
+// Backward, centre pass (runs before the edge pass): G_i[q] = W3_q^T g_i[q] and gb_i = g_i . b3 for the edges, and the
+// layer-3 gradients dW3 = sum_i g_i (x) A_i, db3 = sum_i g_i S_i. Waves own slices of centres, q-outer with the 72 sums
+// of a block in registers; partial row per (wave, block): w3[64] b3[8].
+#define MCCNN_F1_ROWC 72
+__global__ __launch_bounds__(256) void f1_bwd_centres(ConvArgs a, const float* __restrict__ outGrad,
+                                                      const float* __restrict__ A, const float* __restrict__ S,
+                                                      int cPerWave, float* __restrict__ G, float* __restrict__ gb,
+                                                      float* __restrict__ partials) {
+    extern __shared__ float lds[];  // per block: W3[8][8], b3[8]
+    for (int t = threadIdx.x; t < a.nb * 72; t += blockDim.x) {
+        int q = t / 72, r = t - q * 72;
+        lds[t] = (r < 64) ? a.w3[q * 64 + r] : a.b3[q * 8 + r - 64];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + wave;
+    const int c0 = w * cPerWave;
+    if (c0 >= a.m) return;
+    const int c1 = min(a.m, c0 + cPerWave);
+    const int rowA = a.nb * 8;
+    const bool vec = (a.outF & 3) == 0;
+    float* prow = partials + (size_t)w * a.nb * MCCNN_F1_ROWC;
+    for (int q = 0; q < a.nb; ++q) {
+        float acc[64], accb[8];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) accb[k] = 0.f;
+        const float* wq = lds + q * 72;
+        for (int i = c0 + lane; i < c1; i += 64) {
+            const float* grow = outGrad + (size_t)i * a.outF + q * 8;
+            float g[8];
+            if (vec && q * 8 + 8 <= a.outF) {
+                const float4 g0 = reinterpret_cast<const float4*>(grow)[0], g1 = reinterpret_cast<const float4*>(grow)[1];
+                g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+            } else {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) g[n] = (q * 8 + n < a.outF) ? grow[n] : 0.f;
+            }
+            const float4* ap = reinterpret_cast<const float4*>(A + (size_t)i * rowA + q * 8);
+            const float4 x0 = ap[0], x1 = ap[1];
+            const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            const float Si = S[i];
+            float gbv = (q == 0) ? 0.f : gb[i];
+            float Gk[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) Gk[k] = 0.f;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    acc[n * 8 + k] = fmaf(g[n], x[k], acc[n * 8 + k]);
+                    Gk[k] = fmaf(wq[n * 8 + k], g[n], Gk[k]);
+                }
+                accb[n] = fmaf(g[n], Si, accb[n]);
+                gbv = fmaf(g[n], wq[64 + n], gbv);
+            }
+            gb[i] = gbv;
+            float4* dst = reinterpret_cast<float4*>(G + (size_t)i * rowA + q * 8);
+            dst[0] = make_float4(Gk[0], Gk[1], Gk[2], Gk[3]);
+            dst[1] = make_float4(Gk[4], Gk[5], Gk[6], Gk[7]);
+        }
+        float r3 = wave_reduce64(acc, lane);
+        float misc[64];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) misc[k] = accb[k];
+#pragma unroll
+        for (int k = 8; k < 64; ++k) misc[k] = 0.f;
+        float rb = wave_reduce64(misc, lane);
+        float* pq = prow + q * MCCNN_F1_ROWC;
+        pq[lane] = r3;
+        if (lane < 8) pq[64 + lane] = rb;
+    }
+}
+
+// Sums the partial rows of both passes in a fixed order (deterministic parameter gradients, no float atomics).
+__global__ __launch_bounds__(256) void f1_reduce(const float* __restrict__ pe, int rowsE, const float* __restrict__ pc,
+                                                 int rowsC, int nb, float* __restrict__ dw1, float* __restrict__ db1,
+                                                 float* __restrict__ dw2, float* __restrict__ db2,
+                                                 float* __restrict__ dw3, float* __restrict__ db3) {
+    __shared__ float acc[16][17];
+    const int K = nb * 176;
+    const int kk = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + kk;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int q = 0, r = 0;
+    if (k < K) {
+        q = k / 176;
+        r = k - q * 176;
+        const bool fromE = r < MCCNN_F1_ROW;
+        const float* src = fromE ? pe + q * MCCNN_F1_ROW + r : pc + q * MCCNN_F1_ROWC + (r - MCCNN_F1_ROW);
+        const size_t stride = (size_t)nb * (fromE ? MCCNN_F1_ROW : MCCNN_F1_ROWC);
+        const int rows = fromE ? rowsE : rowsC;
+        int w = sl;
+        for (; w + 48 < rows; w += 64) {
+            s0 += src[(size_t)w * stride];
+            s1 += src[(size_t)(w + 16) * stride];
+            s2 += src[(size_t)(w + 32) * stride];
+            s3 += src[(size_t)(w + 48) * stride];
+        }
+        for (; w < rows; w += 16) s0 += src[(size_t)w * stride];
+    }
+    acc[sl][kk] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && k < K) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += acc[i][kk];
+        if (r < 24) dw1[q * 24 + r] = v;
+        else if (r < 32) db1[q * 8 + r - 24] = v;
+        else if (r < 96) dw2[q * 64 + r - 32] = v;
+        else if (r < 104) db2[q * 8 + r - 96] = v;
+        else if (r < 168) dw3[q * 64 + r - 104] = v;
+        else db3[q * 8 + r - 168] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------ host side
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    }
+    return n;
+}
+
+static void f1_bwd_partition(int e, int& cpw, int& waves) {
+    const long long chunks = ((long long)e + 63) / 64;
+    const long long target = (long long)num_cus() * 4 * MCCNN_F1_OCC;  // resident waves per SIMD
+    cpw = (int)((chunks + target - 1) / target);
+    if (cpw < 8) cpw = 8;  // amortises the per-(wave, block) reduction
+    waves = (int)((chunks + cpw - 1) / cpw);
+    if (waves < 1) waves = 1;
+}
+static void f1_centre_partition(int m, int& cPerWave, int& waves) {
+    cPerWave = (m + 1023) / 1024;
+    cPerWave = (cPerWave + 63) / 64 * 64;
+    waves = (m + cPerWave - 1) / cPerWave;
+}
+
+size_t f1_state_bytes(int m, int nb) { return align_up((size_t)m * nb * 8 * sizeof(float)) + align_up((size_t)m * sizeof(float)); }
+
+static void f1_state_split(void* state, int m, int nb, float*& A, float*& S) {
+    A = (float*)state;
+    S = (float*)((char*)state + align_up((size_t)m * nb * 8 * sizeof(float)));
+}
+
+static int f1_run_edges(const ConvArgs& a, float* A, float* S, hipStream_t s) {
+    const size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * (size_t)a.nb * 8) * sizeof(float);
+    int perCU = 0;
+    MCCNN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, reinterpret_cast<const void*>(f1_fwd_edges), 256, lds));
+    if (perCU < 1) perCU = 1;
+    const long long chunks = ((long long)a.e + 63) / 64;
+    long long W = (long long)num_cus() * perCU * 4;
+    if (W > (chunks + 1) / 2) W = (chunks + 1) / 2;
+    if (W < 1) W = 1;
+    f1_fwd_edges<<<(int)((W + 3) / 4), 256, lds, s>>>(a, A, S, (int)W);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+size_t f1_fwd_workspace_bytes(int m, int nb) { return f1_state_bytes(m, nb) + 256; }
+
+int f1_forward(const ConvArgs& a, float* out, void* state, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!state) {
+        if (!ws || ws_bytes < f1_fwd_workspace_bytes(a.m, a.nb)) return MCCNN_E_WORKSPACE;
+        state = ws;
+    }
+    float *A, *S;
+    f1_state_split(state, a.m, a.nb, A, S);
+    int rc = f1_run_edges(a, A, S, s);
+    if (rc) return rc;
+    f1_fwd_centres<<<ceil_div((long long)a.m * a.nb, 256), 256, (size_t)a.nb * 72 * sizeof(float), s>>>(a, A, S, out);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+size_t f1_bwd_workspace_bytes(int m, int e, int nb) {
+    int cpw, wavesE, cpwC, wavesC;
+    f1_bwd_partition(e, cpw, wavesE);
+    f1_centre_partition(m, cpwC, wavesC);
+    size_t b = f1_state_bytes(m, nb);                                               // (A, S) when the caller kept no state
+    b += align_up((size_t)m * nb * 8 * sizeof(float)) + align_up((size_t)m * sizeof(float));  // G, gb
+    b += align_up((size_t)e * sizeof(float4)) + align_up((size_t)e * sizeof(float));          // records, per-edge dFeat
+    b += align_up((size_t)(wavesE + 3) / 4 * 4 * nb * MCCNN_F1_ROW * sizeof(float));
+    b += align_up((size_t)(wavesC + 3) / 4 * 4 * nb * MCCNN_F1_ROWC * sizeof(float));
+    return b + 256;
+}
+
+// feat_grad must be zero on entry (the edge pass adds to it); the six parameter gradients are fully written.
+int f1_backward(const ConvArgs& a, const float* out_grad, const void* state, float* feat_grad, float* dw1, float* db1,
+                float* dw2, float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!ws || ws_bytes < f1_bwd_workspace_bytes(a.m, a.e, a.nb)) return MCCNN_E_WORKSPACE;
+    int cpw, wavesE, cPerWave, wavesC;
+    f1_bwd_partition(a.e, cpw, wavesE);
+    f1_centre_partition(a.m, cPerWave, wavesC);
+    const int blocksE = (wavesE + 3) / 4, blocksC = (wavesC + 3) / 4;
+    Arena ar(ws, ws_bytes);
+    void* own = ar.take<char>(f1_state_bytes(a.m, a.nb));
+    float* G = ar.take<float>((size_t)a.m * a.nb * 8);
+    float* gb = ar.take<float>((size_t)a.m);
+    float4* rec = ar.take<float4>((size_t)a.e);
+    float* dfE = ar.take<float>((size_t)a.e);
+    float* pe = ar.take<float>((size_t)blocksE * 4 * a.nb * MCCNN_F1_ROW);
+    float* pc = ar.take<float>((size_t)blocksC * 4 * a.nb * MCCNN_F1_ROWC);
+    if (!own || !G || !gb || !rec || !dfE || !pe || !pc) return MCCNN_E_WORKSPACE;
+    float *A, *S;
+    if (state) {
+        f1_state_split(const_cast<void*>(state), a.m, a.nb, A, S);
+    } else {
+        f1_state_split(own, a.m, a.nb, A, S);
+        int rc = f1_run_edges(a, A, S, s);
+        if (rc) return rc;
+    }
+    const size_t ldsC = (size_t)a.nb * 72 * sizeof(float);
+    f1_bwd_centres<<<blocksC, 256, ldsC, s>>>(a, out_grad, A, S, cPerWave, G, gb, pc);
+    MCCNN_LAUNCHED();
+    f1_edge_records<<<ceil_div(a.e, 256), 256, 0, s>>>(a, rec);
+    MCCNN_LAUNCHED();
+    const size_t ldsE = (size_t)a.nb * MCCNN_WQ_BWD * sizeof(float);
+    f1_bwd_edges<<<blocksE, 256, ldsE, s>>>(a, rec, G, gb, feat_grad, dfE, cpw, pe);
+    MCCNN_LAUNCHED();
+    f1_reduce<<<ceil_div((long long)a.nb * 176, 16), 256, 0, s>>>(pe, wavesE, pc, wavesC, a.nb, dw1, db1, dw2, db2, dw3, db3);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+}  // namespace mccnn

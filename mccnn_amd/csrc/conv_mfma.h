@@ -1,0 +1,220 @@
+// Shared device helpers of the MFMA convolution kernels (conv.hip, conv_f1.hip): argument block, the 4x4x1 MFMA form
+// of the 8x8 kernel-MLP layers, scheduling phases, fused-DPP segmented scan, slice search, transposing butterfly.
+#pragma once
+#include "common.h"
+
+namespace mccnn {
+
+struct ConvArgs {
+    const float* pts;
+    const float* feats;
+    const int* bids;
+    const float* pdfs;
+    const float* samples;
+    const int* start;
+    const int2* packed;
+    const float* mn;
+    const float* mx;
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+    int n, m, e, Fin, Fout, nb, neuronsOut, outF;
+    float radius, invRadius;
+    int scaleInv, avg, G;
+};
+
+// ---------------------------------------------------------------------------------------
+// MFMA kernels (nb <= MCCNN_LDS_MAX_NB).
+//
+// v_mfma_f32_4x4x1_16b_f32 computes 16 independent 4x4 rank-1 updates per wave:
+//     D[lane 4b+j][reg r] += A(lane 4b+r) * B(lane 4b+j)          (layout probed on gfx950, profiles/)
+// With lane = edge and reg = neuron this is exactly one k-step of an 8x8 block of the kernel MLP
+// for 64 edges at once and with ZERO block-diagonal waste (a 16x16x4 tiling wastes half of every
+// MFMA on the off-diagonal zeros): A = the weight W[r][k] (same for every quad), B = the lane's
+// own activation h[k]. Two accumulators (neurons 0-3 / 4-7) x 8 k-steps = 16 MFMAs per layer, the
+// accumulator is initialised with the bias straight from LDS, numerics == the fmaf chain of v1.
+// The transposed products of the backward pass (t3 = W3^T (g f), t4 = W2^T t3) use the same form
+// with the transposed weight copies staged in LDS.
+// ---------------------------------------------------------------------------------------
+#define MCCNN_LDS_MAX_NB 64
+// floats per MLP block in LDS: W1[8][4] b1[8] W2[8][8] b2[8] W3[8][8] b3[8] (+ W2^T[8][8] W3^T[8][8] for bwd)
+#define MCCNN_WQ_FWD 184
+#define MCCNN_WQ_BWD 312
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_SHL(n) (0x100 + (n))
+
+// MFMA and VALU instructions of one wave are kept in separate PHASES: tools/issue_probe.hip shows that a wave
+// alternating between the two pays ~7 extra cycles per switch (8 mfma + 16 fma cost 163 cycles interleaved, 108
+// grouped = the sum of the parts), and the scheduler's default is to interleave. SALU and memory ops may cross.
+#ifndef MCCNN_NO_PHASES
+#define MCCNN_PHASE() __builtin_amdgcn_sched_barrier(0x4 | 0x10 | 0x80)
+#else
+#define MCCNN_PHASE()
+#endif
+
+// max(x, 0) as ONE instruction: v_med3_f32(x, 0, +inf). fmaxf() costs an extra canonicalising v_max on MFMA results,
+// and med3 with a literal +inf is folded back into that pair -- so the +inf goes through an opaque SGPR.
+__device__ __forceinline__ float relu1(float x) {
+    float inf = __builtin_huge_valf();
+    asm("" : "+s"(inf));
+    return __builtin_amdgcn_fmed3f(x, 0.0f, inf);
+}
+
+// Stage the MLP tensors of all nb blocks into LDS in the per-block layout above.
+template <int WQ>
+__device__ __forceinline__ void stage_weights(const ConvArgs& a, float* wl) {
+    for (int t = threadIdx.x; t < a.nb * WQ; t += blockDim.x) {
+        int q = t / WQ, r = t - q * WQ;
+        float v;
+        if (r < 32) { int row = r >> 2, c = r & 3; v = (c < 3) ? a.w1[(q * 8 + row) * 3 + c] : 0.0f; }
+        else if (r < 40) v = a.b1[q * 8 + r - 32];
+        else if (r < 104) v = a.w2[q * 64 + r - 40];
+        else if (r < 112) v = a.b2[q * 8 + r - 104];
+        else if (r < 176) v = a.w3[q * 64 + r - 112];
+        else if (r < 184) v = a.b3[q * 8 + r - 176];
+        else if (r < 248) { int k = r - 184; v = a.w2[q * 64 + (k & 7) * 8 + (k >> 3)]; }   // W2^T[l][m] = W2[m][l]
+        else { int k = r - 248; v = a.w3[q * 64 + (k & 7) * 8 + (k >> 3)]; }                  // W3^T[m][n] = W3[n][m]
+        wl[t] = v;
+    }
+}
+
+// One 8x8 layer for 64 edges: y = bias + W x, rows i4 / 4+i4 of W supplied by this lane. Two interleaved
+// accumulation chains (neurons 0-3 / 4-7); splitting K into more independent chains was measured slower
+// (tools/issue_probe.hip: a single dependent 4x4x1 chain already issues every ~15 cycles and is hidden from 2 waves
+// per SIMD up).
+__device__ __forceinline__ void layer8(const f32x4* __restrict__ wrows /* 16 x f32x4: row r at [2r],[2r+1] */,
+                                       f32x4 lo, f32x4 hi, int i4, const float* x, float* y) {
+    f32x4 al0 = wrows[2 * i4], al1 = wrows[2 * i4 + 1];
+    f32x4 ah0 = wrows[2 * (4 + i4)], ah1 = wrows[2 * (4 + i4) + 1];
+    float al[8] = {al0.x, al0.y, al0.z, al0.w, al1.x, al1.y, al1.z, al1.w};
+    float ah[8] = {ah0.x, ah0.y, ah0.z, ah0.w, ah1.x, ah1.y, ah1.z, ah1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        lo = MFMA4(al[k], x[k], lo);
+        hi = MFMA4(ah[k], x[k], hi);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { y[r] = lo[r]; y[4 + r] = hi[r]; }
+}
+
+// Kernel MLP of block q (weights at wq in LDS) for the 64 edges of a wave.
+// a1 = relu(pre1), a2 = relu(pre2) are returned because backward needs them.
+__device__ __forceinline__ void mlp_block_mfma(const float* __restrict__ wq, int i4, float d0, float d1, float d2,
+                                               float* pre1, float* a1, float* pre2, float* a2, float* o) {
+    const f32x4* w = reinterpret_cast<const f32x4*>(wq);
+    f32x4 a1lo = w[i4], a1hi = w[4 + i4];
+    f32x4 lo = w[8], hi = w[9];  // b1
+    lo = MFMA4(a1lo.x, d0, lo);
+    hi = MFMA4(a1hi.x, d0, hi);
+    lo = MFMA4(a1lo.y, d1, lo);
+    hi = MFMA4(a1hi.y, d1, hi);
+    lo = MFMA4(a1lo.z, d2, lo);
+    hi = MFMA4(a1hi.z, d2, hi);
+    MCCNN_PHASE();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pre1[r] = lo[r]; pre1[4 + r] = hi[r]; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a1[r] = relu1(pre1[r]);
+    MCCNN_PHASE();
+    layer8(w + 10, w[26], w[27], i4, a1, pre2);  // W2, b2
+    MCCNN_PHASE();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a2[r] = relu1(pre2[r]);
+    MCCNN_PHASE();
+    layer8(w + 28, w[44], w[45], i4, a2, o);     // W3, b3
+    MCCNN_PHASE();
+}
+
+// smallest c in [0, m] with S(c) >= t, S(c) = start[c] (c < m), S(m) = e. 64-ary: three dependent loads for m < 2^18.
+__device__ __forceinline__ int wave_lower_bound(const int* __restrict__ start, int m, int e, int t, int lane) {
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        const int span = hi - lo;
+        const int step = (span + 63) >> 6;
+        const int p = min(lo + lane * step, hi);
+        const int v = (p < m) ? start[p] : e;
+        const unsigned long long b = __ballot(v >= t);
+        const int f = b ? (int)__builtin_ctzll(b) : 64;
+        const int nlo = (f == 0) ? lo : min(lo + (f - 1) * step, hi) + 1;
+        const int nhi = (f == 0) ? lo : ((f == 64) ? hi : min(lo + f * step, hi));
+        lo = nlo;
+        hi = nhi;
+    }
+    return lo;
+}
+
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_rows_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_rows_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xf, false);
+}
+
+// Segmented inclusive scan of 8 values over the 64 lanes: v += m_step * v[lane - step]. The DPP read is folded
+// into the multiply-add (v_fmac_f32_dpp) -- from C++ the compiler emits v_mov_b32_dpp + v_fma (VOP3 cannot carry
+// DPP) -- and the 8 values advance in lock step, so an instruction never reads a register written less than 8
+// instructions earlier (the VALU-write -> DPP-read hazard needs 2 wait states; inline asm gets no automatic nops).
+#define MCCNN_SCAN_STEP(CTRL, M)                                                         \
+    "v_fmac_f32_dpp %0, %0, %" #M " " CTRL "\n v_fmac_f32_dpp %1, %1, %" #M " " CTRL "\n" \
+    "v_fmac_f32_dpp %2, %2, %" #M " " CTRL "\n v_fmac_f32_dpp %3, %3, %" #M " " CTRL "\n" \
+    "v_fmac_f32_dpp %4, %4, %" #M " " CTRL "\n v_fmac_f32_dpp %5, %5, %" #M " " CTRL "\n" \
+    "v_fmac_f32_dpp %6, %6, %" #M " " CTRL "\n v_fmac_f32_dpp %7, %7, %" #M " " CTRL "\n"
+__device__ __forceinline__ void wave_seg_scan8(float* c, float m1, float m2, float m4, float m8, float mA, float mB) {
+    asm("s_nop 1\n"
+        MCCNN_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1", 8)
+        MCCNN_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1", 9)
+        MCCNN_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1", 10)
+        MCCNN_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1", 11)
+        MCCNN_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf", 12)
+        MCCNN_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf", 13)
+        "s_nop 1\n"
+        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7])
+        : "v"(m1), "v"(m2), "v"(m4), "v"(m8), "v"(mA), "v"(mB));
+}
+
+// Transposing butterfly: 64 per-lane values -> lane l ends with sum over all lanes of v[l].
+// 63 exchanges instead of the 64 x 6 of a per-value wave_sum. (Template recursion keeps every index static:
+// a runtime-indexed register array would be demoted to scratch.)
+template <int S>
+__device__ __forceinline__ void butterfly_step(float* v, int lane) {
+    const bool upper = (lane & S) != 0;
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        float send = upper ? v[k] : v[k + S];
+        float keep = upper ? v[k + S] : v[k];
+        v[k] = keep + __shfl_xor(send, S, 64);
+    }
+}
+__device__ __forceinline__ float wave_reduce64(float* v, int lane) {
+    butterfly_step<32>(v, lane);
+    butterfly_step<16>(v, lane);
+    butterfly_step<8>(v, lane);
+    butterfly_step<4>(v, lane);
+    butterfly_step<2>(v, lane);
+    butterfly_step<1>(v, lane);
+    return v[0];
+}
+
+// conv_f1.hip: combin layers with one input feature (layer 3 factored out of the edge sum)
+size_t f1_state_bytes(int m, int nb);
+size_t f1_fwd_workspace_bytes(int m, int nb);
+size_t f1_bwd_workspace_bytes(int m, int e, int nb);
+int f1_forward(const ConvArgs& a, float* out, void* state, void* ws, size_t ws_bytes, hipStream_t s);
+int f1_backward(const ConvArgs& a, const float* out_grad, const void* state, float* feat_grad, float* dw1, float* db1,
+                float* dw2, float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes, hipStream_t s);
+
+}  // namespace mccnn

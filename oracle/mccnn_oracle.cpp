@@ -454,7 +454,10 @@ int orc_spatial_conv_bwd(const float* pts, const float* feats, const int* bids, 
     int nthr = 1;
 #endif
     size_t wsz = 3 * nn + nn + MLP * nn + nn + MLP * nn + nn;
-    std::vector<float> priv((size_t)nthr * wsz, 0.0f);
+    // The reference sums the parameter gradients with float atomics in arrival order (spatial_conv.cu:399-444): the
+    // result carries an order-dependent rounding error of ~1e-4 relative on large neighbour lists. The oracle keeps
+    // the reference's float products and adds them in double, so that it is the order-independent target.
+    std::vector<double> priv((size_t)nthr * wsz, 0.0);
 
 #pragma omp parallel
     {
@@ -463,12 +466,12 @@ int orc_spatial_conv_bwd(const float* pts, const float* feats, const int* bids, 
 #else
         int tid = 0;
 #endif
-        float* pw1 = &priv[(size_t)tid * wsz];
-        float* pb1 = pw1 + 3 * nn;
-        float* pw2 = pb1 + nn;
-        float* pb2 = pw2 + MLP * nn;
-        float* pw3 = pb2 + nn;
-        float* pb3 = pw3 + MLP * nn;
+        double* pw1 = &priv[(size_t)tid * wsz];
+        double* pb1 = pw1 + 3 * nn;
+        double* pw2 = pb1 + nn;
+        double* pb2 = pw2 + MLP * nn;
+        double* pw3 = pb2 + nn;
+        double* pb3 = pw3 + MLP * nn;
 #pragma omp for schedule(dynamic, 64)
         for (int i = 0; i < m; ++i) {
             int e0 = startIdx[i];
@@ -542,19 +545,22 @@ int orc_spatial_conv_bwd(const float* pts, const float* feats, const int* bids, 
             }
         }
     }
-    for (int t = 0; t < nthr; ++t) {
-        const float* p = &priv[(size_t)t * wsz];
-        for (size_t k = 0; k < 3 * nn; ++k) dw1[k] += p[k];
+    std::vector<double> tot(wsz, 0.0);
+    for (int t = 0; t < nthr; ++t)
+        for (size_t k = 0; k < wsz; ++k) tot[k] += priv[(size_t)t * wsz + k];
+    {
+        const double* p = tot.data();
+        for (size_t k = 0; k < 3 * nn; ++k) dw1[k] = (float)p[k];
         p += 3 * nn;
-        for (size_t k = 0; k < nn; ++k) db1[k] += p[k];
+        for (size_t k = 0; k < nn; ++k) db1[k] = (float)p[k];
         p += nn;
-        for (size_t k = 0; k < MLP * nn; ++k) dw2[k] += p[k];
+        for (size_t k = 0; k < MLP * nn; ++k) dw2[k] = (float)p[k];
         p += MLP * nn;
-        for (size_t k = 0; k < nn; ++k) db2[k] += p[k];
+        for (size_t k = 0; k < nn; ++k) db2[k] = (float)p[k];
         p += nn;
-        for (size_t k = 0; k < MLP * nn; ++k) dw3[k] += p[k];
+        for (size_t k = 0; k < MLP * nn; ++k) dw3[k] = (float)p[k];
         p += MLP * nn;
-        for (size_t k = 0; k < nn; ++k) db3[k] += p[k];
+        for (size_t k = 0; k < nn; ++k) db3[k] = (float)p[k];
     }
     return 0;
 }

@@ -123,14 +123,17 @@ CONV_CASES = [
     ("dw32", 32, 32, False, True, True, 0.15),
     ("dw8_noavg_abs", 8, 8, False, False, False, 0.12),
     ("2to5_combin_padded", 2, 5, True, True, True, 0.15),  # 10 neurons -> nb=2, 6 padded neurons... 16 % 2 == 0
+    ("1to13_combin_padded_noavg_abs", 1, 13, True, False, False, 0.12),  # factored Fin=1 path, 3 padded neurons
+    ("1to64_combin_nostate", 1, 64, True, True, True, 0.15),  # backward without the forward's state: recomputed
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_spatial_conv_fwd_bwd(mc, oracle, case):
     import torch
-    _, fin, fout, combin, avg, scaleInv, radius = case
+    name, fin, fout, combin, avg, scaleInv, radius = case
     B = 2
+    mc.KEEP_CONV_STATE = not name.endswith("nostate")
     pts, bids = make_cloud(1500, B, 21, "clustered", True)
     rng = np.random.default_rng(7)
     feats = (2 * rng.random((len(pts), fin)) - 1).astype(np.float32)
@@ -156,14 +159,80 @@ def test_spatial_conv_fwd_bwd(mc, oracle, case):
     assert_close(_unwrap(out), ref, RTOL, "spatial_conv")
     out.backward(_wrap(og))
     torch.cuda.synchronize()
+    mc.KEEP_CONV_STATE = True
     neurons = fin * fout if combin else fin
     got = [sF.grad, tw["w1"].grad, tw["b1"].grad, tw["w2"].grad, tw["b2"].grad, tw["w3"].grad, tw["b3"].grad]
     names = ["featGrad", "dw1", "db1", "dw2", "db2", "dw3", "db3"]
+    # ReLU' = 1[pre >= 0] is discontinuous: the MFMA fma chain and the oracle's mul/add sequence round a
+    # pre-activation differently in the last bit, so among ~1e7 (edge, neuron) evaluations a handful near zero take the
+    # other branch, and in a gradient that is a sum of cancelling signed terms (dW1 = sum t4 (x) delta) one flipped
+    # term shows at ~1e-4 relative. Parameter gradients of the 64-neuron cases are therefore compared at 5e-4 against
+    # the oracle -- and at 2e-5 against the general GPU kernels, which share the arithmetic of the pre-activations.
+    ptol = 5e-4 if (combin and fin * fout >= 64) else RTOL
     for nm, a, b in zip(names, got, rg):
-        assert_close(_unwrap(a), b, RTOL, nm)
+        assert_close(_unwrap(a), b, RTOL if nm == "featGrad" else ptol, nm)
+    if combin and fin == 1:
+        import os
+        os.environ["MCCNN_NO_F1"] = "1"  # read per call: same layer through conv_stream / conv_bwd_mfma
+        try:
+            tw2 = {k: _wrap(v).requires_grad_(True) for k, v in w.items()}
+            sF2 = h["sF"].detach().clone().requires_grad_(True)
+            out2 = mc.spatial_conv(h["sP"], sF2, h["sB"], _wrap(o["pdfs"]), h["C"], h["start"], h["packed"], h["mn"],
+                                   h["mx"], tw2["w1"], tw2["w2"], tw2["w3"], tw2["b1"], tw2["b2"], tw2["b3"], fout,
+                                   combin, B, radius, scaleInv, avg)
+            out2.backward(_wrap(og))
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["MCCNN_NO_F1"]
+        assert_close(_unwrap(out), _unwrap(out2), 2e-5, "factored vs general forward")
+        got2 = [sF2.grad, tw2["w1"].grad, tw2["b1"].grad, tw2["w2"].grad, tw2["b2"].grad, tw2["w3"].grad, tw2["b3"].grad]
+        for nm, a, b in zip(names, got, got2):
+            assert_close(_unwrap(a), _unwrap(b), 2e-5, "factored vs general " + nm)
     # padded output neurons: the library writes zeros (reference leaves them uninitialised)
     dw3 = _unwrap(tw["w3"].grad).reshape(-1)
     assert np.all(dw3[neurons * 8:] == 0)
+
+
+@pytest.mark.parametrize("fin,fout,combin", [(1, 16, True), (3, 8, True), (16, 16, False)], ids=["f1", "combin", "dw"])
+def test_conv_centres_without_neighbours(mc, oracle, fin, fout, combin):
+    """Ragged neighbour lists: centres far from every point (empty rows at the start, in the middle and at the end
+    of the list) give zero output rows and take no part in the gradients; one centre owns a very long row."""
+    import torch
+    B, radius = 1, 0.2
+    pts, bids = make_cloud(1200, B, 33, "clustered", True)
+    rng = np.random.default_rng(3)
+    feats = (2 * rng.random((len(pts), fin)) - 1).astype(np.float32)
+    far = np.array([[9.0, 9.0, 9.0]], np.float32)
+    centres = np.concatenate([far, far + 1, pts[:300], far + 2, far + 3, far + 4, pts[300:500], far + 5]).astype(np.float32)
+    cb = np.zeros((len(centres), 1), np.int32)
+    o = run_chain(oracle, _ident, _ident, pts, bids, feats, B, radius, False, centres=centres, centre_bids=cb,
+                  fout=fout, combin=combin)
+    g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, B, radius, False, centres=centres, centre_bids=cb, fout=fout,
+                  combin=combin)
+    for k in INT_KEYS:
+        assert np.array_equal(g[k], o[k]), k
+    deg = np.diff(np.append(o["startIndexs"].reshape(-1), len(o["packedNeighs"])))
+    assert (deg == 0).sum() == 6 and deg.max() > 64
+    w = o["mlp"]
+    outF = fout if combin else fin
+    og = (2 * np.random.default_rng(5).random((len(centres), outF)) - 1).astype(np.float32)
+    args = (o["sortPts"], o["sortFeatures"], o["sortBatchs"], o["pdfs"], centres, o["startIndexs"], o["packedNeighs"],
+            o["aabbMin"], o["aabbMax"], w["w1"], w["w2"], w["w3"], w["b1"], w["b2"], w["b3"])
+    ref = oracle.spatial_conv(*args, fout, combin, B, radius, False, True)
+    rg = oracle.spatial_conv_grad(*args, og, fout, combin, B, radius, False, True)
+    h = g["_handles"]
+    tw = {k: _wrap(v).requires_grad_(True) for k, v in w.items()}
+    sF = h["sF"].detach().clone().requires_grad_(True)
+    out = mc.spatial_conv(h["sP"], sF, h["sB"], _wrap(o["pdfs"]), h["C"], h["start"], h["packed"], h["mn"], h["mx"],
+                          tw["w1"], tw["w2"], tw["w3"], tw["b1"], tw["b2"], tw["b3"], fout, combin, B, radius, False, True)
+    got = _unwrap(out)
+    assert np.all(got[deg == 0] == 0)
+    assert_close(got, ref, RTOL, "spatial_conv")
+    out.backward(_wrap(og))
+    torch.cuda.synchronize()
+    gg = [sF.grad, tw["w1"].grad, tw["b1"].grad, tw["w2"].grad, tw["b2"].grad, tw["w3"].grad, tw["b3"].grad]
+    for nm, a, b in zip(["featGrad", "dw1", "db1", "dw2", "db2", "dw3", "db3"], gg, rg):
+        assert_close(_unwrap(a), b, RTOL, nm)
 
 
 def test_permutation_ops_and_adjoints(mc, oracle):
