@@ -28,7 +28,7 @@ for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), r
 if rows:
     allc = pd.concat(rows)
     piv = allc.pivot_table(index="Kernel_Name", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
-    keep = [k for k in piv.index if any(t in k for t in ("conv_", "neigh", "pdf_edges", "edge_rec", "scatter_edge", "keys_hist"))]
+    keep = [k for k in piv.index if any(t in k for t in ("conv_", "f1_", "neigh", "pdf_edges", "edge_rec", "scatter_edge", "keys_hist"))]
     pd.set_option("display.width", 250)
     pd.set_option("display.max_columns", 50)
     print("== PMC (mean per dispatch)")
@@ -40,7 +40,7 @@ if rows:
     import json
     traffic = {}
     for k in piv.index:
-        if "FETCH_SIZE" in piv.columns and "WRITE_SIZE" in piv.columns and ("conv_" in k or "neigh" in k or "pdf_edges" in k):
+        if "FETCH_SIZE" in piv.columns and "WRITE_SIZE" in piv.columns and ("conv_" in k or "f1_" in k or "neigh" in k or "pdf_edges" in k):
             f, w = piv.loc[k].get("FETCH_SIZE"), piv.loc[k].get("WRITE_SIZE")
             if f == f and w == w:
                 traffic[k] = {"fetch_bytes": float(f) * 1024 * 2, "write_bytes": float(w) * 1024,
