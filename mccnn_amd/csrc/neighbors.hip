@@ -1,6 +1,7 @@
 // Fixed-radius neighbour search over the 27-cell window and the per-edge kernel density
 // estimate. Replaces tf_ops/find_neighbors.cu and tf_ops/compute_pdf.cu.
 #include "common.h"
+#include <cstdlib>
 
 namespace mccnn {
 
@@ -27,64 +28,123 @@ __device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centre
     return c;
 }
 
-// THREE threads per centre -- one per z-slab of the 27-cell window (table entries 9*slab .. 9*slab+8, so slab order is
-// the table order of find_neighbors.cu:282-291) -- visited in `order` (identity when null). FILL == false counts per
-// (centre, slab), FILL == true writes (j, i) rows at the scanned per-slab offsets; inside a slab: table order, then
-// ascending j. One thread per centre left the chip three quarters empty at 100k centres (1.5 waves per SIMD) and
-// latency-bound; a slab per thread triples the parallelism and shortens every serial walk by three.
-// The 9 cell ranges of a slab are fetched with independent loads and the candidates of a cell 4 at a time; with a
-// cell-coherent visiting order the lanes of a wave read the same cells (broadcast loads, equal trip counts).
+// One wave per 8 consecutive centres of the visiting order (`order`, identity when null; a cell-coherent order --
+// the inverse sort permutation / argsort of the Poisson indices -- makes neighbouring centres share a cell, and never
+// changes results). Centres of one grid cell share their 27-cell window: the
+// wave stages the window's candidates ONCE in LDS (canonical order: table order of find_neighbors.cu:282-291, ascending
+// j inside a cell; the neighbour index travels in the .w lane of the padded point), then tests every centre of that
+// cell against it with lanes = candidates: conflict-free LDS reads instead of one global gather per (centre,
+// candidate) -- the per-centre walks issue 18 M float4 gathers per pass on the 100k room, the window form ~1 M -- and
+// ballot / mbcnt compaction writes the hits in canonical order without per-cell counts. Earlier forms, measured on the
+// 100k room (count + fill): one thread per centre 130 us, three threads per centre (one per z-slab) 37 + 60 us, a
+// thread per (centre, cell) 60 + 82 us, this one 31 + 37 us. FILL == false counts per centre, FILL == true writes the
+// (j, i) rows at startIdx[i].
+// Windows larger than MCCNN_NW_CAP points are processed in segments of the flat candidate list.
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+#ifndef MCCNN_NW_G
+#define MCCNN_NW_G 8
+#endif
+#ifndef MCCNN_NW_CAP
+#define MCCNN_NW_CAP 256
+#endif
 template <bool FILL>
-__global__ __launch_bounds__(256) void neigh_walk(const float* __restrict__ centres, const int* __restrict__ cb, int m,
-                                                  const float4* __restrict__ pts4, const int* __restrict__ cells,
-                                                  const float* __restrict__ mn, const float* __restrict__ mx, int nc,
-                                                  float radius, int scaleInv, const int* __restrict__ order,
-                                                  int* __restrict__ counts3, const int* __restrict__ base3,
-                                                  int* __restrict__ packed) {
-    int tix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tix >= 3 * m) return;
-    const int ci = tix / 3, slab = tix - ci * 3;
-    const int i = order ? order[ci] : ci;
+__global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ centres, const int* __restrict__ cb, int m,
+                                                    const float4* __restrict__ pts4, const int* __restrict__ cells,
+                                                    const float* __restrict__ mn, const float* __restrict__ mx, int nc,
+                                                    float radius, int scaleInv, const int* __restrict__ order,
+                                                    int* __restrict__ cnt, const int* __restrict__ startIdx,
+                                                    int* __restrict__ packed) {
+    __shared__ float4 win[4][MCCNN_NW_CAP];
+    __shared__ int2 ctab[4][32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * 4 + wave) * MCCNN_NW_G;
+    if (g0 >= m) return;
+    float4* lw = win[wave];
+    int2* tab = ctab[wave];
+    // lanes 0..7: one centre each
+    const int ci = g0 + lane;
+    const bool own = lane < MCCNN_NW_G && ci < m;
+    const int i = own ? (order ? order[ci] : ci) : 0;
     CentreCtx c = centre_ctx(centres, cb, mn, mx, i, nc, radius, scaleInv);
-    int k = 0;
-    int2* dst = FILL ? reinterpret_cast<int2*>(packed) + base3[(size_t)i * 3 + slab] : nullptr;
-    const size_t cellBase = (size_t)c.b * nc * nc * nc;
+    const int key = own ? ((c.b * nc + c.x) * nc + c.y) * nc + c.z : -1;
+    int count = 0;                                   // hits of this lane's centre so far
+    const int base = (FILL && own) ? startIdx[i] : 0;
+    unsigned todo = (unsigned)(__ballot(own) & ((1ull << MCCNN_NW_G) - 1));
     const int2* ct = reinterpret_cast<const int2*>(cells);
-    const int Z = c.z + 1 - slab;  // offsets o = 9*slab .. 9*slab+8 share dz = 1 - slab
-    int2 rng[9];
-#pragma unroll
-    for (int u = 0; u < 9; ++u) {
-        int X = c.x + 1 - (u % 3), Y = c.y + 1 - (u / 3);
-        bool ok = X >= 0 && X < nc && Y >= 0 && Y < nc && Z >= 0 && Z < nc;
-        rng[u] = ok ? ct[cellBase + (size_t)X * nc * nc + (size_t)Y * nc + Z] : make_int2(0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < 9; ++u) {
-        const int j0 = rng[u].x, j1 = rng[u].y;
-        for (int j = j0; j < j1; j += 4) {
-            float d[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                int jj = min(j + v, j1 - 1);
-                float4 p = pts4[jj];
-                d[v] = point_dist2(p.x, p.y, p.z, c.cx, c.cy, c.cz);
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                if (j + v < j1 && d[v] < c.T) {
-                    if (FILL) dst[k] = make_int2(j + v, i);
-                    ++k;
-                }
+    int2* out = reinterpret_cast<int2*>(packed);
+    while (todo) {
+        const int lead = __builtin_ctz(todo);
+        const int wkey = __builtin_amdgcn_readlane(key, lead);
+        const unsigned members = (unsigned)(__ballot(own && key == wkey)) & todo;
+        todo &= ~members;
+        // the 27 cell ranges of the window: lane o < 27 owns table entry o
+        const int wb = __builtin_amdgcn_readlane(c.b, lead), wx = __builtin_amdgcn_readlane(c.x, lead);
+        const int wy = __builtin_amdgcn_readlane(c.y, lead), wz = __builtin_amdgcn_readlane(c.z, lead);
+        int j0 = 0, len = 0;
+        if (lane < 27) {
+            const int slab = lane / 9, u = lane - slab * 9;
+            const int X = wx + 1 - (u % 3), Y = wy + 1 - (u / 3), Z = wz + 1 - slab;
+            if (X >= 0 && X < nc && Y >= 0 && Y < nc && Z >= 0 && Z < nc) {
+                const int2 r = ct[(size_t)wb * nc * nc * nc + (size_t)X * nc * nc + (size_t)Y * nc + Z];
+                j0 = r.x;
+                len = r.y - r.x;
             }
         }
+        const int off = wave_incl_scan(len) - len;   // flat offset of cell `lane` in the canonical candidate list
+        const int total = __builtin_amdgcn_readlane(off + len, 26);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 27) tab[lane] = make_int2(j0 - off, off + len);
+        __builtin_amdgcn_wave_barrier();
+        for (int seg = 0; seg < total; seg += MCCNN_NW_CAP) {
+            const int segN = min(MCCNN_NW_CAP, total - seg);
+            // stage [seg, seg + segN) of the flat list: lane = flat position; its cell is found by a 5-step binary
+            // search over the 27 cell end offsets (kept in LDS), then one load and one LDS write per position
+            for (int r = 0; r < segN; r += 64) {
+                const int f = seg + r + lane;
+                int lo = 0, hi = 26;  // smallest o with end[o] > f
+#pragma unroll
+                for (int it = 0; it < 5; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    const bool right = tab[mid].y <= f;
+                    lo = right ? mid + 1 : lo;
+                    hi = right ? hi : mid;
+                }
+                if (r + lane < segN) {
+                    const int2 tb = tab[lo];           // (j0 - off, end)
+                    float4 p = pts4[tb.x + f];
+                    p.w = __int_as_float(tb.x + f);
+                    lw[r + lane] = p;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // every centre of this cell against the staged candidates
+            unsigned mem = members;
+            while (mem) {
+                const int cl = __builtin_ctz(mem);
+                mem &= mem - 1;
+                const float cx = readlane_f(c.cx, cl), cy = readlane_f(c.cy, cl);
+                const float cz = readlane_f(c.cz, cl), T = readlane_f(c.T, cl);
+                int cbase = 0, ccount = __builtin_amdgcn_readlane(count, cl), cid = 0;
+                if (FILL) { cbase = __builtin_amdgcn_readlane(base, cl); cid = __builtin_amdgcn_readlane(i, cl); }
+                for (int r = 0; r < segN; r += 64) {
+                    const int t = r + lane;
+                    const float4 p = lw[min(t, segN - 1)];
+                    const bool hit = t < segN && point_dist2(p.x, p.y, p.z, cx, cy, cz) < T;
+                    const unsigned long long bm = __ballot(hit);
+                    if (FILL && hit) {
+                        const int pos = cbase + ccount + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+                        out[pos] = make_int2(__float_as_int(p.w), cid);
+                    }
+                    ccount += __builtin_popcountll(bm);
+                }
+                if (lane == cl) count = ccount;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    if (!FILL) counts3[(size_t)i * 3 + slab] = k;
-}
-
-// start_idx[i] = offset of centre i's first slab
-__global__ __launch_bounds__(256) void slab_to_start(const int* __restrict__ base3, int m, int* __restrict__ startIdx) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) startIdx[i] = base3[(size_t)i * 3];
+    if (!FILL && own) cnt[i] = count;
 }
 
 // [N,3] -> [N] float4: one 16-byte load per candidate instead of three 4-byte loads at a 12-byte stride
@@ -203,23 +263,23 @@ using namespace mccnn;
 extern "C" {
 
 size_t mccnn_find_neighbors_workspace_bytes(int m, int n) {
-    size_t m3 = 3 * (size_t)(m > 0 ? m : 1);
-    return align_up(m3 * 4) + scan_workspace_bytes((int)m3) + align_up((size_t)(n > 0 ? n : 1) * sizeof(float4)) + 256;
+    size_t m1 = (size_t)(m > 0 ? m : 1);
+    return align_up(m1 * 4) + scan_workspace_bytes((int)m1) + align_up((size_t)(n > 0 ? n : 1) * sizeof(float4)) + 256;
 }
 
 struct NeighWs {
-    int* counts3;  // per (centre, z-slab) hit counts, scanned in place to output offsets
+    int* cnt;  // hits per centre
     void* scanws;
-    float4* pts4;
+    float4* pts4;  // padded points: written by _count, read again by _fill
 };
 static bool neigh_ws(void* ws, size_t ws_bytes, int m, int n, NeighWs& w) {
     if (!ws || ws_bytes < mccnn_find_neighbors_workspace_bytes(m, n)) return false;
-    size_t m3 = 3 * (size_t)(m > 0 ? m : 1);
+    size_t m1 = (size_t)(m > 0 ? m : 1);
     Arena a(ws, ws_bytes);
-    w.counts3 = a.take<int>(m3);
-    w.scanws = a.take<char>(scan_workspace_bytes((int)m3));
+    w.cnt = a.take<int>(m1);
+    w.scanws = a.take<char>(scan_workspace_bytes((int)m1));
     w.pts4 = a.take<float4>((size_t)(n > 0 ? n : 1));
-    return w.counts3 && w.scanws && w.pts4;
+    return w.cnt && w.scanws && w.pts4;
 }
 
 int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
@@ -227,7 +287,6 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
                                int batch_size, int num_cells, float radius, int scale_inv, const int* centre_order,
                                int* start_idx, int* total_dev, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
     if (m < 0 || n < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
-    if ((long long)m * 3 >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     hipStream_t s = (hipStream_t)stream;
     if (m == 0) {
         MCCNN_HIP(hipMemsetAsync(total_dev, 0, sizeof(int), s));
@@ -241,14 +300,12 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
         pad_points<<<ceil_div(n, 256), 256, 0, s>>>(sorted_pts, n, w.pts4);
         MCCNN_LAUNCHED();
     }
-    neigh_walk<false><<<ceil_div(3LL * m, 256), 256, 0, s>>>(centres, centre_batch_ids, m, w.pts4, cell_indexs, aabb_min,
-                                                             aabb_max, num_cells, radius, scale_inv, centre_order,
-                                                             w.counts3, nullptr, nullptr);
+    neigh_window<false><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, w.pts4, cell_indexs, aabb_min,
+                                                                  aabb_max, num_cells, radius, scale_inv, centre_order, w.cnt,
+                                                                  nullptr, nullptr);
     MCCNN_LAUNCHED();
-    int rc = exclusive_scan_i32(w.counts3, w.counts3, 3 * m, total_dev, w.scanws, s);
+    int rc = exclusive_scan_i32(w.cnt, start_idx, m, total_dev, w.scanws, s);
     if (rc) return rc;
-    slab_to_start<<<ceil_div(m, 256), 256, 0, s>>>(w.counts3, m, start_idx);
-    MCCNN_LAUNCHED();
     return 0;
 }
 
@@ -262,12 +319,12 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     if (!centres || !centre_batch_ids || !sorted_pts || !cell_indexs || !aabb_min || !aabb_max || !start_idx || !packed)
         return MCCNN_E_BADARG;
     NeighWs w;
-    // same workspace as the count call: it holds the padded points and the scanned per-slab offsets
+    // same workspace as the count call: it holds the padded points
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    neigh_walk<true><<<ceil_div(3LL * m, 256), 256, 0, s>>>(centres, centre_batch_ids, m, w.pts4, cell_indexs, aabb_min,
-                                                            aabb_max, num_cells, radius, scale_inv, centre_order, nullptr,
-                                                            w.counts3, packed);
+    neigh_window<true><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, w.pts4, cell_indexs, aabb_min,
+                                                                 aabb_max, num_cells, radius, scale_inv, centre_order, nullptr,
+                                                                 start_idx, packed);
     MCCNN_LAUNCHED();
     return 0;
 }
