@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
     CK(mccnn_sort_step1(dP, dB, mn, mx, n, B, nc, keys, idx, ws1, wsb, s));
     float *sP = dalloc<float>(n * 3), *sF = dalloc<float>((size_t)n * Fin); int *sB = dalloc<int>(n), *cells = dalloc<int>((size_t)B * nc * nc * nc * 2);
     wsb = mccnn_sort_step2_workspace_bytes(n); void* ws2 = dalloc<char>(wsb);
-    CK(mccnn_sort_step2(dP, dB, dF, keys, idx, n, Fin, B, nc, sP, sB, sF, cells, ws2, wsb, s));
+    CK(mccnn_sort_step2(dP, dB, dF, keys, idx, n, Fin, B, nc, sP, sB, sF, cells, /*inv_idx=*/nullptr, ws2, wsb, s));
     int *start = dalloc<int>(n), *total = dalloc<int>(1);
     wsb = mccnn_find_neighbors_workspace_bytes(n, n); void* ws3 = dalloc<char>(wsb);
     CK(mccnn_find_neighbors_count(dP, dB, n, sP, n, cells, mn, mx, B, nc, radius, scaleInv, nullptr, start, total, ws3, wsb, s));

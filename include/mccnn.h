@@ -81,12 +81,14 @@ int mccnn_sort_step1(const float* pts, const int* batch_ids, const float* aabb_m
                      int* new_idx, void* ws, size_t ws_bytes, mccnn_stream_t stream);
 
 /* SortPointsStep2 -- sort_gpu.cc:40,270-378, sort_gpu.cu:192-248,473-497.
- * Applies the permutation and builds the (first,last+1) cell table; empty cell = (0,0). */
+ * Applies the permutation and builds the (first,last+1) cell table; empty cell = (0,0).
+ * inv_idx: optional [n] output, inv_idx[new_idx[i]] = i -- the cell-coherent visiting order
+ * mccnn_find_neighbors_* take as centre_order for same-level searches; may be NULL. */
 size_t mccnn_sort_step2_workspace_bytes(int n);
 int mccnn_sort_step2(const float* pts, const int* batch_ids, const float* feats, const int* keys,
                      const int* new_idx, int n, int num_feats, int batch_size, int num_cells,
-                     float* out_pts, int* out_batch_ids, float* out_feats, int* cell_indexs, void* ws,
-                     size_t ws_bytes, mccnn_stream_t stream);
+                     float* out_pts, int* out_batch_ids, float* out_feats, int* cell_indexs,
+                     int* inv_idx, void* ws, size_t ws_bytes, mccnn_stream_t stream);
 
 /* out[i,:] = in[idx[i],:], i < n_idx.  Replaces SortPointsStep2Grad (sort_gpu.cu:260),
  * SortFeaturesBack (:288) and GetSampledFeatures (poisson_sampling.cu:135). */

@@ -91,7 +91,9 @@ def _order_hint(points):
         return None
     if ent[2] is None:
         kind, payload = ent[0], ent[1]
-        if kind == "new_idx":
+        if kind == "order":
+            ent[2] = payload
+        elif kind == "new_idx":
             inv = torch.empty_like(payload)
             check(_lib.load().mccnn_invert_permutation(ptr(payload), payload.shape[0], ptr(inv), stream_handle()),
                   "invert_permutation")
@@ -228,12 +230,17 @@ class _SortPointsStep2(torch.autograd.Function):
         oF = torch.empty_like(feats)
         cells = torch.empty((batchSize, nc, nc, nc, 2), dtype=torch.int32, device=pts.device)
         ws = _ws(lib.mccnn_sort_step2_workspace_bytes(n), pts.device)
+        inv = torch.empty_like(indexs)  # visiting order for find_neighbors over these points, a by-product of the move
         check(lib.mccnn_sort_step2(ptr(pts), ptr(bids), ptr(feats), ptr(keys), ptr(indexs), n, feats.shape[1],
-                                   batchSize, nc, ptr(oP), ptr(oB), ptr(oF), ptr(cells), ptr(ws), ws.numel(),
+                                   batchSize, nc, ptr(oP), ptr(oB), ptr(oF), ptr(cells), ptr(inv), ptr(ws), ws.numel(),
                                    stream_handle()), "sort_points_step2")
         ctx.save_for_backward(indexs)
         ctx.mark_non_differentiable(oB, cells)
-        _remember_order(inPts, "new_idx", indexs)
+        # outputs nobody differentiates through (the sorted points, usually) arrive as None in backward instead of
+        # materialised zero tensors that would be permuted for nothing
+        ctx.set_materialize_grads(False)
+        ctx.needs = (inPts.requires_grad, inFeatures.requires_grad)
+        _remember_order(inPts, "order", inv)
         return oP, oB, oF, cells
 
     @staticmethod
@@ -241,8 +248,8 @@ class _SortPointsStep2(torch.autograd.Function):
         # _sort_points_step2_grad (MCConvModuleSrc:30-33): in[i] = out[index_new_pos[i]]
         (indexs,) = ctx.saved_tensors
         n = indexs.shape[0]
-        dPts = _gather_rows(_f32(gPts, "grad"), indexs, n) if gPts is not None else None
-        dFeats = _gather_rows(_f32(gFeats, "grad"), indexs, n) if gFeats is not None else None
+        dPts = _gather_rows(_f32(gPts, "grad"), indexs, n) if (gPts is not None and ctx.needs[0]) else None
+        dFeats = _gather_rows(_f32(gFeats, "grad"), indexs, n) if (gFeats is not None and ctx.needs[1]) else None
         return dPts, None, dFeats, None, None, None, None, None, None, None
 
 

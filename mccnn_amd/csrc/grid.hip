@@ -172,11 +172,19 @@ __global__ __launch_bounds__(256) void rank_in_cell(const int* __restrict__ keys
 }
 
 // ------------------------------------------------------------------ step 2
+// One launch moves points, batch ids, keys (and feature rows of up to 4 floats) to their sorted positions, clears the
+// cell table for cell_table() (sort_gpu.cu:492) and, if asked, writes the inverse permutation (the cell-coherent
+// visiting order find_neighbors wants): at 100k points each of these as a launch of its own costs ~5 us of pure
+// launch latency.
+template <int FS>  // feature floats moved here (0: separate permute_rows launch)
 __global__ __launch_bounds__(256) void move_points(const float* __restrict__ pts, const int* __restrict__ bids,
-                                                   const int* __restrict__ keys, const int* __restrict__ newIdx,
-                                                   int n, float* __restrict__ oPts, int* __restrict__ oBids,
-                                                   int* __restrict__ sKeys) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                   const float* __restrict__ feats, const int* __restrict__ keys,
+                                                   const int* __restrict__ newIdx, int n, float* __restrict__ oPts,
+                                                   int* __restrict__ oBids, float* __restrict__ oFeats,
+                                                   int* __restrict__ sKeys, int* __restrict__ inv,
+                                                   int2* __restrict__ cells, long long numCells) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long c = i; c < numCells; c += (long long)gridDim.x * blockDim.x) cells[c] = make_int2(0, 0);
     if (i >= n) return;
     int p = newIdx[i];
     oPts[(size_t)p * 3] = pts[(size_t)i * 3];
@@ -184,6 +192,9 @@ __global__ __launch_bounds__(256) void move_points(const float* __restrict__ pts
     oPts[(size_t)p * 3 + 2] = pts[(size_t)i * 3 + 2];
     oBids[p] = bids[i];
     sKeys[p] = keys[i];
+    if (inv) inv[p] = (int)i;
+#pragma unroll
+    for (int f = 0; f < FS; ++f) oFeats[(size_t)p * FS + f] = feats[(size_t)i * FS + f];
 }
 
 // save_indexs, sort_gpu.cu:225-248
@@ -336,22 +347,34 @@ size_t mccnn_sort_step2_workspace_bytes(int n) { return align_up((size_t)(n > 0 
 
 int mccnn_sort_step2(const float* pts, const int* batch_ids, const float* feats, const int* keys, const int* new_idx,
                      int n, int num_feats, int batch_size, int num_cells, float* out_pts, int* out_batch_ids,
-                     float* out_feats, int* cell_indexs, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+                     float* out_feats, int* cell_indexs, int* inv_idx, void* ws, size_t ws_bytes,
+                     mccnn_stream_t stream) {
     if (n < 0 || batch_size <= 0 || num_cells <= 0 || num_feats <= 0 || !cell_indexs) return MCCNN_E_BADARG;
     long long C = total_cells(batch_size, num_cells);
     if (C >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     hipStream_t s = (hipStream_t)stream;
-    MCCNN_HIP(hipMemsetAsync(cell_indexs, 0, (size_t)C * 2 * sizeof(int), s));  // sort_gpu.cu:492
-    if (n == 0) return 0;
+    if (n == 0) {
+        MCCNN_HIP(hipMemsetAsync(cell_indexs, 0, (size_t)C * 2 * sizeof(int), s));  // sort_gpu.cu:492
+        return 0;
+    }
     if (!pts || !batch_ids || !feats || !keys || !new_idx || !out_pts || !out_batch_ids || !out_feats)
         return MCCNN_E_BADARG;
     if (!ws || ws_bytes < mccnn_sort_step2_workspace_bytes(n)) return MCCNN_E_WORKSPACE;
     int* skeys = (int*)ws;
     int blocks = ceil_div(n, 256);
-    move_points<<<blocks, 256, 0, s>>>(pts, batch_ids, keys, new_idx, n, out_pts, out_batch_ids, skeys);
+    int2* ct = reinterpret_cast<int2*>(cell_indexs);
+    switch (num_feats <= 4 ? num_feats : 0) {
+        case 1: move_points<1><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C); break;
+        case 2: move_points<2><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C); break;
+        case 3: move_points<3><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C); break;
+        case 4: move_points<4><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C); break;
+        default: move_points<0><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C); break;
+    }
     MCCNN_LAUNCHED();
-    int rc = launch_permute<false>(feats, new_idx, n, num_feats, out_feats, s);
-    if (rc) return rc;
+    if (num_feats > 4) {
+        int rc = launch_permute<false>(feats, new_idx, n, num_feats, out_feats, s);
+        if (rc) return rc;
+    }
     cell_table<<<blocks, 256, 0, s>>>(skeys, n, cell_indexs);
     MCCNN_LAUNCHED();
     return 0;

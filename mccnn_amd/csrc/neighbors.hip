@@ -32,7 +32,7 @@ __device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centre
 // the inverse sort permutation / argsort of the Poisson indices -- makes neighbouring centres share a cell, and never
 // changes results). Centres of one grid cell share their 27-cell window: the
 // wave stages the window's candidates ONCE in LDS (canonical order: table order of find_neighbors.cu:282-291, ascending
-// j inside a cell; the neighbour index travels in the .w lane of the padded point), then tests every centre of that
+// j inside a cell; the neighbour index travels in the .w lane of the staged point), then tests every centre of that
 // cell against it with lanes = candidates: conflict-free LDS reads instead of one global gather per (centre,
 // candidate) -- the per-centre walks issue 18 M float4 gathers per pass on the 100k room, the window form ~1 M -- and
 // ballot / mbcnt compaction writes the hits in canonical order without per-cell counts. Earlier forms, measured on the
@@ -51,7 +51,7 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 #endif
 template <bool FILL>
 __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ centres, const int* __restrict__ cb, int m,
-                                                    const float4* __restrict__ pts4, const int* __restrict__ cells,
+                                                    const float* __restrict__ pts, const int* __restrict__ cells,
                                                     const float* __restrict__ mn, const float* __restrict__ mx, int nc,
                                                     float radius, int scaleInv, const int* __restrict__ order,
                                                     int* __restrict__ cnt, const int* __restrict__ startIdx,
@@ -113,9 +113,9 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                 }
                 if (r + lane < segN) {
                     const int2 tb = tab[lo];           // (j0 - off, end)
-                    float4 p = pts4[tb.x + f];
-                    p.w = __int_as_float(tb.x + f);
-                    lw[r + lane] = p;
+                    const int j = tb.x + f;
+                    const float* q = pts + (size_t)j * 3;  // 12-byte rows: one dwordx3 load
+                    lw[r + lane] = make_float4(q[0], q[1], q[2], __int_as_float(j));
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -145,12 +145,6 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
         }
     }
     if (!FILL && own) cnt[i] = count;
-}
-
-// [N,3] -> [N] float4: one 16-byte load per candidate instead of three 4-byte loads at a 12-byte stride
-__global__ __launch_bounds__(256) void pad_points(const float* __restrict__ pts, int n, float4* __restrict__ out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = make_float4(pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2], 0.f);
 }
 
 __global__ __launch_bounds__(256) void invert_perm_k(const int* __restrict__ newIdx, int n, int* __restrict__ inv) {
@@ -264,13 +258,13 @@ extern "C" {
 
 size_t mccnn_find_neighbors_workspace_bytes(int m, int n) {
     size_t m1 = (size_t)(m > 0 ? m : 1);
-    return align_up(m1 * 4) + scan_workspace_bytes((int)m1) + align_up((size_t)(n > 0 ? n : 1) * sizeof(float4)) + 256;
+    (void)n;
+    return align_up(m1 * 4) + scan_workspace_bytes((int)m1) + 256;
 }
 
 struct NeighWs {
     int* cnt;  // hits per centre
     void* scanws;
-    float4* pts4;  // padded points: written by _count, read again by _fill
 };
 static bool neigh_ws(void* ws, size_t ws_bytes, int m, int n, NeighWs& w) {
     if (!ws || ws_bytes < mccnn_find_neighbors_workspace_bytes(m, n)) return false;
@@ -278,8 +272,8 @@ static bool neigh_ws(void* ws, size_t ws_bytes, int m, int n, NeighWs& w) {
     Arena a(ws, ws_bytes);
     w.cnt = a.take<int>(m1);
     w.scanws = a.take<char>(scan_workspace_bytes((int)m1));
-    w.pts4 = a.take<float4>((size_t)(n > 0 ? n : 1));
-    return w.cnt && w.scanws && w.pts4;
+    (void)n;
+    return w.cnt && w.scanws;
 }
 
 int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
@@ -296,11 +290,7 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
         return MCCNN_E_BADARG;
     NeighWs w;
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
-    if (n > 0) {
-        pad_points<<<ceil_div(n, 256), 256, 0, s>>>(sorted_pts, n, w.pts4);
-        MCCNN_LAUNCHED();
-    }
-    neigh_window<false><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, w.pts4, cell_indexs, aabb_min,
+    neigh_window<false><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
                                                                   aabb_max, num_cells, radius, scale_inv, centre_order, w.cnt,
                                                                   nullptr, nullptr);
     MCCNN_LAUNCHED();
@@ -319,10 +309,9 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     if (!centres || !centre_batch_ids || !sorted_pts || !cell_indexs || !aabb_min || !aabb_max || !start_idx || !packed)
         return MCCNN_E_BADARG;
     NeighWs w;
-    // same workspace as the count call: it holds the padded points
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    neigh_window<true><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, w.pts4, cell_indexs, aabb_min,
+    neigh_window<true><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
                                                                  aabb_max, num_cells, radius, scale_inv, centre_order, nullptr,
                                                                  start_idx, packed);
     MCCNN_LAUNCHED();

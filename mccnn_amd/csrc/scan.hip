@@ -41,11 +41,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const int* __rest
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
-// Scans one tile per block. offsets == nullptr -> single tile (n <= SCAN_TILE).
+// Scans one tile per block. offsets == nullptr -> single tile (n <= SCAN_TILE). rawSums: `offsets` holds the
+// UNSCANNED tile sums and every block adds up the sums of the tiles before it itself (<= SCAN_TILE tiles): saves the
+// middle launch of the three-level scheme, which at 100k elements costs as much as the scan proper.
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const int* __restrict__ in, int* __restrict__ out,
                                                            int n, const int* __restrict__ offsets,
-                                                           int* __restrict__ total) {
+                                                           int* __restrict__ total, int rawSums) {
     __shared__ int lds[4];
+    int off = 0;
+    if (offsets) {
+        if (rawSums) {
+            int part = 0;
+            for (int t = threadIdx.x; t < (int)blockIdx.x; t += SCAN_THREADS) part += offsets[t];
+            block_excl_scan(part, off, lds);
+        } else {
+            off = offsets[blockIdx.x];
+        }
+    }
     long long base = (long long)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
     int s = 0;
@@ -56,7 +68,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const int* __restrict
     }
     int tot;
     int ex = block_excl_scan(s, tot, lds);
-    int off = offsets ? offsets[blockIdx.x] : 0;
     int run = ex + off;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
@@ -83,7 +94,7 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
     }
     int tiles = ceil_div(n, SCAN_TILE);
     if (tiles == 1) {
-        scan_tiles<<<1, SCAN_THREADS, 0, s>>>(in, out, n, nullptr, total);
+        scan_tiles<<<1, SCAN_THREADS, 0, s>>>(in, out, n, nullptr, total, 0);
         MCCNN_LAUNCHED();
         return 0;
     }
@@ -91,9 +102,12 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
     void* rest = (char*)ws + align_up((size_t)tiles * sizeof(int));
     scan_tile_sums<<<tiles, SCAN_THREADS, 0, s>>>(in, n, sums);
     MCCNN_LAUNCHED();
-    int rc = exclusive_scan_i32(sums, sums, tiles, nullptr, rest, s);
-    if (rc) return rc;
-    scan_tiles<<<tiles, SCAN_THREADS, 0, s>>>(in, out, n, sums, total);
+    const int raw = tiles <= SCAN_TILE ? 1 : 0;
+    if (!raw) {
+        int rc = exclusive_scan_i32(sums, sums, tiles, nullptr, rest, s);
+        if (rc) return rc;
+    }
+    scan_tiles<<<tiles, SCAN_THREADS, 0, s>>>(in, out, n, sums, total, raw);
     MCCNN_LAUNCHED();
     return 0;
 }
