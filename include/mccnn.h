@@ -122,8 +122,10 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
                                int num_cells, float radius, int scale_inv, const int* centre_order,
                                int* start_idx, int* total_dev, void* ws, size_t ws_bytes,
                                mccnn_stream_t stream);
-/* ws: the SAME workspace the count call used, untouched in between (it holds the 16-byte padded copy
- * of sorted_pts and the scanned per-slab output offsets). */
+/* e: capacity of `packed` in rows. Normally the total the count call produced; a caller that wants
+ * to launch the fill before it has read that total back (to hide the read-back behind the kernel)
+ * may pass a guess: rows beyond the capacity are simply not written, and if the total turns out
+ * larger the call is repeated with a big enough buffer. ws: the workspace of the count call. */
 int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m,
                               const float* sorted_pts, int n, const int* cell_indexs,
                               const float* aabb_min, const float* aabb_max, int batch_size,

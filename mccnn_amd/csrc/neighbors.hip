@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                                                     const float* __restrict__ mn, const float* __restrict__ mx, int nc,
                                                     float radius, int scaleInv, const int* __restrict__ order,
                                                     int* __restrict__ cnt, const int* __restrict__ startIdx,
-                                                    int* __restrict__ packed) {
+                                                    int* __restrict__ packed, int capacity) {
     __shared__ float4 win[4][MCCNN_NW_CAP];
     __shared__ int2 ctab[4][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                     const unsigned long long bm = __ballot(hit);
                     if (FILL && hit) {
                         const int pos = cbase + ccount + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
-                        out[pos] = make_int2(__float_as_int(p.w), cid);
+                        if (pos < capacity) out[pos] = make_int2(__float_as_int(p.w), cid);  // capacity < E: see _fill
                     }
                     ccount += __builtin_popcountll(bm);
                 }
@@ -292,7 +292,7 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     neigh_window<false><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
                                                                   aabb_max, num_cells, radius, scale_inv, centre_order, w.cnt,
-                                                                  nullptr, nullptr);
+                                                                  nullptr, nullptr, 0);
     MCCNN_LAUNCHED();
     int rc = exclusive_scan_i32(w.cnt, start_idx, m, total_dev, w.scanws, s);
     if (rc) return rc;
@@ -313,7 +313,7 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     hipStream_t s = (hipStream_t)stream;
     neigh_window<true><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
                                                                  aabb_max, num_cells, radius, scale_inv, centre_order, nullptr,
-                                                                 start_idx, packed);
+                                                                 start_idx, packed, e);
     MCCNN_LAUNCHED();
     return 0;
 }
