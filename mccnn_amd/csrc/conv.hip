@@ -908,9 +908,15 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
 #endif
 #define MCCNN_BWD_MIN_CHUNKS 8  // amortises the per-(wave, block) reduction of the 176 partial sums
 
+// Larger inputs get R equal rounds of resident-many waves with <= 32-chunk slices (see f1_bwd_partition): the slices in
+// flight have to stay inside the Infinity Cache, the q-outer sweep re-reads them nb times.
 static void bwd_partition(int e, int& cpw, int& waves) {
     long long chunks = ((long long)e + 63) / 64;
     cpw = (int)((chunks + MCCNN_BWD_WAVES - 1) / MCCNN_BWD_WAVES);
+    if (cpw > 48) {
+        const long long rounds = (cpw + 31) / 32;
+        cpw = (int)((chunks + (long long)MCCNN_BWD_WAVES * rounds - 1) / ((long long)MCCNN_BWD_WAVES * rounds));
+    }
     if (cpw < MCCNN_BWD_MIN_CHUNKS) cpw = MCCNN_BWD_MIN_CHUNKS;
     waves = (int)((chunks + cpw - 1) / cpw);
     if (waves < 1) waves = 1;
