@@ -13,6 +13,7 @@
 // an LDS tile: no atomics, no pre-zeroing, bit-reproducible.
 #include "conv_mfma.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace mccnn {
 
@@ -263,7 +264,17 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
         float* orow = out + (size_t)ci * outF;
 
         int finQ = 0, foQ = 0;  // (nu % Fin, nu / Fin) of the block's first neuron, kept incrementally
-        auto block = [&](const int q, const float4 fa, const float4 fb) {
+        constexpr bool smallFin = COMBIN && FEAT == 3;  // combin, 2..4 input features
+        float fs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (smallFin) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < a.Fin) fs[k] = a.feats[(size_t)j * a.Fin + k] * inv;
+        }
+        constexpr std::integral_constant<int, 1> ic1{};
+        constexpr std::integral_constant<int, 0> ic0{};
+        auto block = [&](const int q, const float4 fa, const float4 fb, auto finC, auto r0C) {
+            constexpr int FIN_ = decltype(finC)::value, R0_ = decltype(r0C)::value;
             float pre1[8], a1[8], pre2[8], a2[8], o[8], c[8];
             MCCNN_PHASE();
             mlp_block_mfma(wl + q * MCCNN_WQ_FWD, i4, d0, d1, d2, pre1, a1, pre2, a2, o);
@@ -275,13 +286,20 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
 #pragma unroll
                 for (int n = 0; n < 8; ++n) c[n] = f1 * o[n];
             } else {
-                // neuron nu = fo * Fin + fin (combin) or nu = fin (depth-wise): fin advances with nu, no division
-                int fin = finQ;
+                if (COMBIN && smallFin) {
+                    float ffn[8];
+                    combin_pick<FIN_, R0_>(fs, nullptr, ffn, nullptr);  // fs = feature row * 1/(pdf K), once per chunk
 #pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    int nu = q * 8 + n;
-                    c[n] = (nu < a.neuronsOut) ? a.feats[(size_t)j * a.Fin + fin] * o[n] * inv : 0.f;
-                    if (++fin == a.Fin) fin = 0;
+                    for (int n = 0; n < 8; ++n) c[n] = (q * 8 + n < a.neuronsOut) ? ffn[n] * o[n] : 0.f;
+                } else {
+                    // neuron nu = fo * Fin + fin (combin) or nu = fin (depth-wise): fin advances with nu, no division
+                    int fin = finQ;
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) {
+                        int nu = q * 8 + n;
+                        c[n] = (nu < a.neuronsOut) ? a.feats[(size_t)j * a.Fin + fin] * o[n] * inv : 0.f;
+                        if (++fin == a.Fin) fin = 0;
+                    }
                 }
             }
             float* cq = carry + q * 8;
@@ -335,14 +353,29 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
                 float4 fl[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) fl[k] = (k < 2 * left) ? fp[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-                block(q0, fl[0], fl[1]);
-                if (left > 1) block(q0 + 1, fl[2], fl[3]);
-                if (left > 2) block(q0 + 2, fl[4], fl[5]);
-                if (left > 3) block(q0 + 3, fl[6], fl[7]);
+                block(q0, fl[0], fl[1], ic1, ic0);
+                if (left > 1) block(q0 + 1, fl[2], fl[3], ic1, ic0);
+                if (left > 2) block(q0 + 2, fl[4], fl[5], ic1, ic0);
+                if (left > 3) block(q0 + 3, fl[6], fl[7], ic1, ic0);
             }
         } else {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int q = 0; q < a.nb; ++q) block(q, z, z);
+            if constexpr (COMBIN && FEAT == 3) {
+                // static neuron -> fin pattern: r0 = (8 q) % Fin is 0 for Fin = 2, 4 and cycles 0, 2, 1 for Fin = 3
+                if (a.Fin == 2) {
+                    for (int q = 0; q < a.nb; ++q) block(q, z, z, std::integral_constant<int, 2>{}, ic0);
+                } else if (a.Fin == 4) {
+                    for (int q = 0; q < a.nb; ++q) block(q, z, z, std::integral_constant<int, 4>{}, ic0);
+                } else {
+                    for (int q = 0; q < a.nb; q += 3) {
+                        block(q, z, z, std::integral_constant<int, 3>{}, ic0);
+                        if (q + 1 < a.nb) block(q + 1, z, z, std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+                        if (q + 2 < a.nb) block(q + 2, z, z, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+                    }
+                }
+            } else {
+                for (int q = 0; q < a.nb; ++q) block(q, z, z, ic1, ic0);
+            }
         }
         carryKey = cont ? cLast + 1 : -1;
         keyLast = cLast + 1;
@@ -415,8 +448,14 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #pragma unroll
         for (int k = 0; k < 24; ++k) gw1[k] = 0.f;
         const int numOuts = min(a.neuronsOut - q * 8, 8);
+        constexpr bool smallFin = COMBIN && FEAT == 3;  // combin, 2..4 input features
+        const int r0 = smallFin ? (q * 8) % a.Fin : 0, fo0 = smallFin ? (q * 8) / a.Fin : 0;
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+        // the chunk loop as a generic lambda: combin layers with 2..4 input features instantiate it once per static
+        // neuron -> (fin, fo) pattern (FIN_, R0_) and pick the instance once per block, outside the loop
+        auto sweep = [&](auto finC, auto r0C) {
+        constexpr int FIN_ = decltype(finC)::value, R0_ = decltype(r0C)::value;
         int2 prN;
         float4 rcN;
         {
@@ -454,6 +493,18 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
 #pragma unroll
                     for (int n = 0; n < 8; ++n) { g[n] = (act && n < numOuts) ? grow[q * 8 + n] : 0.f; ff[n] = f; }
                 }
+            } else if (COMBIN && smallFin) {
+                // 2..4 input features: the feature row and the <= 5 out-gradients this block touches are loaded once,
+                // the neuron -> (fin, fo) pattern is one of <= 4 static register selections (combin_select)
+                float fs[4], gw[5];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) fs[k] = (k < a.Fin) ? a.feats[(size_t)j * a.Fin + k] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) gw[k] = (act && fo0 + k < outF) ? grow[fo0 + k] : 0.f;
+                combin_pick<FIN_, R0_>(fs, gw, ff, g);
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    if (n >= numOuts) { g[n] = 0.f; ff[n] = 0.f; }
             } else {
 #pragma unroll
                 for (int n = 0; n < 8; ++n) {
@@ -499,6 +550,19 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
                     if (act) {
                         if (q == a.nb - 1) atomicAdd(&featGrad[j], dfOld + sfg);
                         else dfE[t] = dfOld + sfg;
+                    }
+                } else if (smallFin) {
+                    float sf[4] = {0.f, 0.f, 0.f, 0.f};
+                    combin_fold_t<FIN_, R0_>(g, o, sf);  // sf[fin] = sum over the block's neurons with that fin of g o
+                    if (act) {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) {
+                            if (f < a.Fin) {
+                                float* d = dfE + (size_t)t * a.Fin + f;
+                                const float old = (q == 0) ? 0.f : *d;  // Fin <= 4: every fin is first touched by block 0
+                                *d = old + sf[f] * inv;
+                            }
+                        }
                     }
                 } else if (act) {
                     // several neurons of a block may share fin: fold them in registers first
@@ -559,6 +623,23 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
                 gw1[l * 3 + 2] = fmaf(v, rc.z, gw1[l * 3 + 2]);
                 gb1[l] += v;
             }
+        }
+        };
+        if constexpr (smallFin) {
+            switch (a.Fin * 4 + r0) {
+                case 8: sweep(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}); break;
+                case 9: sweep(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}); break;
+                case 12: sweep(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}); break;
+                case 13: sweep(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}); break;
+                case 14: sweep(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}); break;
+                case 16: sweep(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{}); break;
+                case 17: sweep(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}); break;
+                case 18: sweep(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}); break;
+                case 19: sweep(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{}); break;
+                default: break;
+            }
+        } else {
+            sweep(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
         }
         // transposing wave reduction; partial row layout: w1[24] b1[8] w2[64] b2[8] w3[64] b3[8]
         {
@@ -820,7 +901,7 @@ static int launch_conv_stream(const ConvArgs& a, bool combin, bool vec, float* o
     typedef void (*Kern)(ConvArgs, float*, int, const float4*, const int*);
     Kern fn;
     if (TR) fn = vec ? conv_stream<false, 2, true> : conv_stream<false, 0, true>;
-    else if (combin) fn = (a.Fin == 1) ? conv_stream<true, 1, false> : conv_stream<true, 0, false>;
+    else if (combin) fn = (a.Fin == 1) ? conv_stream<true, 1, false> : (a.Fin <= 4 ? conv_stream<true, 3, false> : conv_stream<true, 0, false>);
     else fn = vec ? conv_stream<false, 2, false> : conv_stream<false, 0, false>;
     const size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * (size_t)a.nb * 8) * sizeof(float);
     static int numCU = 0;
@@ -1024,6 +1105,7 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
         int rows = coop ? blocks : waves;  // partial rows to sum
         if (combin) {
             if (a.Fin == 1) conv_bwd_mfma<true, 1, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+            else if (a.Fin <= 4) conv_bwd_mfma<true, 3, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
             else conv_bwd_mfma<true, 0, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
         } else if (coop) {
             if (vec) conv_bwd_mfma<false, 2, true><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);

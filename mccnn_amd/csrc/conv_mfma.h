@@ -209,6 +209,50 @@ __device__ __forceinline__ float wave_reduce64(float* v, int lane) {
     return v[0];
 }
 
+// Combin layers with 2..4 input features: neuron nu = fo * Fin + fin, so inside a block the feature index of neuron n
+// is (r0 + n) % Fin and its output feature fo0 + (r0 + n) / Fin with r0 = (8 q) % Fin, fo0 = (8 q) / Fin. Fin and r0 are
+// wave-uniform: one branch selects a fully static register pattern (no per-neuron gathers, no select chains).
+template <int FIN, int R0>
+__device__ __forceinline__ void combin_pick(const float* __restrict__ fs, const float* __restrict__ gw, float* ff, float* g) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        ff[n] = fs[(R0 + n) % FIN];
+        if (gw) g[n] = gw[(R0 + n) / FIN];
+    }
+}
+__device__ __forceinline__ void combin_select(int Fin, int r0, const float* fs, const float* gw, float* ff, float* g) {
+    switch (Fin * 4 + r0) {
+        case 2 * 4 + 0: combin_pick<2, 0>(fs, gw, ff, g); break;
+        case 2 * 4 + 1: combin_pick<2, 1>(fs, gw, ff, g); break;
+        case 3 * 4 + 0: combin_pick<3, 0>(fs, gw, ff, g); break;
+        case 3 * 4 + 1: combin_pick<3, 1>(fs, gw, ff, g); break;
+        case 3 * 4 + 2: combin_pick<3, 2>(fs, gw, ff, g); break;
+        case 4 * 4 + 0: combin_pick<4, 0>(fs, gw, ff, g); break;
+        case 4 * 4 + 1: combin_pick<4, 1>(fs, gw, ff, g); break;
+        case 4 * 4 + 2: combin_pick<4, 2>(fs, gw, ff, g); break;
+        default: combin_pick<4, 3>(fs, gw, ff, g); break;
+    }
+}
+
+template <int FIN, int R0>
+__device__ __forceinline__ void combin_fold_t(const float* g, const float* o, float* sf) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) sf[(R0 + n) % FIN] = fmaf(g[n], o[n], sf[(R0 + n) % FIN]);
+}
+__device__ __forceinline__ void combin_fold(int Fin, int r0, const float* g, const float* o, float* sf) {
+    switch (Fin * 4 + r0) {
+        case 2 * 4 + 0: combin_fold_t<2, 0>(g, o, sf); break;
+        case 2 * 4 + 1: combin_fold_t<2, 1>(g, o, sf); break;
+        case 3 * 4 + 0: combin_fold_t<3, 0>(g, o, sf); break;
+        case 3 * 4 + 1: combin_fold_t<3, 1>(g, o, sf); break;
+        case 3 * 4 + 2: combin_fold_t<3, 2>(g, o, sf); break;
+        case 4 * 4 + 0: combin_fold_t<4, 0>(g, o, sf); break;
+        case 4 * 4 + 1: combin_fold_t<4, 1>(g, o, sf); break;
+        case 4 * 4 + 2: combin_fold_t<4, 2>(g, o, sf); break;
+        default: combin_fold_t<4, 3>(g, o, sf); break;
+    }
+}
+
 // conv_f1.hip: combin layers with one input feature (layer 3 factored out of the edge sum)
 size_t f1_state_bytes(int m, int nb);
 size_t f1_fwd_workspace_bytes(int m, int nb);

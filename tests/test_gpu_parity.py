@@ -123,6 +123,9 @@ CONV_CASES = [
     ("dw32", 32, 32, False, True, True, 0.15),
     ("dw8_noavg_abs", 8, 8, False, False, False, 0.12),
     ("2to5_combin_padded", 2, 5, True, True, True, 0.15),  # 10 neurons -> nb=2, 6 padded neurons... 16 % 2 == 0
+    ("4to6_combin_abs", 4, 6, True, True, False, 0.12),  # static (fin, fo) patterns: Fin = 2, 3, 4 each have their own
+    ("3to11_combin_padded", 3, 11, True, True, True, 0.15),  # 33 neurons -> nb = 5, r0 cycles 0, 2, 1, 0, 2
+    ("5to3_combin_generic", 5, 3, True, True, True, 0.15),  # Fin > 4: the generic gather path
     ("1to13_combin_padded_noavg_abs", 1, 13, True, False, False, 0.12),  # factored Fin=1 path, 3 padded neurons
     ("1to64_combin_nostate", 1, 64, True, True, True, 0.15),  # backward without the forward's state: recomputed
 ]
