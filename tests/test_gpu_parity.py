@@ -124,8 +124,8 @@ CONV_CASES = [
     ("dw8_noavg_abs", 8, 8, False, False, False, 0.12),
     ("2to5_combin_padded", 2, 5, True, True, True, 0.15),  # 10 neurons -> nb=2, 6 padded neurons... 16 % 2 == 0
     ("4to6_combin_abs", 4, 6, True, True, False, 0.12),  # static (fin, fo) patterns: Fin = 2, 3, 4 each have their own
-    ("3to11_combin_padded", 3, 11, True, True, True, 0.15),  # 33 neurons -> nb = 5, r0 cycles 0, 2, 1, 0, 2
-    ("5to3_combin_generic", 5, 3, True, True, True, 0.15),  # Fin > 4: the generic gather path
+    ("3to16_combin", 3, 16, True, True, True, 0.15),  # 48 neurons -> nb = 6, r0 cycles 0, 2, 1, 0, 2, 1
+    ("8to3_combin_generic", 8, 3, True, True, True, 0.15),  # Fin > 4: the generic gather path
     ("1to13_combin_padded_noavg_abs", 1, 13, True, False, False, 0.12),  # factored Fin=1 path, 3 padded neurons
     ("1to64_combin_nostate", 1, 64, True, True, True, 0.15),  # backward without the forward's state: recomputed
 ]
@@ -167,16 +167,21 @@ def test_spatial_conv_fwd_bwd(mc, oracle, case):
     got = [sF.grad, tw["w1"].grad, tw["b1"].grad, tw["w2"].grad, tw["b2"].grad, tw["w3"].grad, tw["b3"].grad]
     names = ["featGrad", "dw1", "db1", "dw2", "db2", "dw3", "db3"]
     # ReLU' = 1[pre >= 0] is discontinuous: the MFMA fma chain and the oracle's mul/add sequence round a
-    # pre-activation differently in the last bit, so among ~1e7 (edge, neuron) evaluations a handful near zero take the
-    # other branch, and in a gradient that is a sum of cancelling signed terms (dW1 = sum t4 (x) delta) one flipped
-    # term shows at ~1e-4 relative. Parameter gradients of the 64-neuron cases are therefore compared at 5e-4 against
-    # the oracle -- and at 2e-5 against the general GPU kernels, which share the arithmetic of the pre-activations.
-    ptol = 5e-4 if (combin and fin * fout >= 64) else RTOL
+    # pre-activation differently in the last bit, so among ~1e6..1e7 (edge, neuron) evaluations a handful near zero take
+    # the other branch, and in a gradient that is a sum of cancelling signed terms (dW1 = sum t4 (x) delta) one flipped
+    # term shows at ~1e-4 relative. Parameter gradients are therefore compared at 5e-4 against the oracle -- and at 2e-5
+    # against independent GPU implementations that share the fma-chain arithmetic of the pre-activations.
+    ptol = 5e-4
     for nm, a, b in zip(names, got, rg):
         assert_close(_unwrap(a), b, RTOL if nm == "featGrad" else ptol, nm)
+    # second implementation on the GPU: the VALU fallback kernels (every shape) and, for one input feature, the general
+    # MFMA kernels instead of the factored ones -- selected per call through the environment
+    import os
+    others = [("MCCNN_FORCE_VALU", "VALU kernels")]
     if combin and fin == 1:
-        import os
-        os.environ["MCCNN_NO_F1"] = "1"  # read per call: same layer through conv_stream / conv_bwd_mfma
+        others.append(("MCCNN_NO_F1", "general MFMA kernels"))
+    for env, label in others:
+        os.environ[env] = "1"
         try:
             tw2 = {k: _wrap(v).requires_grad_(True) for k, v in w.items()}
             sF2 = h["sF"].detach().clone().requires_grad_(True)
@@ -186,11 +191,14 @@ def test_spatial_conv_fwd_bwd(mc, oracle, case):
             out2.backward(_wrap(og))
             torch.cuda.synchronize()
         finally:
-            del os.environ["MCCNN_NO_F1"]
-        assert_close(_unwrap(out), _unwrap(out2), 2e-5, "factored vs general forward")
+            del os.environ[env]
+        assert_close(_unwrap(out), _unwrap(out2), 2e-5, label + ": forward")
         got2 = [sF2.grad, tw2["w1"].grad, tw2["b1"].grad, tw2["w2"].grad, tw2["b2"].grad, tw2["w3"].grad, tw2["b3"].grad]
+        # the VALU kernels divide by R where the MFMA kernels multiply by 1/R: pre-activations differ in the last bit
+        # and the ReLU' flips described above show up again; the two MFMA paths share every pre-activation
+        gtol = 3e-4 if env == "MCCNN_FORCE_VALU" else 2e-5
         for nm, a, b in zip(names, got, got2):
-            assert_close(_unwrap(a), _unwrap(b), 2e-5, "factored vs general " + nm)
+            assert_close(_unwrap(a), _unwrap(b), 2e-5 if nm == "featGrad" else gtol, label + ": " + nm)
     # padded output neurons: the library writes zeros (reference leaves them uninitialised)
     dw3 = _unwrap(tw["w3"].grad).reshape(-1)
     assert np.all(dw3[neurons * 8:] == 0)
