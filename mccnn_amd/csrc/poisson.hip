@@ -37,6 +37,124 @@ __device__ __forceinline__ long long poisson_slot(const PoissonDims& d, int b, i
 // A thread per cell (the reference's mapping, and this repo's first version) leaves 8000 threads with long dependent
 // load chains per launch: 29 ms for a 100k-point room; this kernel: 0.9 ms for the 27 phases.
 #define MCCNN_PS_ROUNDS 12
+// Register path of poisson_phase_wave for a window of at most NR * 64 candidates. NR is a template parameter so that
+// the three loops over the rounds inside the serial walk are straight-line code: with a run-time round count every
+// own point paid ~36 scalar branches.
+template <int NR>
+__device__ __forceinline__ int poisson_cell_regs(const float* __restrict__ pts, unsigned char* sel, int2 me, int r0, int excl,
+                                                 int total, float T, int lane) {
+    float cx[NR], cy[NR], cz[NR];
+    int cj[NR];
+    bool cs[NR];
+#pragma unroll
+    for (int rd = 0; rd < NR; ++rd) {
+        const int c = rd * 64 + lane;
+        // which of the 27 ranges holds flat candidate c: largest s with excl_s <= c
+        int sidx = 0;
+#pragma unroll
+        for (int step = 16; step >= 1; step >>= 1) {
+            int tt = sidx + step;
+            int e = __shfl(excl, min(tt, 63), 64);
+            if (tt < 27 && e <= c) sidx = tt;
+        }
+        const int j = __shfl(r0, sidx, 64) + (c - __shfl(excl, sidx, 64));
+        const bool valid = c < total;
+        cj[rd] = valid ? j : -1;
+        cx[rd] = valid ? pts[(size_t)j * 3] : 0.f;
+        cy[rd] = valid ? pts[(size_t)j * 3 + 1] : 0.f;
+        cz[rd] = valid ? pts[(size_t)j * 3 + 2] : 0.f;
+        cs[rd] = valid ? (sel[j] != 0) : false;
+    }
+    // the cell's own points are candidates too (offset (0,0,0) is entry 17 of the table): their coordinates come from
+    // the register copies with v_readlane instead of n dependent global loads
+    const int ownBase = __shfl(excl, 17, 64);
+    int kept = 0;
+    for (int i = me.x; i < me.y; ++i) {
+        const int c = ownBase + (i - me.x);
+        const int src = __builtin_amdgcn_readfirstlane(c & 63), rsel = __builtin_amdgcn_readfirstlane(c >> 6);
+        float px = 0.f, py = 0.f, pz = 0.f;
+#pragma unroll
+        for (int rd = 0; rd < NR; ++rd) {
+            if (rd == rsel) {  // wave-uniform
+                px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx[rd]), src));
+                py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy[rd]), src));
+                pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz[rd]), src));
+            }
+        }
+        bool coll = false;
+#pragma unroll
+        for (int rd = 0; rd < NR; ++rd) coll |= cs[rd] && (point_dist2(cx[rd], cy[rd], cz[rd], px, py, pz) < T);
+        if (!__any(coll)) {
+            if (lane == 0) sel[i] = 1;
+            ++kept;
+#pragma unroll
+            for (int rd = 0; rd < NR; ++rd)
+                if (cj[rd] == i) cs[rd] = true;
+        }
+    }
+    return kept;
+}
+
+// Cells with at most 64 points (the normal case): the greedy walk is split into a parallel and a short serial part.
+// Lanes hold the cell's own points. (A) every point is tested against the samples selected EARLIER in the window -- they
+// cannot change while this cell is processed (27-colouring) -- by looping over the selected candidates only (ballot of
+// the selection flags, coordinates by v_readlane): a few dozen iterations without a loop-carried dependency. (B) the
+// serial walk over the own points then only has to propagate the cell's own acceptances: ~15 instructions per point
+// instead of a test against the whole window. Same decisions as the sequential reference loop.
+template <int NR>
+__device__ __forceinline__ int poisson_cell_lanes(const float* __restrict__ pts, unsigned char* sel, int2 me, int r0, int excl,
+                                                  int total, float T, int lane) {
+    float cx[NR], cy[NR], cz[NR];
+    bool cs[NR];
+#pragma unroll
+    for (int rd = 0; rd < NR; ++rd) {
+        const int c = rd * 64 + lane;
+        int sidx = 0;
+#pragma unroll
+        for (int step = 16; step >= 1; step >>= 1) {
+            int tt = sidx + step;
+            int e = __shfl(excl, min(tt, 63), 64);
+            if (tt < 27 && e <= c) sidx = tt;
+        }
+        const int j = __shfl(r0, sidx, 64) + (c - __shfl(excl, sidx, 64));
+        const bool valid = c < total;
+        cs[rd] = valid ? (sel[j] != 0) : false;
+        cx[rd] = valid ? pts[(size_t)j * 3] : 0.f;
+        cy[rd] = valid ? pts[(size_t)j * 3 + 1] : 0.f;
+        cz[rd] = valid ? pts[(size_t)j * 3 + 2] : 0.f;
+    }
+    const int k = me.y - me.x;
+    const bool own = lane < k;
+    const size_t oi = (size_t)(me.x + (own ? lane : 0)) * 3;
+    const float ox = pts[oi], oy = pts[oi + 1], oz = pts[oi + 2];
+    bool rej = !own;
+#pragma unroll
+    for (int rd = 0; rd < NR; ++rd) {
+        unsigned long long m = __ballot(cs[rd]);
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx[rd]), b));
+            const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy[rd]), b));
+            const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz[rd]), b));
+            rej |= point_dist2(qx, qy, qz, ox, oy, oz) < T;
+        }
+    }
+    int kept = 0;
+    for (int i = 0; i < k; ++i) {
+        const unsigned long long rm = __ballot(rej);
+        if (!((rm >> i) & 1ull)) {
+            if (lane == 0) sel[me.x + i] = 1;
+            ++kept;
+            const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ox), i));
+            const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oy), i));
+            const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oz), i));
+            rej |= (lane > i) && (point_dist2(ox, oy, oz, px, py, pz) < T);
+        }
+    }
+    return kept;
+}
+
 __global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restrict__ pts, const int* __restrict__ cells,
                                                           const float* __restrict__ mn, const float* __restrict__ mx,
                                                           int B, PoissonDims d, int ph, float radius, int scaleInv,
@@ -77,58 +195,16 @@ __global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restric
     const int total = __shfl(incl, 63, 64);
     int kept = 0;
     if (total <= 64 * MCCNN_PS_ROUNDS) {
-        float cx[MCCNN_PS_ROUNDS], cy[MCCNN_PS_ROUNDS], cz[MCCNN_PS_ROUNDS];
-        int cj[MCCNN_PS_ROUNDS];
-        bool cs[MCCNN_PS_ROUNDS];
-        const int nr = (total + 63) >> 6;  // rounds actually needed (wave-uniform): skip the rest
-#pragma unroll
-        for (int rd = 0; rd < MCCNN_PS_ROUNDS; ++rd) {
-            cj[rd] = -1; cx[rd] = cy[rd] = cz[rd] = 0.f; cs[rd] = false;
-            if (rd >= nr) continue;
-            const int c = rd * 64 + lane;
-            // which of the 27 ranges holds flat candidate c: largest s with excl_s <= c
-            int sidx = 0;
-#pragma unroll
-            for (int step = 16; step >= 1; step >>= 1) {
-                int tt = sidx + step;
-                int e = __shfl(excl, min(tt, 63), 64);
-                if (tt < 27 && e <= c) sidx = tt;
-            }
-            const int j = __shfl(r0, sidx, 64) + (c - __shfl(excl, sidx, 64));
-            const bool valid = c < total;
-            cj[rd] = valid ? j : -1;
-            cx[rd] = valid ? pts[(size_t)j * 3] : 0.f;
-            cy[rd] = valid ? pts[(size_t)j * 3 + 1] : 0.f;
-            cz[rd] = valid ? pts[(size_t)j * 3 + 2] : 0.f;
-            cs[rd] = valid ? (sel[j] != 0) : false;
-        }
-        // the cell's own points are candidates too (offset (0,0,0) is entry 17 of the table): fetch their coordinates
-        // from the register copies with shuffles instead of n dependent global loads
-        const int ownBase = __shfl(excl, 17, 64);
-        for (int i = me.x; i < me.y; ++i) {
-            const int c = ownBase + (i - me.x);
-            const int src = c & 63, rsel = c >> 6;
-            float px = 0.f, py = 0.f, pz = 0.f;
-#pragma unroll
-            for (int rd = 0; rd < MCCNN_PS_ROUNDS; ++rd) {
-                if (rd == rsel) {  // wave-uniform
-                    px = __shfl(cx[rd], src, 64);
-                    py = __shfl(cy[rd], src, 64);
-                    pz = __shfl(cz[rd], src, 64);
-                }
-            }
-            bool coll = false;
-#pragma unroll
-            for (int rd = 0; rd < MCCNN_PS_ROUNDS; ++rd)
-                if (rd < nr) coll |= cs[rd] && (point_dist2(cx[rd], cy[rd], cz[rd], px, py, pz) < T);
-            if (!__any(coll)) {
-                if (lane == 0) sel[i] = 1;
-                ++kept;
-#pragma unroll
-                for (int rd = 0; rd < MCCNN_PS_ROUNDS; ++rd)
-                    if (rd < nr && cj[rd] == i) cs[rd] = true;
-            }
-        }
+        const int nr = (total + 63) >> 6;  // rounds needed (wave-uniform)
+        if (me.y - me.x <= 64) {
+            if (nr <= 2) kept = poisson_cell_lanes<2>(pts, sel, me, r0, excl, total, T, lane);
+            else if (nr <= 4) kept = poisson_cell_lanes<4>(pts, sel, me, r0, excl, total, T, lane);
+            else if (nr <= 8) kept = poisson_cell_lanes<8>(pts, sel, me, r0, excl, total, T, lane);
+            else kept = poisson_cell_lanes<MCCNN_PS_ROUNDS>(pts, sel, me, r0, excl, total, T, lane);
+        } else if (nr <= 2) kept = poisson_cell_regs<2>(pts, sel, me, r0, excl, total, T, lane);
+        else if (nr <= 4) kept = poisson_cell_regs<4>(pts, sel, me, r0, excl, total, T, lane);
+        else if (nr <= 8) kept = poisson_cell_regs<8>(pts, sel, me, r0, excl, total, T, lane);
+        else kept = poisson_cell_regs<MCCNN_PS_ROUNDS>(pts, sel, me, r0, excl, total, T, lane);
     } else {
         // dense window: stream the candidates for every point; selections of this cell are read back through memory
         volatile unsigned char* vsel = sel;
