@@ -65,6 +65,10 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    # hipcc leaves its unbundled link inputs (<lib>.<n>.hipv4-..., <lib>.<n>.host-...) next to the output
+    for f in os.listdir(LIB_DIR):
+        if f.startswith(os.path.basename(LIB) + ".") and ("hipv4-" in f or ".host-" in f):
+            os.remove(os.path.join(LIB_DIR, f))
     return LIB
 
 

@@ -5,12 +5,14 @@
 //   h1[n] = relu(delta . w1[nu] + b1[nu]);  h2[n] = relu(sum_m h1[m] w2[q][n][m] + b2[nu]);
 //   o[n]  = sum_m h2[m] w3[q][n][m] + b3[nu];   out[i,fo(nu)] += feat[j,fin(nu)] o[n] / (pdf_e K_i)
 //
-// Design (v1, VALU): the reference launches 8 threads per (edge, block) and scatters every
-// product with a float atomicAdd. Here the CSR rows are contiguous (find_neighbors.cu:255-258),
-// so a wave owns G consecutive centres = one contiguous edge range; lanes are edges, the three
-// layers are explicit fmaf chains with wave-uniform weights (scalar loads), the sum over a
-// centre's edges is a segmented wave scan, and every output row is written exactly once from
-// an LDS tile: no atomics, no pre-zeroing, bit-reproducible.
+// The reference launches 8 threads per (edge, block) and scatters every product with a float atomicAdd. Here the CSR
+// rows are contiguous (find_neighbors.cu:255-258): lanes are edges, the sum over a centre's edges is a segmented wave
+// scan and every output row is written exactly once -- no atomics, no pre-zeroing, bit-reproducible.
+//   conv_stream      forward (and, on the transposed list, the depth-wise feature gradient): MFMA kernel MLP,
+//                    edge-balanced slices, wave-wide fused-DPP scan with carry            
+//   conv_bwd_mfma    backward: q-outer sweeps with the weight-gradient sums in VGPRs, deterministic partial rows
+//   conv_fwd_valu / conv_bwd_valu   fallback for nb > MCCNN_LDS_MAX_NB: scalar-loaded weights, fmaf chains, LDS tile
+//   conv_f1.hip      combin layers with ONE input feature take the factored kernels there
 #include "conv_mfma.h"
 #include <cstdlib>
 #include <type_traits>
