@@ -55,19 +55,27 @@ class GradBucket:
         self.flat = None
 
     def allreduce(self, group=None, average=False):
+        """Pack (ONE concatenation kernel), all-reduce, and hand the reduced values back as views of the flat buffer
+        (no copy-back kernels: at a sub-millisecond step a dozen 5 us copies would cost more than the collective)."""
         if not self.params:
             return
         p0 = self.params[0]
         if self.flat is None or self.flat.device != p0.device:
             self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+        base = self.flat.untyped_storage().data_ptr()
+        if all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params):
+            pass  # gradients were accumulated in place into the views handed out last time: already packed
+        elif all(p.grad is not None and p.grad.untyped_storage().data_ptr() != base for p in self.params):
+            torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
+        else:
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                if p.grad is None:
+                    self.flat[off:off + n].zero_()
+                elif p.grad.untyped_storage().data_ptr() != base:
+                    self.flat[off:off + n].copy_(p.grad.reshape(-1))
+                off += n
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             if average:
@@ -75,12 +83,9 @@ class GradBucket:
         off = 0
         for p in self.params:
             n = p.numel()
-            g = self.flat[off:off + n].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
+            p.grad = self.flat[off:off + n].view_as(p)
             off += n
+        # the views stay valid until the next allreduce(): a caller that keeps gradients across steps must clone them
 
 
 def allreduce_mlp_grads(params, group=None, average=False):
