@@ -912,9 +912,7 @@ static int launch_conv_stream(const ConvArgs& a, bool combin, bool vec, float* o
         MCCNN_HIP(hipGetDevice(&dev));
         MCCNN_HIP(hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    int perCU = 0;
-    MCCNN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, reinterpret_cast<const void*>(fn), 256, lds));
-    if (perCU < 1) perCU = 1;
+    const int perCU = cached_blocks_per_cu(reinterpret_cast<const void*>(fn), lds);
     const long long chunks = ((long long)a.e + 63) / 64;
     long long W = (long long)numCU * perCU * 4;
     if (W > (chunks + 1) / 2) W = (chunks + 1) / 2;  // at least ~2 chunks per wave

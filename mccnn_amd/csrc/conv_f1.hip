@@ -495,9 +495,7 @@ static void f1_state_split(void* state, int m, int nb, float*& A, float*& S) {
 
 static int f1_run_edges(const ConvArgs& a, float* A, float* S, hipStream_t s) {
     const size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * (size_t)a.nb * 8) * sizeof(float);
-    int perCU = 0;
-    MCCNN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, reinterpret_cast<const void*>(f1_fwd_edges), 256, lds));
-    if (perCU < 1) perCU = 1;
+    const int perCU = cached_blocks_per_cu(reinterpret_cast<const void*>(f1_fwd_edges), lds);
     const long long chunks = ((long long)a.e + 63) / 64;
     long long W = (long long)num_cus() * perCU * 4;
     if (W > (chunks + 1) / 2) W = (chunks + 1) / 2;

@@ -259,6 +259,19 @@ __device__ __forceinline__ void combin_fold(int Fin, int r0, const float* g, con
     }
 }
 
+// Resident 256-thread workgroups per CU for a kernel / dynamic-LDS size, cached (the query is a driver call).
+inline int cached_blocks_per_cu(const void* fn, size_t lds) {
+    struct Entry { const void* fn; size_t lds; int n; };
+    static Entry cache[32];
+    static int used = 0;
+    for (int i = 0; i < used; ++i)
+        if (cache[i].fn == fn && cache[i].lds == lds) return cache[i].n;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, lds) != hipSuccess || n < 1) n = 1;
+    if (used < 32) cache[used++] = {fn, lds, n};
+    return n;
+}
+
 // conv_f1.hip: combin layers with one input feature (layer 3 factored out of the edge sum)
 size_t f1_state_bytes(int m, int nb);
 size_t f1_fwd_workspace_bytes(int m, int nb);
