@@ -150,12 +150,16 @@ int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, cons
  * count: runs the 27 colour phases, leaves the selection in ws and writes the
  * number of samples S to *total_dev.  fill: emits pts[S,3], batch ids[S] and
  * indices[S] (into the SORTED list) in canonical order.  ws must be preserved
- * between the two calls. */
+ * between the two calls.
+ * mode 0: one launch per phase (27 grid-wide barriers).  mode 1: all phases in one launch, cells
+ * wait on per-cell flags of the earlier-phase cells of their window (same samples, same order).
+ * The waits are bounded; if one times out *total_dev is set to -1 and the caller repeats the
+ * count with mode 0. */
 size_t mccnn_poisson_sampling_workspace_bytes(int n, int batch_size, int num_cells);
 int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batch_ids, int n,
                                  const int* cell_indexs, const float* aabb_min,
                                  const float* aabb_max, int batch_size, int num_cells, float radius,
-                                 int scale_inv, int* total_dev, void* ws, size_t ws_bytes,
+                                 int scale_inv, int mode, int* total_dev, void* ws, size_t ws_bytes,
                                  mccnn_stream_t stream);
 int mccnn_poisson_sampling_fill(const float* sorted_pts, int n, const int* cell_indexs,
                                 int batch_size, int num_cells, int s, float* out_pts,

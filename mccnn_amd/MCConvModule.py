@@ -386,6 +386,8 @@ PDF_MODE = 1
 # keep the forward's per-centre sums for the backward pass (layers with one input feature); False = the backward
 # recomputes them, as a binding without an extra forward output has to
 KEEP_CONV_STATE = True
+# Poisson sampling: try the single-launch dataflow form first (falls back to 27 launches on a timed-out wait)
+POISSON_DATAFLOW = True
 
 
 def compute_pdf(inPts, inBatchIds, aabbMin, aabbMax, startIndexs, neighbors, window, radius, batchSize, scaleInv,
@@ -433,10 +435,16 @@ def poisson_sampling(inPts, inBatchIds, cellIndexs, aabbMin, aabbMax, radius, ba
     _req(wsb > 0, op + ": grid too large")
     ws = _ws(wsb, p.device)
     total = torch.empty(1, dtype=torch.int32, device=p.device)
-    check(lib.mccnn_poisson_sampling_count(ptr(p), ptr(b), n, ptr(cells), ptr(mn), ptr(mx), batchSize, nc,
-                                           float(radius), int(bool(scaleInv)), ptr(total), ptr(ws), ws.numel(),
-                                           stream_handle()), "poisson_sampling(count)")
-    s = int(total.item())
+    # mode 1: all 27 colour phases in one launch (cells wait on their earlier-phase neighbours); a timed-out wait reports
+    # -1 and the phases are run one launch at a time instead
+    s = -1
+    for mode in ((1, 0) if POISSON_DATAFLOW else (0,)):
+        check(lib.mccnn_poisson_sampling_count(ptr(p), ptr(b), n, ptr(cells), ptr(mn), ptr(mx), batchSize, nc,
+                                               float(radius), int(bool(scaleInv)), mode, ptr(total), ptr(ws), ws.numel(),
+                                               stream_handle()), "poisson_sampling(count)")
+        s = int(total.item())
+        if s >= 0:
+            break
     oP = torch.empty((s, 3), dtype=torch.float32, device=p.device)
     oB = torch.empty((s, 1), dtype=torch.int32, device=p.device)
     oI = torch.empty(s, dtype=torch.int32, device=p.device)

@@ -101,10 +101,11 @@ __device__ __forceinline__ int poisson_cell_regs(const float* __restrict__ pts, 
 // the selection flags, coordinates by v_readlane): a few dozen iterations without a loop-carried dependency. (B) the
 // serial walk over the own points then only has to propagate the cell's own acceptances: ~15 instructions per point
 // instead of a test against the whole window. Same decisions as the sequential reference loop.
-template <int NR>
+template <int NR, typename Wait>
 __device__ __forceinline__ int poisson_cell_lanes(const float* __restrict__ pts, unsigned char* sel, int2 me, int r0, int excl,
-                                                  int total, float T, int lane) {
+                                                  int total, float T, int lane, Wait wait) {
     float cx[NR], cy[NR], cz[NR];
+    int cj[NR];
     bool cs[NR];
 #pragma unroll
     for (int rd = 0; rd < NR; ++rd) {
@@ -118,7 +119,7 @@ __device__ __forceinline__ int poisson_cell_lanes(const float* __restrict__ pts,
         }
         const int j = __shfl(r0, sidx, 64) + (c - __shfl(excl, sidx, 64));
         const bool valid = c < total;
-        cs[rd] = valid ? (sel[j] != 0) : false;
+        cj[rd] = valid ? j : -1;
         cx[rd] = valid ? pts[(size_t)j * 3] : 0.f;
         cy[rd] = valid ? pts[(size_t)j * 3 + 1] : 0.f;
         cz[rd] = valid ? pts[(size_t)j * 3 + 2] : 0.f;
@@ -127,6 +128,11 @@ __device__ __forceinline__ int poisson_cell_lanes(const float* __restrict__ pts,
     const bool own = lane < k;
     const size_t oi = (size_t)(me.x + (own ? lane : 0)) * 3;
     const float ox = pts[oi], oy = pts[oi + 1], oz = pts[oi + 2];
+    // coordinates do not depend on the neighbours' decisions, the selection flags do: in the dataflow form the wait for
+    // the earlier-phase cells sits between the two, so that only the flag bytes are loaded after it
+    if (!wait()) return -1;
+#pragma unroll
+    for (int rd = 0; rd < NR; ++rd) cs[rd] = (cj[rd] >= 0) ? (sel[cj[rd]] != 0) : false;
     bool rej = !own;
 #pragma unroll
     for (int rd = 0; rd < NR; ++rd) {
@@ -155,17 +161,24 @@ __device__ __forceinline__ int poisson_cell_lanes(const float* __restrict__ pts,
     return kept;
 }
 
-__global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restrict__ pts, const int* __restrict__ cells,
-                                                          const float* __restrict__ mn, const float* __restrict__ mx,
-                                                          int B, PoissonDims d, int ph, float radius, int scaleInv,
-                                                          unsigned char* sel, int* __restrict__ slotCount) {
-    const int lane = threadIdx.x & 63;
-    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per phase group
-    const long long perBatch = (long long)d.G * d.G * d.G;
-    if (t >= perBatch * B) return;
-    const int b = (int)(t / perBatch);
-    const int r = (int)(t - (long long)b * perBatch);
-    const int gx = r % d.G, gy = (r / d.G) % d.G, gz = r / (d.G * d.G);
+// phase index of an (ox,oy,oz) offset triple = inverse of the table at poisson_sampling.cu:192-196
+__device__ __forceinline__ int pool_phase_of(int ox, int oy, int oz) {
+    for (int p = 0; p < 27; ++p) {
+        int dx, dy, dz;
+        pool_offset(p, dx, dy, dz);
+        if (dx == ox && dy == oy && dz == oz) return p;
+    }
+    return -1;
+}
+
+// One cell of one colour phase, one wave. `done` != nullptr is the dataflow form (poisson_dataflow below): the wave
+// first waits until the non-empty cells of its window that belong to EARLIER phases have published their selections.
+#define MCCNN_PS_SPIN_LIMIT (1 << 16)
+__device__ __forceinline__ void poisson_cell(const float* __restrict__ pts, const int* __restrict__ cells,
+                                             const float* __restrict__ mn, const float* __restrict__ mx,
+                                             const PoissonDims& d, int b, int gx, int gy, int gz, int ph, float radius,
+                                             int scaleInv, unsigned char* sel, int* __restrict__ slotCount, int* done,
+                                             int* fail, int lane) {
     int ox, oy, oz;
     pool_offset(ph, ox, oy, oz);
     const int nc = d.nc;
@@ -180,16 +193,40 @@ __global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restric
     const float T = sqrt_threshold(R);
     // the 27 candidate ranges, one per lane
     int r0 = 0, cnt = 0;
+    bool needWait = false;
+    size_t waitIdx = 0;
     if (lane < 27) {
         int dx, dy, dz;
         pool_offset(lane, dx, dy, dz);
         int X = xC + dx, Y = yC + dy, Z = zC + dz;
         if (X >= 0 && X < nc && Y >= 0 && Y < nc && Z >= 0 && Z < nc) {
-            int2 rr = ct[cellBase + (size_t)X * nc * nc + (size_t)Y * nc + Z];
+            const size_t ci = cellBase + (size_t)X * nc * nc + (size_t)Y * nc + Z;
+            int2 rr = ct[ci];
             r0 = rr.x;
             cnt = rr.y - rr.x;
+            needWait = done && cnt > 0 && pool_phase_of(X % 3 - 1, Y % 3 - 1, Z % 3 - 1) < ph;
+            waitIdx = ci;
         }
     }
+    // bounded spin on the flags of the earlier-phase cells of the window: a timeout raises `fail`, the caller then falls
+    // back to one launch per phase. Returns false if the cell must be abandoned.
+    auto wait = [&]() -> bool {
+        if (!done) return true;
+        bool waitFailed = false;
+        if (needWait) {
+            int spins = 0;
+            while (__hip_atomic_load(done + waitIdx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                if (++spins > MCCNN_PS_SPIN_LIMIT) { waitFailed = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (__any(waitFailed)) {
+            if (lane == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the neighbours' sel[] bytes are visible from here on
+        return true;
+    };
     const int incl = wave_incl_scan(cnt);
     const int excl = incl - cnt;
     const int total = __shfl(incl, 63, 64);
@@ -197,14 +234,17 @@ __global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restric
     if (total <= 64 * MCCNN_PS_ROUNDS) {
         const int nr = (total + 63) >> 6;  // rounds needed (wave-uniform)
         if (me.y - me.x <= 64) {
-            if (nr <= 2) kept = poisson_cell_lanes<2>(pts, sel, me, r0, excl, total, T, lane);
-            else if (nr <= 4) kept = poisson_cell_lanes<4>(pts, sel, me, r0, excl, total, T, lane);
-            else if (nr <= 8) kept = poisson_cell_lanes<8>(pts, sel, me, r0, excl, total, T, lane);
-            else kept = poisson_cell_lanes<MCCNN_PS_ROUNDS>(pts, sel, me, r0, excl, total, T, lane);
-        } else if (nr <= 2) kept = poisson_cell_regs<2>(pts, sel, me, r0, excl, total, T, lane);
+            if (nr <= 2) kept = poisson_cell_lanes<2>(pts, sel, me, r0, excl, total, T, lane, wait);
+            else if (nr <= 4) kept = poisson_cell_lanes<4>(pts, sel, me, r0, excl, total, T, lane, wait);
+            else if (nr <= 8) kept = poisson_cell_lanes<8>(pts, sel, me, r0, excl, total, T, lane, wait);
+            else kept = poisson_cell_lanes<MCCNN_PS_ROUNDS>(pts, sel, me, r0, excl, total, T, lane, wait);
+        } else if (!wait()) kept = -1;
+        else if (nr <= 2) kept = poisson_cell_regs<2>(pts, sel, me, r0, excl, total, T, lane);
         else if (nr <= 4) kept = poisson_cell_regs<4>(pts, sel, me, r0, excl, total, T, lane);
         else if (nr <= 8) kept = poisson_cell_regs<8>(pts, sel, me, r0, excl, total, T, lane);
         else kept = poisson_cell_regs<MCCNN_PS_ROUNDS>(pts, sel, me, r0, excl, total, T, lane);
+    } else if (!wait()) {
+        kept = -1;
     } else {
         // dense window: stream the candidates for every point; selections of this cell are read back through memory
         volatile unsigned char* vsel = sel;
@@ -231,18 +271,58 @@ __global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restric
             }
         }
     }
+    if (kept < 0) return;  // abandoned: a wait timed out (dataflow form only)
     if (lane == 0) slotCount[poisson_slot(d, b, ph, gx, gy, gz)] = kept;
+    if (done) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // sel[] of this cell before its flag
+        if (lane == 0)
+            __hip_atomic_store(done + cellBase + (size_t)xC * nc * nc + (size_t)yC * nc + zC, 1, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-// phase index of an (ox,oy,oz) offset triple = inverse of the table at poisson_sampling.cu:192-196
-__device__ __forceinline__ int pool_phase_of(int ox, int oy, int oz) {
-    for (int p = 0; p < 27; ++p) {
-        int dx, dy, dz;
-        pool_offset(p, dx, dy, dz);
-        if (dx == ox && dy == oy && dz == oz) return p;
-    }
-    return -1;
+// selectSamples for ONE phase over all batches (poisson_sampling.cu:51-124), one wave per cell of the phase.
+__global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restrict__ pts, const int* __restrict__ cells,
+                                                          const float* __restrict__ mn, const float* __restrict__ mx,
+                                                          int B, PoissonDims d, int ph, float radius, int scaleInv,
+                                                          unsigned char* sel, int* __restrict__ slotCount) {
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per phase group
+    const long long perBatch = (long long)d.G * d.G * d.G;
+    if (t >= perBatch * B) return;
+    const int b = (int)(t / perBatch);
+    const int r = (int)(t - (long long)b * perBatch);
+    poisson_cell(pts, cells, mn, mx, d, b, r % d.G, (r / d.G) % d.G, r / (d.G * d.G), ph, radius, scaleInv, sel, slotCount,
+                 nullptr, nullptr, lane);
 }
+
+// All 27 phases in ONE launch (dataflow form). Waves are ordered phase-major, so every wave a cell has to wait for has
+// a lower workgroup index and was dispatched earlier: a cell spins (bounded, with s_sleep) on the `done` flags of the
+// non-empty earlier-phase cells of its window, processes its points, publishes its own flag. Independent regions of the
+// cloud run ahead of each other instead of meeting at 27 grid-wide barriers; the critical path is the longest chain of
+// dependent cells (<= 27), not 27 launches. Same samples, same order as the phased form.
+__global__ __launch_bounds__(256) void poisson_dataflow(const float* __restrict__ pts, const int* __restrict__ cells,
+                                                        const float* __restrict__ mn, const float* __restrict__ mx,
+                                                        int B, PoissonDims d, float radius, int scaleInv,
+                                                        unsigned char* sel, int* __restrict__ slotCount, int* done,
+                                                        int* fail) {
+    const int lane = threadIdx.x & 63;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long perPhase = (long long)d.G * d.G * d.G * B;
+    if (w >= perPhase * 27) return;
+    const int ph = (int)(w / perPhase);
+    const long long t = w - (long long)ph * perPhase;
+    const long long perBatch = (long long)d.G * d.G * d.G;
+    const int b = (int)(t / perBatch);
+    const int r = (int)(t - (long long)b * perBatch);
+    poisson_cell(pts, cells, mn, mx, d, b, r % d.G, (r / d.G) % d.G, r / (d.G * d.G), ph, radius, scaleInv, sel, slotCount,
+                 done, fail, lane);
+}
+
+__global__ void poisson_flag_failure(const int* __restrict__ fail, int* __restrict__ total) {
+    if (*fail) *total = -1;
+}
+
 
 // One thread per grid cell: emit its kept points at the cell's canonical output base.
 __global__ __launch_bounds__(256) void poisson_emit(const float* __restrict__ pts, const int* __restrict__ cells,
@@ -287,12 +367,14 @@ size_t mccnn_poisson_sampling_workspace_bytes(int n, int batch_size, int num_cel
     if (batch_size <= 0 || num_cells <= 0) return 0;
     long long S = poisson_slots(batch_size, num_cells);
     if (S >= 0x7fffffffLL) return 0;
-    return align_up((size_t)(n > 0 ? n : 1)) + align_up((size_t)S * 4) + scan_workspace_bytes((int)S) + 256;
+    size_t C = (size_t)batch_size * num_cells * num_cells * num_cells;
+    return align_up((size_t)(n > 0 ? n : 1)) + align_up((size_t)S * 4) + scan_workspace_bytes((int)S) +
+           align_up((C + 1) * sizeof(int)) + 256;  // + per-cell done flags and the failure flag of the dataflow form
 }
 
 int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batch_ids, int n, const int* cell_indexs,
                                  const float* aabb_min, const float* aabb_max, int batch_size, int num_cells,
-                                 float radius, int scale_inv, int* total_dev, void* ws, size_t ws_bytes,
+                                 float radius, int scale_inv, int mode, int* total_dev, void* ws, size_t ws_bytes,
                                  mccnn_stream_t stream) {
     (void)sorted_batch_ids;
     if (n < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
@@ -309,11 +391,24 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
     unsigned char* sel = a.take<unsigned char>((size_t)n);
     int* slots = a.take<int>((size_t)S);
     void* scanws = a.take<char>(scan_workspace_bytes((int)S));
-    if (!sel || !slots || !scanws) return MCCNN_E_WORKSPACE;
+    const size_t C = (size_t)batch_size * num_cells * num_cells * num_cells;
+    int* flags = a.take<int>(C + 1);  // done[C], fail
+    if (!sel || !slots || !scanws || !flags) return MCCNN_E_WORKSPACE;
     MCCNN_HIP(hipMemsetAsync(sel, 0, (size_t)n, s));
     MCCNN_HIP(hipMemsetAsync(slots, 0, (size_t)S * sizeof(int), s));
     PoissonDims d = poisson_dims(num_cells);
     long long threads = (long long)batch_size * d.G * d.G * d.G;
+    if (mode == 1) {
+        MCCNN_HIP(hipMemsetAsync(flags, 0, (C + 1) * sizeof(int), s));
+        poisson_dataflow<<<ceil_div(threads * 27, 4), 256, 0, s>>>(sorted_pts, cell_indexs, aabb_min, aabb_max, batch_size, d,
+                                                                  radius, scale_inv, sel, slots, flags, flags + C);
+        MCCNN_LAUNCHED();
+        int rc = exclusive_scan_i32(slots, slots, (int)S, total_dev, scanws, s);
+        if (rc) return rc;
+        poisson_flag_failure<<<1, 1, 0, s>>>(flags + C, total_dev);  // *total_dev = -1: repeat the call with mode 0
+        MCCNN_LAUNCHED();
+        return 0;
+    }
     for (int ph = 0; ph < 27; ++ph) {
         poisson_phase_wave<<<ceil_div(threads, 4), 256, 0, s>>>(sorted_pts, cell_indexs, aabb_min, aabb_max, batch_size,
                                                                 d, ph, radius, scale_inv, sel, slots);

@@ -248,6 +248,27 @@ def test_conv_centres_without_neighbours(mc, oracle, fin, fout, combin):
         assert_close(_unwrap(a), b, RTOL, nm)
 
 
+def test_poisson_dataflow_and_phased_forms_agree(mc, oracle):
+    """All 27 colour phases in one launch (cells wait on per-cell flags) against one launch per phase and the oracle:
+    uniform, clustered (cells with > 64 points, windows beyond the register path) and multi-cloud inputs."""
+    for n, B, seed, kind, radius in ((4096, 1, 1, "uniform", 0.1), (3000, 3, 5, "clustered", 0.25), (600, 2, 9, "sphere", 0.6)):
+        pts, bids = make_cloud(n, B, seed, kind, True)
+        feats = np.ones((len(pts), 1), np.float32)
+        o = run_chain(oracle, _ident, _ident, pts, bids, feats, B, radius, True, poisson_radius=radius)
+        outs = []
+        for flag in (True, False):
+            mc.POISSON_DATAFLOW = flag
+            try:
+                g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, B, radius, True, poisson_radius=radius)
+            finally:
+                mc.POISSON_DATAFLOW = True
+            outs.append(g)
+            for k in ("samplePts", "sampleBatchs", "sampleIndexs"):
+                assert np.array_equal(g[k], o[k]), (kind, flag, k)
+        for k in ("samplePts", "sampleBatchs", "sampleIndexs"):
+            assert np.array_equal(outs[0][k], outs[1][k])
+
+
 def test_permutation_ops_and_adjoints(mc, oracle):
     import torch
     rng = np.random.default_rng(2)
