@@ -98,6 +98,8 @@ def _order_hint(points):
             check(_lib.load().mccnn_invert_permutation(ptr(payload), payload.shape[0], ptr(inv), stream_handle()),
                   "invert_permutation")
             ent[2] = inv
+        elif payload.shape[0] < 16384:
+            return None  # a small sample set is searched in ~10 us either way: the argsort would cost more than it saves
         else:  # "sorted_pos": position of every point in some cell-sorted list
             ent[2] = torch.argsort(payload).to(torch.int32)
     return ent[2]
