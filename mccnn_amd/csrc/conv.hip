@@ -58,22 +58,22 @@ __device__ __forceinline__ void mlp_block(const ConvArgs& a, int q, float d0, fl
     const float* b2 = a.b2 + q * 8;
     const float* w3 = a.w3 + q * 64;
     const float* b3 = a.b3 + q * 8;
+    // the chains the MFMA kernels issue (conv_mfma.h): k-ordered fma from zero, bias last
 #pragma unroll
-    for (int n = 0; n < 8; ++n)
-        pre1[n] = fmaf(d2, w1[n * 3 + 2], fmaf(d1, w1[n * 3 + 1], fmaf(d0, w1[n * 3], b1[n])));
+    for (int n = 0; n < 8; ++n) pre1[n] = fmaf(d2, w1[n * 3 + 2], fmaf(d1, w1[n * 3 + 1], d0 * w1[n * 3])) + b1[n];
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
-        float s = b2[n];
+        float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s = fmaf(relu(pre1[k]), w2[n * 8 + k], s);
-        pre2[n] = s;
+        pre2[n] = s + b2[n];
     }
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
-        float s = b3[n];
+        float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s = fmaf(relu(pre2[k]), w3[n * 8 + k], s);
-        o[n] = s;
+        o[n] = s + b3[n];
     }
 }
 
@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
             if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, a.bids[j]));
             const float* pp = a.pts + (size_t)j * 3;
             const float* cc = a.samples + (size_t)ci * 3;
-            d0 = (pp[0] - cc[0]) * invR; d1 = (pp[1] - cc[1]) * invR; d2 = (pp[2] - cc[2]) * invR;
+            const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, a.bids[j]) : a.radius;
+            d0 = div_exact(pp[0] - cc[0], R, invR); d1 = div_exact(pp[1] - cc[1], R, invR); d2 = div_exact(pp[2] - cc[2], R, invR);
             float K = 1.0f;
             if (a.avg) K = (float)(((ci + 1 < a.m) ? a.start[ci + 1] : a.e) - a.start[ci]);
             inv = in ? __builtin_amdgcn_rcpf(pdf * K) : 0.0f;
@@ -408,7 +409,8 @@ __global__ __launch_bounds__(256) void edge_records(ConvArgs a, float4* __restri
     int e0 = a.start[pr.y];
     int e1 = (pr.y < a.m - 1) ? a.start[pr.y + 1] : a.e;
     float K = a.avg ? (float)(e1 - e0) : 1.0f;
-    rec[t] = make_float4((p[0] - c[0]) * invR, (p[1] - c[1]) * invR, (p[2] - c[2]) * invR,
+    const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, a.bids[pr.x]) : a.radius;
+    rec[t] = make_float4(div_exact(p[0] - c[0], R, invR), div_exact(p[1] - c[1], R, invR), div_exact(p[2] - c[2], R, invR),
                          __builtin_amdgcn_rcpf(a.pdfs[t] * K));
 }
 
@@ -452,7 +454,6 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
         const int numOuts = min(a.neuronsOut - q * 8, 8);
         constexpr bool smallFin = COMBIN && FEAT == 3;  // combin, 2..4 input features
         const int r0 = smallFin ? (q * 8) % a.Fin : 0, fo0 = smallFin ? (q * 8) / a.Fin : 0;
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
         // the chunk loop as a generic lambda: combin layers with 2..4 input features instantiate it once per static
         // neuron -> (fin, fo) pattern (FIN_, R0_) and pick the instance once per block, outside the loop
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
             // t3 = 1[pre2 >= 0] * W3^T (g f) / (pdf K)             (:403-414)
             float t3[8];
             MCCNN_PHASE();
-            layer8(w4 + 62, zero4, zero4, i4, gf, t3);  // W3^T rows at float 248 -> f32x4 index 62
+            layer8<false>(w4 + 62, nullptr, i4, gf, t3);  // W3^T rows at float 248 -> f32x4 index 62
             MCCNN_PHASE();
 #pragma unroll
             for (int k = 0; k < 8; ++k) t3[k] = p2[k] ? t3[k] * inv : 0.f;
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
             // t4 = 1[pre1 >= 0] * W2^T t3                          (:428-434)
             float t4[8];
             MCCNN_PHASE();
-            layer8(w4 + 46, zero4, zero4, i4, t3, t4);  // W2^T rows at float 184 -> f32x4 index 46
+            layer8<false>(w4 + 46, nullptr, i4, t3, t4);  // W2^T rows at float 184 -> f32x4 index 46
             MCCNN_PHASE();
             // dW1 += t4 delta^T, db1 += t4                         (:439-444)
 #pragma unroll
@@ -892,6 +893,11 @@ static int fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_f
     return 0;
 }
 
+std::atomic<int>& conv_impl_override() {
+    static std::atomic<int> v{(getenv("MCCNN_FORCE_VALU") ? 1 : 0) | (getenv("MCCNN_NO_F1") ? 2 : 0)};
+    return v;
+}
+
 }  // namespace mccnn
 
 using namespace mccnn;
@@ -906,12 +912,7 @@ static int launch_conv_stream(const ConvArgs& a, bool combin, bool vec, float* o
     else if (combin) fn = (a.Fin == 1) ? conv_stream<true, 1, false> : (a.Fin <= 4 ? conv_stream<true, 3, false> : conv_stream<true, 0, false>);
     else fn = vec ? conv_stream<false, 2, false> : conv_stream<false, 0, false>;
     const size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * (size_t)a.nb * 8) * sizeof(float);
-    static int numCU = 0;
-    if (!numCU) {
-        int dev = 0;
-        MCCNN_HIP(hipGetDevice(&dev));
-        MCCNN_HIP(hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    const int numCU = num_cus();
     const int perCU = cached_blocks_per_cu(reinterpret_cast<const void*>(fn), lds);
     const long long chunks = ((long long)a.e + 63) / 64;
     long long W = (long long)numCU * perCU * 4;
@@ -924,10 +925,12 @@ static int launch_conv_stream(const ConvArgs& a, bool combin, bool vec, float* o
 
 extern "C" {
 
+int mccnn_debug_conv_impl(int mask) { return conv_impl_override().exchange(mask & 3); }
+
 // combin layers with one input feature take the factored path of conv_f1.hip (f1_*)
 static bool f1_shape(int num_in_feats, int num_out_feats, int combin) {
     return combin && num_in_feats == 1 && num_out_feats > 0 && (num_out_feats + 7) / 8 <= MCCNN_LDS_MAX_NB &&
-           !getenv("MCCNN_FORCE_VALU") && !getenv("MCCNN_NO_F1");
+           (conv_impl_override().load(std::memory_order_relaxed) & 3) == 0;
 }
 
 size_t mccnn_spatial_conv_state_bytes(int m, int num_in_feats, int num_out_feats, int combin) {
@@ -941,7 +944,9 @@ size_t mccnn_spatial_conv_fwd_workspace_bytes(int m, int e, int num_in_feats, in
     return 256;
 }  // none needed today
 
-static bool use_mfma(const ConvArgs& a) { return a.nb <= MCCNN_LDS_MAX_NB && !getenv("MCCNN_FORCE_VALU"); }
+static bool use_mfma(const ConvArgs& a) {
+    return a.nb <= MCCNN_LDS_MAX_NB && (conv_impl_override().load(std::memory_order_relaxed) & 1) == 0;
+}
 
 int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
                            const float* pdfs, const float* samples, const int* start_idx, const int* packed,

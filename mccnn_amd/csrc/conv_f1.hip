@@ -15,31 +15,6 @@
 
 namespace mccnn {
 
-// layers 1 and 2 of block q for the 64 edges of a wave (see mlp_block_mfma)
-__device__ __forceinline__ void mlp_block_l12(const float* __restrict__ wq, int i4, float d0, float d1, float d2,
-                                              float* pre1, float* a1, float* pre2, float* a2) {
-    const f32x4* w = reinterpret_cast<const f32x4*>(wq);
-    f32x4 a1lo = w[i4], a1hi = w[4 + i4];
-    f32x4 lo = w[8], hi = w[9];  // b1
-    lo = MFMA4(a1lo.x, d0, lo);
-    hi = MFMA4(a1hi.x, d0, hi);
-    lo = MFMA4(a1lo.y, d1, lo);
-    hi = MFMA4(a1hi.y, d1, hi);
-    lo = MFMA4(a1lo.z, d2, lo);
-    hi = MFMA4(a1hi.z, d2, hi);
-    MCCNN_PHASE();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { pre1[r] = lo[r]; pre1[4 + r] = hi[r]; }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) a1[r] = relu1(pre1[r]);
-    MCCNN_PHASE();
-    layer8(w + 10, w[26], w[27], i4, a1, pre2);  // W2, b2
-    MCCNN_PHASE();
-#pragma unroll
-    for (int r = 0; r < 8; ++r) a2[r] = relu1(pre2[r]);
-    MCCNN_PHASE();
-}
-
 // segmented inclusive wave scan of ONE value (once per chunk: the nops cover the VALU-write -> DPP-read hazard)
 __device__ __forceinline__ float wave_seg_scan1(float v, float m1, float m2, float m4, float m8, float mA, float mB) {
     asm("s_nop 1\n"
@@ -103,7 +78,8 @@ __global__ __launch_bounds__(256) void f1_fwd_edges(ConvArgs a, float* __restric
         if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, a.bids[j]));
         const float* pp = a.pts + (size_t)j * 3;
         const float* cc = a.samples + (size_t)ci * 3;
-        const float d0 = (pp[0] - cc[0]) * invR, d1 = (pp[1] - cc[1]) * invR, d2 = (pp[2] - cc[2]) * invR;
+        const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, a.bids[j]) : a.radius;
+        const float d0 = div_exact(pp[0] - cc[0], R, invR), d1 = div_exact(pp[1] - cc[1], R, invR), d2 = div_exact(pp[2] - cc[2], R, invR);
         float K = 1.0f;
         if (a.avg) K = (float)(((ci + 1 < a.m) ? a.start[ci + 1] : a.e) - a.start[ci]);
         const float s = in ? a.feats[j] * __builtin_amdgcn_rcpf(pdf * K) : 0.0f;
@@ -207,7 +183,8 @@ __global__ __launch_bounds__(256) void f1_edge_records(ConvArgs a, float4* __res
     int e0 = a.start[pr.y];
     int e1 = (pr.y < a.m - 1) ? a.start[pr.y + 1] : a.e;
     float K = a.avg ? (float)(e1 - e0) : 1.0f;
-    rec[t] = make_float4((p[0] - c[0]) * invR, (p[1] - c[1]) * invR, (p[2] - c[2]) * invR,
+    const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, a.bids[pr.x]) : a.radius;
+    rec[t] = make_float4(div_exact(p[0] - c[0], R, invR), div_exact(p[1] - c[1], R, invR), div_exact(p[2] - c[2], R, invR),
                          __builtin_amdgcn_rcpf(a.pdfs[t] * K));
 }
 
@@ -245,7 +222,6 @@ __global__ __launch_bounds__(256, MCCNN_F1_OCC) void f1_bwd_edges(ConvArgs a, co
         for (int k = 0; k < 8; ++k) { gb2[k] = 0.f; gb1[k] = 0.f; }
 #pragma unroll
         for (int k = 0; k < 24; ++k) gw1[k] = 0.f;
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         const bool last = (q == a.nb - 1);
 
         int2 prN;
@@ -308,7 +284,7 @@ __global__ __launch_bounds__(256, MCCNN_F1_OCC) void f1_bwd_edges(ConvArgs a, co
             // t4 = 1[pre1 >= 0] * W2^T t3 ; dW1 += t4 delta^T, db1 += t4
             float t4[8];
             MCCNN_PHASE();
-            layer8(w4 + 46, zero4, zero4, i4, t3, t4);  // W2^T rows at float 184 -> f32x4 index 46
+            layer8<false>(w4 + 46, nullptr, i4, t3, t4);  // W2^T rows at float 184 -> f32x4 index 46
             MCCNN_PHASE();
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
@@ -455,15 +431,6 @@ __global__ __launch_bounds__(256) void f1_reduce(const float* __restrict__ pe, i
 }
 
 // ------------------------------------------------------------------------------------ host side
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    }
-    return n;
-}
-
 // The q-outer sweep re-reads a wave's slice nb times (32 B per edge and sweep). With one slice per resident wave the
 // slices of a launch together must stay inside the 256 MB Infinity Cache or every sweep comes from HBM (8 rooms, 36 M
 // edges: 3.5 ms instead of 8 x 0.4): larger inputs get R equal rounds of resident-many waves with <= 32-chunk slices,

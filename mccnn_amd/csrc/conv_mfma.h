@@ -2,6 +2,8 @@
 // of the 8x8 kernel-MLP layers, scheduling phases, fused-DPP segmented scan, slice search, transposing butterfly.
 #pragma once
 #include "common.h"
+#include <atomic>
+#include <mutex>
 
 namespace mccnn {
 
@@ -29,8 +31,11 @@ struct ConvArgs {
 // With lane = edge and reg = neuron this is exactly one k-step of an 8x8 block of the kernel MLP
 // for 64 edges at once and with ZERO block-diagonal waste (a 16x16x4 tiling wastes half of every
 // MFMA on the off-diagonal zeros): A = the weight W[r][k] (same for every quad), B = the lane's
-// own activation h[k]. Two accumulators (neurons 0-3 / 4-7) x 8 k-steps = 16 MFMAs per layer, the
-// accumulator is initialised with the bias straight from LDS, numerics == the fmaf chain of v1.
+// own activation h[k]. Two accumulators (neurons 0-3 / 4-7) x 8 k-steps = 16 MFMAs per layer. An f32 MFMA is
+// bit for bit a k-ordered fmaf chain, and the chain is the one the reference compiles to (nvcc contracts
+// `aux += h*w` into fma; spatial_conv.cu:57-62,372-378): it starts at ZERO and the bias comes LAST, as one more
+// k-step with B = 1.0 (fma(b, 1, acc) == acc + b exactly). Pre-activations -- and with them every ReLU / ReLU'
+// decision -- are therefore bit-identical to those of the test suite's sequential CPU restatement of the same chains.
 // The transposed products of the backward pass (t3 = W3^T (g f), t4 = W2^T t3) use the same form
 // with the transposed weight copies staged in LDS.
 // ---------------------------------------------------------------------------------------
@@ -76,7 +81,7 @@ __device__ __forceinline__ void stage_weights(const ConvArgs& a, float* wl) {
     for (int t = threadIdx.x; t < a.nb * WQ; t += blockDim.x) {
         int q = t / WQ, r = t - q * WQ;
         float v;
-        if (r < 32) { int row = r >> 2, c = r & 3; v = (c < 3) ? a.w1[(q * 8 + row) * 3 + c] : 0.0f; }
+        if (r < 32) { int row = r >> 2, c = r & 3; v = (c < 3) ? a.w1[(q * 8 + row) * 3 + c] : a.b1[q * 8 + row]; }  // row = (w0, w1, w2, b1)
         else if (r < 40) v = a.b1[q * 8 + r - 32];
         else if (r < 104) v = a.w2[q * 64 + r - 40];
         else if (r < 112) v = a.b2[q * 8 + r - 104];
@@ -88,23 +93,73 @@ __device__ __forceinline__ void stage_weights(const ConvArgs& a, float* wl) {
     }
 }
 
-// One 8x8 layer for 64 edges: y = bias + W x, rows i4 / 4+i4 of W supplied by this lane. Two interleaved
-// accumulation chains (neurons 0-3 / 4-7); splitting K into more independent chains was measured slower
-// (tools/issue_probe.hip: a single dependent 4x4x1 chain already issues every ~15 cycles and is hidden from 2 waves
-// per SIMD up).
+// 1.0 in a VGPR the optimiser cannot see through (the bias k-step's B operand)
+__device__ __forceinline__ float opaque_one() {
+    float one = 1.0f;
+    asm("" : "+v"(one));
+    return one;
+}
+
+// One 8x8 layer for 64 edges: y = W x (+ bias), rows i4 / 4+i4 of W supplied by this lane. Two interleaved
+// accumulation chains (neurons 0-3 / 4-7) that start at zero; splitting K into more independent chains was measured
+// slower (tools/issue_probe.hip: a single dependent 4x4x1 chain already issues every ~15 cycles and is hidden from 2
+// waves per SIMD up). BIAS: bias[i4] / bias[4 + i4] enter as a ninth k-step against B = 1.0.
+template <bool BIAS>
 __device__ __forceinline__ void layer8(const f32x4* __restrict__ wrows /* 16 x f32x4: row r at [2r],[2r+1] */,
-                                       f32x4 lo, f32x4 hi, int i4, const float* x, float* y) {
+                                       const float* __restrict__ bias, int i4, const float* x, float* y) {
     f32x4 al0 = wrows[2 * i4], al1 = wrows[2 * i4 + 1];
     f32x4 ah0 = wrows[2 * (4 + i4)], ah1 = wrows[2 * (4 + i4) + 1];
     float al[8] = {al0.x, al0.y, al0.z, al0.w, al1.x, al1.y, al1.z, al1.w};
     float ah[8] = {ah0.x, ah0.y, ah0.z, ah0.w, ah1.x, ah1.y, ah1.z, ah1.w};
+    float bl = 0.f, bh = 0.f;
+    if (BIAS) { bl = bias[i4]; bh = bias[4 + i4]; }
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         lo = MFMA4(al[k], x[k], lo);
         hi = MFMA4(ah[k], x[k], hi);
     }
+    if (BIAS) {
+        const float one = opaque_one();
+        lo = MFMA4(bl, one, lo);
+        hi = MFMA4(bh, one, hi);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { y[r] = lo[r]; y[4 + r] = hi[r]; }
+}
+
+// Layer 1 for 64 edges: pre1 = ((d0 w0 + d1 w1) + d2 w2) + b1 as fma steps (spatial_conv.cu:49-52); the LDS row of
+// neuron r is (w0, w1, w2, b1).
+__device__ __forceinline__ void layer1_mfma(const f32x4* __restrict__ w, int i4, float d0, float d1, float d2, float* pre1) {
+    f32x4 a1lo = w[i4], a1hi = w[4 + i4];
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+    const float one = opaque_one();
+    lo = MFMA4(a1lo.x, d0, lo);
+    hi = MFMA4(a1hi.x, d0, hi);
+    lo = MFMA4(a1lo.y, d1, lo);
+    hi = MFMA4(a1hi.y, d1, hi);
+    lo = MFMA4(a1lo.z, d2, lo);
+    hi = MFMA4(a1hi.z, d2, hi);
+    lo = MFMA4(a1lo.w, one, lo);
+    hi = MFMA4(a1hi.w, one, hi);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pre1[r] = lo[r]; pre1[4 + r] = hi[r]; }
+}
+
+// Layers 1 and 2 of block q (weights at wq in LDS) for the 64 edges of a wave. a1 = relu(pre1), a2 = relu(pre2).
+__device__ __forceinline__ void mlp_block_l12(const float* __restrict__ wq, int i4, float d0, float d1, float d2,
+                                              float* pre1, float* a1, float* pre2, float* a2) {
+    const f32x4* w = reinterpret_cast<const f32x4*>(wq);
+    layer1_mfma(w, i4, d0, d1, d2, pre1);
+    MCCNN_PHASE();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a1[r] = relu1(pre1[r]);
+    MCCNN_PHASE();
+    layer8<true>(w + 10, wq + 104, i4, a1, pre2);  // W2, b2
+    MCCNN_PHASE();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a2[r] = relu1(pre2[r]);
+    MCCNN_PHASE();
 }
 
 // Kernel MLP of block q (weights at wq in LDS) for the 64 edges of a wave.
@@ -112,27 +167,19 @@ __device__ __forceinline__ void layer8(const f32x4* __restrict__ wrows /* 16 x f
 __device__ __forceinline__ void mlp_block_mfma(const float* __restrict__ wq, int i4, float d0, float d1, float d2,
                                                float* pre1, float* a1, float* pre2, float* a2, float* o) {
     const f32x4* w = reinterpret_cast<const f32x4*>(wq);
-    f32x4 a1lo = w[i4], a1hi = w[4 + i4];
-    f32x4 lo = w[8], hi = w[9];  // b1
-    lo = MFMA4(a1lo.x, d0, lo);
-    hi = MFMA4(a1hi.x, d0, hi);
-    lo = MFMA4(a1lo.y, d1, lo);
-    hi = MFMA4(a1hi.y, d1, hi);
-    lo = MFMA4(a1lo.z, d2, lo);
-    hi = MFMA4(a1hi.z, d2, hi);
+    mlp_block_l12(wq, i4, d0, d1, d2, pre1, a1, pre2, a2);
+    layer8<true>(w + 28, wq + 176, i4, a2, o);     // W3, b3
     MCCNN_PHASE();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { pre1[r] = lo[r]; pre1[4 + r] = hi[r]; }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) a1[r] = relu1(pre1[r]);
-    MCCNN_PHASE();
-    layer8(w + 10, w[26], w[27], i4, a1, pre2);  // W2, b2
-    MCCNN_PHASE();
-#pragma unroll
-    for (int r = 0; r < 8; ++r) a2[r] = relu1(pre2[r]);
-    MCCNN_PHASE();
-    layer8(w + 28, w[44], w[45], i4, a2, o);     // W3, b3
-    MCCNN_PHASE();
+}
+
+// Correctly rounded x / R from y = RN(1 / R) in three instructions (Markstein): q = RN(x y) is within one ulp,
+// r = x - q R is exact in an fma, RN(q + r y) is the correctly rounded quotient. The reference divides
+// (spatial_conv.cu:155-158); the quotient feeds layer 1, whose pre-activations have to be
+// bit-identical (see above). Spelled with fma builtins: the library is compiled with -ffp-contract=off.
+__device__ __forceinline__ float div_exact(float x, float R, float invR) {
+    const float q = x * invR;
+    const float r = __builtin_fmaf(-q, R, x);
+    return __builtin_fmaf(r, invR, q);
 }
 
 // smallest c in [0, m] with S(c) >= t, S(c) = start[c] (c < m), S(m) = e. 64-ary: three dependent loads for m < 2^18.
@@ -259,18 +306,41 @@ __device__ __forceinline__ void combin_fold(int Fin, int r0, const float* g, con
     }
 }
 
-// Resident 256-thread workgroups per CU for a kernel / dynamic-LDS size, cached (the query is a driver call).
+// Resident 256-thread workgroups per CU for a kernel / dynamic-LDS size. The query is a driver call (~10 us), so the
+// answers are cached; the table is append-only behind a mutex (the ops may be called from several host threads).
 inline int cached_blocks_per_cu(const void* fn, size_t lds) {
     struct Entry { const void* fn; size_t lds; int n; };
     static Entry cache[32];
     static int used = 0;
-    for (int i = 0; i < used; ++i)
-        if (cache[i].fn == fn && cache[i].lds == lds) return cache[i].n;
+    static std::mutex mu;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (int i = 0; i < used; ++i)
+            if (cache[i].fn == fn && cache[i].lds == lds) return cache[i].n;
+    }
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, lds) != hipSuccess || n < 1) n = 1;
+    std::lock_guard<std::mutex> g(mu);
     if (used < 32) cache[used++] = {fn, lds, n};
     return n;
 }
+
+// CUs of the current device (constant per process for a homogeneous node; initialised once, thread-safe).
+inline int num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+            v = 256;
+        return v;
+    }();
+    return n;
+}
+
+// Implementation override for A/B tests of the conv kernels: bit 0 = VALU fallback kernels, bit 1 = general MFMA
+// kernels for one-input-feature layers. Read ONCE from the environment (MCCNN_FORCE_VALU / MCCNN_NO_F1) when the
+// library is first used; tests switch it through mccnn_debug_conv_impl(). Not part of the product configuration.
+std::atomic<int>& conv_impl_override();
 
 // conv_f1.hip: combin layers with one input feature (layer 3 factored out of the edge sum)
 size_t f1_state_bytes(int m, int nb);

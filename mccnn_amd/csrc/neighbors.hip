@@ -188,20 +188,23 @@ __global__ __launch_bounds__(256) void pdf_edges_ref(const float* __restrict__ p
 }
 
 // ---- single-precision KDE (mode 1) ------------------------------------------------------------------
-// Pre-pass: one float4 per edge with the neighbour's coordinates already scaled by 1/(R_b h); the pair loop
-// then costs one (wave-broadcast) 16-byte load and ~9 VALU instructions per pair.
-__global__ __launch_bounds__(256) void pdf_scaled_coords(const float* __restrict__ pts, const int* __restrict__ bids,
-                                                         const int2* __restrict__ packed, int e,
-                                                         const float* __restrict__ mn, const float* __restrict__ mx,
-                                                         float window, float radius, int scaleInv,
-                                                         float4* __restrict__ sc) {
+// Pre-pass: one float4 per edge with the neighbour's RAW coordinates and, in .w, the scale 1/(R_b h) of its cloud.
+// The pair loop subtracts raw coordinates -- the difference of two nearby floats is (nearly) exact, as in the
+// reference's (p_a - p_b) * invRadH (compute_pdf.cu:78-80) -- and applies the scale to the squared distance; scaling
+// the absolute coordinates first would lose |p| / (R h) * 2^-24 to cancellation (1e-3 for a scene 100 m from the
+// origin at r = 0.1).
+__global__ __launch_bounds__(256) void pdf_edge_coords(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                       const int2* __restrict__ packed, int e,
+                                                       const float* __restrict__ mn, const float* __restrict__ mx,
+                                                       float window, float radius, int scaleInv,
+                                                       float4* __restrict__ sc) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= e) return;
     int j = packed[t].x;
     float R = scaleInv ? radius * max_extent(mn, mx, bids[j]) : radius;
     float s = (float)(1.0 / (double)(R * window));
     const float* p = pts + (size_t)j * 3;
-    sc[t] = make_float4(p[0] * s, p[1] * s, p[2] * s, 0.f);
+    sc[t] = make_float4(p[0], p[1], p[2], s);
 }
 
 // Mode 1, row form: one wave per centre. Lanes hold the row's own points (a), the loop runs over the row's points b
@@ -219,7 +222,6 @@ __global__ __launch_bounds__(256) void pdf_rows(const float4* __restrict__ sc, c
     const int i1 = __builtin_amdgcn_readfirstlane((row < m - 1) ? startIdx[row + 1] : e);
     const int k = i1 - i0;
     if (k <= 0) return;
-    const float c = -0.5f * 1.44269504088896f;  // exp(-x/2) = exp2(c x)
     const float invH = 1.0f / window;
     const float g1 = invH * 0.39894228f;
     const float norm = g1 * g1 * g1;
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(256) void pdf_rows(const float4* __restrict__ sc, c
     for (int a0 = 0; a0 < k; a0 += 64) {
         const int a = a0 + lane;
         const float4 me = rowp[min(a, k - 1)];
+        const float c = (-0.5f * 1.44269504088896f) * (me.w * me.w);  // exp(-|d s|^2 / 2) = exp2(c |d|^2), s = 1 / (R h)
         float acc = 0.f;
         int b = 0;
         for (; b + 4 <= k; b += 4) {
@@ -347,7 +350,7 @@ int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, cons
     else {
         if (!ws || ws_bytes < mccnn_compute_pdf_workspace_bytes(e, mode)) return MCCNN_E_WORKSPACE;
         float4* sc = (float4*)ws;
-        pdf_scaled_coords<<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, e, aabb_min, aabb_max,
+        pdf_edge_coords<<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, e, aabb_min, aabb_max,
                                                           window, radius, scale_inv, sc);
         MCCNN_LAUNCHED();
         pdf_rows<<<ceil_div(m, 4), 256, 0, s>>>(sc, start_idx, m, e, window, pdfs);

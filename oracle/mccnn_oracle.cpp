@@ -10,7 +10,7 @@
 // it can neither be imported nor compiled in this image. This oracle is pinned
 // instead by (a) the structural known answers that do exist in the reference
 // (the two 27-entry offset tables, the Gaussian constant, the numCells formula),
-// (b) an independent NumPy float64 brute-force cross-check (oracle/np_reference.py),
+// (b) an independent NumPy float64 brute-force cross-check (tests/test_oracle_cpu.py),
 // (c) finite-difference gradient checks and (d) invariants -- see tests/.
 //
 // Canonical order. Two reference kernels depend on atomic arrival order
@@ -19,9 +19,11 @@
 // ascending original index within a grid cell, and for Poisson sampling
 // batch -> phase 0..26 -> cell in launch-linear thread order -> point order.
 //
-// Arithmetic: every float expression is evaluated in the precision and order the
-// reference source spells out (build with -ffp-contract=off); doubles appear
-// only where the reference promotes (compute_pdf.cu:72-92).
+// Arithmetic: the geometry (cell coordinates, distances, KDE) is evaluated in the
+// precision and order the reference source spells out (build with -ffp-contract=off);
+// doubles appear only where the reference promotes (compute_pdf.cu:72-92). The kernel
+// MLP follows the reference as nvcc compiles it: fused multiply-add chains, see
+// layer1() / dot8() below.
 //
 // With -fopenmp the per-centre / per-point loops run in parallel (used only for
 // the cpu_baseline timing leg); integer outputs are unchanged by that, float
@@ -69,6 +71,27 @@ inline int cellCoord(float p, float mn, float cellSize, int nc) {
 }
 
 inline float relu(float x) { return x > 0.0f ? x : 0.0f; }  // max(x, 0.0), spatial_conv.cu:49
+
+// Kernel-MLP arithmetic as the reference is COMPILED, not as a strict C reading of its source: nvcc contracts
+// float `a*b + c` into one fused multiply-add by default (-fmad=true), and where the source promotes to double
+// (`auxResult += max(x, 0.0)*w`, spatial_conv.cu:375,390: the double product of two floats is exact, the sum is
+// rounded once on the assignment to the float accumulator) the result is a fused multiply-add as well. So every
+// hidden-layer sum is a k-ordered fmaf chain that starts at 0, and the bias is added last, where the source adds it
+// (spatial_conv.cu:57-62, 68-73, 372-378). This file is built with -ffp-contract=off: the chains are spelled out.
+//
+// Layer 1 (spatial_conv.cu:49-52, 363-366): c0*w0 + c1*w1 + c2*w2 + b, contracted left to right.
+inline float layer1(const float d[3], const float* w, float b) {
+    float t = d[0] * w[0];
+    t = std::fmaf(d[1], w[1], t);
+    t = std::fmaf(d[2], w[2], t);
+    return t + b;
+}
+// sum_{k<8} x[k] * w[k*stride], sequential in k, accumulator starts at 0 (spatial_conv.cu:57-61, 428-433)
+inline float dot8(const float* x, const float* w, int stride) {
+    float a = 0.0f;
+    for (int k = 0; k < MLP; ++k) a = std::fmaf(x[k], w[k * stride], a);
+    return a;
+}
 
 }  // namespace
 
@@ -402,18 +425,13 @@ int orc_spatial_conv_fwd(const float* pts, const float* feats, const int* bids, 
                 float h1[MLP], h2[MLP];
                 for (int t8 = 0; t8 < MLP; ++t8) {
                     int nu = off + t8;
-                    h1[t8] = relu(d[0] * w1[nu * 3] + d[1] * w1[nu * 3 + 1] + d[2] * w1[nu * 3 + 2] + b1[nu]);
+                    h1[t8] = relu(layer1(d, &w1[nu * 3], b1[nu]));
                 }
-                for (int t8 = 0; t8 < MLP; ++t8) {
-                    float a = 0.0f;
-                    for (int k = 0; k < MLP; ++k) a += h1[k] * w2[off * MLP + t8 * MLP + k];
-                    h2[t8] = relu(a + b2[off + t8]);
-                }
+                for (int t8 = 0; t8 < MLP; ++t8) h2[t8] = relu(dot8(h1, &w2[off * MLP + t8 * MLP], 1) + b2[off + t8]);
                 for (int t8 = 0; t8 < MLP; ++t8) {
                     int nu = off + t8;
                     if (nu >= neuronsOut) continue;
-                    float a = 0.0f;
-                    for (int k = 0; k < MLP; ++k) a += h2[k] * w3[off * MLP + t8 * MLP + k];
+                    float a = dot8(h2, &w3[off * MLP + t8 * MLP], 1);
                     a = a + b3[nu];
                     int fin = nu % Fin;
                     int fo = combin ? nu / Fin : fin;
@@ -489,14 +507,15 @@ int orc_spatial_conv_bwd(const float* pts, const float* feats, const int* bids, 
                 for (int q = 0; q < nb; ++q) {
                     int off = q * MLP;
                     float pre1[MLP], pre2[MLP], t3[MLP], t4[MLP];
+                    float a1[MLP], a2[MLP];
                     for (int t8 = 0; t8 < MLP; ++t8) {
                         int nu = off + t8;
-                        pre1[t8] = d[0] * w1[nu * 3] + d[1] * w1[nu * 3 + 1] + d[2] * w1[nu * 3 + 2] + b1[nu];
+                        pre1[t8] = layer1(d, &w1[nu * 3], b1[nu]);
+                        a1[t8] = relu(pre1[t8]);
                     }
                     for (int t8 = 0; t8 < MLP; ++t8) {
-                        float a = 0.0f;
-                        for (int k = 0; k < MLP; ++k) a += relu(pre1[k]) * w2[off * MLP + t8 * MLP + k];
-                        pre2[t8] = a + b2[off + t8];
+                        pre2[t8] = dot8(a1, &w2[off * MLP + t8 * MLP], 1) + b2[off + t8];
+                        a2[t8] = relu(pre2[t8]);
                     }
                     int numOuts = std::min(neuronsOut - off, MLP);
                     for (int t8 = 0; t8 < numOuts; ++t8) {  // spatial_conv.cu:383-400
@@ -506,11 +525,8 @@ int orc_spatial_conv_bwd(const float* pts, const float* feats, const int* bids, 
                         float f = feats[(size_t)j * Fin + fin];
                         float og = g[fo];
                         float cf = (f * og) / c;
-                        float a = 0.0f;
-                        for (int k = 0; k < MLP; ++k) {
-                            pw3[off * MLP + t8 * MLP + k] += cf * relu(pre2[k]);
-                            a += relu(pre2[k]) * w3[off * MLP + t8 * MLP + k];
-                        }
+                        for (int k = 0; k < MLP; ++k) pw3[off * MLP + t8 * MLP + k] += cf * a2[k];
+                        float a = dot8(a2, &w3[off * MLP + t8 * MLP], 1);
                         pb3[nu] += cf;
                         a = a + b3[nu];
 #pragma omp atomic
@@ -523,19 +539,17 @@ int orc_spatial_conv_bwd(const float* pts, const float* feats, const int* bids, 
                             int nu = off + k;
                             int fin = nu % Fin;
                             int fo = combin ? nu / Fin : fin;
-                            a += g[fo] * feats[(size_t)j * Fin + fin] * w3[off * MLP + t8 + k * MLP];
+                            a = std::fmaf(g[fo] * feats[(size_t)j * Fin + fin], w3[off * MLP + t8 + k * MLP], a);
                         }
                         t3[t8] = (cf * a) / c;
                     }
                     for (int t8 = 0; t8 < MLP; ++t8) {  // :419-425
-                        for (int k = 0; k < MLP; ++k) pw2[off * MLP + t8 * MLP + k] += t3[t8] * relu(pre1[k]);
+                        for (int k = 0; k < MLP; ++k) pw2[off * MLP + t8 * MLP + k] += t3[t8] * a1[k];
                         pb2[off + t8] += t3[t8];
                     }
                     for (int t8 = 0; t8 < MLP; ++t8) {  // :428-434
-                        float a = 0.0f;
                         float cf = (pre1[t8] >= 0.0f) ? 1.0f : 0.0f;
-                        for (int k = 0; k < MLP; ++k) a += t3[k] * w2[off * MLP + t8 + k * MLP];
-                        t4[t8] = cf * a;
+                        t4[t8] = cf * dot8(t3, &w2[off * MLP + t8], MLP);
                     }
                     for (int t8 = 0; t8 < MLP; ++t8) {  // :439-444
                         for (int k = 0; k < 3; ++k) pw1[(off + t8) * 3 + k] += t4[t8] * d[k];

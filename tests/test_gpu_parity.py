@@ -75,6 +75,21 @@ def test_grid_neighbors_pdf_poisson(mc, oracle, case):
     assert_close(_unwrap(fast), o["pdfs"], RTOL, "pdfs(mode 1)")
 
 
+def test_pdf_translated_cloud(mc, oracle):
+    """Scene far from the origin (+500 m, absolute radius 0.1): the single-precision KDE subtracts raw coordinates
+    before it scales (compute_pdf.cu:78-80), so its error does not grow with |p| / (R h)."""
+    pts, bids = make_cloud(3000, 2, 17, "uniform")
+    pts = (pts + np.float32(500.0)).astype(np.float32)
+    feats = np.ones((len(pts), 1), np.float32)
+    g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, 2, 0.1, False, pdf_kwargs=dict(mode=0))
+    o = run_chain(oracle, _ident, _ident, pts, bids, feats, 2, 0.1, False)
+    compare_chain(g, o, pdf_rtol=2e-6)
+    h = g["_handles"]
+    fast = mc.compute_pdf(h["sP"], h["sB"], h["mn"], h["mx"], h["start"], h["packed"], 0.2, 0.1, 2, False, mode=1)
+    err = np.abs(_unwrap(fast) - o["pdfs"]).max() / np.abs(o["pdfs"]).max()
+    assert err <= 2e-5, err   # same error as at the origin (~1e-5), far inside RTOL
+
+
 def test_dense_cells(mc, oracle):
     """A few very dense cells (>1000 points in one 27-window): exercises the streaming branch of the Poisson kernel,
     long cell segments in the stable ranking and long CSR rows."""
@@ -168,14 +183,12 @@ def test_spatial_conv_fwd_bwd(mc, oracle, case):
     neurons = fin * fout if combin else fin
     got = [sF.grad, tw["w1"].grad, tw["b1"].grad, tw["w2"].grad, tw["b2"].grad, tw["w3"].grad, tw["b3"].grad]
     names = ["featGrad", "dw1", "db1", "dw2", "db2", "dw3", "db3"]
-    # ReLU' = 1[pre >= 0] is discontinuous: the MFMA fma chain and the oracle's mul/add sequence round a
-    # pre-activation differently in the last bit, so among ~1e6..1e7 (edge, neuron) evaluations a handful near zero take
-    # the other branch, and in a gradient that is a sum of cancelling signed terms (dW1 = sum t4 (x) delta) one flipped
-    # term shows at ~1e-4 relative. Parameter gradients are therefore compared at 5e-4 against the oracle -- and at 2e-5
-    # against independent GPU implementations that share the fma-chain arithmetic of the pre-activations.
-    ptol = 5e-4
+    # ReLU' = 1[pre >= 0] is discontinuous, so the pre-activations have to be bit-identical on both sides or a handful
+    # of (edge, neuron) terms near zero take the other branch: the MFMA chains (zero start, bias as the last k-step,
+    # correctly rounded delta = (p - c) / R) replay the oracle's fmaf chains exactly, and every gradient holds the
+    # north-star tolerance.
     for nm, a, b in zip(names, got, rg):
-        assert_close(_unwrap(a), b, RTOL if nm == "featGrad" else ptol, nm)
+        assert_close(_unwrap(a), b, RTOL, nm)
     # second implementation on the GPU: the VALU fallback kernels (every shape) and, for one input feature, the general
     # MFMA kernels instead of the factored ones -- selected per call through the environment
     import os
@@ -196,11 +209,9 @@ def test_spatial_conv_fwd_bwd(mc, oracle, case):
             del os.environ[env]
         assert_close(_unwrap(out), _unwrap(out2), 2e-5, label + ": forward")
         got2 = [sF2.grad, tw2["w1"].grad, tw2["b1"].grad, tw2["w2"].grad, tw2["b2"].grad, tw2["w3"].grad, tw2["b3"].grad]
-        # the VALU kernels divide by R where the MFMA kernels multiply by 1/R: pre-activations differ in the last bit
-        # and the ReLU' flips described above show up again; the two MFMA paths share every pre-activation
-        gtol = 3e-4 if env == "MCCNN_FORCE_VALU" else 2e-5
+        # all three GPU implementations share every pre-activation bit for bit; they differ in summation order only
         for nm, a, b in zip(names, got, got2):
-            assert_close(_unwrap(a), _unwrap(b), 2e-5 if nm == "featGrad" else gtol, label + ": " + nm)
+            assert_close(_unwrap(a), _unwrap(b), 2e-5, label + ": " + nm)
     # padded output neurons: the library writes zeros (reference leaves them uninitialised)
     dw3 = _unwrap(tw["w3"].grad).reshape(-1)
     assert np.all(dw3[neurons * 8:] == 0)
