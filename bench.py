@@ -10,12 +10,16 @@ drop-in builder API (mccnn_amd.MCConvBuilder.ConvolutionBuilder.create_convoluti
     fwd = sort_points_step1, sort_points_step2, find_neighbors, compute_pdf, spatial_conv
     bwd = spatial_conv_grad, sort_points_step2_grad            
 plus, for N > 1, ONE RCCL all-reduce of the flattened kernel-MLP weight gradients. The batch shards
-cloud-per-GPU (one 100k-point room per rank, weak scaling); there is no data-path collective.
+cloud-per-GPU; there is no data-path collective.
+    --scaling weak   (default) one 100k-point room per rank: the work grows with N
+    --scaling strong a fixed batch of --strong-rooms (8) rooms is split over the N ranks (BASELINE cfg4 at N = 8)
 Inputs are synthetic and resident in HBM before the timed region. The timed region is bracketed by
 barrier + torch.cuda.synchronize() on both sides and the max over ranks is reported.
 
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the field contract), including
   roofline     -- the dominant kernel's algorithmic flops (or bytes) / its HIP-event duration
+  layers       -- the same measurement for all three layer shapes of SURVEY 8d (1to64, 3to8, dw256), so that the
+                  headline shape cannot hide the depth-wise regime
   cpu_baseline -- the CPU oracle (OpenMP port of the reference algorithms; the reference's own ops
                   are GPU-only and cannot run on a CPU) timed on this box's host cores.
 """
@@ -40,17 +44,37 @@ LAYERS = {  # name: (Fin, Fout, combin)   -- SURVEY 8(d) layer shapes
 }
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector == f32 MFMA dense peak
+PROFILE_ROUND = "r02"    # profiles/<round>_pmc_traffic_<layer>.json supplies roofline.traffic
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_inputs(npts, rooms, rank, layer, device):
+def conv_bound(fin, combin):
+    """combin layers and small nb are bounded by matrix/FMA throughput, wide depth-wise layers by the
+    gather of feature / gradient rows (4 Fin bytes per edge and direction)."""
+    return "hbm" if (not combin and fin >= 64) else "mfma"
+
+
+def conv_work(which, fin, fout, combin, nb, n, m, e):
+    """(bound, algorithmic work per launch) of spatial_conv forward / backward."""
+    outF = fout if combin else fin
+    if conv_bound(fin, combin) == "mfma":
+        return "mfma", (320.0 if which == "fwd" else 912.0) * nb * e
+    fwd_bytes = e * (24 + 4 * fin) + m * (16 + 4 * outF)
+    if which == "fwd":
+        return "hbm", float(fwd_bytes)
+    # backward re-reads what forward reads, gathers the out-gradient row per edge, adds the E*4Fin feature-gradient
+    # contribution, reads M*4Fout and writes the 704*nb parameter gradients
+    return "hbm", float(fwd_bytes + e * 4 * fin + e * 4 * fin + m * 4 * outF + 704 * nb)
+
+
+def make_inputs(npts, seeds, layer, device, rank):
     from tests.helpers import make_room
     fin, fout, combin = LAYERS[layer]
-    pts = np.concatenate([make_room(npts, 20180601 + rank * rooms + r) for r in range(rooms)])
-    bids = np.repeat(np.arange(rooms, dtype=np.int32), npts).reshape(-1, 1)
+    pts = np.concatenate([make_room(npts, s) for s in seeds])
+    bids = np.repeat(np.arange(len(seeds), dtype=np.int32), npts).reshape(-1, 1)
     rng = np.random.default_rng(7 + rank)
     feats = (2 * rng.random((len(pts), fin)) - 1).astype(np.float32)
     outF = fout if combin else fin
@@ -60,7 +84,9 @@ def make_inputs(npts, rooms, rank, layer, device):
 
 
 def ev_time(fn, iters=5):
-    """Average HIP-event duration (ms) of fn() on the current stream, queue drained before each call."""
+    """Average HIP-event duration (ms) of fn() on the current stream (the one every C-ABI call is launched on), queue
+    drained before each call; one untimed call first."""
+    r = fn()
     ts = []
     for _ in range(iters):
         torch.cuda.synchronize()
@@ -73,18 +99,244 @@ def ev_time(fn, iters=5):
     return float(np.mean(ts)), r
 
 
+class Workload:
+    """One layer shape on this rank's share of the batch."""
+
+    def __init__(self, args, layer, seeds, rank, world, device):
+        from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+        self.args, self.layer, self.world, self.device = args, layer, world, device
+        self.fin, self.fout, self.combin = LAYERS[layer]
+        self.B = len(seeds)
+        (self.pts_np, self.bids_np, self.feats_np, self.ograd_np, self.P, self.Bi, self.F, self.OG) = make_inputs(
+            args.points, seeds, layer, device, rank)
+        self.F.requires_grad_(True)
+        # level-0-only hierarchy: computes the (whole-batch, absolute-radius) bounding box once, outside the step; with
+        # N > 1 the shards all-reduce it before anything is sorted (aabb_gpu.cu:104-114)
+        self.ph = PointHierarchy(self.P, self.F, self.Bi, [], "bench_PH", self.B, False,
+                                 aabbReduceGroup=True if world > 1 else None)
+        self.builder = ConvolutionBuilder(KDEWindow=args.window, relativeRadius=False)
+        torch.manual_seed(1234)  # identical kernel-MLP weights on every rank
+        self.bucket = None
+        self.out = self.step()  # creates the variables
+        self.e_local = int(next(iter(self.builder.cacheNeighs_.values()))[1].shape[0])
+
+    def step(self):
+        from mccnn_amd.dist import GradBucket
+        a = self.args
+        self.builder.reset()
+        self.F.grad = None
+        for p in self.builder.parameters():
+            p.grad = None
+        out = self.builder.create_convolution("Conv", self.ph, 0, self.F, self.fin, a.radius, outNumFeatures=self.fout,
+                                              multiFeatureConv=self.combin, KDEWindow=a.window)
+        out.backward(self.OG)
+        if self.world > 1:
+            if self.bucket is None:  # the variables exist after the first create_convolution
+                self.bucket = GradBucket(self.builder.parameters())
+            self.bucket.allreduce()
+        return out
+
+    def timed(self, steps, warmup):
+        """K timed steps after W warm-up steps; barrier + synchronize on both sides; max over ranks."""
+        for _ in range(max(warmup, 0)):
+            self.step()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        m_local = self.P.shape[0]
+        if self.world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            cnt = torch.tensor([m_local], dtype=torch.float64, device=self.device)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            m_total = float(cnt.item())
+        else:
+            m_total = float(m_local)
+        return elapsed / steps * 1e3, m_total * steps / elapsed, m_total
+
+    def breakdown(self):
+        """Per-op HIP-event times through the C-ABI on rank 0 and the roofline of the dominant op."""
+        from mccnn_amd import MCConvModule as M
+        from mccnn_amd._lib import ptr, stream_handle, check
+        a, B, P, Bi, device = self.args, self.B, self.P, self.Bi, self.device
+        fin, fout, combin = self.fin, self.fout, self.combin
+        mn, mx = self.ph.aabbMin_, self.ph.aabbMax_
+        r, w = a.radius, a.window
+        Fd = self.F.detach()
+        t_s1, (keys, idx) = ev_time(lambda: M.sort_points_step1(P, Bi, mn, mx, B, r, False))
+        t_s2, (sP, sB, sF, cells) = ev_time(lambda: M.sort_points_step2(P, Bi, Fd, keys, idx, mn, mx, B, r, False))
+        t_fn, (start, packed) = ev_time(lambda: M.find_neighbors(P, Bi, sP, cells, mn, mx, r, B, False))
+        t_pdf, pdfs = ev_time(lambda: M.compute_pdf(sP, sB, mn, mx, start, packed, w, r, B, False))
+        ws = [p.detach() for p in self.builder.parameters()]  # weights, biases, weights2, biases2, weights3, biases3
+        nb = ws[0].shape[1] // 8
+        w1, b1, w2, b2, w3, b3 = ws[0], ws[1], ws[2].reshape(8, -1), ws[3].reshape(-1), ws[4].reshape(8, -1), ws[5].reshape(-1)
+        lib = M._lib.load()
+        n, m, e = sP.shape[0], P.shape[0], packed.shape[0]
+        outF = fout if combin else fin
+        o = torch.empty((m, outF), dtype=torch.float32, device=device)
+        fwd_ws = torch.empty(max(256, lib.mccnn_spatial_conv_fwd_workspace_bytes(m, e, fin, fout, int(combin))),
+                             dtype=torch.uint8, device=device)
+        conv_args = (ptr(sP), ptr(sF), ptr(sB), ptr(pdfs), ptr(P), ptr(start), ptr(packed), ptr(mn), ptr(mx), ptr(w1),
+                     ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3))
+        sbytes = lib.mccnn_spatial_conv_state_bytes(m, fin, fout, int(combin))
+        state = torch.empty(sbytes, dtype=torch.uint8, device=device) if sbytes else None  # kept fwd -> bwd, as autograd does
+        t_fwd, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_fwd(*conv_args, n, m, e, fin, fout, int(combin), B, r, 0,
+                                                                    1, ptr(o), ptr(state), ptr(fwd_ws), fwd_ws.numel(),
+                                                                    stream_handle()), "conv_fwd"))
+        fg = torch.empty_like(sF)
+        gws = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]
+        bwd_ws = torch.empty(max(256, lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, fout, int(combin))),
+                             dtype=torch.uint8, device=device)
+        # the transposed neighbour list of depth-wise layers is built once per neighbour list and shared by the layers
+        # that convolve over it (ConvolutionBuilder caches the list the same way): timed on its own line
+        start_t = perm_t = None
+        t_tr = None
+        if not combin:
+            start_t = torch.empty(n + 1, dtype=torch.int32, device=device)
+            perm_t = torch.empty(max(e, 1), dtype=torch.int32, device=device)
+            tws = torch.empty(max(256, lib.mccnn_transpose_neighbors_workspace_bytes(n, e)), dtype=torch.uint8, device=device)
+            t_tr, _ = ev_time(lambda: check(lib.mccnn_transpose_neighbors(ptr(packed), e, n, ptr(start_t), ptr(perm_t),
+                                                                           ptr(tws), tws.numel(), stream_handle()),
+                                            "transpose_neighbors"))
+        t_bwd, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_bwd(*conv_args, ptr(self.OG), n, m, e, fin, fout, int(combin), B,
+                                                                    r, 0, 1, ptr(state), ptr(start_t), ptr(perm_t), ptr(fg),
+                                                                    *[ptr(g) for g in gws],
+                                                                    ptr(bwd_ws), bwd_ws.numel(), stream_handle()),
+                                         "conv_bwd"))
+        t_s2g, _ = ev_time(lambda: M._gather_rows(fg, idx, n))
+        C = int(np.prod(cells.shape[:4]))
+        # algorithmic work per launch (SURVEY 8d; stated in DESIGN.md section 6)
+        alg = {
+            "sort_points_step1": ("hbm", n * 16 + n * 8 + 4 * C, t_s1),
+            "sort_points_step2": ("hbm", n * (16 + 8 + 4 * fin) + n * (16 + 4 * fin) + 8 * C, t_s2),
+            "find_neighbors": ("hbm", 16 * m + 12 * n + 8 * C + 4 * m + 8 * e, t_fn),
+            "compute_pdf": ("hbm", 24 * e, t_pdf),
+            "spatial_conv_fwd": conv_work("fwd", fin, fout, combin, nb, n, m, e) + (t_fwd,),
+            "spatial_conv_bwd": conv_work("bwd", fin, fout, combin, nb, n, m, e) + (t_bwd,),
+            "sort_points_step2_grad": ("hbm", n * (4 + 8 * fin), t_s2g),
+        }
+        if t_tr is not None:
+            alg["transpose_neighbors"] = ("hbm", 8 * e + 4 * e + 4 * n, t_tr)
+        breakdown = {}
+        for k, (bound, work, ms) in alg.items():
+            ach = work / (ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
+            breakdown[k] = {"ms": round(ms, 4), "bound": bound, "achieved": round(ach, 3),
+                            "unit": "GB/s" if bound == "hbm" else "TFLOP/s"}
+        dom = max(alg, key=lambda k: alg[k][2])
+        bound, work, ms = alg[dom]
+        peak = HBM_PEAK_GBS if bound == "hbm" else F32_PEAK_TFLOPS
+        ach = work / (ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
+        roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak,
+                    "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "ms": round(ms, 4), "edges": e, "mlp_blocks": nb}
+        if combin and fin == 1:
+            # one-input-feature layers run the factored kernels (conv_f1.hip): layer 3 is applied per centre, so fewer
+            # flops are EXECUTED than the algorithm of SURVEY 8d counts; `achieved` keeps the contract's algorithmic
+            # figure (an effective rate), this is the rate of the arithmetic actually issued
+            ex = {"spatial_conv_fwd": 224.0 * nb * e + 144.0 * nb * m, "spatial_conv_bwd": 560.0 * nb * e + 290.0 * nb * m}
+            if dom in ex:
+                roofline["executed_tflops"] = round(ex[dom] / (ms * 1e-3) / 1e12, 3)
+                roofline["executed_frac"] = round(roofline["executed_tflops"] / peak, 4)
+        # HBM-side bytes per launch of the dominant kernel come from the separate rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE passes of THIS command (tools/prof.sh), committed under profiles/ -- bench.py cannot collect
+        # counters itself; null when the committed profile does not cover this workload.
+        tfile = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PROFILE_ROUND, self.layer))
+        if dom == "spatial_conv_bwd" and os.path.exists(tfile) and a.points == 100000 and B == 1:
+            with open(tfile) as fh:
+                for kname, tr in json.load(fh).items():
+                    if kname.startswith("conv_bwd_mfma") or kname.startswith("f1_bwd_edges"):
+                        roofline["traffic"] = int(tr["bytes"])
+                        roofline["traffic_source"] = "profiles/" + os.path.basename(tfile)
+        return roofline, breakdown
+
+
+def cpu_baseline(wl, out_gpu):
+    """SURVEY 8d: the oracle's OpenMP build on all host cores, identical workload, median of 5 steps after one warm-up;
+    plus a single-thread figure on a bounded sample (a slab of the same room holding 1/16 of the points)."""
+    from oracle.oracle import Oracle
+    a = wl.args
+    ws = [p.detach().cpu().numpy() for p in wl.builder.parameters()]
+    w1, b1, w2, b2, w3, b3 = ws[0], ws[1], ws[2].reshape(8, -1), ws[3].reshape(-1), ws[4].reshape(8, -1), ws[5].reshape(-1)
+
+    def make_step(orc, pts, bids, feats, ograd, B):
+        mn, mx = orc.compute_aabb(pts, bids, B, False)
+
+        def cpu_step():
+            k, i = orc.sort_points_step1(pts, bids, mn, mx, B, a.radius, False)
+            sp, sb, sf, cl = orc.sort_points_step2(pts, bids, feats, k, i, mn, mx, B, a.radius, False)
+            st, pk = orc.find_neighbors(pts, bids, sp, cl, mn, mx, a.radius, B, False)
+            pdf = orc.compute_pdf(sp, sb, mn, mx, st, pk, a.window, a.radius, B, False)
+            arg = (sp, sf, sb, pdf, pts, st, pk, mn, mx, w1, w2, w3, b1, b2, b3)
+            oc = orc.spatial_conv(*arg, wl.fout, wl.combin, B, a.radius, False, True)
+            g = orc.spatial_conv_grad(*arg, ograd, wl.fout, wl.combin, B, a.radius, False, True)
+            orc.sort_points_step2_grad(i, np.zeros_like(sp), g[0])
+            return oc
+        return cpu_step
+
+    def median_of(fn, runs, budget_s):
+        oc = fn()  # warm-up
+        ts = []
+        t0 = time.perf_counter()
+        while len(ts) < runs and (len(ts) < 1 or time.perf_counter() - t0 < budget_s):
+            c0 = time.perf_counter()
+            oc = fn()
+            ts.append(time.perf_counter() - c0)
+        return float(np.median(ts)), len(ts), oc
+
+    orc = Oracle(omp=True)
+    step = make_step(orc, wl.pts_np, wl.bids_np, wl.feats_np, wl.ograd_np, wl.B)
+    med, runs, oc = median_of(step, 5, 25.0)
+    m_local = len(wl.pts_np)
+    cpu = {"value": round(m_local / med, 1), "unit": "points/s", "cores": orc.num_threads(), "kind": "port",
+           "sample": "median of %d steps (fwd+bwd) of the identical workload after 1 warm-up, OpenMP over centres, "
+                     "%.2f s per step" % (runs, med)}
+    err = float(np.abs(out_gpu.detach().cpu().numpy() - oc).max() / max(np.abs(oc).max(), 1e-30))
+    cpu["gpu_vs_oracle_max_rel_err"] = float("%.3e" % err)
+    # single thread: a slab of the first room along x holding 1/16 of its points (same density, so the same number of
+    # neighbours per point away from the two cut faces)
+    try:
+        first = wl.pts_np[:a.points]
+        order = np.argsort(first[:, 0], kind="stable")
+        k = max(len(first) // 16, 1)
+        lo = (len(first) - k) // 2
+        sel = np.sort(order[lo:lo + k])
+        orc1 = Oracle(omp=False)
+        step1 = make_step(orc1, first[sel], np.zeros((k, 1), np.int32), wl.feats_np[:a.points][sel],
+                          wl.ograd_np[:a.points][sel], 1)
+        med1, runs1, _ = median_of(step1, 3, 20.0)
+        cpu["single_thread"] = {"value": round(k / med1, 1), "unit": "points/s", "cores": 1,
+                                "sample": "median of %d steps on a %d-point x-slab of the room (1/16 of the points, "
+                                          "same density), %.2f s per step" % (runs1, k, med1)}
+    except Exception as ex:  # informative only
+        cpu["single_thread"] = {"error": repr(ex)}
+    return cpu
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100000, help="points per room")
-    ap.add_argument("--rooms-per-gpu", type=int, default=1)
+    ap.add_argument("--rooms-per-gpu", type=int, default=1, help="weak scaling: rooms on every rank")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--strong-rooms", type=int, default=8, help="strong scaling: rooms in the fixed batch")
     ap.add_argument("--layer", choices=sorted(LAYERS), default="1to64")
     ap.add_argument("--radius", type=float, default=0.1)
     ap.add_argument("--window", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-layers", action="store_true", help="skip the per-layer-shape measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,200 +365,73 @@ def main():
         mbuild.build()
     if world > 1:
         dist.barrier()
-    from mccnn_amd import MCConvModule as M
-    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
-    from mccnn_amd.dist import GradBucket, allreduce_aabb
 
-    fin, fout, combin = LAYERS[args.layer]
-    B = args.rooms_per_gpu
-    npts = args.points
-    pts_np, bids_np, feats_np, ograd_np, P, Bi, F, OG = make_inputs(npts, B, rank, args.layer, device)
-    F.requires_grad_(True)
-    m_local = P.shape[0]
-
-    # level-0-only hierarchy: computes the (whole-batch, absolute-radius) bounding box once, outside the step
-    ph = PointHierarchy(P, F, Bi, [], "bench_PH", B, False)
-    if world > 1:
-        allreduce_aabb(ph.aabbMin_, ph.aabbMax_)
-    builder = ConvolutionBuilder(KDEWindow=args.window, relativeRadius=False)
-    torch.manual_seed(1234)  # identical kernel-MLP weights on every rank
-
-    state = {"bucket": None}
-
-    def step():
-        builder.reset()
-        F.grad = None
-        for p in builder.parameters():
-            p.grad = None
-        out = builder.create_convolution("Conv", ph, 0, F, fin, args.radius, outNumFeatures=fout,
-                                         multiFeatureConv=combin, KDEWindow=args.window)
-        out.backward(OG)
-        if world > 1:
-            if state["bucket"] is None:  # the variables exist after the first create_convolution
-                state["bucket"] = GradBucket(builder.parameters())
-            state["bucket"].allreduce()
-        return out
-
-    out = step()  # creates the variables
-    e_local = int(next(iter(builder.cacheNeighs_.values()))[1].shape[0])
-    for _ in range(max(args.warmup - 1, 0)):
-        step()
-
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        cnt = torch.tensor([m_local], dtype=torch.float64, device=device)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        m_total = float(cnt.item())
+    # which rooms this rank owns: weak = its own rooms_per_gpu rooms; strong = its share of a fixed batch
+    if args.scaling == "strong":
+        from mccnn_amd.dist import cloud_partition
+        first, last = cloud_partition(args.strong_rooms, world)[rank]
+        seeds = [20180601 + r for r in range(first, last)]
+        if not seeds:
+            raise SystemExit("--scaling strong needs --strong-rooms >= number of ranks")
     else:
-        m_total = float(m_local)
-    ms_per_step = elapsed / args.steps * 1e3
-    value = m_total * args.steps / elapsed
+        seeds = [20180601 + rank * args.rooms_per_gpu + r for r in range(args.rooms_per_gpu)]
 
-    # ------------------------------------------------------------------ per-op breakdown + roofline (rank 0)
-    roofline, breakdown = None, None
+    wl = Workload(args, args.layer, seeds, rank, world, device)
+    ms_per_step, value, m_total = wl.timed(args.steps, max(args.warmup - 1, 0))
+
+    roofline = breakdown = None
     if rank == 0 and not args.no_breakdown:
-        mn, mx = ph.aabbMin_, ph.aabbMax_
-        r, w = args.radius, args.window
-        Fd = F.detach()
-        t_s1, (keys, idx) = ev_time(lambda: M.sort_points_step1(P, Bi, mn, mx, B, r, False))
-        t_s2, (sP, sB, sF, cells) = ev_time(lambda: M.sort_points_step2(P, Bi, Fd, keys, idx, mn, mx, B, r, False))
-        t_fn, (start, packed) = ev_time(lambda: M.find_neighbors(P, Bi, sP, cells, mn, mx, r, B, False))
-        t_pdf, pdfs = ev_time(lambda: M.compute_pdf(sP, sB, mn, mx, start, packed, w, r, B, False))
-        ws = [p.detach() for p in builder.parameters()]  # weights, biases, weights2, biases2, weights3, biases3
-        nb = ws[0].shape[1] // 8
-        w1, b1, w2, b2, w3, b3 = ws[0], ws[1], ws[2].reshape(8, -1), ws[3].reshape(-1), ws[4].reshape(8, -1), ws[5].reshape(-1)
-        lib = M._lib.load()
-        from mccnn_amd._lib import ptr, stream_handle, check
-        n, m, e = sP.shape[0], P.shape[0], packed.shape[0]
-        outF = fout if combin else fin
-        o = torch.empty((m, outF), dtype=torch.float32, device=device)
-        fwd_ws = torch.empty(max(256, lib.mccnn_spatial_conv_fwd_workspace_bytes(m, e, fin, fout, int(combin))),
-                             dtype=torch.uint8, device=device)
-        conv_args = (ptr(sP), ptr(sF), ptr(sB), ptr(pdfs), ptr(P), ptr(start), ptr(packed), ptr(mn), ptr(mx), ptr(w1),
-                     ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3))
-        sbytes = lib.mccnn_spatial_conv_state_bytes(m, fin, fout, int(combin))
-        state = torch.empty(sbytes, dtype=torch.uint8, device=device) if sbytes else None  # kept fwd -> bwd, as autograd does
-        t_fwd, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_fwd(*conv_args, n, m, e, fin, fout, int(combin), B, r, 0,
-                                                                    1, ptr(o), ptr(state), ptr(fwd_ws), fwd_ws.numel(),
-                                                                    stream_handle()), "conv_fwd"))
-        fg = torch.empty_like(sF)
-        gws = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]
-        bwd_ws = torch.empty(max(256, lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, fout, int(combin))),
-                             dtype=torch.uint8, device=device)
-        # start_t / perm_t = NULL: the call builds the transposed list itself (worst case: no sharing across layers)
-        t_bwd, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_bwd(*conv_args, ptr(OG), n, m, e, fin, fout, int(combin), B,
-                                                                    r, 0, 1, ptr(state), None, None, ptr(fg),
-                                                                    *[ptr(g) for g in gws],
-                                                                    ptr(bwd_ws), bwd_ws.numel(), stream_handle()),
-                                         "conv_bwd"))
-        t_s2g, _ = ev_time(lambda: M._gather_rows(fg, idx, n))
-        C = int(np.prod(cells.shape[:4]))
-        # algorithmic work per launch (stated in DESIGN.md)
-        alg = {
-            "sort_points_step1": ("hbm", n * 16 + n * 8 + 4 * C, t_s1),
-            "sort_points_step2": ("hbm", n * (16 + 8 + 4 * fin) + n * (16 + 4 * fin) + 8 * C, t_s2),
-            "find_neighbors": ("hbm", 16 * m + 12 * n + 8 * C + 4 * m + 8 * e, t_fn),
-            "compute_pdf": ("hbm", 24 * e, t_pdf),
-            "spatial_conv_fwd": ("mfma", 320.0 * nb * e, t_fwd),
-            "spatial_conv_bwd": ("mfma", 912.0 * nb * e, t_bwd),
-            "sort_points_step2_grad": ("hbm", n * (4 + 8 * fin), t_s2g),
-        }
-        breakdown = {}
-        for k, (bound, work, ms) in alg.items():
-            ach = work / (ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
-            breakdown[k] = {"ms": round(ms, 4), "bound": bound, "achieved": round(ach, 3),
-                            "unit": "GB/s" if bound == "hbm" else "TFLOP/s"}
-        dom = max(alg, key=lambda k: alg[k][2])
-        bound, work, ms = alg[dom]
-        peak = HBM_PEAK_GBS if bound == "hbm" else F32_PEAK_TFLOPS
-        ach = work / (ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
-        roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak,
-                    "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                    "ms": round(ms, 4), "edges": e, "mlp_blocks": nb}
-        if combin and fin == 1:
-            # one-input-feature layers run the factored kernels (conv_f1.hip): layer 3 is applied per centre, so fewer
-            # flops are EXECUTED than the algorithm of SURVEY 8d counts; `achieved` keeps the contract's algorithmic
-            # figure (an effective rate), this is the rate of the arithmetic actually issued
-            ex = {"spatial_conv_fwd": 192.0 * nb * e + 144.0 * nb * m, "spatial_conv_bwd": 528.0 * nb * e + 290.0 * nb * m}
-            if dom in ex:
-                roofline["executed_tflops"] = round(ex[dom] / (ms * 1e-3) / 1e12, 3)
-                roofline["executed_frac"] = round(roofline["executed_tflops"] / peak, 4)
-        # HBM-side bytes per launch of the dominant kernel come from the separate rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE passes of THIS command (tools/prof.sh), committed under profiles/ -- bench.py cannot collect
-        # counters itself; null when the committed profile does not cover this workload.
-        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_%s.json" % args.layer)
-        if dom == "spatial_conv_bwd" and os.path.exists(tfile) and args.points == 100000 and args.rooms_per_gpu == 1:
-            with open(tfile) as fh:
-                for kname, tr in json.load(fh).items():
-                    if kname.startswith("conv_bwd_mfma") or kname.startswith("f1_bwd_edges"):
-                        roofline["traffic"] = int(tr["bytes"])
-                        roofline["traffic_source"] = "profiles/" + os.path.basename(tfile)
+        roofline, breakdown = wl.breakdown()
+
+    # ------------------------------------------------------------------ all three layer shapes (every rank takes part)
+    layers = None
+    if not args.no_layers:
+        layers = {}
+        for name in sorted(LAYERS):
+            w2 = wl if name == args.layer else Workload(args, name, seeds, rank, world, device)
+            if w2 is wl:
+                ms, val = ms_per_step, value
+            else:
+                ms, val, _ = w2.timed(max(args.steps // 2, 3), 2)
+            ent = {"ms_per_step": round(ms, 4), "value": round(val, 1), "unit": "points/s", "edges_per_gpu": w2.e_local}
+            if rank == 0 and not args.no_breakdown:
+                rl, bd = (roofline, breakdown) if w2 is wl else w2.breakdown()
+                ent["roofline"] = rl
+                ent["conv_ms"] = {"fwd": bd["spatial_conv_fwd"]["ms"], "bwd": bd["spatial_conv_bwd"]["ms"]}
+                ent["conv_rate"] = {"fwd": bd["spatial_conv_fwd"], "bwd": bd["spatial_conv_bwd"]}
+            layers[name] = ent
+            if w2 is not wl:
+                del w2
+                torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N == 1)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            from oracle.oracle import Oracle
-            orc = Oracle(omp=True)
-            ws = [p.detach().cpu().numpy() for p in builder.parameters()]
-            w1, b1, w2, b2, w3, b3 = ws[0], ws[1], ws[2].reshape(8, -1), ws[3].reshape(-1), ws[4].reshape(8, -1), ws[5].reshape(-1)
-            mn, mx = orc.compute_aabb(pts_np, bids_np, B, False)
-            def cpu_step():
-                k, i = orc.sort_points_step1(pts_np, bids_np, mn, mx, B, args.radius, False)
-                sp, sb, sf, cl = orc.sort_points_step2(pts_np, bids_np, feats_np, k, i, mn, mx, B, args.radius, False)
-                st, pk = orc.find_neighbors(pts_np, bids_np, sp, cl, mn, mx, args.radius, B, False)
-                pdf = orc.compute_pdf(sp, sb, mn, mx, st, pk, args.window, args.radius, B, False)
-                a = (sp, sf, sb, pdf, pts_np, st, pk, mn, mx, w1, w2, w3, b1, b2, b3)
-                oc = orc.spatial_conv(*a, fout, combin, B, args.radius, False, True)
-                g = orc.spatial_conv_grad(*a, ograd_np, fout, combin, B, args.radius, False, True)
-                orc.sort_points_step2_grad(i, np.zeros_like(sp), g[0])
-                return oc
-
-            # bounded sample: whole steps of the identical workload until ~3 s of wall time (>= 2 steps), best step
-            times = []
-            tstart = time.perf_counter()
-            while len(times) < 2 or (time.perf_counter() - tstart < 3.0 and len(times) < 8):
-                c0 = time.perf_counter()
-                oc = cpu_step()
-                times.append(time.perf_counter() - c0)
-            best = min(times)
-            cpu = {"value": round(m_local / best, 1), "unit": "points/s", "cores": orc.num_threads(),
-                   "kind": "port",
-                   "sample": "%d steps (fwd+bwd) of the identical workload, OpenMP over centres, best step %.2f s "
-                             "(%.0f core-seconds in total)" % (len(times), best, sum(times) * orc.num_threads())}
-            # cross-check the GPU result of the timed workload against the oracle (same inputs)
-            err = float(np.abs(out.detach().cpu().numpy() - oc).max() / max(np.abs(oc).max(), 1e-30))
-            cpu["gpu_vs_oracle_max_rel_err"] = float("%.3e" % err)
+            cpu = cpu_baseline(wl, wl.out)
         except Exception as ex:  # the baseline is informative; never fail the bench on it
             cpu = {"error": repr(ex)}
 
     if rank == 0:
+        fin, fout, combin = LAYERS[args.layer]
+        B = len(seeds)
+        if args.scaling == "strong":
+            par = "fixed batch of %d rooms split cloud-per-GPU over %d rank(s)" % (args.strong_rooms, world)
+        else:
+            par = "cloud-per-GPU dp%d" % world
         rec = {
             "metric": "MC-convolved points/sec (fwd+bwd), 100k-pt cloud r=0.1",
             "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ScanNet-like non-uniform room, %d pts/room, %d room(s)/GPU, absolute radius %g, "
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ScanNet-like non-uniform room, %d pts/room, %d room(s) on rank 0, absolute radius %g, "
                                    "KDE window %g, same-level conv %s (Fin=%d, Fout=%d, %s), avg on"
-                                   % (npts, B, args.radius, args.window, args.layer, fin, fout,
+                                   % (args.points, B, args.radius, args.window, args.layer, fin, fout,
                                       "combin" if combin else "depth-wise"),
-                       "points_per_gpu": m_local, "edges_per_gpu": e_local, "layer": args.layer,
-                       "parallelism": "cloud-per-GPU dp%d" % world},
-            "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown,
+                       "points_total": int(m_total), "points_per_gpu": int(wl.P.shape[0]), "edges_per_gpu": wl.e_local,
+                       "layer": args.layer, "parallelism": par,
+                       "collective_backend": (backend if world > 1 else None), "rccl_world_size": world},
+            "roofline": roofline, "cpu_baseline": cpu, "layers": layers, "breakdown": breakdown,
         }
         print(json.dumps(rec), flush=True)
     if world > 1:

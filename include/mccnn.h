@@ -47,7 +47,7 @@ typedef void* mccnn_stream_t; /* hipStream_t */
 
 #define MCCNN_OK 0
 #define MCCNN_E_BADARG (-1)     /* null pointer / non-positive size            */
-#define MCCNN_E_BATCHID (-2)    /* reserved (batch id outside [0,B))           */
+#define MCCNN_E_BATCHID (-2)    /* batch id outside [0,B): raised by the binding from mccnn_check_batch_ids */
 #define MCCNN_E_TOOLARGE (-3)   /* B*nc^3 or E does not fit int32              */
 #define MCCNN_E_WORKSPACE (-4)  /* workspace smaller than *_workspace_bytes    */
 #define MCCNN_E_SHAPE (-5)      /* MLP shape rules of spatial_conv.cc:258-300  */
@@ -58,6 +58,14 @@ int mccnn_block_size(void);
 int mccnn_abi_version(void);
 const char* mccnn_arch(void);
 const char* mccnn_error_string(int code);
+
+/* Batch ids index per-cloud tables (boxes, cell grids) in every op. The reference never checks them
+ * (an id outside [0, batch_size) reads / writes out of bounds: sort_gpu.cu:46-59, aabb_gpu.cu:97-103). Here
+ * every kernel clamps the id before it indexes (memory-safe, result unspecified for invalid input) and this
+ * asynchronous check counts the invalid ids into *bad_count_dev, for a binding that wants to raise
+ * MCCNN_E_BATCHID (costs the caller one 4-byte read-back; mccnn_amd.MCConvModule.CHECK_BATCH_IDS). */
+int mccnn_check_batch_ids(const int* batch_ids, int n, int batch_size, int* bad_count_dev,
+                          mccnn_stream_t stream);
 
 /* ComputeAabb -- aabb_gpu.cc:22-86, aabb_gpu.cu:57-140.
  * scale_inv == 0: every row receives the whole-batch box (aabb_gpu.cu:104-114). */
@@ -213,6 +221,12 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats,
 size_t mccnn_transpose_neighbors_workspace_bytes(int n, int e);
 int mccnn_transpose_neighbors(const int* packed, int e, int n, int* start_t, int* perm_t, void* ws,
                               size_t ws_bytes, mccnn_stream_t stream);
+
+/* TEST HOOK, not part of the operator surface: selects the convolution implementation for A/B
+ * parity tests (bit 0: VALU fallback kernels, bit 1: general MFMA kernels for one-input-feature
+ * layers; 0 = product default). Returns the previous mask. Initial value: MCCNN_FORCE_VALU /
+ * MCCNN_NO_F1 in the environment, read once. */
+int mccnn_debug_conv_impl(int mask);
 
 #ifdef __cplusplus
 }

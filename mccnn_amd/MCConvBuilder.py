@@ -33,7 +33,12 @@ class PointHierarchy:
     """
 
     def __init__(self, inPoints, inFeatures, inBatchIds, radiusList, hierarchyName="Point_Hierarchy", batchSize=32,
-                 relativeRadius=True):
+                 relativeRadius=True, aabbReduceGroup=None):
+        """aabbReduceGroup (extension, data-parallel shards only): with relativeRadius=False the reference uses ONE box
+        for the whole batch (aabb_gpu.cu:104-114). A shard that holds part of the batch passes its process group here
+        (`True` = the default group) and the MIN/MAX all-reduce of the box runs between compute_aabb and the first
+        sort, so every level of the sharded hierarchy -- cells, keys, Poisson samples -- equals the corresponding
+        slice of the single-device hierarchy (mccnn_amd.dist)."""
         self.points_ = [inPoints]
         self.features_ = [inFeatures]
         self.batchIds_ = [inBatchIds]
@@ -44,6 +49,9 @@ class PointHierarchy:
         self.hierarchyName_ = hierarchyName
 
         aabbMin, aabbMax = compute_aabb(inPoints, inBatchIds, batchSize, self.relativeRadius_)
+        if aabbReduceGroup is not None and not self.relativeRadius_:
+            from .dist import allreduce_aabb
+            aabbMin, aabbMax = allreduce_aabb(aabbMin, aabbMax, None if aabbReduceGroup is True else aabbReduceGroup)
         self.aabbMin_ = aabbMin
         self.aabbMax_ = aabbMax
         _log("########## Point Hierarchy: %s (Rel: %s)" % (hierarchyName, relativeRadius))

@@ -10,6 +10,7 @@ Shape / attribute validation mirrors the OP_REQUIRES blocks of the reference wra
 raises InvalidArgumentError (the analogue of tf.errors.InvalidArgumentError).
 """
 import ctypes as C
+import threading
 import weakref
 
 import torch
@@ -76,7 +77,7 @@ def _tensor_key(t):
     # storage address + version: autograd hands the op a different tensor OBJECT over the same storage, so object
     # identity cannot be used here. A recycled address can only yield a stale permutation of the same length,
     # which is still a valid visiting order (results do not depend on it).
-    return (t.data_ptr(), t._version, t.shape[0])
+    return (t.device.index, t.data_ptr(), t._version, t.shape[0])
 
 
 def _remember_order(points, kind, payload):
@@ -105,25 +106,29 @@ def _order_hint(points):
     return ent[2]
 
 
-_EDGE_GUESS = {}  # (M, N, radius, B, scaleInv) -> capacity to try first in find_neighbors
-_PINNED = []
+_EDGE_GUESS = {}  # (device, M, N, radius, B, scaleInv) -> capacity to try first in find_neighbors
+_TLS = threading.local()
 
 
 def _pinned_int():
-    if not _PINNED:
-        _PINNED.append(torch.empty(1, dtype=torch.int32).pin_memory())
-    return _PINNED[0]
+    """One pinned int32 per host thread: the copy into it and the wait for it happen back to back on the calling
+    thread, so concurrent callers (threads / streams) never share a slot."""
+    buf = getattr(_TLS, "pinned", None)
+    if buf is None:
+        buf = _TLS.pinned = torch.empty(1, dtype=torch.int32).pin_memory()
+    return buf
+
 
 _NUM_CELLS_CACHE = {}
-# Transposed neighbour lists (CSR by neighbour index), shared by every depth-wise layer that convolves over the same
-# neighbour list -- the counterpart of ConvolutionBuilder's cacheNeighs_ for the backward pass.
-_TRANSPOSE_CACHE = {}
 
 
 def _transposed_neighbors(packed, n):
-    key = (packed.data_ptr(), packed._version, packed.shape[0], n)
-    hit = _TRANSPOSE_CACHE.get(key)
-    if hit is not None:
+    """Transposed neighbour list (CSR by neighbour index) of `packed`, shared by every depth-wise layer that
+    convolves over the same list -- the counterpart of ConvolutionBuilder's cacheNeighs_ for the backward pass. It is
+    stored ON the neighbour-list tensor object, so it lives exactly as long as the list itself (the builder's cache
+    entry) and there is no global table to go stale."""
+    hit = getattr(packed, "_mccnn_transposed", None)
+    if hit is not None and hit[2] == (packed._version, n):
         return hit
     lib = _lib.load()
     e = packed.shape[0]
@@ -132,10 +137,39 @@ def _transposed_neighbors(packed, n):
     ws = _ws(lib.mccnn_transpose_neighbors_workspace_bytes(n, e), packed.device)
     check(lib.mccnn_transpose_neighbors(ptr(packed), e, n, ptr(start_t), ptr(perm_t), ptr(ws), ws.numel(),
                                         stream_handle()), "transpose_neighbors")
-    if len(_TRANSPOSE_CACHE) > 16:
-        _TRANSPOSE_CACHE.clear()
-    _TRANSPOSE_CACHE[key] = (start_t, perm_t, packed)  # keep `packed` alive: the key is its address
-    return _TRANSPOSE_CACHE[key]
+    hit = (start_t, perm_t, (packed._version, n))
+    try:
+        packed._mccnn_transposed = hit
+    except AttributeError:  # a tensor subclass without a __dict__: recompute next time
+        pass
+    return hit
+
+
+def clear_caches():
+    """Drop the per-shape launch hints (visiting orders, edge-count guesses, num_cells read-backs). They only affect
+    speed, never results, and are bounded in size; call this to release the device tensors they hold."""
+    _ORDER_HINTS.clear()
+    _NUM_CELLS_CACHE.clear()
+    _EDGE_GUESS.clear()
+
+
+#: debug aid: raise MCCNN_E_BATCHID from compute_aabb (the entry of every op chain) when a batch id lies outside
+#: [0, batchSize) -- one 4-byte read-back per call. The kernels clamp ids either way (memory-safe).
+CHECK_BATCH_IDS = False
+
+
+def check_batch_ids(inBatchIds, batchSize):
+    """Number of batch ids outside [0, batchSize) (synchronises)."""
+    bids = _i32(inBatchIds, "batch_ids")
+    bad = torch.empty(1, dtype=torch.int32, device=bids.device)
+    check(_lib.load().mccnn_check_batch_ids(ptr(bids), bids.shape[0], int(batchSize), ptr(bad), stream_handle()),
+          "check_batch_ids")
+    return int(bad.item())
+
+
+def debug_conv_impl(mask):
+    """Test hook: bit 0 = VALU fallback kernels, bit 1 = general MFMA kernels for Fin = 1. Returns the previous mask."""
+    return int(_lib.load().mccnn_debug_conv_impl(int(mask)))
 
 
 def _num_cells(aabbMin, aabbMax, batchSize, cellSize, scaleInv):
@@ -170,6 +204,8 @@ def compute_aabb(inPts, inBatchIds, batchSize, scaleInv=True):
     _check_points(pts, "points", op)
     _check_batch_ids(bids, pts.shape[0], op)
     lib = _lib.load()
+    if CHECK_BATCH_IDS and check_batch_ids(bids, batchSize):
+        check(-2, op)  # MCCNN_E_BATCHID
     mn = torch.empty((batchSize, 3), dtype=torch.float32, device=pts.device)
     mx = torch.empty_like(mn)
     ws = _ws(lib.mccnn_compute_aabb_workspace_bytes(batchSize), pts.device)
@@ -356,7 +392,7 @@ def find_neighbors(inPts, inBatchIds, inPts2, cellIndexs, aabbMin, aabbMax, radi
     # The size of the second output is only known on the device. Searches repeat with the same shapes step after
     # step, so the fill is launched into a buffer sized from the last total of this shape BEFORE the total is read
     # back: the host round trip (~30 us of idle GPU) hides behind the kernel. Too small a guess -> exact rerun.
-    gkey = (m, n2, float(radius), int(batchSize), bool(scaleInv))
+    gkey = (c.device.index, m, n2, float(radius), int(batchSize), bool(scaleInv))
     guess = _EDGE_GUESS.get(gkey, 0)
     packed = None
     if guess > 0:
@@ -388,8 +424,10 @@ PDF_MODE = 1
 # keep the forward's per-centre sums for the backward pass (layers with one input feature); False = the backward
 # recomputes them, as a binding without an extra forward output has to
 KEEP_CONV_STATE = True
-# Poisson sampling: try the single-launch dataflow form first (falls back to 27 launches on a timed-out wait)
+# Poisson sampling: try the single-launch dataflow form first (falls back to 27 launches on a timed-out wait).
+# False = phased form only; 2 = dataflow form that gives up at the first unfinished dependency (tests of the fallback)
 POISSON_DATAFLOW = True
+POISSON_FALLBACKS = 0  # number of calls that had to repeat with the phased form
 
 
 def compute_pdf(inPts, inBatchIds, aabbMin, aabbMax, startIndexs, neighbors, window, radius, batchSize, scaleInv,
@@ -439,14 +477,16 @@ def poisson_sampling(inPts, inBatchIds, cellIndexs, aabbMin, aabbMax, radius, ba
     total = torch.empty(1, dtype=torch.int32, device=p.device)
     # mode 1: all 27 colour phases in one launch (cells wait on their earlier-phase neighbours); a timed-out wait reports
     # -1 and the phases are run one launch at a time instead
+    global POISSON_FALLBACKS
     s = -1
-    for mode in ((1, 0) if POISSON_DATAFLOW else (0,)):
+    for mode in ((2 if POISSON_DATAFLOW == 2 else 1, 0) if POISSON_DATAFLOW else (0,)):
         check(lib.mccnn_poisson_sampling_count(ptr(p), ptr(b), n, ptr(cells), ptr(mn), ptr(mx), batchSize, nc,
                                                float(radius), int(bool(scaleInv)), mode, ptr(total), ptr(ws), ws.numel(),
                                                stream_handle()), "poisson_sampling(count)")
         s = int(total.item())
         if s >= 0:
             break
+        POISSON_FALLBACKS += 1
     oP = torch.empty((s, 3), dtype=torch.float32, device=p.device)
     oB = torch.empty((s, 1), dtype=torch.int32, device=p.device)
     oI = torch.empty(s, dtype=torch.int32, device=p.device)
@@ -544,6 +584,7 @@ class _SpatialConv(torch.autograd.Function):
                                          stream_handle()), "spatial_conv")
         ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3)
         ctx.state = state
+        ctx.packed_obj = packedNeighs if pk is packedNeighs else pk  # the builder's cached tensor object (see _transposed_neighbors)
         ctx.attrs = (numOutFeatures, bool(combin), batchSize, float(radius), bool(scaleInv), bool(avg))
         return out
 
@@ -561,7 +602,7 @@ class _SpatialConv(torch.autograd.Function):
         ws = _ws(lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, numOutFeatures, int(combin)), pts.device)
         start_t = perm_t = None
         if not combin and e > 0:
-            start_t, perm_t, _ = _transposed_neighbors(pk, n)
+            start_t, perm_t, _ = _transposed_neighbors(ctx.packed_obj, n)
         check(lib.mccnn_spatial_conv_bwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                          ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
                                          ptr(og), n, m, e, fin, numOutFeatures, int(combin), batchSize, radius,

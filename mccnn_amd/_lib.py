@@ -19,6 +19,8 @@ SIGNATURES = {
     "mccnn_abi_version": (_i, []),
     "mccnn_arch": (C.c_char_p, []),
     "mccnn_error_string": (C.c_char_p, [_i]),
+    "mccnn_check_batch_ids": (_i, [_vp, _i, _i, _vp, _vp]),
+    "mccnn_debug_conv_impl": (_i, [_i]),
     "mccnn_compute_aabb_workspace_bytes": (_sz, [_i]),
     "mccnn_compute_aabb": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_num_cells": (_i, [_vp, _vp, _i, _f, _i, C.POINTER(_i), _vp]),

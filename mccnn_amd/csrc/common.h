@@ -103,6 +103,9 @@ __device__ __forceinline__ void pool_offset(int o, int& dx, int& dy, int& dz) {
     dz = (int)((v >> 4) & 3) - 1;
 }
 
+// every kernel clamps a batch id before it indexes a per-cloud table (mccnn_check_batch_ids reports invalid ids)
+__device__ __forceinline__ int clamp_batch(int b, int B) { return max(0, min(b, B - 1)); }
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // wave64 inclusive scan (int)

@@ -36,7 +36,7 @@ __device__ __forceinline__ EdgeCtx load_edge(const ConvArgs& a, int t) {
     int2 pr = a.packed[t];
     c.j = pr.x;
     c.i = pr.y;
-    int b = a.bids[c.j];
+    int b = clamp_batch(a.bids[c.j], a.B);
     float ext = max_extent(a.mn, a.mx, b);
     float R = a.scaleInv ? a.radius * ext : a.radius;
     c.d0 = (a.pts[(size_t)c.j * 3] - a.samples[(size_t)c.i * 3]) / R;       // spatial_conv.cu:155-158
@@ -233,10 +233,10 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
             ci = pr.y;
             j = pr.x;
             float invR = a.invRadius;
-            if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, a.bids[j]));
+            if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B)));
             const float* pp = a.pts + (size_t)j * 3;
             const float* cc = a.samples + (size_t)ci * 3;
-            const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, a.bids[j]) : a.radius;
+            const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B)) : a.radius;
             d0 = div_exact(pp[0] - cc[0], R, invR); d1 = div_exact(pp[1] - cc[1], R, invR); d2 = div_exact(pp[2] - cc[2], R, invR);
             float K = 1.0f;
             if (a.avg) K = (float)(((ci + 1 < a.m) ? a.start[ci + 1] : a.e) - a.start[ci]);
@@ -403,13 +403,13 @@ __global__ __launch_bounds__(256) void edge_records(ConvArgs a, float4* __restri
     if (t >= a.e) return;
     int2 pr = a.packed[t];
     float invR = a.invRadius;
-    if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, a.bids[pr.x]));
+    if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[pr.x], a.B)));
     const float* p = a.pts + (size_t)pr.x * 3;
     const float* c = a.samples + (size_t)pr.y * 3;
     int e0 = a.start[pr.y];
     int e1 = (pr.y < a.m - 1) ? a.start[pr.y + 1] : a.e;
     float K = a.avg ? (float)(e1 - e0) : 1.0f;
-    const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, a.bids[pr.x]) : a.radius;
+    const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[pr.x], a.B)) : a.radius;
     rec[t] = make_float4(div_exact(p[0] - c[0], R, invR), div_exact(p[1] - c[1], R, invR), div_exact(p[2] - c[2], R, invR),
                          __builtin_amdgcn_rcpf(a.pdfs[t] * K));
 }
@@ -886,7 +886,7 @@ static int fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_f
     a.pts = sorted_pts; a.feats = sorted_feats; a.bids = sorted_batch_ids; a.pdfs = pdfs; a.samples = samples;
     a.start = start_idx; a.packed = reinterpret_cast<const int2*>(packed); a.mn = aabb_min; a.mx = aabb_max;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3;
-    a.n = n; a.m = m; a.e = e; a.Fin = Fin; a.Fout = Fout; a.radius = radius; a.invRadius = 1.0f / radius; a.scaleInv = scale_inv; a.avg = avg;
+    a.n = n; a.m = m; a.e = e; a.Fin = Fin; a.Fout = Fout; a.radius = radius; a.invRadius = 1.0f / radius; a.scaleInv = scale_inv; a.avg = avg; a.B = batch_size;
     if (m > 0 && (!samples || !start_idx || !aabb_min || !aabb_max || !w1 || !b1 || !w2 || !b2 || !w3 || !b3))
         return MCCNN_E_BADARG;
     if (e > 0 && (!sorted_pts || !sorted_feats || !sorted_batch_ids || !pdfs || !packed)) return MCCNN_E_BADARG;

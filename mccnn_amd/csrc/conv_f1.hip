@@ -75,10 +75,10 @@ __global__ __launch_bounds__(256) void f1_fwd_edges(ConvArgs a, float* __restric
         if (t + 64 < eEnd) { prN = a.packed[t + 64]; pdfN = a.pdfs[t + 64]; }
         const int ci = pr.y, j = pr.x;
         float invR = a.invRadius;
-        if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, a.bids[j]));
+        if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B)));
         const float* pp = a.pts + (size_t)j * 3;
         const float* cc = a.samples + (size_t)ci * 3;
-        const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, a.bids[j]) : a.radius;
+        const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B)) : a.radius;
         const float d0 = div_exact(pp[0] - cc[0], R, invR), d1 = div_exact(pp[1] - cc[1], R, invR), d2 = div_exact(pp[2] - cc[2], R, invR);
         float K = 1.0f;
         if (a.avg) K = (float)(((ci + 1 < a.m) ? a.start[ci + 1] : a.e) - a.start[ci]);
@@ -177,13 +177,13 @@ __global__ __launch_bounds__(256) void f1_edge_records(ConvArgs a, float4* __res
     if (t >= a.e) return;
     int2 pr = a.packed[t];
     float invR = a.invRadius;
-    if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, a.bids[pr.x]));
+    if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[pr.x], a.B)));
     const float* p = a.pts + (size_t)pr.x * 3;
     const float* c = a.samples + (size_t)pr.y * 3;
     int e0 = a.start[pr.y];
     int e1 = (pr.y < a.m - 1) ? a.start[pr.y + 1] : a.e;
     float K = a.avg ? (float)(e1 - e0) : 1.0f;
-    const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, a.bids[pr.x]) : a.radius;
+    const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[pr.x], a.B)) : a.radius;
     rec[t] = make_float4(div_exact(p[0] - c[0], R, invR), div_exact(p[1] - c[1], R, invR), div_exact(p[2] - c[2], R, invR),
                          __builtin_amdgcn_rcpf(a.pdfs[t] * K));
 }

@@ -20,7 +20,7 @@ struct ConvArgs {
     const float *w1, *b1, *w2, *b2, *w3, *b3;
     int n, m, e, Fin, Fout, nb, neuronsOut, outF;
     float radius, invRadius;
-    int scaleInv, avg, G;
+    int scaleInv, avg, G, B;
 };
 
 // ---------------------------------------------------------------------------------------

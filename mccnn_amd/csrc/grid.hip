@@ -123,17 +123,22 @@ __global__ void num_cells_dev(const float* __restrict__ mn, const float* __restr
     *out = nc == 0 ? 1 : nc;
 }
 
+__global__ __launch_bounds__(256) void check_bids(const int* __restrict__ bids, int n, int B, int* __restrict__ bad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (bids[i] < 0 || bids[i] >= B)) atomicAdd(bad, 1);  // one atomic per wave (the compiler aggregates)
+}
+
 // ------------------------------------------------------------------ keys + histogram
 // calc_key + update_counters fused (sort_gpu.cu:35-80). arrival[i] = rank in atomic arrival
 // order; it is only used to park point ids in their cell segment, the final order is fixed
 // by rank_in_cell below.
 __global__ __launch_bounds__(256) void keys_hist(const float* __restrict__ pts, const int* __restrict__ bids,
                                                  const float* __restrict__ mn, const float* __restrict__ mx,
-                                                 int n, int nc, int* __restrict__ keys, int* __restrict__ cnt,
+                                                 int n, int B, int nc, int* __restrict__ keys, int* __restrict__ cnt,
                                                  int* __restrict__ arrival) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int b = bids[i];
+    int b = clamp_batch(bids[i], B);
     float cs = max_extent(mn, mx, b) / (float)nc;
     int x = cell_coord(pts[(size_t)i * 3], mn[b * 3], cs, nc);
     int y = cell_coord(pts[(size_t)i * 3 + 1], mn[b * 3 + 1], cs, nc);
@@ -264,6 +269,16 @@ using namespace mccnn;
 
 extern "C" {
 
+int mccnn_check_batch_ids(const int* batch_ids, int n, int batch_size, int* bad_count_dev, mccnn_stream_t stream) {
+    if (n < 0 || batch_size <= 0 || !bad_count_dev || (n > 0 && !batch_ids)) return MCCNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    MCCNN_HIP(hipMemsetAsync(bad_count_dev, 0, sizeof(int), s));
+    if (n == 0) return 0;
+    check_bids<<<ceil_div(n, 256), 256, 0, s>>>(batch_ids, n, batch_size, bad_count_dev);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
 size_t mccnn_compute_aabb_workspace_bytes(int batch_size) {
     return align_up((size_t)(batch_size > 0 ? batch_size : 1) * 6 * sizeof(unsigned));
 }
@@ -332,7 +347,7 @@ int mccnn_sort_step1(const float* pts, const int* batch_ids, const float* aabb_m
     if (!cnt || !start || !slot || !scanws) return MCCNN_E_WORKSPACE;
     MCCNN_HIP(hipMemsetAsync(cnt, 0, (size_t)C * sizeof(int), s));
     int blocks = ceil_div(n, 256);
-    keys_hist<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, num_cells, keys, cnt, new_idx);
+    keys_hist<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, keys, cnt, new_idx);
     MCCNN_LAUNCHED();
     int rc = exclusive_scan_i32(cnt, start, (int)C, start + C, scanws, s);
     if (rc) return rc;

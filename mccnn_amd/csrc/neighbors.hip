@@ -12,9 +12,9 @@ struct CentreCtx {
 
 __device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centres, const int* __restrict__ cb,
                                                 const float* __restrict__ mn, const float* __restrict__ mx,
-                                                int i, int nc, float radius, int scaleInv) {
+                                                int i, int B, int nc, float radius, int scaleInv) {
     CentreCtx c;
-    c.b = cb[i];
+    c.b = clamp_batch(cb[i], B);
     c.cx = centres[(size_t)i * 3];
     c.cy = centres[(size_t)i * 3 + 1];
     c.cz = centres[(size_t)i * 3 + 2];
@@ -52,7 +52,7 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 template <bool FILL>
 __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ centres, const int* __restrict__ cb, int m,
                                                     const float* __restrict__ pts, const int* __restrict__ cells,
-                                                    const float* __restrict__ mn, const float* __restrict__ mx, int nc,
+                                                    const float* __restrict__ mn, const float* __restrict__ mx, int B, int nc,
                                                     float radius, int scaleInv, const int* __restrict__ order,
                                                     int* __restrict__ cnt, const int* __restrict__ startIdx,
                                                     int* __restrict__ packed, int capacity) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
     const int ci = g0 + lane;
     const bool own = lane < MCCNN_NW_G && ci < m;
     const int i = own ? (order ? order[ci] : ci) : 0;
-    CentreCtx c = centre_ctx(centres, cb, mn, mx, i, nc, radius, scaleInv);
+    CentreCtx c = centre_ctx(centres, cb, mn, mx, i, B, nc, radius, scaleInv);
     const int key = own ? ((c.b * nc + c.x) * nc + c.y) * nc + c.z : -1;
     int count = 0;                                   // hits of this lane's centre so far
     const int base = (FILL && own) ? startIdx[i] : 0;
@@ -157,14 +157,14 @@ __global__ __launch_bounds__(256) void invert_perm_k(const int* __restrict__ new
 __global__ __launch_bounds__(256) void pdf_edges_ref(const float* __restrict__ pts, const int* __restrict__ bids,
                                                  const int* __restrict__ startIdx, int m,
                                                  const int2* __restrict__ packed, int e, const float* __restrict__ mn,
-                                                 const float* __restrict__ mx, float window, float radius,
+                                                 const float* __restrict__ mx, int B, float window, float radius,
                                                  int scaleInv, float* __restrict__ pdfs) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= e) return;
     int2 pr = packed[t];
     int cur = pr.x, centre = pr.y;
     float cx = pts[(size_t)cur * 3], cy = pts[(size_t)cur * 3 + 1], cz = pts[(size_t)cur * 3 + 2];
-    int b = bids[cur];
+    int b = clamp_batch(bids[cur], B);
     float ext = max_extent(mn, mx, b);
     float R = scaleInv ? radius * ext : radius;
     int i0 = startIdx[centre];
@@ -196,12 +196,12 @@ __global__ __launch_bounds__(256) void pdf_edges_ref(const float* __restrict__ p
 __global__ __launch_bounds__(256) void pdf_edge_coords(const float* __restrict__ pts, const int* __restrict__ bids,
                                                        const int2* __restrict__ packed, int e,
                                                        const float* __restrict__ mn, const float* __restrict__ mx,
-                                                       float window, float radius, int scaleInv,
+                                                       int B, float window, float radius, int scaleInv,
                                                        float4* __restrict__ sc) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= e) return;
     int j = packed[t].x;
-    float R = scaleInv ? radius * max_extent(mn, mx, bids[j]) : radius;
+    float R = scaleInv ? radius * max_extent(mn, mx, clamp_batch(bids[j], B)) : radius;
     float s = (float)(1.0 / (double)(R * window));
     const float* p = pts + (size_t)j * 3;
     sc[t] = make_float4(p[0], p[1], p[2], s);
@@ -294,7 +294,7 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
     NeighWs w;
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     neigh_window<false><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
-                                                                  aabb_max, num_cells, radius, scale_inv, centre_order, w.cnt,
+                                                                  aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, w.cnt,
                                                                   nullptr, nullptr, 0);
     MCCNN_LAUNCHED();
     int rc = exclusive_scan_i32(w.cnt, start_idx, m, total_dev, w.scanws, s);
@@ -315,7 +315,7 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     neigh_window<true><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
-                                                                 aabb_max, num_cells, radius, scale_inv, centre_order, nullptr,
+                                                                 aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, nullptr,
                                                                  start_idx, packed, e);
     MCCNN_LAUNCHED();
     return 0;
@@ -346,12 +346,12 @@ int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, cons
     const int2* pk = reinterpret_cast<const int2*>(packed);
     if (mode == 0)
         pdf_edges_ref<<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, start_idx, m, pk, e, aabb_min,
-                                                      aabb_max, window, radius, scale_inv, pdfs);
+                                                      aabb_max, batch_size, window, radius, scale_inv, pdfs);
     else {
         if (!ws || ws_bytes < mccnn_compute_pdf_workspace_bytes(e, mode)) return MCCNN_E_WORKSPACE;
         float4* sc = (float4*)ws;
         pdf_edge_coords<<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, e, aabb_min, aabb_max,
-                                                          window, radius, scale_inv, sc);
+                                                        batch_size, window, radius, scale_inv, sc);
         MCCNN_LAUNCHED();
         pdf_rows<<<ceil_div(m, 4), 256, 0, s>>>(sc, start_idx, m, e, window, pdfs);
     }

@@ -178,7 +178,7 @@ __device__ __forceinline__ void poisson_cell(const float* __restrict__ pts, cons
                                              const float* __restrict__ mn, const float* __restrict__ mx,
                                              const PoissonDims& d, int b, int gx, int gy, int gz, int ph, float radius,
                                              int scaleInv, unsigned char* sel, int* __restrict__ slotCount, int* done,
-                                             int* fail, int lane) {
+                                             int* fail, int spinLimit, int lane) {
     int ox, oy, oz;
     pool_offset(ph, ox, oy, oz);
     const int nc = d.nc;
@@ -216,7 +216,7 @@ __device__ __forceinline__ void poisson_cell(const float* __restrict__ pts, cons
         if (needWait) {
             int spins = 0;
             while (__hip_atomic_load(done + waitIdx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                if (++spins > MCCNN_PS_SPIN_LIMIT) { waitFailed = true; break; }
+                if (++spins > spinLimit) { waitFailed = true; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
         }
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restric
     const int b = (int)(t / perBatch);
     const int r = (int)(t - (long long)b * perBatch);
     poisson_cell(pts, cells, mn, mx, d, b, r % d.G, (r / d.G) % d.G, r / (d.G * d.G), ph, radius, scaleInv, sel, slotCount,
-                 nullptr, nullptr, lane);
+                 nullptr, nullptr, 0, lane);
 }
 
 // All 27 phases in ONE launch (dataflow form). Waves are ordered phase-major, so every wave a cell has to wait for has
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void poisson_dataflow(const float* __restrict_
                                                         const float* __restrict__ mn, const float* __restrict__ mx,
                                                         int B, PoissonDims d, float radius, int scaleInv,
                                                         unsigned char* sel, int* __restrict__ slotCount, int* done,
-                                                        int* fail) {
+                                                        int* fail, int spinLimit) {
     const int lane = threadIdx.x & 63;
     const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long perPhase = (long long)d.G * d.G * d.G * B;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void poisson_dataflow(const float* __restrict_
     const int b = (int)(t / perBatch);
     const int r = (int)(t - (long long)b * perBatch);
     poisson_cell(pts, cells, mn, mx, d, b, r % d.G, (r / d.G) % d.G, r / (d.G * d.G), ph, radius, scaleInv, sel, slotCount,
-                 done, fail, lane);
+                 done, fail, spinLimit, lane);
 }
 
 __global__ void poisson_flag_failure(const int* __restrict__ fail, int* __restrict__ total) {
@@ -398,10 +398,13 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
     MCCNN_HIP(hipMemsetAsync(slots, 0, (size_t)S * sizeof(int), s));
     PoissonDims d = poisson_dims(num_cells);
     long long threads = (long long)batch_size * d.G * d.G * d.G;
-    if (mode == 1) {
+    if (mode == 1 || mode == 2) {
+        // mode 2 (tests only): no spinning at all -- the first cell whose predecessor has not finished raises the
+        // failure flag, which exercises the caller's fallback to the phased form
+        const int spinLimit = mode == 1 ? MCCNN_PS_SPIN_LIMIT : 0;
         MCCNN_HIP(hipMemsetAsync(flags, 0, (C + 1) * sizeof(int), s));
         poisson_dataflow<<<ceil_div(threads * 27, 4), 256, 0, s>>>(sorted_pts, cell_indexs, aabb_min, aabb_max, batch_size, d,
-                                                                  radius, scale_inv, sel, slots, flags, flags + C);
+                                                                  radius, scale_inv, sel, slots, flags, flags + C, spinLimit);
         MCCNN_LAUNCHED();
         int rc = exclusive_scan_i32(slots, slots, (int)S, total_dev, scanws, s);
         if (rc) return rc;

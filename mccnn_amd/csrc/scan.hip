@@ -44,8 +44,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const int* __rest
 // Scans one tile per block. offsets == nullptr -> single tile (n <= SCAN_TILE). rawSums: `offsets` holds the
 // UNSCANNED tile sums and every block adds up the sums of the tiles before it itself (<= SCAN_TILE tiles): saves the
 // middle launch of the three-level scheme, which at 100k elements costs as much as the scan proper.
-__global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const int* __restrict__ in, int* __restrict__ out,
-                                                           int n, const int* __restrict__ offsets,
+// `out` may alias `in` (callers scan in place): neither is __restrict__; every thread loads its items before the
+// first barrier of block_excl_scan and stores after the last one.
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const int* in, int* out,
+                                                           int n, const int* offsets,
                                                            int* __restrict__ total, int rawSums) {
     __shared__ int lds[4];
     int off = 0;

@@ -38,12 +38,14 @@ def shard_clouds(points, batchIds, features, batchSize, rank, world_size):
 
 
 def allreduce_aabb(aabbMin, aabbMax, group=None):
-    """Whole-batch box across shards (needed only for relativeRadius=False). In place."""
+    """Whole-batch box across shards (needed only for relativeRadius=False). Returns NEW tensors: the op layer caches
+    the number of grid cells per box tensor object, and an in-place collective would not invalidate that entry."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return aabbMin, aabbMax
-    dist.all_reduce(aabbMin, op=dist.ReduceOp.MIN, group=group)
-    dist.all_reduce(aabbMax, op=dist.ReduceOp.MAX, group=group)
-    return aabbMin, aabbMax
+    mn, mx = aabbMin.clone(), aabbMax.clone()
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    return mn, mx
 
 
 class GradBucket:

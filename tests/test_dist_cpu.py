@@ -60,7 +60,7 @@ def _worker(rank, world, port, q):
         got = [p.grad.clone() for p in params]
         mn = torch.tensor([[0.0 + rank, -1.0, 2.0 - rank]])
         mx = torch.tensor([[5.0 + rank, 4.0, 9.0 - rank]])
-        allreduce_aabb(mn, mx)
+        mn, mx = allreduce_aabb(mn, mx)
         q.put((rank, [g.numpy() for g in got], mn.numpy(), mx.numpy()))
     finally:
         dist.destroy_process_group()

@@ -1,0 +1,181 @@
+"""BASELINE.json configs at their stated sizes, HIP path (through the C-ABI) against the CPU oracle:
+
+  cfg1  ModelNet40 MCClassS, 32 clouds x 1 024 points, grow 16   (models/MCClassS.py:29-71)
+  cfg2  ModelNet40 MCClassH, 32 clouds x 4 096 points, 3 Poisson levels (models/MCClassH.py:30-187)
+
+For every level of the point hierarchy and every convolution of the graph: ALL integer outputs (keys, sort order, cell
+tables, Poisson samples and their indices, CSR start indices, packed neighbours) bit-exact, KDE / convolution outputs
+and the seven gradients within 1e-4 relative. The networks' dense layers (BN, 1x1 convs) are not on the hot path: each
+convolution is fed seeded random features / out-gradients of the shape the graph gives it."""
+import math
+
+import numpy as np
+import pytest
+
+from tests.helpers import make_mlp, conv_nb
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4  # north_star: "fp32 features within 1e-4 rel"
+
+
+def _wrap(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def _unwrap(t):
+    return t.detach().cpu().numpy()
+
+
+def _ident(x):
+    return x
+
+
+@pytest.fixture(scope="module")
+def oracle_omp():
+    """The OpenMP build of the oracle: identical integer outputs, parameter gradients summed in double."""
+    from oracle.oracle import Oracle
+    return Oracle(omp=True)
+
+
+def modelnet_like(n, B, seed):
+    """B synthetic shapes with n points each, normalised like the ModelNet loader (centred, inside the unit sphere):
+    an ellipsoid shell plus the faces of a box, different proportions per cloud."""
+    rng = np.random.default_rng(seed)
+    pts, bids = [], []
+    for b in range(B):
+        k = n // 2
+        v = rng.normal(size=(k, 3))
+        shell = v / np.linalg.norm(v, axis=1, keepdims=True) * (0.3 + 0.7 * rng.random(3))
+        box = (rng.random((n - k, 3)) - 0.5) * (0.4 + 1.2 * rng.random(3))
+        face = rng.integers(0, 3, n - k)
+        half = (np.abs(box).max(axis=0) + 1e-3)
+        box[np.arange(n - k), face] = np.sign(box[np.arange(n - k), face]) * half[face]
+        p = np.concatenate([shell, box])
+        p -= p.mean(axis=0)
+        p /= np.linalg.norm(p, axis=1).max()
+        rng.shuffle(p)
+        pts.append(p)
+        bids.append(np.full((n, 1), b, np.int32))
+    return np.concatenate(pts).astype(np.float32), np.concatenate(bids)
+
+
+def build_hierarchy(ops, wrap, unwrap, pts, bids, feats, B, radii):
+    """PointHierarchy.__init__ (MCConvBuilder.py:101-128) op by op; returns per-level handles and the integer record."""
+    P, Bi, F = wrap(pts), wrap(bids), wrap(feats)
+    mn, mx = ops.compute_aabb(P, Bi, B, True)
+    levels = [(P, Bi, F)]
+    rec = [dict(aabbMin=unwrap(mn), aabbMax=unwrap(mx))]
+    for r in radii:
+        cP, cB, cF = levels[-1]
+        keys, idx = ops.sort_points_step1(cP, cB, mn, mx, B, r, True)
+        sP, sB, sF, cells = ops.sort_points_step2(cP, cB, cF, keys, idx, mn, mx, B, r, True)
+        sp, sb, si = ops.poisson_sampling(sP, sB, cells, mn, mx, r, B, True)
+        sf = ops.get_sampled_features(si, sF)
+        ti = ops.transform_indexs(si, idx)
+        levels.append((sp, sb, sf))
+        rec.append(dict(keys=unwrap(keys), indexs=unwrap(idx), cellIndexs=unwrap(cells), samplePts=unwrap(sp),
+                        sampleBatchs=unwrap(sb), sampleIndexs=unwrap(si), sampleFeatures=unwrap(sf),
+                        transformedIndexs=unwrap(ti)))
+    return mn, mx, levels, rec
+
+
+def run_conv(ops, wrap, unwrap, mn, mx, levels, B, spec, seed, is_gpu):
+    """One create_convolution (MCConvBuilder.py:349-427): grid of the input level, neighbours of the output level's
+    points, KDE, convolution forward and backward on seeded random features / out-gradients."""
+    lin, lout, radius, window, fin, fout, combin = spec
+    inP, inB, _ = levels[lin]
+    outP, outB, _ = levels[lout]
+    n, m = int(inP.shape[0]), int(outP.shape[0])
+    rng = np.random.default_rng(seed)
+    feats = (2 * rng.random((n, fin)) - 1).astype(np.float32)
+    outF = fout if combin else fin
+    og = (2 * rng.random((m, outF)) - 1).astype(np.float32)
+    w = make_mlp(conv_nb(fin, fout, combin), seed + 1)
+    keys, idx = ops.sort_points_step1(inP, inB, mn, mx, B, radius, True)
+    sP, sB, sF, cells = ops.sort_points_step2(inP, inB, wrap(feats), keys, idx, mn, mx, B, radius, True)
+    start, packed = ops.find_neighbors(outP, outB, sP, cells, mn, mx, radius, B, True)
+    pdfs = ops.compute_pdf(sP, sB, mn, mx, start, packed, window, radius, B, True)
+    r = dict(keys=unwrap(keys), indexs=unwrap(idx), cellIndexs=unwrap(cells), startIndexs=unwrap(start),
+             packedNeighs=unwrap(packed), pdfs=unwrap(pdfs))
+    if is_gpu:
+        tw = {k: wrap(v).requires_grad_(True) for k, v in w.items()}
+        sFr = sF.detach().clone().requires_grad_(True)
+        out = ops.spatial_conv(sP, sFr, sB, pdfs, outP, start, packed, mn, mx, tw["w1"], tw["w2"], tw["w3"], tw["b1"],
+                               tw["b2"], tw["b3"], fout, combin, B, radius, True, True)
+        out.backward(wrap(og))
+        r["out"] = unwrap(out)
+        r["grads"] = [unwrap(t) for t in (sFr.grad, tw["w1"].grad, tw["b1"].grad, tw["w2"].grad, tw["b2"].grad,
+                                          tw["w3"].grad, tw["b3"].grad)]
+    else:
+        a = (sP, sF, sB, pdfs, outP, start, packed, mn, mx, w["w1"], w["w2"], w["w3"], w["b1"], w["b2"], w["b3"])
+        r["out"] = ops.spatial_conv(*a, fout, combin, B, radius, True, True)
+        r["grads"] = list(ops.spatial_conv_grad(*a, og, fout, combin, B, radius, True, True))
+    return r
+
+
+def rel_err(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)) if ref.size else 0.0
+
+
+INT_HIER = ["keys", "indexs", "cellIndexs", "sampleBatchs", "sampleIndexs", "transformedIndexs"]
+INT_CONV = ["keys", "indexs", "cellIndexs", "startIndexs", "packedNeighs"]
+GRADS = ["featGrad", "dw1", "db1", "dw2", "db2", "dw3", "db3"]
+S3 = math.sqrt(3.0) + 0.1
+
+# (inLevel, outLevel, convRadius, KDEWindow, Fin, Fout, multiFeatureConv)
+MCCLASS_S_K16 = [  # models/MCClassS.py:38-71, grow 16 (BASELINE cfg1)
+    (0, 1, 0.2, 0.2, 1, 16, True),
+    (1, 2, 0.8, 0.2, 32, 32, False),
+    (2, 3, S3, 0.2, 64, 64, False),
+]
+MCCLASS_H_K16 = [  # models/MCClassH.py:40-187, both logit branches, grow 16
+    (0, 0, 0.1, 0.25, 1, 16, True),      # Conv_1
+    (0, 1, 0.2, 0.2, 32, 32, False),     # Pool_1
+    (1, 1, 0.4, 0.25, 32, 32, False),    # Conv_2
+    (1, 2, 0.8, 0.2, 128, 128, False),   # Pool_2
+    (2, 2, 1.2, 0.25, 128, 128, False),  # Conv_3
+    (2, 3, S3, 0.2, 512, 512, False),    # Pool_3
+    (1, 1, 0.4, 0.25, 1, 32, True),      # Conv_2_2
+]
+
+
+def check_config(mc, orc, n_per, B, radii, convs, seed):
+    pts, bids = modelnet_like(n_per, B, seed)
+    feats = np.ones((len(pts), 1), np.float32)  # ModelNet.py:168: one constant input feature
+    gmn, gmx, glev, grec = build_hierarchy(mc, _wrap, _unwrap, pts, bids, feats, B, radii)
+    omn, omx, olev, orec = build_hierarchy(orc, _ident, _ident, pts, bids, feats, B, radii)
+    assert np.array_equal(grec[0]["aabbMin"], orec[0]["aabbMin"]) and np.array_equal(grec[0]["aabbMax"], orec[0]["aabbMax"])
+    sizes = []
+    for lvl in range(1, len(radii) + 1):
+        for k in INT_HIER + ["samplePts", "sampleFeatures"]:
+            assert grec[lvl][k].shape == orec[lvl][k].shape, (lvl, k, grec[lvl][k].shape, orec[lvl][k].shape)
+            assert np.array_equal(grec[lvl][k], orec[lvl][k]), "level %d: %s differs" % (lvl, k)
+        sizes.append(len(orec[lvl]["sampleIndexs"]))
+    assert sizes[0] > sizes[1] > sizes[2] >= B  # a real three-level hierarchy; the last level holds >= 1 point per cloud
+    worst = {}
+    for ci, spec in enumerate(convs):
+        g = run_conv(mc, _wrap, _unwrap, gmn, gmx, glev, B, spec, 100 + ci, True)
+        o = run_conv(orc, _ident, _ident, omn, omx, olev, B, spec, 100 + ci, False)
+        for k in INT_CONV:
+            assert g[k].shape == o[k].shape, (spec, k, g[k].shape, o[k].shape)
+            assert np.array_equal(g[k], o[k]), "conv %s: %s differs" % (spec, k)
+        errs = {"pdfs": rel_err(g["pdfs"], o["pdfs"]), "out": rel_err(g["out"], o["out"])}
+        for nm, a, b in zip(GRADS, g["grads"], o["grads"]):
+            errs[nm] = rel_err(a, b)
+        for nm, e in errs.items():
+            assert e <= RTOL, "conv %s: %s max |diff| / max |ref| = %.3e" % (spec, nm, e)
+            worst[nm] = max(worst.get(nm, 0.0), e)
+    return sizes, worst
+
+
+def test_cfg1_mcclass_s_32x1024(mc, oracle_omp):
+    sizes, worst = check_config(mc, oracle_omp, 1024, 32, [0.1, 0.4, S3], MCCLASS_S_K16, 41)
+    print("cfg1 level sizes", sizes, "worst rel errs", {k: "%.1e" % v for k, v in worst.items()})
+
+
+def test_cfg2_mcclass_h_32x4096(mc, oracle_omp):
+    sizes, worst = check_config(mc, oracle_omp, 4096, 32, [0.1, 0.4, S3], MCCLASS_H_K16, 43)
+    print("cfg2 level sizes", sizes, "worst rel errs", {k: "%.1e" % v for k, v in worst.items()})

@@ -1,0 +1,128 @@
+"""Data-parallel equivalence on the GPU: two ranks (gloo, sharing the one GPU of the test box -- the
+production backend is nccl == RCCL, one GPU per rank) each take half of a 4-cloud batch with an ABSOLUTE radius, i.e.
+the case where the reference uses ONE bounding box for the whole batch (aabb_gpu.cu:104-114). With the box all-reduced
+before anything is sorted (PointHierarchy(aabbReduceGroup=...)) every integer output of a shard -- keys, sort order,
+cell tables, Poisson samples, neighbour lists -- is the corresponding slice of the single-process batch, and the
+all-reduced kernel-MLP gradients equal the single-process gradients within the north-star tolerance."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+B, NPER, R_POISSON, R_CONV, FIN, FOUT = 4, 3000, 0.08, 0.12, 3, 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs():
+    from tests.helpers import make_cloud
+    pts, bids = make_cloud(NPER, B, 29, "clustered", True)
+    rng = np.random.default_rng(31)
+    feats = (2 * rng.random((len(pts), FIN)) - 1).astype(np.float32)
+    return pts, bids, feats
+
+
+def _run(pts, bids, feats, batchSize, group):
+    """PointHierarchy (one Poisson level) + a same-level convolution and a pooling convolution, backward of a fixed
+    linear functional of both outputs. Returns integer records and float results as numpy."""
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    P = torch.from_numpy(pts).cuda()
+    Bi = torch.from_numpy(bids).cuda()
+    F = torch.from_numpy(feats).cuda().requires_grad_(True)
+    ph = PointHierarchy(P, F, Bi, [R_POISSON], "PH", batchSize, False, aabbReduceGroup=group)
+    cb = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=False)
+    torch.manual_seed(5)  # identical kernel-MLP weights everywhere
+    o0 = cb.create_convolution("C0", ph, 0, F, FIN, R_CONV, outNumFeatures=FOUT, multiFeatureConv=True)
+    o1 = cb.create_convolution("C1", ph, 0, o0, FOUT, R_CONV, outPointHierarchy=ph, outPointLevel=1)
+    loss = (o0 * torch.linspace(-1, 1, FOUT, device="cuda")).sum() + (o1 * torch.linspace(1, 2, FOUT, device="cuda")).sum()
+    loss.backward()
+    grid = cb.cacheGrids_["PH|0|%s|False" % R_CONV]
+    neigh0 = cb.cacheNeighs_["PH|0|%s|False|PH|0" % R_CONV]
+    neigh1 = cb.cacheNeighs_["PH|0|%s|False|PH|1" % R_CONV]
+    ints = dict(aabbMin=ph.aabbMin_, aabbMax=ph.aabbMax_, samplePts=ph.points_[1], sampleBatchs=ph.batchIds_[1],
+                sampleIndexs=ph.sampledIndexs_[0], cellIndexs=grid[2], indexs=grid[3], start0=neigh0[0], packed0=neigh0[1],
+                start1=neigh1[0], packed1=neigh1[1])
+    ints = {k: v.detach().cpu().numpy() for k, v in ints.items()}
+    floats = dict(o0=o0.detach().cpu().numpy(), o1=o1.detach().cpu().numpy(), dF=F.grad.detach().cpu().numpy())
+    return ints, floats, cb
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from mccnn_amd.dist import shard_clouds, GradBucket
+        pts, bids, feats = _inputs()
+        lp, lb, lf, lB, (first, last) = shard_clouds(torch.from_numpy(pts), torch.from_numpy(bids),
+                                                     torch.from_numpy(feats), B, rank, world)
+        ints, floats, cb = _run(lp.numpy(), lb.numpy().astype(np.int32), lf.numpy(), lB, True)
+        GradBucket(cb.parameters()).allreduce()
+        grads = {k: v.grad.detach().cpu().numpy() for k, v in cb.named_parameters()}
+        q.put((rank, first, last, ints, floats, grads))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_shards_equal_the_single_process_batch(mc):
+    import torch
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    pts, bids, feats = _inputs()
+    full_i, full_f, cb = _run(pts, bids, feats, B, None)
+    full_g = {k: v.grad.detach().cpu().numpy() for k, v in cb.named_parameters()}
+    ids = bids.reshape(-1)
+    nc3 = full_i["cellIndexs"].shape[1] ** 3
+    sample_cloud = full_i["sampleBatchs"].reshape(-1)
+    for rank, first, last, ints, floats, grads in res:
+        mask = (ids >= first) & (ids < last)
+        p0 = int(np.flatnonzero(mask)[0])                       # points of earlier shards (clouds are contiguous)
+        smask = (sample_cloud >= first) & (sample_cloud < last)
+        s0 = int(np.flatnonzero(smask)[0])                      # Poisson samples of earlier shards
+        # the whole-batch box on every shard
+        assert np.array_equal(ints["aabbMin"], full_i["aabbMin"][first:last])
+        assert np.array_equal(ints["aabbMax"], full_i["aabbMax"][first:last])
+        # grid: sort order and cell table are the shard's slice, shifted by the points that precede it
+        assert np.array_equal(ints["indexs"], full_i["indexs"][mask] - p0)
+        cells = full_i["cellIndexs"][first:last].copy()
+        cells[cells[..., 1] > cells[..., 0]] -= p0
+        assert np.array_equal(ints["cellIndexs"], cells) and cells.size == (last - first) * nc3 * 2
+        # Poisson level
+        assert np.array_equal(ints["samplePts"], full_i["samplePts"][smask])
+        assert np.array_equal(ints["sampleBatchs"], full_i["sampleBatchs"][smask] - first)
+        assert np.array_equal(ints["sampleIndexs"], full_i["sampleIndexs"][smask] - p0)
+        # neighbour lists: same-level (centres = the shard's points) and pooling (centres = its samples)
+        for tag, cmask, c0 in (("0", mask, p0), ("1", smask, s0)):
+            st = np.append(full_i["start" + tag].reshape(-1), len(full_i["packed" + tag]))
+            rows = np.flatnonzero(cmask)
+            e0, e1 = st[rows[0]], st[rows[-1] + 1]
+            assert np.array_equal(ints["start" + tag].reshape(-1), st[rows] - e0)
+            assert np.array_equal(ints["packed" + tag], full_i["packed" + tag][e0:e1] - np.array([p0, c0]))
+        # float outputs of the shard: the slice of the single-process result (summation chunking may differ)
+        for k, m in (("o0", mask), ("o1", smask), ("dF", mask)):
+            ref = full_f[k][m]
+            assert np.abs(floats[k] - ref).max() <= 1e-5 * np.abs(full_f[k]).max(), k
+        # all-reduced kernel-MLP gradients == single-process gradients
+        for k, g in grads.items():
+            assert np.abs(g - full_g[k]).max() <= 1e-4 * max(np.abs(full_g[k]).max(), 1e-30), k

@@ -1,8 +1,9 @@
-"""BASELINE.json full size (100 000-point non-uniform room, absolute radius 0.1): the oracle is too slow to sit in
-the test loop at this size for every op, so parity is checked through size-independent properties of the domain --
+"""BASELINE.json full size (100 000-point non-uniform room, absolute radius 0.1). First part: size-independent
+properties of the domain --
 sortedness, partition / prefix-sum consistency, symmetry of the neighbour relation, exact radius predicate,
 linearity of the convolution in the features, the adjoint identity <conv(F), G> = <F, conv_grad(G)>, a directional
-derivative for the weight gradients -- plus an oracle spot check on a subset of centres."""
+derivative for the weight gradients. Second part (end of the file): the whole chain and every gradient against the
+oracle's OpenMP build, for one room and for a two-room batch."""
 import numpy as np
 import pytest
 
@@ -154,3 +155,109 @@ def test_pdf_and_poisson_properties(mc, room):
     st2, pk2 = mc.find_neighbors(room["P"], room["Bi"], p2, c2, room["mn"], room["mx"], R, B, False)
     cnt = torch.diff(torch.cat([st2[:, 0], torch.tensor([pk2.shape[0]], device="cuda", dtype=torch.int32)]))
     assert bool((cnt >= 1).all())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Full-size comparisons with the oracle itself (its OpenMP build: identical integer outputs, parameter gradients summed
+# in double): the whole op chain of a 100k-point room and of a two-room batch (E ~ 9 M edges: the backward kernels then
+# work in ROUNDS of cache-sized slices, conv.hip bwd_partition / conv_f1.hip f1_bwd_partition), every integer output
+# bit-exact, convolution outputs and all seven gradients within the north-star tolerance.
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def oracle_omp():
+    from oracle.oracle import Oracle
+    return Oracle(omp=True)
+
+
+def _chain(mc, rooms):
+    import torch
+    pts = np.concatenate([make_room(N, 20180601 + r) for r in range(rooms)])
+    bids = np.repeat(np.arange(rooms, dtype=np.int32), N).reshape(-1, 1)
+    P, Bi = torch.from_numpy(pts).cuda(), torch.from_numpy(bids).cuda()
+    F1 = torch.ones((len(pts), 1), device="cuda")
+    mn, mx = mc.compute_aabb(P, Bi, rooms, False)
+    keys, idx = mc.sort_points_step1(P, Bi, mn, mx, rooms, R, False)
+    sP, sB, _, cells = mc.sort_points_step2(P, Bi, F1, keys, idx, mn, mx, rooms, R, False)
+    start, packed = mc.find_neighbors(P, Bi, sP, cells, mn, mx, R, rooms, False)
+    pdfs = mc.compute_pdf(sP, sB, mn, mx, start, packed, 0.2, R, rooms, False)
+    return dict(pts=pts, bids=bids, P=P, Bi=Bi, mn=mn, mx=mx, keys=keys, idx=idx, sP=sP, sB=sB, cells=cells, start=start,
+                packed=packed, pdfs=pdfs, B=rooms)
+
+
+@pytest.fixture(scope="module")
+def chain1(mc):
+    return _chain(mc, 1)
+
+
+@pytest.fixture(scope="module")
+def chain2(mc):
+    return _chain(mc, 2)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _check_ints(c, orc):
+    B = c["B"]
+    mn, mx = orc.compute_aabb(c["pts"], c["bids"], B, False)
+    assert np.array_equal(_np(c["mn"]), mn) and np.array_equal(_np(c["mx"]), mx)
+    k, i = orc.sort_points_step1(c["pts"], c["bids"], mn, mx, B, R, False)
+    assert np.array_equal(_np(c["keys"]), k) and np.array_equal(_np(c["idx"]), i)
+    sp, sb, _, cl = orc.sort_points_step2(c["pts"], c["bids"], np.ones((len(c["pts"]), 1), np.float32), k, i, mn, mx, B, R,
+                                          False)
+    assert np.array_equal(_np(c["sP"]), sp) and np.array_equal(_np(c["sB"]), sb) and np.array_equal(_np(c["cells"]), cl)
+    st, pk = orc.find_neighbors(c["pts"], c["bids"], sp, cl, mn, mx, R, B, False)
+    assert np.array_equal(_np(c["start"]), st)
+    assert np.array_equal(_np(c["packed"]), pk)
+    pdf = orc.compute_pdf(sp, sb, mn, mx, st, pk, 0.2, R, B, False)
+    err = np.abs(_np(c["pdfs"]) - pdf).max() / np.abs(pdf).max()
+    assert err <= RTOL, err
+    return len(pk)
+
+
+def _check_conv(mc, orc, c, fin, fout, combin, seed):
+    import torch
+    B, n = c["B"], len(c["pts"])
+    rng = np.random.default_rng(seed)
+    feats = (2 * rng.random((n, fin)) - 1).astype(np.float32)      # rows of the SORTED points
+    outF = fout if combin else fin
+    og = (2 * rng.random((n, outF)) - 1).astype(np.float32)
+    w = make_mlp(((fin * fout if combin else fin) + 7) // 8, seed + 1)
+    tw = {k: torch.from_numpy(v).cuda().requires_grad_(True) for k, v in w.items()}
+    sF = torch.from_numpy(feats).cuda().requires_grad_(True)
+    out = mc.spatial_conv(c["sP"], sF, c["sB"], c["pdfs"], c["P"], c["start"], c["packed"], c["mn"], c["mx"], tw["w1"],
+                          tw["w2"], tw["w3"], tw["b1"], tw["b2"], tw["b3"], fout, combin, B, R, False, True)
+    out.backward(torch.from_numpy(og).cuda())
+    torch.cuda.synchronize()
+    a = (_np(c["sP"]), feats, _np(c["sB"]), _np(c["pdfs"]), c["pts"], _np(c["start"]), _np(c["packed"]), _np(c["mn"]),
+         _np(c["mx"]), w["w1"], w["w2"], w["w3"], w["b1"], w["b2"], w["b3"])
+    ref = orc.spatial_conv(*a, fout, combin, B, R, False, True)
+    rg = orc.spatial_conv_grad(*a, og, fout, combin, B, R, False, True)
+    errs = {"out": float(np.abs(_np(out) - ref).max() / np.abs(ref).max())}
+    got = [sF.grad, tw["w1"].grad, tw["b1"].grad, tw["w2"].grad, tw["b2"].grad, tw["w3"].grad, tw["b3"].grad]
+    for nm, g, r_ in zip(["featGrad", "dw1", "db1", "dw2", "db2", "dw3", "db3"], got, rg):
+        errs[nm] = float(np.abs(_np(g).astype(np.float64) - r_).max() / max(np.abs(r_).max(), 1e-30))
+    print("E=%d Fin=%d Fout=%d combin=%s" % (c["packed"].shape[0], fin, fout, combin), {k: "%.1e" % v for k, v in errs.items()})
+    for nm, e in errs.items():
+        assert e <= RTOL, (nm, e)
+
+
+def test_fullsize_integer_outputs_vs_oracle(chain1, oracle_omp):
+    assert _check_ints(chain1, oracle_omp) > 4_000_000
+
+
+@pytest.mark.parametrize("shape", [(1, 64, True), (3, 8, True), (256, 256, False)], ids=["1to64", "3to8", "dw256"])
+def test_fullsize_conv_and_gradients_vs_oracle(mc, oracle_omp, chain1, shape):
+    _check_conv(mc, oracle_omp, chain1, *shape, seed=5)
+
+
+def test_two_rooms_integer_outputs_vs_oracle(chain2, oracle_omp):
+    assert _check_ints(chain2, oracle_omp) > 2048 * 48 * 64   # beyond one round of the backward partition
+
+
+@pytest.mark.parametrize("shape", [(1, 64, True), (3, 8, True), (64, 64, False)], ids=["1to64", "3to8", "dw64"])
+def test_two_rooms_conv_and_gradients_vs_oracle(mc, oracle_omp, chain2, shape):
+    _check_conv(mc, oracle_omp, chain2, *shape, seed=9)

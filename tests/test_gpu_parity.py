@@ -190,13 +190,12 @@ def test_spatial_conv_fwd_bwd(mc, oracle, case):
     for nm, a, b in zip(names, got, rg):
         assert_close(_unwrap(a), b, RTOL, nm)
     # second implementation on the GPU: the VALU fallback kernels (every shape) and, for one input feature, the general
-    # MFMA kernels instead of the factored ones -- selected per call through the environment
-    import os
-    others = [("MCCNN_FORCE_VALU", "VALU kernels")]
+    # MFMA kernels instead of the factored ones -- selected per call through the library's test hook
+    others = [(1, "VALU kernels")]
     if combin and fin == 1:
-        others.append(("MCCNN_NO_F1", "general MFMA kernels"))
-    for env, label in others:
-        os.environ[env] = "1"
+        others.append((2, "general MFMA kernels"))
+    for mask, label in others:
+        mc.debug_conv_impl(mask)
         try:
             tw2 = {k: _wrap(v).requires_grad_(True) for k, v in w.items()}
             sF2 = h["sF"].detach().clone().requires_grad_(True)
@@ -206,7 +205,7 @@ def test_spatial_conv_fwd_bwd(mc, oracle, case):
             out2.backward(_wrap(og))
             torch.cuda.synchronize()
         finally:
-            del os.environ[env]
+            mc.debug_conv_impl(0)
         assert_close(_unwrap(out), _unwrap(out2), 2e-5, label + ": forward")
         got2 = [sF2.grad, tw2["w1"].grad, tw2["b1"].grad, tw2["w2"].grad, tw2["b2"].grad, tw2["w3"].grad, tw2["b3"].grad]
         # all three GPU implementations share every pre-activation bit for bit; they differ in summation order only
@@ -278,6 +277,47 @@ def test_poisson_dataflow_and_phased_forms_agree(mc, oracle):
                 assert np.array_equal(g[k], o[k]), (kind, flag, k)
         for k in ("samplePts", "sampleBatchs", "sampleIndexs"):
             assert np.array_equal(outs[0][k], outs[1][k])
+
+
+def test_poisson_timeout_falls_back_to_phased_form(mc, oracle):
+    """The dataflow kernel relies on earlier-phase cells finishing while later ones wait (bounded spin). Mode 2 removes
+    the spin altogether: a cell whose predecessor is not done yet raises the failure flag, the count reports -1 and the
+    op repeats with one launch per phase -- same samples, same order."""
+    pts, bids = make_cloud(4096, 2, 3, "uniform", True)
+    feats = np.ones((len(pts), 1), np.float32)
+    o = run_chain(oracle, _ident, _ident, pts, bids, feats, 2, 0.1, True, poisson_radius=0.1)
+    before = mc.POISSON_FALLBACKS
+    mc.POISSON_DATAFLOW = 2
+    try:
+        g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, 2, 0.1, True, poisson_radius=0.1)
+    finally:
+        mc.POISSON_DATAFLOW = True
+    assert mc.POISSON_FALLBACKS == before + 1          # the fallback really ran
+    for k in ("samplePts", "sampleBatchs", "sampleIndexs", "sampleFeatures", "transformedIndexs"):
+        assert np.array_equal(g[k], o[k]), k
+
+
+def test_batch_id_validation(mc):
+    """Batch ids outside [0, batchSize): counted by mccnn_check_batch_ids, raised as MCCNN_E_BATCHID by the binding when
+    CHECK_BATCH_IDS is on; the kernels clamp ids, so the chain stays memory-safe either way."""
+    import torch
+    from mccnn_amd._lib import MCCNNError
+    pts, bids = make_cloud(256, 2, 0)
+    bad = bids.copy()
+    bad[5, 0] = 7
+    bad[9, 0] = -1
+    P, Bi = _wrap(pts), _wrap(bad)
+    assert mc.check_batch_ids(_wrap(bids), 2) == 0 and mc.check_batch_ids(Bi, 2) == 2
+    mc.CHECK_BATCH_IDS = True
+    try:
+        with pytest.raises(MCCNNError, match="batch id"):
+            mc.compute_aabb(P, Bi, 2, True)
+    finally:
+        mc.CHECK_BATCH_IDS = False
+    mn, mx = mc.compute_aabb(P, Bi, 2, True)                       # invalid ids are skipped by the box ...
+    k, i = mc.sort_points_step1(P, Bi, mn, mx, 2, 0.2, True)       # ... and clamped by the grid: still a permutation
+    torch.cuda.synchronize()
+    assert np.array_equal(np.sort(_unwrap(i)), np.arange(len(pts)))
 
 
 def test_permutation_ops_and_adjoints(mc, oracle):

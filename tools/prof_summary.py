@@ -1,24 +1,43 @@
-"""Summarise rocprofv3 kernel-trace stats + PMC passes written by tools/prof.sh."""
+"""Summarise the rocprofv3 passes written by tools/prof.sh: python tools/prof_summary.py <dir> [drop]
+
+Kernel times come from the per-dispatch kernel trace with the first `drop` dispatches of every kernel left out (steady
+state); counters are means per dispatch. HBM-side traffic is corrected as /opt/skills/guides/MI355X_MICROARCH.md
+prescribes for gfx950: FETCH_SIZE counts 64 B per 128-B request (doubled), both counters are in KB, WRITE_SIZE is
+uncalibrated. Writes <dir>/traffic.json and <dir>/kernels.json next to the text summary."""
 import glob
+import json
 import os
 import sys
 
 import pandas as pd
 
 out = sys.argv[1]
+drop = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 
 
 def short(n):
     n = n.split("(")[0]
-    return n.replace("void mccnn::", "").replace("mccnn::", "")[:60]
+    return n.replace("void mccnn::", "").replace("mccnn::", "")[:64]
 
 
-for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+kern = {}
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
     df = pd.read_csv(f)
-    df["Name"] = df["Name"].map(short)
-    cols = [c for c in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage") if c in df.columns]
-    print("== kernel stats (%s)" % os.path.relpath(f, out))
-    print(df[cols].head(25).to_string(index=False))
+    df["Name"] = df["Kernel_Name"].map(short)
+    df["ns"] = df["End_Timestamp"] - df["Start_Timestamp"]
+    df = df.sort_values("Start_Timestamp")
+    rows = []
+    for name, g in df.groupby("Name", sort=False):
+        steady = g["ns"].iloc[drop:] if len(g) > drop else g["ns"]
+        rows.append((name, len(g), len(steady), steady.mean() / 1e3, steady.min() / 1e3, g["ns"].iloc[0] / 1e3, steady.sum() / 1e3,
+                     int(g["VGPR_Count"].iloc[0]), int(g["Scratch_Size"].iloc[0]), int(g["LDS_Block_Size"].iloc[0])))
+    t = pd.DataFrame(rows, columns=["kernel", "calls", "steady", "avg_us", "min_us", "first_us", "total_us", "vgpr", "scratch", "lds"])
+    t = t.sort_values("total_us", ascending=False)
+    t["pct"] = 100 * t["total_us"] / t["total_us"].sum()
+    print("== kernels, steady state (first %d dispatches of each kernel dropped; %s)" % (drop, os.path.relpath(f, out)))
+    pd.set_option("display.width", 250)
+    print(t.head(40).to_string(index=False, float_format=lambda x: "%.1f" % x))
+    kern = {r.kernel: {"avg_us": round(r.avg_us, 2), "calls": int(r.calls), "vgpr": r.vgpr, "scratch": r.scratch} for r in t.itertuples()}
 rows = []
 for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     df = pd.read_csv(f)
@@ -28,21 +47,26 @@ for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), r
 if rows:
     allc = pd.concat(rows)
     piv = allc.pivot_table(index="Kernel_Name", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
-    keep = [k for k in piv.index if any(t in k for t in ("conv_", "f1_", "neigh", "pdf_edges", "edge_rec", "scatter_edge", "keys_hist"))]
-    pd.set_option("display.width", 250)
-    pd.set_option("display.max_columns", 50)
+    tags = ("conv_", "f1_", "neigh", "pdf_", "edge_rec", "scatter_edge", "keys_", "grid_", "sort_", "cell_", "poisson", "tr_", "scan", "rank_", "move_")
+    keep = [k for k in piv.index if any(t in k for t in tags)]
+    pd.set_option("display.max_columns", 60)
+    pd.set_option("display.max_rows", 200)
     print("== PMC (mean per dispatch)")
     print(piv.loc[keep].T.to_string(float_format=lambda x: "%.4g" % x))
-
-# HBM-side traffic per dispatch of the conv kernels, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for
-# gfx950 (FETCH_SIZE counts 64 B per 128-B request: doubled; both counters are in KB; WRITE_SIZE is uncalibrated).
-if rows:
-    import json
+    # derived: MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in piv.columns and "GRBM_GUI_ACTIVE" in piv.columns:
+        print("== MFMA pipe busy (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs))")
+        for k in keep:
+            a, b = piv.loc[k].get("SQ_VALU_MFMA_BUSY_CYCLES"), piv.loc[k].get("GRBM_GUI_ACTIVE")
+            if a == a and b == b and b > 0 and a > 0:
+                print("   %-50s %.3f" % (k, a / (b / 8 * 1024)))
+                kern.setdefault(k, {})["mfma_busy"] = round(a / (b / 8 * 1024), 4)
     traffic = {}
     for k in piv.index:
-        if "FETCH_SIZE" in piv.columns and "WRITE_SIZE" in piv.columns and ("conv_" in k or "f1_" in k or "neigh" in k or "pdf_edges" in k):
+        if "FETCH_SIZE" in piv.columns and "WRITE_SIZE" in piv.columns and k in keep:
             f, w = piv.loc[k].get("FETCH_SIZE"), piv.loc[k].get("WRITE_SIZE")
             if f == f and w == w:
                 traffic[k] = {"fetch_bytes": float(f) * 1024 * 2, "write_bytes": float(w) * 1024,
                               "bytes": float(f) * 1024 * 2 + float(w) * 1024}
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+json.dump(kern, open(os.path.join(out, "kernels.json"), "w"), indent=1)
