@@ -133,7 +133,10 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
 /* e: capacity of `packed` in rows. Normally the total the count call produced; a caller that wants
  * to launch the fill before it has read that total back (to hide the read-back behind the kernel)
  * may pass a guess: rows beyond the capacity are simply not written, and if the total turns out
- * larger the call is repeated with a big enough buffer. ws: the workspace of the count call. */
+ * larger the call is repeated with a big enough buffer. ws: the workspace of the count call,
+ * UNTOUCHED in between -- the count pass leaves the hit masks of every (centre, 64-candidate round)
+ * there and the fill pass only compacts them (one traversal of the candidate windows, not two as in
+ * find_neighbors.cu:268-372). */
 int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m,
                               const float* sorted_pts, int n, const int* cell_indexs,
                               const float* aabb_min, const float* aabb_max, int batch_size,

@@ -49,17 +49,37 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 #ifndef MCCNN_NW_CAP
 #define MCCNN_NW_CAP 256
 #endif
-template <bool FILL>
+// Hit masks the count pass leaves for the fill pass: MCCNN_NW_ROUNDS 64-candidate rounds per centre (windows of up to
+// 512 points; larger ones are searched again by the fill pass).
+#ifndef MCCNN_NW_ROUNDS
+#define MCCNN_NW_ROUNDS 8
+#endif
+
+// Workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only): hand every XCD one CONTIGUOUS run of
+// tiles. Tiles follow the cell-coherent visiting order, so an XCD then works on one region of space and its private L2
+// holds that region's points and cell ranges once -- with the default interleaving every one of the 8 L2s pulled the
+// whole point set through the fabric (22 + 28 MB fetched for 3 MB of inputs on the 100k room). Bijective for any n.
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+// MODE 0 = count: hits per centre, and the ballot of every 64-candidate round is saved (`masks`).
+// MODE 1 = fill: writes the (j, i) rows at startIdx[i]. Windows whose rounds fit the saved masks are a pure
+//          compaction -- no point is loaded and no distance evaluated a second time; larger windows are searched again.
+template <int MODE>
 __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ centres, const int* __restrict__ cb, int m,
                                                     const float* __restrict__ pts, const int* __restrict__ cells,
                                                     const float* __restrict__ mn, const float* __restrict__ mx, int B, int nc,
                                                     float radius, int scaleInv, const int* __restrict__ order,
-                                                    int* __restrict__ cnt, const int* __restrict__ startIdx,
-                                                    int* __restrict__ packed, int capacity) {
+                                                    int* __restrict__ cnt, unsigned long long* __restrict__ masks,
+                                                    const int* __restrict__ startIdx, int* __restrict__ packed,
+                                                    int capacity) {
+    constexpr bool FILL = MODE == 1;
     __shared__ float4 win[4][MCCNN_NW_CAP];
     __shared__ int2 ctab[4][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g0 = (blockIdx.x * 4 + wave) * MCCNN_NW_G;
+    const int g0 = (xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave) * MCCNN_NW_G;
     if (g0 >= m) return;
     float4* lw = win[wave];
     int2* tab = ctab[wave];
@@ -97,23 +117,51 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
         __builtin_amdgcn_wave_barrier();
         if (lane < 27) tab[lane] = make_int2(j0 - off, off + len);
         __builtin_amdgcn_wave_barrier();
+        // neighbour index of flat position f of the window: its cell is found by a 5-step binary search over the 27
+        // cell end offsets (kept in LDS)
+        auto flat_to_j = [&](int f) -> int {
+            int lo = 0, hi = 26;  // smallest o with end[o] > f
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int mid = (lo + hi) >> 1;
+                const bool right = tab[mid].y <= f;
+                lo = right ? mid + 1 : lo;
+                hi = right ? hi : mid;
+            }
+            return tab[lo].x + f;  // (j0 - off) + f
+        };
+        if (FILL && total <= MCCNN_NW_ROUNDS * 64) {
+            // pure compaction from the saved ballots: lane = candidate of round r, the same for every centre of the cell
+            int jr[MCCNN_NW_ROUNDS];
+#pragma unroll
+            for (int r = 0; r < MCCNN_NW_ROUNDS; ++r) jr[r] = (r * 64 < total) ? flat_to_j(min(r * 64 + lane, total - 1)) : 0;
+            unsigned mem = members;
+            while (mem) {
+                const int cl = __builtin_ctz(mem);
+                mem &= mem - 1;
+                const int cbase = __builtin_amdgcn_readlane(base, cl), cid = __builtin_amdgcn_readlane(i, cl);
+                const unsigned long long* mrow = masks + (size_t)cid * MCCNN_NW_ROUNDS;
+                int run = 0;
+#pragma unroll
+                for (int r = 0; r < MCCNN_NW_ROUNDS; ++r) {
+                    if (r * 64 < total) {
+                        const unsigned long long bm = mrow[r];  // wave-uniform address
+                        if ((bm >> lane) & 1ull) {
+                            const int pos = cbase + run + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+                            if (pos < capacity) out[pos] = make_int2(jr[r], cid);  // capacity < E: see _fill
+                        }
+                        run += __builtin_popcountll(bm);
+                    }
+                }
+            }
+            continue;
+        }
         for (int seg = 0; seg < total; seg += MCCNN_NW_CAP) {
             const int segN = min(MCCNN_NW_CAP, total - seg);
-            // stage [seg, seg + segN) of the flat list: lane = flat position; its cell is found by a 5-step binary
-            // search over the 27 cell end offsets (kept in LDS), then one load and one LDS write per position
+            // stage [seg, seg + segN) of the flat list: lane = flat position, one load and one LDS write per position
             for (int r = 0; r < segN; r += 64) {
-                const int f = seg + r + lane;
-                int lo = 0, hi = 26;  // smallest o with end[o] > f
-#pragma unroll
-                for (int it = 0; it < 5; ++it) {
-                    const int mid = (lo + hi) >> 1;
-                    const bool right = tab[mid].y <= f;
-                    lo = right ? mid + 1 : lo;
-                    hi = right ? hi : mid;
-                }
+                const int j = flat_to_j(min(seg + r + lane, total - 1));
                 if (r + lane < segN) {
-                    const int2 tb = tab[lo];           // (j0 - off, end)
-                    const int j = tb.x + f;
                     const float* q = pts + (size_t)j * 3;  // 12-byte rows: one dwordx3 load
                     lw[r + lane] = make_float4(q[0], q[1], q[2], __int_as_float(j));
                 }
@@ -126,8 +174,9 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                 mem &= mem - 1;
                 const float cx = readlane_f(c.cx, cl), cy = readlane_f(c.cy, cl);
                 const float cz = readlane_f(c.cz, cl), T = readlane_f(c.T, cl);
-                int cbase = 0, ccount = __builtin_amdgcn_readlane(count, cl), cid = 0;
-                if (FILL) { cbase = __builtin_amdgcn_readlane(base, cl); cid = __builtin_amdgcn_readlane(i, cl); }
+                const int cid = __builtin_amdgcn_readlane(i, cl);
+                int cbase = 0, ccount = __builtin_amdgcn_readlane(count, cl);
+                if (FILL) cbase = __builtin_amdgcn_readlane(base, cl);
                 for (int r = 0; r < segN; r += 64) {
                     const int t = r + lane;
                     const float4 p = lw[min(t, segN - 1)];
@@ -136,6 +185,10 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                     if (FILL && hit) {
                         const int pos = cbase + ccount + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
                         if (pos < capacity) out[pos] = make_int2(__float_as_int(p.w), cid);  // capacity < E: see _fill
+                    }
+                    if (!FILL) {
+                        const int round = (seg + r) >> 6;
+                        if (round < MCCNN_NW_ROUNDS && lane == 0) masks[(size_t)cid * MCCNN_NW_ROUNDS + round] = bm;
                     }
                     ccount += __builtin_popcountll(bm);
                 }
@@ -262,12 +315,13 @@ extern "C" {
 size_t mccnn_find_neighbors_workspace_bytes(int m, int n) {
     size_t m1 = (size_t)(m > 0 ? m : 1);
     (void)n;
-    return align_up(m1 * 4) + scan_workspace_bytes((int)m1) + 256;
+    return align_up(m1 * 4) + scan_workspace_bytes((int)m1) + align_up(m1 * MCCNN_NW_ROUNDS * sizeof(unsigned long long)) + 256;
 }
 
 struct NeighWs {
     int* cnt;  // hits per centre
     void* scanws;
+    unsigned long long* masks;  // per centre: the ballots of its first MCCNN_NW_ROUNDS candidate rounds (count -> fill)
 };
 static bool neigh_ws(void* ws, size_t ws_bytes, int m, int n, NeighWs& w) {
     if (!ws || ws_bytes < mccnn_find_neighbors_workspace_bytes(m, n)) return false;
@@ -275,8 +329,9 @@ static bool neigh_ws(void* ws, size_t ws_bytes, int m, int n, NeighWs& w) {
     Arena a(ws, ws_bytes);
     w.cnt = a.take<int>(m1);
     w.scanws = a.take<char>(scan_workspace_bytes((int)m1));
+    w.masks = a.take<unsigned long long>(m1 * MCCNN_NW_ROUNDS);
     (void)n;
-    return w.cnt && w.scanws;
+    return w.cnt && w.scanws && w.masks;
 }
 
 int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
@@ -293,9 +348,9 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
         return MCCNN_E_BADARG;
     NeighWs w;
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
-    neigh_window<false><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
-                                                                  aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, w.cnt,
-                                                                  nullptr, nullptr, 0);
+    neigh_window<0><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
+                                                              aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, w.cnt,
+                                                              w.masks, nullptr, nullptr, 0);
     MCCNN_LAUNCHED();
     int rc = exclusive_scan_i32(w.cnt, start_idx, m, total_dev, w.scanws, s);
     if (rc) return rc;
@@ -314,9 +369,9 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     NeighWs w;
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    neigh_window<true><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
-                                                                 aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, nullptr,
-                                                                 start_idx, packed, e);
+    neigh_window<1><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
+                                                              aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, nullptr,
+                                                              w.masks, start_idx, packed, e);
     MCCNN_LAUNCHED();
     return 0;
 }
