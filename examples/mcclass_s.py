@@ -21,10 +21,11 @@ from mccnn_amd.MCNetworkUtils import (MLP_2_hidden, batch_norm_RELU_drop_out, co
 class MCClassS:
     """models/MCClassS.py create_network(): 3 Poisson levels, 3 MC convolutions, global-feature MLP."""
 
-    def __init__(self, numInputFeatures, batchSize, k, numOutCat, device):
+    def __init__(self, numInputFeatures, batchSize, k, numOutCat, device, ops=None):
         self.args = (numInputFeatures, batchSize, k, numOutCat)
         self.store = VariableStore(device)
-        self.convBuilder = ConvolutionBuilder(KDEWindow=0.2, device=device)
+        self.ops = ops  # None = the HIP op surface; the parity tests pass the CPU checker's
+        self.convBuilder = ConvolutionBuilder(KDEWindow=0.2, device=device, ops=ops)
 
     def parameters(self):
         return self.convBuilder.parameters() + self.store.parameters()
@@ -35,7 +36,7 @@ class MCClassS:
         st, mConvBuilder = self.store, self.convBuilder
         mConvBuilder.reset()
         mPointHierarchy = PointHierarchy(points, features, batchIds, [0.1, 0.4, math.sqrt(3.0) + 0.1], "MCClassS_PH",
-                                         batchSize)
+                                         batchSize, ops=self.ops)
         convFeatures1 = mConvBuilder.create_convolution(
             convName="Conv_1", inPointHierarchy=mPointHierarchy, inPointLevel=0, outPointLevel=1, inFeatures=features,
             inNumFeatures=numInputFeatures, outNumFeatures=k, convRadius=0.2, multiFeatureConv=True)
@@ -61,10 +62,11 @@ class MCClassS:
 class MCNormS:
     """models/MCNormS.py create_network(): two same-level multi-feature convolutions (normal estimation)."""
 
-    def __init__(self, numInputFeatures, batchSize, k, device):
+    def __init__(self, numInputFeatures, batchSize, k, device, ops=None):
         self.args = (numInputFeatures, batchSize, k)
         self.store = VariableStore(device)
-        self.convBuilder = ConvolutionBuilder(KDEWindow=0.2, device=device)
+        self.ops = ops
+        self.convBuilder = ConvolutionBuilder(KDEWindow=0.2, device=device, ops=ops)
 
     def parameters(self):
         return self.convBuilder.parameters() + self.store.parameters()
@@ -73,7 +75,7 @@ class MCNormS:
         numInputFeatures, batchSize, k = self.args
         cb = self.convBuilder
         cb.reset()
-        ph = PointHierarchy(points, features, batchIds, [], "MCNormS_PH", batchSize)
+        ph = PointHierarchy(points, features, batchIds, [], "MCNormS_PH", batchSize, ops=self.ops)
         c1 = cb.create_convolution(convName="Conv_1", inPointHierarchy=ph, inPointLevel=0, inFeatures=features,
                                    inNumFeatures=numInputFeatures, outNumFeatures=k, convRadius=0.15, multiFeatureConv=True)
         c1 = batch_norm_RELU_drop_out("BN_RELU", c1, isTraining, False, False, self.store)

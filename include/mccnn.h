@@ -216,6 +216,32 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats,
                            float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes,
                            mccnn_stream_t stream);
 
+/* bf16 FEATURE STORAGE for depth-wise layers (extension, BASELINE cfg3; the reference is f32-only).
+ * Same operators as mccnn_spatial_conv_fwd / _bwd with combin == 0, but the gathered rows -- features
+ * [n, num_feats], outputs [m, num_feats], out-gradients and feature gradients -- are stored as bf16
+ * (two-byte elements, round-to-nearest-even on store, widened exactly on load); the kernel-MLP
+ * tensors, every product and every accumulation stay f32. These layers are bound by the gather of
+ * 4 * Fin bytes per edge and direction: bf16 rows halve that. Requirements: num_feats % 8
+ * == 0, (num_feats + 7) / 8 <= 64 blocks, 16-byte aligned row buffers; otherwise MCCNN_E_SHAPE.
+ * Workspace sizes: the f32 queries with num_in_feats = num_out_feats = num_feats, combin = 0. */
+int mccnn_spatial_conv_fwd_bf16(const float* sorted_pts, const void* sorted_feats_bf16,
+                                const int* sorted_batch_ids, const float* pdfs, const float* samples,
+                                const int* start_idx, const int* packed, const float* aabb_min,
+                                const float* aabb_max, const float* w1, const float* b1, const float* w2,
+                                const float* b2, const float* w3, const float* b3, int n, int m, int e,
+                                int num_feats, int batch_size, float radius, int scale_inv, int avg,
+                                void* out_bf16, void* ws, size_t ws_bytes, mccnn_stream_t stream);
+int mccnn_spatial_conv_bwd_bf16(const float* sorted_pts, const void* sorted_feats_bf16,
+                                const int* sorted_batch_ids, const float* pdfs, const float* samples,
+                                const int* start_idx, const int* packed, const float* aabb_min,
+                                const float* aabb_max, const float* w1, const float* b1, const float* w2,
+                                const float* b2, const float* w3, const float* b3,
+                                const void* out_grad_bf16, int n, int m, int e, int num_feats,
+                                int batch_size, float radius, int scale_inv, int avg, const int* start_t,
+                                const int* perm_t, void* feat_grad_bf16, float* dw1, float* db1, float* dw2,
+                                float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes,
+                                mccnn_stream_t stream);
+
 /* Transposed neighbour list (CSR by neighbour index j): start_t[n+1] and perm_t[e] = edge ids
  * grouped by j, ascending inside a row. Depth-wise SpatialConvGrad needs it to compute the
  * feature gradient without float atomics; pass the pair to mccnn_spatial_conv_bwd (start_t /

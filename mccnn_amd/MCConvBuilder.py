@@ -17,6 +17,25 @@ from .MCConvModule import (compute_aabb, sort_points_step1, sort_points_step2, s
                            compute_pdf, poisson_sampling, get_sampled_features, spatial_conv, get_block_size,
                            transform_indexs, find_neighbors)
 
+_OP_NAMES = ("compute_aabb", "sort_points_step1", "sort_points_step2", "sort_features", "sort_features_back",
+             "compute_pdf", "poisson_sampling", "get_sampled_features", "spatial_conv", "get_block_size",
+             "transform_indexs", "find_neighbors")
+
+
+class _Ops:
+    """The twelve names the reference builder imports from MCConvModule (MCConvBuilder.py:20-21). By default they are
+    this module's own imports of the HIP op surface, looked up at call time; a caller may hand the builder classes
+    another object with the same names (`ops=`) -- the parity tests run the identical graph through the CPU checker."""
+
+    def __init__(self, ops=None):
+        self._ops = ops
+
+    def __getattr__(self, name):
+        if name not in _OP_NAMES:
+            raise AttributeError(name)
+        return getattr(self._ops, name) if self._ops is not None else globals()[name]
+
+
 _VERBOSE = False
 
 
@@ -33,12 +52,13 @@ class PointHierarchy:
     """
 
     def __init__(self, inPoints, inFeatures, inBatchIds, radiusList, hierarchyName="Point_Hierarchy", batchSize=32,
-                 relativeRadius=True, aabbReduceGroup=None):
+                 relativeRadius=True, aabbReduceGroup=None, ops=None):
         """aabbReduceGroup (extension, data-parallel shards only): with relativeRadius=False the reference uses ONE box
         for the whole batch (aabb_gpu.cu:104-114). A shard that holds part of the batch passes its process group here
         (`True` = the default group) and the MIN/MAX all-reduce of the box runs between compute_aabb and the first
         sort, so every level of the sharded hierarchy -- cells, keys, Poisson samples -- equals the corresponding
         slice of the single-device hierarchy (mccnn_amd.dist)."""
+        ops = _Ops(ops)
         self.points_ = [inPoints]
         self.features_ = [inFeatures]
         self.batchIds_ = [inBatchIds]
@@ -48,7 +68,7 @@ class PointHierarchy:
         self.relativeRadius_ = relativeRadius
         self.hierarchyName_ = hierarchyName
 
-        aabbMin, aabbMax = compute_aabb(inPoints, inBatchIds, batchSize, self.relativeRadius_)
+        aabbMin, aabbMax = ops.compute_aabb(inPoints, inBatchIds, batchSize, self.relativeRadius_)
         if aabbReduceGroup is not None and not self.relativeRadius_:
             from .dist import allreduce_aabb
             aabbMin, aabbMax = allreduce_aabb(aabbMin, aabbMax, None if aabbReduceGroup is True else aabbReduceGroup)
@@ -59,15 +79,15 @@ class PointHierarchy:
         currPts, currFeatures, currBatchIds = inPoints, inFeatures, inBatchIds
         for level, currRadius in enumerate(radiusList):
             _log("Level: %d | Poisson Disk Radius: %s" % (level + 1, currRadius))
-            keys, indexs = sort_points_step1(currPts, currBatchIds, self.aabbMin_, self.aabbMax_, self.batchSize_,
+            keys, indexs = ops.sort_points_step1(currPts, currBatchIds, self.aabbMin_, self.aabbMax_, self.batchSize_,
                                              currRadius, self.relativeRadius_)
-            sortPts, sortBatchs, sortFeatures, cellIndexs = sort_points_step2(
+            sortPts, sortBatchs, sortFeatures, cellIndexs = ops.sort_points_step2(
                 currPts, currBatchIds, currFeatures, keys, indexs, self.aabbMin_, self.aabbMax_, self.batchSize_,
                 currRadius, self.relativeRadius_)
-            sampledPts, sampledBatchsIds, sampledIndexs = poisson_sampling(
+            sampledPts, sampledBatchsIds, sampledIndexs = ops.poisson_sampling(
                 sortPts, sortBatchs, cellIndexs, aabbMin, aabbMax, currRadius, batchSize, self.relativeRadius_)
-            sampledFeatures = get_sampled_features(sampledIndexs, sortFeatures)
-            transformedIndexs = transform_indexs(sampledIndexs, indexs)
+            sampledFeatures = ops.get_sampled_features(sampledIndexs, sortFeatures)
+            transformedIndexs = ops.transform_indexs(sampledIndexs, indexs)
 
             self.points_.append(sampledPts)
             self.batchIds_.append(sampledBatchsIds)
@@ -91,7 +111,8 @@ class ConvolutionBuilder:
     (MCConvBuilder.py:133-427)."""
 
     def __init__(self, multiFeatureConvs=False, KDEWindow=0.25, relativeRadius=True, usePDF=True, useAVG=True,
-                 decayLossCollection='weight_decay_loss', device=None):
+                 decayLossCollection='weight_decay_loss', device=None, ops=None):
+        self.ops_ = _Ops(ops)
         self.cacheGrids_ = {}
         self.cacheNeighs_ = {}
         self.cachePDFs_ = {}
@@ -191,14 +212,14 @@ class ConvolutionBuilder:
         # grid (MCConvBuilder.py:349-363)
         if keyGrid in self.cacheGrids_:
             currGridTuple = self.cacheGrids_[keyGrid]
-            sortFeatures = sort_features(inFeatures, currGridTuple[3])
+            sortFeatures = self.ops_.sort_features(inFeatures, currGridTuple[3])
             self._trace("sort_features", keyGrid)
         else:
-            keys, indexs = sort_points_step1(
+            keys, indexs = self.ops_.sort_points_step1(
                 inPointHierarchy.points_[inPointLevel], inPointHierarchy.batchIds_[inPointLevel],
                 inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, inPointHierarchy.batchSize_, convRadius,
                 currRelativeRadius)
-            sortPts, sortBatchs, sortFeatures, cellIndexs = sort_points_step2(
+            sortPts, sortBatchs, sortFeatures, cellIndexs = self.ops_.sort_points_step2(
                 inPointHierarchy.points_[inPointLevel], inPointHierarchy.batchIds_[inPointLevel], inFeatures, keys,
                 indexs, inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, inPointHierarchy.batchSize_,
                 convRadius, currRelativeRadius)
@@ -211,7 +232,7 @@ class ConvolutionBuilder:
         if keyNeighs in self.cacheNeighs_:
             currNeighTuple = self.cacheNeighs_[keyNeighs]
         else:
-            startIndexs, packedNeighs = find_neighbors(
+            startIndexs, packedNeighs = self.ops_.find_neighbors(
                 currOutPointHierarchy.points_[currOutPointLevel], currOutPointHierarchy.batchIds_[currOutPointLevel],
                 currGridTuple[0], currGridTuple[2], inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, convRadius,
                 inPointHierarchy.batchSize_, currRelativeRadius)
@@ -224,7 +245,7 @@ class ConvolutionBuilder:
             currPDFs = self.cachePDFs_[keyPDF]
         else:
             if currUsePDF:
-                currPDFs = compute_pdf(currGridTuple[0], currGridTuple[1], inPointHierarchy.aabbMin_,
+                currPDFs = self.ops_.compute_pdf(currGridTuple[0], currGridTuple[1], inPointHierarchy.aabbMin_,
                                        inPointHierarchy.aabbMax_, currNeighTuple[0], currNeighTuple[1], currKDEWindow,
                                        convRadius, inPointHierarchy.batchSize_, currRelativeRadius)
                 self._trace("compute_pdf", keyPDF)
@@ -234,7 +255,7 @@ class ConvolutionBuilder:
             self.cachePDFs_[keyPDF] = currPDFs
 
         # variables (MCConvBuilder.py:394-419)
-        blockSize = get_block_size()
+        blockSize = self.ops_.get_block_size()
         numOutNeurons = inNumFeatures * currNumOutFeatures if currMultiFeatureConv else inNumFeatures
         numBlocks = int(numOutNeurons / blockSize)
         if numOutNeurons % blockSize != 0:
@@ -258,7 +279,7 @@ class ConvolutionBuilder:
         biases3 = self._get_variable(convName + '_biases3', (numBlocks, blockSize), dev, zeros).reshape(nn)
 
         self._trace("spatial_conv", convName, (3, nn), currNumOutFeatures, bool(currMultiFeatureConv))
-        return spatial_conv(currGridTuple[0], sortFeatures, currGridTuple[1], currPDFs,
+        return self.ops_.spatial_conv(currGridTuple[0], sortFeatures, currGridTuple[1], currPDFs,
                             currOutPointHierarchy.points_[currOutPointLevel], currNeighTuple[0], currNeighTuple[1],
                             inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, weights, weights2, weights3, biases,
                             biases2, biases3, currNumOutFeatures, currMultiFeatureConv, inPointHierarchy.batchSize_,

@@ -34,6 +34,26 @@ def _f32(t, name):
     return t.contiguous()
 
 
+def _feat(t, name):
+    """Feature rows: float32, or bfloat16 storage (extension, BASELINE cfg3: depth-wise layers gather half the bytes).
+    bf16 rows need an even number of features -- the row permutations move them as 32-bit words."""
+    _req(isinstance(t, torch.Tensor) and t.is_cuda, "%s must be a CUDA tensor" % name)
+    _req(t.dtype in (torch.float32, torch.bfloat16), "%s must be float32 (or bfloat16 storage)" % name)
+    if t.dtype == torch.bfloat16:
+        _req(t.dim() == 2 and t.shape[1] % 2 == 0, "%s: bfloat16 rows need an even number of features" % name)
+    return t.contiguous()
+
+
+def _rows32(t):
+    """A bf16 row tensor seen as rows of 32-bit words (no copy); f32 tensors pass through."""
+    return t.view(torch.float32) if t.dtype == torch.bfloat16 else t
+
+
+def _like_rows(words, ref):
+    """Undo _rows32 for a result tensor."""
+    return words.view(torch.bfloat16) if ref.dtype == torch.bfloat16 else words
+
+
 def _i32(t, name):
     _req(isinstance(t, torch.Tensor) and t.is_cuda, "%s must be a CUDA tensor" % name)
     _req(t.dtype == torch.int32, "%s must be int32" % name)
@@ -239,18 +259,20 @@ def sort_points_step1(inPts, inBatchIds, aabbMin, aabbMax, batchSize, cellSize, 
 
 def _gather_rows(src, idx, n_rows):
     lib = _lib.load()
-    out = torch.empty((n_rows, src.shape[1]), dtype=torch.float32, device=src.device)
-    check(lib.mccnn_permute_gather(ptr(src), ptr(idx), n_rows, src.shape[1], ptr(out), stream_handle()),
+    w = _rows32(src)
+    out = torch.empty((n_rows, w.shape[1]), dtype=torch.float32, device=src.device)
+    check(lib.mccnn_permute_gather(ptr(w), ptr(idx), n_rows, w.shape[1], ptr(out), stream_handle()),
           "permute_gather")
-    return out
+    return _like_rows(out, src)
 
 
 def _scatter_rows(src, idx, n_out, zero_fill):
     lib = _lib.load()
-    out = torch.empty((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
-    check(lib.mccnn_permute_scatter(ptr(src), ptr(idx), src.shape[0], src.shape[1], ptr(out), n_out,
+    w = _rows32(src)
+    out = torch.empty((n_out, w.shape[1]), dtype=torch.float32, device=src.device)
+    check(lib.mccnn_permute_scatter(ptr(w), ptr(idx), w.shape[0], w.shape[1], ptr(out), n_out,
                                     int(zero_fill), stream_handle()), "permute_scatter")
-    return out
+    return _like_rows(out, src)
 
 
 class _SortPointsStep2(torch.autograd.Function):
@@ -259,7 +281,7 @@ class _SortPointsStep2(torch.autograd.Function):
         op = "SortPointsStep2Op"
         _req(batchSize > 0, op + " expects a positive batch size")
         pts, bids = _f32(inPts, "points"), _i32(inBatchIds, "batch_ids")
-        feats = _f32(inFeatures, "features")
+        feats = _feat(inFeatures, "features")
         keys, indexs = _i32(keys, "keys"), _i32(indexs, "index_new_pos")
         mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
         _check_points(pts, "points", op)
@@ -275,11 +297,12 @@ class _SortPointsStep2(torch.autograd.Function):
         oP = torch.empty_like(pts)
         oB = torch.empty_like(bids)
         oF = torch.empty_like(feats)
+        fw, oFw = _rows32(feats), _rows32(oF)
         cells = torch.empty((batchSize, nc, nc, nc, 2), dtype=torch.int32, device=pts.device)
         ws = _ws(lib.mccnn_sort_step2_workspace_bytes(n), pts.device)
         inv = torch.empty_like(indexs)  # visiting order for find_neighbors over these points, a by-product of the move
-        check(lib.mccnn_sort_step2(ptr(pts), ptr(bids), ptr(feats), ptr(keys), ptr(indexs), n, feats.shape[1],
-                                   batchSize, nc, ptr(oP), ptr(oB), ptr(oF), ptr(cells), ptr(inv), ptr(ws), ws.numel(),
+        check(lib.mccnn_sort_step2(ptr(pts), ptr(bids), ptr(fw), ptr(keys), ptr(indexs), n, fw.shape[1],
+                                   batchSize, nc, ptr(oP), ptr(oB), ptr(oFw), ptr(cells), ptr(inv), ptr(ws), ws.numel(),
                                    stream_handle()), "sort_points_step2")
         ctx.save_for_backward(indexs)
         ctx.mark_non_differentiable(oB, cells)
@@ -296,7 +319,7 @@ class _SortPointsStep2(torch.autograd.Function):
         (indexs,) = ctx.saved_tensors
         n = indexs.shape[0]
         dPts = _gather_rows(_f32(gPts, "grad"), indexs, n) if (gPts is not None and ctx.needs[0]) else None
-        dFeats = _gather_rows(_f32(gFeats, "grad"), indexs, n) if (gFeats is not None and ctx.needs[1]) else None
+        dFeats = _gather_rows(_feat(gFeats, "grad"), indexs, n) if (gFeats is not None and ctx.needs[1]) else None
         return dPts, None, dFeats, None, None, None, None, None, None, None
 
 
@@ -311,7 +334,7 @@ class _SortFeatures(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, inFeatures, indexs):
-        f, idx = _f32(inFeatures, "features"), _i32(indexs, "index_new_pos")
+        f, idx = _feat(inFeatures, "features"), _i32(indexs, "index_new_pos")
         _req(idx.dim() == 1, "SortFeaturesBackGradOp expects indexs with the following dimensions (numPoints)")
         _req(f.dim() == 2 and f.shape[1] > 0 and f.shape[0] == idx.shape[0],
              "SortFeaturesBackGradOp expects features with dimensions (numPoints, numFeatures)")
@@ -321,7 +344,7 @@ class _SortFeatures(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
-        return _gather_rows(_f32(g, "grad"), idx, idx.shape[0]), None
+        return _gather_rows(_feat(g, "grad"), idx, idx.shape[0]), None
 
 
 def sort_features(inFeatures, indexs):
@@ -333,7 +356,7 @@ class _SortFeaturesBack(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, inFeatures, indexs):
-        f, idx = _f32(inFeatures, "features"), _i32(indexs, "index_new_pos")
+        f, idx = _feat(inFeatures, "features"), _i32(indexs, "index_new_pos")
         _req(idx.dim() == 1, "SortFeaturesBackOp expects indexs with the following dimensions (numPoints)")
         _req(f.dim() == 2 and f.shape[1] > 0 and f.shape[0] == idx.shape[0],
              "SortFeaturesBackOp expects features with dimensions (numPoints, numFeatures)")
@@ -343,7 +366,7 @@ class _SortFeaturesBack(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
-        return _scatter_rows(_f32(g, "grad"), idx, idx.shape[0], False), None
+        return _scatter_rows(_feat(g, "grad"), idx, idx.shape[0], False), None
 
 
 def sort_features_back(inFeatures, indexs):
@@ -501,7 +524,7 @@ class _GetSampledFeatures(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, inSampledIndexs, pInFeatures):
-        idx, f = _i32(inSampledIndexs, "sampled_indexs"), _f32(pInFeatures, "features")
+        idx, f = _i32(inSampledIndexs, "sampled_indexs"), _feat(pInFeatures, "features")
         _req(idx.dim() == 1, "GetSampledFeaturesOp expects indexs with the following dimensions (numSamples)")
         _req(f.dim() == 2 and f.shape[1] > 0, "GetSampledFeaturesOp expects features with dimensions (numPoints, numFeatures)")
         ctx.save_for_backward(idx)
@@ -511,7 +534,7 @@ class _GetSampledFeatures(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
-        return None, _scatter_rows(_f32(g, "grad"), idx, ctx.n, True)
+        return None, _scatter_rows(_feat(g, "grad"), idx, ctx.n, True)
 
 
 def get_sampled_features(inSampledIndexs, pInFeatures):
@@ -558,7 +581,8 @@ class _SpatialConv(torch.autograd.Function):
                 aabbMax, weights1, biases1, weights2, biases2, weightsOut, biasesOut, numOutFeatures, combin,
                 batchSize, radius, scaleInv, avg):
         op = "SpatialConvOp"
-        pts, feats, bids = _f32(inPts, "points"), _f32(inFeatures, "features"), _i32(inBatchIds, "batch_ids")
+        pts, feats, bids = _f32(inPts, "points"), _feat(inFeatures, "features"), _i32(inBatchIds, "batch_ids")
+        bf16 = feats.dtype == torch.bfloat16
         pdfs, smp = _f32(inPDFs, "pdfs"), _f32(inSamplePts, "sample_pts")
         st, pk = _i32(neighStartIndexs, "start_neighs_indexs"), _i32(packedNeighs, "neighs_indexs")
         mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
@@ -569,8 +593,22 @@ class _SpatialConv(torch.autograd.Function):
                                     numOutFeatures, combin, batchSize, radius)
         lib = _lib.load()
         outF = numOutFeatures if combin else fin
-        out = torch.empty((m, outF), dtype=torch.float32, device=pts.device)
         ws = _ws(lib.mccnn_spatial_conv_fwd_workspace_bytes(m, e, fin, numOutFeatures, int(bool(combin))), pts.device)
+        if bf16:
+            # bf16 feature storage (extension): depth-wise layers only, rows in / rows out as bf16, f32 arithmetic
+            _req(not combin and fin % 8 == 0, op + ": bfloat16 feature storage needs a depth-wise layer with numFeatures % 8 == 0")
+            out = torch.empty((m, outF), dtype=torch.bfloat16, device=pts.device)
+            check(lib.mccnn_spatial_conv_fwd_bf16(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
+                                                  ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
+                                                  n, m, e, fin, batchSize, float(radius), int(bool(scaleInv)),
+                                                  int(bool(avg)), ptr(out), ptr(ws), ws.numel(), stream_handle()),
+                  "spatial_conv(bf16)")
+            ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3)
+            ctx.state = None
+            ctx.packed_obj = packedNeighs if pk is packedNeighs else pk
+            ctx.attrs = (numOutFeatures, bool(combin), batchSize, float(radius), bool(scaleInv), bool(avg))
+            return out
+        out = torch.empty((m, outF), dtype=torch.float32, device=pts.device)
         # per-centre sums the backward pass can reuse (layers with one input feature); only kept when a gradient
         # will be asked for
         state = None
@@ -593,7 +631,10 @@ class _SpatialConv(torch.autograd.Function):
         # _spatial_conv_grad (MCConvModuleSrc:74-81): grads for features and the 6 MLP tensors only
         pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
         numOutFeatures, combin, batchSize, radius, scaleInv, avg = ctx.attrs
-        og = _f32(outGrad, "out_features_grad")
+        bf16 = feats.dtype == torch.bfloat16
+        og = _feat(outGrad, "out_features_grad")
+        if bf16 and og.dtype != torch.bfloat16:
+            og = og.to(torch.bfloat16)
         lib = _lib.load()
         n, fin = feats.shape
         m, e = smp.shape[0], pk.shape[0]
@@ -603,6 +644,15 @@ class _SpatialConv(torch.autograd.Function):
         start_t = perm_t = None
         if not combin and e > 0:
             start_t, perm_t, _ = _transposed_neighbors(ctx.packed_obj, n)
+        if bf16:
+            check(lib.mccnn_spatial_conv_bwd_bf16(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
+                                                  ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
+                                                  ptr(og), n, m, e, fin, batchSize, radius, int(scaleInv), int(avg),
+                                                  ptr(start_t), ptr(perm_t), ptr(fg), ptr(dw1), ptr(db1), ptr(dw2),
+                                                  ptr(db2), ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
+                  "spatial_conv_grad(bf16)")
+            return (None, fg, None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
+                    None, None, None, None, None, None)
         check(lib.mccnn_spatial_conv_bwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                          ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
                                          ptr(og), n, m, e, fin, numOutFeatures, int(combin), batchSize, radius,

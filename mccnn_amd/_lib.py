@@ -46,6 +46,8 @@ SIGNATURES = {
     "mccnn_spatial_conv_fwd": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_spatial_conv_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mccnn_spatial_conv_bwd": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _i, _i, _f, _i, _i] + [_vp] * 10 + [_vp, _sz, _vp]),
+    "mccnn_spatial_conv_fwd_bf16": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
+    "mccnn_spatial_conv_bwd_bf16": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _f, _i, _i] + [_vp] * 9 + [_vp, _sz, _vp]),
     "mccnn_transpose_neighbors_workspace_bytes": (_sz, [_i, _i]),
     "mccnn_transpose_neighbors": (_i, [_vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
 }

@@ -77,7 +77,8 @@ __device__ __forceinline__ void mlp_block(const ConvArgs& a, int q, float d0, fl
     }
 }
 
-// FEAT: 0 generic, 1 combin with Fin == 1, 2 no-combin with Fin % 8 == 0 (vector loads)
+// FEAT: 0 generic, 1 combin with Fin == 1, 2 no-combin with Fin % 8 == 0 (vector loads), 3 combin with Fin = 2..4
+//       (MFMA kernels only), 4 = 2 with bf16 feature / output rows (MFMA kernels only)
 template <bool COMBIN, int FEAT>
 __global__ __launch_bounds__(256) void conv_fwd_valu(ConvArgs a, float* __restrict__ out) {
     extern __shared__ float lds[];
@@ -193,11 +194,15 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
     const int eBeg = a.start[cA];
     const int eEnd = (cB < a.m) ? a.start[cB] : a.e;
     const bool vecOut = (!COMBIN || FEAT == 1) && (outF & 3) == 0;
+    constexpr bool BF = FEAT == 4;  // bf16 rows: `a.feats` and `out` hold 2-byte elements
+    const unsigned short* feats16 = reinterpret_cast<const unsigned short*>(a.feats);
+    unsigned short* out16 = reinterpret_cast<unsigned short*>(out);
 
     // rows of centres without neighbours are never reached by an edge: zero them where the gap shows up
     auto zero_rows = [&](int c0, int c1) {
+        const int words = BF ? outF / 2 : outF;  // 32-bit words per row (bf16 rows: outF % 8 == 0)
         for (int c = c0; c < c1; ++c)
-            for (int f = 0; f < outF; ++f) out[(size_t)c * outF + f] = 0.0f;
+            for (int f = 0; f < words; ++f) out[(size_t)c * words + f] = 0.0f;
     };
 
     int keyLast = cA;     // key (= centre + 1) of the previous chunk's last edge; cA stands for "centre cA-1 is done"
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
             float pre1[8], a1[8], pre2[8], a2[8], o[8], c[8];
             MCCNN_PHASE();
             mlp_block_mfma(wl + q * MCCNN_WQ_FWD, i4, d0, d1, d2, pre1, a1, pre2, a2, o);
-            if (FEAT == 2) {
+            if (FEAT == 2 || FEAT == 4) {
                 float f[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
 #pragma unroll
                 for (int n = 0; n < 8; ++n) c[n] = (f[n] * inv) * o[n];
@@ -318,7 +323,9 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
             if (!COMBIN || FEAT == 1) {
                 if (!COMBIN && FEAT == 0) finQ += 8;  // depth-wise, scalar path: fin = nu
                 if (tail) {
-                    {
+                    if (BF) {
+                        reinterpret_cast<uint4*>(out16 + (size_t)ci * outF)[q] = f32x8_to_bf16(c);
+                    } else {
                     float* dst = orow + q * 8;
                     if (vecOut) {
                         reinterpret_cast<float4*>(dst)[0] = make_float4(c[0], c[1], c[2], c[3]);
@@ -347,7 +354,24 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
                 }
             }
         };
-        if (FEAT == 2) {
+        if (FEAT == 4) {
+            // bf16 rows: 64 bytes (4 blocks) per load group, half the bytes of the f32 form per edge
+            for (int q0 = 0; q0 < a.nb; q0 += 4) {
+                const uint4* fp = reinterpret_cast<const uint4*>(feats16 + (size_t)j * a.Fin + q0 * 8);
+                const int left = a.nb - q0;
+                uint4 fl[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) fl[k] = (k < left) ? fp[k] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k < left) {
+                        float f[8];
+                        bf16x8_to_f32(fl[k], f);
+                        block(q0 + k, make_float4(f[0], f[1], f[2], f[3]), make_float4(f[4], f[5], f[6], f[7]), ic1, ic0);
+                    }
+                }
+            }
+        } else if (FEAT == 2) {
             // the feature row is read one 128-byte line (4 blocks) at a time: fetching 32 bytes per block would pull
             // every line through L1 four times, and L1 does not hold 64 rows x 20 waves in between
             for (int q0 = 0; q0 < a.nb; q0 += 4) {
@@ -476,7 +500,16 @@ __global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, 
             // g_n and f_n first: the gathers fly while the MFMA chains run
             float g[8], ff[8];
             const float* grow = outGrad + (size_t)pr.y * outF;
-            if (FEAT == 2) {
+            if (FEAT == 4) {
+                // bf16 rows: the block's 8 out-gradients / features are one 16-byte piece each
+                const uint4 gu = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(outGrad) + (size_t)pr.y * outF)[q];
+                const uint4 fu = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(a.feats) + (size_t)j * a.Fin)[q];
+                float gg[8], f8[8];
+                bf16x8_to_f32(gu, gg);
+                bf16x8_to_f32(fu, f8);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) { g[n] = act ? gg[n] : 0.f; ff[n] = f8[n]; }
+            } else if (FEAT == 2) {
                 const float4* gp = reinterpret_cast<const float4*>(grow + q * 8);
                 const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)j * a.Fin + q * 8);
                 float4 ga = gp[0], gb = gp[1], fa = fp[0], fb = fp[1];
@@ -904,11 +937,12 @@ using namespace mccnn;
 
 // Launch of the streaming reduction kernel: as many waves as the chip keeps resident (one balanced round).
 template <bool TR>
-static int launch_conv_stream(const ConvArgs& a, bool combin, bool vec, float* out, const float4* rec, const int* permT,
-                              hipStream_t s) {
+static int launch_conv_stream(const ConvArgs& a, bool combin, bool vec, bool bf16, float* out, const float4* rec,
+                              const int* permT, hipStream_t s) {
     typedef void (*Kern)(ConvArgs, float*, int, const float4*, const int*);
     Kern fn;
-    if (TR) fn = vec ? conv_stream<false, 2, true> : conv_stream<false, 0, true>;
+    if (bf16) fn = TR ? conv_stream<false, 4, true> : conv_stream<false, 4, false>;
+    else if (TR) fn = vec ? conv_stream<false, 2, true> : conv_stream<false, 0, true>;
     else if (combin) fn = (a.Fin == 1) ? conv_stream<true, 1, false> : (a.Fin <= 4 ? conv_stream<true, 3, false> : conv_stream<true, 0, false>);
     else fn = vec ? conv_stream<false, 2, false> : conv_stream<false, 0, false>;
     const size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * (size_t)a.nb * 8) * sizeof(float);
@@ -948,13 +982,19 @@ static bool use_mfma(const ConvArgs& a) {
     return a.nb <= MCCNN_LDS_MAX_NB && (conv_impl_override().load(std::memory_order_relaxed) & 1) == 0;
 }
 
-int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
-                           const float* pdfs, const float* samples, const int* start_idx, const int* packed,
-                           const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
-                           const float* w2, const float* b2, const float* w3, const float* b3, int n, int m, int e,
-                           int num_in_feats, int num_out_feats, int combin, int batch_size, float radius,
-                           int scale_inv, int avg, float* out, void* state, void* ws, size_t ws_bytes,
-                           mccnn_stream_t stream) {
+// bf16 feature storage: depth-wise layers on the MFMA path only (rows of Fin % 8 == 0 two-byte elements, 16-byte aligned)
+static bool bf16_shape_ok(const ConvArgs& a, int combin, const void* p0, const void* p1) {
+    return !combin && a.Fin % 8 == 0 && a.nb <= MCCNN_LDS_MAX_NB && ((((uintptr_t)p0 | (uintptr_t)p1) & 15) == 0) &&
+           (conv_impl_override().load(std::memory_order_relaxed) & 1) == 0;
+}
+
+static int conv_fwd_impl(const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
+                         const float* pdfs, const float* samples, const int* start_idx, const int* packed,
+                         const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
+                         const float* w2, const float* b2, const float* w3, const float* b3, int n, int m, int e,
+                         int num_in_feats, int num_out_feats, int combin, int batch_size, float radius,
+                         int scale_inv, int avg, float* out, void* state, void* ws, size_t ws_bytes,
+                         mccnn_stream_t stream, int bf16) {
     ConvArgs a;
     int rc = fill_args(a, sorted_pts, sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min,
                        aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_in_feats, num_out_feats, combin, batch_size,
@@ -964,10 +1004,11 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     if (!out) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats) & 15) == 0);
+    if (bf16 && !bf16_shape_ok(a, combin, sorted_feats, out)) return MCCNN_E_SHAPE;
     if (e > 0 && f1_shape(num_in_feats, num_out_feats, combin)) return f1_forward(a, out, state, ws, ws_bytes, s);
-    if (use_mfma(a) && e > 0) return launch_conv_stream<false>(a, combin != 0, vec, out, nullptr, nullptr, s);
+    if (use_mfma(a) && e > 0) return launch_conv_stream<false>(a, combin != 0, vec, bf16 != 0, out, nullptr, nullptr, s);
     if (e == 0) {
-        MCCNN_HIP(hipMemsetAsync(out, 0, (size_t)m * a.outF * sizeof(float), s));
+        MCCNN_HIP(hipMemsetAsync(out, 0, (size_t)m * a.outF * (bf16 ? 2 : sizeof(float)), s));
         return 0;
     }
     // fallback for very wide layers (nb > MCCNN_LDS_MAX_NB): VALU kernel with scalar-loaded weights
@@ -987,6 +1028,29 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, c
     }
     MCCNN_LAUNCHED();
     return 0;
+}
+
+int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
+                           const float* pdfs, const float* samples, const int* start_idx, const int* packed,
+                           const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
+                           const float* w2, const float* b2, const float* w3, const float* b3, int n, int m, int e,
+                           int num_in_feats, int num_out_feats, int combin, int batch_size, float radius,
+                           int scale_inv, int avg, float* out, void* state, void* ws, size_t ws_bytes,
+                           mccnn_stream_t stream) {
+    return conv_fwd_impl(sorted_pts, sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min, aabb_max,
+                         w1, b1, w2, b2, w3, b3, n, m, e, num_in_feats, num_out_feats, combin, batch_size, radius, scale_inv,
+                         avg, out, state, ws, ws_bytes, stream, 0);
+}
+
+int mccnn_spatial_conv_fwd_bf16(const float* sorted_pts, const void* sorted_feats_bf16, const int* sorted_batch_ids,
+                                const float* pdfs, const float* samples, const int* start_idx, const int* packed,
+                                const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
+                                const float* w2, const float* b2, const float* w3, const float* b3, int n, int m, int e,
+                                int num_feats, int batch_size, float radius, int scale_inv, int avg, void* out_bf16,
+                                void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    return conv_fwd_impl(sorted_pts, (const float*)sorted_feats_bf16, sorted_batch_ids, pdfs, samples, start_idx, packed,
+                         aabb_min, aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_feats, num_feats, 0, batch_size, radius,
+                         scale_inv, avg, (float*)out_bf16, nullptr, ws, ws_bytes, stream, 1);
 }
 
 #ifndef MCCNN_BWD_WAVES
@@ -1057,14 +1121,14 @@ size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_fe
     return bytes + 256;
 }
 
-int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
-                           const float* pdfs, const float* samples, const int* start_idx, const int* packed,
-                           const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
-                           const float* w2, const float* b2, const float* w3, const float* b3, const float* out_grad,
-                           int n, int m, int e, int num_in_feats, int num_out_feats, int combin, int batch_size,
-                           float radius, int scale_inv, int avg, const void* state, const int* start_t,
-                           const int* perm_t, float* feat_grad, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
-                           void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
+                         const float* pdfs, const float* samples, const int* start_idx, const int* packed,
+                         const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
+                         const float* w2, const float* b2, const float* w3, const float* b3, const float* out_grad,
+                         int n, int m, int e, int num_in_feats, int num_out_feats, int combin, int batch_size,
+                         float radius, int scale_inv, int avg, const void* state, const int* start_t,
+                         const int* perm_t, float* feat_grad, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
+                         void* ws, size_t ws_bytes, mccnn_stream_t stream, int bf16) {
     ConvArgs a;
     int rc = fill_args(a, sorted_pts, sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min,
                        aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_in_feats, num_out_feats, combin, batch_size,
@@ -1076,10 +1140,11 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats | (uintptr_t)out_grad) & 15) == 0);
     size_t lds = ((size_t)a.nb * MCCNN_WQ_BWD + 4 * 192) * sizeof(float);
     bool mfma = use_mfma(a) && lds <= 64 * 1024 && m > 0 && e > 0;
+    if (bf16 && (!bf16_shape_ok(a, combin, sorted_feats, out_grad) || lds > 64 * 1024 || (((uintptr_t)feat_grad) & 15))) return MCCNN_E_SHAPE;
     // depth-wise MFMA path writes every feat_grad row itself (conv_stream over the transposed list); everything else
     // accumulates into it
     bool dfeatT = mfma && !combin;
-    if (n > 0 && !dfeatT) MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * sizeof(float), s));
+    if (n > 0 && !dfeatT) MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * (bf16 ? 2 : sizeof(float)), s));
     if (!mfma || m == 0 || e == 0) {
         MCCNN_HIP(hipMemsetAsync(dw1, 0, 3 * nn * sizeof(float), s));
         MCCNN_HIP(hipMemsetAsync(db1, 0, nn * sizeof(float), s));
@@ -1112,6 +1177,9 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
             if (a.Fin == 1) conv_bwd_mfma<true, 1, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
             else if (a.Fin <= 4) conv_bwd_mfma<true, 3, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
             else conv_bwd_mfma<true, 0, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+        } else if (bf16) {
+            if (coop) conv_bwd_mfma<false, 4, true><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+            else conv_bwd_mfma<false, 4, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
         } else if (coop) {
             if (vec) conv_bwd_mfma<false, 2, true><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
             else conv_bwd_mfma<false, 0, true><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
@@ -1145,7 +1213,7 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
             t.start = start_t;
             t.m = n;
             t.feats = out_grad;
-            int rc3 = launch_conv_stream<true>(t, false, vecD, feat_grad, rec, perm_t, s);
+            int rc3 = launch_conv_stream<true>(t, false, vecD, bf16 != 0, feat_grad, rec, perm_t, s);
             if (rc3) return rc3;
         } else {
             return MCCNN_E_TOOLARGE;  // unreachable: the depth-wise tile always fits for nb <= MCCNN_LDS_MAX_NB
@@ -1158,6 +1226,33 @@ int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, c
     else conv_bwd_valu<false><<<blocks, 256, 0, s>>>(a, out_grad, feat_grad, dw1, db1, dw2, db2, dw3, db3);
     MCCNN_LAUNCHED();
     return 0;
+}
+
+int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
+                           const float* pdfs, const float* samples, const int* start_idx, const int* packed,
+                           const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
+                           const float* w2, const float* b2, const float* w3, const float* b3, const float* out_grad,
+                           int n, int m, int e, int num_in_feats, int num_out_feats, int combin, int batch_size,
+                           float radius, int scale_inv, int avg, const void* state, const int* start_t,
+                           const int* perm_t, float* feat_grad, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
+                           void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    return conv_bwd_impl(sorted_pts, sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min, aabb_max,
+                         w1, b1, w2, b2, w3, b3, out_grad, n, m, e, num_in_feats, num_out_feats, combin, batch_size, radius,
+                         scale_inv, avg, state, start_t, perm_t, feat_grad, dw1, db1, dw2, db2, dw3, db3, ws, ws_bytes, stream, 0);
+}
+
+int mccnn_spatial_conv_bwd_bf16(const float* sorted_pts, const void* sorted_feats_bf16, const int* sorted_batch_ids,
+                                const float* pdfs, const float* samples, const int* start_idx, const int* packed,
+                                const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
+                                const float* w2, const float* b2, const float* w3, const float* b3,
+                                const void* out_grad_bf16, int n, int m, int e, int num_feats, int batch_size, float radius,
+                                int scale_inv, int avg, const int* start_t, const int* perm_t, void* feat_grad_bf16,
+                                float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, void* ws,
+                                size_t ws_bytes, mccnn_stream_t stream) {
+    return conv_bwd_impl(sorted_pts, (const float*)sorted_feats_bf16, sorted_batch_ids, pdfs, samples, start_idx, packed,
+                         aabb_min, aabb_max, w1, b1, w2, b2, w3, b3, (const float*)out_grad_bf16, n, m, e, num_feats, num_feats,
+                         0, batch_size, radius, scale_inv, avg, nullptr, start_t, perm_t, (float*)feat_grad_bf16, dw1, db1,
+                         dw2, db2, dw3, db3, ws, ws_bytes, stream, 1);
 }
 
 }  // extern "C"

@@ -172,6 +172,25 @@ __device__ __forceinline__ void mlp_block_mfma(const float* __restrict__ wq, int
     MCCNN_PHASE();
 }
 
+// bf16 feature storage (depth-wise layers, extension: the reference is f32-only): rows are stored as bf16, every value is
+// widened exactly to f32 on load, all arithmetic and accumulation stay f32, results are rounded to nearest-even on store
+// (v_cvt_pk_bf16_f32). A block's 8 features are one 16-byte piece.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bf16x8_to_f32(const uint4 u, float* f) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned f32x2_to_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ uint4 f32x8_to_bf16(const float* c) {
+    return make_uint4(f32x2_to_bf16(c[0], c[1]), f32x2_to_bf16(c[2], c[3]), f32x2_to_bf16(c[4], c[5]), f32x2_to_bf16(c[6], c[7]));
+}
+
 // Correctly rounded x / R from y = RN(1 / R) in three instructions (Markstein): q = RN(x y) is within one ulp,
 // r = x - q R is exact in an fma, RN(q + r y) is the correctly rounded quotient. The reference divides
 // (spatial_conv.cu:155-158); the quotient feeds layer 1, whose pre-activations have to be

@@ -135,8 +135,9 @@ __global__ __launch_bounds__(256) void check_bids(const int* __restrict__ bids, 
 __global__ __launch_bounds__(256) void keys_hist(const float* __restrict__ pts, const int* __restrict__ bids,
                                                  const float* __restrict__ mn, const float* __restrict__ mx,
                                                  int n, int B, int nc, int* __restrict__ keys, int* __restrict__ cnt,
-                                                 int* __restrict__ arrival) {
+                                                 int* __restrict__ arrival, const int* __restrict__ nDev) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nDev) n = *nDev;  // device-side point count (hierarchy levels chained without a host read-back)
     if (i >= n) return;
     int b = clamp_batch(bids[i], B);
     float cs = max_extent(mn, mx, b) / (float)nc;
@@ -149,8 +150,10 @@ __global__ __launch_bounds__(256) void keys_hist(const float* __restrict__ pts, 
 }
 
 __global__ __launch_bounds__(256) void park_ids(const int* __restrict__ keys, const int* __restrict__ start,
-                                                const int* __restrict__ arrival, int n, int* __restrict__ slot) {
+                                                const int* __restrict__ arrival, int n, int* __restrict__ slot,
+                                                const int* __restrict__ nDev) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nDev) n = *nDev;
     if (i < n) slot[start[keys[i]] + arrival[i]] = i;
 }
 
@@ -160,8 +163,10 @@ __global__ __launch_bounds__(256) void park_ids(const int* __restrict__ keys, co
 // different cell. Cost is quadratic in the cell occupancy -- fine for radius-sized cells (tens of points), slow
 // for degenerate grids that put >1e4 points into one cell.
 __global__ __launch_bounds__(256) void rank_in_cell(const int* __restrict__ keys, const int* __restrict__ start,
-                                                    const int* __restrict__ slot, int n, int* __restrict__ newIdx) {
+                                                    const int* __restrict__ slot, int n, int* __restrict__ newIdx,
+                                                    const int* __restrict__ nDev) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nDev) n = *nDev;
     if (p >= n) return;
     const int id = slot[p];
     const int k = keys[id];
@@ -187,9 +192,11 @@ __global__ __launch_bounds__(256) void move_points(const float* __restrict__ pts
                                                    const int* __restrict__ newIdx, int n, float* __restrict__ oPts,
                                                    int* __restrict__ oBids, float* __restrict__ oFeats,
                                                    int* __restrict__ sKeys, int* __restrict__ inv,
-                                                   int2* __restrict__ cells, long long numCells) {
+                                                   int2* __restrict__ cells, long long numCells,
+                                                   const int* __restrict__ nDev) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (long long c = i; c < numCells; c += (long long)gridDim.x * blockDim.x) cells[c] = make_int2(0, 0);
+    if (nDev) n = *nDev;
     if (i >= n) return;
     int p = newIdx[i];
     oPts[(size_t)p * 3] = pts[(size_t)i * 3];
@@ -203,8 +210,10 @@ __global__ __launch_bounds__(256) void move_points(const float* __restrict__ pts
 }
 
 // save_indexs, sort_gpu.cu:225-248
-__global__ __launch_bounds__(256) void cell_table(const int* __restrict__ sKeys, int n, int* __restrict__ cells) {
+__global__ __launch_bounds__(256) void cell_table(const int* __restrict__ sKeys, int n, int* __restrict__ cells,
+                                                  const int* __restrict__ nDev) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nDev) n = *nDev;
     if (p >= n) return;
     int k = sKeys[p];
     if (p == 0 || sKeys[p - 1] != k) cells[2 * (size_t)k] = p;
@@ -253,13 +262,16 @@ static int launch_permute(const float* in, const int* idx, int n, int F, float* 
     return 0;
 }
 
-__global__ __launch_bounds__(256) void invert_perm(const int* __restrict__ newIdx, int n, int* __restrict__ inv) {
+__global__ __launch_bounds__(256) void invert_perm(const int* __restrict__ newIdx, int n, int* __restrict__ inv,
+                                                   const int* __restrict__ nDev) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nDev) n = *nDev;
     if (i < n) inv[newIdx[i]] = i;
 }
 __global__ __launch_bounds__(256) void map_indexs(const int* __restrict__ in, int s, const int* __restrict__ inv,
-                                                  int* __restrict__ out) {
+                                                  int* __restrict__ out, const int* __restrict__ sDev) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sDev) s = *sDev;
     if (i < s) out[i] = inv[in[i]];
 }
 
@@ -329,9 +341,9 @@ size_t mccnn_sort_step1_workspace_bytes(int n, int batch_size, int num_cells) {
            scan_workspace_bytes((int)C) + 256;
 }
 
-int mccnn_sort_step1(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n,
-                     int batch_size, int num_cells, int* keys, int* new_idx, void* ws, size_t ws_bytes,
-                     mccnn_stream_t stream) {
+static int sort_step1_impl(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n,
+                           int batch_size, int num_cells, int* keys, int* new_idx, void* ws, size_t ws_bytes,
+                           mccnn_stream_t stream, const int* n_dev) {
     if (n < 0 || batch_size <= 0 || num_cells <= 0 || !aabb_min || !aabb_max) return MCCNN_E_BADARG;
     if (n == 0) return 0;
     if (!pts || !batch_ids || !keys || !new_idx) return MCCNN_E_BADARG;
@@ -347,24 +359,40 @@ int mccnn_sort_step1(const float* pts, const int* batch_ids, const float* aabb_m
     if (!cnt || !start || !slot || !scanws) return MCCNN_E_WORKSPACE;
     MCCNN_HIP(hipMemsetAsync(cnt, 0, (size_t)C * sizeof(int), s));
     int blocks = ceil_div(n, 256);
-    keys_hist<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, keys, cnt, new_idx);
+    keys_hist<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, keys, cnt, new_idx, n_dev);
     MCCNN_LAUNCHED();
     int rc = exclusive_scan_i32(cnt, start, (int)C, start + C, scanws, s);
     if (rc) return rc;
-    park_ids<<<blocks, 256, 0, s>>>(keys, start, new_idx, n, slot);
+    park_ids<<<blocks, 256, 0, s>>>(keys, start, new_idx, n, slot, n_dev);
     MCCNN_LAUNCHED();
-    rank_in_cell<<<blocks, 256, 0, s>>>(keys, start, slot, n, new_idx);
+    rank_in_cell<<<blocks, 256, 0, s>>>(keys, start, slot, n, new_idx, n_dev);
     MCCNN_LAUNCHED();
     return 0;
 }
 
+int mccnn_sort_step1(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n,
+                     int batch_size, int num_cells, int* keys, int* new_idx, void* ws, size_t ws_bytes,
+                     mccnn_stream_t stream) {
+    return sort_step1_impl(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, keys, new_idx, ws, ws_bytes, stream,
+                           nullptr);
+}
+
+int mccnn_sort_step1_dn(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n_cap,
+                        const int* n_dev, int batch_size, int num_cells, int* keys, int* new_idx, void* ws,
+                        size_t ws_bytes, mccnn_stream_t stream) {
+    if (!n_dev) return MCCNN_E_BADARG;
+    return sort_step1_impl(pts, batch_ids, aabb_min, aabb_max, n_cap, batch_size, num_cells, keys, new_idx, ws, ws_bytes,
+                           stream, n_dev);
+}
+
 size_t mccnn_sort_step2_workspace_bytes(int n) { return align_up((size_t)(n > 0 ? n : 1) * 4); }
 
-int mccnn_sort_step2(const float* pts, const int* batch_ids, const float* feats, const int* keys, const int* new_idx,
-                     int n, int num_feats, int batch_size, int num_cells, float* out_pts, int* out_batch_ids,
-                     float* out_feats, int* cell_indexs, int* inv_idx, void* ws, size_t ws_bytes,
-                     mccnn_stream_t stream) {
-    if (n < 0 || batch_size <= 0 || num_cells <= 0 || num_feats <= 0 || !cell_indexs) return MCCNN_E_BADARG;
+static int sort_step2_impl(const float* pts, const int* batch_ids, const float* feats, const int* keys, const int* new_idx,
+                           int n, int num_feats, int batch_size, int num_cells, float* out_pts, int* out_batch_ids,
+                           float* out_feats, int* cell_indexs, int* inv_idx, void* ws, size_t ws_bytes,
+                           mccnn_stream_t stream, const int* n_dev) {
+    // num_feats == 0 (geometry only: no feature rows are moved) is accepted by the device-count form
+    if (n < 0 || batch_size <= 0 || num_cells <= 0 || num_feats < (n_dev ? 0 : 1) || !cell_indexs) return MCCNN_E_BADARG;
     long long C = total_cells(batch_size, num_cells);
     if (C >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     hipStream_t s = (hipStream_t)stream;
@@ -372,27 +400,44 @@ int mccnn_sort_step2(const float* pts, const int* batch_ids, const float* feats,
         MCCNN_HIP(hipMemsetAsync(cell_indexs, 0, (size_t)C * 2 * sizeof(int), s));  // sort_gpu.cu:492
         return 0;
     }
-    if (!pts || !batch_ids || !feats || !keys || !new_idx || !out_pts || !out_batch_ids || !out_feats)
+    if (!pts || !batch_ids || !keys || !new_idx || !out_pts || !out_batch_ids || (num_feats > 0 && (!feats || !out_feats)))
         return MCCNN_E_BADARG;
+    if (n_dev && num_feats > 4) return MCCNN_E_BADARG;  // wide feature rows are gathered after the sizes are known
     if (!ws || ws_bytes < mccnn_sort_step2_workspace_bytes(n)) return MCCNN_E_WORKSPACE;
     int* skeys = (int*)ws;
     int blocks = ceil_div(n, 256);
     int2* ct = reinterpret_cast<int2*>(cell_indexs);
     switch (num_feats <= 4 ? num_feats : 0) {
-        case 1: move_points<1><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C); break;
-        case 2: move_points<2><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C); break;
-        case 3: move_points<3><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C); break;
-        case 4: move_points<4><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C); break;
-        default: move_points<0><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C); break;
+        case 1: move_points<1><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C, n_dev); break;
+        case 2: move_points<2><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C, n_dev); break;
+        case 3: move_points<3><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C, n_dev); break;
+        case 4: move_points<4><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C, n_dev); break;
+        default: move_points<0><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C, n_dev); break;
     }
     MCCNN_LAUNCHED();
     if (num_feats > 4) {
         int rc = launch_permute<false>(feats, new_idx, n, num_feats, out_feats, s);
         if (rc) return rc;
     }
-    cell_table<<<blocks, 256, 0, s>>>(skeys, n, cell_indexs);
+    cell_table<<<blocks, 256, 0, s>>>(skeys, n, cell_indexs, n_dev);
     MCCNN_LAUNCHED();
     return 0;
+}
+
+int mccnn_sort_step2(const float* pts, const int* batch_ids, const float* feats, const int* keys, const int* new_idx,
+                     int n, int num_feats, int batch_size, int num_cells, float* out_pts, int* out_batch_ids,
+                     float* out_feats, int* cell_indexs, int* inv_idx, void* ws, size_t ws_bytes,
+                     mccnn_stream_t stream) {
+    return sort_step2_impl(pts, batch_ids, feats, keys, new_idx, n, num_feats, batch_size, num_cells, out_pts, out_batch_ids,
+                           out_feats, cell_indexs, inv_idx, ws, ws_bytes, stream, nullptr);
+}
+
+int mccnn_sort_step2_dn(const float* pts, const int* batch_ids, const int* keys, const int* new_idx, int n_cap,
+                        const int* n_dev, int batch_size, int num_cells, float* out_pts, int* out_batch_ids,
+                        int* cell_indexs, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    if (!n_dev) return MCCNN_E_BADARG;
+    return sort_step2_impl(pts, batch_ids, nullptr, keys, new_idx, n_cap, 0, batch_size, num_cells, out_pts, out_batch_ids,
+                           nullptr, cell_indexs, nullptr, ws, ws_bytes, stream, n_dev);
 }
 
 int mccnn_permute_gather(const float* in, const int* idx, int n_idx, int num_feats, float* out,
@@ -418,19 +463,30 @@ int mccnn_permute_scatter(const float* in, const int* idx, int n_idx, int num_fe
 
 size_t mccnn_transform_indexs_workspace_bytes(int n) { return align_up((size_t)(n > 0 ? n : 1) * 4); }
 
-int mccnn_transform_indexs(const int* in_idx, int s_count, const int* new_idx, int n, int* out_idx, void* ws,
-                           size_t ws_bytes, mccnn_stream_t stream) {
+static int transform_indexs_impl(const int* in_idx, int s_count, const int* new_idx, int n, int* out_idx, void* ws,
+                                 size_t ws_bytes, mccnn_stream_t stream, const int* s_dev, const int* n_dev) {
     if (s_count < 0 || n < 0) return MCCNN_E_BADARG;
     if (s_count == 0) return 0;
     if (!in_idx || !new_idx || !out_idx || n == 0) return MCCNN_E_BADARG;
     if (!ws || ws_bytes < mccnn_transform_indexs_workspace_bytes(n)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     int* inv = (int*)ws;
-    invert_perm<<<ceil_div(n, 256), 256, 0, s>>>(new_idx, n, inv);
+    invert_perm<<<ceil_div(n, 256), 256, 0, s>>>(new_idx, n, inv, n_dev);
     MCCNN_LAUNCHED();
-    map_indexs<<<ceil_div(s_count, 256), 256, 0, s>>>(in_idx, s_count, inv, out_idx);
+    map_indexs<<<ceil_div(s_count, 256), 256, 0, s>>>(in_idx, s_count, inv, out_idx, s_dev);
     MCCNN_LAUNCHED();
     return 0;
+}
+
+int mccnn_transform_indexs(const int* in_idx, int s_count, const int* new_idx, int n, int* out_idx, void* ws,
+                           size_t ws_bytes, mccnn_stream_t stream) {
+    return transform_indexs_impl(in_idx, s_count, new_idx, n, out_idx, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+int mccnn_transform_indexs_dn(const int* in_idx, int s_cap, const int* s_dev, const int* new_idx, int n_cap,
+                              const int* n_dev, int* out_idx, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    if (!s_dev || !n_dev) return MCCNN_E_BADARG;
+    return transform_indexs_impl(in_idx, s_cap, new_idx, n_cap, out_idx, ws, ws_bytes, stream, s_dev, n_dev);
 }
 
 }  // extern "C"

@@ -2,6 +2,8 @@
 
   cfg1  ModelNet40 MCClassS, 32 clouds x 1 024 points, grow 16   (models/MCClassS.py:29-71)
   cfg2  ModelNet40 MCClassH, 32 clouds x 4 096 points, 3 Poisson levels (models/MCClassH.py:30-187)
+  cfg3  ShapeNet-Part MCSeg, 16 clouds x 8 192 points, grow 32, bf16 feature rows in the depth-wise layers
+        (models/MCSeg.py:29-198; encoder, decoder and the two skip up-samplings)
 
 For every level of the point hierarchy and every convolution of the graph: ALL integer outputs (keys, sort order, cell
 tables, Poisson samples and their indices, CSR start indices, packed neighbours) bit-exact, KDE / convolution outputs
@@ -80,10 +82,18 @@ def build_hierarchy(ops, wrap, unwrap, pts, bids, feats, B, radii):
     return mn, mx, levels, rec
 
 
-def run_conv(ops, wrap, unwrap, mn, mx, levels, B, spec, seed, is_gpu):
+def bf16_round(a):
+    """float32 array -> the float32 values of its bfloat16 rounding (round to nearest even, what the kernels store)."""
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+
+
+def run_conv(ops, wrap, unwrap, mn, mx, levels, B, spec, seed, is_gpu, bf16=False):
     """One create_convolution (MCConvBuilder.py:349-427): grid of the input level, neighbours of the output level's
-    points, KDE, convolution forward and backward on seeded random features / out-gradients."""
-    lin, lout, radius, window, fin, fout, combin = spec
+    points, KDE, convolution forward and backward on seeded random features / out-gradients. bf16: the depth-wise
+    layer keeps feature / output / gradient ROWS in bfloat16 (GPU) -- the oracle gets the same rounded values as
+    float32 and its float32 results are rounded the same way by the caller."""
+    lin, lout, radius, window, fin, fout, combin = spec[:7]
     inP, inB, _ = levels[lin]
     outP, outB, _ = levels[lout]
     n, m = int(inP.shape[0]), int(outP.shape[0])
@@ -91,6 +101,8 @@ def run_conv(ops, wrap, unwrap, mn, mx, levels, B, spec, seed, is_gpu):
     feats = (2 * rng.random((n, fin)) - 1).astype(np.float32)
     outF = fout if combin else fin
     og = (2 * rng.random((m, outF)) - 1).astype(np.float32)
+    if bf16:
+        feats, og = bf16_round(feats), bf16_round(og)
     w = make_mlp(conv_nb(fin, fout, combin), seed + 1)
     keys, idx = ops.sort_points_step1(inP, inB, mn, mx, B, radius, True)
     sP, sB, sF, cells = ops.sort_points_step2(inP, inB, wrap(feats), keys, idx, mn, mx, B, radius, True)
@@ -99,13 +111,17 @@ def run_conv(ops, wrap, unwrap, mn, mx, levels, B, spec, seed, is_gpu):
     r = dict(keys=unwrap(keys), indexs=unwrap(idx), cellIndexs=unwrap(cells), startIndexs=unwrap(start),
              packedNeighs=unwrap(packed), pdfs=unwrap(pdfs))
     if is_gpu:
+        import torch
         tw = {k: wrap(v).requires_grad_(True) for k, v in w.items()}
-        sFr = sF.detach().clone().requires_grad_(True)
+        sFr = sF.detach().clone()
+        if bf16:
+            sFr = sFr.to(torch.bfloat16)      # exact: the values are bf16 already
+        sFr.requires_grad_(True)
         out = ops.spatial_conv(sP, sFr, sB, pdfs, outP, start, packed, mn, mx, tw["w1"], tw["w2"], tw["w3"], tw["b1"],
                                tw["b2"], tw["b3"], fout, combin, B, radius, True, True)
-        out.backward(wrap(og))
-        r["out"] = unwrap(out)
-        r["grads"] = [unwrap(t) for t in (sFr.grad, tw["w1"].grad, tw["b1"].grad, tw["w2"].grad, tw["b2"].grad,
+        out.backward(wrap(og).to(out.dtype))
+        r["out"] = unwrap(out.float())
+        r["grads"] = [unwrap(t.float()) for t in (sFr.grad, tw["w1"].grad, tw["b1"].grad, tw["w2"].grad, tw["b2"].grad,
                                           tw["w3"].grad, tw["b3"].grad)]
     else:
         a = (sP, sF, sB, pdfs, outP, start, packed, mn, mx, w["w1"], w["w2"], w["w3"], w["b1"], w["b2"], w["b3"])
@@ -142,7 +158,17 @@ MCCLASS_H_K16 = [  # models/MCClassH.py:40-187, both logit branches, grow 16
 ]
 
 
-def check_config(mc, orc, n_per, B, radii, convs, seed):
+def bf16_close(got, ref32):
+    """got: values read back from bf16 storage; ref32: the oracle's float32 result. Both sides round nearly equal float32
+    numbers (~1e-6 apart), so after rounding they are equal or ONE bf16 step (2^-8 of the element) apart."""
+    ref = bf16_round(ref32)
+    scale = np.abs(ref32).max()
+    diff = np.abs(got.astype(np.float64) - ref)
+    assert np.all(diff <= 2.0 ** -7 * np.abs(ref) + 1e-6 * scale), float((diff / np.maximum(np.abs(ref), 1e-6 * scale)).max())
+    return float((diff > 0).mean())
+
+
+def check_config(mc, orc, n_per, B, radii, convs, seed, level_sizes_strict=True):
     pts, bids = modelnet_like(n_per, B, seed)
     feats = np.ones((len(pts), 1), np.float32)  # ModelNet.py:168: one constant input feature
     gmn, gmx, glev, grec = build_hierarchy(mc, _wrap, _unwrap, pts, bids, feats, B, radii)
@@ -157,13 +183,19 @@ def check_config(mc, orc, n_per, B, radii, convs, seed):
     assert sizes[0] > sizes[1] > sizes[2] >= B  # a real three-level hierarchy; the last level holds >= 1 point per cloud
     worst = {}
     for ci, spec in enumerate(convs):
-        g = run_conv(mc, _wrap, _unwrap, gmn, gmx, glev, B, spec, 100 + ci, True)
-        o = run_conv(orc, _ident, _ident, omn, omx, olev, B, spec, 100 + ci, False)
+        bf16 = len(spec) > 7 and spec[7]
+        g = run_conv(mc, _wrap, _unwrap, gmn, gmx, glev, B, spec, 100 + ci, True, bf16)
+        o = run_conv(orc, _ident, _ident, omn, omx, olev, B, spec, 100 + ci, False, bf16)
         for k in INT_CONV:
             assert g[k].shape == o[k].shape, (spec, k, g[k].shape, o[k].shape)
             assert np.array_equal(g[k], o[k]), "conv %s: %s differs" % (spec, k)
-        errs = {"pdfs": rel_err(g["pdfs"], o["pdfs"]), "out": rel_err(g["out"], o["out"])}
-        for nm, a, b in zip(GRADS, g["grads"], o["grads"]):
+        errs = {"pdfs": rel_err(g["pdfs"], o["pdfs"])}
+        if bf16:  # rows stored in bf16: equal to the rounded oracle rows up to one bf16 step; parameter gradients are f32
+            worst["bf16_rows_off_by_one_step"] = max(worst.get("bf16_rows_off_by_one_step", 0.0),
+                                                     bf16_close(g["out"], o["out"]), bf16_close(g["grads"][0], o["grads"][0]))
+        else:
+            errs["out"] = rel_err(g["out"], o["out"])
+        for nm, a, b in list(zip(GRADS, g["grads"], o["grads"]))[1 if bf16 else 0:]:
             errs[nm] = rel_err(a, b)
         for nm, e in errs.items():
             assert e <= RTOL, "conv %s: %s max |diff| / max |ref| = %.3e" % (spec, nm, e)
@@ -179,3 +211,26 @@ def test_cfg1_mcclass_s_32x1024(mc, oracle_omp):
 def test_cfg2_mcclass_h_32x4096(mc, oracle_omp):
     sizes, worst = check_config(mc, oracle_omp, 4096, 32, [0.1, 0.4, S3], MCCLASS_H_K16, 43)
     print("cfg2 level sizes", sizes, "worst rel errs", {k: "%.1e" % v for k, v in worst.items()})
+
+
+MCSEG_K32 = [  # models/MCSeg.py:36-198, grow 32 (BASELINE cfg3); last field: bf16 feature storage for the depth-wise layers
+    (0, 0, 0.03, 0.25, 1, 32, True, False),        # Conv_1
+    (0, 1, 0.05, 0.2, 64, 64, False, True),        # Pool_1
+    (1, 1, 0.1, 0.25, 64, 64, False, True),        # Conv_2
+    (1, 2, 0.2, 0.2, 128, 128, False, True),       # Pool_2
+    (2, 2, 0.4, 0.25, 128, 128, False, True),      # Conv_3
+    (2, 3, 0.8, 0.2, 256, 256, False, True),       # Pool_3
+    (3, 3, S3, 0.25, 256, 256, False, True),       # Conv_4
+    (3, 2, S3, 0.25, 512, 512, False, False),      # Up_3_4: 64 blocks -> the backward's LDS tile is too large: f32 rows
+    (2, 2, 0.4, 0.25, 256, 256, False, True),      # DeConv_3
+    (2, 1, 0.2, 0.25, 256, 256, False, True),      # Up_2_3
+    (1, 1, 0.1, 0.25, 128, 128, False, True),      # DeConv_2
+    (1, 0, 0.05, 0.25, 128, 128, False, True),     # Up_1_2
+    (2, 0, 0.2, 0.25, 256, 256, False, True),      # Up_1_3
+    (0, 0, 0.03, 0.25, 128, 128, False, True),     # DeConv_1
+]
+
+
+def test_cfg3_mcseg_16x8192_bf16_rows(mc, oracle_omp):
+    sizes, worst = check_config(mc, oracle_omp, 8192, 16, [0.025, 0.1, 0.4], MCSEG_K32, 47)
+    print("cfg3 level sizes", sizes, "worst", {k: "%.1e" % v for k, v in worst.items()})

@@ -79,3 +79,58 @@ def test_mcnorm_s_gradient_matches_finite_difference(mc):
             p.add_(eps * dirs[k])
     fd = (lp - lm) / (2 * eps)
     assert abs(fd - an) <= 3e-2 * max(abs(an), 1e-3), (fd, an)
+
+
+def test_mcclass_s_cfg1_matches_the_oracle_path(mc):
+    """BASELINE cfg1 end to end (MCClassS, 32 clouds x 1 024 points, grow 16): the same graph -- hierarchy, pooling and
+    depth-wise MC convolutions, batch-norm / 1x1 / MLP helpers -- once on the HIP ops and once with the CPU oracle behind
+    the builder's op names (tests/oracle_ops.py), identical parameters. Logits, loss and the gradient of EVERY parameter
+    (18 kernel-MLP tensors, dense layers, batch-norm scales) agree; the dense layers are torch on both sides (GPU vs
+    CPU), which is what the tolerances below leave room for."""
+    import torch
+    from mcclass_s import MCClassS
+    from oracle.oracle import Oracle
+    from tests.oracle_ops import OracleOps
+    from tests.test_gpu_configs import modelnet_like
+    B, n, k, ncat = 32, 1024, 16, 40
+    pts, bids = modelnet_like(n, B, 51)
+    y = np.random.default_rng(2).integers(0, ncat, B)
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    gnet = MCClassS(1, B, k, ncat, dev)
+    P, Bi = torch.from_numpy(pts).to(dev), torch.from_numpy(bids).to(dev)
+    F = torch.ones((len(pts), 1), device=dev)
+    with torch.no_grad():
+        gnet(P, Bi, F, True, useDropOutFull=False)              # creates the variables
+    cnet = MCClassS(1, B, k, ncat, torch.device("cpu"), ops=OracleOps(Oracle(omp=True)))
+    for name, p in gnet.convBuilder.variables_.items():
+        cnet.convBuilder.variables_[name] = torch.nn.Parameter(p.detach().cpu().clone())
+    for name, p in gnet.store.variables_.items():
+        cnet.store.variables_[name] = torch.nn.Parameter(p.detach().cpu().clone())
+    cnet.store.buffers_ = {k_: v.detach().cpu().clone() for k_, v in gnet.store.buffers_.items()}
+    res = {}
+    for tag, net, dv in (("gpu", gnet, dev), ("cpu", cnet, torch.device("cpu"))):
+        for p in net.parameters():
+            p.grad = None
+        logits = net(torch.from_numpy(pts).to(dv), torch.from_numpy(bids).to(dv), torch.ones((len(pts), 1), device=dv), True,
+                     useDropOutFull=False)
+        loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(y).to(dv))
+        loss.backward()
+        named = dict(net.convBuilder.named_parameters())
+        named.update(dict(net.store.named_parameters()))
+        res[tag] = (logits.detach().cpu().numpy(), float(loss), {k_: v.grad.detach().cpu().numpy() for k_, v in named.items()},
+                    [int(p.shape[0]) for p in net.lastHierarchy.points_])
+    (gl, gloss, gg, gsz), (cl, closs, cg, csz) = res["gpu"], res["cpu"]
+    assert gsz == csz and gsz[0] == B * n and gsz[-1] == B
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    # tensors whose exact gradient is zero (biases in front of a batch-norm, which removes the mean) hold rounding noise
+    # only: differences are measured against the tensor's own scale or 1e-4 of the largest gradient, whichever is larger
+    gmax = max(float(np.abs(v).max()) for v in cg.values())
+    err = {k_: float(np.abs(gg[k_] - cg[k_]).max() / max(np.abs(cg[k_]).max(), 1e-4 * gmax)) for k_ in cg}
+    worst = max(err, key=err.get)
+    print("cfg1 end to end: logits %.1e loss %.1e worst gradient %.1e (%s) over %d tensors" % (
+        rel(gl, cl), abs(gloss - closs), err[worst], worst, len(cg)))
+    assert rel(gl, cl) <= 1e-4 and abs(gloss - closs) <= 1e-5 * abs(closs)
+    assert set(gg) == set(cg) and len([k_ for k_ in cg if k_.startswith("Conv_")]) == 18
+    for k_ in cg:
+        assert err[k_] <= 1e-3, (k_, err[k_])
