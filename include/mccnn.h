@@ -251,6 +251,27 @@ size_t mccnn_transpose_neighbors_workspace_bytes(int n, int e);
 int mccnn_transpose_neighbors(const int* packed, int e, int n, int* start_t, int* perm_t, void* ws,
                               size_t ws_bytes, mccnn_stream_t stream);
 
+/* DEVICE-SIDE POINT COUNTS (hierarchy construction without per-level host read-backs).
+ * PointHierarchy (MCConvBuilder.py:101-128) chains sort -> Poisson sampling -> transform_indexs level
+ * after level, and the reference reads the number of samples back to the host at every level
+ * (poisson_sampling.cu:222) because it sizes the next level's launches. These variants take the
+ * number of valid points from DEVICE memory (*n_dev <= n_cap; launches and buffers are sized by the
+ * capacity n_cap), so a caller can run all levels back to back -- mccnn_poisson_sampling_count /_fill
+ * already work from the cell table and take n_cap as n -- and read every level's size back ONCE at the
+ * end. Same results as the host-count forms. sort_step2_dn moves geometry only (feature rows are
+ * gathered once the sizes are known). */
+int mccnn_sort_step1_dn(const float* pts, const int* batch_ids, const float* aabb_min,
+                        const float* aabb_max, int n_cap, const int* n_dev, int batch_size,
+                        int num_cells, int* keys, int* new_idx, void* ws, size_t ws_bytes,
+                        mccnn_stream_t stream);
+int mccnn_sort_step2_dn(const float* pts, const int* batch_ids, const int* keys, const int* new_idx,
+                        int n_cap, const int* n_dev, int batch_size, int num_cells, float* out_pts,
+                        int* out_batch_ids, int* cell_indexs, void* ws, size_t ws_bytes,
+                        mccnn_stream_t stream);
+int mccnn_transform_indexs_dn(const int* in_idx, int s_cap, const int* s_dev, const int* new_idx,
+                              int n_cap, const int* n_dev, int* out_idx, void* ws, size_t ws_bytes,
+                              mccnn_stream_t stream);
+
 /* TEST HOOK, not part of the operator surface: selects the convolution implementation for A/B
  * parity tests (bit 0: VALU fallback kernels, bit 1: general MFMA kernels for one-input-feature
  * layers; 0 = product default). Returns the previous mask. Initial value: MCCNN_FORCE_VALU /

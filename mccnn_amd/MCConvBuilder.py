@@ -37,6 +37,9 @@ class _Ops:
 
 
 _VERBOSE = False
+#: build all levels of a PointHierarchy with ONE host read-back (MCConvModule.point_hierarchy_levels) instead of one per
+#: level; results are identical. Only with the HIP op surface on CUDA tensors.
+FUSED_HIERARCHY = True
 
 
 def _log(msg):
@@ -75,6 +78,24 @@ class PointHierarchy:
         self.aabbMin_ = aabbMin
         self.aabbMax_ = aabbMax
         _log("########## Point Hierarchy: %s (Rel: %s)" % (hierarchyName, relativeRadius))
+
+        if FUSED_HIERARCHY and ops._ops is None and len(radiusList) > 0 and getattr(inPoints, "is_cuda", False) \
+                and poisson_sampling.__module__.endswith("MCConvModule"):
+            from . import MCConvModule as _M
+            fused = _M.point_hierarchy_levels(inPoints, inBatchIds, aabbMin, aabbMax, list(radiusList), batchSize,
+                                              self.relativeRadius_)
+            if fused is not None:
+                currFeatures = inFeatures
+                for (sampledPts, sampledBatchsIds, _sortedIdx, transformedIndexs), currRadius in zip(fused, radiusList):
+                    # the level's feature rows: sortFeatures[sampledIndexs] == features[transformedIndexs]
+                    # (MCConvBuilder.py:112-116), one differentiable gather now that the sizes are known
+                    currFeatures = ops.get_sampled_features(transformedIndexs, currFeatures)
+                    self.points_.append(sampledPts)
+                    self.batchIds_.append(sampledBatchsIds)
+                    self.features_.append(currFeatures)
+                    self.sampledIndexs_.append(transformedIndexs)
+                    self.radiusList_.append(currRadius)
+                return
 
         currPts, currFeatures, currBatchIds = inPoints, inFeatures, inBatchIds
         for level, currRadius in enumerate(radiusList):

@@ -519,6 +519,69 @@ def poisson_sampling(inPts, inBatchIds, cellIndexs, aabbMin, aabbMax, radius, ba
     return oP, oB, oI
 
 
+def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batchSize, scaleInv):
+    """Geometry of ALL levels of a point hierarchy (MCConvBuilder.py:101-128: sort_points_step1/2 -> poisson_sampling ->
+    transform_indexs per level) with ONE host read-back at the end instead of one per level: every level takes its point
+    count from device memory (mccnn_*_dn), launches and buffers are sized by the first level's point count.
+    Returns [(sampledPts [S,3], sampledBatchIds [S,1], sampledIndexs [S] into the level's sorted list,
+    transformedIndexs [S] into the level's input order)] per level -- bit-identical to the op-by-op chain -- or None
+    if a wait of the single-launch Poisson kernel timed out somewhere (the caller then runs the op-by-op chain)."""
+    op = "PointHierarchy"
+    pts, bids = _f32(inPts.detach(), "points"), _i32(inBatchIds, "batch_ids")
+    mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
+    _check_points(pts, "points", op)
+    _check_batch_ids(bids, pts.shape[0], op)
+    _check_aabb(mn, mx, batchSize, op)
+    lib = _lib.load()
+    dev, cap, L = pts.device, pts.shape[0], len(radiusList)
+    if cap == 0 or L == 0:
+        return []
+    sizes = torch.empty(L + 1, dtype=torch.int32, device=dev)
+    sizes[0] = cap
+    i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    cur_pts, cur_bids, levels = pts, bids, []
+    si = int(bool(scaleInv))
+    for l, radius in enumerate(radiusList):
+        _req(radius > 0.0, op + " expects positive radii")
+        nc = _num_cells(mn, mx, batchSize, radius, scaleInv)
+        n_dev, s_dev = sizes[l:l + 1], sizes[l + 1:l + 2]
+        keys, idx = i32(cap), i32(cap)
+        wsb = lib.mccnn_sort_step1_workspace_bytes(cap, batchSize, nc)
+        _req(wsb > 0, op + ": batch_size * num_cells^3 does not fit 32-bit keys")
+        ws = _ws(wsb, dev)
+        check(lib.mccnn_sort_step1_dn(ptr(cur_pts), ptr(cur_bids), ptr(mn), ptr(mx), cap, ptr(n_dev), batchSize, nc,
+                                      ptr(keys), ptr(idx), ptr(ws), ws.numel(), stream_handle()), "sort_points_step1(dn)")
+        sP, sB, cells = f32(cap, 3), i32(cap, 1), i32(batchSize, nc, nc, nc, 2)
+        ws2 = _ws(lib.mccnn_sort_step2_workspace_bytes(cap), dev)
+        check(lib.mccnn_sort_step2_dn(ptr(cur_pts), ptr(cur_bids), ptr(keys), ptr(idx), cap, ptr(n_dev), batchSize, nc,
+                                      ptr(sP), ptr(sB), ptr(cells), ptr(ws2), ws2.numel(), stream_handle()),
+              "sort_points_step2(dn)")
+        wsb = lib.mccnn_poisson_sampling_workspace_bytes(cap, batchSize, nc)
+        _req(wsb > 0, op + ": grid too large")
+        wsp = _ws(wsb, dev)
+        check(lib.mccnn_poisson_sampling_count(ptr(sP), ptr(sB), cap, ptr(cells), ptr(mn), ptr(mx), batchSize, nc,
+                                               float(radius), si, 1, ptr(s_dev), ptr(wsp), wsp.numel(), stream_handle()),
+              "poisson_sampling(count)")
+        oP, oB, oI, ti = f32(cap, 3), i32(cap, 1), i32(cap), i32(cap)
+        check(lib.mccnn_poisson_sampling_fill(ptr(sP), cap, ptr(cells), batchSize, nc, cap, ptr(oP), ptr(oB), ptr(oI),
+                                              ptr(wsp), wsp.numel(), stream_handle()), "poisson_sampling(fill)")
+        wst = _ws(lib.mccnn_transform_indexs_workspace_bytes(cap), dev)
+        check(lib.mccnn_transform_indexs_dn(ptr(oI), cap, ptr(s_dev), ptr(idx), cap, ptr(n_dev), ptr(ti), ptr(wst),
+                                            wst.numel(), stream_handle()), "transform_indexs(dn)")
+        levels.append((oP, oB, oI, ti))
+        cur_pts, cur_bids = oP, oB
+    host = sizes.cpu().tolist()  # the ONE read-back: every level's sample count
+    if any(s < 0 for s in host[1:]):
+        return None
+    out = []
+    for (oP, oB, oI, ti), s in zip(levels, host[1:]):
+        sp, sb, si_, t_ = oP[:s], oB[:s], oI[:s], ti[:s]
+        _remember_order(sp, "sorted_pos", si_)
+        out.append((sp, sb, si_, t_))
+    return out
+
+
 class _GetSampledFeatures(torch.autograd.Function):
     """GetSampledFeatures (+Grad: scatter with zero fill), MCConvModuleSrc:63-68."""
 

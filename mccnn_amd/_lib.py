@@ -28,6 +28,9 @@ SIGNATURES = {
     "mccnn_sort_step1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_sort_step2_workspace_bytes": (_sz, [_i]),
     "mccnn_sort_step2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_sort_step1_dn": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_sort_step2_dn": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_transform_indexs_dn": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_permute_gather": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "mccnn_permute_scatter": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     "mccnn_transform_indexs_workspace_bytes": (_sz, [_i]),

@@ -1,0 +1,63 @@
+"""all levels of a PointHierarchy built with ONE host read-back (device-side point counts,
+MCConvModule.point_hierarchy_levels) against the op-by-op chain of MCConvBuilder.py:101-128 and against the oracle:
+identical points, batch ids, sample indices and features at every level, identical feature gradients."""
+import math
+
+import numpy as np
+import pytest
+
+from tests.helpers import make_cloud, make_room
+
+pytestmark = pytest.mark.gpu
+
+
+def _levels(ph):
+    return [(p.detach().cpu().numpy(), b.cpu().numpy(), f.detach().cpu().numpy()) for p, b, f in
+            zip(ph.points_, ph.batchIds_, ph.features_)], [i.cpu().numpy() for i in ph.sampledIndexs_]
+
+
+@pytest.mark.parametrize("case", ["relative_batched", "room_absolute"])
+def test_fused_hierarchy_equals_the_op_chain(mc, oracle, case):
+    import torch
+    import mccnn_amd.MCConvBuilder as MB
+    if case == "relative_batched":
+        pts, bids = make_cloud(3000, 5, 3, "clustered", True)
+        B, radii, rel = 5, [0.1, 0.4, math.sqrt(3.0) + 0.1], True
+    else:
+        pts = make_room(100000, 20180601)
+        bids = np.zeros((len(pts), 1), np.int32)
+        B, radii, rel = 1, [0.1, 0.2, 0.4, 0.8], False
+    feats = np.random.default_rng(1).random((len(pts), 3), dtype=np.float32)
+    P, Bi = torch.from_numpy(pts).cuda(), torch.from_numpy(bids).cuda()
+    res = {}
+    for fused in (True, False):
+        MB.FUSED_HIERARCHY = fused
+        try:
+            F = torch.from_numpy(feats).cuda().requires_grad_(True)
+            ph = MB.PointHierarchy(P, F, Bi, radii, "PH", B, rel)
+            (ph.features_[-1] * torch.linspace(1, 2, 3, device="cuda")).sum().backward()
+            res[fused] = (_levels(ph), F.grad.cpu().numpy())
+        finally:
+            MB.FUSED_HIERARCHY = True
+    (lv_f, idx_f), g_f = res[True]
+    (lv_o, idx_o), g_o = res[False]
+    assert len(lv_f) == len(radii) + 1
+    for (pf, bf, ff), (po, bo, fo) in zip(lv_f, lv_o):
+        assert np.array_equal(pf, po) and np.array_equal(bf, bo) and np.array_equal(ff, fo)
+    for a, b in zip(idx_f, idx_o):
+        assert np.array_equal(a, b)
+    assert np.array_equal(g_f, g_o)
+    # and against the oracle, level by level (hierarchy of the relative case only: the sequential Poisson oracle needs
+    # minutes for the 100k room)
+    if case == "relative_batched":
+        mn, mx = oracle.compute_aabb(pts, bids, B, rel)
+        cp, cb, cf = pts, bids, feats
+        for l, r in enumerate(radii):
+            k, i = oracle.sort_points_step1(cp, cb, mn, mx, B, r, rel)
+            sp, sb, sf, cl = oracle.sort_points_step2(cp, cb, cf, k, i, mn, mx, B, r, rel)
+            op, ob, oi = oracle.poisson_sampling(sp, sb, cl, mn, mx, r, B, rel)
+            of = oracle.get_sampled_features(oi, sf)
+            ti = oracle.transform_indexs(oi, i)
+            assert np.array_equal(lv_f[l + 1][0], op) and np.array_equal(lv_f[l + 1][1], ob)
+            assert np.array_equal(lv_f[l + 1][2], of) and np.array_equal(idx_f[l], ti)
+            cp, cb, cf = op, ob, of
