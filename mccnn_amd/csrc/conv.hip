@@ -927,7 +927,8 @@ static int fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_f
 }
 
 std::atomic<int>& conv_impl_override() {
-    static std::atomic<int> v{(getenv("MCCNN_FORCE_VALU") ? 1 : 0) | (getenv("MCCNN_NO_F1") ? 2 : 0)};
+    static std::atomic<int> v{(getenv("MCCNN_FORCE_VALU") ? 1 : 0) | (getenv("MCCNN_NO_F1") ? 2 : 0) |
+                              (getenv("MCCNN_F1_SCAN") ? 4 : 0)};
     return v;
 }
 
@@ -959,7 +960,7 @@ static int launch_conv_stream(const ConvArgs& a, bool combin, bool vec, bool bf1
 
 extern "C" {
 
-int mccnn_debug_conv_impl(int mask) { return conv_impl_override().exchange(mask & 3); }
+int mccnn_debug_conv_impl(int mask) { return conv_impl_override().exchange(mask & 7); }
 
 // combin layers with one input feature take the factored path of conv_f1.hip (f1_*)
 static bool f1_shape(int num_in_feats, int num_out_feats, int combin) {

@@ -194,6 +194,7 @@ def test_spatial_conv_fwd_bwd(mc, oracle, case):
     others = [(1, "VALU kernels")]
     if combin and fin == 1:
         others.append((2, "general MFMA kernels"))
+        others.append((4, "factored kernels, DPP-scan forward"))
     for mask, label in others:
         mc.debug_conv_impl(mask)
         try:
