@@ -199,10 +199,13 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
     unsigned short* out16 = reinterpret_cast<unsigned short*>(out);
 
     // rows of centres without neighbours are never reached by an edge: zero them where the gap shows up
+    // (depth-wise layers wider than one launch's weight tile are run in column tiles: `out` then points at the tile's
+    // first column, rows keep the full stride outF and only the tile's columns belong to this launch)
     auto zero_rows = [&](int c0, int c1) {
-        const int words = BF ? outF / 2 : outF;  // 32-bit words per row (bf16 rows: outF % 8 == 0)
+        const int width = COMBIN ? outF : min(a.nb * 8, a.neuronsOut);
+        const int words = BF ? width / 2 : width, stride = BF ? outF / 2 : outF;  // 32-bit words (bf16 rows: % 8 == 0)
         for (int c = c0; c < c1; ++c)
-            for (int f = 0; f < words; ++f) out[(size_t)c * words + f] = 0.0f;
+            for (int f = 0; f < words; ++f) out[(size_t)c * stride + f] = 0.0f;
     };
 
     int keyLast = cA;     // key (= centre + 1) of the previous chunk's last edge; cA stands for "centre cA-1 is done"
@@ -927,8 +930,7 @@ static int fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_f
 }
 
 std::atomic<int>& conv_impl_override() {
-    static std::atomic<int> v{(getenv("MCCNN_FORCE_VALU") ? 1 : 0) | (getenv("MCCNN_NO_F1") ? 2 : 0) |
-                              (getenv("MCCNN_F1_SCAN") ? 4 : 0)};
+    static std::atomic<int> v{(getenv("MCCNN_FORCE_VALU") ? 1 : 0) | (getenv("MCCNN_NO_F1") ? 2 : 0)};
     return v;
 }
 
@@ -960,7 +962,7 @@ static int launch_conv_stream(const ConvArgs& a, bool combin, bool vec, bool bf1
 
 extern "C" {
 
-int mccnn_debug_conv_impl(int mask) { return conv_impl_override().exchange(mask & 7); }
+int mccnn_debug_conv_impl(int mask) { return conv_impl_override().exchange(mask & 3); }
 
 // combin layers with one input feature take the factored path of conv_f1.hip (f1_*)
 static bool f1_shape(int num_in_feats, int num_out_feats, int combin) {
@@ -979,13 +981,35 @@ size_t mccnn_spatial_conv_fwd_workspace_bytes(int m, int e, int num_in_feats, in
     return 256;
 }  // none needed today
 
-static bool use_mfma(const ConvArgs& a) {
-    return a.nb <= MCCNN_LDS_MAX_NB && (conv_impl_override().load(std::memory_order_relaxed) & 1) == 0;
+// Depth-wise layers of any width run on the MFMA kernels: block q only touches feature columns 8q .. 8q+7, so a layer
+// wider than one launch's LDS weight tile is cut into column tiles (pointer offsets, unchanged row strides). Combin
+// layers beyond MCCNN_LDS_MAX_NB blocks (Fin * Fout > 512: not in the reference's models) keep the VALU kernels.
+static bool use_mfma(const ConvArgs& a, bool combin) {
+    return (a.nb <= MCCNN_LDS_MAX_NB || !combin) && (conv_impl_override().load(std::memory_order_relaxed) & 1) == 0;
 }
+#define MCCNN_TILE_FWD 64  // blocks per forward launch  (184 floats of LDS per block)
+#define MCCNN_TILE_BWD 48  // blocks per backward launch (312 floats of LDS per block: 60 KB)
+static void tile_split(int nb, int maxTile, int& tiles, int& per) {
+    tiles = (nb + maxTile - 1) / maxTile;
+    per = (nb + tiles - 1) / tiles;
+}
+// the arguments of column tile [q0, q0 + nbT) of a depth-wise layer (feature rows `elem` bytes per element)
+static ConvArgs tile_args(const ConvArgs& a, int q0, int nbT, size_t elem) {
+    ConvArgs t = a;
+    t.feats = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.feats) + (size_t)q0 * 8 * elem);
+    t.w1 = a.w1 + (size_t)q0 * 24; t.b1 = a.b1 + (size_t)q0 * 8;
+    t.w2 = a.w2 + (size_t)q0 * 64; t.b2 = a.b2 + (size_t)q0 * 8;
+    t.w3 = a.w3 + (size_t)q0 * 64; t.b3 = a.b3 + (size_t)q0 * 8;
+    t.nb = nbT;
+    t.neuronsOut = a.neuronsOut - q0 * 8 < nbT * 8 ? a.neuronsOut - q0 * 8 : nbT * 8;
+    return t;
+}
+static float* col_offset(float* p, int q0, size_t elem) { return reinterpret_cast<float*>(reinterpret_cast<char*>(p) + (size_t)q0 * 8 * elem); }
+static const float* col_offset_c(const float* p, int q0, size_t elem) { return col_offset(const_cast<float*>(p), q0, elem); }
 
 // bf16 feature storage: depth-wise layers on the MFMA path only (rows of Fin % 8 == 0 two-byte elements, 16-byte aligned)
 static bool bf16_shape_ok(const ConvArgs& a, int combin, const void* p0, const void* p1) {
-    return !combin && a.Fin % 8 == 0 && a.nb <= MCCNN_LDS_MAX_NB && ((((uintptr_t)p0 | (uintptr_t)p1) & 15) == 0) &&
+    return !combin && a.Fin % 8 == 0 && ((((uintptr_t)p0 | (uintptr_t)p1) & 15) == 0) &&
            (conv_impl_override().load(std::memory_order_relaxed) & 1) == 0;
 }
 
@@ -1007,7 +1031,18 @@ static int conv_fwd_impl(const float* sorted_pts, const float* sorted_feats, con
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats) & 15) == 0);
     if (bf16 && !bf16_shape_ok(a, combin, sorted_feats, out)) return MCCNN_E_SHAPE;
     if (e > 0 && f1_shape(num_in_feats, num_out_feats, combin)) return f1_forward(a, out, state, ws, ws_bytes, s);
-    if (use_mfma(a) && e > 0) return launch_conv_stream<false>(a, combin != 0, vec, bf16 != 0, out, nullptr, nullptr, s);
+    if (use_mfma(a, combin != 0) && e > 0) {
+        if (combin || a.nb <= MCCNN_TILE_FWD) return launch_conv_stream<false>(a, combin != 0, vec, bf16 != 0, out, nullptr, nullptr, s);
+        int tiles, per;
+        tile_split(a.nb, MCCNN_TILE_FWD, tiles, per);
+        const size_t elem = bf16 ? 2 : sizeof(float);
+        for (int q0 = 0; q0 < a.nb; q0 += per) {
+            const ConvArgs t = tile_args(a, q0, a.nb - q0 < per ? a.nb - q0 : per, elem);
+            int rc2 = launch_conv_stream<false>(t, false, vec, bf16 != 0, col_offset(out, q0, elem), nullptr, nullptr, s);
+            if (rc2) return rc2;
+        }
+        return 0;
+    }
     if (e == 0) {
         MCCNN_HIP(hipMemsetAsync(out, 0, (size_t)m * a.outF * (bf16 ? 2 : sizeof(float)), s));
         return 0;
@@ -1139,9 +1174,11 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
     hipStream_t s = (hipStream_t)stream;
     size_t nn = (size_t)a.nb * 8;
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats | (uintptr_t)out_grad) & 15) == 0);
-    size_t lds = ((size_t)a.nb * MCCNN_WQ_BWD + 4 * 192) * sizeof(float);
-    bool mfma = use_mfma(a) && lds <= 64 * 1024 && m > 0 && e > 0;
-    if (bf16 && (!bf16_shape_ok(a, combin, sorted_feats, out_grad) || lds > 64 * 1024 || (((uintptr_t)feat_grad) & 15))) return MCCNN_E_SHAPE;
+    int tilesB = 1, perB = a.nb;
+    if (!combin) tile_split(a.nb, MCCNN_TILE_BWD, tilesB, perB);
+    size_t lds = ((size_t)perB * MCCNN_WQ_BWD + 4 * 192) * sizeof(float);
+    bool mfma = use_mfma(a, combin != 0) && lds <= 64 * 1024 && m > 0 && e > 0;
+    if (bf16 && (!bf16_shape_ok(a, combin, sorted_feats, out_grad) || (((uintptr_t)feat_grad) & 15))) return MCCNN_E_SHAPE;
     // depth-wise MFMA path writes every feat_grad row itself (conv_stream over the transposed list); everything else
     // accumulates into it
     bool dfeatT = mfma && !combin;
@@ -1172,26 +1209,34 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
         a.G = 0;
         edge_records<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
         MCCNN_LAUNCHED();
-        const bool coop = !combin && a.nb >= 4;
-        int rows = coop ? blocks : waves;  // partial rows to sum
-        if (combin) {
-            if (a.Fin == 1) conv_bwd_mfma<true, 1, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-            else if (a.Fin <= 4) conv_bwd_mfma<true, 3, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-            else conv_bwd_mfma<true, 0, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-        } else if (bf16) {
-            if (coop) conv_bwd_mfma<false, 4, true><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-            else conv_bwd_mfma<false, 4, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-        } else if (coop) {
-            if (vec) conv_bwd_mfma<false, 2, true><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-            else conv_bwd_mfma<false, 0, true><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-        } else {
-            if (vec) conv_bwd_mfma<false, 2, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
-            else conv_bwd_mfma<false, 0, false><<<blocks, 256, lds, s>>>(a, rec, out_grad, feat_grad, dfE, cpw, partials);
+        const size_t elem = bf16 ? 2 : sizeof(float);
+        for (int q0 = 0; q0 < a.nb; q0 += perB) {  // one pass for combin layers, column tiles for wide depth-wise layers
+            const int nbT = a.nb - q0 < perB ? a.nb - q0 : perB;
+            const ConvArgs t = combin ? a : tile_args(a, q0, nbT, elem);
+            const float* og = combin ? out_grad : col_offset_c(out_grad, q0, elem);
+            const size_t ldsT = ((size_t)nbT * MCCNN_WQ_BWD + 4 * 192) * sizeof(float);
+            const bool coop = !combin && nbT >= 4;
+            const int rows = coop ? blocks : waves;  // partial rows to sum
+            if (combin) {
+                if (a.Fin == 1) conv_bwd_mfma<true, 1, false><<<blocks, 256, ldsT, s>>>(t, rec, og, feat_grad, dfE, cpw, partials);
+                else if (a.Fin <= 4) conv_bwd_mfma<true, 3, false><<<blocks, 256, ldsT, s>>>(t, rec, og, feat_grad, dfE, cpw, partials);
+                else conv_bwd_mfma<true, 0, false><<<blocks, 256, ldsT, s>>>(t, rec, og, feat_grad, dfE, cpw, partials);
+            } else if (bf16) {
+                if (coop) conv_bwd_mfma<false, 4, true><<<blocks, 256, ldsT, s>>>(t, rec, og, feat_grad, dfE, cpw, partials);
+                else conv_bwd_mfma<false, 4, false><<<blocks, 256, ldsT, s>>>(t, rec, og, feat_grad, dfE, cpw, partials);
+            } else if (coop) {
+                if (vec) conv_bwd_mfma<false, 2, true><<<blocks, 256, ldsT, s>>>(t, rec, og, feat_grad, dfE, cpw, partials);
+                else conv_bwd_mfma<false, 0, true><<<blocks, 256, ldsT, s>>>(t, rec, og, feat_grad, dfE, cpw, partials);
+            } else {
+                if (vec) conv_bwd_mfma<false, 2, false><<<blocks, 256, ldsT, s>>>(t, rec, og, feat_grad, dfE, cpw, partials);
+                else conv_bwd_mfma<false, 0, false><<<blocks, 256, ldsT, s>>>(t, rec, og, feat_grad, dfE, cpw, partials);
+            }
+            MCCNN_LAUNCHED();
+            reduce_partials<<<ceil_div((long long)nbT * 176, 16), 256, 0, s>>>(
+                partials, rows, nbT, dw1 + (size_t)q0 * 24, db1 + (size_t)q0 * 8, dw2 + (size_t)q0 * 64, db2 + (size_t)q0 * 8,
+                dw3 + (size_t)q0 * 64, db3 + (size_t)q0 * 8);
+            MCCNN_LAUNCHED();
         }
-        MCCNN_LAUNCHED();
-        reduce_partials<<<ceil_div((long long)a.nb * 176, 16), 256, 0, s>>>(partials, rows, a.nb, dw1, db1, dw2, db2,
-                                                                            dw3, db3);
-        MCCNN_LAUNCHED();
         if (combin && a.Fin > 1) {  // Fin == 1: the main kernel adds each edge's finished sum itself
             long long total = (long long)e * a.Fin;
             scatter_edge_featgrad<<<ceil_div(total, 256), 256, 0, s>>>(a.packed, dfE, total, a.Fin, feat_grad);
@@ -1210,12 +1255,17 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
                 perm_t = pt;
             }
             bool vecD = (a.Fin % 8 == 0) && ((((uintptr_t)out_grad) & 15) == 0);
-            ConvArgs t = a;  // rows = the n neighbour points, CSR = start_t, gathered rows = outGrad
-            t.start = start_t;
-            t.m = n;
-            t.feats = out_grad;
-            int rc3 = launch_conv_stream<true>(t, false, vecD, bf16 != 0, feat_grad, rec, perm_t, s);
-            if (rc3) return rc3;
+            int tilesF, perF;
+            tile_split(a.nb, MCCNN_TILE_FWD, tilesF, perF);
+            for (int q0 = 0; q0 < a.nb; q0 += perF) {
+                ConvArgs t = a;  // rows = the n neighbour points, CSR = start_t, gathered rows = outGrad
+                t.feats = out_grad;
+                t = tile_args(t, q0, a.nb - q0 < perF ? a.nb - q0 : perF, elem);
+                t.start = start_t;
+                t.m = n;
+                int rc3 = launch_conv_stream<true>(t, false, vecD, bf16 != 0, col_offset(feat_grad, q0, elem), rec, perm_t, s);
+                if (rc3) return rc3;
+            }
         } else {
             return MCCNN_E_TOOLARGE;  // unreachable: the depth-wise tile always fits for nb <= MCCNN_LDS_MAX_NB
         }

@@ -12,7 +12,6 @@
 // forward issues 22 MFMAs instead of 38, the backward 38 instead of 70 and 104 accumulator FMAs instead of 176.
 // The forward leaves (A, S) in an optional state buffer for the backward; without it the backward recomputes them.
 #include "conv_mfma.h"
-#include <cstdlib>
 
 namespace mccnn {
 
@@ -136,172 +135,6 @@ __global__ __launch_bounds__(256) void f1_fwd_edges(ConvArgs a, float* __restric
     if (lane == 0) zero_rows(keyLast, cB);
 }
 
-// ---------------------------------------------------------------------------------------
-// Forward, edge pass, TRANSPOSED reduction (the default). The segmented sum over a centre's edges is the only
-// cross-lane step of the forward pass; as a wave-wide fused-DPP scan it costs 48 DPP multiply-adds per block (4.2
-// cycles each, tools/conv_probe.hip: 200 of the block's 575 cycles). Here every lane writes its 8 values per block into
-// an LDS tile [64 edges][8 NBT + 4] (16-byte stores, conflict free: the row stride is an odd multiple of 4 banks), and
-// after a group of NBT blocks the wave sums the tile COLUMN-wise with plain adds: lane = (r, n) owns column n and the
-// edges congruent to r modulo 64 / (8 NBT). Segment boundaries are the same for every column, so the walk is a
-// wave-uniform scalar loop; at the end of a segment the 64 / (8 NBT) partial sums of a column meet through two
-// cross-lane exchanges and the centre's finished row leaves as one coalesced store. A centre that continues into the
-// next chunk simply stays in the lanes' accumulators (no carry through LDS, no masks). 64 LDS reads + 64 adds per
-// chunk replace nb x 48 DPP operations. NBT = 2 (16 columns, 5 KB of LDS per wave) keeps the occupancy of the scan form;
-// wider layers take NBT = 4 / 8 so that at most 8 accumulators per lane stay live across the chunk.
-// The next chunk's gathers (points, centre, feature, row length) are prefetched a whole chunk ahead.
-// ---------------------------------------------------------------------------------------
-#define MCCNN_F1T_MAXGROUPS 8
-template <int NBT>
-__global__ __launch_bounds__(256) void f1_fwd_edges_t(ConvArgs a, float* __restrict__ A, float* __restrict__ S,
-                                                      int numWaves) {
-    constexpr int COLS = 8 * NBT, G = 64 / COLS, TS = COLS + 4;
-    extern __shared__ float lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
-    const int rowA = a.nb * 8;
-    float* wl = lds;
-    float* tile = lds + a.nb * MCCNN_WQ_FWD + (size_t)wave * 64 * TS;
-    stage_weights<MCCNN_WQ_FWD>(a, wl);
-    __syncthreads();
-    const int w = blockIdx.x * 4 + wave;
-    if (w >= numWaves) return;
-    const int tA = (int)(((long long)a.e * w) / numWaves);
-    const int tB = (int)(((long long)a.e * (w + 1)) / numWaves);
-    const int cA = (w == 0) ? 0 : wave_lower_bound(a.start, a.m, a.e, tA, lane);
-    const int cB = (w == numWaves - 1) ? a.m : wave_lower_bound(a.start, a.m, a.e, tB, lane);
-    if (cA >= cB) return;
-    const int eBeg = a.start[cA];
-    const int eEnd = (cB < a.m) ? a.start[cB] : a.e;
-    const int numGroups = (a.nb + NBT - 1) / NBT;  // <= MCCNN_F1T_MAXGROUPS (host picks NBT)
-
-    auto zero_rows = [&](int c0, int c1) {  // centres without neighbours
-        for (int c = c0; c < c1; ++c) {
-            for (int f = 0; f < rowA; ++f) A[(size_t)c * rowA + f] = 0.0f;
-            S[c] = 0.0f;
-        }
-    };
-
-    // per-edge inputs of one chunk, loaded a whole chunk ahead
-    struct EdgeIn { int2 pr; float pdf, px, py, pz, cx, cy, cz, f; int e0, e1, b; };
-    auto load_edge = [&](int t, bool ok, EdgeIn& x) {
-        x.pr = make_int2(0, cA);
-        x.pdf = 1.0f; x.px = x.py = x.pz = x.cx = x.cy = x.cz = x.f = 0.f; x.e0 = 0; x.e1 = 1; x.b = 0;
-        if (ok) {
-            x.pr = a.packed[t];
-            x.pdf = a.pdfs[t];
-            const float* pp = a.pts + (size_t)x.pr.x * 3;
-            const float* cc = a.samples + (size_t)x.pr.y * 3;
-            x.px = pp[0]; x.py = pp[1]; x.pz = pp[2];
-            x.cx = cc[0]; x.cy = cc[1]; x.cz = cc[2];
-            x.f = a.feats[x.pr.x];
-            x.e0 = a.start[x.pr.y];
-            x.e1 = (x.pr.y + 1 < a.m) ? a.start[x.pr.y + 1] : a.e;
-            if (a.scaleInv) x.b = clamp_batch(a.bids[x.pr.x], a.B);
-        }
-    };
-
-    int keyLast = cA;
-    float carryS = 0.f;
-    bool haveCarry = false;
-    float acc[MCCNN_F1T_MAXGROUPS];  // lane (r, n): running partial sum of column n of group g (a centre in progress)
-#pragma unroll
-    for (int g = 0; g < MCCNN_F1T_MAXGROUPS; ++g) acc[g] = 0.f;
-    const int r = lane / COLS, n = lane % COLS;
-    const float* col = tile + r * TS + n;
-    EdgeIn nx;
-    load_edge(eBeg + lane, eBeg + lane < eEnd, nx);
-    for (int base = eBeg; base < eEnd; base += 64) {
-        const int t = base + lane;
-        const int nIn = min(64, eEnd - base);
-        const bool in = lane < nIn;
-        const EdgeIn cur = nx;
-        load_edge(t + 64, t + 64 < eEnd, nx);  // the next chunk's gathers fly while this chunk computes
-        const int ci = cur.pr.y;
-        const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, cur.b) : a.radius;
-        const float invR = a.scaleInv ? 1.0f / R : a.invRadius;
-        const float d0 = div_exact(cur.px - cur.cx, R, invR), d1 = div_exact(cur.py - cur.cy, R, invR),
-                    d2 = div_exact(cur.pz - cur.cz, R, invR);
-        const float K = a.avg ? (float)(cur.e1 - cur.e0) : 1.0f;
-        const float s = in ? cur.f * __builtin_amdgcn_rcpf(cur.pdf * K) : 0.0f;
-        const int key = in ? ci + 1 : 0;
-        const int cLast = __builtin_amdgcn_readlane(ci, nIn - 1);
-        const int rowEnd = __builtin_amdgcn_readlane(cur.e1, nIn - 1);
-        const bool cont = rowEnd > base + 64;  // the chunk's last centre goes on in the next chunk
-        int keyPrev = __shfl_up(key, 1, 64);
-        if (lane == 0) keyPrev = keyLast;
-        const int keyNext = __shfl_down(key, 1, 64);
-        const bool tail = in && ((lane == nIn - 1) ? !cont : (key != keyNext));
-        if (in && key - keyPrev > 1) zero_rows(keyPrev, ci);
-        const unsigned long long tails = __ballot(tail);
-
-        // S_i = sum of s over the centre's edges: one value per chunk, fused-DPP scan
-        {
-            const float m1 = (key != 0 && dpp_i<DPP_ROW_SHR(1)>(key) == key) ? 1.f : 0.f;
-            const float m2 = (key != 0 && dpp_i<DPP_ROW_SHR(2)>(key) == key) ? 1.f : 0.f;
-            const float m4 = (key != 0 && dpp_i<DPP_ROW_SHR(4)>(key) == key) ? 1.f : 0.f;
-            const float m8 = (key != 0 && dpp_i<DPP_ROW_SHR(8)>(key) == key) ? 1.f : 0.f;
-            const float mA = (key != 0 && dpp_rows_i<DPP_ROW_BCAST15, 0xA>(key) == key) ? 1.f : 0.f;
-            const float mB = (key != 0 && dpp_rows_i<DPP_ROW_BCAST31, 0xC>(key) == key) ? 1.f : 0.f;
-            const float mC = (haveCarry && key == keyLast) ? 1.f : 0.f;
-            float sv = wave_seg_scan1(s, m1, m2, m4, m8, mA, mB);
-            sv = fmaf(mC, carryS, sv);
-            if (tail) S[ci] = sv;
-            carryS = __shfl(sv, 63, 64);
-        }
-
-        float* trow = tile + lane * TS;
-#pragma unroll 1
-        for (int g = 0; g < numGroups; ++g) {
-            const int q0 = g * NBT, qn = min(NBT, a.nb - q0);
-#pragma unroll
-            for (int qq = 0; qq < NBT; ++qq) {
-                if (qq < qn) {
-                    float pre1[8], a1[8], pre2[8], a2[8], c[8];
-                    MCCNN_PHASE();
-                    mlp_block_l12(wl + (q0 + qq) * MCCNN_WQ_FWD, i4, d0, d1, d2, pre1, a1, pre2, a2);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) c[k] = s * a2[k];
-                    *reinterpret_cast<f32x4*>(trow + qq * 8) = (f32x4){c[0], c[1], c[2], c[3]};
-                    *reinterpret_cast<f32x4*>(trow + qq * 8 + 4) = (f32x4){c[4], c[5], c[6], c[7]};
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // lane (r, n) sums column n over the edges e + r, e + r + G, ... of every segment; segments end where `tails`
-            // has a bit -- the same for every column, so the control flow is wave-uniform
-            const int cols = qn * 8;
-            float run = 0.f;
-#pragma unroll
-            for (int gg = 0; gg < MCCNN_F1T_MAXGROUPS; ++gg) run = (gg == g) ? acc[gg] : run;
-            int e = 0;
-            while (e < nIn) {
-                const unsigned long long rest = tails >> e;
-                const bool closes = rest != 0ull;
-                const int end = closes ? e + (int)__builtin_ctzll(rest) + 1 : nIn;
-                for (int t0 = e; t0 < end; t0 += 4 * G) {
-                    float v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = (t0 + k * G + r < end) ? col[(t0 + k * G) * TS] : 0.f;
-                    run += (v[0] + v[1]) + (v[2] + v[3]);
-                }
-                if (closes) {
-                    float tot = run;
-#pragma unroll
-                    for (int d = COLS; d < 64; d <<= 1) tot += __shfl_xor(tot, d, 64);
-                    const int centre = __builtin_amdgcn_readlane(ci, end - 1);
-                    if (lane < cols) A[(size_t)centre * rowA + q0 * 8 + lane] = tot;
-                    run = 0.f;
-                }
-                e = end;
-            }
-#pragma unroll
-            for (int gg = 0; gg < MCCNN_F1T_MAXGROUPS; ++gg) acc[gg] = (gg == g) ? run : acc[gg];
-            __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next group
-        }
-        haveCarry = cont;
-        keyLast = cLast + 1;
-    }
-    if (lane == 0) zero_rows(keyLast, cB);
-}
-
 // Forward, centre pass: out_i[8q+n] = W3_q[n] . A_i[q] + b3_q[n] S_i. One thread per (centre, block): consecutive lanes
 // read / write consecutive 32-byte pieces of a row; weights from LDS.
 __global__ __launch_bounds__(256) void f1_fwd_centres(ConvArgs a, const float* __restrict__ A,
@@ -375,7 +208,11 @@ __global__ __launch_bounds__(256, MCCNN_F1_OCC) void f1_bwd_edges(ConvArgs a, co
     stage_weights<MCCNN_WQ_BWD>(a, wl);
     __syncthreads();
     const int waveGlobal = blockIdx.x * 4 + wave;
+#ifdef MCCNN_ABL_SAMESLICE  // timing ablation only (wrong results): every wave sweeps the first slice -> all loads hit the caches
+    const long long eBegL = ((long long)waveGlobal * cpw * 64 < a.e) ? 0 : a.e;
+#else
     const long long eBegL = (long long)waveGlobal * cpw * 64;
+#endif
     if (eBegL >= a.e) return;
     const int eBeg = (int)eBegL;
     const int eEnd = (int)min((long long)a.e, eBegL + (long long)cpw * 64);
@@ -434,10 +271,14 @@ __global__ __launch_bounds__(256, MCCNN_F1_OCC) void f1_bwd_edges(ConvArgs a, co
             float sfg = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) sfg = fmaf(Gq[k], a2[k], sfg);
+#ifndef MCCNN_ABL_NODF  // timing ablation only: no per-edge feature-gradient traffic
             if (act) {
                 if (last) atomicAdd(&featGrad[j], (dfOld + sfg + gbi) * inv);
                 else dfE[t] = dfOld + sfg;
             }
+#else
+            asm volatile("" ::"v"(sfg), "v"(dfOld), "v"(gbi));
+#endif
             // t3 = 1[pre2 >= 0] * G_i s_e ; dW2 += t3 a1^T, db2 += t3
             float t3[8];
 #pragma unroll
@@ -614,8 +455,11 @@ static void f1_bwd_partition(int e, int& cpw, int& waves) {
     waves = (int)((chunks + cpw - 1) / cpw);
     if (waves < 1) waves = 1;
 }
+#ifndef MCCNN_F1_CENTRE_WAVES
+#define MCCNN_F1_CENTRE_WAVES 1024
+#endif
 static void f1_centre_partition(int m, int& cPerWave, int& waves) {
-    cPerWave = (m + 1023) / 1024;
+    cPerWave = (m + MCCNN_F1_CENTRE_WAVES - 1) / MCCNN_F1_CENTRE_WAVES;
     cPerWave = (cPerWave + 63) / 64 * 64;
     waves = (m + cPerWave - 1) / cPerWave;
 }
@@ -628,31 +472,6 @@ static void f1_state_split(void* state, int m, int nb, float*& A, float*& S) {
 }
 
 static int f1_run_edges(const ConvArgs& a, float* A, float* S, hipStream_t s) {
-    if ((conv_impl_override().load(std::memory_order_relaxed) & 4) == 0) {
-        // transposed reduction: weights + one [64][8 NBT + 4] tile per wave; NBT keeps the groups per chunk <= 8
-        typedef void (*Kern)(ConvArgs, float*, float*, int);
-        static const int forced = getenv("MCCNN_F1T_NBT") ? atoi(getenv("MCCNN_F1T_NBT")) : 0;  // tuning experiments only
-        int nbt = a.nb <= 2 * MCCNN_F1T_MAXGROUPS ? 2 : (a.nb <= 4 * MCCNN_F1T_MAXGROUPS ? 4 : 8);
-        if (forced == 2 || forced == 4 || forced == 8) nbt = (a.nb + forced - 1) / forced <= MCCNN_F1T_MAXGROUPS ? forced : nbt;
-        Kern fn = nbt == 2 ? f1_fwd_edges_t<2> : (nbt == 4 ? f1_fwd_edges_t<4> : f1_fwd_edges_t<8>);
-        const size_t ldsT = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * 64 * (size_t)(8 * nbt + 4)) * sizeof(float);
-        if (ldsT > 64 * 1024) {
-            static std::atomic<size_t> optedIn[3];
-            std::atomic<size_t>& o = optedIn[nbt == 2 ? 0 : (nbt == 4 ? 1 : 2)];
-            if (ldsT > o.load(std::memory_order_relaxed)) {
-                MCCNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsT));
-                o.store(ldsT, std::memory_order_relaxed);
-            }
-        }
-        const int perCU = cached_blocks_per_cu(reinterpret_cast<const void*>(fn), ldsT);
-        const long long chunks = ((long long)a.e + 63) / 64;
-        long long W = (long long)num_cus() * perCU * 4;
-        if (W > (chunks + 1) / 2) W = (chunks + 1) / 2;
-        if (W < 1) W = 1;
-        fn<<<(int)((W + 3) / 4), 256, ldsT, s>>>(a, A, S, (int)W);
-        MCCNN_LAUNCHED();
-        return 0;
-    }
     const size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * (size_t)a.nb * 8) * sizeof(float);
     const int perCU = cached_blocks_per_cu(reinterpret_cast<const void*>(f1_fwd_edges), lds);
     const long long chunks = ((long long)a.e + 63) / 64;

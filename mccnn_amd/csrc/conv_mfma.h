@@ -357,8 +357,7 @@ inline int num_cus() {
 }
 
 // Implementation override for A/B tests of the conv kernels: bit 0 = VALU fallback kernels, bit 1 = general MFMA
-// kernels for one-input-feature layers, bit 2 = the DPP-scan form of the factored forward pass (instead of the
-// transposed reduction). Read ONCE from the environment (MCCNN_FORCE_VALU / MCCNN_NO_F1 / MCCNN_F1_SCAN) when the
+// kernels for one-input-feature layers. Read ONCE from the environment (MCCNN_FORCE_VALU / MCCNN_NO_F1) when the
 // library is first used; tests switch it through mccnn_debug_conv_impl(). Not part of the product configuration.
 std::atomic<int>& conv_impl_override();
 

@@ -221,7 +221,7 @@ MCSEG_K32 = [  # models/MCSeg.py:36-198, grow 32 (BASELINE cfg3); last field: bf
     (2, 2, 0.4, 0.25, 128, 128, False, True),      # Conv_3
     (2, 3, 0.8, 0.2, 256, 256, False, True),       # Pool_3
     (3, 3, S3, 0.25, 256, 256, False, True),       # Conv_4
-    (3, 2, S3, 0.25, 512, 512, False, False),      # Up_3_4: 64 blocks -> the backward's LDS tile is too large: f32 rows
+    (3, 2, S3, 0.25, 512, 512, False, True),       # Up_3_4: 64 blocks, two column tiles in the backward pass
     (2, 2, 0.4, 0.25, 256, 256, False, True),      # DeConv_3
     (2, 1, 0.2, 0.25, 256, 256, False, True),      # Up_2_3
     (1, 1, 0.1, 0.25, 128, 128, False, True),      # DeConv_2

@@ -141,7 +141,9 @@ CONV_CASES = [
     ("4to6_combin_abs", 4, 6, True, True, False, 0.12),  # static (fin, fo) patterns: Fin = 2, 3, 4 each have their own
     ("3to16_combin", 3, 16, True, True, True, 0.15),  # 48 neurons -> nb = 6, r0 cycles 0, 2, 1, 0, 2, 1
     ("8to3_combin_generic", 8, 3, True, True, True, 0.15),  # Fin > 4: the generic gather path
-    ("dw520_valu_fallback", 520, 520, False, True, True, 0.3),  # nb = 65 > MCCNN_LDS_MAX_NB: automatic VALU fallback
+    ("dw520_two_column_tiles", 520, 520, False, True, True, 0.3),  # nb = 65 > one launch's LDS weight tile: column tiles
+    ("dw2048_column_tiles", 2048, 2048, False, True, True, 0.3),  # MCClassH Pool_3 at grow 64: nb = 256 (4 fwd / 6 bwd tiles)
+    ("4to130_combin_valu_fallback", 4, 130, True, True, True, 0.3),  # combin, nb = 65 > MCCNN_LDS_MAX_NB: VALU kernels
     ("1to256_combin", 1, 256, True, True, True, 0.15),  # nb = 32 through the factored path
     ("1to13_combin_padded_noavg_abs", 1, 13, True, False, False, 0.12),  # factored Fin=1 path, 3 padded neurons
     ("1to64_combin_nostate", 1, 64, True, True, True, 0.15),  # backward without the forward's state: recomputed
@@ -154,7 +156,7 @@ def test_spatial_conv_fwd_bwd(mc, oracle, case):
     name, fin, fout, combin, avg, scaleInv, radius = case
     B = 2
     mc.KEEP_CONV_STATE = not name.endswith("nostate")
-    pts, bids = make_cloud(1000 if fin > 256 else 1500, B, 21, "clustered", True)
+    pts, bids = make_cloud(300 if fin > 1024 else (1000 if fin > 256 else 1500), B, 21, "clustered", True)
     rng = np.random.default_rng(7)
     feats = (2 * rng.random((len(pts), fin)) - 1).astype(np.float32)
     o = run_chain(oracle, _ident, _ident, pts, bids, feats, B, radius, scaleInv, fout=fout, combin=combin)
@@ -194,7 +196,6 @@ def test_spatial_conv_fwd_bwd(mc, oracle, case):
     others = [(1, "VALU kernels")]
     if combin and fin == 1:
         others.append((2, "general MFMA kernels"))
-        others.append((4, "factored kernels, DPP-scan forward"))
     for mask, label in others:
         mc.debug_conv_impl(mask)
         try:
