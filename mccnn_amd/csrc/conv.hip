@@ -446,8 +446,11 @@ __global__ __launch_bounds__(256) void edge_records(ConvArgs a, float4* __restri
 #endif
 // Waves own equal, contiguous EDGE ranges (cpw chunks of 64 edges each): nothing in the backward pass needs
 // centre alignment, and equal edge counts remove the tail that centre-aligned ranges show on non-uniform clouds.
+#ifndef MCCNN_BWD_OCC_COMBIN
+#define MCCNN_BWD_OCC_COMBIN MCCNN_BWD_OCC
+#endif
 template <bool COMBIN, int FEAT, bool COOP>
-__global__ __launch_bounds__(256, MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, const float4* __restrict__ rec,
+__global__ __launch_bounds__(256, (COMBIN && FEAT != 1) ? MCCNN_BWD_OCC_COMBIN : MCCNN_BWD_OCC) void conv_bwd_mfma(ConvArgs a, const float4* __restrict__ rec,
                                                                     const float* __restrict__ outGrad,
                                                                     float* __restrict__ featGrad,
                                                                     float* __restrict__ dfE, int cpw,
