@@ -188,7 +188,7 @@ class Workload:
                              dtype=torch.uint8, device=device)
         conv_args = (ptr(sP), ptr(sF), ptr(sB), ptr(pdfs), ptr(P), ptr(start), ptr(packed), ptr(mn), ptr(mx), ptr(w1),
                      ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3))
-        sbytes = lib.mccnn_spatial_conv_state_bytes(m, fin, fout, int(combin))
+        sbytes = lib.mccnn_spatial_conv_state_bytes(m, e, fin, fout, int(combin))
         state = torch.empty(sbytes, dtype=torch.uint8, device=device) if sbytes else None  # kept fwd -> bwd, as autograd does
         t_fwd, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_fwd(*conv_args, n, m, e, fin, fout, int(combin), B, r, 0,
                                                                     1, ptr(o), ptr(state), ptr(fwd_ws), fwd_ws.numel(),

@@ -181,10 +181,12 @@ int mccnn_poisson_sampling_fill(const float* sorted_pts, int n, const int* cell_
  * out[M, combin ? num_out_feats : num_in_feats].  Every output row is written
  * (no pre-zeroing needed).
  * state: optional device buffer of mccnn_spatial_conv_state_bytes() bytes (0 = this layer shape
- * keeps no state). Combin layers with one input feature leave their per-centre sums there; handing
- * the same buffer to mccnn_spatial_conv_bwd saves it one pass over the edges. NULL is always
- * allowed (the reference op has no such output: SpatialConvGrad then recomputes). */
-size_t mccnn_spatial_conv_state_bytes(int m, int num_in_feats, int num_out_feats, int combin);
+ * keeps no state). The forward pass leaves there what it has computed anyway and the backward pass
+ * needs again: one 16-byte record (delta, 1 / (pdf K)) per edge and, for combin layers with one
+ * input feature, the per-centre sums of the factored algorithm; handing the same buffer to
+ * mccnn_spatial_conv_bwd saves it its pre-pass over the edges (and, for those layers, one more).
+ * NULL is always allowed (the reference op has no such output: SpatialConvGrad then recomputes). */
+size_t mccnn_spatial_conv_state_bytes(int m, int e, int num_in_feats, int num_out_feats, int combin);
 size_t mccnn_spatial_conv_fwd_workspace_bytes(int m, int e, int num_in_feats, int num_out_feats,
                                               int combin);
 int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats,

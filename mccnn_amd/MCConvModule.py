@@ -672,10 +672,10 @@ class _SpatialConv(torch.autograd.Function):
             ctx.attrs = (numOutFeatures, bool(combin), batchSize, float(radius), bool(scaleInv), bool(avg))
             return out
         out = torch.empty((m, outF), dtype=torch.float32, device=pts.device)
-        # per-centre sums the backward pass can reuse (layers with one input feature); only kept when a gradient
-        # will be asked for
+        # what the backward pass can reuse: per-edge records (16 B per edge) and, for layers with one input feature, the
+        # per-centre sums; only kept when a gradient will be asked for
         state = None
-        sbytes = lib.mccnn_spatial_conv_state_bytes(m, fin, numOutFeatures, int(bool(combin)))
+        sbytes = lib.mccnn_spatial_conv_state_bytes(m, e, fin, numOutFeatures, int(bool(combin)))
         if KEEP_CONV_STATE and sbytes and e > 0 and any(t.requires_grad for t in (feats, w1, b1, w2, b2, w3, b3)):
             state = torch.empty(sbytes, dtype=torch.uint8, device=pts.device)
         check(lib.mccnn_spatial_conv_fwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),

@@ -45,7 +45,7 @@ SIGNATURES = {
     "mccnn_poisson_sampling_count": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
     "mccnn_poisson_sampling_fill": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_spatial_conv_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "mccnn_spatial_conv_state_bytes": (_sz, [_i, _i, _i, _i]),
+    "mccnn_spatial_conv_state_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "mccnn_spatial_conv_fwd": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_spatial_conv_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mccnn_spatial_conv_bwd": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _i, _i, _f, _i, _i] + [_vp] * 10 + [_vp, _sz, _vp]),

@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void conv_fwd_valu(ConvArgs a, float* __restri
 // is the forward convolution with the roles of centres and neighbours swapped (a.feats = outGrad, a.m = n).
 template <bool COMBIN, int FEAT, bool TR>
 __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict__ out, int numWaves,
-                                                   const float4* __restrict__ rec, const int* __restrict__ permT) {
+                                                   const float4* __restrict__ rec, const int* __restrict__ permT,
+                                                   float4* __restrict__ recOut) {
     extern __shared__ float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
     const int outF = a.outF;
@@ -249,6 +250,9 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
             float K = 1.0f;
             if (a.avg) K = (float)(((ci + 1 < a.m) ? a.start[ci + 1] : a.e) - a.start[ci]);
             inv = in ? __builtin_amdgcn_rcpf(pdf * K) : 0.0f;
+            // optional forward state: the per-edge record (delta, 1 / (pdf K)) the backward pass would otherwise
+            // recompute in a pass of its own -- identical bits (edge_records spells the same expressions)
+            if (recOut && in) recOut[t] = make_float4(d0, d1, d2, inv);
         }
         const int key = in ? ci + 1 : 0;
         const int cLast = __builtin_amdgcn_readlane(ci, nIn - 1);
@@ -944,8 +948,8 @@ using namespace mccnn;
 // Launch of the streaming reduction kernel: as many waves as the chip keeps resident (one balanced round).
 template <bool TR>
 static int launch_conv_stream(const ConvArgs& a, bool combin, bool vec, bool bf16, float* out, const float4* rec,
-                              const int* permT, hipStream_t s) {
-    typedef void (*Kern)(ConvArgs, float*, int, const float4*, const int*);
+                              const int* permT, hipStream_t s, float4* recOut = nullptr) {
+    typedef void (*Kern)(ConvArgs, float*, int, const float4*, const int*, float4*);
     Kern fn;
     if (bf16) fn = TR ? conv_stream<false, 4, true> : conv_stream<false, 4, false>;
     else if (TR) fn = vec ? conv_stream<false, 2, true> : conv_stream<false, 0, true>;
@@ -958,7 +962,7 @@ static int launch_conv_stream(const ConvArgs& a, bool combin, bool vec, bool bf1
     long long W = (long long)numCU * perCU * 4;
     if (W > (chunks + 1) / 2) W = (chunks + 1) / 2;  // at least ~2 chunks per wave
     if (W < 1) W = 1;
-    fn<<<(int)((W + 3) / 4), 256, lds, s>>>(a, out, (int)W, rec, permT);
+    fn<<<(int)((W + 3) / 4), 256, lds, s>>>(a, out, (int)W, rec, permT, recOut);
     MCCNN_LAUNCHED();
     return 0;
 }
@@ -973,9 +977,15 @@ static bool f1_shape(int num_in_feats, int num_out_feats, int combin) {
            (conv_impl_override().load(std::memory_order_relaxed) & 3) == 0;
 }
 
-size_t mccnn_spatial_conv_state_bytes(int m, int num_in_feats, int num_out_feats, int combin) {
-    if (m <= 0 || !f1_shape(num_in_feats, num_out_feats, combin)) return 0;
-    return f1_state_bytes(m, (num_out_feats + 7) / 8);
+// Forward state: one record (delta, 1 / (pdf K)) per edge -- every layer on the MFMA kernels -- followed, for combin
+// layers with one input feature, by the per-centre sums (A, S) of the factored algorithm.
+static size_t state_record_bytes(int e) { return align_up((size_t)(e > 0 ? e : 0) * sizeof(float4)); }
+size_t mccnn_spatial_conv_state_bytes(int m, int e, int num_in_feats, int num_out_feats, int combin) {
+    if (m <= 0 || e <= 0 || num_in_feats <= 0 || num_out_feats <= 0) return 0;
+    if (f1_shape(num_in_feats, num_out_feats, combin)) return state_record_bytes(e) + f1_state_bytes(m, (num_out_feats + 7) / 8);
+    const long long neurons = combin ? (long long)num_in_feats * num_out_feats : num_in_feats;
+    const bool mfma = (!combin || (neurons + 7) / 8 <= MCCNN_LDS_MAX_NB) && (conv_impl_override().load(std::memory_order_relaxed) & 1) == 0;
+    return mfma ? state_record_bytes(e) : 0;
 }
 
 size_t mccnn_spatial_conv_fwd_workspace_bytes(int m, int e, int num_in_feats, int num_out_feats, int combin) {
@@ -1033,15 +1043,18 @@ static int conv_fwd_impl(const float* sorted_pts, const float* sorted_feats, con
     hipStream_t s = (hipStream_t)stream;
     bool vec = !combin && (a.Fin % 8 == 0) && ((((uintptr_t)sorted_feats) & 15) == 0);
     if (bf16 && !bf16_shape_ok(a, combin, sorted_feats, out)) return MCCNN_E_SHAPE;
-    if (e > 0 && f1_shape(num_in_feats, num_out_feats, combin)) return f1_forward(a, out, state, ws, ws_bytes, s);
+    float4* recOut = state ? reinterpret_cast<float4*>(state) : nullptr;
+    if (e > 0 && f1_shape(num_in_feats, num_out_feats, combin))
+        return f1_forward(a, out, recOut, state ? (char*)state + state_record_bytes(e) : nullptr, ws, ws_bytes, s);
     if (use_mfma(a, combin != 0) && e > 0) {
-        if (combin || a.nb <= MCCNN_TILE_FWD) return launch_conv_stream<false>(a, combin != 0, vec, bf16 != 0, out, nullptr, nullptr, s);
+        if (combin || a.nb <= MCCNN_TILE_FWD) return launch_conv_stream<false>(a, combin != 0, vec, bf16 != 0, out, nullptr, nullptr, s, recOut);
         int tiles, per;
         tile_split(a.nb, MCCNN_TILE_FWD, tiles, per);
         const size_t elem = bf16 ? 2 : sizeof(float);
         for (int q0 = 0; q0 < a.nb; q0 += per) {
             const ConvArgs t = tile_args(a, q0, a.nb - q0 < per ? a.nb - q0 : per, elem);
-            int rc2 = launch_conv_stream<false>(t, false, vec, bf16 != 0, col_offset(out, q0, elem), nullptr, nullptr, s);
+            int rc2 = launch_conv_stream<false>(t, false, vec, bf16 != 0, col_offset(out, q0, elem), nullptr, nullptr, s,
+                                                q0 == 0 ? recOut : nullptr);  // the records do not depend on the tile
             if (rc2) return rc2;
         }
         return 0;
@@ -1196,8 +1209,10 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
     }
     if (m == 0 || e == 0) return 0;
     if (!out_grad) return MCCNN_E_BADARG;
+    const float4* recIn = state ? reinterpret_cast<const float4*>(state) : nullptr;
     if (mfma && f1_shape(num_in_feats, num_out_feats, combin))
-        return f1_backward(a, out_grad, state, feat_grad, dw1, db1, dw2, db2, dw3, db3, ws, ws_bytes, s);
+        return f1_backward(a, out_grad, recIn, state ? (const char*)state + state_record_bytes(e) : nullptr, feat_grad, dw1, db1,
+                           dw2, db2, dw3, db3, ws, ws_bytes, s);
     if (mfma) {
         if (!ws || ws_bytes < mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, num_in_feats, num_out_feats, combin))
             return MCCNN_E_WORKSPACE;
@@ -1210,8 +1225,12 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
         float* dfE = combin ? ar.take<float>((size_t)e * a.Fin) : nullptr;
         if (!partials || !rec || (combin && !dfE)) return MCCNN_E_WORKSPACE;
         a.G = 0;
-        edge_records<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
-        MCCNN_LAUNCHED();
+        if (recIn) {
+            rec = const_cast<float4*>(recIn);  // left there by the forward call of the same inputs
+        } else {
+            edge_records<<<ceil_div(e, 256), 256, 0, s>>>(a, rec);
+            MCCNN_LAUNCHED();
+        }
         const size_t elem = bf16 ? 2 : sizeof(float);
         for (int q0 = 0; q0 < a.nb; q0 += perB) {  // one pass for combin layers, column tiles for wide depth-wise layers
             const int nbT = a.nb - q0 < perB ? a.nb - q0 : perB;

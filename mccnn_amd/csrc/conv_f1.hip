@@ -35,7 +35,7 @@ __device__ __forceinline__ float wave_seg_scan1(float v, float m1, float m2, flo
 // scan with carry, the last lane of a centre stores its finished sums.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void f1_fwd_edges(ConvArgs a, float* __restrict__ A, float* __restrict__ S,
-                                                    int numWaves) {
+                                                    int numWaves, float4* __restrict__ recOut) {
     extern __shared__ float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
     const int rowA = a.nb * 8;
@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void f1_fwd_edges(ConvArgs a, float* __restric
         const float d0 = div_exact(pp[0] - cc[0], R, invR), d1 = div_exact(pp[1] - cc[1], R, invR), d2 = div_exact(pp[2] - cc[2], R, invR);
         float K = 1.0f;
         if (a.avg) K = (float)(((ci + 1 < a.m) ? a.start[ci + 1] : a.e) - a.start[ci]);
-        const float s = in ? a.feats[j] * __builtin_amdgcn_rcpf(pdf * K) : 0.0f;
+        const float inv = in ? __builtin_amdgcn_rcpf(pdf * K) : 0.0f;
+        const float s = in ? a.feats[j] * inv : 0.0f;
+        if (recOut && in) recOut[t] = make_float4(d0, d1, d2, inv);  // the record f1_edge_records would compute (same bits)
         const int key = in ? ci + 1 : 0;
         const int cLast = __builtin_amdgcn_readlane(ci, nIn - 1);
         const int rowEnd = (cLast + 1 < a.m) ? a.start[cLast + 1] : a.e;
@@ -471,28 +473,28 @@ static void f1_state_split(void* state, int m, int nb, float*& A, float*& S) {
     S = (float*)((char*)state + align_up((size_t)m * nb * 8 * sizeof(float)));
 }
 
-static int f1_run_edges(const ConvArgs& a, float* A, float* S, hipStream_t s) {
+static int f1_run_edges(const ConvArgs& a, float* A, float* S, float4* recOut, hipStream_t s) {
     const size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * (size_t)a.nb * 8) * sizeof(float);
     const int perCU = cached_blocks_per_cu(reinterpret_cast<const void*>(f1_fwd_edges), lds);
     const long long chunks = ((long long)a.e + 63) / 64;
     long long W = (long long)num_cus() * perCU * 4;
     if (W > (chunks + 1) / 2) W = (chunks + 1) / 2;
     if (W < 1) W = 1;
-    f1_fwd_edges<<<(int)((W + 3) / 4), 256, lds, s>>>(a, A, S, (int)W);
+    f1_fwd_edges<<<(int)((W + 3) / 4), 256, lds, s>>>(a, A, S, (int)W, recOut);
     MCCNN_LAUNCHED();
     return 0;
 }
 
 size_t f1_fwd_workspace_bytes(int m, int nb) { return f1_state_bytes(m, nb) + 256; }
 
-int f1_forward(const ConvArgs& a, float* out, void* state, void* ws, size_t ws_bytes, hipStream_t s) {
+int f1_forward(const ConvArgs& a, float* out, float4* rec_out, void* state, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!state) {
         if (!ws || ws_bytes < f1_fwd_workspace_bytes(a.m, a.nb)) return MCCNN_E_WORKSPACE;
         state = ws;
     }
     float *A, *S;
     f1_state_split(state, a.m, a.nb, A, S);
-    int rc = f1_run_edges(a, A, S, s);
+    int rc = f1_run_edges(a, A, S, rec_out, s);
     if (rc) return rc;
     f1_fwd_centres<<<ceil_div((long long)a.m * a.nb, 256), 256, (size_t)a.nb * 72 * sizeof(float), s>>>(a, A, S, out);
     MCCNN_LAUNCHED();
@@ -512,7 +514,7 @@ size_t f1_bwd_workspace_bytes(int m, int e, int nb) {
 }
 
 // feat_grad must be zero on entry (the edge pass adds to it); the six parameter gradients are fully written.
-int f1_backward(const ConvArgs& a, const float* out_grad, const void* state, float* feat_grad, float* dw1, float* db1,
+int f1_backward(const ConvArgs& a, const float* out_grad, const float4* rec_in, const void* state, float* feat_grad, float* dw1, float* db1,
                 float* dw2, float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!ws || ws_bytes < f1_bwd_workspace_bytes(a.m, a.e, a.nb)) return MCCNN_E_WORKSPACE;
     int cpw, wavesE, cPerWave, wavesC;
@@ -533,16 +535,21 @@ int f1_backward(const ConvArgs& a, const float* out_grad, const void* state, flo
         f1_state_split(const_cast<void*>(state), a.m, a.nb, A, S);
     } else {
         f1_state_split(own, a.m, a.nb, A, S);
-        int rc = f1_run_edges(a, A, S, s);
+        int rc = f1_run_edges(a, A, S, nullptr, s);
         if (rc) return rc;
     }
     const size_t ldsC = (size_t)a.nb * 72 * sizeof(float);
     f1_bwd_centres<<<blocksC, 256, ldsC, s>>>(a, out_grad, A, S, cPerWave, G, gb, pc);
     MCCNN_LAUNCHED();
-    f1_edge_records<<<ceil_div(a.e, 256), 256, 0, s>>>(a, rec);
-    MCCNN_LAUNCHED();
+    const float4* recUse = rec;
+    if (rec_in) {
+        recUse = rec_in;  // written by the forward call of the same inputs
+    } else {
+        f1_edge_records<<<ceil_div(a.e, 256), 256, 0, s>>>(a, rec);
+        MCCNN_LAUNCHED();
+    }
     const size_t ldsE = (size_t)a.nb * MCCNN_WQ_BWD * sizeof(float);
-    f1_bwd_edges<<<blocksE, 256, ldsE, s>>>(a, rec, G, gb, feat_grad, dfE, cpw, pe);
+    f1_bwd_edges<<<blocksE, 256, ldsE, s>>>(a, recUse, G, gb, feat_grad, dfE, cpw, pe);
     MCCNN_LAUNCHED();
     f1_reduce<<<ceil_div((long long)a.nb * 176, 16), 256, 0, s>>>(pe, wavesE, pc, wavesC, a.nb, dw1, db1, dw2, db2, dw3, db3);
     MCCNN_LAUNCHED();

@@ -365,8 +365,8 @@ std::atomic<int>& conv_impl_override();
 size_t f1_state_bytes(int m, int nb);
 size_t f1_fwd_workspace_bytes(int m, int nb);
 size_t f1_bwd_workspace_bytes(int m, int e, int nb);
-int f1_forward(const ConvArgs& a, float* out, void* state, void* ws, size_t ws_bytes, hipStream_t s);
-int f1_backward(const ConvArgs& a, const float* out_grad, const void* state, float* feat_grad, float* dw1, float* db1,
+int f1_forward(const ConvArgs& a, float* out, float4* rec_out, void* state, void* ws, size_t ws_bytes, hipStream_t s);
+int f1_backward(const ConvArgs& a, const float* out_grad, const float4* rec_in, const void* state, float* feat_grad, float* dw1, float* db1,
                 float* dw2, float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes, hipStream_t s);
 
 }  // namespace mccnn
