@@ -41,8 +41,12 @@ struct Arena {
 
 // Exclusive prefix sum of n int32 (out may alias in). If total != nullptr the grand
 // total is written there. ws must hold scan_workspace_bytes(n). Defined in scan.hip.
+// Up to 2 M elements the scan is ONE launch (decoupled look-back); its status words are the first
+// scan_status_bytes(n) bytes of ws and have to be zero on entry: pass status_zeroed = true when the caller has cleared
+// them together with something it clears anyway, otherwise the scan issues the memset itself.
 size_t scan_workspace_bytes(int n);
-int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t s);
+size_t scan_status_bytes(int n);
+int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t s, bool status_zeroed = false);
 
 // ---------------------------------------------------------------------------------------
 // Geometry helpers. The library is compiled with -ffp-contract=off, so each expression

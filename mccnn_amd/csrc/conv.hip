@@ -1140,16 +1140,19 @@ int mccnn_transpose_neighbors(const int* packed, int e, int n, int* start_t, int
     if (!packed || !perm_t) return MCCNN_E_BADARG;
     if (!ws || ws_bytes < mccnn_transpose_neighbors_workspace_bytes(n, e)) return MCCNN_E_WORKSPACE;
     Arena ar(ws, ws_bytes);
-    int* cnt = ar.take<int>((size_t)n);
+    // row counters and the scan's status words are neighbours: ONE memset clears both
+    const size_t cntBytes = align_up((size_t)n * 4);
+    char* blk = ar.take<char>(cntBytes + scan_workspace_bytes(n));
     int* slot = ar.take<int>((size_t)e);
     int* tmp = ar.take<int>((size_t)e);
-    void* scanws = ar.take<char>(scan_workspace_bytes(n));
-    if (!cnt || !slot || !tmp || !scanws) return MCCNN_E_WORKSPACE;
+    if (!blk || !slot || !tmp) return MCCNN_E_WORKSPACE;
+    int* cnt = (int*)blk;
+    void* scanws = blk + cntBytes;
     const int2* pk = reinterpret_cast<const int2*>(packed);
-    MCCNN_HIP(hipMemsetAsync(cnt, 0, (size_t)n * sizeof(int), s));
+    MCCNN_HIP(hipMemsetAsync(blk, 0, cntBytes + scan_status_bytes(n), s));
     tr_count<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, cnt, slot);
     MCCNN_LAUNCHED();
-    int rc = exclusive_scan_i32(cnt, start_t, n, start_t + n, scanws, s);
+    int rc = exclusive_scan_i32(cnt, start_t, n, start_t + n, scanws, s, true);
     if (rc) return rc;
     tr_fill<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, start_t, slot, tmp);
     MCCNN_LAUNCHED();

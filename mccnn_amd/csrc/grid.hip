@@ -352,16 +352,19 @@ static int sort_step1_impl(const float* pts, const int* batch_ids, const float* 
     if (!ws || ws_bytes < mccnn_sort_step1_workspace_bytes(n, batch_size, num_cells)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     Arena a(ws, ws_bytes);
-    int* cnt = a.take<int>((size_t)C);
+    // counters and the scan's status words are neighbours: ONE memset clears both
+    const size_t cntBytes = align_up((size_t)C * 4), scanBytes = scan_workspace_bytes((int)C);
+    char* blk = a.take<char>(cntBytes + scanBytes);
     int* start = a.take<int>((size_t)C + 1);
     int* slot = a.take<int>((size_t)n);
-    void* scanws = a.take<char>(scan_workspace_bytes((int)C));
-    if (!cnt || !start || !slot || !scanws) return MCCNN_E_WORKSPACE;
-    MCCNN_HIP(hipMemsetAsync(cnt, 0, (size_t)C * sizeof(int), s));
+    if (!blk || !start || !slot) return MCCNN_E_WORKSPACE;
+    int* cnt = (int*)blk;
+    void* scanws = blk + cntBytes;
+    MCCNN_HIP(hipMemsetAsync(blk, 0, cntBytes + scan_status_bytes((int)C), s));
     int blocks = ceil_div(n, 256);
     keys_hist<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, keys, cnt, new_idx, n_dev);
     MCCNN_LAUNCHED();
-    int rc = exclusive_scan_i32(cnt, start, (int)C, start + C, scanws, s);
+    int rc = exclusive_scan_i32(cnt, start, (int)C, start + C, scanws, s, true);
     if (rc) return rc;
     park_ids<<<blocks, 256, 0, s>>>(keys, start, new_idx, n, slot, n_dev);
     MCCNN_LAUNCHED();

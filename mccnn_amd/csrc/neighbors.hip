@@ -74,8 +74,11 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                                                     float radius, int scaleInv, const int* __restrict__ order,
                                                     int* __restrict__ cnt, unsigned long long* __restrict__ masks,
                                                     const int* __restrict__ startIdx, int* __restrict__ packed,
-                                                    int capacity) {
+                                                    int capacity, unsigned long long* __restrict__ zeroWords, int numZero) {
     constexpr bool FILL = MODE == 1;
+    // the status words of the prefix sum that follows the count pass (scan.hip): cleared here, no launch of their own
+    if (!FILL && blockIdx.x == 0)
+        for (int k = threadIdx.x; k < numZero; k += blockDim.x) zeroWords[k] = 0ull;
     __shared__ float4 win[4][MCCNN_NW_CAP];
     __shared__ int2 ctab[4][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -350,9 +353,10 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     neigh_window<0><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
                                                               aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, w.cnt,
-                                                              w.masks, nullptr, nullptr, 0);
+                                                              w.masks, nullptr, nullptr, 0, (unsigned long long*)w.scanws,
+                                                              (int)(scan_status_bytes(m) / sizeof(unsigned long long)));
     MCCNN_LAUNCHED();
-    int rc = exclusive_scan_i32(w.cnt, start_idx, m, total_dev, w.scanws, s);
+    int rc = exclusive_scan_i32(w.cnt, start_idx, m, total_dev, w.scanws, s, true);
     if (rc) return rc;
     return 0;
 }
@@ -371,7 +375,7 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     hipStream_t s = (hipStream_t)stream;
     neigh_window<1><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
                                                               aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, nullptr,
-                                                              w.masks, start_idx, packed, e);
+                                                              w.masks, start_idx, packed, e, nullptr, 0);
     MCCNN_LAUNCHED();
     return 0;
 }

@@ -389,13 +389,16 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
     if (!ws || ws_bytes < mccnn_poisson_sampling_workspace_bytes(n, batch_size, num_cells)) return MCCNN_E_WORKSPACE;
     Arena a(ws, ws_bytes);
     unsigned char* sel = a.take<unsigned char>((size_t)n);
-    int* slots = a.take<int>((size_t)S);
-    void* scanws = a.take<char>(scan_workspace_bytes((int)S));
+    // slot counters and the scan's status words are neighbours: ONE memset clears both
+    const size_t slotBytes = align_up((size_t)S * 4);
+    char* blk = a.take<char>(slotBytes + scan_workspace_bytes((int)S));
     const size_t C = (size_t)batch_size * num_cells * num_cells * num_cells;
     int* flags = a.take<int>(C + 1);  // done[C], fail
-    if (!sel || !slots || !scanws || !flags) return MCCNN_E_WORKSPACE;
+    if (!sel || !blk || !flags) return MCCNN_E_WORKSPACE;
+    int* slots = (int*)blk;
+    void* scanws = blk + slotBytes;
     MCCNN_HIP(hipMemsetAsync(sel, 0, (size_t)n, s));
-    MCCNN_HIP(hipMemsetAsync(slots, 0, (size_t)S * sizeof(int), s));
+    MCCNN_HIP(hipMemsetAsync(blk, 0, slotBytes + scan_status_bytes((int)S), s));
     PoissonDims d = poisson_dims(num_cells);
     long long threads = (long long)batch_size * d.G * d.G * d.G;
     if (mode == 1 || mode == 2) {
@@ -406,7 +409,7 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
         poisson_dataflow<<<ceil_div(threads * 27, 4), 256, 0, s>>>(sorted_pts, cell_indexs, aabb_min, aabb_max, batch_size, d,
                                                                   radius, scale_inv, sel, slots, flags, flags + C, spinLimit);
         MCCNN_LAUNCHED();
-        int rc = exclusive_scan_i32(slots, slots, (int)S, total_dev, scanws, s);
+        int rc = exclusive_scan_i32(slots, slots, (int)S, total_dev, scanws, s, true);
         if (rc) return rc;
         poisson_flag_failure<<<1, 1, 0, s>>>(flags + C, total_dev);  // *total_dev = -1: repeat the call with mode 0
         MCCNN_LAUNCHED();
@@ -417,7 +420,7 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
                                                                 d, ph, radius, scale_inv, sel, slots);
         MCCNN_LAUNCHED();
     }
-    return exclusive_scan_i32(slots, slots, (int)S, total_dev, scanws, s);
+    return exclusive_scan_i32(slots, slots, (int)S, total_dev, scanws, s, true);
 }
 
 int mccnn_poisson_sampling_fill(const float* sorted_pts, int n, const int* cell_indexs, int batch_size, int num_cells,

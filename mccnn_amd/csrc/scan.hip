@@ -79,8 +79,76 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const int* in, int* o
     if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total = run;
 }
 
+// ------------------------------------------------------------------ single pass (decoupled look-back)
+// One launch instead of two for up to SCAN_CHAIN_TILES tiles (2 M elements: every use at the benchmark sizes). Tile b
+// publishes its aggregate, then wave 0 looks back over the status words of its predecessors -- 64 at a time -- until it
+// meets an inclusive prefix, and publishes its own. A status word is ONE aligned 8-byte agent-scope store: bits 63..62 =
+// state (0 empty, 1 aggregate, 2 inclusive prefix), low 32 bits = value -- the data is the flag, no fences needed.
+// All tiles of such a launch are resident at once (<= 4 small workgroups per CU), so a predecessor always makes
+// progress; the words must be zero on entry (the callers fold that into a memset / kernel they run anyway).
+constexpr int SCAN_CHAIN_TILES = 1024;
+__global__ __launch_bounds__(SCAN_THREADS) void scan_chained(const int* in, int* out, int n,
+                                                             unsigned long long* status, int* total) {
+    __shared__ int lds[4];
+    __shared__ int sOff;
+    const int tile = blockIdx.x;
+    const long long base = (long long)tile * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    int tot;
+    const int ex = block_excl_scan(s, tot, lds);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int excl = 0;
+        if (tile == 0) {
+            if (lane == 0) __hip_atomic_store(status, (2ull << 62) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(status + tile, (1ull << 62) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int hi = tile - 1;  // look back over tiles hi, hi - 1, ... (lane l reads tile hi - l)
+            while (true) {
+                const int p = hi - lane;
+                unsigned long long w = 0;
+                bool ready;
+                do {  // every word of the window has to be published before the window can be summed
+                    w = (p >= 0) ? __hip_atomic_load(status + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+                    ready = __all((w >> 62) != 0);
+                    if (!ready) __builtin_amdgcn_s_sleep(2);
+                } while (!ready);
+                const unsigned long long pref = __ballot((w >> 62) == 2);      // lanes holding an inclusive prefix
+                const int first = (int)__builtin_ctzll(pref ? pref : 1ull << 63);
+                int val = (pref == 0 || lane <= first) ? (int)(unsigned)w : 0;    // aggregates up to and incl. the prefix
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
+                excl += val;
+                if (pref) break;
+                hi -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(status + tile, (2ull << 62) | (unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) sOff = excl;
+    }
+    __syncthreads();
+    int run = ex + sOff;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (total && tile == (int)gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total = run;
+}
+
+size_t scan_status_bytes(int n) {
+    const long long tiles = ((long long)n + SCAN_TILE - 1) / SCAN_TILE;
+    return (tiles > 1 && tiles <= SCAN_CHAIN_TILES) ? align_up((size_t)tiles * sizeof(unsigned long long)) : 0;
+}
+
 size_t scan_workspace_bytes(int n) {
-    size_t bytes = 0;
+    size_t bytes = scan_status_bytes(n);
     long long m = n;
     while (m > SCAN_TILE) {
         m = (m + SCAN_TILE - 1) / SCAN_TILE;
@@ -89,7 +157,7 @@ size_t scan_workspace_bytes(int n) {
     return bytes + 256;
 }
 
-int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t s) {
+int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t s, bool status_zeroed) {
     if (n <= 0) {
         if (total) MCCNN_HIP(hipMemsetAsync(total, 0, sizeof(int), s));
         return 0;
@@ -97,6 +165,13 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
     int tiles = ceil_div(n, SCAN_TILE);
     if (tiles == 1) {
         scan_tiles<<<1, SCAN_THREADS, 0, s>>>(in, out, n, nullptr, total, 0);
+        MCCNN_LAUNCHED();
+        return 0;
+    }
+    const size_t sb = scan_status_bytes(n);
+    if (sb) {  // single pass; the status words sit at the start of the workspace
+        if (!status_zeroed) MCCNN_HIP(hipMemsetAsync(ws, 0, sb, s));
+        scan_chained<<<tiles, SCAN_THREADS, 0, s>>>(in, out, n, (unsigned long long*)ws, total);
         MCCNN_LAUNCHED();
         return 0;
     }
