@@ -133,13 +133,17 @@ class Workload:
         if self.world > 1:
             if self.bucket is None:  # the variables exist after the first create_convolution
                 self.bucket = GradBucket(self.builder.parameters())
-            self.bucket.allreduce()
+            # enqueued on RCCL's stream; the next step's grid build, search and forward pass run under it (the reduced
+            # gradients are not read before the next pack, or the wait() that closes the timed region)
+            self.bucket.allreduce(async_op=True)
         return out
 
     def timed(self, steps, warmup):
         """K timed steps after W warm-up steps; barrier + synchronize on both sides; max over ranks."""
         for _ in range(max(warmup, 0)):
             self.step()
+        if self.bucket is not None:
+            self.bucket.wait()
         torch.cuda.synchronize()
         if self.world > 1:
             dist.barrier()
@@ -147,6 +151,8 @@ class Workload:
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
+        if self.bucket is not None:
+            self.bucket.wait()  # the last step's all-reduce finishes inside the timed region
         torch.cuda.synchronize()
         if self.world > 1:
             dist.barrier()

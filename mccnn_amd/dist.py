@@ -55,12 +55,27 @@ class GradBucket:
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.pending = None  # (work handle, divisor) of an asynchronous all-reduce that has not been waited for
 
-    def allreduce(self, group=None, average=False):
+    def wait(self):
+        """Completes an asynchronous allreduce(): the gradients may be read on the current stream afterwards."""
+        if self.pending is not None:
+            work, div = self.pending
+            self.pending = None
+            work.wait()  # GPU-side: the current stream waits for the collective's stream (host-side for gloo)
+            if div != 1:
+                self.flat.div_(div)
+
+    def allreduce(self, group=None, average=False, async_op=False):
         """Pack (ONE concatenation kernel), all-reduce, and hand the reduced values back as views of the flat buffer
-        (no copy-back kernels: at a sub-millisecond step a dozen 5 us copies would cost more than the collective)."""
+        (no copy-back kernels: at a sub-millisecond step a dozen 5 us copies would cost more than the collective).
+
+        async_op=True returns right after the collective is enqueued on its own stream: what the caller launches next
+        (the next step's grid build / neighbour search / forward pass) overlaps with it, and wait() -- or the next
+        allreduce() -- makes the current stream wait before the gradients are read or the buffer is packed again."""
         if not self.params:
             return
+        self.wait()  # the flat buffer is about to be overwritten
         p0 = self.params[0]
         if self.flat is None or self.flat.device != p0.device:
             self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
@@ -79,9 +94,13 @@ class GradBucket:
                     self.flat[off:off + n].copy_(p.grad.reshape(-1))
                 off += n
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            if average:
-                self.flat.div_(dist.get_world_size(group))
+            div = dist.get_world_size(group) if average else 1
+            if async_op:
+                self.pending = (dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=True), div)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                if div != 1:
+                    self.flat.div_(div)
         off = 0
         for p in self.params:
             n = p.numel()

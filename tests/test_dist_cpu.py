@@ -58,6 +58,22 @@ def _worker(rank, world, port, q):
         assert bucket.numel == 48 + 16 + 128 + 16 + 128 + 16  # 176 * nb
         bucket.allreduce()
         got = [p.grad.clone() for p in params]
+        # asynchronous form (what bench.py uses): a second step's gradients, averaged; values valid after wait()
+        for k, p in enumerate(params):
+            p.grad = torch.full(p.shape, float(rank + 1) * (k + 1) * 10.0)
+        bucket.allreduce(average=True, async_op=True)
+        assert bucket.pending is not None
+        bucket.wait()
+        assert bucket.pending is None
+        got += [p.grad.clone() for p in params]
+        # a third allreduce() without an explicit wait() first completes the pending one before it repacks
+        for k, p in enumerate(params):
+            p.grad = torch.full(p.shape, float(rank))
+        bucket.allreduce(async_op=True)
+        for k, p in enumerate(params):
+            p.grad = torch.full(p.shape, 1.0)
+        bucket.allreduce()
+        got += [p.grad.clone() for p in params]
         mn = torch.tensor([[0.0 + rank, -1.0, 2.0 - rank]])
         mx = torch.tensor([[5.0 + rank, 4.0, 9.0 - rank]])
         mn, mx = allreduce_aabb(mn, mx)
@@ -78,7 +94,12 @@ def test_two_rank_gloo_allreduce():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, grads, mn, mx in res:
-        for k, g in enumerate(grads):
+        assert len(grads) == 18
+        for k, g in enumerate(grads[:6]):
             expect = 0.0 if k == 3 else 3.0 * (k + 1)  # (1 + 2) * (k + 1); tensor 3 had no grad anywhere
             assert np.all(g == expect), (rank, k)
+        for k, g in enumerate(grads[6:12]):
+            assert np.all(g == 15.0 * (k + 1)), (rank, k)  # mean of 10 (k + 1) and 20 (k + 1)
+        for k, g in enumerate(grads[12:]):
+            assert np.all(g == 2.0), (rank, k)
         assert mn.tolist() == [[0.0, -1.0, 1.0]] and mx.tolist() == [[6.0, 4.0, 9.0]]
