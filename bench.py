@@ -219,6 +219,21 @@ class Workload:
                                                                     *[ptr(g) for g in gws],
                                                                     ptr(bwd_ws), bwd_ws.numel(), stream_handle()),
                                          "conv_bwd"))
+        # depth-wise layers with bf16 feature rows (extension, BASELINE cfg3): same launches, rows stored as bf16
+        bf16 = None
+        if not combin and fin % 8 == 0:
+            f16, og16 = sF.to(torch.bfloat16), self.OG.to(torch.bfloat16)
+            o16, fg16 = torch.empty_like(og16), torch.empty_like(f16)
+            t_f16, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_fwd_bf16(*conv_args[:1], ptr(f16), *conv_args[2:], n, m, e, fin,
+                                                                             B, r, 0, 1, ptr(o16), ptr(fwd_ws), fwd_ws.numel(),
+                                                                             stream_handle()), "conv_fwd_bf16"))
+            t_b16, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_bwd_bf16(*conv_args[:1], ptr(f16), *conv_args[2:], ptr(og16), n,
+                                                                             m, e, fin, B, r, 0, 1, ptr(start_t), ptr(perm_t),
+                                                                             ptr(fg16), *[ptr(g) for g in gws], ptr(bwd_ws),
+                                                                             bwd_ws.numel(), stream_handle()), "conv_bwd_bf16"))
+            bf16 = {"fwd_ms": round(t_f16, 4), "bwd_ms": round(t_b16, 4),
+                    "note": "features, outputs and their gradients stored as bf16 rows; MLP and accumulation f32"}
+            del f16, og16, o16, fg16
         t_s2g, _ = ev_time(lambda: M._gather_rows(fg, idx, n))
         C = int(np.prod(cells.shape[:4]))
         # algorithmic work per launch (stated in DESIGN.md section 6)
@@ -234,10 +249,18 @@ class Workload:
         if t_tr is not None:
             alg["transpose_neighbors"] = ("hbm", 8 * e + 4 * e + 4 * n, t_tr)
         breakdown = {}
+        if bf16 is not None:
+            breakdown["spatial_conv_bf16_rows"] = bf16
         for k, (bound, work, ms) in alg.items():
             ach = work / (ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
             breakdown[k] = {"ms": round(ms, 4), "bound": bound, "achieved": round(ach, 3),
                             "unit": "GB/s" if bound == "hbm" else "TFLOP/s"}
+            if bound == "hbm" and k.startswith("spatial_conv_"):
+                # wide depth-wise layers are priced by their gather bytes; the kernel-MLP rate of the same
+                # launch is printed beside it -- at sizes whose rows stay in the Infinity Cache it is the tighter bound
+                flops = (320.0 if k.endswith("fwd") else 912.0) * nb * e
+                breakdown[k]["mlp_tflops"] = round(flops / (ms * 1e-3) / 1e12, 3)
+                breakdown[k]["mlp_frac_of_f32_peak"] = round(flops / (ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4)
         dom = max(alg, key=lambda k: alg[k][2])
         bound, work, ms = alg[dom]
         peak = HBM_PEAK_GBS if bound == "hbm" else F32_PEAK_TFLOPS
@@ -405,6 +428,8 @@ def main():
                 ent["roofline"] = rl
                 ent["conv_ms"] = {"fwd": bd["spatial_conv_fwd"]["ms"], "bwd": bd["spatial_conv_bwd"]["ms"]}
                 ent["conv_rate"] = {"fwd": bd["spatial_conv_fwd"], "bwd": bd["spatial_conv_bwd"]}
+                if "spatial_conv_bf16_rows" in bd:
+                    ent["bf16_rows"] = bd["spatial_conv_bf16_rows"]
             layers[name] = ent
             if w2 is not wl:
                 del w2

@@ -245,11 +245,18 @@ __global__ __launch_bounds__(256, MCCNN_F1_OCC) void f1_bwd_edges(ConvArgs a, co
             const int j = pr.x, ci = pr.y;
             const float inv = act ? rc.w : 0.f;
             const float4* gp = reinterpret_cast<const float4*>(G + (size_t)ci * rowA + q * 8);
+#ifdef MCCNN_ABL_NOGATHER  // timing ablation only (wrong results): the kernel with every gather already in registers
+            const float4 g0 = make_float4(rc.x, rc.y, rc.z, rc.w), g1 = make_float4(rc.y, rc.z, rc.x, rc.w);
+            const float f = rc.z;
+            float dfOld = 0.f, gbi = 0.f;
+            (void)gp;
+#else
             const float4 g0 = gp[0], g1 = gp[1];
             const float f = a.feats[j];
             float dfOld = 0.f, gbi = 0.f;
             if (act && q > 0) dfOld = dfE[t];
             if (last) gbi = gb[ci];
+#endif
             {
                 int tn = min(t + 64, a.e - 1);  // clamped: branch-free prefetch of the next chunk
                 prN = a.packed[tn];

@@ -57,6 +57,9 @@ CASES = [
     ("abs_radius_batched", 1500, 3, "uniform", True, 0.12, False, 3, 0.2),
     ("single_cell", 300, 4, "uniform", False, 1.2, True, 2, 1.3),
     ("tiny", 3, 2, "uniform", False, 0.5, True, 1, 0.5),
+    # 5 x 80^3 = 2.56 M cells = 1250 scan tiles: past the single-pass (decoupled look-back) limit of 1024 tiles, the
+    # cell-offset prefix sum takes the three-level form
+    ("fine_grid_3level_scan", 1500, 5, "uniform", True, 0.0125, True, 1, 0.0125),
 ]
 
 
