@@ -116,8 +116,10 @@ int mccnn_transform_indexs(const int* in_idx, int s, const int* new_idx, int n, 
 
 /* FindNeighbors -- find_neighbors.cc:25,80-185, find_neighbors.cu:40-372.
  * count: start_idx[i] = exclusive prefix of the per-centre neighbour counts and
- * *total_dev (device int) = E.  The caller reads E, allocates packed[E,2] and
- * calls fill with the same arguments.  Row order: centre ascending; inside a
+ * *total_dev = E.  total_dev is any DEVICE-ACCESSIBLE int: device memory, or a pinned host
+ * word (hipHostMalloc) -- then no device-to-host copy is needed and a host that polls the
+ * word sees E as soon as the count retires (the Python layer does this).  The caller reads
+ * E, allocates packed[E,2] and calls fill with the same arguments.  Row order: centre ascending; inside a
  * centre the 27-cell table order of find_neighbors.cu:282-291, then ascending j.
  * centre_order (optional, may be NULL): a permutation of 0..m-1 giving the order in
  * which threads visit the centres. It never changes the result; a spatially coherent

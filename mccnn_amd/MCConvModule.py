@@ -10,6 +10,7 @@ Shape / attribute validation mirrors the OP_REQUIRES blocks of the reference wra
 raises InvalidArgumentError (the analogue of tf.errors.InvalidArgumentError).
 """
 import ctypes as C
+import os
 import threading
 import weakref
 
@@ -137,6 +138,34 @@ def _pinned_int():
     if buf is None:
         buf = _TLS.pinned = torch.empty(1, dtype=torch.int32).pin_memory()
     return buf
+
+
+def _host_mailbox():
+    """(pinned int32 tensor, NumPy view of it) per host thread. Pinned host memory is device-accessible, so a kernel
+    can store a count STRAIGHT into it: no device-to-host copy is enqueued and the host sees the value as soon as the
+    producing kernel retires -- it polls the word instead of sleeping on an event (a blocking wait wakes up ~10 us
+    late, which at a sub-millisecond step is idle GPU time)."""
+    box = getattr(_TLS, "mailbox", None)
+    if box is None:
+        t = torch.empty(1, dtype=torch.int32).pin_memory()
+        box = _TLS.mailbox = (t, t.numpy())
+    return box
+
+
+# find_neighbors: True = the count kernel stores the edge total into the pinned mailbox and the host polls it;
+# False = total in device memory + an asynchronous copy + an event wait
+COUNT_MAILBOX = os.environ.get("MCCNN_COUNT_MAILBOX", "1") != "0"
+_MAILBOX_SPINS = 2000000  # ~0.1 s of polling, then a plain stream synchronisation
+
+
+def _await_mailbox(view):
+    """Value a kernel of the current stream wrote to the mailbox (armed with -1 by the caller before the launch)."""
+    for _ in range(_MAILBOX_SPINS):
+        v = int(view[0])
+        if v >= 0:
+            return v
+    torch.cuda.current_stream().synchronize()
+    return int(view[0])
 
 
 _NUM_CELLS_CACHE = {}
@@ -402,7 +431,7 @@ def find_neighbors(inPts, inBatchIds, inPts2, cellIndexs, aabbMin, aabbMax, radi
     lib = _lib.load()
     m, nc = c.shape[0], cells.shape[1]
     start = torch.empty((m, 1), dtype=torch.int32, device=c.device)
-    total = torch.empty(1, dtype=torch.int32, device=c.device)
+    box, boxv = _host_mailbox()
     n2 = p2.shape[0]
     ws = _ws(lib.mccnn_find_neighbors_workspace_bytes(m, n2), c.device)
     order = _order_hint(inPts)
@@ -410,28 +439,43 @@ def find_neighbors(inPts, inBatchIds, inPts2, cellIndexs, aabbMin, aabbMax, radi
         order = None
     args = (ptr(c), ptr(cb), m, ptr(p2), n2, ptr(cells), ptr(mn), ptr(mx), batchSize, nc, float(radius),
             int(bool(scaleInv)), ptr(order))
-    check(lib.mccnn_find_neighbors_count(*args, ptr(start), ptr(total), ptr(ws), ws.numel(), stream_handle()),
+    # The size of the second output is only known on the device: the prefix sum stores the total straight into a
+    # pinned host word (no copy is enqueued) and the host polls it.
+    total = None
+    if COUNT_MAILBOX:
+        boxv[0] = -1
+        total_ptr = box.data_ptr()
+    else:  # the total lands in device memory and is copied to the host (stream-ordered BEFORE the fill)
+        total = torch.empty(1, dtype=torch.int32, device=c.device)
+        total_ptr = ptr(total)
+    check(lib.mccnn_find_neighbors_count(*args, ptr(start), total_ptr, ptr(ws), ws.numel(), stream_handle()),
           "find_neighbors(count)")
-    # The size of the second output is only known on the device. Searches repeat with the same shapes step after
-    # step, so the fill is launched into a buffer sized from the last total of this shape BEFORE the total is read
-    # back: the host round trip (~30 us of idle GPU) hides behind the kernel. Too small a guess -> exact rerun.
+    ev = None
+    if total is not None:
+        box.copy_(total, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+
+    def read_total():
+        if ev is None:
+            return _await_mailbox(boxv)
+        ev.synchronize()
+        return int(boxv[0])
+    # Searches repeat with the same shapes step after step, so the fill is launched into a buffer sized from the last
+    # total of this shape BEFORE the total is read: the host round trip hides behind the kernel. Too small a guess ->
+    # exact rerun.
     gkey = (c.device.index, m, n2, float(radius), int(batchSize), bool(scaleInv))
     guess = _EDGE_GUESS.get(gkey, 0)
     packed = None
     if guess > 0:
-        host = _pinned_int()
-        host.copy_(total, non_blocking=True)  # stream-ordered BEFORE the fill: ready while the fill still runs
-        ev = torch.cuda.Event()
-        ev.record()
         buf = torch.empty((guess, 2), dtype=torch.int32, device=c.device)
         check(lib.mccnn_find_neighbors_fill(*args, ptr(start), guess, ptr(buf), ptr(ws), ws.numel(), stream_handle()),
               "find_neighbors(fill)")
-        ev.synchronize()
-        e = int(host[0])
+        e = read_total()
         if e <= guess:
             packed = buf[:e]
     else:
-        e = int(total.item())
+        e = read_total()
     if packed is None:
         packed = torch.empty((e, 2), dtype=torch.int32, device=c.device)
         check(lib.mccnn_find_neighbors_fill(*args, ptr(start), e, ptr(packed), ptr(ws), ws.numel(), stream_handle()),
