@@ -334,75 +334,90 @@ __global__ __launch_bounds__(256, MCCNN_F1_OCC) void f1_bwd_edges(ConvArgs a, co
 // layer-3 gradients dW3 = sum_i g_i (x) A_i, db3 = sum_i g_i S_i. Waves own slices of centres, q-outer with the 72 sums
 // of a block in registers; partial row per (wave, block): w3[64] b3[8].
 #define MCCNN_F1_ROWC 72
+// One wave per (slice of centres, block): nb times more waves than a q-outer sweep per slice. The pass is a chain of
+// dependent latencies per wave (load -> 137 FMAs -> stores, then two 6-step butterflies), not arithmetic, so its time
+// is the length of that chain: with the blocks spread over waves it is 1 / nb of it (41 -> 12 us on the 100k room).
+// The bias term of the feature gradient, gb_i = g_i . b3 over the whole row, has waves of its own (pseudo-block
+// q == nb: one ascending fma chain per centre, no sums to reduce), so the blocks stay independent.
 __global__ __launch_bounds__(256) void f1_bwd_centres(ConvArgs a, const float* __restrict__ outGrad,
                                                       const float* __restrict__ A, const float* __restrict__ S,
-                                                      int cPerWave, float* __restrict__ G, float* __restrict__ gb,
-                                                      float* __restrict__ partials) {
-    extern __shared__ float lds[];  // per block: W3[8][8], b3[8]
-    for (int t = threadIdx.x; t < a.nb * 72; t += blockDim.x) {
-        int q = t / 72, r = t - q * 72;
-        lds[t] = (r < 64) ? a.w3[q * 64 + r] : a.b3[q * 8 + r - 64];
-    }
-    __syncthreads();
+                                                      int cPerWave, int numSlices, float* __restrict__ G,
+                                                      float* __restrict__ gb, float* __restrict__ partials) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int w = blockIdx.x * 4 + wave;
+    const int wid = blockIdx.x * 4 + wave;  // block-major inside a slice: neighbouring waves read the same rows
+    const int w = wid / (a.nb + 1), q = wid - w * (a.nb + 1);
+    if (w >= numSlices) return;
     const int c0 = w * cPerWave;
-    if (c0 >= a.m) return;
     const int c1 = min(a.m, c0 + cPerWave);
-    const int rowA = a.nb * 8;
-    const bool vec = (a.outF & 3) == 0;
-    float* prow = partials + (size_t)w * a.nb * MCCNN_F1_ROWC;
-    for (int q = 0; q < a.nb; ++q) {
-        float acc[64], accb[8];
-#pragma unroll
-        for (int k = 0; k < 64; ++k) acc[k] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) accb[k] = 0.f;
-        const float* wq = lds + q * 72;
+    if (q == a.nb) {
         for (int i = c0 + lane; i < c1; i += 64) {
-            const float* grow = outGrad + (size_t)i * a.outF + q * 8;
-            float g[8];
-            if (vec && q * 8 + 8 <= a.outF) {
-                const float4 g0 = reinterpret_cast<const float4*>(grow)[0], g1 = reinterpret_cast<const float4*>(grow)[1];
-                g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
-            } else {
-#pragma unroll
-                for (int n = 0; n < 8; ++n) g[n] = (q * 8 + n < a.outF) ? grow[n] : 0.f;
-            }
-            const float4* ap = reinterpret_cast<const float4*>(A + (size_t)i * rowA + q * 8);
-            const float4 x0 = ap[0], x1 = ap[1];
-            const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-            const float Si = S[i];
-            float gbv = (q == 0) ? 0.f : gb[i];
-            float Gk[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) Gk[k] = 0.f;
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    acc[n * 8 + k] = fmaf(g[n], x[k], acc[n * 8 + k]);
-                    Gk[k] = fmaf(wq[n * 8 + k], g[n], Gk[k]);
+            const float* row = outGrad + (size_t)i * a.outF;
+            float gbv = 0.f;
+            int f = 0;
+            if ((a.outF & 3) == 0) {
+                for (; f + 4 <= a.outF; f += 4) {
+                    const float4 gg = *reinterpret_cast<const float4*>(row + f);
+                    gbv = fmaf(gg.x, a.b3[f], gbv);
+                    gbv = fmaf(gg.y, a.b3[f + 1], gbv);
+                    gbv = fmaf(gg.z, a.b3[f + 2], gbv);
+                    gbv = fmaf(gg.w, a.b3[f + 3], gbv);
                 }
-                accb[n] = fmaf(g[n], Si, accb[n]);
-                gbv = fmaf(g[n], wq[64 + n], gbv);
             }
+            for (; f < a.outF; ++f) gbv = fmaf(row[f], a.b3[f], gbv);
             gb[i] = gbv;
-            float4* dst = reinterpret_cast<float4*>(G + (size_t)i * rowA + q * 8);
-            dst[0] = make_float4(Gk[0], Gk[1], Gk[2], Gk[3]);
-            dst[1] = make_float4(Gk[4], Gk[5], Gk[6], Gk[7]);
         }
-        float r3 = wave_reduce64(acc, lane);
-        float misc[64];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) misc[k] = accb[k];
-#pragma unroll
-        for (int k = 8; k < 64; ++k) misc[k] = 0.f;
-        float rb = wave_reduce64(misc, lane);
-        float* pq = prow + q * MCCNN_F1_ROWC;
-        pq[lane] = r3;
-        if (lane < 8) pq[64 + lane] = rb;
+        return;
     }
+    const int rowA = a.nb * 8;
+    const bool vec = (a.outF & 3) == 0 && q * 8 + 8 <= a.outF;
+    float wq[64];  // W3[8][8] of this block: wave-uniform -> scalar registers
+#pragma unroll
+    for (int r = 0; r < 64; ++r) wq[r] = a.w3[q * 64 + r];
+    float acc[64], accb[8];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) accb[k] = 0.f;
+    for (int i = c0 + lane; i < c1; i += 64) {
+        const float* grow = outGrad + (size_t)i * a.outF + q * 8;
+        float g[8];
+        if (vec) {
+            const float4 g0 = reinterpret_cast<const float4*>(grow)[0], g1 = reinterpret_cast<const float4*>(grow)[1];
+            g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+        } else {
+#pragma unroll
+            for (int n = 0; n < 8; ++n) g[n] = (q * 8 + n < a.outF) ? grow[n] : 0.f;
+        }
+        const float4* ap = reinterpret_cast<const float4*>(A + (size_t)i * rowA + q * 8);
+        const float4 x0 = ap[0], x1 = ap[1];
+        const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const float Si = S[i];
+        float Gk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Gk[k] = 0.f;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                acc[n * 8 + k] = fmaf(g[n], x[k], acc[n * 8 + k]);
+                Gk[k] = fmaf(wq[n * 8 + k], g[n], Gk[k]);
+            }
+            accb[n] = fmaf(g[n], Si, accb[n]);
+        }
+        float4* dst = reinterpret_cast<float4*>(G + (size_t)i * rowA + q * 8);
+        dst[0] = make_float4(Gk[0], Gk[1], Gk[2], Gk[3]);
+        dst[1] = make_float4(Gk[4], Gk[5], Gk[6], Gk[7]);
+    }
+    float r3 = wave_reduce64(acc, lane);
+    float misc[64];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) misc[k] = accb[k];
+#pragma unroll
+    for (int k = 8; k < 64; ++k) misc[k] = 0.f;
+    float rb = wave_reduce64(misc, lane);
+    float* pq = partials + ((size_t)w * a.nb + q) * MCCNN_F1_ROWC;
+    pq[lane] = r3;
+    if (lane < 8) pq[64 + lane] = rb;
 }
 
 // Sums the partial rows of both passes in a fixed order (deterministic parameter gradients, no float atomics).
@@ -545,8 +560,7 @@ int f1_backward(const ConvArgs& a, const float* out_grad, const float4* rec_in, 
         int rc = f1_run_edges(a, A, S, nullptr, s);
         if (rc) return rc;
     }
-    const size_t ldsC = (size_t)a.nb * 72 * sizeof(float);
-    f1_bwd_centres<<<blocksC, 256, ldsC, s>>>(a, out_grad, A, S, cPerWave, G, gb, pc);
+    f1_bwd_centres<<<ceil_div((long long)wavesC * (a.nb + 1), 4), 256, 0, s>>>(a, out_grad, A, S, cPerWave, wavesC, G, gb, pc);
     MCCNN_LAUNCHED();
     const float4* recUse = rec;
     if (rec_in) {
