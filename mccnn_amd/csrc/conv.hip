@@ -757,32 +757,33 @@ __global__ __launch_bounds__(256) void scatter_edge_featgrad(const int2* __restr
 }
 
 // Sums the per-wave partial rows in a fixed order and scatters them to the six gradient tensors.
-__global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ partials, int numWaves, int nb,
-                                                       float* __restrict__ dw1, float* __restrict__ db1,
-                                                       float* __restrict__ dw2, float* __restrict__ db2,
-                                                       float* __restrict__ dw3, float* __restrict__ db3) {
-    // 16 consecutive parameters x 16 row slices per workgroup; 4 independent accumulators keep loads in flight
-    __shared__ float acc[16][17];
+__global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ partials, int numWaves, int nb,
+                                                        float* __restrict__ dw1, float* __restrict__ db1,
+                                                        float* __restrict__ dw2, float* __restrict__ db2,
+                                                        float* __restrict__ dw3, float* __restrict__ db3) {
+    // 16 consecutive parameters x 64 row slices per workgroup, 4 independent accumulators per thread: the sum over
+    // ~2000 rows is a chain of dependent load latencies, 256 rows in flight per parameter make it 8 links long
+    __shared__ float acc[64][17];
     const int K = nb * 176;
     const int kk = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int k = blockIdx.x * 16 + kk;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (k < K) {
         int w = sl;
-        for (; w + 48 < numWaves; w += 64) {
+        for (; w + 192 < numWaves; w += 256) {
             s0 += partials[(size_t)w * K + k];
-            s1 += partials[(size_t)(w + 16) * K + k];
-            s2 += partials[(size_t)(w + 32) * K + k];
-            s3 += partials[(size_t)(w + 48) * K + k];
+            s1 += partials[(size_t)(w + 64) * K + k];
+            s2 += partials[(size_t)(w + 128) * K + k];
+            s3 += partials[(size_t)(w + 192) * K + k];
         }
-        for (; w < numWaves; w += 16) s0 += partials[(size_t)w * K + k];
+        for (; w < numWaves; w += 64) s0 += partials[(size_t)w * K + k];
     }
     acc[sl][kk] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sl == 0 && k < K) {
         float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v += acc[i][kk];
+        for (int i = 0; i < 64; ++i) v += acc[i][kk];
         int q = k / 176, r = k - q * 176;
         if (r < 24) dw1[q * 24 + r] = v;
         else if (r < 32) db1[q * 8 + r - 24] = v;
@@ -1257,7 +1258,7 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
                 else conv_bwd_mfma<false, 0, false><<<blocks, 256, ldsT, s>>>(t, rec, og, feat_grad, dfE, cpw, partials);
             }
             MCCNN_LAUNCHED();
-            reduce_partials<<<ceil_div((long long)nbT * 176, 16), 256, 0, s>>>(
+            reduce_partials<<<ceil_div((long long)nbT * 176, 16), 1024, 0, s>>>(
                 partials, rows, nbT, dw1 + (size_t)q0 * 24, db1 + (size_t)q0 * 8, dw2 + (size_t)q0 * 64, db2 + (size_t)q0 * 8,
                 dw3 + (size_t)q0 * 64, db3 + (size_t)q0 * 8);
             MCCNN_LAUNCHED();

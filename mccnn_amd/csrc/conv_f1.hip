@@ -421,11 +421,11 @@ __global__ __launch_bounds__(256) void f1_bwd_centres(ConvArgs a, const float* _
 }
 
 // Sums the partial rows of both passes in a fixed order (deterministic parameter gradients, no float atomics).
-__global__ __launch_bounds__(256) void f1_reduce(const float* __restrict__ pe, int rowsE, const float* __restrict__ pc,
+__global__ __launch_bounds__(1024) void f1_reduce(const float* __restrict__ pe, int rowsE, const float* __restrict__ pc,
                                                  int rowsC, int nb, float* __restrict__ dw1, float* __restrict__ db1,
                                                  float* __restrict__ dw2, float* __restrict__ db2,
                                                  float* __restrict__ dw3, float* __restrict__ db3) {
-    __shared__ float acc[16][17];
+    __shared__ float acc[64][17];  // 16 parameters x 64 row slices per workgroup (see reduce_partials, conv.hip)
     const int K = nb * 176;
     const int kk = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int k = blockIdx.x * 16 + kk;
@@ -439,20 +439,20 @@ __global__ __launch_bounds__(256) void f1_reduce(const float* __restrict__ pe, i
         const size_t stride = (size_t)nb * (fromE ? MCCNN_F1_ROW : MCCNN_F1_ROWC);
         const int rows = fromE ? rowsE : rowsC;
         int w = sl;
-        for (; w + 48 < rows; w += 64) {
+        for (; w + 192 < rows; w += 256) {
             s0 += src[(size_t)w * stride];
-            s1 += src[(size_t)(w + 16) * stride];
-            s2 += src[(size_t)(w + 32) * stride];
-            s3 += src[(size_t)(w + 48) * stride];
+            s1 += src[(size_t)(w + 64) * stride];
+            s2 += src[(size_t)(w + 128) * stride];
+            s3 += src[(size_t)(w + 192) * stride];
         }
-        for (; w < rows; w += 16) s0 += src[(size_t)w * stride];
+        for (; w < rows; w += 64) s0 += src[(size_t)w * stride];
     }
     acc[sl][kk] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sl == 0 && k < K) {
         float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v += acc[i][kk];
+        for (int i = 0; i < 64; ++i) v += acc[i][kk];
         if (r < 24) dw1[q * 24 + r] = v;
         else if (r < 32) db1[q * 8 + r - 24] = v;
         else if (r < 96) dw2[q * 64 + r - 32] = v;
@@ -572,7 +572,7 @@ int f1_backward(const ConvArgs& a, const float* out_grad, const float4* rec_in, 
     const size_t ldsE = (size_t)a.nb * MCCNN_WQ_BWD * sizeof(float);
     f1_bwd_edges<<<blocksE, 256, ldsE, s>>>(a, recUse, G, gb, feat_grad, dfE, cpw, pe);
     MCCNN_LAUNCHED();
-    f1_reduce<<<ceil_div((long long)a.nb * 176, 16), 256, 0, s>>>(pe, wavesE, pc, wavesC, a.nb, dw1, db1, dw2, db2, dw3, db3);
+    f1_reduce<<<ceil_div((long long)a.nb * 176, 16), 1024, 0, s>>>(pe, wavesE, pc, wavesC, a.nb, dw1, db1, dw2, db2, dw3, db3);
     MCCNN_LAUNCHED();
     return 0;
 }
