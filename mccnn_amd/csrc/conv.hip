@@ -1202,7 +1202,9 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
     // depth-wise MFMA path writes every feat_grad row itself (conv_stream over the transposed list); everything else
     // accumulates into it
     bool dfeatT = mfma && !combin;
-    if (n > 0 && !dfeatT) MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * (bf16 ? 2 : sizeof(float)), s));
+    // (the factored Fin = 1 path clears feat_grad in its centre pass, which runs before the edges add to it)
+    const bool f1Clears = mfma && m > 0 && e > 0 && f1_shape(num_in_feats, num_out_feats, combin);
+    if (n > 0 && !dfeatT && !f1Clears) MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * (bf16 ? 2 : sizeof(float)), s));
     if (!mfma || m == 0 || e == 0) {
         MCCNN_HIP(hipMemsetAsync(dw1, 0, 3 * nn * sizeof(float), s));
         MCCNN_HIP(hipMemsetAsync(db1, 0, nn * sizeof(float), s));

@@ -342,7 +342,11 @@ __global__ __launch_bounds__(256, MCCNN_F1_OCC) void f1_bwd_edges(ConvArgs a, co
 __global__ __launch_bounds__(256) void f1_bwd_centres(ConvArgs a, const float* __restrict__ outGrad,
                                                       const float* __restrict__ A, const float* __restrict__ S,
                                                       int cPerWave, int numSlices, float* __restrict__ G,
-                                                      float* __restrict__ gb, float* __restrict__ partials) {
+                                                      float* __restrict__ gb, float* __restrict__ partials,
+                                                      float* __restrict__ featGrad) {
+    // the edge pass ADDS to the feature gradient: cleared here (this pass runs first), no memset launch of its own
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x)
+        featGrad[i] = 0.f;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + wave;  // block-major inside a slice: neighbouring waves read the same rows
     const int w = wid / (a.nb + 1), q = wid - w * (a.nb + 1);
@@ -535,7 +539,7 @@ size_t f1_bwd_workspace_bytes(int m, int e, int nb) {
     return b + 256;
 }
 
-// feat_grad must be zero on entry (the edge pass adds to it); the six parameter gradients are fully written.
+// feat_grad and the six parameter gradients are fully written (feat_grad is cleared by the centre pass).
 int f1_backward(const ConvArgs& a, const float* out_grad, const float4* rec_in, const void* state, float* feat_grad, float* dw1, float* db1,
                 float* dw2, float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!ws || ws_bytes < f1_bwd_workspace_bytes(a.m, a.e, a.nb)) return MCCNN_E_WORKSPACE;
@@ -560,7 +564,7 @@ int f1_backward(const ConvArgs& a, const float* out_grad, const float4* rec_in, 
         int rc = f1_run_edges(a, A, S, nullptr, s);
         if (rc) return rc;
     }
-    f1_bwd_centres<<<ceil_div((long long)wavesC * (a.nb + 1), 4), 256, 0, s>>>(a, out_grad, A, S, cPerWave, wavesC, G, gb, pc);
+    f1_bwd_centres<<<ceil_div((long long)wavesC * (a.nb + 1), 4), 256, 0, s>>>(a, out_grad, A, S, cPerWave, wavesC, G, gb, pc, feat_grad);
     MCCNN_LAUNCHED();
     const float4* recUse = rec;
     if (rec_in) {
