@@ -205,7 +205,6 @@ __global__ __launch_bounds__(256, MCCNN_F1_OCC) void f1_bwd_edges(ConvArgs a, co
                                                        float* __restrict__ partials) {
     extern __shared__ float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
-    const int rowA = a.nb * 8;
     float* wl = lds;
     stage_weights<MCCNN_WQ_BWD>(a, wl);
     __syncthreads();
@@ -244,7 +243,8 @@ __global__ __launch_bounds__(256, MCCNN_F1_OCC) void f1_bwd_edges(ConvArgs a, co
             const float4 rc = rcN;
             const int j = pr.x, ci = pr.y;
             const float inv = act ? rc.w : 0.f;
-            const float4* gp = reinterpret_cast<const float4*>(G + (size_t)ci * rowA + q * 8);
+            // G is block-major, [q][centre][8]: inside a sweep the 32-byte pieces of consecutive centres are adjacent
+            const float4* gp = reinterpret_cast<const float4*>(G + ((size_t)q * a.m + ci) * 8);
 #ifdef MCCNN_ABL_NOGATHER  // timing ablation only (wrong results): the kernel with every gather already in registers
             const float4 g0 = make_float4(rc.x, rc.y, rc.z, rc.w), g1 = make_float4(rc.y, rc.z, rc.x, rc.w);
             const float f = rc.z;
@@ -349,11 +349,16 @@ __global__ __launch_bounds__(256) void f1_bwd_centres(ConvArgs a, const float* _
         featGrad[i] = 0.f;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + wave;  // block-major inside a slice: neighbouring waves read the same rows
-    const int w = wid / (a.nb + 1), q = wid - w * (a.nb + 1);
+    // wave-uniform by construction; readfirstlane tells the compiler, so the block's weights below are scalar loads
+    const int w = __builtin_amdgcn_readfirstlane(wid / (a.nb + 1));
+    const int q = __builtin_amdgcn_readfirstlane(wid - w * (a.nb + 1));
     if (w >= numSlices) return;
     const int c0 = w * cPerWave;
     const int c1 = min(a.m, c0 + cPerWave);
     if (q == a.nb) {
+#ifdef MCCNN_ABL_NODOT  // timing ablation only (wrong results)
+        return;
+#endif
         for (int i = c0 + lane; i < c1; i += 64) {
             const float* row = outGrad + (size_t)i * a.outF;
             float gbv = 0.f;
@@ -408,10 +413,14 @@ __global__ __launch_bounds__(256) void f1_bwd_centres(ConvArgs a, const float* _
             }
             accb[n] = fmaf(g[n], Si, accb[n]);
         }
-        float4* dst = reinterpret_cast<float4*>(G + (size_t)i * rowA + q * 8);
+        float4* dst = reinterpret_cast<float4*>(G + ((size_t)q * a.m + i) * 8);  // block-major: 2 KB contiguous per wave
         dst[0] = make_float4(Gk[0], Gk[1], Gk[2], Gk[3]);
         dst[1] = make_float4(Gk[4], Gk[5], Gk[6], Gk[7]);
     }
+#ifdef MCCNN_ABL_NOBFLY  // timing ablation only (wrong results)
+    float r3 = acc[lane & 7] + acc[8 + (lane & 7)], rb = accb[lane & 7];
+    for (int k = 16; k < 64; ++k) r3 += acc[k];
+#else
     float r3 = wave_reduce64(acc, lane);
     float misc[64];
 #pragma unroll
@@ -419,6 +428,7 @@ __global__ __launch_bounds__(256) void f1_bwd_centres(ConvArgs a, const float* _
 #pragma unroll
     for (int k = 8; k < 64; ++k) misc[k] = 0.f;
     float rb = wave_reduce64(misc, lane);
+#endif
     float* pq = partials + ((size_t)w * a.nb + q) * MCCNN_F1_ROWC;
     pq[lane] = r3;
     if (lane < 8) pq[64 + lane] = rb;
