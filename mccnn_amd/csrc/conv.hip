@@ -542,11 +542,17 @@ __global__ __launch_bounds__(256, (COMBIN && FEAT != 1) ? MCCNN_BWD_OCC_COMBIN :
             } else if (COMBIN && smallFin) {
                 // 2..4 input features: the feature row and the <= 5 out-gradients this block touches are loaded once,
                 // the neuron -> (fin, fo) pattern is one of <= 4 static register selections (combin_select)
-                float fs[4], gw[5];
+                // Unconditional loads (clamped column, static counts): nothing selects on a loaded value here, so the
+                // first use of the gathers is after the forward MLP and their latency flies under its MFMA chains.
+                // Lanes past the slice end carry inv = 0, which zeroes every term they feed; padded neurons
+                // (n >= numOuts) are zeroed below by block-uniform selects.
+                constexpr int NG = (R0_ + 8 + FIN_ - 1) / FIN_;  // output features the block's 8 neurons span
+                float fs[4] = {0.f, 0.f, 0.f, 0.f}, gw[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+                const float* frow = a.feats + (size_t)j * FIN_;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) fs[k] = (k < a.Fin) ? a.feats[(size_t)j * a.Fin + k] : 0.f;
+                for (int k = 0; k < FIN_; ++k) fs[k] = frow[k];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) gw[k] = (act && fo0 + k < outF) ? grow[fo0 + k] : 0.f;
+                for (int k = 0; k < NG; ++k) gw[k] = grow[min(fo0 + k, outF - 1)];
                 combin_pick<FIN_, R0_>(fs, gw, ff, g);
 #pragma unroll
                 for (int n = 0; n < 8; ++n)
