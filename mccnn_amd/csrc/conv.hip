@@ -448,6 +448,10 @@ __global__ __launch_bounds__(256) void edge_records(ConvArgs a, float4* __restri
 #ifndef MCCNN_BWD_OCC
 #define MCCNN_BWD_OCC 2
 #endif
+// combin layers with 2..4 input features and at most this many blocks keep one plane of per-edge feature-gradient sums
+// per block (E * Fin floats each) instead of a read-modify-write of one plane
+#define MCCNN_DF_PLANES 4
+static inline int df_planes(int Fin, int nb) { return (Fin >= 2 && Fin <= 4 && nb <= MCCNN_DF_PLANES) ? nb : 1; }
 // Waves own equal, contiguous EDGE ranges (cpw chunks of 64 edges each): nothing in the backward pass needs
 // centre alignment, and equal edge counts remove the tail that centre-aligned ranges show on non-uniform clouds.
 #ifndef MCCNN_BWD_OCC_COMBIN
@@ -607,12 +611,20 @@ __global__ __launch_bounds__(256, (COMBIN && FEAT != 1) ? MCCNN_BWD_OCC_COMBIN :
                     float sf[4] = {0.f, 0.f, 0.f, 0.f};
                     combin_fold_t<FIN_, R0_>(g, o, sf);  // sf[fin] = sum over the block's neurons with that fin of g o
                     if (act) {
+                        if (a.nb <= MCCNN_DF_PLANES) {
+                            // few blocks: every block has its own plane of per-edge sums -- stores only, nothing to
+                            // read back inside the sweep; scatter_edge_featgrad adds the planes
+                            float* d = dfE + ((size_t)q * a.e + t) * FIN_;
 #pragma unroll
-                        for (int f = 0; f < 4; ++f) {
-                            if (f < a.Fin) {
-                                float* d = dfE + (size_t)t * a.Fin + f;
-                                const float old = (q == 0) ? 0.f : *d;  // Fin <= 4: every fin is first touched by block 0
-                                *d = old + sf[f] * inv;
+                            for (int f = 0; f < FIN_; ++f) d[f] = sf[f] * inv;
+                        } else {
+#pragma unroll
+                            for (int f = 0; f < 4; ++f) {
+                                if (f < a.Fin) {
+                                    float* d = dfE + (size_t)t * a.Fin + f;
+                                    const float old = (q == 0) ? 0.f : *d;  // Fin <= 4: every fin is first touched by block 0
+                                    *d = old + sf[f] * inv;
+                                }
                             }
                         }
                     }
@@ -753,13 +765,17 @@ __global__ __launch_bounds__(256) void tr_rank(const int2* __restrict__ packed, 
 }
 
 // combin layers: featGrad[j, f] += dfE[e, f] (one atomic per edge and input feature)
+// (`planes` > 1: the per-edge sums of the blocks lie in separate planes of `total` floats each, added here)
 __global__ __launch_bounds__(256) void scatter_edge_featgrad(const int2* __restrict__ packed, const float* __restrict__ dfE,
-                                                             long long total, int Fin, float* __restrict__ featGrad) {
+                                                             long long total, int Fin, int planes,
+                                                             float* __restrict__ featGrad) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     long long e = t / Fin;
     int f = (int)(t - e * Fin);
-    atomicAdd(&featGrad[(size_t)packed[e].x * Fin + f], dfE[t]);
+    float v = dfE[t];
+    for (int p = 1; p < planes; ++p) v += dfE[(size_t)p * total + t];
+    atomicAdd(&featGrad[(size_t)packed[e].x * Fin + f], v);
 }
 
 // Sums the per-wave partial rows in a fixed order and scatters them to the six gradient tensors.
@@ -1177,7 +1193,7 @@ size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_fe
     bwd_partition(e, cpw, waves);
     size_t bytes = align_up((size_t)(((long long)waves + 3) / 4 * 4 * nb * 176) * sizeof(float));  // partial rows
     bytes += align_up((size_t)e * sizeof(float4));                                                // edge records
-    if (combin) bytes += align_up((size_t)e * num_in_feats * sizeof(float));                      // per-edge dFeat
+    if (combin) bytes += align_up((size_t)e * num_in_feats * df_planes(num_in_feats, (int)nb) * sizeof(float));  // per-edge dFeat
     else bytes += align_up((size_t)(n + 1) * 4) + align_up((size_t)e * 4) +                       // start_t, perm_t
                   mccnn_transpose_neighbors_workspace_bytes(n, e);
     return bytes + 256;
@@ -1234,7 +1250,7 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
         Arena ar(ws, ws_bytes);
         float* partials = ar.take<float>((size_t)blocks * 4 * a.nb * 176);
         float4* rec = ar.take<float4>((size_t)e);
-        float* dfE = combin ? ar.take<float>((size_t)e * a.Fin) : nullptr;
+        float* dfE = combin ? ar.take<float>((size_t)e * a.Fin * df_planes(a.Fin, a.nb)) : nullptr;
         if (!partials || !rec || (combin && !dfE)) return MCCNN_E_WORKSPACE;
         a.G = 0;
         if (recIn) {
@@ -1273,7 +1289,8 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
         }
         if (combin && a.Fin > 1) {  // Fin == 1: the main kernel adds each edge's finished sum itself
             long long total = (long long)e * a.Fin;
-            scatter_edge_featgrad<<<ceil_div(total, 256), 256, 0, s>>>(a.packed, dfE, total, a.Fin, feat_grad);
+            scatter_edge_featgrad<<<ceil_div(total, 256), 256, 0, s>>>(a.packed, dfE, total, a.Fin, df_planes(a.Fin, a.nb),
+                                                                       feat_grad);
             MCCNN_LAUNCHED();
         } else if (combin) {
         } else if (dfeatT) {
