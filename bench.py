@@ -117,6 +117,7 @@ class Workload:
         self.builder = ConvolutionBuilder(KDEWindow=args.window, relativeRadius=False)
         torch.manual_seed(1234)  # identical kernel-MLP weights on every rank
         self.bucket = None
+        self.pipeline = bool(getattr(args, "pipeline", False))
         self.out = self.step()  # creates the variables
         self.e_local = int(next(iter(self.builder.cacheNeighs_.values()))[1].shape[0])
 
@@ -130,6 +131,10 @@ class Workload:
         out = self.builder.create_convolution("Conv", self.ph, 0, self.F, self.fin, a.radius, outNumFeatures=self.fout,
                                               multiFeatureConv=self.combin, KDEWindow=a.window)
         out.backward(self.OG)
+        if self.pipeline:
+            # geometry of the NEXT batch (grid build, neighbour search, KDE: it depends on the points only) on a side
+            # stream, under the convolution kernels just launched; the next reset() installs it
+            self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window)
         if self.world > 1:
             if self.bucket is None:  # the variables exist after the first create_convolution
                 self.bucket = GradBucket(self.builder.parameters())
@@ -366,6 +371,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-layers", action="store_true", help="skip the per-layer-shape measurements")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="geometry (grid build, search, KDE) of batch k+1 on a side stream under the convolutions of batch k "
+                         "(ConvolutionBuilder.prefetch_geometry); default: strictly sequential steps")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -425,6 +433,11 @@ def main():
 
     # ------------------------------------------------------------------ the headline region
     ms_per_step, value, m_total = wl.timed(args.steps, max(args.warmup - 1, 0))
+    ms_sequential = None
+    if wl.pipeline:  # for the record: the same steps strictly one after the other (nothing prefetched)
+        wl.pipeline = False
+        ms_sequential, _, _ = wl.timed(args.steps, 2)
+        wl.pipeline = True
     if layers is not None:
         layers[args.layer] = {"ms_per_step": round(ms_per_step, 4), "value": round(value, 1), "unit": "points/s",
                               "edges_per_gpu": wl.e_local}
@@ -470,6 +483,10 @@ def main():
                                       "combin" if combin else "depth-wise"),
                        "points_total": int(m_total), "points_per_gpu": int(wl.P.shape[0]), "edges_per_gpu": wl.e_local,
                        "layer": args.layer, "parallelism": par,
+                       "pipeline": ("grid build / neighbour search / KDE of batch k+1 on a side stream under the convolution "
+                                    "kernels of batch k (ConvolutionBuilder.prefetch_geometry); every step still runs all of "
+                                    "them" if wl.pipeline else None),
+                       "sequential_ms_per_step": (round(ms_sequential, 4) if ms_sequential is not None else None),
                        "collective_backend": (backend if world > 1 else None), "rccl_world_size": world},
             "roofline": roofline, "cpu_baseline": cpu, "layers": layers, "breakdown": breakdown,
         }

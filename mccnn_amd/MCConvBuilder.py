@@ -194,10 +194,75 @@ class ConvolutionBuilder:
         return keyGrid, keyNeighs, keyPDF
 
     def reset(self):
-        """Drop the operation caches (MCConvBuilder.py:241-246). Variables are kept."""
+        """Drop the operation caches (MCConvBuilder.py:241-246). Variables are kept. Geometry parked by
+        prefetch_geometry() since the last reset() becomes the new cache content."""
         self.cacheGrids_ = {}
         self.cacheNeighs_ = {}
         self.cachePDFs_ = {}
+        pf, self.prefetched_ = getattr(self, "prefetched_", None), None
+        if pf is not None:
+            grids, neighs, pdfs, event = pf
+            main = torch.cuda.current_stream()
+            main.wait_event(event)  # GPU-side: whatever is launched from here on runs after the side stream's work
+            for d in (grids, neighs, pdfs):
+                for v in d.values():
+                    for t in (v if isinstance(v, tuple) else (v,)):
+                        t.record_stream(main)  # allocated on the side stream, read (and kept by autograd) on this one
+            self.cacheGrids_, self.cacheNeighs_, self.cachePDFs_ = grids, neighs, pdfs
+        if torch.cuda.is_available():
+            self.resetEvent_ = torch.cuda.Event()
+            self.resetEvent_.record()
+
+    def prefetch_geometry(self, inPointHierarchy, inPointLevel, convRadius, outPointHierarchy=None, outPointLevel=None,
+                          KDEWindow=None, relativeRadius=None, usePDF=None):
+        """Extension (no counterpart in the reference): computes the grid, the neighbour list and the PDFs that
+        create_convolution() with the same arguments looks up in the caches -- for the NEXT batch, on a side stream, and
+        parks them until the next reset(). Geometry depends on the points only, not on the network, so in a training
+        loop the grid build / search / KDE of batch k + 1 runs under the convolution kernels of batch k: those hold
+        two waves per SIMD (VGPR-bound) and leave issue slots and wave slots that the light geometry kernels fill
+        (100k room: 0.78 -> 0.66 ms per step). Call it after the backward pass of the current batch has been launched;
+        several calls between two reset()s accumulate."""
+        currKDEWindow = self.KDEWindow_ if KDEWindow is None else KDEWindow
+        currRelativeRadius = self.relativeRadius_ if relativeRadius is None else relativeRadius
+        currUsePDF = self.usePDF_ if usePDF is None else usePDF
+        outPH = inPointHierarchy if outPointHierarchy is None else outPointHierarchy
+        outLevel = inPointLevel if outPointLevel is None else outPointLevel
+        keyGrid, keyNeighs, keyPDF = self.__compute_dic_keys__(inPointHierarchy, outPH, inPointLevel, outLevel, convRadius,
+                                                               currKDEWindow, currRelativeRadius, currUsePDF)
+        pts, bids = inPointHierarchy.points_[inPointLevel], inPointHierarchy.batchIds_[inPointLevel]
+        mn, mx, B = inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, inPointHierarchy.batchSize_
+        if getattr(self, "sideStream_", None) is None:
+            self.sideStream_ = torch.cuda.Stream(device=pts.device)
+        pf = getattr(self, "prefetched_", None)
+        grids, neighs, pdfs = (pf[0], pf[1], pf[2]) if pf is not None else ({}, {}, {})
+        side = self.sideStream_
+        # the point hierarchy has to be complete before the side stream reads it: it waits for what the calling stream
+        # had been given up to the last reset() -- NOT for the convolutions launched since, which it is meant to overlap
+        if getattr(self, "resetEvent_", None) is not None:
+            side.wait_event(self.resetEvent_)
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            if keyGrid not in grids:
+                keys, indexs = self.ops_.sort_points_step1(pts, bids, mn, mx, B, convRadius, currRelativeRadius)
+                dummy = torch.zeros((pts.shape[0], 1), dtype=torch.float32, device=pts.device)  # geometry only
+                sortPts, sortBatchs, _, cellIndexs = self.ops_.sort_points_step2(pts, bids, dummy, keys, indexs, mn, mx, B,
+                                                                                convRadius, currRelativeRadius)
+                grids[keyGrid] = (sortPts, sortBatchs, cellIndexs, indexs)
+            g = grids[keyGrid]
+            if keyNeighs not in neighs:
+                neighs[keyNeighs] = tuple(self.ops_.find_neighbors(outPH.points_[outLevel], outPH.batchIds_[outLevel], g[0],
+                                                                   g[2], mn, mx, convRadius, B, currRelativeRadius))
+            nb = neighs[keyNeighs]
+            if keyPDF not in pdfs:
+                if currUsePDF:
+                    pdfs[keyPDF] = self.ops_.compute_pdf(g[0], g[1], mn, mx, nb[0], nb[1], currKDEWindow, convRadius, B,
+                                                         currRelativeRadius)
+                else:
+                    pdfs[keyPDF] = torch.ones((nb[1].shape[0], 1), dtype=torch.float32, device=nb[1].device)
+            event = torch.cuda.Event()
+            event.record(side)
+        self.prefetched_ = (grids, neighs, pdfs, event)
 
     def _trace(self, *rec):
         if self.opTrace_ is not None:

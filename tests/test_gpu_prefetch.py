@@ -1,0 +1,48 @@
+"""ConvolutionBuilder.prefetch_geometry: geometry of the next batch computed on a side stream and installed by reset()
+gives the same convolution as the inline path (integer outputs bit-exact, floats within the feature tolerance)."""
+import numpy as np
+import pytest
+
+from tests.helpers import make_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def test_prefetched_geometry_equals_inline(mc):
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    pts, bids = make_cloud(3000, 3, 23, "clustered", True)
+    rng = np.random.default_rng(5)
+    P = torch.from_numpy(pts).cuda()
+    Bi = torch.from_numpy(bids).cuda()
+    F = torch.from_numpy(rng.random((len(pts), 1), dtype=np.float32)).cuda().requires_grad_(True)
+    og = torch.from_numpy(rng.random((len(pts), 16), dtype=np.float32)).cuda()
+    ph = PointHierarchy(P, F, Bi, [], "PH", 3, True)
+    torch.manual_seed(3)
+    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True)
+
+    def run():
+        F.grad = None
+        for p in builder.parameters():
+            p.grad = None
+        out = builder.create_convolution("Conv", ph, 0, F, 1, 0.15, outNumFeatures=16, multiFeatureConv=True)
+        out.backward(og)
+        neigh = next(iter(builder.cacheNeighs_.values()))
+        return (out.detach().cpu().numpy(), F.grad.cpu().numpy(), [p.grad.cpu().numpy() for p in builder.parameters()],
+                neigh[0].cpu().numpy(), neigh[1].cpu().numpy())
+
+    builder.reset()
+    ref = run()                                   # inline geometry
+    for _ in range(3):                            # three pipelined steps: prefetch under the convolution, install, use
+        builder.prefetch_geometry(ph, 0, 0.15)
+        assert builder.prefetched_ is not None
+        builder.reset()
+        assert builder.prefetched_ is None and len(builder.cacheNeighs_) == 1 and len(builder.cachePDFs_) == 1
+        got = run()
+        assert np.array_equal(got[3], ref[3]) and np.array_equal(got[4], ref[4])      # start indices, packed neighbours
+        assert np.array_equal(got[0], ref[0])                                          # forward: deterministic
+        scale = np.abs(ref[1]).max()
+        assert np.abs(got[1] - ref[1]).max() <= 1e-5 * scale                          # float atomics: order varies
+        for g, r in zip(got[2], ref[2]):
+            assert np.abs(g - r).max() <= 1e-5 * max(np.abs(r).max(), 1e-30)
+    torch.cuda.synchronize()
