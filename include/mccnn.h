@@ -158,6 +158,15 @@ int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, cons
                       int m, const int* packed, int e, const float* aabb_min, const float* aabb_max,
                       int batch_size, float window, float radius, int scale_inv, int mode,
                       float* pdfs, void* ws, size_t ws_bytes, mccnn_stream_t stream);
+/* ComputePDF with the edge count read from DEVICE memory (single-precision KDE only): packed / pdfs hold
+ * e_capacity rows, *e_dev (<= e_capacity expected) of them are valid. Lets a caller that guessed the size of
+ * the neighbour list enqueue search and KDE back to back without waiting for the count
+ * (ConvolutionBuilder.prefetch_geometry); if *e_dev turns out larger than e_capacity the rows are cut and
+ * the caller repeats with the exact size. Workspace: mccnn_compute_pdf_workspace_bytes(e_capacity, 1). */
+int mccnn_compute_pdf_dn(const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx, int m,
+                         const int* packed, int e_capacity, const int* e_dev, const float* aabb_min,
+                         const float* aabb_max, int batch_size, float window, float radius, int scale_inv,
+                         float* pdfs, void* ws, size_t ws_bytes, mccnn_stream_t stream);
 
 /* PoissonSampling -- poisson_sampling.cc:26,109-211, poisson_sampling.cu:51-230.
  * count: runs the 27 colour phases, leaves the selection in ws and writes the

@@ -204,6 +204,11 @@ class ConvolutionBuilder:
             grids, neighs, pdfs, event = pf
             main = torch.cuda.current_stream()
             main.wait_event(event)  # GPU-side: whatever is launched from here on runs after the side stream's work
+            for kN, h in list(neighs.items()):
+                if hasattr(h, "finalize"):  # enqueued without a host wait: the edge total has arrived by now
+                    st, pk, pdf = h.finalize()
+                    neighs[kN] = (st, pk)
+                    pdfs[h.keyPDF] = pdf
             for d in (grids, neighs, pdfs):
                 for v in d.values():
                     for t in (v if isinstance(v, tuple) else (v,)):
@@ -250,6 +255,18 @@ class ConvolutionBuilder:
                                                                                 convRadius, currRelativeRadius)
                 grids[keyGrid] = (sortPts, sortBatchs, cellIndexs, indexs)
             g = grids[keyGrid]
+            deferred = None
+            if getattr(self.ops_, "_ops", 0) is None:  # the HIP op surface (not a checker handed in through `ops=`)
+                from . import MCConvModule as _hip_ops
+                deferred = _hip_ops.find_neighbors_pdf_deferred
+            if keyNeighs not in neighs and keyPDF not in pdfs and currUsePDF and deferred is not None:
+                # search + KDE without a host wait (list sizes from the last total of this shape; None on the first call)
+                h = deferred(outPH.points_[outLevel], outPH.batchIds_[outLevel], g[0], g[1], g[2], mn, mx, convRadius, B,
+                             currRelativeRadius, currKDEWindow)
+                if h is not None:
+                    h.keyPDF = keyPDF
+                    neighs[keyNeighs] = h
+                    pdfs[keyPDF] = h
             if keyNeighs not in neighs:
                 neighs[keyNeighs] = tuple(self.ops_.find_neighbors(outPH.points_[outLevel], outPH.batchIds_[outLevel], g[0],
                                                                    g[2], mn, mx, convRadius, B, currRelativeRadius))

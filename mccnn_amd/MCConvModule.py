@@ -164,7 +164,7 @@ def _await_mailbox(view):
         v = int(view[0])
         if v >= 0:
             return v
-    torch.cuda.current_stream().synchronize()
+    torch.cuda.synchronize()  # every stream of the device: the producer may not be the calling stream
     return int(view[0])
 
 
@@ -521,6 +521,103 @@ def compute_pdf(inPts, inBatchIds, aabbMin, aabbMax, startIndexs, neighbors, win
                                 float(window), float(radius), int(bool(scaleInv)), md, ptr(pdfs), ptr(ws), ws.numel(),
                                 stream_handle()), "compute_pdf")
     return pdfs
+
+
+class DeferredNeighborsPDF:
+    """find_neighbors + compute_pdf enqueued WITHOUT a host wait (extension for ConvolutionBuilder.prefetch_geometry):
+    the lists are sized from the last total of the same shape, the KDE kernels read the true total from device memory,
+    and the total travels to a pinned host word that finalize() reads later -- by then it has long arrived. If the
+    guess turns out too small, finalize() repeats both ops with the exact size."""
+
+    def __init__(self, args_fn, pdf_fn, start, packed, pdfs, total_dev, slot, guess, gkey):
+        self._args_fn, self._pdf_fn = args_fn, pdf_fn
+        self.start, self._packed, self._pdfs, self._total_dev = start, packed, pdfs, total_dev
+        self._slot, self._guess, self._gkey = slot, guess, gkey
+
+    def finalize(self):
+        """-> (startIndexs [M,1], packedNeighs [E,2], pdfs [E,1]); call on the stream that will consume them, after it
+        has been ordered behind the producing stream."""
+        e = _await_mailbox(self._slot[1])
+        _slot_pool().append(self._slot)
+        self._slot = None
+        if e <= self._guess:
+            packed, pdfs = self._packed[:e], self._pdfs[:e]
+        else:
+            packed = self._args_fn(e)
+            pdfs = self._pdf_fn(packed)
+        if len(_EDGE_GUESS) > 256:
+            _EDGE_GUESS.clear()
+        _EDGE_GUESS[self._gkey] = e + e // 16 + 64
+        return self.start, packed, pdfs
+
+
+def _slot_pool():
+    pool = getattr(_TLS, "slots", None)
+    if pool is None:
+        pool = _TLS.slots = []
+    return pool
+
+
+def find_neighbors_pdf_deferred(inPts, inBatchIds, sortedPts, sortedBatchIds, cellIndexs, aabbMin, aabbMax, radius,
+                                batchSize, scaleInv, window):
+    """See DeferredNeighborsPDF. Returns None when there is no size guess for this shape yet (first call) or the
+    reference-arithmetic KDE is selected: the caller then takes find_neighbors() + compute_pdf()."""
+    if int(PDF_MODE) != 1:
+        return None
+    op = "FindNeighborsOp"
+    _req(radius > 0.0 and window > 0.0 and batchSize > 0, op + " expects positive radius, window and batch size")
+    c, cb = _f32(inPts.detach(), "points"), _i32(inBatchIds, "batch_ids")
+    p2, b2 = _f32(sortedPts.detach(), "points2"), _i32(sortedBatchIds, "batch_ids2")
+    cells = _i32(cellIndexs, "cell_indexs")
+    mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
+    _check_points(c, "points", op)
+    _check_batch_ids(cb, c.shape[0], op)
+    _check_points(p2, "points2", op)
+    _check_batch_ids(b2, p2.shape[0], op)
+    _req(cells.dim() == 5 and cells.shape[0] == batchSize, op + " expects a five dimension tensor for the cell indices")
+    _check_aabb(mn, mx, batchSize, op)
+    m, n2, nc = c.shape[0], p2.shape[0], cells.shape[1]
+    gkey = (c.device.index, m, n2, float(radius), int(batchSize), bool(scaleInv))
+    guess = _EDGE_GUESS.get(gkey, 0)
+    if guess <= 0 or m == 0:
+        return None
+    lib = _lib.load()
+    start = torch.empty((m, 1), dtype=torch.int32, device=c.device)
+    total_dev = torch.empty(1, dtype=torch.int32, device=c.device)
+    ws = _ws(lib.mccnn_find_neighbors_workspace_bytes(m, n2), c.device)
+    order = _order_hint(inPts)
+    if order is not None and order.shape[0] != m:
+        order = None
+    args = (ptr(c), ptr(cb), m, ptr(p2), n2, ptr(cells), ptr(mn), ptr(mx), batchSize, nc, float(radius),
+            int(bool(scaleInv)), ptr(order))
+    check(lib.mccnn_find_neighbors_count(*args, ptr(start), ptr(total_dev), ptr(ws), ws.numel(), stream_handle()),
+          "find_neighbors(count)")
+    pool = _slot_pool()
+    if pool:
+        slot = pool.pop()
+    else:
+        t = torch.empty(1, dtype=torch.int32).pin_memory()
+        slot = (t, t.numpy())
+    slot[1][0] = -1
+    slot[0].copy_(total_dev, non_blocking=True)  # stream-ordered behind the count; nobody waits for it here
+    packed = torch.empty((guess, 2), dtype=torch.int32, device=c.device)
+    check(lib.mccnn_find_neighbors_fill(*args, ptr(start), guess, ptr(packed), ptr(ws), ws.numel(), stream_handle()),
+          "find_neighbors(fill)")
+    pdfs = torch.empty((guess, 1), dtype=torch.float32, device=c.device)
+    pws = _ws(lib.mccnn_compute_pdf_workspace_bytes(guess, 1), c.device)
+    check(lib.mccnn_compute_pdf_dn(ptr(p2), ptr(b2), ptr(start), m, ptr(packed), guess, ptr(total_dev), ptr(mn), ptr(mx),
+                                   batchSize, float(window), float(radius), int(bool(scaleInv)), ptr(pdfs), ptr(pws),
+                                   pws.numel(), stream_handle()), "compute_pdf(dn)")
+
+    def refill(e):  # the guess was too small: exact repeat (the count's hit masks are gone: a fresh count first)
+        st, pk = find_neighbors(inPts, inBatchIds, sortedPts, cellIndexs, aabbMin, aabbMax, radius, batchSize, scaleInv)
+        start.copy_(st)
+        return pk
+
+    def repdf(pk):
+        return compute_pdf(sortedPts, sortedBatchIds, aabbMin, aabbMax, start, pk, window, radius, batchSize, scaleInv)
+
+    return DeferredNeighborsPDF(refill, repdf, start, packed, pdfs, total_dev, slot, guess, gkey)
 
 
 def poisson_sampling(inPts, inBatchIds, cellIndexs, aabbMin, aabbMax, radius, batchSize, scaleInv):

@@ -41,6 +41,7 @@ SIGNATURES = {
     "mccnn_invert_permutation": (_i, [_vp, _i, _vp, _vp]),
     "mccnn_compute_pdf_workspace_bytes": (_sz, [_i, _i]),
     "mccnn_compute_pdf": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _f, _f, _i, _i, _vp, _vp, _sz, _vp]),
+    "mccnn_compute_pdf_dn": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _sz, _vp]),
     "mccnn_poisson_sampling_workspace_bytes": (_sz, [_i, _i, _i]),
     "mccnn_poisson_sampling_count": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
     "mccnn_poisson_sampling_fill": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

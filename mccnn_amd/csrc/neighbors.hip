@@ -253,8 +253,9 @@ __global__ __launch_bounds__(256) void pdf_edge_coords(const float* __restrict__
                                                        const int2* __restrict__ packed, int e,
                                                        const float* __restrict__ mn, const float* __restrict__ mx,
                                                        int B, float window, float radius, int scaleInv,
-                                                       float4* __restrict__ sc) {
+                                                       float4* __restrict__ sc, const int* __restrict__ eDev) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (eDev) e = min(e, max(*eDev, 0));  // device-side edge count (e is then the capacity of the lists)
     if (t >= e) return;
     int j = packed[t].x;
     float R = scaleInv ? radius * max_extent(mn, mx, clamp_batch(bids[j], B)) : radius;
@@ -270,12 +271,16 @@ __global__ __launch_bounds__(256) void pdf_edge_coords(const float* __restrict__
 // thread-per-edge form it replaced: identical results. (Reading the pre-scaled coordinates per POINT through the
 // neighbour index instead of the per-edge copy makes the scalar loads dependent: measured slower, 124 us.)
 __global__ __launch_bounds__(256) void pdf_rows(const float4* __restrict__ sc, const int* __restrict__ startIdx, int m,
-                                                int e, float window, float* __restrict__ pdfs) {
+                                                int e, float window, float* __restrict__ pdfs,
+                                                const int* __restrict__ eDev) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m) return;
+    const int cap = e;
+    if (eDev) e = min(e, max(*eDev, 0));
     const int lane = threadIdx.x & 63;
     const int i0 = __builtin_amdgcn_readfirstlane(startIdx[row]);
-    const int i1 = __builtin_amdgcn_readfirstlane((row < m - 1) ? startIdx[row + 1] : e);
+    int i1 = __builtin_amdgcn_readfirstlane((row < m - 1) ? startIdx[row + 1] : e);
+    if (eDev) i1 = min(i1, cap);  // a capacity below the true total: rows are cut, the caller repeats with the exact size
     const int k = i1 - i0;
     if (k <= 0) return;
     const float invH = 1.0f / window;
@@ -393,14 +398,15 @@ size_t mccnn_compute_pdf_workspace_bytes(int e, int mode) {
     return (mode != 0 && e > 0) ? align_up((size_t)e * sizeof(float4)) : 256;
 }
 
-int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx, int m,
-                      const int* packed, int e, const float* aabb_min, const float* aabb_max, int batch_size,
-                      float window, float radius, int scale_inv, int mode, float* pdfs, void* ws, size_t ws_bytes,
-                      mccnn_stream_t stream) {
+static int compute_pdf_impl(const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx, int m,
+                            const int* packed, int e, const int* e_dev, const float* aabb_min, const float* aabb_max,
+                            int batch_size, float window, float radius, int scale_inv, int mode, float* pdfs, void* ws,
+                            size_t ws_bytes, mccnn_stream_t stream) {
     if (m < 0 || e < 0 || batch_size <= 0 || !(radius > 0.0f) || !(window > 0.0f)) return MCCNN_E_BADARG;
     if (e == 0) return 0;
     if (!sorted_pts || !sorted_batch_ids || !start_idx || !packed || !aabb_min || !aabb_max || !pdfs || m == 0)
         return MCCNN_E_BADARG;
+    if (e_dev && mode == 0) return MCCNN_E_BADARG;  // the device-count form exists for the single-precision KDE only
     hipStream_t s = (hipStream_t)stream;
     const int2* pk = reinterpret_cast<const int2*>(packed);
     if (mode == 0)
@@ -410,12 +416,29 @@ int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, cons
         if (!ws || ws_bytes < mccnn_compute_pdf_workspace_bytes(e, mode)) return MCCNN_E_WORKSPACE;
         float4* sc = (float4*)ws;
         pdf_edge_coords<<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, e, aabb_min, aabb_max,
-                                                        batch_size, window, radius, scale_inv, sc);
+                                                        batch_size, window, radius, scale_inv, sc, e_dev);
         MCCNN_LAUNCHED();
-        pdf_rows<<<ceil_div(m, 4), 256, 0, s>>>(sc, start_idx, m, e, window, pdfs);
+        pdf_rows<<<ceil_div(m, 4), 256, 0, s>>>(sc, start_idx, m, e, window, pdfs, e_dev);
     }
     MCCNN_LAUNCHED();
     return 0;
+}
+
+int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx, int m,
+                      const int* packed, int e, const float* aabb_min, const float* aabb_max, int batch_size,
+                      float window, float radius, int scale_inv, int mode, float* pdfs, void* ws, size_t ws_bytes,
+                      mccnn_stream_t stream) {
+    return compute_pdf_impl(sorted_pts, sorted_batch_ids, start_idx, m, packed, e, nullptr, aabb_min, aabb_max, batch_size,
+                            window, radius, scale_inv, mode, pdfs, ws, ws_bytes, stream);
+}
+
+int mccnn_compute_pdf_dn(const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx, int m,
+                         const int* packed, int e_capacity, const int* e_dev, const float* aabb_min,
+                         const float* aabb_max, int batch_size, float window, float radius, int scale_inv, float* pdfs,
+                         void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    if (!e_dev) return MCCNN_E_BADARG;
+    return compute_pdf_impl(sorted_pts, sorted_batch_ids, start_idx, m, packed, e_capacity, e_dev, aabb_min, aabb_max,
+                            batch_size, window, radius, scale_inv, 1, pdfs, ws, ws_bytes, stream);
 }
 
 }  // extern "C"
