@@ -2,6 +2,7 @@
 # Usage (on the GPU box, from the repo root):
 #     tools/prof.sh <tag> <bench args...>            profile `python bench.py <args>` (headline layer only)
 #     PROF_CMD="python tools/hier_time.py" tools/prof.sh <tag>      profile another command
+# The profiled steps are strictly sequential (--no-pipeline): kernel times and counters of one kernel at a time.
 # One kernel-trace stats pass + SEPARATE PMC passes (counters are never combined with other trace domains).
 # Averages are taken over the steady state: prof_summary.py drops the first WARM dispatches of every kernel (the cold
 # call that pages code objects in is 2-5x slower than the rest and used to bias "AverageNs" of a 3-step run).
@@ -14,7 +15,7 @@ REPO=$PWD
 cd /tmp
 STEPS=${PROF_STEPS:-20}
 WARM=${PROF_WARM:-5}
-CMD=${PROF_CMD:-"python $REPO/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-breakdown --no-layers $*"}
+CMD=${PROF_CMD:-"python $REPO/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-breakdown --no-layers --no-pipeline $*"}
 echo "$CMD" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- $CMD > $OUT/trace.log 2>&1
 if [ -z "${PROF_NO_PMC:-}" ]; then
