@@ -94,5 +94,14 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_handle():
+    """hipStream_t of torch's current stream. Called once per C-ABI launch (10-20 times per step): the two raw C calls
+    cost ~0.5 us, torch.cuda.current_stream().cuda_stream ~9 us (device-index resolution, a Stream object) -- at a
+    sub-millisecond step that difference was 10 % of the host path."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
