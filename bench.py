@@ -414,6 +414,11 @@ def main():
     if world != args.gpus:
         log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
 
+    # one process per GPU: the autograd engine's per-device worker thread only adds a thread hand-off (~0.2 ms per
+    # backward() call, more than a quarter of a step here); run the backward pass on the calling thread
+    if hasattr(torch.autograd, "set_multithreading_enabled"):
+        torch.autograd.set_multithreading_enabled(False)
+
     from mccnn_amd import build as mbuild
     if rank == 0 and mbuild.needs_build():
         mbuild.build()

@@ -250,7 +250,9 @@ class ConvolutionBuilder:
         with torch.cuda.stream(side):
             if keyGrid not in grids:
                 keys, indexs = self.ops_.sort_points_step1(pts, bids, mn, mx, B, convRadius, currRelativeRadius)
-                dummy = torch.zeros((pts.shape[0], 1), dtype=torch.float32, device=pts.device)  # geometry only
+                dummy = getattr(self, "prefetchDummy_", None)  # geometry only: one zero feature per point, kept
+                if dummy is None or dummy.shape[0] != pts.shape[0] or dummy.device != pts.device:
+                    dummy = self.prefetchDummy_ = torch.zeros((pts.shape[0], 1), dtype=torch.float32, device=pts.device)
                 sortPts, sortBatchs, _, cellIndexs = self.ops_.sort_points_step2(pts, bids, dummy, keys, indexs, mn, mx, B,
                                                                                 convRadius, currRelativeRadius)
                 grids[keyGrid] = (sortPts, sortBatchs, cellIndexs, indexs)
