@@ -150,7 +150,7 @@ class Workload:
         if self.pipeline:
             # geometry of the NEXT batch (grid build, neighbour search, KDE: it depends on the points only) on a side
             # stream, under the convolution kernels just launched; the next reset() installs it
-            self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window)
+            self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window, transposed=not self.combin)
         if self.world > 1:
             if self.bucket is None:  # the variables exist after the first create_convolution
                 self.bucket = GradBucket(self.builder.parameters())

@@ -214,19 +214,26 @@ class ConvolutionBuilder:
                     for t in (v if isinstance(v, tuple) else (v,)):
                         t.record_stream(main)  # allocated on the side stream, read (and kept by autograd) on this one
             self.cacheGrids_, self.cacheNeighs_, self.cachePDFs_ = grids, neighs, pdfs
+            for kN, kG in getattr(self, "prefetchTransposed_", ()):
+                if kN in neighs and kG in grids and getattr(self.ops_, "_ops", 0) is None:
+                    from . import MCConvModule as _hip_ops
+                    _hip_ops.prefetch_transposed(neighs[kN][1], grids[kG][0].shape[0], self.sideStream_)
+            self.prefetchTransposed_ = set()
         if torch.cuda.is_available():
             self.resetEvent_ = torch.cuda.Event()
             self.resetEvent_.record()
 
     def prefetch_geometry(self, inPointHierarchy, inPointLevel, convRadius, outPointHierarchy=None, outPointLevel=None,
-                          KDEWindow=None, relativeRadius=None, usePDF=None):
+                          KDEWindow=None, relativeRadius=None, usePDF=None, transposed=False):
         """Extension (no counterpart in the reference): computes the grid, the neighbour list and the PDFs that
         create_convolution() with the same arguments looks up in the caches -- for the NEXT batch, on a side stream, and
         parks them until the next reset(). Geometry depends on the points only, not on the network, so in a training
         loop the grid build / search / KDE of batch k + 1 runs under the convolution kernels of batch k: those hold
         two waves per SIMD (VGPR-bound) and leave issue slots and wave slots that the light geometry kernels fill
         (100k room: 0.78 -> 0.66 ms per step). Call it after the backward pass of the current batch has been launched;
-        several calls between two reset()s accumulate."""
+        several calls between two reset()s accumulate. transposed=True (depth-wise layers will convolve over this
+        neighbour list): reset() also starts the list's transposition for their backward pass on the side stream, where
+        it runs under the forward convolutions."""
         currKDEWindow = self.KDEWindow_ if KDEWindow is None else KDEWindow
         currRelativeRadius = self.relativeRadius_ if relativeRadius is None else relativeRadius
         currUsePDF = self.usePDF_ if usePDF is None else usePDF
@@ -269,6 +276,8 @@ class ConvolutionBuilder:
                     h.keyPDF = keyPDF
                     neighs[keyNeighs] = h
                     pdfs[keyPDF] = h
+            if transposed:
+                self.prefetchTransposed_ = getattr(self, "prefetchTransposed_", set()) | {(keyNeighs, keyGrid)}
             if keyNeighs not in neighs:
                 neighs[keyNeighs] = tuple(self.ops_.find_neighbors(outPH.points_[outLevel], outPH.batchIds_[outLevel], g[0],
                                                                    g[2], mn, mx, convRadius, B, currRelativeRadius))

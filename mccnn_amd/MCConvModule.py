@@ -171,6 +171,21 @@ def _await_mailbox(view):
 _NUM_CELLS_CACHE = {}
 
 
+def prefetch_transposed(packed, n, stream):
+    """Builds the transposed neighbour list of `packed` on `stream` (a side stream) ahead of the backward pass that will
+    ask for it; the consumer waits for the recorded event (see _transposed_neighbors). `packed` must be ready on
+    `stream`."""
+    with torch.cuda.stream(stream):
+        if getattr(packed, "_mccnn_transposed", None) is None:
+            _transposed_neighbors(packed, n)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            try:
+                packed._mccnn_transposed_event = ev
+            except AttributeError:
+                stream.synchronize()
+
+
 def _transposed_neighbors(packed, n):
     """Transposed neighbour list (CSR by neighbour index) of `packed`, shared by every depth-wise layer that
     convolves over the same list -- the counterpart of ConvolutionBuilder's cacheNeighs_ for the backward pass. It is
@@ -178,6 +193,12 @@ def _transposed_neighbors(packed, n):
     entry) and there is no global table to go stale."""
     hit = getattr(packed, "_mccnn_transposed", None)
     if hit is not None and hit[2] == (packed._version, n):
+        ev = getattr(packed, "_mccnn_transposed_event", None)
+        if ev is not None:  # built ahead of time on another stream (prefetch_transposed): order this stream behind it
+            torch.cuda.current_stream().wait_event(ev)
+            for t in hit[:2]:
+                t.record_stream(torch.cuda.current_stream())
+            packed._mccnn_transposed_event = None
         return hit
     lib = _lib.load()
     e = packed.shape[0]

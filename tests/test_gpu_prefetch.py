@@ -46,3 +46,40 @@ def test_prefetched_geometry_equals_inline(mc):
         for g, r in zip(got[2], ref[2]):
             assert np.abs(g - r).max() <= 1e-5 * max(np.abs(r).max(), 1e-30)
     torch.cuda.synchronize()
+
+
+def test_prefetched_transposed_list_depthwise(mc):
+    """Depth-wise layer: the transposed neighbour list its backward needs is built on the side stream at reset();
+    the gradients equal the inline path's (the transposed gather is deterministic: bit for bit)."""
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    pts, bids = make_cloud(2500, 2, 29, "uniform", True)
+    rng = np.random.default_rng(6)
+    P = torch.from_numpy(pts).cuda()
+    Bi = torch.from_numpy(bids).cuda()
+    F = torch.from_numpy(rng.random((len(pts), 16), dtype=np.float32)).cuda().requires_grad_(True)
+    og = torch.from_numpy(rng.random((len(pts), 16), dtype=np.float32)).cuda()
+    ph = PointHierarchy(P, F, Bi, [], "PH", 2, True)
+    torch.manual_seed(4)
+    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True)
+
+    def run():
+        F.grad = None
+        for p in builder.parameters():
+            p.grad = None
+        out = builder.create_convolution("Conv", ph, 0, F, 16, 0.2, multiFeatureConv=False)
+        out.backward(og)
+        return out.detach().cpu().numpy(), F.grad.cpu().numpy(), [p.grad.cpu().numpy() for p in builder.parameters()]
+
+    builder.reset()
+    ref = run()
+    for _ in range(2):
+        builder.prefetch_geometry(ph, 0, 0.2, transposed=True)
+        builder.reset()
+        packed = next(iter(builder.cacheNeighs_.values()))[1]
+        assert getattr(packed, "_mccnn_transposed", None) is not None  # started at reset(), on the side stream
+        got = run()
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        for g, r in zip(got[2], ref[2]):
+            assert np.array_equal(g, r)
+    torch.cuda.synchronize()
