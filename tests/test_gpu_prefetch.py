@@ -83,3 +83,33 @@ def test_prefetched_transposed_list_depthwise(mc):
         for g, r in zip(got[2], ref[2]):
             assert np.array_equal(g, r)
     torch.cuda.synchronize()
+
+
+def test_prefetch_with_too_small_size_guess_is_repaired(mc):
+    """The deferred search + KDE size their lists from the last total of the shape; a guess that is too small is
+    detected when the total is read and both ops are repeated with the exact size."""
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    pts, bids = make_cloud(2000, 2, 31, "uniform")
+    rng = np.random.default_rng(8)
+    P = torch.from_numpy(pts).cuda()
+    Bi = torch.from_numpy(bids).cuda()
+    F = torch.from_numpy(rng.random((len(pts), 1), dtype=np.float32)).cuda()
+    ph = PointHierarchy(P, F, Bi, [], "PH", 2, True)
+    torch.manual_seed(5)
+    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True)
+    builder.reset()
+    ref = builder.create_convolution("Conv", ph, 0, F, 1, 0.2, outNumFeatures=8, multiFeatureConv=True).detach().cpu().numpy()
+    e_ref = next(iter(builder.cacheNeighs_.values()))[1].shape[0]
+    assert len(mc._EDGE_GUESS) > 0
+    for k in list(mc._EDGE_GUESS):
+        mc._EDGE_GUESS[k] = 16                    # far below the ~1e5 edges of this cloud
+    builder.prefetch_geometry(ph, 0, 0.2)
+    h = next(iter(builder.prefetched_[1].values()))
+    assert hasattr(h, "finalize")                 # the deferred path was taken
+    builder.reset()
+    st, pk = next(iter(builder.cacheNeighs_.values()))
+    assert pk.shape[0] == e_ref and next(iter(builder.cachePDFs_.values())).shape[0] == e_ref
+    got = builder.create_convolution("Conv", ph, 0, F, 1, 0.2, outNumFeatures=8, multiFeatureConv=True).detach().cpu().numpy()
+    assert np.array_equal(got, ref)
+    torch.cuda.synchronize()
