@@ -1,8 +1,15 @@
-import sys, time, os
+"""Wall time of one MCClassS training step (cfg1: 32 clouds x 1024 points, k = 16), with the autograd engine's worker
+thread and on the calling thread: python tools/e2e_time.py (on the GPU box)."""
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from mcclass_s import MCClassS, synthetic_batch
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from mcclass_s import MCClassS, synthetic_batch  # noqa: E402
+
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
 B, n, k = 32, 1024, 16
@@ -10,12 +17,25 @@ net = MCClassS(1, B, k, 40, dev)
 P, Bi, F, y = synthetic_batch(B, n, 40, rng, dev)
 net(P, Bi, F, True)
 opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+
+
 def step():
     logits = net(P, Bi, F, True)
     loss = torch.nn.functional.cross_entropy(logits, y)
-    opt.zero_grad(set_to_none=True); loss.backward(); opt.step()
-for _ in range(3): step()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10): step()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-print("MCClassS cfg1 (32 x 1024 pts, k=16): %.2f ms/step, %.0f clouds/s, levels %s" % (dt * 1e3, B / dt, [int(p.shape[0]) for p in net.lastHierarchy.points_]))
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+
+
+for mt in (True, False):
+    torch.autograd.set_multithreading_enabled(mt)
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    print("MCClassS cfg1 (32 x 1024 pts, k=16), autograd multithreading %s: %.2f ms/step, %.0f clouds/s, levels %s"
+          % (mt, dt * 1e3, B / dt, [int(p.shape[0]) for p in net.lastHierarchy.points_]))
