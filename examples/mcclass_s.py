@@ -110,7 +110,7 @@ def main():
     rng = np.random.default_rng(0)
     torch.manual_seed(0)
     # one process per GPU: run the backward pass on the calling thread -- the autograd engine's per-device worker thread
-    # only adds a hand-off per backward() and this network is host-bound (cfg1 step: 6.3 -> 5.1 ms, tools/e2e_time.py)
+    # only adds a hand-off per backward() and this network is host-bound (cfg1 step: 4.0 -> 3.3 ms, tools/e2e_time.py)
     torch.autograd.set_multithreading_enabled(False)
     net = MCClassS(1, args.batch, 16, 4, device)
     P, Bi, F, y = synthetic_batch(args.batch, args.points, 4, rng, device)
