@@ -16,6 +16,12 @@ cloud-per-GPU; there is no data-path collective.
 Inputs are synthetic and resident in HBM before the timed region. The timed region is bracketed by
 barrier + torch.cuda.synchronize() on both sides and the max over ranks is reported.
 
+Steps are PIPELINED by default (--no-pipeline for strictly sequential steps): the geometry ops of a batch (grid build,
+neighbour search, KDE -- they depend on the points only) are launched on a side stream while the convolution kernels of
+the previous batch run (ConvolutionBuilder.prefetch_geometry). Every step still executes every op: inside the timed
+region K geometry passes and K convolution passes run. Before timing, three pipelined steps are checked to reproduce a
+sequential step's forward output bit for bit; config.sequential_ms_per_step reports the same K steps unpipelined.
+
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the field contract), including
   roofline     -- the dominant kernel's algorithmic flops (or bytes) / its HIP-event duration
   layers       -- the same measurement for all three layer shapes of SURVEY 8d (1to64, 3to8, dw256), so that the
