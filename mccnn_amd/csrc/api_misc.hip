@@ -4,7 +4,7 @@
 extern "C" {
 
 int mccnn_block_size(void) { return MCCNN_MLP; }
-int mccnn_abi_version(void) { return 3; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts
+int mccnn_abi_version(void) { return 4; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn
 const char* mccnn_arch(void) { return "gfx950"; }
 
 const char* mccnn_error_string(int code) {
