@@ -128,6 +128,26 @@ def _order_hint(points):
 
 
 _EDGE_GUESS = {}  # (device, M, N, radius, B, scaleInv) -> capacity to try first in find_neighbors
+# ... and, for batches whose sizes change from step to step (ragged training batches), the edges per centre of the last
+# search with the same radius: (device, radius, scaleInv) -> E / M
+_EDGE_RATIO = {}
+
+
+def _edge_guess(gkey):
+    g = _EDGE_GUESS.get(gkey, 0)
+    if g <= 0:
+        ratio = _EDGE_RATIO.get((gkey[0], gkey[3], gkey[5]), 0.0)
+        if ratio > 0.0:
+            g = int(ratio * gkey[1] * 1.25) + 1024  # sizes differ: more head room than for a repeated shape
+    return g
+
+
+def _remember_edges(gkey, e):
+    if len(_EDGE_GUESS) > 256:
+        _EDGE_GUESS.clear()
+    _EDGE_GUESS[gkey] = e + e // 16 + 64  # a little head room: totals of a shape vary slightly from batch to batch
+    if gkey[1] > 0:
+        _EDGE_RATIO[(gkey[0], gkey[3], gkey[5])] = e / float(gkey[1])
 _TLS = threading.local()
 
 
@@ -221,6 +241,7 @@ def clear_caches():
     _ORDER_HINTS.clear()
     _NUM_CELLS_CACHE.clear()
     _EDGE_GUESS.clear()
+    _EDGE_RATIO.clear()
 
 
 #: debug aid: raise MCCNN_E_BATCHID from compute_aabb (the entry of every op chain) when a batch id lies outside
@@ -486,7 +507,7 @@ def find_neighbors(inPts, inBatchIds, inPts2, cellIndexs, aabbMin, aabbMax, radi
     # total of this shape BEFORE the total is read: the host round trip hides behind the kernel. Too small a guess ->
     # exact rerun.
     gkey = (c.device.index, m, n2, float(radius), int(batchSize), bool(scaleInv))
-    guess = _EDGE_GUESS.get(gkey, 0)
+    guess = _edge_guess(gkey)
     packed = None
     if guess > 0:
         buf = torch.empty((guess, 2), dtype=torch.int32, device=c.device)
@@ -501,9 +522,7 @@ def find_neighbors(inPts, inBatchIds, inPts2, cellIndexs, aabbMin, aabbMax, radi
         packed = torch.empty((e, 2), dtype=torch.int32, device=c.device)
         check(lib.mccnn_find_neighbors_fill(*args, ptr(start), e, ptr(packed), ptr(ws), ws.numel(), stream_handle()),
               "find_neighbors(fill)")
-    if len(_EDGE_GUESS) > 256:
-        _EDGE_GUESS.clear()
-    _EDGE_GUESS[gkey] = e + e // 16 + 64  # a little head room: totals of a shape vary slightly from batch to batch
+    _remember_edges(gkey, e)
     return start, packed
 
 
@@ -566,9 +585,7 @@ class DeferredNeighborsPDF:
         else:
             packed = self._args_fn(e)
             pdfs = self._pdf_fn(packed)
-        if len(_EDGE_GUESS) > 256:
-            _EDGE_GUESS.clear()
-        _EDGE_GUESS[self._gkey] = e + e // 16 + 64
+        _remember_edges(self._gkey, e)
         return self.start, packed, pdfs
 
 
@@ -599,7 +616,7 @@ def find_neighbors_pdf_deferred(inPts, inBatchIds, sortedPts, sortedBatchIds, ce
     _check_aabb(mn, mx, batchSize, op)
     m, n2, nc = c.shape[0], p2.shape[0], cells.shape[1]
     gkey = (c.device.index, m, n2, float(radius), int(batchSize), bool(scaleInv))
-    guess = _EDGE_GUESS.get(gkey, 0)
+    guess = _edge_guess(gkey)
     if guess <= 0 or m == 0:
         return None
     lib = _lib.load()
