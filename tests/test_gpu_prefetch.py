@@ -113,3 +113,26 @@ def test_prefetch_with_too_small_size_guess_is_repaired(mc):
     got = builder.create_convolution("Conv", ph, 0, F, 1, 0.2, outNumFeatures=8, multiFeatureConv=True).detach().cpu().numpy()
     assert np.array_equal(got, ref)
     torch.cuda.synchronize()
+
+
+def test_deferred_search_and_kde_equal_the_two_ops(mc):
+    """find_neighbors_pdf_deferred (lists sized by a guess, KDE reading the edge count from device memory) returns the
+    same start indices, neighbour list and pdfs -- bit for bit -- as find_neighbors + compute_pdf."""
+    import torch
+    pts, bids = make_cloud(1800, 3, 37, "clustered", True)
+    P = torch.from_numpy(pts).cuda()
+    Bi = torch.from_numpy(bids).cuda()
+    F = torch.ones((len(pts), 1), device="cuda")
+    B, r, w = 3, 0.12, 0.25
+    mn, mx = mc.compute_aabb(P, Bi, B, True)
+    keys, idx = mc.sort_points_step1(P, Bi, mn, mx, B, r, True)
+    sP, sB, sF, cells = mc.sort_points_step2(P, Bi, F, keys, idx, mn, mx, B, r, True)
+    mc.clear_caches()
+    assert mc.find_neighbors_pdf_deferred(P, Bi, sP, sB, cells, mn, mx, r, B, True, w) is None   # no size guess yet
+    start, packed = mc.find_neighbors(P, Bi, sP, cells, mn, mx, r, B, True)
+    pdfs = mc.compute_pdf(sP, sB, mn, mx, start, packed, w, r, B, True)
+    h = mc.find_neighbors_pdf_deferred(P, Bi, sP, sB, cells, mn, mx, r, B, True, w)
+    assert h is not None
+    st2, pk2, pdf2 = h.finalize()
+    torch.cuda.synchronize()
+    assert torch.equal(st2, start) and torch.equal(pk2, packed) and torch.equal(pdf2, pdfs)
