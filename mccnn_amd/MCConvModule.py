@@ -886,6 +886,10 @@ class _SpatialConv(torch.autograd.Function):
         start_t = perm_t = None
         if not combin and e > 0:
             start_t, perm_t, _ = _transposed_neighbors(ctx.packed_obj, n)
+        elif combin and 2 <= fin <= 4 and e > 0 and getattr(ctx.packed_obj, "_mccnn_transposed", None) is not None:
+            # the transposed list exists already (prefetched with the geometry): the feature gradient is then gathered
+            # through it instead of added with float atomics (deterministic, and cheaper than the atomics)
+            start_t, perm_t, _ = _transposed_neighbors(ctx.packed_obj, n)
         if bf16:
             check(lib.mccnn_spatial_conv_bwd_bf16(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                                   ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),

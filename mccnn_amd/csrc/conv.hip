@@ -778,6 +778,42 @@ __global__ __launch_bounds__(256) void scatter_edge_featgrad(const int2* __restr
     atomicAdd(&featGrad[(size_t)packed[e].x * Fin + f], v);
 }
 
+// The same sum without atomics, when the caller supplies the transposed neighbour list (it costs more to build than
+// the atomics it saves, but a caller that prefetches the geometry of the next batch builds it for free on its side
+// stream): 16 lanes per point split the point's edges, every lane adds the planes of its edges, a 4-step butterfly adds
+// the lanes. Every row is written exactly once, in a fixed order: bit-reproducible feature gradients.
+template <int FIN>
+__global__ __launch_bounds__(256) void gather_edge_featgrad(const int* __restrict__ startT, const int* __restrict__ permT,
+                                                            const float* __restrict__ dfE, long long total, int planes,
+                                                            int n, int e, float* __restrict__ featGrad) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = (int)(tid >> 4), sub = (int)(tid & 15);
+    float acc[FIN];
+#pragma unroll
+    for (int f = 0; f < FIN; ++f) acc[f] = 0.f;
+    if (j < n) {
+        const int t0 = startT[j], t1 = (j + 1 < n) ? startT[j + 1] : e;
+        for (int t = t0 + sub; t < t1; t += 16) {
+            const long long base = (long long)permT[t] * FIN;
+            for (int p = 0; p < planes; ++p) {
+#pragma unroll
+                for (int f = 0; f < FIN; ++f) acc[f] += dfE[(size_t)p * total + base + f];
+            }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < FIN; ++f) {
+        acc[f] += __shfl_xor(acc[f], 8, 64);
+        acc[f] += __shfl_xor(acc[f], 4, 64);
+        acc[f] += __shfl_xor(acc[f], 2, 64);
+        acc[f] += __shfl_xor(acc[f], 1, 64);
+    }
+    if (j < n && sub == 0) {
+#pragma unroll
+        for (int f = 0; f < FIN; ++f) featGrad[(size_t)j * FIN + f] = acc[f];
+    }
+}
+
 // Sums the per-wave partial rows in a fixed order and scatters them to the six gradient tensors.
 __global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ partials, int numWaves, int nb,
                                                         float* __restrict__ dw1, float* __restrict__ db1,
@@ -1226,7 +1262,10 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
     bool dfeatT = mfma && !combin;
     // (the factored Fin = 1 path clears feat_grad in its centre pass, which runs before the edges add to it)
     const bool f1Clears = mfma && m > 0 && e > 0 && f1_shape(num_in_feats, num_out_feats, combin);
-    if (n > 0 && !dfeatT && !f1Clears) MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * (bf16 ? 2 : sizeof(float)), s));
+    // (... and the transposed gather of combin layers with 2..4 input features writes every row)
+    const bool gatherT = mfma && combin && a.Fin >= 2 && a.Fin <= 4 && start_t && perm_t && m > 0 && e > 0;
+    if (n > 0 && !dfeatT && !f1Clears && !gatherT)
+        MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * (bf16 ? 2 : sizeof(float)), s));
     if (!mfma || m == 0 || e == 0) {
         MCCNN_HIP(hipMemsetAsync(dw1, 0, 3 * nn * sizeof(float), s));
         MCCNN_HIP(hipMemsetAsync(db1, 0, nn * sizeof(float), s));
@@ -1289,8 +1328,15 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
         }
         if (combin && a.Fin > 1) {  // Fin == 1: the main kernel adds each edge's finished sum itself
             long long total = (long long)e * a.Fin;
-            scatter_edge_featgrad<<<ceil_div(total, 256), 256, 0, s>>>(a.packed, dfE, total, a.Fin, df_planes(a.Fin, a.nb),
-                                                                       feat_grad);
+            const int planes = df_planes(a.Fin, a.nb);
+            if (start_t && perm_t && a.Fin <= 4) {  // transposed list at hand: deterministic gather, no atomics
+                const int gblocks = ceil_div((long long)n * 16, 256);
+                if (a.Fin == 2) gather_edge_featgrad<2><<<gblocks, 256, 0, s>>>(start_t, perm_t, dfE, total, planes, n, e, feat_grad);
+                else if (a.Fin == 3) gather_edge_featgrad<3><<<gblocks, 256, 0, s>>>(start_t, perm_t, dfE, total, planes, n, e, feat_grad);
+                else gather_edge_featgrad<4><<<gblocks, 256, 0, s>>>(start_t, perm_t, dfE, total, planes, n, e, feat_grad);
+            } else {
+                scatter_edge_featgrad<<<ceil_div(total, 256), 256, 0, s>>>(a.packed, dfE, total, a.Fin, planes, feat_grad);
+            }
             MCCNN_LAUNCHED();
         } else if (combin) {
         } else if (dfeatT) {

@@ -136,3 +136,39 @@ def test_deferred_search_and_kde_equal_the_two_ops(mc):
     st2, pk2, pdf2 = h.finalize()
     torch.cuda.synchronize()
     assert torch.equal(st2, start) and torch.equal(pk2, packed) and torch.equal(pdf2, pdfs)
+
+
+def test_combin_feature_gradient_through_the_transposed_list(mc):
+    """Combin layer with 3 input features: with a (prefetched) transposed list the feature gradient is gathered in a
+    fixed order instead of added with float atomics -- equal to the atomic form within float-sum noise, and bit-identical
+    from run to run."""
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    pts, bids = make_cloud(2500, 2, 41, "uniform", True)
+    rng = np.random.default_rng(9)
+    P = torch.from_numpy(pts).cuda()
+    Bi = torch.from_numpy(bids).cuda()
+    F = torch.from_numpy(rng.random((len(pts), 3), dtype=np.float32)).cuda().requires_grad_(True)
+    og = torch.from_numpy(rng.random((len(pts), 8), dtype=np.float32)).cuda()
+    ph = PointHierarchy(P, F, Bi, [], "PH", 2, True)
+    torch.manual_seed(6)
+    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True)
+
+    def run():
+        F.grad = None
+        for p in builder.parameters():
+            p.grad = None
+        out = builder.create_convolution("Conv", ph, 0, F, 3, 0.2, outNumFeatures=8, multiFeatureConv=True)
+        out.backward(og)
+        return F.grad.cpu().numpy()
+
+    builder.reset()
+    ref = run()                                   # float atomics
+    got = []
+    for _ in range(2):
+        builder.prefetch_geometry(ph, 0, 0.2, transposed=True)
+        builder.reset()
+        got.append(run())                         # transposed gather
+    assert np.array_equal(got[0], got[1])
+    assert np.abs(got[0] - ref).max() <= 1e-5 * np.abs(ref).max()
+    torch.cuda.synchronize()
