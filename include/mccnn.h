@@ -215,7 +215,9 @@ int mccnn_spatial_conv_fwd(const float* sorted_pts, const float* sorted_feats,
  * padded output neurons (nu >= neuronsOut), which the reference leaves
  * uninitialised (spatial_conv.cu:921,924), are zero. state: the buffer the forward call of the
  * SAME inputs filled, or NULL. start_t / perm_t: optional transposed neighbour list (see
- * mccnn_transpose_neighbors), used by depth-wise layers only. */
+ * mccnn_transpose_neighbors): depth-wise layers need it (built internally when NULL); combin layers
+ * with 2..4 input features use it IF supplied -- their feature gradient is then gathered in a fixed
+ * order instead of added with float atomics (bit-reproducible); NULL keeps the atomics. */
 size_t mccnn_spatial_conv_bwd_workspace_bytes(int n, int m, int e, int num_in_feats,
                                               int num_out_feats, int combin);
 int mccnn_spatial_conv_bwd(const float* sorted_pts, const float* sorted_feats,
