@@ -243,6 +243,8 @@ class ConvolutionBuilder:
                                                                currKDEWindow, currRelativeRadius, currUsePDF)
         pts, bids = inPointHierarchy.points_[inPointLevel], inPointHierarchy.batchIds_[inPointLevel]
         mn, mx, B = inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, inPointHierarchy.batchSize_
+        if not pts.is_cuda:
+            return  # host tensors (a CPU checker behind `ops=`): nothing to overlap, create_convolution computes inline
         if getattr(self, "sideStream_", None) is None:
             self.sideStream_ = torch.cuda.Stream(device=pts.device)
         pf = getattr(self, "prefetched_", None)

@@ -577,6 +577,8 @@ class DeferredNeighborsPDF:
     def finalize(self):
         """-> (startIndexs [M,1], packedNeighs [E,2], pdfs [E,1]); call on the stream that will consume them, after it
         has been ordered behind the producing stream."""
+        if self._slot is None:
+            raise RuntimeError("DeferredNeighborsPDF.finalize() called twice")
         e = _await_mailbox(self._slot[1])
         _slot_pool().append(self._slot)
         self._slot = None
