@@ -95,3 +95,24 @@ def test_builder_caches_and_errors(shimmed_builder):
     with pytest.raises(RuntimeError):
         cb.create_convolution("D", ph, 0, feats, 8, 0.3, outPointHierarchy=ph2)
     assert b.shape == (128, 8)
+
+
+def test_prefetch_geometry_is_a_no_op_on_host_tensors(shimmed_builder):
+    """The side-stream prefetch exists for the HIP op surface; with host tensors (CPU checker behind the op names) it
+    must neither run an op nor park anything, and reset() / create_convolution() behave as before."""
+    MB, calls = shimmed_builder
+    B = 2
+    rng = np.random.default_rng(1)
+    pts = torch.from_numpy(rng.random((B * 64, 3), dtype=np.float32))
+    bids = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), 64).reshape(-1, 1))
+    feats = torch.ones((B * 64, 1), dtype=torch.float32)
+    ph = MB.PointHierarchy(pts, feats, bids, [], "PH", B)
+    cb = MB.ConvolutionBuilder(KDEWindow=0.2)
+    before = len(calls)
+    cb.prefetch_geometry(ph, 0, 0.3)
+    assert len(calls) == before and getattr(cb, "prefetched_", None) is None
+    cb.reset()
+    assert cb.cacheGrids_ == {} and cb.cacheNeighs_ == {} and cb.cachePDFs_ == {}
+    out = cb.create_convolution(convName="Conv", inPointHierarchy=ph, inPointLevel=0, inFeatures=feats, inNumFeatures=1,
+                                outNumFeatures=8, convRadius=0.3, multiFeatureConv=True)
+    assert out.shape == (B * 64, 8) and len(cb.cacheNeighs_) == 1
