@@ -147,6 +147,13 @@ class ConvolutionBuilder:
         self.variables_ = {}        # name -> torch.nn.Parameter (tf.get_variable store)
         self.collections_ = {}      # collection name -> list of parameters (tf.add_to_collection)
         self.opTrace_ = None        # optional list the builder appends (op, key) records to (tests)
+        # prefetch_geometry(): side stream, parked geometry (grids, neighbours, pdfs, event), the event of the last
+        # reset(), neighbour lists to transpose ahead of time, the dummy feature column of the geometry-only sort
+        self.sideStream_ = None
+        self.prefetched_ = None
+        self.resetEvent_ = None
+        self.prefetchTransposed_ = set()
+        self.prefetchDummy_ = None
 
     # ------------------------------------------------------------------ variable store
     def parameters(self):
@@ -199,7 +206,7 @@ class ConvolutionBuilder:
         self.cacheGrids_ = {}
         self.cacheNeighs_ = {}
         self.cachePDFs_ = {}
-        pf, self.prefetched_ = getattr(self, "prefetched_", None), None
+        pf, self.prefetched_ = self.prefetched_, None
         if pf is not None:
             grids, neighs, pdfs, event = pf
             main = torch.cuda.current_stream()
@@ -214,7 +221,7 @@ class ConvolutionBuilder:
                     for t in (v if isinstance(v, tuple) else (v,)):
                         t.record_stream(main)  # allocated on the side stream, read (and kept by autograd) on this one
             self.cacheGrids_, self.cacheNeighs_, self.cachePDFs_ = grids, neighs, pdfs
-            for kN, kG in getattr(self, "prefetchTransposed_", ()):
+            for kN, kG in self.prefetchTransposed_:
                 if kN in neighs and kG in grids and getattr(self.ops_, "_ops", 0) is None:
                     from . import MCConvModule as _hip_ops
                     _hip_ops.prefetch_transposed(neighs[kN][1], grids[kG][0].shape[0], self.sideStream_)
@@ -245,21 +252,21 @@ class ConvolutionBuilder:
         mn, mx, B = inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, inPointHierarchy.batchSize_
         if not pts.is_cuda:
             return  # host tensors (a CPU checker behind `ops=`): nothing to overlap, create_convolution computes inline
-        if getattr(self, "sideStream_", None) is None:
+        if self.sideStream_ is None:
             self.sideStream_ = torch.cuda.Stream(device=pts.device)
-        pf = getattr(self, "prefetched_", None)
+        pf = self.prefetched_
         grids, neighs, pdfs = (pf[0], pf[1], pf[2]) if pf is not None else ({}, {}, {})
         side = self.sideStream_
         # the point hierarchy has to be complete before the side stream reads it: it waits for what the calling stream
         # had been given up to the last reset() -- NOT for the convolutions launched since, which it is meant to overlap
-        if getattr(self, "resetEvent_", None) is not None:
+        if self.resetEvent_ is not None:
             side.wait_event(self.resetEvent_)
         else:
             side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             if keyGrid not in grids:
                 keys, indexs = self.ops_.sort_points_step1(pts, bids, mn, mx, B, convRadius, currRelativeRadius)
-                dummy = getattr(self, "prefetchDummy_", None)  # geometry only: one zero feature per point, kept
+                dummy = self.prefetchDummy_  # geometry only: one zero feature per point, kept
                 if dummy is None or dummy.shape[0] != pts.shape[0] or dummy.device != pts.device:
                     dummy = self.prefetchDummy_ = torch.zeros((pts.shape[0], 1), dtype=torch.float32, device=pts.device)
                 sortPts, sortBatchs, _, cellIndexs = self.ops_.sort_points_step2(pts, bids, dummy, keys, indexs, mn, mx, B,
@@ -279,7 +286,7 @@ class ConvolutionBuilder:
                     neighs[keyNeighs] = h
                     pdfs[keyPDF] = h
             if transposed:
-                self.prefetchTransposed_ = getattr(self, "prefetchTransposed_", set()) | {(keyNeighs, keyGrid)}
+                self.prefetchTransposed_ = self.prefetchTransposed_ | {(keyNeighs, keyGrid)}
             if keyNeighs not in neighs:
                 neighs[keyNeighs] = tuple(self.ops_.find_neighbors(outPH.points_[outLevel], outPH.batchIds_[outLevel], g[0],
                                                                    g[2], mn, mx, convRadius, B, currRelativeRadius))
