@@ -298,6 +298,13 @@ class Workload:
                 flops = (320.0 if k.endswith("fwd") else 912.0) * nb * e
                 breakdown[k]["mlp_tflops"] = round(flops / (ms * 1e-3) / 1e12, 3)
                 breakdown[k]["mlp_frac_of_f32_peak"] = round(flops / (ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4)
+        # compute_pdf is VALU / transcendental-bound, not byte-bound: its natural rate is pair terms per second,
+        # sum over the centres of k_i^2
+        kk = torch.diff(torch.cat([start.reshape(-1).to(torch.int64),
+                                   torch.tensor([e], dtype=torch.int64, device=device)]))
+        pairs = float((kk * kk).sum().item())
+        breakdown["compute_pdf"]["pair_terms"] = int(pairs)
+        breakdown["compute_pdf"]["gpairs_per_s"] = round(pairs / (t_pdf * 1e-3) / 1e9, 1)
         dom = max(alg, key=lambda k: alg[k][2])
         bound, work, ms = alg[dom]
         peak = HBM_PEAK_GBS if bound == "hbm" else F32_PEAK_TFLOPS
