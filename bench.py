@@ -370,7 +370,14 @@ def cpu_baseline(wl, out_gpu):
     step = make_step(orc, wl.pts_np, wl.bids_np, wl.feats_np, wl.ograd_np, wl.B)
     med, runs, oc = median_of(step, 5, 25.0)
     m_local = len(wl.pts_np)
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "")
+    except OSError:
+        pass
     cpu = {"value": round(m_local / med, 1), "unit": "points/s", "cores": orc.num_threads(), "kind": "port",
+           "host": "%s, %d logical cores" % (cpu_model, os.cpu_count() or 0),
            "sample": "median of %d steps (fwd+bwd) of the identical workload after 1 warm-up, OpenMP over centres, "
                      "%.2f s per step" % (runs, med)}
     err = float(np.abs(out_gpu.detach().cpu().numpy() - oc).max() / max(np.abs(oc).max(), 1e-30))
@@ -502,6 +509,9 @@ def main():
             ent = layers[name]
             ent["roofline"] = rl
             ent["conv_ms"] = {"fwd": bd["spatial_conv_fwd"]["ms"], "bwd": bd["spatial_conv_bwd"]["ms"]}
+            # conv-only rate: spatial_conv forward + backward with the neighbour list and PDFs cached, as
+            # every further layer over the same (level, radius) sees it through ConvolutionBuilder's caches
+            ent["conv_only_points_per_s"] = round(w2.P.shape[0] / ((bd["spatial_conv_fwd"]["ms"] + bd["spatial_conv_bwd"]["ms"]) * 1e-3), 1)
             ent["conv_rate"] = {"fwd": bd["spatial_conv_fwd"], "bwd": bd["spatial_conv_bwd"]}
             if "spatial_conv_bf16_rows" in bd:
                 ent["bf16_rows"] = bd["spatial_conv_bf16_rows"]
