@@ -89,7 +89,7 @@ def make_inputs(npts, seeds, layer, device, rank):
     return pts, bids, feats, ograd, t(pts), t(bids), t(feats), t(ograd)
 
 
-def ev_time(fn, iters=5):
+def ev_time(fn, iters=20):
     """Average HIP-event duration (ms) of fn() on the current stream (the one every C-ABI call is launched on), queue
     drained before each call; one untimed call first."""
     r = fn()
