@@ -111,6 +111,7 @@ class Workload:
     def __init__(self, args, layer, seeds, rank, world, device):
         from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
         self.args, self.layer, self.world, self.device = args, layer, world, device
+        self.dist_on = dist.is_available() and dist.is_initialized()
         self.fin, self.fout, self.combin = LAYERS[layer]
         self.B = len(seeds)
         (self.pts_np, self.bids_np, self.feats_np, self.ograd_np, self.P, self.Bi, self.F, self.OG) = make_inputs(
@@ -119,7 +120,7 @@ class Workload:
         # level-0-only hierarchy: computes the (whole-batch, absolute-radius) bounding box once, outside the step; with
         # N > 1 the shards all-reduce it before anything is sorted (aabb_gpu.cu:104-114)
         self.ph = PointHierarchy(self.P, self.F, self.Bi, [], "bench_PH", self.B, False,
-                                 aabbReduceGroup=True if world > 1 else None)
+                                 aabbReduceGroup=True if self.dist_on else None)
         self.builder = ConvolutionBuilder(KDEWindow=args.window, relativeRadius=False)
         torch.manual_seed(1234)  # identical kernel-MLP weights on every rank
         self.bucket = None
@@ -144,7 +145,7 @@ class Workload:
             self.pipeline = False
             self.builder.prefetched_ = None
             torch.cuda.synchronize()
-        if world > 1:
+        if self.dist_on:
             flag = torch.tensor([1.0 if ok else 0.0], device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(flag.item() > 0.5)
@@ -167,9 +168,9 @@ class Workload:
             # geometry of the NEXT batch (grid build, neighbour search, KDE: it depends on the points only) on a side
             # stream, under the convolution kernels just launched; the next reset() installs it
             self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window, transposed=not self.combin)
-        if self.world > 1 and not self.skip_allreduce:
+        if self.dist_on and not self.skip_allreduce:
             if self.bucket is None:  # the variables exist after the first create_convolution
-                self.bucket = GradBucket(self.builder.parameters())
+                self.bucket = GradBucket(self.builder.parameters(), single_rank=True)
             # enqueued on RCCL's stream; the next step's grid build, search and forward pass run under it (the reduced
             # gradients are not read before the next pack, or the wait() that closes the timed region)
             self.bucket.allreduce(async_op=True)
@@ -182,7 +183,7 @@ class Workload:
         if self.bucket is not None:
             self.bucket.wait()
         torch.cuda.synchronize()
-        if self.world > 1:
+        if self.dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -191,12 +192,12 @@ class Workload:
         if self.bucket is not None:
             self.bucket.wait()  # the last step's all-reduce finishes inside the timed region
         torch.cuda.synchronize()
-        if self.world > 1:
+        if self.dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         m_local = self.P.shape[0]
-        if self.world > 1:
+        if self.dist_on:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
@@ -434,9 +435,14 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # MCCNN_BENCH_FORCE_PG=1: a process group of ONE rank, so that a 1-GPU box exercises RCCL's init, the asynchronous
+    # gradient all-reduce and the barriers of the N > 1 path (tests/test_gpu_dist.py)
+    dist_on = world > 1 or os.environ.get("MCCNN_BENCH_FORCE_PG") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -452,7 +458,7 @@ def main():
     from mccnn_amd import build as mbuild
     if rank == 0 and mbuild.needs_build():
         mbuild.build()
-    if world > 1:
+    if dist_on:
         dist.barrier()
 
     # which rooms this rank owns: weak = its own rooms_per_gpu rooms; strong = its share of a fixed batch
@@ -550,11 +556,16 @@ def main():
                                     "them" if wl.pipeline else None),
                        "pipelined_ms_per_step": (round(ms_pipelined, 4) if ms_pipelined is not None else None),
                        "sequential_ms_per_step": (round(ms_sequential, 4) if ms_sequential is not None else None),
-                       "collective_backend": (backend if world > 1 else None), "rccl_world_size": world},
+                       "collective_backend": (backend if dist_on else None), "rccl_world_size": world},
             "roofline": roofline, "cpu_baseline": cpu, "layers": layers, "breakdown": breakdown,
         }
+        try:  # RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION): push it out BEFORE the record
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

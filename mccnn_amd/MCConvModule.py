@@ -883,7 +883,12 @@ class _SpatialConv(torch.autograd.Function):
         n, fin = feats.shape
         m, e = smp.shape[0], pk.shape[0]
         fg = torch.empty_like(feats)
-        dw1, db1, dw2, db2, dw3, db3 = (torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3))
+        # the six MLP gradients are consecutive slices of ONE buffer, in the order the builder creates the variables:
+        # a data-parallel step all-reduces that buffer as it is (dist.GradBucket), with no packing kernel in between
+        gflat = torch.empty(w1.numel() + b1.numel() + w2.numel() + b2.numel() + w3.numel() + b3.numel(),
+                            dtype=w1.dtype, device=w1.device)
+        dw1, db1, dw2, db2, dw3, db3 = gflat.split([w1.numel(), b1.numel(), w2.numel(), b2.numel(), w3.numel(), b3.numel()])
+        dw1, dw2, dw3 = dw1.view_as(w1), dw2.view_as(w2), dw3.view_as(w3)
         ws = _ws(lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, numOutFeatures, int(combin)), pts.device)
         start_t = perm_t = None
         if not combin and e > 0:

@@ -51,10 +51,19 @@ def allreduce_aabb(aabbMin, aabbMax, group=None):
 class GradBucket:
     """One flat buffer for all kernel-MLP gradients -> a single all-reduce per step."""
 
-    def __init__(self, params):
+    def __init__(self, params, single_rank=False):
+        """single_rank=True runs the collective even in a process group of one rank (tests of the RCCL path on a 1-GPU
+        box); by default a single rank only packs."""
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off * 4)
+            off += p.numel()
         self.flat = None
+        self.own = None      # the bucket's own buffer (used when the gradients do not already lie in one)
+        self.single_rank = bool(single_rank)
         self.pending = None  # (work handle, divisor) of an asynchronous all-reduce that has not been waited for
 
     def wait(self):
@@ -67,8 +76,10 @@ class GradBucket:
                 self.flat.div_(div)
 
     def allreduce(self, group=None, average=False, async_op=False):
-        """Pack (ONE concatenation kernel), all-reduce, and hand the reduced values back as views of the flat buffer
-        (no copy-back kernels: at a sub-millisecond step a dozen 5 us copies would cost more than the collective).
+        """All-reduce the gradients as one flat buffer. When they already lie side by side (one conv layer: its backward
+        writes them so) that memory is reduced in place with no packing at all; otherwise they are packed with ONE
+        concatenation kernel and handed back as views of the bucket's buffer (no copy-back kernels: at a sub-millisecond
+        step a dozen 5 us copies would cost more than the collective).
 
         async_op=True returns right after the collective is enqueued on its own stream: what the caller launches next
         (the next step's grid build / neighbour search / forward pass) overlaps with it, and wait() -- or the next
@@ -76,24 +87,36 @@ class GradBucket:
         if not self.params:
             return
         self.wait()  # the flat buffer is about to be overwritten
-        p0 = self.params[0]
-        if self.flat is None or self.flat.device != p0.device:
-            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
-        base = self.flat.untyped_storage().data_ptr()
-        if all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params):
-            pass  # gradients were accumulated in place into the views handed out last time: already packed
-        elif all(p.grad is not None and p.grad.untyped_storage().data_ptr() != base for p in self.params):
-            torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
+        grads = [p.grad for p in self.params]
+        g0 = grads[0]
+        repoint = False
+        if (g0 is not None and g0.dtype == torch.float32 and
+                all(g is not None and g.data_ptr() == g0.data_ptr() + o and g.is_contiguous()
+                    for g, o in zip(grads, self.offsets))
+                and g0.untyped_storage().nbytes() - 4 * g0.storage_offset() >= 4 * self.numel):
+            # the gradients already lie side by side in parameter order -- spatial_conv's backward writes a layer's six
+            # tensors as slices of one buffer, and the views handed out below are accumulated into in place: reduce that
+            # memory as it is. (Host time matters: a pipelined step is host-bound, a dozen tensor ops are 0.1 ms.)
+            self.flat = torch.as_strided(g0, (self.numel,), (1,))
         else:
-            off = 0
-            for p in self.params:
-                n = p.numel()
-                if p.grad is None:
-                    self.flat[off:off + n].zero_()
-                elif p.grad.untyped_storage().data_ptr() != base:
-                    self.flat[off:off + n].copy_(p.grad.reshape(-1))
-                off += n
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            p0 = self.params[0]
+            if self.own is None or self.own.device != p0.device:
+                self.own = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
+            self.flat = self.own
+            repoint = True
+            base = self.flat.untyped_storage().data_ptr()
+            if all(g is not None and g.untyped_storage().data_ptr() != base for g in grads):
+                torch.cat([g.reshape(-1) for g in grads], out=self.flat)  # ONE concatenation kernel
+            else:
+                off = 0
+                for p, g in zip(self.params, grads):
+                    n = p.numel()
+                    if g is None:
+                        self.flat[off:off + n].zero_()
+                    elif g.untyped_storage().data_ptr() != base or g.data_ptr() != self.flat.data_ptr() + 4 * off:
+                        self.flat[off:off + n].copy_(g.reshape(-1))
+                    off += n
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.single_rank):
             div = dist.get_world_size(group) if average else 1
             if async_op:
                 self.pending = (dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=True), div)
@@ -101,11 +124,12 @@ class GradBucket:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
                 if div != 1:
                     self.flat.div_(div)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        if repoint:
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                p.grad = self.flat[off:off + n].view_as(p)
+                off += n
         # the views stay valid until the next allreduce(): a caller that keeps gradients across steps must clone them
 
 

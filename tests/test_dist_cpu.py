@@ -74,6 +74,22 @@ def _worker(rank, world, port, q):
             p.grad = torch.full(p.shape, 1.0)
         bucket.allreduce()
         got += [p.grad.clone() for p in params]
+        # gradients that already lie side by side in one buffer (what spatial_conv's backward hands to autograd) are
+        # reduced where they are: no packing, the tensors are not re-pointed
+        ext = torch.full((bucket.numel + 5,), float(rank + 1))[5:]  # with a storage offset, as a slice of a larger pool
+        off = 0
+        for p in params:
+            p.grad = ext[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        before = [p.grad for p in params]
+        bucket.allreduce(async_op=True)
+        bucket.wait()
+        assert all(p.grad is b for p, b in zip(params, before)) and bucket.flat.data_ptr() == ext.data_ptr()
+        assert bool((ext == 3.0).all())
+        # ... and a buffer that is too short, or out of order, takes the packing path
+        params[0].grad, params[1].grad = torch.ones(3, 16), torch.ones(16)
+        bucket.allreduce()
+        assert bucket.flat is bucket.own and bool((params[0].grad == 2.0).all()) and bool((params[5].grad == 6.0).all())
         mn = torch.tensor([[0.0 + rank, -1.0, 2.0 - rank]])
         mx = torch.tensor([[5.0 + rank, 4.0, 9.0 - rank]])
         mn, mx = allreduce_aabb(mn, mx)

@@ -126,3 +126,27 @@ def test_two_shards_equal_the_single_process_batch(mc):
         # all-reduced kernel-MLP gradients == single-process gradients
         for k, g in grads.items():
             assert np.abs(g - full_g[k]).max() <= 1e-4 * max(np.abs(full_g[k]).max(), 1e-30), k
+
+
+def test_bench_through_rccl_with_one_rank(mc):
+    """The N > 1 code path of bench.py (RCCL init with device_id, whole-batch box all-reduce, the asynchronous gradient
+    all-reduce under the next step's kernels, barriers, max-over-ranks timing) on the one GPU of this box: a process
+    group of a single nccl rank (MCCNN_BENCH_FORCE_PG=1). Pipelined steps must survive the all-reduce on RCCL's stream
+    and the points/s must be that of the plain run's order of magnitude."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MCCNN_BENCH_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "3", "--no-layers",
+                        "--no-breakdown", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # RCCL may print its version banner on stdout as well: the record is the one line that is a JSON object
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["config"]["collective_backend"] == "nccl" and rec["n_gpus"] == 1
+    assert rec["config"]["pipeline"] is not None and rec["config"]["pipelined_ms_per_step"] is not None
+    assert rec["value"] > 5e7
