@@ -264,29 +264,14 @@ __global__ __launch_bounds__(256) void pdf_edge_coords(const float* __restrict__
     sc[t] = make_float4(p[0], p[1], p[2], s);
 }
 
-// Mode 1, row form: one wave per centre. Lanes hold the row's own points (a), the loop runs over the row's points b
-// with x_b wave-uniform: scalar loads into SGPRs, no vector memory or LDS traffic in the inner loop and no divergence
-// between rows of different length (a thread per edge walks its row with one gather per pair and idles while a
-// longer row in the same wave finishes: 136 -> 100 us on the 100k room). Same arithmetic and summation order as the
-// thread-per-edge form it replaced: identical results. (Reading the pre-scaled coordinates per POINT through the
-// neighbour index instead of the per-edge copy makes the scalar loads dependent: measured slower, 124 us.)
-__global__ __launch_bounds__(256) void pdf_rows(const float4* __restrict__ sc, const int* __restrict__ startIdx, int m,
-                                                int e, float window, float* __restrict__ pdfs,
-                                                const int* __restrict__ eDev) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= m) return;
-    const int cap = e;
-    if (eDev) e = min(e, max(*eDev, 0));
-    const int lane = threadIdx.x & 63;
-    const int i0 = __builtin_amdgcn_readfirstlane(startIdx[row]);
-    int i1 = __builtin_amdgcn_readfirstlane((row < m - 1) ? startIdx[row + 1] : e);
-    if (eDev) i1 = min(i1, cap);  // a capacity below the true total: rows are cut, the caller repeats with the exact size
-    const int k = i1 - i0;
-    if (k <= 0) return;
-    const float invH = 1.0f / window;
-    const float g1 = invH * 0.39894228f;
-    const float norm = g1 * g1 * g1;
-    const float4* __restrict__ rowp = sc + i0;
+// One row of the KDE with the row's points (a) in the lanes and its points (b) wave-uniform: scalar loads into SGPRs,
+// no vector memory or LDS traffic in the pair loop, no divergence between rows of different length (a thread per edge
+// walks its row with one gather per pair and idles while a longer row in the same wave finishes: 136 -> 100 us on the
+// 100k room). Same arithmetic and summation order as the thread-per-edge form it replaced: identical results. (Reading
+// the pre-scaled coordinates per POINT through the neighbour index instead of the per-edge copy makes the scalar loads
+// dependent: measured slower, 124 us.)
+__device__ __forceinline__ void pdf_row_scalar(const float4* __restrict__ rowp, int k, int i0, int i1, int lane, float norm,
+                                               float* __restrict__ pdfs) {
     for (int a0 = 0; a0 < k; a0 += 64) {
         const int a = a0 + lane;
         const float4 me = rowp[min(a, k - 1)];
@@ -311,6 +296,156 @@ __global__ __launch_bounds__(256) void pdf_rows(const float4* __restrict__ sc, c
             acc += __builtin_amdgcn_exp2f(c * fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
         }
         if (a < k) pdfs[i0 + a] = (acc * norm) / ((float)i1 - i0);
+    }
+}
+
+// Mode 2, row form on the VALU only: one wave per centre.
+__global__ __launch_bounds__(256) void pdf_rows(const float4* __restrict__ sc, const int* __restrict__ startIdx, int m,
+                                                int e, float window, float* __restrict__ pdfs,
+                                                const int* __restrict__ eDev) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const int cap = e;
+    if (eDev) e = min(e, max(*eDev, 0));
+    const int lane = threadIdx.x & 63;
+    const int i0 = __builtin_amdgcn_readfirstlane(startIdx[row]);
+    int i1 = __builtin_amdgcn_readfirstlane((row < m - 1) ? startIdx[row + 1] : e);
+    if (eDev) i1 = min(i1, cap);  // a capacity below the true total: rows are cut, the caller repeats with the exact size
+    const int k = i1 - i0;
+    if (k <= 0) return;
+    const float invH = 1.0f / window;
+    const float g1 = invH * 0.39894228f;
+    pdf_row_scalar(sc + i0, k, i0, i1, lane, g1 * g1 * g1, pdfs);
+}
+
+// Mode 1, the pair sums as a Gram matrix on the matrix cores: one wave per centre, v_mfma_f32_16x16x4_f32 per 16 x 16
+// tile of pairs. With u = (p - o) s sqrt(log2(e) / 2), o = the row's first point (every point of a row lies within 2 R of
+// it, so |u| <= 2 / h and the subtraction p - o of nearby floats is (nearly) exact -- a scene 500 m from the origin costs
+// nothing) and q = |u|^2:
+//     |u_i - u_j|^2 = [u_i, 1] . [-2 u_j, q_j] + q_i      (K = 4: one instruction, q_i rides in as the C operand)
+// and the weight is exp2(-that): per PAIR one v_exp_f32 and one add on the VALU instead of the nine instructions of the
+// scalar-broadcast loop, and a row of 45 points fills 88 % of its 3 x 3 tiles where it filled 70 % of 64 lanes. Error
+// against the subtract-first form: <= 1e-5 relative per value (|u|^2 <= 300, measured 9e-6 worst over rows up to 120
+// points; tests hold 1e-4 against the oracle). Operands are staged per wave in LDS as planes ([ux uy uz 1] for A,
+// [-2ux -2uy -2uz q] for B; rows of the last tile beyond k carry q = 3e38, whose weights underflow to exactly 0).
+// Rows longer than MCCNN_PDF_CAP points take the scalar loop.
+#define MCCNN_PDF_CAP 192
+#define MCCNN_PDF_ROWS 4  // consecutive rows per wave: the next row's points are requested while this row's tiles run
+typedef float pdf_v4f __attribute__((ext_vector_type(4)));
+#if defined(MCCNN_PDF_ABL) && MCCNN_PDF_ABL == 1   // timing ablations only (wrong results): 1 no exponentials, 2 no tiles, 3 no MFMA
+#define PDF_EXP(x) (x)
+#else
+#define PDF_EXP(x) __builtin_amdgcn_exp2f(x)
+#endif
+#if defined(MCCNN_PDF_ABL) && MCCNN_PDF_ABL == 3
+#define PDF_MFMA(a, b, c) ((c) * (a) + (b))
+#else
+#define PDF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#endif
+__global__ __launch_bounds__(256) void pdf_rows_mfma(const float4* __restrict__ sc, const int* __restrict__ startIdx, int m,
+                                                     int e, float window, float* __restrict__ pdfs,
+                                                     const int* __restrict__ eDev) {
+    __shared__ __attribute__((aligned(16))) float planes[4][4 * MCCNN_PDF_CAP];  // per wave: ux, uy, uz, q
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform: rows, tile counts and loops live in SGPRs
+    const int r0 = (blockIdx.x * 4 + wave) * MCCNN_PDF_ROWS;
+    if (r0 >= m) return;
+    const int nr = min(MCCNN_PDF_ROWS, m - r0);
+    const int cap = e;
+    if (eDev) e = min(e, max(*eDev, 0));
+    // row bounds of this wave's rows in lanes 0..nr (a capacity below the true total cuts rows: the caller repeats)
+    int stv = e;
+    if (lane <= nr && r0 + lane < m) stv = startIdx[r0 + lane];
+    stv = min(stv, cap);
+    const float invH = 1.0f / window;
+    const float g1 = invH * 0.39894228f;
+    const float norm = g1 * g1 * g1;
+    float* __restrict__ P = planes[wave];
+    const int c = lane >> 4, mm = lane & 15;
+    const float* __restrict__ pa = P + (c & 3) * MCCNN_PDF_CAP + mm;   // component c of point 16 t + mm (c = 3: q)
+    const float* __restrict__ pq = P + 3 * MCCNN_PDF_CAP + 4 * c;      // q of points 16 t + 4 c + (0..3)
+    const float bscale = (c == 3) ? 1.0f : -2.0f;
+
+    int i0 = __builtin_amdgcn_readlane(stv, 0), i1 = __builtin_amdgcn_readlane(stv, 1);
+    float4 nxt = sc[max(min(i0 + lane, i1 - 1), 0)];
+    for (int rr = 0; rr < nr; ++rr) {
+        const float4 me = nxt;
+        const int k = i1 - i0, rowStart = i0, rowEnd = i1;
+        if (rr + 1 < nr) {
+            i0 = i1;
+            i1 = __builtin_amdgcn_readlane(stv, rr + 2);
+            nxt = sc[max(min(i0 + lane, i1 - 1), 0)];
+        }
+        if (k <= 0) continue;
+        const float4* __restrict__ rowp = sc + rowStart;
+        if (k > MCCNN_PDF_CAP) {
+            pdf_row_scalar(rowp, k, rowStart, rowEnd, lane, norm, pdfs);
+            continue;
+        }
+#if defined(MCCNN_PDF_ABL) && MCCNN_PDF_ABL == 2
+        const int T = 0;
+#else
+        const int T = (k + 15) >> 4;
+#endif
+        const float ox = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, me.x)));
+        const float oy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, me.y)));
+        const float oz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, me.z)));
+        for (int a0 = 0; a0 < 16 * T; a0 += 64) {
+            const int a = a0 + lane;
+            if (a < 16 * T) {
+                const float4 p = (a0 == 0) ? me : rowp[min(a, k - 1)];
+                const float sp = p.w * 0.84932180f;  // s sqrt(log2(e) / 2)
+                const float ux = (p.x - ox) * sp, uy = (p.y - oy) * sp, uz = (p.z - oz) * sp;
+                P[a] = ux;
+                P[MCCNN_PDF_CAP + a] = uy;
+                P[2 * MCCNN_PDF_CAP + a] = uz;
+                P[3 * MCCNN_PDF_CAP + a] = (a < k) ? fmaf(uz, uz, fmaf(uy, uy, ux * ux)) : 3.0e38f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float scale = norm / ((float)rowEnd - rowStart);  // one division per row
+        for (int J = 0; J < T; ++J) {
+            const float bop = pa[16 * J] * bscale;
+            float acc0 = 0.f, acc1 = 0.f;
+            int I = 0;
+            for (; I + 2 <= T; I += 2) {
+                const float v0 = pa[16 * I], v1 = pa[16 * I + 16];
+                const float a0 = (c == 3) ? 1.0f : v0, a1 = (c == 3) ? 1.0f : v1;
+                const pdf_v4f c0 = *reinterpret_cast<const pdf_v4f*>(pq + 16 * I);
+                const pdf_v4f c1 = *reinterpret_cast<const pdf_v4f*>(pq + 16 * I + 16);
+                const pdf_v4f d0 = PDF_MFMA(a0, bop, c0);
+                const pdf_v4f d1 = PDF_MFMA(a1, bop, c1);
+                acc0 += (PDF_EXP(-d0[0]) + PDF_EXP(-d0[1])) +
+                        (PDF_EXP(-d0[2]) + PDF_EXP(-d0[3]));
+                acc1 += (PDF_EXP(-d1[0]) + PDF_EXP(-d1[1])) +
+                        (PDF_EXP(-d1[2]) + PDF_EXP(-d1[3]));
+            }
+            if (I < T) {
+                const float v0 = pa[16 * I];
+                const float a0 = (c == 3) ? 1.0f : v0;
+                const pdf_v4f c0 = *reinterpret_cast<const pdf_v4f*>(pq + 16 * I);
+                const pdf_v4f d0 = PDF_MFMA(a0, bop, c0);
+                acc0 += (PDF_EXP(-d0[0]) + PDF_EXP(-d0[1])) +
+                        (PDF_EXP(-d0[2]) + PDF_EXP(-d0[3]));
+            }
+            // the four 16-lane groups hold the partial sums of four different quarter-sets of rows i: add them up with the
+            // two gfx950 row-swap instructions (VALU; a ds_bpermute pair is two LDS round trips per column block)
+            float acc = acc0 + acc1;
+            {   // (inline asm: with both operands the same value the builtin hands back the first result twice)
+                float lo = acc, hi = acc;
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+                acc = lo + hi;  // rows 0,1: x0 + x1; rows 2,3: x2 + x3
+                lo = acc;
+                hi = acc;
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+                acc = lo + hi;
+            }
+            const int a = 16 * J + mm;
+            if (c == 0 && a < k) pdfs[rowStart + a] = acc * scale;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -418,7 +553,10 @@ static int compute_pdf_impl(const float* sorted_pts, const int* sorted_batch_ids
         pdf_edge_coords<<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, e, aabb_min, aabb_max,
                                                         batch_size, window, radius, scale_inv, sc, e_dev);
         MCCNN_LAUNCHED();
-        pdf_rows<<<ceil_div(m, 4), 256, 0, s>>>(sc, start_idx, m, e, window, pdfs, e_dev);
+        if (mode == 2)
+            pdf_rows<<<ceil_div(m, 4), 256, 0, s>>>(sc, start_idx, m, e, window, pdfs, e_dev);
+        else
+            pdf_rows_mfma<<<ceil_div(m, 4 * MCCNN_PDF_ROWS), 256, 0, s>>>(sc, start_idx, m, e, window, pdfs, e_dev);
     }
     MCCNN_LAUNCHED();
     return 0;

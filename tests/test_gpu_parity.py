@@ -72,10 +72,15 @@ def test_grid_neighbors_pdf_poisson(mc, oracle, case):
                   pdf_kwargs=dict(mode=0))
     o = run_chain(oracle, _ident, _ident, pts, bids, feats, B, radius, scaleInv, poisson_radius=prad)
     compare_chain(g, o, pdf_rtol=2e-6)  # mode 0 replays the reference arithmetic
-    # mode 1 (single precision KDE) stays inside the feature-path tolerance
+    # the single-precision KDEs (mode 1: pair sums as Gram-matrix tiles on the matrix cores, the default; mode 2: the
+    # subtract-first VALU loop) stay inside the feature-path tolerance -- per VALUE, not only against the largest one
     h = g["_handles"]
-    fast = mc.compute_pdf(h["sP"], h["sB"], h["mn"], h["mx"], h["start"], h["packed"], 0.2, radius, B, scaleInv, mode=1)
-    assert_close(_unwrap(fast), o["pdfs"], RTOL, "pdfs(mode 1)")
+    for mode in (1, 2):
+        fast = _unwrap(mc.compute_pdf(h["sP"], h["sB"], h["mn"], h["mx"], h["start"], h["packed"], 0.2, radius, B,
+                                      scaleInv, mode=mode))
+        assert_close(fast, o["pdfs"], RTOL, "pdfs(mode %d)" % mode)
+        worst = float(np.max(np.abs(fast - o["pdfs"]) / np.abs(o["pdfs"]))) if fast.size else 0.0
+        assert worst <= RTOL, (mode, worst)
 
 
 def test_pdf_translated_cloud(mc, oracle):
@@ -88,9 +93,10 @@ def test_pdf_translated_cloud(mc, oracle):
     o = run_chain(oracle, _ident, _ident, pts, bids, feats, 2, 0.1, False)
     compare_chain(g, o, pdf_rtol=2e-6)
     h = g["_handles"]
-    fast = mc.compute_pdf(h["sP"], h["sB"], h["mn"], h["mx"], h["start"], h["packed"], 0.2, 0.1, 2, False, mode=1)
-    err = np.abs(_unwrap(fast) - o["pdfs"]).max() / np.abs(o["pdfs"]).max()
-    assert err <= 2e-5, err   # same error as at the origin (~1e-5), far inside RTOL
+    for mode in (1, 2):  # mode 1 takes the row's first point as origin before it scales: nothing lost either
+        fast = mc.compute_pdf(h["sP"], h["sB"], h["mn"], h["mx"], h["start"], h["packed"], 0.2, 0.1, 2, False, mode=mode)
+        err = np.abs(_unwrap(fast) - o["pdfs"]).max() / np.abs(o["pdfs"]).max()
+        assert err <= 2e-5, (mode, err)   # same error as at the origin (~1e-5), far inside RTOL
 
 
 def test_dense_cells(mc, oracle):
@@ -105,8 +111,20 @@ def test_dense_cells(mc, oracle):
     feats = rng.random((len(pts), 2), dtype=np.float32)
     g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, 1, 0.1, True, poisson_radius=0.1, pdf_kwargs=dict(mode=0))
     o = run_chain(oracle, _ident, _ident, pts, bids, feats, 1, 0.1, True, poisson_radius=0.1)
-    assert np.diff(np.append(o["startIndexs"][:, 0], len(o["packedNeighs"]))).max() > 800
+    klen = np.diff(np.append(o["startIndexs"][:, 0], len(o["packedNeighs"])))
+    assert klen.max() > 800
     compare_chain(g, o, pdf_rtol=2e-6)
+    # default KDE: rows of 65..192 points run several tiles per side, longer ones take the scalar loop
+    assert ((klen > 64) & (klen <= 192)).any() and (klen > 192).any()
+    _check_fast_pdf(mc, g["_handles"], o, 0.1, 1, True)
+
+
+def _check_fast_pdf(mc, h, o, radius, B, scaleInv):
+    for mode in (1, 2):
+        fast = _unwrap(mc.compute_pdf(h["sP"], h["sB"], h["mn"], h["mx"], h["start"], h["packed"], 0.2, radius, B,
+                                      scaleInv, mode=mode))
+        worst = float(np.max(np.abs(fast - o["pdfs"]) / np.abs(o["pdfs"])))
+        assert worst <= RTOL, (mode, worst)
 
 
 def test_room_absolute_radius(mc, oracle):
@@ -118,6 +136,7 @@ def test_room_absolute_radius(mc, oracle):
     g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, B, 0.1, False, poisson_radius=0.2, pdf_kwargs=dict(mode=0))
     o = run_chain(oracle, _ident, _ident, pts, bids, feats, B, 0.1, False, poisson_radius=0.2)
     compare_chain(g, o, pdf_rtol=2e-6)
+    _check_fast_pdf(mc, g["_handles"], o, 0.1, B, False)
 
 
 def test_pooling_centres_differ_from_points(mc, oracle):
