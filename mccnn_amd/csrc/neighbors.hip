@@ -329,8 +329,13 @@ __global__ __launch_bounds__(256) void pdf_rows(const float4* __restrict__ sc, c
 // points; tests hold 1e-4 against the oracle). Operands are staged per wave in LDS as planes ([ux uy uz 1] for A,
 // [-2ux -2uy -2uz q] for B; rows of the last tile beyond k carry q = 3e38, whose weights underflow to exactly 0).
 // Rows longer than MCCNN_PDF_CAP points take the scalar loop.
+#ifndef MCCNN_PDF_CAP
 #define MCCNN_PDF_CAP 192
-#define MCCNN_PDF_ROWS 4  // consecutive rows per wave: the next row's points are requested while this row's tiles run
+#endif
+#ifndef MCCNN_PDF_ROWS
+#define MCCNN_PDF_ROWS 4
+#endif
+// MCCNN_PDF_ROWS // consecutive rows per wave: the next row's points are requested while this row's tiles run
 typedef float pdf_v4f __attribute__((ext_vector_type(4)));
 #if defined(MCCNN_PDF_ABL) && MCCNN_PDF_ABL == 1   // timing ablations only (wrong results): 1 no exponentials, 2 no tiles, 3 no MFMA
 #define PDF_EXP(x) (x)
@@ -342,10 +347,53 @@ typedef float pdf_v4f __attribute__((ext_vector_type(4)));
 #else
 #define PDF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 #endif
-__global__ __launch_bounds__(256) void pdf_rows_mfma(const float4* __restrict__ sc, const int* __restrict__ startIdx, int m,
-                                                     int e, float window, float* __restrict__ pdfs,
+struct PdfPoint { float x, y, z; };
+__device__ __forceinline__ PdfPoint pdf_gather(const float* __restrict__ pts, int j) {
+    const float* p = pts + (size_t)j * 3;
+    return PdfPoint{p[0], p[1], p[2]};
+}
+
+// Row longer than the tile planes hold: subtract-first pair loop (the arithmetic of pdf_row_scalar) with the row staged
+// through the wave's LDS planes MCCNN_PDF_CAP points at a time (one broadcast ds_read_b128 per pair step).
+__device__ __noinline__ void pdf_row_long(const float* __restrict__ pts, const int2* __restrict__ rowpk, int k, int rowStart,
+                                          int lane, float s, float scale, float* __restrict__ P,
+                                          float* __restrict__ pdfs) {
+    float4* __restrict__ P4 = reinterpret_cast<float4*>(P);
+    const float cc = (-0.5f * 1.44269504088896f) * (s * s);
+    for (int a0 = 0; a0 < k; a0 += 64) {
+        const int a = a0 + lane;
+        const PdfPoint me = pdf_gather(pts, rowpk[min(a, k - 1)].x);
+        float acc = 0.f;
+        for (int b0 = 0; b0 < k; b0 += MCCNN_PDF_CAP) {
+            const int nb = min(MCCNN_PDF_CAP, k - b0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < nb; t += 64) {
+                const PdfPoint q = pdf_gather(pts, rowpk[b0 + t].x);
+                P4[t] = make_float4(q.x, q.y, q.z, 0.f);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int t = 0; t < nb; ++t) {
+                const float4 q = P4[t];
+                const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
+                acc += __builtin_amdgcn_exp2f(cc * fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+            }
+        }
+        if (a < k) pdfs[rowStart + a] = acc * scale;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void pdf_rows_mfma(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                     const int2* __restrict__ packed, const int* __restrict__ startIdx,
+                                                     int m, int e, const float* __restrict__ mn,
+                                                     const float* __restrict__ mx, int B, float window, float radius,
+                                                     int scaleInv, float* __restrict__ pdfs,
                                                      const int* __restrict__ eDev) {
-    __shared__ __attribute__((aligned(16))) float planes[4][4 * MCCNN_PDF_CAP];  // per wave: ux, uy, uz, q
+    __shared__ __attribute__((aligned(16))) float planes[4][5 * MCCNN_PDF_CAP];  // per wave: ux, uy, uz, q, ones
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform: rows, tile counts and loops live in SGPRs
     const int r0 = (blockIdx.x * 4 + wave) * MCCNN_PDF_ROWS;
     if (r0 >= m) return;
@@ -361,24 +409,57 @@ __global__ __launch_bounds__(256) void pdf_rows_mfma(const float4* __restrict__ 
     const float norm = g1 * g1 * g1;
     float* __restrict__ P = planes[wave];
     const int c = lane >> 4, mm = lane & 15;
-    const float* __restrict__ pa = P + (c & 3) * MCCNN_PDF_CAP + mm;   // component c of point 16 t + mm (c = 3: q)
-    const float* __restrict__ pq = P + 3 * MCCNN_PDF_CAP + 4 * c;      // q of points 16 t + 4 c + (0..3)
+    const float* __restrict__ pb = P + c * MCCNN_PDF_CAP + mm;                   // B: component c of point 16 t + mm (c = 3: q)
+    const float* __restrict__ pa = P + (c == 3 ? 4 : c) * MCCNN_PDF_CAP + mm;    // A: the same, with 1 in place of q
+    const float* __restrict__ pq = P + 3 * MCCNN_PDF_CAP + 4 * c;                // C: q of points 16 t + 4 c + (0..3)
     const float bscale = (c == 3) ? 1.0f : -2.0f;
+    for (int t = lane; t < MCCNN_PDF_CAP; t += 64) P[4 * MCCNN_PDF_CAP + t] = 1.0f;
+    // 1 / (R h): one value for all clouds with an absolute radius, per row otherwise
+    float sAbs = 0.f;
+    if (!scaleInv) sAbs = (float)(1.0 / (double)(radius * window));
 
+    // Two loads deep: the neighbour INDICES of row r + 1 and the POINTS of row r are requested one row ahead (the
+    // first 64 entries of a row; longer rows fetch the rest when they are staged).
+    // (An empty row requests nothing: with a device-side count of 0 not even packed[0] is a valid index.)
     int i0 = __builtin_amdgcn_readlane(stv, 0), i1 = __builtin_amdgcn_readlane(stv, 1);
-    float4 nxt = sc[max(min(i0 + lane, i1 - 1), 0)];
+    int jn = 0, bn = 0;
+    PdfPoint pn{0.f, 0.f, 0.f};
+    if (i1 > i0) {
+        jn = packed[min(i0 + lane, i1 - 1)].x;
+        pn = pdf_gather(pts, jn);
+        bn = bids[jn];
+    }
+    if (nr > 1) {
+        const int n1 = __builtin_amdgcn_readlane(stv, 2);
+        if (n1 > i1) jn = packed[min(i1 + lane, n1 - 1)].x;
+    }
     for (int rr = 0; rr < nr; ++rr) {
-        const float4 me = nxt;
-        const int k = i1 - i0, rowStart = i0, rowEnd = i1;
+        const PdfPoint me = pn;
+        const int bme = bn;
+        const int k = i1 - i0, rowStart = i0;
         if (rr + 1 < nr) {
             i0 = i1;
             i1 = __builtin_amdgcn_readlane(stv, rr + 2);
-            nxt = sc[max(min(i0 + lane, i1 - 1), 0)];
+            if (i1 > i0) {
+                pn = pdf_gather(pts, jn);
+                bn = bids[jn];
+            }
+            if (rr + 2 < nr) {
+                const int n1 = __builtin_amdgcn_readlane(stv, rr + 3);
+                if (n1 > i1) jn = packed[min(i1 + lane, n1 - 1)].x;
+            }
         }
         if (k <= 0) continue;
-        const float4* __restrict__ rowp = sc + rowStart;
+        const int2* __restrict__ rowpk = packed + rowStart;
+        // 1 / (R h) of the row's cloud (every neighbour of a centre lies in the centre's cloud)
+        float s = sAbs;
+        if (scaleInv) {
+            const int b0 = clamp_batch(__builtin_amdgcn_readfirstlane(bme), B);
+            s = (float)(1.0 / (double)((radius * max_extent(mn, mx, b0)) * window));
+        }
+        const float scale = norm * __builtin_amdgcn_rcpf((float)k);  // 1 ulp: this mode is not the bit-exact one
         if (k > MCCNN_PDF_CAP) {
-            pdf_row_scalar(rowp, k, rowStart, rowEnd, lane, norm, pdfs);
+            pdf_row_long(pts, rowpk, k, rowStart, lane, s, scale, P, pdfs);
             continue;
         }
 #if defined(MCCNN_PDF_ABL) && MCCNN_PDF_ABL == 2
@@ -389,11 +470,11 @@ __global__ __launch_bounds__(256) void pdf_rows_mfma(const float4* __restrict__ 
         const float ox = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, me.x)));
         const float oy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, me.y)));
         const float oz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, me.z)));
+        const float sp = s * 0.84932180f;  // s sqrt(log2(e) / 2)
         for (int a0 = 0; a0 < 16 * T; a0 += 64) {
             const int a = a0 + lane;
             if (a < 16 * T) {
-                const float4 p = (a0 == 0) ? me : rowp[min(a, k - 1)];
-                const float sp = p.w * 0.84932180f;  // s sqrt(log2(e) / 2)
+                const PdfPoint p = (a0 == 0) ? me : pdf_gather(pts, rowpk[min(a, k - 1)].x);
                 const float ux = (p.x - ox) * sp, uy = (p.y - oy) * sp, uz = (p.z - oz) * sp;
                 P[a] = ux;
                 P[MCCNN_PDF_CAP + a] = uy;
@@ -404,30 +485,27 @@ __global__ __launch_bounds__(256) void pdf_rows_mfma(const float4* __restrict__ 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float scale = norm / ((float)rowEnd - rowStart);  // one division per row
         for (int J = 0; J < T; ++J) {
-            const float bop = pa[16 * J] * bscale;
+            const float bop = pb[16 * J] * bscale;
             float acc0 = 0.f, acc1 = 0.f;
-            int I = 0;
-            for (; I + 2 <= T; I += 2) {
-                const float v0 = pa[16 * I], v1 = pa[16 * I + 16];
-                const float a0 = (c == 3) ? 1.0f : v0, a1 = (c == 3) ? 1.0f : v1;
+            // tile pairs at compile-time LDS offsets (no address arithmetic in the loop); T <= MCCNN_PDF_CAP / 16
+#pragma unroll
+            for (int I = 0; I < MCCNN_PDF_CAP / 16; I += 2) {
+                if (I + 2 > T) break;
+                const float a0 = pa[16 * I], a1 = pa[16 * I + 16];
                 const pdf_v4f c0 = *reinterpret_cast<const pdf_v4f*>(pq + 16 * I);
                 const pdf_v4f c1 = *reinterpret_cast<const pdf_v4f*>(pq + 16 * I + 16);
                 const pdf_v4f d0 = PDF_MFMA(a0, bop, c0);
                 const pdf_v4f d1 = PDF_MFMA(a1, bop, c1);
-                acc0 += (PDF_EXP(-d0[0]) + PDF_EXP(-d0[1])) +
-                        (PDF_EXP(-d0[2]) + PDF_EXP(-d0[3]));
-                acc1 += (PDF_EXP(-d1[0]) + PDF_EXP(-d1[1])) +
-                        (PDF_EXP(-d1[2]) + PDF_EXP(-d1[3]));
+                acc0 += (PDF_EXP(-d0[0]) + PDF_EXP(-d0[1])) + (PDF_EXP(-d0[2]) + PDF_EXP(-d0[3]));
+                acc1 += (PDF_EXP(-d1[0]) + PDF_EXP(-d1[1])) + (PDF_EXP(-d1[2]) + PDF_EXP(-d1[3]));
             }
-            if (I < T) {
-                const float v0 = pa[16 * I];
-                const float a0 = (c == 3) ? 1.0f : v0;
+            if (T & 1) {
+                const int I = T - 1;
+                const float a0 = pa[16 * I];
                 const pdf_v4f c0 = *reinterpret_cast<const pdf_v4f*>(pq + 16 * I);
                 const pdf_v4f d0 = PDF_MFMA(a0, bop, c0);
-                acc0 += (PDF_EXP(-d0[0]) + PDF_EXP(-d0[1])) +
-                        (PDF_EXP(-d0[2]) + PDF_EXP(-d0[3]));
+                acc0 += (PDF_EXP(-d0[0]) + PDF_EXP(-d0[1])) + (PDF_EXP(-d0[2]) + PDF_EXP(-d0[3]));
             }
             // the four 16-lane groups hold the partial sums of four different quarter-sets of rows i: add them up with the
             // two gfx950 row-swap instructions (VALU; a ds_bpermute pair is two LDS round trips per column block)
@@ -530,7 +608,7 @@ int mccnn_invert_permutation(const int* new_idx, int n, int* inv, mccnn_stream_t
 }
 
 size_t mccnn_compute_pdf_workspace_bytes(int e, int mode) {
-    return (mode != 0 && e > 0) ? align_up((size_t)e * sizeof(float4)) : 256;
+    return (mode == 2 && e > 0) ? align_up((size_t)e * sizeof(float4)) : 256;
 }
 
 static int compute_pdf_impl(const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx, int m,
@@ -548,15 +626,18 @@ static int compute_pdf_impl(const float* sorted_pts, const int* sorted_batch_ids
         pdf_edges_ref<<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, start_idx, m, pk, e, aabb_min,
                                                       aabb_max, batch_size, window, radius, scale_inv, pdfs);
     else {
-        if (!ws || ws_bytes < mccnn_compute_pdf_workspace_bytes(e, mode)) return MCCNN_E_WORKSPACE;
-        float4* sc = (float4*)ws;
-        pdf_edge_coords<<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, e, aabb_min, aabb_max,
-                                                        batch_size, window, radius, scale_inv, sc, e_dev);
-        MCCNN_LAUNCHED();
-        if (mode == 2)
+        if (mode == 2) {
+            if (!ws || ws_bytes < mccnn_compute_pdf_workspace_bytes(e, mode)) return MCCNN_E_WORKSPACE;
+            float4* sc = (float4*)ws;
+            pdf_edge_coords<<<ceil_div(e, 256), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, e, aabb_min, aabb_max,
+                                                            batch_size, window, radius, scale_inv, sc, e_dev);
+            MCCNN_LAUNCHED();
             pdf_rows<<<ceil_div(m, 4), 256, 0, s>>>(sc, start_idx, m, e, window, pdfs, e_dev);
-        else
-            pdf_rows_mfma<<<ceil_div(m, 4 * MCCNN_PDF_ROWS), 256, 0, s>>>(sc, start_idx, m, e, window, pdfs, e_dev);
+        } else {
+            pdf_rows_mfma<<<ceil_div(m, 4 * MCCNN_PDF_ROWS), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, start_idx, m, e,
+                                                                         aabb_min, aabb_max, batch_size, window, radius,
+                                                                         scale_inv, pdfs, e_dev);
+        }
     }
     MCCNN_LAUNCHED();
     return 0;
