@@ -151,8 +151,12 @@ int mccnn_invert_permutation(const int* new_idx, int n, int* inv, mccnn_stream_t
 /* ComputePDF -- compute_pdf.cc:25,57-142, compute_pdf.cu:40-119.
  * mode 0: the reference's arithmetic (double exp per axis, float rounding per
  *         statement, compute_pdf.cu:72-92);
- * mode 1: single-precision evaluation (one expf per pair); agrees with mode 0 to
- *         ~1e-6 relative, inside the 1e-4 tolerance of the feature path. */
+ * mode 1: single precision, the pair sums of a row as 16 x 16 Gram-matrix tiles on the
+ *         matrix cores (coordinates relative to the row's first point); agrees with
+ *         mode 0 to ~1e-5 relative per value, inside the 1e-4 tolerance of the feature
+ *         path; needs no workspace beyond the 256-byte minimum;
+ * mode 2: single precision on the VALU (subtract-first pair loop, ~1e-6 relative);
+ *         workspace: 16 bytes per edge. */
 size_t mccnn_compute_pdf_workspace_bytes(int e, int mode);
 int mccnn_compute_pdf(const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx,
                       int m, const int* packed, int e, const float* aabb_min, const float* aabb_max,
