@@ -306,6 +306,7 @@ class Workload:
         pairs = float((kk * kk).sum().item())
         breakdown["compute_pdf"]["pair_terms"] = int(pairs)
         breakdown["compute_pdf"]["gpairs_per_s"] = round(pairs / (t_pdf * 1e-3) / 1e9, 1)
+        breakdown["compute_pdf"]["bound"] = "valu+mfma issue (one v_exp_f32 per pair, one 16x16x4 MFMA per 256 pairs); GB/s of the 24 E algorithmic bytes for reference"
         dom = max(alg, key=lambda k: alg[k][2])
         bound, work, ms = alg[dom]
         peak = HBM_PEAK_GBS if bound == "hbm" else F32_PEAK_TFLOPS
