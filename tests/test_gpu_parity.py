@@ -405,3 +405,30 @@ def test_empty_inputs(mc):
     Bi = torch.zeros((0, 1), dtype=torch.int32).cuda()
     mn, mx = mc.compute_aabb(P, Bi, 2, True)
     assert np.all(_unwrap(mn) == np.finfo(np.float32).max) and np.all(_unwrap(mx) == -np.finfo(np.float32).max)
+
+
+def test_pdf_row_lengths_at_tile_and_plane_boundaries(mc, oracle):
+    """KDE rows of exactly k points for k around the 16-point tile edge, the 64-point gather chunk and the 192-point LDS
+    plane capacity of the matrix-core kernel (rows above it take its subtract-first loop): clusters of k points, each
+    inside a ball of diameter < r and far from the next one, so that every centre of a cluster has the whole cluster --
+    and nothing else -- as its row."""
+    ks = [1, 2, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 100, 127, 128, 129, 191, 192, 193, 257, 400]
+    rng = np.random.default_rng(23)
+    r = 0.1
+    pts = []
+    for n, k in enumerate(ks):
+        centre = np.array([0.5 * (n % 5), 0.5 * ((n // 5) % 5), 0.5 * (n // 25)]) + 0.05
+        d = rng.normal(size=(k, 3))
+        d *= (0.045 * rng.random((k, 1)) ** (1 / 3)) / np.linalg.norm(d, axis=1, keepdims=True)
+        pts.append(centre + d)
+    pts = np.concatenate(pts).astype(np.float32)
+    perm = rng.permutation(len(pts))
+    pts = pts[perm]
+    bids = np.zeros((len(pts), 1), np.int32)
+    feats = np.ones((len(pts), 1), np.float32)
+    g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, 1, r, False, pdf_kwargs=dict(mode=0))
+    o = run_chain(oracle, _ident, _ident, pts, bids, feats, 1, r, False)
+    klen = np.diff(np.append(o["startIndexs"][:, 0], len(o["packedNeighs"])))
+    assert sorted(set(klen.tolist())) == sorted(ks)
+    compare_chain(g, o, pdf_rtol=2e-6)
+    _check_fast_pdf(mc, g["_handles"], o, r, 1, False)
