@@ -172,3 +172,56 @@ def test_combin_feature_gradient_through_the_transposed_list(mc):
     assert np.array_equal(got[0], got[1])
     assert np.abs(got[0] - ref).max() <= 1e-5 * np.abs(ref).max()
     torch.cuda.synchronize()
+
+
+def test_pipeline_over_changing_batches(mc):
+    """A training loop's shape: every step convolves a DIFFERENT batch while the geometry of the next one is prefetched.
+    Batch sizes and edge counts change from step to step (the deferred search sizes its lists from the last total of
+    the same shape, so some guesses are too small and finalize() repairs them): every step must reproduce what the
+    same batch gives without any prefetch."""
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    rng = np.random.default_rng(9)
+    batches = []
+    for n_per, B, seed, kind in ((1500, 2, 31, "uniform"), (4000, 2, 32, "clustered"), (800, 2, 33, "uniform"),
+                                 (3000, 2, 34, "clustered"), (4000, 2, 35, "uniform")):
+        pts, bids = make_cloud(n_per, B, seed, kind, True)
+        P = torch.from_numpy(pts).cuda()
+        Bi = torch.from_numpy(bids).cuda()
+        F = torch.from_numpy(rng.random((len(pts), 1), dtype=np.float32)).cuda().requires_grad_(True)
+        og = torch.from_numpy(rng.random((len(pts), 16), dtype=np.float32)).cuda()
+        batches.append((PointHierarchy(P, F, Bi, [], "PH", B, False), F, og))
+    torch.manual_seed(5)
+    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=False)
+
+    def conv(ph, F, og):
+        F.grad = None
+        for p in builder.parameters():
+            p.grad = None
+        out = builder.create_convolution("Conv", ph, 0, F, 1, 0.12, outNumFeatures=16, multiFeatureConv=True)
+        out.backward(og)
+        return out
+
+    refs = []
+    for ph, F, og in batches:                      # no prefetch: the inline path, batch by batch
+        builder.reset()
+        out = conv(ph, F, og)
+        neigh = next(iter(builder.cacheNeighs_.values()))
+        refs.append((out.detach().clone(), F.grad.clone(), neigh[1].clone()))
+    order = [0, 1, 2, 3, 4, 1, 0, 4, 2, 3, 3, 0]
+    builder.reset()
+    builder.prefetch_geometry(batches[order[0]][0], 0, 0.12)
+    for step, b in enumerate(order):
+        ph, F, og = batches[b]
+        builder.reset()                            # installs the geometry prefetched for THIS batch
+        assert builder.prefetched_ is None and len(builder.cacheNeighs_) == 1 and len(builder.cachePDFs_) == 1
+        out = conv(ph, F, og)
+        assert len(builder.cacheNeighs_) == 1      # the convolution used the installed lists, it searched nothing itself
+        if step + 1 < len(order):
+            builder.prefetch_geometry(batches[order[step + 1]][0], 0, 0.12)   # under the kernels just launched
+        neigh = next(iter(builder.cacheNeighs_.values()))
+        assert torch.equal(neigh[1], refs[b][2]), (step, b)
+        assert torch.equal(out.detach(), refs[b][0]), (step, b)
+        scale = float(refs[b][1].abs().max())
+        assert float((F.grad - refs[b][1]).abs().max()) <= 1e-5 * scale, (step, b)
+    torch.cuda.synchronize()
