@@ -11,6 +11,8 @@ is called every forward pass (eager), so:
 """
 import math
 
+import os
+import sys
 import torch
 
 from .MCConvModule import (compute_aabb, sort_points_step1, sort_points_step2, sort_features, sort_features_back,
@@ -45,6 +47,9 @@ FUSED_HIERARCHY = True
 def _log(msg):
     if _VERBOSE:
         print(msg)
+
+
+_RECORD_STREAMS = os.environ.get("MCCNN_PREFETCH_RECORD_STREAM", "0") == "1"
 
 
 class PointHierarchy:
@@ -154,6 +159,8 @@ class ConvolutionBuilder:
         self.resetEvent_ = None
         self.prefetchTransposed_ = set()
         self.prefetchDummy_ = None
+        self.sideTensors_ = []      # tensors of the installed prefetch (allocated on the side stream), see __retire_side_tensors__
+        self.sideRecorded_ = 0      # how many of them needed the record_stream() fallback so far (tests)
 
     # ------------------------------------------------------------------ variable store
     def parameters(self):
@@ -203,6 +210,7 @@ class ConvolutionBuilder:
     def reset(self):
         """Drop the operation caches (MCConvBuilder.py:241-246). Variables are kept. Geometry parked by
         prefetch_geometry() since the last reset() becomes the new cache content."""
+        self.__retire_side_tensors__()
         self.cacheGrids_ = {}
         self.cacheNeighs_ = {}
         self.cachePDFs_ = {}
@@ -219,16 +227,54 @@ class ConvolutionBuilder:
             for d in (grids, neighs, pdfs):
                 for v in d.values():
                     for t in (v if isinstance(v, tuple) else (v,)):
-                        t.record_stream(main)  # allocated on the side stream, read (and kept by autograd) on this one
+                        if _RECORD_STREAMS:
+                            t.record_stream(main)
+                        else:
+                            self.sideTensors_.append(t)  # allocated on the side stream, read on this one: see below
             self.cacheGrids_, self.cacheNeighs_, self.cachePDFs_ = grids, neighs, pdfs
-            for kN, kG in self.prefetchTransposed_:
-                if kN in neighs and kG in grids and getattr(self.ops_, "_ops", 0) is None:
-                    from . import MCConvModule as _hip_ops
-                    _hip_ops.prefetch_transposed(neighs[kN][1], grids[kG][0].shape[0], self.sideStream_)
-            self.prefetchTransposed_ = set()
         if torch.cuda.is_available():
             self.resetEvent_ = torch.cuda.Event()
             self.resetEvent_.record()
+        if pf is not None:
+            for kN, kG in self.prefetchTransposed_:
+                if kN in neighs and kG in grids and getattr(self.ops_, "_ops", 0) is None:
+                    from . import MCConvModule as _hip_ops
+                    self.sideStream_.wait_event(self.resetEvent_)
+                    _hip_ops.prefetch_transposed(neighs[kN][1], grids[kG][0].shape[0], self.sideStream_)
+            self.prefetchTransposed_ = set()
+
+    def __retire_side_tensors__(self):
+        """Lifetime of the tensors prefetch_geometry() allocated on the side stream and the main stream reads.
+        Tensor.record_stream() would make the allocator record one event per block on the main stream when the block is
+        freed -- 8 blocks x 5.5 us of main-queue time between the backward pass of one step and the forward pass of the
+        next (0.66 -> 0.63 ms per step on the 100k room). Instead the builder is their last owner: it drops them HERE,
+        before reset() records the event every later piece of side-stream work waits for, so whatever reuses their memory
+        (only side-stream allocations can) runs after everything the main stream had been given by now. A tensor somebody
+        else still holds at this point (an autograd graph kept alive, a user variable) may get more readers later: that
+        one falls back to record_stream()."""
+        tensors, self.sideTensors_ = self.sideTensors_, []
+        if not tensors:
+            return
+        main = torch.cuda.current_stream()
+        extra = []
+        for t in tensors:  # the transposed lists built on the side stream live (and die) with their neighbour list
+            hit = getattr(t, "_mccnn_transposed", None)
+            if hit is not None:
+                extra.extend(hit[:2])
+        self.cacheGrids_ = self.cacheNeighs_ = self.cachePDFs_ = None  # the cache dictionaries' references go first
+        probe = hasattr(torch.Tensor, "_use_count")
+        while tensors:
+            t = tensors.pop()
+            # owners left: this frame (t) and getrefcount's argument on the Python side, the Python object on the C++ side
+            if not probe or sys.getrefcount(t) > 2 or t._use_count() > 1:
+                t.record_stream(main)
+                self.sideRecorded_ += 1
+            del t
+        for t in extra:
+            if not probe or t._use_count() > 1:
+                t.record_stream(main)
+                self.sideRecorded_ += 1
+        del extra
 
     def prefetch_geometry(self, inPointHierarchy, inPointLevel, convRadius, outPointHierarchy=None, outPointLevel=None,
                           KDEWindow=None, relativeRadius=None, usePDF=None, transposed=False):

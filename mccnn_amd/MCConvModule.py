@@ -216,8 +216,9 @@ def _transposed_neighbors(packed, n):
         ev = getattr(packed, "_mccnn_transposed_event", None)
         if ev is not None:  # built ahead of time on another stream (prefetch_transposed): order this stream behind it
             torch.cuda.current_stream().wait_event(ev)
-            for t in hit[:2]:
-                t.record_stream(torch.cuda.current_stream())
+            if os.environ.get("MCCNN_PREFETCH_RECORD_STREAM", "0") == "1":
+                for t in hit[:2]:
+                    t.record_stream(torch.cuda.current_stream())
             packed._mccnn_transposed_event = None
         return hit
     lib = _lib.load()
@@ -849,7 +850,7 @@ class _SpatialConv(torch.autograd.Function):
                   "spatial_conv(bf16)")
             ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3)
             ctx.state = None
-            ctx.packed_obj = packedNeighs if pk is packedNeighs else pk
+            ctx.packed_ref = weakref.ref(packedNeighs if pk is packedNeighs else pk)
             ctx.attrs = (numOutFeatures, bool(combin), batchSize, float(radius), bool(scaleInv), bool(avg))
             return out
         out = torch.empty((m, outF), dtype=torch.float32, device=pts.device)
@@ -866,7 +867,10 @@ class _SpatialConv(torch.autograd.Function):
                                          stream_handle()), "spatial_conv")
         ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3)
         ctx.state = state
-        ctx.packed_obj = packedNeighs if pk is packedNeighs else pk  # the builder's cached tensor object (see _transposed_neighbors)
+        # the builder's cached tensor OBJECT carries the transposed list (see _transposed_neighbors). A weak reference: the
+        # graph object outlives its backward pass (as long as the caller keeps the output or the loss), and a strong one
+        # would make the graph a co-owner of the list for that long (ConvolutionBuilder.__retire_side_tensors__)
+        ctx.packed_ref = weakref.ref(packedNeighs if pk is packedNeighs else pk)
         ctx.attrs = (numOutFeatures, bool(combin), batchSize, float(radius), bool(scaleInv), bool(avg))
         return out
 
@@ -891,12 +895,15 @@ class _SpatialConv(torch.autograd.Function):
         dw1, dw2, dw3 = dw1.view_as(w1), dw2.view_as(w2), dw3.view_as(w3)
         ws = _ws(lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, numOutFeatures, int(combin)), pts.device)
         start_t = perm_t = None
+        packed_obj = ctx.packed_ref()
+        if packed_obj is None:  # the list object is gone (its cache entry was dropped): the saved tensor has the same rows
+            packed_obj = pk
         if not combin and e > 0:
-            start_t, perm_t, _ = _transposed_neighbors(ctx.packed_obj, n)
-        elif combin and 2 <= fin <= 4 and e > 0 and getattr(ctx.packed_obj, "_mccnn_transposed", None) is not None:
+            start_t, perm_t, _ = _transposed_neighbors(packed_obj, n)
+        elif combin and 2 <= fin <= 4 and e > 0 and getattr(packed_obj, "_mccnn_transposed", None) is not None:
             # the transposed list exists already (prefetched with the geometry): the feature gradient is then gathered
             # through it instead of added with float atomics (deterministic, and cheaper than the atomics)
-            start_t, perm_t, _ = _transposed_neighbors(ctx.packed_obj, n)
+            start_t, perm_t, _ = _transposed_neighbors(packed_obj, n)
         if bf16:
             check(lib.mccnn_spatial_conv_bwd_bf16(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                                   ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),

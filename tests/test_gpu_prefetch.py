@@ -225,3 +225,48 @@ def test_pipeline_over_changing_batches(mc):
         scale = float(refs[b][1].abs().max())
         assert float((F.grad - refs[b][1]).abs().max()) <= 1e-5 * scale, (step, b)
     torch.cuda.synchronize()
+
+
+def test_side_stream_tensor_lifetime(mc):
+    """The prefetched tensors are allocated on the side stream and read on the main one. In the plain training loop the
+    builder is their last owner and drops them inside reset() (no record_stream(), no allocator events on the main
+    queue); a tensor that somebody else still holds at that point -- here: an autograd graph that has not run its
+    backward pass yet -- falls back to record_stream()."""
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    pts, bids = make_cloud(2000, 2, 41, "uniform", True)
+    rng = np.random.default_rng(8)
+    P = torch.from_numpy(pts).cuda()
+    Bi = torch.from_numpy(bids).cuda()
+    F = torch.from_numpy(rng.random((len(pts), 1), dtype=np.float32)).cuda().requires_grad_(True)
+    og = torch.from_numpy(rng.random((len(pts), 16), dtype=np.float32)).cuda()
+    ph = PointHierarchy(P, F, Bi, [], "PH", 2, True)
+    torch.manual_seed(6)
+    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True)
+
+    def conv():
+        return builder.create_convolution("Conv", ph, 0, F, 1, 0.15, outNumFeatures=16, multiFeatureConv=True)
+
+    builder.reset()
+    ref = conv()
+    ref.backward(og)
+    ref_grad = F.grad.clone()
+    for _ in range(4):                      # the plain loop: nothing needs the fallback
+        builder.prefetch_geometry(ph, 0, 0.15)
+        builder.reset()
+        F.grad = None
+        out = conv()
+        out.backward(og)
+        assert torch.equal(out.detach(), ref.detach())
+    assert builder.sideRecorded_ == 0
+    builder.prefetch_geometry(ph, 0, 0.15)
+    builder.reset()
+    F.grad = None
+    late = conv()                           # graph kept alive across the next reset(): it still owns the lists
+    builder.prefetch_geometry(ph, 0, 0.15)
+    builder.reset()
+    assert builder.sideRecorded_ > 0
+    late.backward(og)                       # reads the retired lists AFTER the reset
+    assert torch.equal(late.detach(), ref.detach())
+    assert float((F.grad - ref_grad).abs().max()) <= 1e-5 * float(ref_grad.abs().max())
+    torch.cuda.synchronize()
