@@ -283,7 +283,7 @@ class ConvolutionBuilder:
         parks them until the next reset(). Geometry depends on the points only, not on the network, so in a training
         loop the grid build / search / KDE of batch k + 1 runs under the convolution kernels of batch k: those hold
         two waves per SIMD (VGPR-bound) and leave issue slots and wave slots that the light geometry kernels fill
-        (100k room: 0.78 -> 0.66 ms per step). Call it after the backward pass of the current batch has been launched;
+        (100k room: 0.74 -> 0.63 ms per step). Call it after the backward pass of the current batch has been launched;
         several calls between two reset()s accumulate. transposed=True (depth-wise layers will convolve over this
         neighbour list): reset() also starts the list's transposition for their backward pass on the side stream, where
         it runs under the forward convolutions."""
