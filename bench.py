@@ -407,8 +407,8 @@ def cpu_baseline(wl, out_gpu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)   # 0.6 ms each: a 20-step region is too short to be stable
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=100000, help="points per room")
     ap.add_argument("--rooms-per-gpu", type=int, default=1, help="weak scaling: rooms on every rank")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
