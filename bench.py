@@ -11,8 +11,10 @@ drop-in builder API (mccnn_amd.MCConvBuilder.ConvolutionBuilder.create_convoluti
     bwd = spatial_conv_grad, sort_points_step2_grad            
 plus, for N > 1, ONE RCCL all-reduce of the flattened kernel-MLP weight gradients. The batch shards
 cloud-per-GPU; there is no data-path collective.
-    --scaling weak   (default) one 100k-point room per rank: the work grows with N
-    --scaling strong a fixed batch of --strong-rooms (8) rooms is split over the N ranks (BASELINE cfg4 at N = 8)
+    headline (`value`, `scaling: weak`): one 100k-point room per rank -- BASELINE cfg4 at N = 8
+    `strong` object: a fixed batch of --strong-rooms (8) rooms split over the N ranks (the north star's "strong scaling
+    on batched clouds"); measured in the same run, so the driver's per-N lines carry both curves.
+    --scaling weak|strong restricts the run to one of them (strong: the fixed batch becomes the headline).
 Inputs are synthetic and resident in HBM before the timed region. The timed region is bracketed by
 barrier + torch.cuda.synchronize() on both sides and the max over ranks is reported.
 
@@ -26,6 +28,10 @@ Rank 0 prints ONE JSON line (see README / DESIGN.md for the field contract), inc
   roofline     -- the dominant kernel's algorithmic flops (or bytes) / its HIP-event duration
   layers       -- the same measurement for all three layer shapes of SURVEY 8d (1to64, 3to8, dw256), so that the
                   headline shape cannot hide the depth-wise regime
+  configs      -- BASELINE.json configs cfg0..cfg4 (mccnn_amd.workloads): one step = PointHierarchy + forward +
+                  backward of EVERY convolution of the model's graph; points/s, launches per step, per-layer conv
+                  times with their rooflines, and the CPU port on a bounded sample of the same graph
+                  (--config cfgN: only that one; --no-configs: none)
   cpu_baseline -- the CPU oracle (OpenMP port of the reference algorithms; the reference's own ops
                   are GPU-only and cannot run on a CPU) timed on this box's host cores.
 """
@@ -50,7 +56,7 @@ LAYERS = {  # name: (Fin, Fout, combin)   -- SURVEY 8(d) layer shapes
 }
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector == f32 MFMA dense peak
-PROFILE_ROUND = "r02"    # profiles/<round>_pmc_traffic_<layer>.json supplies roofline.traffic
+PROFILE_ROUND = "r03"    # profiles/<round>_pmc_traffic_<layer>.json supplies roofline.traffic
 
 
 def log(*a):
@@ -77,10 +83,9 @@ def conv_work(which, fin, fout, combin, nb, n, m, e):
 
 
 def make_inputs(npts, seeds, layer, device, rank):
-    from tests.helpers import make_room
+    from mccnn_amd.workloads import rooms
     fin, fout, combin = LAYERS[layer]
-    pts = np.concatenate([make_room(npts, s) for s in seeds])
-    bids = np.repeat(np.arange(len(seeds), dtype=np.int32), npts).reshape(-1, 1)
+    pts, bids = rooms(npts, seeds)
     rng = np.random.default_rng(7 + rank)
     feats = (2 * rng.random((len(pts), fin)) - 1).astype(np.float32)
     outF = fout if combin else fin
@@ -124,9 +129,11 @@ class Workload:
         self.builder = ConvolutionBuilder(KDEWindow=args.window, relativeRadius=False)
         torch.manual_seed(1234)  # identical kernel-MLP weights on every rank
         self.bucket = None
+        self.params = []
         self.pipeline = False
         self.skip_allreduce = False
         self.out = self.step()  # creates the variables (strictly sequential step)
+        self.params = list(self.builder.parameters())
         ok = not getattr(args, "no_pipeline", False)
         if ok:
             # pipelined steps must reproduce the sequential forward output bit for bit (the forward is deterministic);
@@ -159,7 +166,7 @@ class Workload:
         a = self.args
         self.builder.reset()
         self.F.grad = None
-        for p in self.builder.parameters():
+        for p in self.params:
             p.grad = None
         out = self.builder.create_convolution("Conv", self.ph, 0, self.F, self.fin, a.radius, outNumFeatures=self.fout,
                                               multiFeatureConv=self.combin, KDEWindow=a.window)
@@ -170,14 +177,15 @@ class Workload:
             self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window, transposed=not self.combin)
         if self.dist_on and not self.skip_allreduce:
             if self.bucket is None:  # the variables exist after the first create_convolution
-                self.bucket = GradBucket(self.builder.parameters(), single_rank=True)
+                self.bucket = GradBucket(list(self.builder.parameters()), single_rank=True)
             # enqueued on RCCL's stream; the next step's grid build, search and forward pass run under it (the reduced
             # gradients are not read before the next pack, or the wait() that closes the timed region)
             self.bucket.allreduce(async_op=True)
         return out
 
     def timed(self, steps, warmup):
-        """K timed steps after W warm-up steps; barrier + synchronize on both sides; max over ranks."""
+        """K timed steps after W warm-up steps; barrier + synchronize on both sides; max over ranks. self.rank_stats holds
+        every rank's own loop time and how long it then waited for the last gradient all-reduce (a slow rank shows)."""
         for _ in range(max(warmup, 0)):
             self.step()
         if self.bucket is not None:
@@ -189,14 +197,18 @@ class Workload:
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
+        torch.cuda.current_stream().synchronize()  # this rank's own kernels
+        t_own = time.perf_counter() - t0
         if self.bucket is not None:
             self.bucket.wait()  # the last step's all-reduce finishes inside the timed region
         torch.cuda.synchronize()
+        t_wait = time.perf_counter() - t0 - t_own
         if self.dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         m_local = self.P.shape[0]
+        self.rank_stats = None
         if self.dist_on:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -204,6 +216,12 @@ class Workload:
             cnt = torch.tensor([m_local], dtype=torch.float64, device=self.device)
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
             m_total = float(cnt.item())
+            mine = torch.tensor([t_own / steps * 1e3, t_wait * 1e3, float(m_local)], dtype=torch.float64, device=self.device)
+            every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, mine)
+            self.rank_stats = {"own_ms_per_step": [round(float(t[0]), 4) for t in every],
+                               "allreduce_wait_ms_at_region_end": [round(float(t[1]), 4) for t in every],
+                               "points": [int(t[2]) for t in every]}
         else:
             m_total = float(m_local)
         return elapsed / steps * 1e3, m_total * steps / elapsed, m_total
@@ -314,6 +332,16 @@ class Workload:
         roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak,
                     "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                     "ms": round(ms, 4), "edges": e, "mlp_blocks": nb}
+        if bound == "hbm" and dom.startswith("spatial_conv_"):
+            # wide depth-wise layer on ONE room: its gathered rows (SURVEY 8d prices the layer by them) are Infinity-Cache
+            # hits, not HBM traffic (counter traffic is ~1/3 of the algorithmic bytes), so the HBM peak is the wrong
+            # yardstick: the kernel-MLP issue rate bounds the launch. `frac` is the MLP fraction of the f32 peak; the
+            # gather rate of the algorithmic bytes is kept beside it.
+            flops = (320.0 if dom.endswith("fwd") else 912.0) * nb * e
+            roofline.update({"bound": "cache-gather", "achieved": round(flops / (ms * 1e-3) / 1e12, 3), "peak": F32_PEAK_TFLOPS,
+                             "unit": "TFLOP/s (kernel MLP)", "frac": round(flops / (ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
+                             "gather_GBs_of_algorithmic_bytes": round(ach, 1),
+                             "gather_frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4)})
         if combin and fin == 1:
             # one-input-feature layers run the factored kernels (conv_f1.hip): layer 3 is applied per centre, so fewer
             # flops are EXECUTED than the algorithm of SURVEY 8d counts; `achieved` keeps the contract's algorithmic
@@ -322,6 +350,17 @@ class Workload:
             if dom in ex:
                 roofline["executed_tflops"] = round(ex[dom] / (ms * 1e-3) / 1e12, 3)
                 roofline["executed_frac"] = round(roofline["executed_tflops"] / peak, 4)
+            # never read the algorithmic fraction alone: both directions, algorithmic / executed / matrix-pipe busy
+            both = {}
+            for k, alg_f in (("spatial_conv_fwd", 320.0), ("spatial_conv_bwd", 912.0)):
+                t_ms = alg[k][2]
+                both[k[13:]] = {"ms": round(t_ms, 4),
+                                "algorithmic_frac": round(alg_f * nb * e / (t_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
+                                "executed_frac": round(ex[k] / (t_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4)}
+            roofline["fwd_bwd"] = both
+        busy = mfma_busy_from_profile(self.layer)
+        if busy is not None and a.points == 100000 and B == 1:
+            roofline["mfma_pipe_busy"] = busy
         # HBM-side bytes per launch of the dominant kernel come from the separate rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE passes of THIS command (tools/prof.sh), committed under profiles/ -- bench.py cannot collect
         # counters itself; null when the committed profile does not cover this workload.
@@ -333,6 +372,272 @@ class Workload:
                         roofline["traffic"] = int(tr["bytes"])
                         roofline["traffic_source"] = "profiles/" + os.path.basename(tfile)
         return roofline, breakdown
+
+
+class ConfigWorkload:
+    """One BASELINE.json configuration (mccnn_amd.workloads.CONFIGS): a step builds the PointHierarchy of the batch and
+    runs forward + backward of EVERY convolution of the model's graph through the builder -- shared grids / neighbour
+    lists / PDFs come from ConvolutionBuilder's caches exactly as in the reference's graph (MCConvBuilder.py:349-391).
+    The dense layers between the convolutions are not on the hot path: every convolution is fed seeded random features
+    and out-gradients of the shape the graph gives it (as tests/test_gpu_configs.py does)."""
+
+    def __init__(self, cfg, device, clouds=None, points=None):
+        from mccnn_amd.MCConvBuilder import ConvolutionBuilder
+        from mccnn_amd.workloads import config_points
+        from mccnn_amd import _lib
+        self.cfg, self.device = cfg, device
+        if points is not None:
+            self.pts_np, self.bids_np, self.B = points
+        else:
+            self.pts_np, self.bids_np, self.B = config_points(cfg, clouds)
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
+        self.P, self.Bi = t(self.pts_np), t(self.bids_np)
+        self.F0 = torch.ones((self.P.shape[0], 1), dtype=torch.float32, device=device)  # ModelNet.py:168
+        self.builder = ConvolutionBuilder(KDEWindow=0.25, relativeRadius=cfg.relative)
+        self.lib = _lib.load()
+        self.feats = self.ogs = None
+        torch.manual_seed(4321)
+        self.outs = self.step()  # creates variables, features and out-gradients
+        self.params = list(self.builder.parameters())
+
+    def hierarchy(self):
+        from mccnn_amd.MCConvBuilder import PointHierarchy
+        return PointHierarchy(self.P, self.F0, self.Bi, list(self.cfg.hierarchy), "PH_" + self.cfg.name, self.B,
+                              self.cfg.relative)
+
+    def _make_rows(self, ph):
+        self.feats_np, self.ogs_np, self.feats, self.ogs = [], [], [], []
+        for ci, c in enumerate(self.cfg.convs):
+            rng = np.random.default_rng(100 + ci)
+            n, m = int(ph.points_[c.lin].shape[0]), int(ph.points_[c.lout].shape[0])
+            outF = c.fout if c.combin else c.fin
+            f = (2 * rng.random((n, c.fin)) - 1).astype(np.float32)
+            g = (2 * rng.random((m, outF)) - 1).astype(np.float32)
+            ft, gt = torch.from_numpy(f).to(self.device), torch.from_numpy(g).to(self.device)
+            if c.bf16:
+                ft, gt = ft.to(torch.bfloat16), gt.to(torch.bfloat16)
+                f, g = ft.float().cpu().numpy(), gt.float().cpu().numpy()  # the CPU leg gets the same rounded values
+            self.feats_np.append(f)
+            self.ogs_np.append(g)
+            self.feats.append(ft.requires_grad_(True))
+            self.ogs.append(gt)
+
+    def conv(self, ph, ci):
+        c = self.cfg.convs[ci]
+        return self.builder.create_convolution(c.name, ph, c.lin, self.feats[ci], c.fin, c.radius, ph, c.lout, c.combin,
+                                               c.fout, c.window)
+
+    def step(self):
+        self.builder.reset()
+        ph = self.ph = self.hierarchy()
+        if self.feats is None:
+            self._make_rows(ph)
+        outs = [self.conv(ph, ci) for ci in range(len(self.cfg.convs))]
+        inputs = self.feats + list(self.builder.parameters())
+        # gradients of every convolution w.r.t. its features and its six kernel-MLP tensors, nothing accumulated
+        self.grads = torch.autograd.grad(outs, inputs, self.ogs, allow_unused=True)
+        return outs
+
+    def timed(self, steps, warmup):
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        l0 = self.lib.mccnn_debug_launch_count()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        launches = (self.lib.mccnn_debug_launch_count() - l0) / float(steps)
+        return el / steps * 1e3, launches
+
+    def per_layer(self, iters=5):
+        """HIP-event times of the hierarchy build and of every convolution's forward / backward with the geometry
+        cached (what the layer itself costs; the first use of a grid / neighbour list / PDF is in the step time)."""
+        def ev():
+            return torch.cuda.Event(enable_timing=True)
+        self.builder.reset()
+        t_h = []
+        for _ in range(iters):
+            torch.cuda.synchronize()
+            a, b = ev(), ev()
+            a.record()
+            ph = self.hierarchy()
+            b.record()
+            b.synchronize()
+            t_h.append(a.elapsed_time(b))
+        for ci in range(len(self.cfg.convs)):  # populate the caches
+            self.conv(ph, ci)
+        layers = []
+        for ci, c in enumerate(self.cfg.convs):
+            tf, tb = [], []
+            inputs = [self.feats[ci]] + [p for n_, p in self.builder.named_parameters() if n_.startswith(c.name + "_")]
+            for it in range(iters + 1):
+                torch.cuda.synchronize()
+                a, b, d = ev(), ev(), ev()
+                a.record()
+                out = self.conv(ph, ci)
+                b.record()
+                torch.autograd.grad([out], inputs, [self.ogs[ci]])
+                d.record()
+                d.synchronize()
+                if it:
+                    tf.append(a.elapsed_time(b))
+                    tb.append(b.elapsed_time(d))
+            keyG, keyN, _ = self.builder.__compute_dic_keys__(ph, ph, c.lin, c.lout, c.radius, c.window, self.cfg.relative, True)
+            e = int(self.builder.cacheNeighs_[keyN][1].shape[0])
+            n, m = int(ph.points_[c.lin].shape[0]), int(ph.points_[c.lout].shape[0])
+            nb = ((c.fin * c.fout if c.combin else c.fin) + 7) // 8
+            ent = {"name": c.name, "levels": [c.lin, c.lout], "radius": round(c.radius, 4), "fin": c.fin, "fout": c.fout,
+                   "combin": c.combin, "bf16_rows": c.bf16, "points_in": n, "centres": m, "edges": e, "mlp_blocks": nb,
+                   "fwd_ms": round(float(np.mean(tf)), 4), "bwd_ms": round(float(np.mean(tb)), 4)}
+            for which, ms in (("fwd", ent["fwd_ms"]), ("bwd", ent["bwd_ms"])):
+                flops = (320.0 if which == "fwd" else 912.0) * nb * e
+                rl = {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 3), "peak": F32_PEAK_TFLOPS,
+                      "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4)}
+                if conv_bound(c.fin, c.combin) == "hbm":
+                    _, byt = conv_work(which, c.fin, c.fout, c.combin, nb, n, m, e)
+                    if c.bf16:
+                        byt = byt - (e * 2 * c.fin if which == "fwd" else e * 6 * c.fin)  # half-width gathered rows
+                    rl["bound"] = "cache-gather"
+                    rl["gather_GBs_of_algorithmic_bytes"] = round(byt / (ms * 1e-3) / 1e9, 1)
+                ent["roofline_" + which] = rl
+            layers.append(ent)
+        return float(np.mean(t_h)), layers, [int(p.shape[0]) for p in ph.points_]
+
+
+def cpu_config(cw, sample_clouds, budget_s=8.0):
+    """The CPU port (oracle, OpenMP over centres) on a BOUNDED sample of the configuration -- the first `sample_clouds`
+    clouds (rooms: an x-slab with 1/16 of the points, same density) -- running the same graph: hierarchy op by op,
+    then every convolution forward + backward with grids / neighbour lists / PDFs shared like the builder's caches.
+    The GPU path runs the same sample once and every convolution output is compared (checker use of the oracle)."""
+    from oracle.oracle import Oracle
+    from mccnn_amd.workloads import config_points
+    cfg = cw.cfg
+    if cfg.cloud_kind == "room":
+        first = cw.pts_np[:cfg.points]
+        order = np.argsort(first[:, 0], kind="stable")
+        k = max(len(first) // 16, 1)
+        lo = (len(first) - k) // 2
+        sel = np.sort(order[lo:lo + k])
+        pts, bids, B = first[sel], np.zeros((k, 1), np.int32), 1
+        what = "x-slab of the first room holding 1/16 of its points (%d), same density" % k
+    else:
+        pts, bids, B = config_points(cfg, min(sample_clouds, cfg.clouds))
+        what = "the first %d of %d clouds (%d points)" % (B, cfg.clouds, len(pts))
+    gw = ConfigWorkload(cfg, cw.device, points=(pts, bids, B))
+    sd = {k_: v.detach().clone() for k_, v in cw.builder.state_dict().items()}
+    gw.builder.load_state_dict(sd)   # the same kernel-MLP variables as the timed workload
+    g_outs = [o.detach().float().cpu().numpy() for o in gw.step()]
+    torch.cuda.synchronize()
+    orc = Oracle(omp=True)
+    W = {k_: v.detach().cpu().numpy() for k_, v in sd.items()}
+    rel, f0 = cfg.relative, np.ones((len(pts), 1), np.float32)
+
+    def cpu_step():
+        mn, mx = orc.compute_aabb(pts, bids, B, rel)
+        lev = [(pts, bids)]
+        cp, cb, cf = pts, bids, f0
+        for r in cfg.hierarchy:      # MCConvBuilder.py:101-128
+            k_, i_ = orc.sort_points_step1(cp, cb, mn, mx, B, r, rel)
+            sp, sb, sf, cl = orc.sort_points_step2(cp, cb, cf, k_, i_, mn, mx, B, r, rel)
+            op, ob, oi = orc.poisson_sampling(sp, sb, cl, mn, mx, r, B, rel)
+            cf = orc.get_sampled_features(oi, sf)
+            orc.transform_indexs(oi, i_)
+            cp, cb = op, ob
+            lev.append((cp, cb))
+        grids, neighs, pdfs, outs = {}, {}, {}, []
+        for ci, c in enumerate(cfg.convs):     # MCConvBuilder.py:349-427
+            kg, kn = (c.lin, c.radius), (c.lin, c.radius, c.lout)
+            kp = kn + (c.window,)
+            ip, ib = lev[c.lin]
+            o_p, o_b = lev[c.lout]
+            if kg not in grids:
+                k_, i_ = orc.sort_points_step1(ip, ib, mn, mx, B, c.radius, rel)
+                sp, sb, sf, cl = orc.sort_points_step2(ip, ib, cw_feats[ci], k_, i_, mn, mx, B, c.radius, rel)
+                grids[kg] = (sp, sb, cl, i_)
+            else:
+                sf = orc.sort_features(cw_feats[ci], grids[kg][3])
+            sp, sb, cl, i_ = grids[kg]
+            if kn not in neighs:
+                neighs[kn] = orc.find_neighbors(o_p, o_b, sp, cl, mn, mx, c.radius, B, rel)
+            st, pk = neighs[kn]
+            if kp not in pdfs:
+                pdfs[kp] = orc.compute_pdf(sp, sb, mn, mx, st, pk, c.window, c.radius, B, rel)
+            nm = c.name
+            a_ = (sp, sf, sb, pdfs[kp], o_p, st, pk, mn, mx, W[nm + "_weights"], W[nm + "_weights2"].reshape(8, -1),
+                  W[nm + "_weights3"].reshape(8, -1), W[nm + "_biases"], W[nm + "_biases2"].reshape(-1),
+                  W[nm + "_biases3"].reshape(-1))
+            outs.append(orc.spatial_conv(*a_, c.fout, c.combin, B, c.radius, rel, True))
+            g_ = orc.spatial_conv_grad(*a_, cw_ogs[ci], c.fout, c.combin, B, c.radius, rel, True)
+            orc.sort_points_step2_grad(i_, np.zeros_like(sp), g_[0])
+        return outs
+
+    cw_feats, cw_ogs = gw.feats_np, gw.ogs_np
+    outs = cpu_step()  # warm-up (and the outputs the GPU sample is checked against)
+    ts = []
+    t0 = time.perf_counter()
+    while len(ts) < 3 and (not ts or time.perf_counter() - t0 < budget_s):
+        c0 = time.perf_counter()
+        cpu_step()
+        ts.append(time.perf_counter() - c0)
+    med = float(np.median(ts))
+    worst = 0.0
+    for ci, (go, co) in enumerate(zip(g_outs, outs)):
+        tol_scale = max(float(np.abs(co).max()), 1e-30)
+        worst = max(worst, float(np.abs(go - co).max() / tol_scale) if not cfg.convs[ci].bf16 else 0.0)
+    return {"value": round(len(pts) / med, 1), "unit": "points/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": "%s; median of %d steps after 1 warm-up, %.2f s per step" % (what, len(ts), med),
+            "gpu_vs_oracle_max_rel_err_f32_layers": float("%.3e" % worst)}
+
+
+def run_config(name, device, args, want_cpu):
+    from mccnn_amd.workloads import CONFIGS
+    cfg = CONFIGS[name]
+    cw = ConfigWorkload(cfg, device)
+    steps = {"cfg0": 200, "cfg1": 100, "cfg2": 40, "cfg3": 30, "cfg4": 30}[name]
+    ms, launches = cw.timed(steps, 5)
+    n = int(cw.P.shape[0])
+    t_h, layers, sizes = cw.per_layer()
+    ent = {"workload": cfg.what, "points": n, "clouds": cw.B, "level_sizes": sizes, "convolutions": len(cfg.convs),
+           "steps": steps, "ms_per_step": round(ms, 4), "value": round(n / (ms * 1e-3), 1), "unit": "points/s",
+           "library_launches_per_step": round(launches, 1), "hierarchy_ms": round(t_h, 4),
+           "conv_fwd_bwd_ms_cached_geometry": round(sum(l["fwd_ms"] + l["bwd_ms"] for l in layers), 4),
+           "layers": layers}
+    if want_cpu:
+        try:
+            ent["cpu_baseline"] = cpu_config(cw, {"cfg0": 1, "cfg1": 8, "cfg2": 4, "cfg3": 2, "cfg4": 1}[name])
+        except Exception as ex:  # informative; never fail the bench on it
+            ent["cpu_baseline"] = {"error": repr(ex)}
+    del cw
+    torch.cuda.empty_cache()
+    return ent
+
+
+def mfma_busy_from_profile(layer):
+    """Matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)) of the main forward /
+    backward kernels of `layer`, from the committed rocprofv3 --pmc pass of this command (tools/prof.sh); bench.py
+    cannot collect counters itself. None when the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "%s_kernels_%s.json" % (PROFILE_ROUND, layer))
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as fh:
+            ks = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    out = {}
+    for name, rec in ks.items():
+        if "mfma_busy" not in rec:
+            continue
+        if name.startswith(("f1_fwd_edges", "conv_stream")) and "fwd" not in out:
+            out["fwd"] = {"kernel": name.split("(")[0][:60], "busy": rec["mfma_busy"]}
+        if name.startswith(("f1_bwd_edges", "conv_bwd_mfma", "dw_bwd")) and "bwd" not in out:
+            out["bwd"] = {"kernel": name.split("(")[0][:60], "busy": rec["mfma_busy"]}
+    if not out:
+        return None
+    out["source"] = "profiles/" + os.path.basename(path)
+    return out
 
 
 def cpu_baseline(wl, out_gpu):
@@ -411,7 +716,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=100000, help="points per room")
     ap.add_argument("--rooms-per-gpu", type=int, default=1, help="weak scaling: rooms on every rank")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("both", "weak", "strong"), default="both",
+                    help="both (default): headline = weak (one room per rank), the fixed batch of --strong-rooms rooms split "
+                         "over the ranks is measured beside it (`strong` object); weak / strong: only that one")
     ap.add_argument("--strong-rooms", type=int, default=8, help="strong scaling: rooms in the fixed batch")
     ap.add_argument("--layer", choices=sorted(LAYERS), default="1to64")
     ap.add_argument("--radius", type=float, default=0.1)
@@ -419,6 +726,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-layers", action="store_true", help="skip the per-layer-shape measurements")
+    ap.add_argument("--config", choices=("cfg0", "cfg1", "cfg2", "cfg3", "cfg4"), default=None,
+                    help="measure only this BASELINE.json configuration in the `configs` object (default: all five)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE.json configuration measurements")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="strictly sequential steps. Default: the geometry (grid build, search, KDE) of batch k+1 runs on a "
                          "side stream under the convolutions of batch k (ConvolutionBuilder.prefetch_geometry); every step "
@@ -430,6 +740,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if world != args.gpus:
+        # the N > 1 path must be impossible to mis-run: --gpus N is only valid under a launcher that started N ranks
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d -- launch N > 1 as `python -m torch.distributed.run "
+                         "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`"
+                         % (args.gpus, world))
     # one process per GPU; MCCNN_BENCH_BACKEND=gloo lets several ranks share one GPU (single-GPU smoke test of the
     # N > 1 code path only -- the real runs use nccl == RCCL over xGMI)
     backend = os.environ.get("MCCNN_BENCH_BACKEND", "nccl")
@@ -448,8 +763,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
-    if world != args.gpus:
-        log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+        if dist.get_world_size() != world:
+            raise SystemExit("bench.py: process group of %d ranks, WORLD_SIZE %d" % (dist.get_world_size(), world))
 
     # one process per GPU: the autograd engine's per-device worker thread only adds a thread hand-off (~0.2 ms per
     # backward() call, more than a quarter of a step here); run the backward pass on the calling thread
@@ -462,11 +777,15 @@ def main():
     if dist_on:
         dist.barrier()
 
+    from mccnn_amd.dist import cloud_partition
+
+    def strong_seeds():
+        first, last = cloud_partition(args.strong_rooms, world)[rank]
+        return [20180601 + r for r in range(first, last)]
+
     # which rooms this rank owns: weak = its own rooms_per_gpu rooms; strong = its share of a fixed batch
     if args.scaling == "strong":
-        from mccnn_amd.dist import cloud_partition
-        first, last = cloud_partition(args.strong_rooms, world)[rank]
-        seeds = [20180601 + r for r in range(first, last)]
+        seeds = strong_seeds()
         if not seeds:
             raise SystemExit("--scaling strong needs --strong-rooms >= number of ranks")
     else:
@@ -485,13 +804,33 @@ def main():
         for name in sorted(LAYERS, reverse=True):  # the long one first: it carries the load through the ramp
             if name != args.layer:
                 others[name] = Workload(args, name, seeds, rank, world, device)
+    wl_strong = None
+    if args.scaling == "both" and args.strong_rooms >= world:
+        sseeds = strong_seeds()
+        if sseeds != seeds:  # (one rank of an 8-rank run with 8 rooms owns exactly its weak-scaling room)
+            wl_strong = Workload(args, args.layer, sseeds, rank, world, device)
     layers = None if args.no_layers else {}
     for name, w2 in others.items():
         ms, val, _ = w2.timed(max(args.steps // 2, 3), 2)
         layers[name] = {"ms_per_step": round(ms, 4), "value": round(val, 1), "unit": "points/s", "edges_per_gpu": w2.e_local}
 
+    # ------------------------------------------------------------------ strong scaling: the fixed batch split over the ranks
+    strong = None
+    if args.scaling == "both" and args.strong_rooms >= world:
+        sw = wl_strong if wl_strong is not None else wl
+        s_ms, s_val, s_total = sw.timed(max(args.steps // 4, 5) if wl_strong is not None else args.steps, 3)
+        strong = {"rooms": args.strong_rooms, "rooms_on_rank0": len(strong_seeds()), "points_total": int(s_total),
+                  "ms_per_step": round(s_ms, 4), "value": round(s_val, 1), "unit": "points/s", "scaling": "strong",
+                  "mode": "pipelined" if sw.pipeline else "sequential", "rank_stats": sw.rank_stats,
+                  "note": "fixed batch of %d rooms split cloud-per-GPU over %d rank(s); speed-up at N ranks = value(N) / "
+                          "value(1)" % (args.strong_rooms, world)}
+        if wl_strong is not None:
+            del wl_strong, sw
+            torch.cuda.empty_cache()
+
     # ------------------------------------------------------------------ the headline region
     ms_per_step, value, m_total = wl.timed(args.steps, max(args.warmup - 1, 0))
+    rank_stats = wl.rank_stats
     ms_sequential = ms_pipelined = None
     headline_mode = "sequential"
     if wl.pipeline:  # the same K steps strictly one after the other (nothing prefetched)
@@ -503,6 +842,7 @@ def main():
             # e.g. a slow host, or ranks sharing one GPU: the pipelined form is the host-heavier one. Both regions are
             # K timed steps of the same work; the faster one is the headline, the other is reported beside it.
             ms_per_step, value, headline_mode = ms_sequential, value_seq, "sequential"
+            rank_stats = wl.rank_stats
     if layers is not None:
         layers[args.layer] = {"ms_per_step": round(ms_per_step, 4), "value": round(value, 1), "unit": "points/s",
                               "edges_per_gpu": wl.e_local}
@@ -525,6 +865,17 @@ def main():
     others.clear()
     torch.cuda.empty_cache()
 
+    # ------------------------------------------------------------------ BASELINE.json configurations (rank 0, N == 1)
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        configs = {}
+        for name in ((args.config,) if args.config else ("cfg0", "cfg1", "cfg2", "cfg3", "cfg4")):
+            try:
+                configs[name] = run_config(name, device, args, not args.no_cpu_baseline)
+            except Exception as ex:
+                configs[name] = {"error": repr(ex)}
+                log("config %s failed: %r" % (name, ex))
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N == 1)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -544,7 +895,8 @@ def main():
             "metric": "MC-convolved points/sec (fwd+bwd), 100k-pt cloud r=0.1",
             "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.scaling == "strong" else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
             "config": {"workload": "ScanNet-like non-uniform room, %d pts/room, %d room(s) on rank 0, absolute radius %g, "
                                    "KDE window %g, same-level conv %s (Fin=%d, Fout=%d, %s), avg on"
                                    % (args.points, B, args.radius, args.window, args.layer, fin, fout,
@@ -557,8 +909,10 @@ def main():
                                     "them" if wl.pipeline else None),
                        "pipelined_ms_per_step": (round(ms_pipelined, 4) if ms_pipelined is not None else None),
                        "sequential_ms_per_step": (round(ms_sequential, 4) if ms_sequential is not None else None),
-                       "collective_backend": (backend if dist_on else None), "rccl_world_size": world},
-            "roofline": roofline, "cpu_baseline": cpu, "layers": layers, "breakdown": breakdown,
+                       "collective_backend": (backend if dist_on else None),
+                       "rccl_world_size": (dist.get_world_size() if dist_on else 1), "rank_stats": rank_stats},
+            "roofline": roofline, "cpu_baseline": cpu, "strong": strong, "layers": layers, "configs": configs,
+            "breakdown": breakdown,
         }
         try:  # RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION): push it out BEFORE the record
             import ctypes

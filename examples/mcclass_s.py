@@ -18,19 +18,19 @@ from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
 from mccnn_amd.MCNetworkUtils import (MLP_2_hidden, batch_norm_RELU_drop_out, conv_1x1, VariableStore)
 
 
-class MCClassS:
-    """models/MCClassS.py create_network(): 3 Poisson levels, 3 MC convolutions, global-feature MLP."""
+class MCClassS(torch.nn.Module):
+    """models/MCClassS.py create_network(): 3 Poisson levels, 3 MC convolutions, global-feature MLP. A torch.nn.Module
+    whose sub-modules (the convolution builder and the dense helpers' variable store) register every variable under
+    the reference's name, so `parameters()` / `state_dict()` / optimisers / DDP see the whole network."""
 
     def __init__(self, numInputFeatures, batchSize, k, numOutCat, device, ops=None):
+        super().__init__()
         self.args = (numInputFeatures, batchSize, k, numOutCat)
         self.store = VariableStore(device)
         self.ops = ops  # None = the HIP op surface; the parity tests pass the CPU checker's
         self.convBuilder = ConvolutionBuilder(KDEWindow=0.2, device=device, ops=ops)
 
-    def parameters(self):
-        return self.convBuilder.parameters() + self.store.parameters()
-
-    def __call__(self, points, batchIds, features, isTraining, keepProbConv=1.0, keepProbFull=0.5, useConvDropOut=False,
+    def forward(self, points, batchIds, features, isTraining, keepProbConv=1.0, keepProbFull=0.5, useConvDropOut=False,
                  useDropOutFull=True):
         numInputFeatures, batchSize, k, numOutCat = self.args
         st, mConvBuilder = self.store, self.convBuilder
@@ -59,19 +59,17 @@ class MCClassS:
         return finalLogits
 
 
-class MCNormS:
+class MCNormS(torch.nn.Module):
     """models/MCNormS.py create_network(): two same-level multi-feature convolutions (normal estimation)."""
 
     def __init__(self, numInputFeatures, batchSize, k, device, ops=None):
+        super().__init__()
         self.args = (numInputFeatures, batchSize, k)
         self.store = VariableStore(device)
         self.ops = ops
         self.convBuilder = ConvolutionBuilder(KDEWindow=0.2, device=device, ops=ops)
 
-    def parameters(self):
-        return self.convBuilder.parameters() + self.store.parameters()
-
-    def __call__(self, points, batchIds, features, isTraining):
+    def forward(self, points, batchIds, features, isTraining):
         numInputFeatures, batchSize, k = self.args
         cb = self.convBuilder
         cb.reset()

@@ -297,6 +297,10 @@ int mccnn_transform_indexs_dn(const int* in_idx, int s_cap, const int* s_dev, co
  * MCCNN_NO_F1 in the environment, read once. */
 int mccnn_debug_conv_impl(int mask);
 
+/* Diagnostics: number of kernel launches the library has issued in this process (all streams). bench.py prints the
+ * difference over one step: below ~50k points a step is bound by launches, not by the kernels. */
+long long mccnn_debug_launch_count(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,11 +52,37 @@ def _log(msg):
 _RECORD_STREAMS = os.environ.get("MCCNN_PREFETCH_RECORD_STREAM", "0") == "1"
 
 
-class PointHierarchy:
+def _storage_users(t):
+    """How many TensorImpls / wrappers share t's storage beyond what t itself accounts for (views made by anybody: a
+    user's slice of a cached list). A tensor that is itself a view (packed = buf[:e] inside find_neighbors) accounts for
+    its base as well. None when this torch build does not expose the count."""
+    fn = getattr(torch._C, "_storage_Use_Count", None)
+    if fn is None:
+        return None
+    try:
+        return int(fn(t.untyped_storage()._cdata)) - (1 if t._base is not None else 0)
+    except Exception:
+        return None
+
+
+def _storage_baseline():
+    """The count _storage_users() reports for a tensor nobody else shares (the probe's own wrapper included)."""
+    global _STORAGE_BASE
+    if _STORAGE_BASE is None:
+        _STORAGE_BASE = _storage_users(torch.empty(1)) or 0
+    return _STORAGE_BASE
+
+
+_STORAGE_BASE = None
+
+
+class PointHierarchy(torch.nn.Module):
     """Point hierarchy built by successive Poisson-disk sampling (MCConvBuilder.py:24-131).
 
     Attributes (same names as the reference): points_, features_, batchIds_, sampledIndexs_,
-    radiusList_, batchSize_, relativeRadius_, hierarchyName_, aabbMin_, aabbMax_.
+    radiusList_, batchSize_, relativeRadius_, hierarchyName_, aabbMin_, aabbMax_. A torch.nn.Module without parameters
+    (the reference's class holds none either); readyEvent_ (extension) is recorded on the stream that built the
+    hierarchy once all levels are enqueued -- ConvolutionBuilder.prefetch_geometry() orders its side stream behind it.
     """
 
     def __init__(self, inPoints, inFeatures, inBatchIds, radiusList, hierarchyName="Point_Hierarchy", batchSize=32,
@@ -66,7 +92,9 @@ class PointHierarchy:
         (`True` = the default group) and the MIN/MAX all-reduce of the box runs between compute_aabb and the first
         sort, so every level of the sharded hierarchy -- cells, keys, Poisson samples -- equals the corresponding
         slice of the single-device hierarchy (mccnn_amd.dist)."""
+        super().__init__()
         ops = _Ops(ops)
+        self.readyEvent_ = None
         self.points_ = [inPoints]
         self.features_ = [inFeatures]
         self.batchIds_ = [inBatchIds]
@@ -100,6 +128,7 @@ class PointHierarchy:
                     self.features_.append(currFeatures)
                     self.sampledIndexs_.append(transformedIndexs)
                     self.radiusList_.append(currRadius)
+                self.__mark_ready__()
                 return
 
         currPts, currFeatures, currBatchIds = inPoints, inFeatures, inBatchIds
@@ -121,6 +150,13 @@ class PointHierarchy:
             self.sampledIndexs_.append(transformedIndexs)
             self.radiusList_.append(currRadius)
             currPts, currBatchIds, currFeatures = sampledPts, sampledBatchsIds, sampledFeatures
+        self.__mark_ready__()
+
+    def __mark_ready__(self):
+        """Everything the hierarchy holds (points of every level, boxes) has been enqueued on the current stream."""
+        if getattr(self.points_[0], "is_cuda", False):
+            self.readyEvent_ = torch.cuda.Event()
+            self.readyEvent_.record()
 
 
 def _fan_avg_uniform_(t, fan_in, fan_out):
@@ -132,12 +168,16 @@ def _fan_avg_uniform_(t, fan_in, fan_out):
     return t
 
 
-class ConvolutionBuilder:
+class ConvolutionBuilder(torch.nn.Module):
     """Creates MC convolutions on point hierarchies, caching grids / neighbours / pdfs
-    (MCConvBuilder.py:133-427)."""
+    (MCConvBuilder.py:133-427). A torch.nn.Module: the kernel-MLP variables are registered parameters under the
+    reference's names (`<convName>_weights`, `_biases`, `_weights2`, ... MCConvBuilder.py:407-419), created on first use
+    of a convName (tf.get_variable semantics), so `parameters()`, `state_dict()`, `.to()`, optimisers and DDP wrappers
+    work on the builder as on any module; `forward` is create_convolution."""
 
     def __init__(self, multiFeatureConvs=False, KDEWindow=0.25, relativeRadius=True, usePDF=True, useAVG=True,
                  decayLossCollection='weight_decay_loss', device=None, ops=None):
+        super().__init__()
         self.ops_ = _Ops(ops)
         self.cacheGrids_ = {}
         self.cacheNeighs_ = {}
@@ -149,7 +189,6 @@ class ConvolutionBuilder:
         self.useAVG_ = useAVG
         self.decayLossCollection_ = decayLossCollection
         self.device_ = device
-        self.variables_ = {}        # name -> torch.nn.Parameter (tf.get_variable store)
         self.collections_ = {}      # collection name -> list of parameters (tf.add_to_collection)
         self.opTrace_ = None        # optional list the builder appends (op, key) records to (tests)
         # prefetch_geometry(): side stream, parked geometry (grids, neighbours, pdfs, event), the event of the last
@@ -163,34 +202,34 @@ class ConvolutionBuilder:
         self.sideRecorded_ = 0      # how many of them needed the record_stream() fallback so far (tests)
 
     # ------------------------------------------------------------------ variable store
-    def parameters(self):
-        return list(self.variables_.values())
-
-    def named_parameters(self):
-        return list(self.variables_.items())
+    @property
+    def variables_(self):
+        """name -> torch.nn.Parameter (the module's registered parameters: the tf.get_variable store)."""
+        return self._parameters
 
     def get_collection(self, name):
         return list(self.collections_.get(name, []))
 
-    def state_dict(self):
-        return {k: v.detach().clone() for k, v in self.variables_.items()}
-
-    def load_state_dict(self, sd):
-        for k, v in sd.items():
-            if k in self.variables_:
-                with torch.no_grad():
-                    self.variables_[k].copy_(v)
-            else:
-                self.variables_[k] = torch.nn.Parameter(v.detach().clone())
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """Variables are created lazily (first create_convolution of a convName): a checkpoint may name variables that
+        do not exist yet -- they are adopted as they are (also when a parent module's load_state_dict() recurses here)."""
+        for k, v in state_dict.items():
+            name = k[len(prefix):] if k.startswith(prefix) else None
+            if name and "." not in name and name not in self._parameters:
+                self.register_parameter(name, torch.nn.Parameter(v.detach().clone()))
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def _get_variable(self, name, shape, device, init):
-        p = self.variables_.get(name)
+        p = self._parameters.get(name)
         if p is None:
             p = torch.nn.Parameter(init(torch.empty(shape, dtype=torch.float32, device=device)))
-            self.variables_[name] = p
+            self.register_parameter(name, p)
         elif tuple(p.shape) != tuple(shape):
             raise RuntimeError("variable %s exists with shape %s, requested %s" % (name, tuple(p.shape), shape))
         return p
+
+    def forward(self, *args, **kwargs):
+        return self.create_convolution(*args, **kwargs)
 
     def _add_to_collection(self, name, p):
         lst = self.collections_.setdefault(name, [])
@@ -262,16 +301,20 @@ class ConvolutionBuilder:
             if hit is not None:
                 extra.extend(hit[:2])
         self.cacheGrids_ = self.cacheNeighs_ = self.cachePDFs_ = None  # the cache dictionaries' references go first
-        probe = hasattr(torch.Tensor, "_use_count")
+        # Is the builder the LAST owner? Exactly three counts answer that, and a build of torch that lacks one of them
+        # takes the always-correct record_stream() path: Python references to the tensor object (this frame + the
+        # probe's argument), C++ references to its TensorImpl (the Python object; a view of it holds one more), and
+        # TensorImpls over its STORAGE (views made by anybody: packed = buf[:e], a user's slice of a cached list).
+        probe = hasattr(torch.Tensor, "_use_count") and _storage_baseline() > 0
+        base = _storage_baseline()
         while tensors:
             t = tensors.pop()
-            # owners left: this frame (t) and getrefcount's argument on the Python side, the Python object on the C++ side
-            if not probe or sys.getrefcount(t) > 2 or t._use_count() > 1:
+            if not probe or sys.getrefcount(t) > 2 or t._use_count() > 1 or (_storage_users(t) or base + 1) > base:
                 t.record_stream(main)
                 self.sideRecorded_ += 1
             del t
         for t in extra:
-            if not probe or t._use_count() > 1:
+            if not probe or t._use_count() > 1 or (_storage_users(t) or base + 1) > base:
                 t.record_stream(main)
                 self.sideRecorded_ += 1
         del extra
@@ -303,12 +346,21 @@ class ConvolutionBuilder:
         pf = self.prefetched_
         grids, neighs, pdfs = (pf[0], pf[1], pf[2]) if pf is not None else ({}, {}, {})
         side = self.sideStream_
-        # the point hierarchy has to be complete before the side stream reads it: it waits for what the calling stream
-        # had been given up to the last reset() -- NOT for the convolutions launched since, which it is meant to overlap
-        if self.resetEvent_ is not None:
-            side.wait_event(self.resetEvent_)
-        else:
-            side.wait_stream(torch.cuda.current_stream())
+        # the point hierarchies have to be complete before the side stream reads them. Each records an event when its
+        # last level has been enqueued (PointHierarchy.readyEvent_): the side stream waits for exactly that -- NOT for the
+        # convolutions launched since, which it is meant to overlap. In a training loop reset() comes first and the next
+        # batch's hierarchy is built after it, so the event of the last reset() alone would not cover that work. A
+        # hierarchy without an event (built by other means) falls back to everything the calling stream holds now.
+        waited = False
+        for ph in ((inPointHierarchy,) if outPH is inPointHierarchy else (inPointHierarchy, outPH)):
+            ev = getattr(ph, "readyEvent_", None)
+            if ev is None:
+                side.wait_stream(torch.cuda.current_stream())
+                waited = True
+                break
+            side.wait_event(ev)
+        if not waited and self.resetEvent_ is not None:
+            side.wait_event(self.resetEvent_)  # memory retired at the last reset() is reused only behind it
         with torch.cuda.stream(side):
             if keyGrid not in grids:
                 keys, indexs = self.ops_.sort_points_step1(pts, bids, mn, mx, B, convRadius, currRelativeRadius)

@@ -12,6 +12,7 @@ raises InvalidArgumentError (the analogue of tf.errors.InvalidArgumentError).
 import ctypes as C
 import os
 import threading
+import time
 import weakref
 
 import torch
@@ -175,12 +176,28 @@ def _host_mailbox():
 # find_neighbors: True = the count kernel stores the edge total into the pinned mailbox and the host polls it;
 # False = total in device memory + an asynchronous copy + an event wait
 COUNT_MAILBOX = os.environ.get("MCCNN_COUNT_MAILBOX", "1") != "0"
-_MAILBOX_SPINS = 2000000  # ~0.1 s of polling, then a plain stream synchronisation
+_MAILBOX_SPIN_S = 200e-6  # tight polling for this long (the producing kernel retires within tens of microseconds) ...
+_MAILBOX_YIELD_S = 0.25   # ... then polling that hands the GIL to other threads between reads, then a synchronisation
 
 
 def _await_mailbox(view):
-    """Value a kernel of the current stream wrote to the mailbox (armed with -1 by the caller before the launch)."""
-    for _ in range(_MAILBOX_SPINS):
+    """Value a kernel of the current stream wrote to the mailbox (armed with -1 by the caller before the launch). The
+    tight spin is bounded by TIME: a data-loader or autograd thread of the same process is not starved for longer than
+    a fraction of a millisecond; after that every read is followed by time.sleep(0), which releases the GIL."""
+    v = int(view[0])
+    if v >= 0:
+        return v
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(64):
+            v = int(view[0])
+            if v >= 0:
+                return v
+        dt = time.perf_counter() - t0
+        if dt > _MAILBOX_SPIN_S:
+            break
+    while time.perf_counter() - t0 < _MAILBOX_YIELD_S:
+        time.sleep(0)
         v = int(view[0])
         if v >= 0:
             return v
@@ -219,7 +236,8 @@ def _transposed_neighbors(packed, n):
             if os.environ.get("MCCNN_PREFETCH_RECORD_STREAM", "0") == "1":
                 for t in hit[:2]:
                     t.record_stream(torch.cuda.current_stream())
-            packed._mccnn_transposed_event = None
+            # the event stays with the list: a later consumer on another stream has to wait for it, too (waiting for an
+            # event that has fired costs nothing on the queue)
         return hit
     lib = _lib.load()
     e = packed.shape[0]
@@ -716,8 +734,11 @@ def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batc
     _check_aabb(mn, mx, batchSize, op)
     lib = _lib.load()
     dev, cap, L = pts.device, pts.shape[0], len(radiusList)
-    if cap == 0 or L == 0:
+    if L == 0:
         return []
+    if cap == 0 or not POISSON_DATAFLOW:
+        return None  # an empty cloud, or the single-launch Poisson kernel switched off: the op-by-op chain handles it
+    pmode = 2 if POISSON_DATAFLOW == 2 else 1
     sizes = torch.empty(L + 1, dtype=torch.int32, device=dev)
     sizes[0] = cap
     i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
@@ -743,7 +764,7 @@ def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batc
         _req(wsb > 0, op + ": grid too large")
         wsp = _ws(wsb, dev)
         check(lib.mccnn_poisson_sampling_count(ptr(sP), ptr(sB), cap, ptr(cells), ptr(mn), ptr(mx), batchSize, nc,
-                                               float(radius), si, 1, ptr(s_dev), ptr(wsp), wsp.numel(), stream_handle()),
+                                               float(radius), si, pmode, ptr(s_dev), ptr(wsp), wsp.numel(), stream_handle()),
               "poisson_sampling(count)")
         oP, oB, oI, ti = f32(cap, 3), i32(cap, 1), i32(cap), i32(cap)
         check(lib.mccnn_poisson_sampling_fill(ptr(sP), cap, ptr(cells), batchSize, nc, cap, ptr(oP), ptr(oB), ptr(oI),

@@ -14,29 +14,39 @@ import torch
 import torch.distributed as dist
 
 
-class VariableStore:
-    """name -> torch.nn.Parameter / buffer; tf.get_variable + tf.add_to_collection semantics."""
+class VariableStore(torch.nn.Module):
+    """name -> torch.nn.Parameter / buffer; tf.get_variable + tf.add_to_collection semantics on a torch.nn.Module, so
+    that `parameters()`, `state_dict()`, `.to()`, optimisers and DDP wrappers see the variables under the reference's
+    names (`Reduce_1_weights`, `Final_Logits_BN_h1/gamma`, ...). Variables are created on first use (tf.get_variable),
+    so load_state_dict() also accepts names that do not exist yet."""
 
     def __init__(self, device=None):
+        super().__init__()
         self.device = device
-        self.variables_ = {}
-        self.buffers_ = {}
         self.collections_ = {}
 
+    @property
+    def variables_(self):
+        return self._parameters
+
+    @property
+    def buffers_(self):
+        return self._buffers
+
     def get_variable(self, name, shape, init, device=None):
-        p = self.variables_.get(name)
+        p = self._parameters.get(name)
         if p is None:
             p = torch.nn.Parameter(init(torch.empty(shape, dtype=torch.float32, device=device or self.device)))
-            self.variables_[name] = p
+            self.register_parameter(name, p)
         elif tuple(p.shape) != tuple(shape):
             raise RuntimeError("variable %s exists with shape %s, requested %s" % (name, tuple(p.shape), shape))
         return p
 
     def get_buffer(self, name, shape, fill, device=None):
-        b = self.buffers_.get(name)
+        b = self._buffers.get(name)
         if b is None:
             b = torch.full(shape, float(fill), dtype=torch.float32, device=device or self.device)
-            self.buffers_[name] = b
+            self.register_buffer(name, b)
         return b
 
     def add_to_collection(self, coll, p):
@@ -47,11 +57,17 @@ class VariableStore:
     def get_collection(self, coll):
         return list(self.collections_.get(coll, []))
 
-    def parameters(self):
-        return list(self.variables_.values())
-
-    def named_parameters(self):
-        return list(self.variables_.items())
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # lazily created variables: adopt what is not there yet (also when a parent module's load_state_dict() recurses
+        # into this one -- variable names hold no '.', so every key below `prefix` without one is this module's own)
+        for k, v in state_dict.items():
+            name = k[len(prefix):] if k.startswith(prefix) else None
+            if name and "." not in name and name not in self._parameters and name not in self._buffers:
+                if name.endswith("/moving_mean") or name.endswith("/moving_variance"):
+                    self.register_buffer(name, v.detach().clone())
+                else:
+                    self.register_parameter(name, torch.nn.Parameter(v.detach().clone()))
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
 
 _DEFAULT_STORE = VariableStore()

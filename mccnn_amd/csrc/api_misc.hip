@@ -1,11 +1,16 @@
 // Version / diagnostics entry points of libmccnn_hip.
 #include "common.h"
 
+namespace mccnn {
+std::atomic<long long> g_launches{0};
+}
+
 extern "C" {
 
 int mccnn_block_size(void) { return MCCNN_MLP; }
 int mccnn_abi_version(void) { return 4; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn
 const char* mccnn_arch(void) { return "gfx950"; }
+long long mccnn_debug_launch_count(void) { return mccnn::g_launches.load(std::memory_order_relaxed); }
 
 const char* mccnn_error_string(int code) {
     switch (code) {

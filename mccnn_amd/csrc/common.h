@@ -1,6 +1,7 @@
 // Shared host/device helpers of libmccnn_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cfloat>
 #include <cstdint>
 #include "mccnn.h"
@@ -13,13 +14,23 @@
         hipError_t e__ = (call);                \
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
+#define MCCNN_MEMSET(call)                      \
+    do {                                        \
+        ::mccnn::g_launches.fetch_add(1, std::memory_order_relaxed); \
+        MCCNN_HIP(call);                        \
+    } while (0)
 #define MCCNN_LAUNCHED()                        \
     do {                                        \
+        ::mccnn::g_launches.fetch_add(1, std::memory_order_relaxed); \
         hipError_t e__ = hipGetLastError();     \
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
 
 namespace mccnn {
+
+// kernel launches issued by the library so far (diagnostics: mccnn_debug_launch_count; the launch-bound small-batch
+// regime is measured in launches per step). Defined in api_misc.hip.
+extern std::atomic<long long> g_launches;
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

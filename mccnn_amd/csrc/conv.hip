@@ -1119,7 +1119,7 @@ static int conv_fwd_impl(const float* sorted_pts, const float* sorted_feats, con
         return 0;
     }
     if (e == 0) {
-        MCCNN_HIP(hipMemsetAsync(out, 0, (size_t)m * a.outF * (bf16 ? 2 : sizeof(float)), s));
+        MCCNN_MEMSET(hipMemsetAsync(out, 0, (size_t)m * a.outF * (bf16 ? 2 : sizeof(float)), s));
         return 0;
     }
     // fallback for very wide layers (nb > MCCNN_LDS_MAX_NB): VALU kernel with scalar-loaded weights
@@ -1193,7 +1193,7 @@ int mccnn_transpose_neighbors(const int* packed, int e, int n, int* start_t, int
     if (e < 0 || n < 0 || !start_t) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (e == 0 || n == 0) {
-        MCCNN_HIP(hipMemsetAsync(start_t, 0, (size_t)(n + 1) * sizeof(int), s));
+        MCCNN_MEMSET(hipMemsetAsync(start_t, 0, (size_t)(n + 1) * sizeof(int), s));
         return 0;
     }
     if (!packed || !perm_t) return MCCNN_E_BADARG;
@@ -1208,7 +1208,7 @@ int mccnn_transpose_neighbors(const int* packed, int e, int n, int* start_t, int
     int* cnt = (int*)blk;
     void* scanws = blk + cntBytes;
     const int2* pk = reinterpret_cast<const int2*>(packed);
-    MCCNN_HIP(hipMemsetAsync(blk, 0, cntBytes + scan_status_bytes(n), s));
+    MCCNN_MEMSET(hipMemsetAsync(blk, 0, cntBytes + scan_status_bytes(n), s));
     tr_count<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, cnt, slot);
     MCCNN_LAUNCHED();
     int rc = exclusive_scan_i32(cnt, start_t, n, start_t + n, scanws, s, true);
@@ -1265,14 +1265,14 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
     // (... and the transposed gather of combin layers with 2..4 input features writes every row)
     const bool gatherT = mfma && combin && a.Fin >= 2 && a.Fin <= 4 && start_t && perm_t && m > 0 && e > 0;
     if (n > 0 && !dfeatT && !f1Clears && !gatherT)
-        MCCNN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * (bf16 ? 2 : sizeof(float)), s));
+        MCCNN_MEMSET(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * (bf16 ? 2 : sizeof(float)), s));
     if (!mfma || m == 0 || e == 0) {
-        MCCNN_HIP(hipMemsetAsync(dw1, 0, 3 * nn * sizeof(float), s));
-        MCCNN_HIP(hipMemsetAsync(db1, 0, nn * sizeof(float), s));
-        MCCNN_HIP(hipMemsetAsync(dw2, 0, 8 * nn * sizeof(float), s));
-        MCCNN_HIP(hipMemsetAsync(db2, 0, nn * sizeof(float), s));
-        MCCNN_HIP(hipMemsetAsync(dw3, 0, 8 * nn * sizeof(float), s));
-        MCCNN_HIP(hipMemsetAsync(db3, 0, nn * sizeof(float), s));
+        MCCNN_MEMSET(hipMemsetAsync(dw1, 0, 3 * nn * sizeof(float), s));
+        MCCNN_MEMSET(hipMemsetAsync(db1, 0, nn * sizeof(float), s));
+        MCCNN_MEMSET(hipMemsetAsync(dw2, 0, 8 * nn * sizeof(float), s));
+        MCCNN_MEMSET(hipMemsetAsync(db2, 0, nn * sizeof(float), s));
+        MCCNN_MEMSET(hipMemsetAsync(dw3, 0, 8 * nn * sizeof(float), s));
+        MCCNN_MEMSET(hipMemsetAsync(db3, 0, nn * sizeof(float), s));
     }
     if (m == 0 || e == 0) return 0;
     if (!out_grad) return MCCNN_E_BADARG;

@@ -284,7 +284,7 @@ extern "C" {
 int mccnn_check_batch_ids(const int* batch_ids, int n, int batch_size, int* bad_count_dev, mccnn_stream_t stream) {
     if (n < 0 || batch_size <= 0 || !bad_count_dev || (n > 0 && !batch_ids)) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    MCCNN_HIP(hipMemsetAsync(bad_count_dev, 0, sizeof(int), s));
+    MCCNN_MEMSET(hipMemsetAsync(bad_count_dev, 0, sizeof(int), s));
     if (n == 0) return 0;
     check_bids<<<ceil_div(n, 256), 256, 0, s>>>(batch_ids, n, batch_size, bad_count_dev);
     MCCNN_LAUNCHED();
@@ -360,7 +360,7 @@ static int sort_step1_impl(const float* pts, const int* batch_ids, const float* 
     if (!blk || !start || !slot) return MCCNN_E_WORKSPACE;
     int* cnt = (int*)blk;
     void* scanws = blk + cntBytes;
-    MCCNN_HIP(hipMemsetAsync(blk, 0, cntBytes + scan_status_bytes((int)C), s));
+    MCCNN_MEMSET(hipMemsetAsync(blk, 0, cntBytes + scan_status_bytes((int)C), s));
     int blocks = ceil_div(n, 256);
     keys_hist<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, keys, cnt, new_idx, n_dev);
     MCCNN_LAUNCHED();
@@ -400,7 +400,7 @@ static int sort_step2_impl(const float* pts, const int* batch_ids, const float* 
     if (C >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
-        MCCNN_HIP(hipMemsetAsync(cell_indexs, 0, (size_t)C * 2 * sizeof(int), s));  // sort_gpu.cu:492
+        MCCNN_MEMSET(hipMemsetAsync(cell_indexs, 0, (size_t)C * 2 * sizeof(int), s));  // sort_gpu.cu:492
         return 0;
     }
     if (!pts || !batch_ids || !keys || !new_idx || !out_pts || !out_batch_ids || (num_feats > 0 && (!feats || !out_feats)))
@@ -457,7 +457,7 @@ int mccnn_permute_scatter(const float* in, const int* idx, int n_idx, int num_fe
     hipStream_t s = (hipStream_t)stream;
     if (zero_fill && n_out > 0) {
         if (!out) return MCCNN_E_BADARG;
-        MCCNN_HIP(hipMemsetAsync(out, 0, (size_t)n_out * num_feats * sizeof(float), s));
+        MCCNN_MEMSET(hipMemsetAsync(out, 0, (size_t)n_out * num_feats * sizeof(float), s));
     }
     if (n_idx == 0) return 0;
     if (!in || !idx || !out) return MCCNN_E_BADARG;

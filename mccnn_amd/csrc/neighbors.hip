@@ -562,7 +562,7 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
     if (m < 0 || n < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (m == 0) {
-        MCCNN_HIP(hipMemsetAsync(total_dev, 0, sizeof(int), s));
+        MCCNN_MEMSET(hipMemsetAsync(total_dev, 0, sizeof(int), s));
         return 0;
     }
     if (!centres || !centre_batch_ids || !cell_indexs || !aabb_min || !aabb_max || !start_idx || (n > 0 && !sorted_pts))

@@ -380,7 +380,7 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
     if (n < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
-        MCCNN_HIP(hipMemsetAsync(total_dev, 0, sizeof(int), s));
+        MCCNN_MEMSET(hipMemsetAsync(total_dev, 0, sizeof(int), s));
         return 0;
     }
     if (!sorted_pts || !cell_indexs || !aabb_min || !aabb_max) return MCCNN_E_BADARG;
@@ -397,15 +397,15 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
     if (!sel || !blk || !flags) return MCCNN_E_WORKSPACE;
     int* slots = (int*)blk;
     void* scanws = blk + slotBytes;
-    MCCNN_HIP(hipMemsetAsync(sel, 0, (size_t)n, s));
-    MCCNN_HIP(hipMemsetAsync(blk, 0, slotBytes + scan_status_bytes((int)S), s));
+    MCCNN_MEMSET(hipMemsetAsync(sel, 0, (size_t)n, s));
+    MCCNN_MEMSET(hipMemsetAsync(blk, 0, slotBytes + scan_status_bytes((int)S), s));
     PoissonDims d = poisson_dims(num_cells);
     long long threads = (long long)batch_size * d.G * d.G * d.G;
     if (mode == 1 || mode == 2) {
         // mode 2 (tests only): no spinning at all -- the first cell whose predecessor has not finished raises the
         // failure flag, which exercises the caller's fallback to the phased form
         const int spinLimit = mode == 1 ? MCCNN_PS_SPIN_LIMIT : 0;
-        MCCNN_HIP(hipMemsetAsync(flags, 0, (C + 1) * sizeof(int), s));
+        MCCNN_MEMSET(hipMemsetAsync(flags, 0, (C + 1) * sizeof(int), s));
         poisson_dataflow<<<ceil_div(threads * 27, 4), 256, 0, s>>>(sorted_pts, cell_indexs, aabb_min, aabb_max, batch_size, d,
                                                                   radius, scale_inv, sel, slots, flags, flags + C, spinLimit);
         MCCNN_LAUNCHED();

@@ -84,14 +84,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const int* in, int* o
 // publishes its aggregate, then wave 0 looks back over the status words of its predecessors -- 64 at a time -- until it
 // meets an inclusive prefix, and publishes its own. A status word is ONE aligned 8-byte agent-scope store: bits 63..62 =
 // state (0 empty, 1 aggregate, 2 inclusive prefix), low 32 bits = value -- the data is the flag, no fences needed.
-// All tiles of such a launch are resident at once (<= 4 small workgroups per CU), so a predecessor always makes
-// progress; the words must be zero on entry (the callers fold that into a memset / kernel they run anyway).
+// Forward progress: a workgroup takes its tile from an atomic TICKET (the word after the last status word), not from
+// blockIdx -- a tile's predecessors are then held by workgroups that started before it and are running, whatever
+// order the dispatcher hands workgroups out in and however few of them fit beside other kernels (these scans also run
+// on a side stream under VGPR-bound convolution kernels, where residency of the whole grid is not guaranteed). The
+// words must be zero on entry (the callers fold that into a memset / kernel they run anyway).
 constexpr int SCAN_CHAIN_TILES = 1024;
 __global__ __launch_bounds__(SCAN_THREADS) void scan_chained(const int* in, int* out, int n,
                                                              unsigned long long* status, int* total) {
     __shared__ int lds[4];
     __shared__ int sOff;
-    const int tile = blockIdx.x;
+    __shared__ int sTile;
+    if (threadIdx.x == 0)
+        sTile = (int)__hip_atomic_fetch_add(status + gridDim.x, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int tile = sTile;
     const long long base = (long long)tile * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
     int s = 0;
@@ -144,7 +151,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained(const int* in, int*
 
 size_t scan_status_bytes(int n) {
     const long long tiles = ((long long)n + SCAN_TILE - 1) / SCAN_TILE;
-    return (tiles > 1 && tiles <= SCAN_CHAIN_TILES) ? align_up((size_t)tiles * sizeof(unsigned long long)) : 0;
+    // one status word per tile + the ticket counter
+    return (tiles > 1 && tiles <= SCAN_CHAIN_TILES) ? align_up((size_t)(tiles + 1) * sizeof(unsigned long long)) : 0;
 }
 
 size_t scan_workspace_bytes(int n) {
@@ -159,7 +167,7 @@ size_t scan_workspace_bytes(int n) {
 
 int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t s, bool status_zeroed) {
     if (n <= 0) {
-        if (total) MCCNN_HIP(hipMemsetAsync(total, 0, sizeof(int), s));
+        if (total) MCCNN_MEMSET(hipMemsetAsync(total, 0, sizeof(int), s));
         return 0;
     }
     int tiles = ceil_div(n, SCAN_TILE);
@@ -170,7 +178,7 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
     }
     const size_t sb = scan_status_bytes(n);
     if (sb) {  // single pass; the status words sit at the start of the workspace
-        if (!status_zeroed) MCCNN_HIP(hipMemsetAsync(ws, 0, sb, s));
+        if (!status_zeroed) MCCNN_MEMSET(hipMemsetAsync(ws, 0, sb, s));
         scan_chained<<<tiles, SCAN_THREADS, 0, s>>>(in, out, n, (unsigned long long*)ws, total);
         MCCNN_LAUNCHED();
         return 0;

@@ -1,6 +1,8 @@
 """Shared input generators and the op-chain driver used by both the oracle and the GPU tests."""
 import numpy as np
 
+from mccnn_amd.workloads import make_room, conv_nb  # noqa: F401  (the generators live with the product: bench.py uses them too)
+
 
 def make_cloud(n_per, B, seed, kind="uniform", ragged=False):
     """Flattened ragged batch: points [N,3] f32, batch ids [N,1] i32, clouds concatenated."""
@@ -26,56 +28,12 @@ def make_cloud(n_per, B, seed, kind="uniform", ragged=False):
     return np.concatenate(pts).astype(np.float32), np.concatenate(bids).astype(np.int32)
 
 
-def make_room(n, seed, oversample=3.0):
-    """Synthetic ScanNet-like room: surfaces of a 6.0 x 4.0 x 2.8 m box (floor + 4 walls)
-    plus 6 axis-aligned furniture boxes, sampled uniformly by area, then thinned to n points with the
-    reference's *gradient* protocol along the longest axis (utils/DataSet.py:431-492:
-    keep-prob = sqrt(clip((x - 0.2 L) / (0.6 L), 0.01, 1)))."""
-    rng = np.random.default_rng(seed)
-    L, W, H = 6.0, 4.0, 2.8
-    rects = []  # (origin, edge u, edge v)
-    rects.append(((0, 0, 0), (L, 0, 0), (0, W, 0)))  # floor
-    rects.append(((0, 0, 0), (L, 0, 0), (0, 0, H)))
-    rects.append(((0, W, 0), (L, 0, 0), (0, 0, H)))
-    rects.append(((0, 0, 0), (0, W, 0), (0, 0, H)))
-    rects.append(((L, 0, 0), (0, W, 0), (0, 0, H)))
-    frng = np.random.default_rng(20180601)  # furniture layout is fixed across rooms
-    for _ in range(6):
-        sx, sy, sz = 0.4 + 1.2 * frng.random(), 0.4 + 0.8 * frng.random(), 0.3 + 0.9 * frng.random()
-        ox, oy = (L - sx) * frng.random(), (W - sy) * frng.random()
-        o = np.array([ox, oy, 0.0])
-        for (a, u, v) in (((0, 0, sz), (sx, 0, 0), (0, sy, 0)), ((0, 0, 0), (sx, 0, 0), (0, 0, sz)),
-                          ((0, sy, 0), (sx, 0, 0), (0, 0, sz)), ((0, 0, 0), (0, sy, 0), (0, 0, sz)),
-                          ((sx, 0, 0), (0, sy, 0), (0, 0, sz))):
-            rects.append((tuple(o + np.array(a)), u, v))
-    areas = np.array([np.linalg.norm(np.cross(u, v)) for (_, u, v) in rects])
-    total = int(n * oversample)
-    which = rng.choice(len(rects), size=total, p=areas / areas.sum())
-    uv = rng.random((total, 2))
-    org = np.array([r[0] for r in rects], dtype=np.float64)[which]
-    eu = np.array([r[1] for r in rects], dtype=np.float64)[which]
-    ev = np.array([r[2] for r in rects], dtype=np.float64)[which]
-    p = org + eu * uv[:, :1] + ev * uv[:, 1:]
-    prob = np.sqrt(np.clip((p[:, 0] - 0.2 * L) / (0.6 * L), 0.01, 1.0))
-    keep = rng.random(total) < prob
-    p = p[keep]
-    if len(p) < n:
-        return make_room(n, seed, oversample * 1.6)
-    sel = rng.choice(len(p), size=n, replace=False)
-    return p[sel].astype(np.float32)
-
-
 def make_mlp(nb, seed, scale=0.5, bias=0.1):
     """Kernel-MLP tensors in the reference's declared shapes (MCConvBuilder.py:407-419)."""
     rng = np.random.default_rng(seed)
     nn = 8 * nb
     u = lambda *s: (scale * (2 * rng.random(s) - 1)).astype(np.float32)
     return dict(w1=u(3, nn), b1=(bias * u(nn)), w2=u(8, nn), b2=(bias * u(nn)), w3=u(8, nn), b3=(bias * u(nn)))
-
-
-def conv_nb(fin, fout, combin):
-    neurons = fin * fout if combin else fin
-    return (neurons + 7) // 8
 
 
 def run_chain(ops, wrap, unwrap, pts, bids, feats, B, radius, scaleInv, window=0.2, fout=8, combin=True, avg=True,

@@ -116,3 +116,40 @@ def test_prefetch_geometry_is_a_no_op_on_host_tensors(shimmed_builder):
     out = cb.create_convolution(convName="Conv", inPointHierarchy=ph, inPointLevel=0, inFeatures=feats, inNumFeatures=1,
                                 outNumFeatures=8, convRadius=0.3, multiFeatureConv=True)
     assert out.shape == (B * 64, 8) and len(cb.cacheNeighs_) == 1
+
+
+def test_builder_is_a_torch_module_with_reference_variable_names(shimmed_builder):
+    """ConvolutionBuilder / PointHierarchy as torch.nn.Modules -- the kernel-MLP variables are
+    registered parameters under the reference's names (MCConvBuilder.py:407-419), so parameters(), state_dict(),
+    optimisers and parent modules see them; a checkpoint loads into a builder that has not created its variables yet."""
+    MB, calls = shimmed_builder
+    rng = np.random.default_rng(2)
+    pts = torch.from_numpy(rng.random((96, 3), dtype=np.float32))
+    bids = torch.zeros((96, 1), dtype=torch.int32)
+    feats = torch.from_numpy(rng.random((96, 3), dtype=np.float32))
+    ph = MB.PointHierarchy(pts, feats, bids, [], "PH", 1)
+    cb = MB.ConvolutionBuilder(KDEWindow=0.2)
+    assert isinstance(cb, torch.nn.Module) and isinstance(ph, torch.nn.Module) and len(list(ph.parameters())) == 0
+    out = cb(convName="Conv_1", inPointHierarchy=ph, inPointLevel=0, inFeatures=feats, inNumFeatures=3, outNumFeatures=8,
+             convRadius=0.3, multiFeatureConv=True)          # forward == create_convolution
+    names = [n for n, _ in cb.named_parameters()]
+    assert names == ["Conv_1_weights", "Conv_1_biases", "Conv_1_weights2", "Conv_1_biases2", "Conv_1_weights3", "Conv_1_biases3"]
+    sd = cb.state_dict()
+    assert list(sd) == names and tuple(sd["Conv_1_weights"].shape) == (3, 24) and tuple(sd["Conv_1_weights2"].shape) == (3, 8, 8)
+    assert cb.variables_["Conv_1_weights"] is dict(cb.named_parameters())["Conv_1_weights"]
+    torch.optim.SGD(cb.parameters(), lr=0.1)                  # an optimiser takes the module's parameters as they are
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.convBuilder = MB.ConvolutionBuilder(KDEWindow=0.2)
+
+    net = Net()                                               # a fresh network: no variables created yet
+    net.load_state_dict({"convBuilder." + k: v for k, v in sd.items()})
+    assert [n for n, _ in net.named_parameters()] == ["convBuilder." + n for n in names]
+    out2 = net.convBuilder.create_convolution(convName="Conv_1", inPointHierarchy=ph, inPointLevel=0, inFeatures=feats,
+                                              inNumFeatures=3, outNumFeatures=8, convRadius=0.3, multiFeatureConv=True)
+    assert torch.equal(out, out2)                             # the adopted variables are the ones the convolution uses
+    with pytest.raises(RuntimeError):                         # tf.get_variable: same name, other shape
+        net.convBuilder.create_convolution(convName="Conv_1", inPointHierarchy=ph, inPointLevel=0, inFeatures=feats,
+                                           inNumFeatures=3, outNumFeatures=16, convRadius=0.3, multiFeatureConv=True)

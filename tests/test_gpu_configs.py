@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 
 from tests.helpers import make_mlp, conv_nb
+from mccnn_amd.workloads import modelnet_like, mcclass_s, mcclass_h, mcseg
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4  # north_star: "fp32 features within 1e-4 rel"
@@ -38,28 +39,6 @@ def oracle_omp():
     """The OpenMP build of the oracle: identical integer outputs, parameter gradients summed in double."""
     from oracle.oracle import Oracle
     return Oracle(omp=True)
-
-
-def modelnet_like(n, B, seed):
-    """B synthetic shapes with n points each, normalised like the ModelNet loader (centred, inside the unit sphere):
-    an ellipsoid shell plus the faces of a box, different proportions per cloud."""
-    rng = np.random.default_rng(seed)
-    pts, bids = [], []
-    for b in range(B):
-        k = n // 2
-        v = rng.normal(size=(k, 3))
-        shell = v / np.linalg.norm(v, axis=1, keepdims=True) * (0.3 + 0.7 * rng.random(3))
-        box = (rng.random((n - k, 3)) - 0.5) * (0.4 + 1.2 * rng.random(3))
-        face = rng.integers(0, 3, n - k)
-        half = (np.abs(box).max(axis=0) + 1e-3)
-        box[np.arange(n - k), face] = np.sign(box[np.arange(n - k), face]) * half[face]
-        p = np.concatenate([shell, box])
-        p -= p.mean(axis=0)
-        p /= np.linalg.norm(p, axis=1).max()
-        rng.shuffle(p)
-        pts.append(p)
-        bids.append(np.full((n, 1), b, np.int32))
-    return np.concatenate(pts).astype(np.float32), np.concatenate(bids)
 
 
 def build_hierarchy(ops, wrap, unwrap, pts, bids, feats, B, radii):
@@ -141,21 +120,20 @@ INT_CONV = ["keys", "indexs", "cellIndexs", "startIndexs", "packedNeighs"]
 GRADS = ["featGrad", "dw1", "db1", "dw2", "db2", "dw3", "db3"]
 S3 = math.sqrt(3.0) + 0.1
 
-# (inLevel, outLevel, convRadius, KDEWindow, Fin, Fout, multiFeatureConv)
-MCCLASS_S_K16 = [  # models/MCClassS.py:38-71, grow 16 (BASELINE cfg1)
-    (0, 1, 0.2, 0.2, 1, 16, True),
-    (1, 2, 0.8, 0.2, 32, 32, False),
-    (2, 3, S3, 0.2, 64, 64, False),
-]
-MCCLASS_H_K16 = [  # models/MCClassH.py:40-187, both logit branches, grow 16
-    (0, 0, 0.1, 0.25, 1, 16, True),      # Conv_1
-    (0, 1, 0.2, 0.2, 32, 32, False),     # Pool_1
-    (1, 1, 0.4, 0.25, 32, 32, False),    # Conv_2
-    (1, 2, 0.8, 0.2, 128, 128, False),   # Pool_2
-    (2, 2, 1.2, 0.25, 128, 128, False),  # Conv_3
-    (2, 3, S3, 0.2, 512, 512, False),    # Pool_3
-    (1, 1, 0.4, 0.25, 1, 32, True),      # Conv_2_2
-]
+# (inLevel, outLevel, convRadius, KDEWindow, Fin, Fout, multiFeatureConv, bf16 rows): the graphs of mccnn_amd.workloads
+# (each row cites its create_convolution call there), layers of identical shape over identical levels taken once
+def _specs(convs):
+    seen, out = set(), []
+    for c in convs:
+        t = (c.lin, c.lout, c.radius, c.window, c.fin, c.fout, c.combin, c.bf16)
+        if t not in seen:
+            seen.add(t)
+            out.append(t)
+    return out
+
+
+MCCLASS_S_K16 = _specs(mcclass_s(16))  # models/MCClassS.py:38-71, grow 16 (BASELINE cfg1)
+MCCLASS_H_K16 = _specs(mcclass_h(16))  # models/MCClassH.py:40-187, both logit branches, grow 16 (7 distinct of 10 layers)
 
 
 def bf16_close(got, ref32):
@@ -203,6 +181,34 @@ def check_config(mc, orc, n_per, B, radii, convs, seed, level_sizes_strict=True)
     return sizes, worst
 
 
+def test_cfg0_uniform4096_conv_3to8_on_its_own_input(mc, oracle_omp):
+    """BASELINE configs[0] as stated: ONE 4 096-point uniform cloud (seed 1), relative radius 0.1 (10^3 cells), one
+    same-level convolution Fin = 3 -> Fout = 8 (nb = 3): grid, neighbours, KDE, forward and all seven gradients on that
+    very input (mccnn_amd.workloads.CONFIGS['cfg0'] -- the input bench.py times for this config)."""
+    from mccnn_amd.workloads import CONFIGS, config_points
+    cfg = CONFIGS["cfg0"]
+    pts, bids, B = config_points(cfg)
+    assert pts.shape == (4096, 3) and B == 1 and len(cfg.convs) == 1
+    c = cfg.convs[0]
+    spec = (c.lin, c.lout, c.radius, c.window, c.fin, c.fout, c.combin)
+    assert spec == (0, 0, 0.1, 0.2, 3, 8, True)
+    feats = np.ones((len(pts), 1), np.float32)
+    gmn, gmx, glev, grec = build_hierarchy(mc, _wrap, _unwrap, pts, bids, feats, B, [])
+    omn, omx, olev, orec = build_hierarchy(oracle_omp, _ident, _ident, pts, bids, feats, B, [])
+    assert np.array_equal(grec[0]["aabbMin"], orec[0]["aabbMin"]) and np.array_equal(grec[0]["aabbMax"], orec[0]["aabbMax"])
+    g = run_conv(mc, _wrap, _unwrap, gmn, gmx, glev, B, spec, 100, True)
+    o = run_conv(oracle_omp, _ident, _ident, omn, omx, olev, B, spec, 100, False)
+    assert g["cellIndexs"].shape == (1, 10, 10, 10, 2)
+    for k in INT_CONV:
+        assert g[k].shape == o[k].shape and np.array_equal(g[k], o[k]), k
+    errs = {"pdfs": rel_err(g["pdfs"], o["pdfs"]), "out": rel_err(g["out"], o["out"])}
+    for nm, a, b in zip(GRADS, g["grads"], o["grads"]):
+        errs[nm] = rel_err(a, b)
+    print("cfg0: E = %d" % len(o["packedNeighs"]), {k: "%.1e" % v for k, v in errs.items()})
+    for nm, e in errs.items():
+        assert e <= RTOL, (nm, e)
+
+
 def test_cfg1_mcclass_s_32x1024(mc, oracle_omp):
     sizes, worst = check_config(mc, oracle_omp, 1024, 32, [0.1, 0.4, S3], MCCLASS_S_K16, 41)
     print("cfg1 level sizes", sizes, "worst rel errs", {k: "%.1e" % v for k, v in worst.items()})
@@ -213,22 +219,7 @@ def test_cfg2_mcclass_h_32x4096(mc, oracle_omp):
     print("cfg2 level sizes", sizes, "worst rel errs", {k: "%.1e" % v for k, v in worst.items()})
 
 
-MCSEG_K32 = [  # models/MCSeg.py:36-198, grow 32 (BASELINE cfg3); last field: bf16 feature storage for the depth-wise layers
-    (0, 0, 0.03, 0.25, 1, 32, True, False),        # Conv_1
-    (0, 1, 0.05, 0.2, 64, 64, False, True),        # Pool_1
-    (1, 1, 0.1, 0.25, 64, 64, False, True),        # Conv_2
-    (1, 2, 0.2, 0.2, 128, 128, False, True),       # Pool_2
-    (2, 2, 0.4, 0.25, 128, 128, False, True),      # Conv_3
-    (2, 3, 0.8, 0.2, 256, 256, False, True),       # Pool_3
-    (3, 3, S3, 0.25, 256, 256, False, True),       # Conv_4
-    (3, 2, S3, 0.25, 512, 512, False, True),       # Up_3_4: 64 blocks, two column tiles in the backward pass
-    (2, 2, 0.4, 0.25, 256, 256, False, True),      # DeConv_3
-    (2, 1, 0.2, 0.25, 256, 256, False, True),      # Up_2_3
-    (1, 1, 0.1, 0.25, 128, 128, False, True),      # DeConv_2
-    (1, 0, 0.05, 0.25, 128, 128, False, True),     # Up_1_2
-    (2, 0, 0.2, 0.25, 256, 256, False, True),      # Up_1_3
-    (0, 0, 0.03, 0.25, 128, 128, False, True),     # DeConv_1
-]
+MCSEG_K32 = _specs(mcseg(32))  # models/MCSeg.py:36-198, grow 32 (BASELINE cfg3), bf16 feature storage for the depth-wise layers
 
 
 def test_cfg3_mcseg_16x8192_bf16_rows(mc, oracle_omp):

@@ -142,11 +142,65 @@ def test_bench_through_rccl_with_one_rank(mc):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "3", "--no-layers",
-                        "--no-breakdown", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True,
-                       timeout=600)
+                        "--no-breakdown", "--no-cpu-baseline", "--no-configs", "--strong-rooms", "2"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     # RCCL may print its version banner on stdout as well: the record is the one line that is a JSON object
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["config"]["collective_backend"] == "nccl" and rec["n_gpus"] == 1
     assert rec["config"]["pipeline"] is not None and rec["config"]["pipelined_ms_per_step"] is not None
     assert rec["value"] > 5e7
+    assert rec["config"]["rccl_world_size"] == 1 and rec["scaling"] == "weak"
+    # both curves in one line: the fixed batch (here 2 rooms, all on this rank) beside the one-room-per-rank headline
+    assert rec["strong"]["rooms"] == 2 and rec["strong"]["points_total"] == 200000 and rec["strong"]["value"] > 5e7
+    assert len(rec["config"]["rank_stats"]["own_ms_per_step"]) == 1
+
+
+def _torchrun_bench(nproc, extra, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MCCNN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MCCNN_BENCH_FORCE_PG"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "4",
+           "--warmup", "2", "--points", "20000", "--no-layers", "--no-breakdown", "--no-cpu-baseline", "--no-configs"] + extra
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines          # rank 0 prints ONE record
+    return json.loads(lines[0])
+
+
+def test_bench_eight_ranks_sharing_the_gpu_weak_and_strong(mc):
+    """The driver's 8-GPU command line, with eight gloo ranks sharing the one GPU of this box (launch path, whole-batch
+    box all-reduce, gradient all-reduce, barriers, max-over-ranks timing, per-rank statistics): one room per rank is both
+    the weak-scaling headline and the rank's share of the fixed 8-room batch, so the `strong` object carries the same
+    partition."""
+    rec = _torchrun_bench(8, [])
+    assert rec["n_gpus"] == 8 and rec["config"]["rccl_world_size"] == 8 and rec["scaling"] == "weak"
+    assert rec["config"]["points_total"] == 8 * 20000 and rec["config"]["points_per_gpu"] == 20000
+    st = rec["config"]["rank_stats"]
+    assert len(st["own_ms_per_step"]) == 8 and st["points"] == [20000] * 8 and min(st["own_ms_per_step"]) > 0
+    assert rec["strong"]["rooms"] == 8 and rec["strong"]["points_total"] == 8 * 20000 and rec["strong"]["rooms_on_rank0"] == 1
+    assert rec["value"] > 0 and rec["strong"]["value"] > 0
+
+
+def test_bench_two_ranks_strong_batch_of_four_rooms(mc):
+    """Strong scaling with several rooms per rank: a fixed batch of 4 rooms over 2 ranks (2 + 2), next to the weak headline
+    (1 + 1); and --gpus that disagrees with the launcher is refused instead of silently measuring something else."""
+    import subprocess
+    import sys
+    rec = _torchrun_bench(2, ["--strong-rooms", "4"])
+    assert rec["n_gpus"] == 2 and rec["config"]["points_total"] == 2 * 20000
+    assert rec["strong"]["rooms"] == 4 and rec["strong"]["rooms_on_rank0"] == 2 and rec["strong"]["points_total"] == 4 * 20000
+    assert rec["strong"]["rank_stats"]["points"] == [40000, 40000]
+    only = _torchrun_bench(2, ["--scaling", "strong", "--strong-rooms", "4"])
+    assert only["scaling"] == "strong" and only["strong"] is None and only["config"]["points_total"] == 4 * 20000
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

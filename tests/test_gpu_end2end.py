@@ -91,7 +91,7 @@ def test_mcclass_s_cfg1_matches_the_oracle_path(mc):
     from mcclass_s import MCClassS
     from oracle.oracle import Oracle
     from tests.oracle_ops import OracleOps
-    from tests.test_gpu_configs import modelnet_like
+    from mccnn_amd.workloads import modelnet_like
     B, n, k, ncat = 32, 1024, 16, 40
     pts, bids = modelnet_like(n, B, 51)
     y = np.random.default_rng(2).integers(0, ncat, B)
@@ -103,11 +103,13 @@ def test_mcclass_s_cfg1_matches_the_oracle_path(mc):
     with torch.no_grad():
         gnet(P, Bi, F, True, useDropOutFull=False)              # creates the variables
     cnet = MCClassS(1, B, k, ncat, torch.device("cpu"), ops=OracleOps(Oracle(omp=True)))
-    for name, p in gnet.convBuilder.variables_.items():
-        cnet.convBuilder.variables_[name] = torch.nn.Parameter(p.detach().cpu().clone())
-    for name, p in gnet.store.variables_.items():
-        cnet.store.variables_[name] = torch.nn.Parameter(p.detach().cpu().clone())
-    cnet.store.buffers_ = {k_: v.detach().cpu().clone() for k_, v in gnet.store.buffers_.items()}
+    # the models are torch.nn.Modules whose sub-modules register every variable under the reference's name: the whole
+    # network state travels through state_dict() / load_state_dict() (variables the CPU twin has not created yet are adopted)
+    sd = {k_: v.detach().cpu().clone() for k_, v in gnet.state_dict().items()}
+    assert "convBuilder.Conv_1_weights" in sd and "store.Reduce_1_weights" in sd and "store.Reduce_1_In_BN_BN/moving_mean" in sd
+    cnet.load_state_dict(sd)
+    assert len(list(cnet.parameters())) == len(list(gnet.parameters())) == len(list(gnet.convBuilder.parameters())) + len(
+        list(gnet.store.parameters()))
     res = {}
     for tag, net, dv in (("gpu", gnet, dev), ("cpu", cnet, torch.device("cpu"))):
         for p in net.parameters():
@@ -133,4 +135,4 @@ def test_mcclass_s_cfg1_matches_the_oracle_path(mc):
     assert rel(gl, cl) <= 1e-4 and abs(gloss - closs) <= 1e-5 * abs(closs)
     assert set(gg) == set(cg) and len([k_ for k_ in cg if k_.startswith("Conv_")]) == 18
     for k_ in cg:
-        assert err[k_] <= 1e-3, (k_, err[k_])
+        assert err[k_] <= 1e-4, (k_, err[k_])

@@ -261,3 +261,21 @@ def test_two_rooms_integer_outputs_vs_oracle(chain2, oracle_omp):
 @pytest.mark.parametrize("shape", [(1, 64, True), (3, 8, True), (64, 64, False)], ids=["1to64", "3to8", "dw64"])
 def test_two_rooms_conv_and_gradients_vs_oracle(mc, oracle_omp, chain2, shape):
     _check_conv(mc, oracle_omp, chain2, *shape, seed=9)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE cfg4 as ONE batch: eight 100k-point rooms on one GPU (800 k points, ~36 M edges) -- the N = 1 point of the
+# strong-scaling run (bench.py --scaling strong --strong-rooms 8). The backward kernels then work in R > 2 rounds of
+# cache-sized slices. Integer outputs bit-exact, the headline layer and a depth-wise layer within the tolerance.
+@pytest.fixture(scope="module")
+def chain8(mc):
+    return _chain(mc, 8)
+
+
+def test_eight_rooms_integer_outputs_vs_oracle(chain8, oracle_omp):
+    assert _check_ints(chain8, oracle_omp) > 30_000_000
+
+
+@pytest.mark.parametrize("shape", [(1, 64, True), (64, 64, False)], ids=["1to64", "dw64"])
+def test_eight_rooms_conv_and_gradients_vs_oracle(mc, oracle_omp, chain8, shape):
+    _check_conv(mc, oracle_omp, chain8, *shape, seed=13)

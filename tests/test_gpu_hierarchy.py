@@ -61,3 +61,35 @@ def test_fused_hierarchy_equals_the_op_chain(mc, oracle, case):
             assert np.array_equal(lv_f[l + 1][0], op) and np.array_equal(lv_f[l + 1][1], ob)
             assert np.array_equal(lv_f[l + 1][2], of) and np.array_equal(idx_f[l], ti)
             cp, cb, cf = op, ob, of
+
+
+@pytest.mark.parametrize("dataflow", [False, 2], ids=["dataflow_off", "dataflow_gives_up"])
+def test_fused_hierarchy_honours_the_poisson_switch_and_falls_back(mc, dataflow):
+    """MCConvModule.POISSON_DATAFLOW also governs the fused hierarchy: False = no single-launch Poisson kernel anywhere
+    (the fused path declines, the op-by-op chain runs the phased form); 2 = the single-launch kernel gives up at the
+    first unfinished dependency, a level reports -1, point_hierarchy_levels() returns None and PointHierarchy repeats
+    op by op. Either way the hierarchy equals the default one."""
+    import torch
+    import mccnn_amd.MCConvBuilder as MB
+    pts, bids = make_cloud(3000, 4, 5, "clustered", True)
+    B, radii = 4, [0.1, 0.4]
+    P, Bi = torch.from_numpy(pts).cuda(), torch.from_numpy(bids).cuda()
+    F = torch.from_numpy(np.random.default_rng(2).random((len(pts), 2), dtype=np.float32)).cuda()
+    ref = MB.PointHierarchy(P, F, Bi, radii, "PH", B, True)
+    mn, mx = ref.aabbMin_, ref.aabbMax_
+    before = mc.POISSON_FALLBACKS
+    mc.POISSON_DATAFLOW = dataflow
+    try:
+        fused = mc.point_hierarchy_levels(P, Bi, mn, mx, radii, B, True)
+        assert fused is None                      # declined (False) or a level timed out (2)
+        ph = MB.PointHierarchy(P, F, Bi, radii, "PH", B, True)
+    finally:
+        mc.POISSON_DATAFLOW = True
+    if dataflow == 2:
+        assert mc.POISSON_FALLBACKS > before       # the op-by-op chain had to repeat with the phased form, too
+    assert len(ph.points_) == len(ref.points_) == 3
+    for a, b in zip(ph.points_ + ph.batchIds_ + ph.features_ + ph.sampledIndexs_,
+                    ref.points_ + ref.batchIds_ + ref.features_ + ref.sampledIndexs_):
+        assert torch.equal(a, b)
+    assert mc.point_hierarchy_levels(P[:0], Bi[:0], mn, mx, radii, B, True) is None   # empty cloud: op-by-op chain
+    assert mc.point_hierarchy_levels(P, Bi, mn, mx, [], B, True) == []

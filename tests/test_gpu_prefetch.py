@@ -270,3 +270,59 @@ def test_side_stream_tensor_lifetime(mc):
     assert torch.equal(late.detach(), ref.detach())
     assert float((F.grad - ref_grad).abs().max()) <= 1e-5 * float(ref_grad.abs().max())
     torch.cuda.synchronize()
+
+
+def test_prefetch_waits_for_a_hierarchy_built_after_reset(mc):
+    """A real training loop builds the NEXT batch's PointHierarchy (host-to-device copies, compute_aabb, Poisson levels)
+    on the calling stream AFTER the last reset(). prefetch_geometry() has to order the side stream behind that work
+    (PointHierarchy.readyEvent_), not merely behind the reset: every step must reproduce the inline result although the
+    points arrive through asynchronous copies enqueued right before the prefetch."""
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    rng = np.random.default_rng(12)
+    host = []
+    for n_per, seed in ((60000, 51), (50000, 52), (64000, 53), (40000, 54)):
+        pts, bids = make_cloud(n_per, 2, seed, "uniform", True)
+        host.append((torch.from_numpy(pts).pin_memory(), torch.from_numpy(bids).pin_memory(),
+                     torch.from_numpy(rng.random((len(pts), 1), dtype=np.float32)).pin_memory(),
+                     torch.from_numpy(rng.random((len(pts), 16), dtype=np.float32)).cuda()))
+    torch.manual_seed(5)
+    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True)
+    R = 0.03
+
+    def upload(b):
+        hp, hb, hf, og = host[b]
+        P, Bi = hp.to("cuda", non_blocking=True), hb.to("cuda", non_blocking=True)
+        F = hf.to("cuda", non_blocking=True).requires_grad_(True)
+        return PointHierarchy(P, F, Bi, [0.05], "PH", 2, True), F, og   # one Poisson level: more work before the event
+
+    def conv(ph, F, og):
+        for p in builder.parameters():
+            p.grad = None
+        out = builder.create_convolution("Conv", ph, 0, F, 1, R, outNumFeatures=16, multiFeatureConv=True)
+        out.backward(og)
+        return out
+
+    refs = []
+    for b in range(len(host)):                     # inline path
+        builder.reset()
+        ph, F, og = upload(b)
+        out = conv(ph, F, og)
+        refs.append((out.detach().clone(), next(iter(builder.cacheNeighs_.values()))[1].clone()))
+    torch.cuda.synchronize()
+    order = [0, 1, 2, 3, 2, 0, 3, 1]
+    builder.reset()
+    nxt = upload(order[0])
+    assert nxt[0].readyEvent_ is not None
+    builder.prefetch_geometry(nxt[0], 0, R)
+    for step, b in enumerate(order):
+        ph, F, og = nxt
+        builder.reset()                            # installs batch b's geometry
+        assert len(builder.cacheNeighs_) == 1
+        out = conv(ph, F, og)
+        if step + 1 < len(order):
+            nxt = upload(order[step + 1])          # AFTER the reset, on the calling stream, asynchronous copies
+            builder.prefetch_geometry(nxt[0], 0, R)
+        assert torch.equal(next(iter(builder.cacheNeighs_.values()))[1], refs[b][1]), (step, b)
+        assert torch.equal(out.detach(), refs[b][0]), (step, b)
+    torch.cuda.synchronize()

@@ -3,7 +3,7 @@ import sys, cProfile, pstats, io
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.argv = ["bench.py", "--steps", "200", "--warmup", "5", "--points", "10000", "--no-cpu-baseline", "--no-breakdown", "--no-layers"]
+sys.argv = ["bench.py", "--steps", "200", "--warmup", "5", "--points", "10000", "--no-cpu-baseline", "--no-configs", "--scaling", "weak", "--no-breakdown", "--no-layers"]
 import runpy
 pr = cProfile.Profile()
 pr.enable()

@@ -5,6 +5,6 @@ export TMPDIR=/tmp
 REPO=$PWD
 for L in $LAYERS; do
   OUT=/tmp/kt_${TAG}_$L; rm -rf $OUT
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT -o t --output-format csv -- python $REPO/bench.py --steps 10 --warmup 2 --layer $L --no-cpu-baseline --no-breakdown > /dev/null 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT -o t --output-format csv -- python $REPO/bench.py --steps 10 --warmup 2 --layer $L --no-cpu-baseline --no-configs --scaling weak --no-breakdown > /dev/null 2>&1)
   echo "== $TAG $L"; python tools/kt.py $OUT
 done

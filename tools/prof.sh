@@ -15,7 +15,7 @@ REPO=$PWD
 cd /tmp
 STEPS=${PROF_STEPS:-20}
 WARM=${PROF_WARM:-5}
-CMD=${PROF_CMD:-"python $REPO/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-breakdown --no-layers --no-pipeline $*"}
+CMD=${PROF_CMD:-"python $REPO/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-breakdown --no-layers --no-configs --scaling weak --no-pipeline $*"}
 echo "$CMD" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- $CMD > $OUT/trace.log 2>&1
 if [ -z "${PROF_NO_PMC:-}" ]; then

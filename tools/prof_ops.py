@@ -1,6 +1,6 @@
 import sys, torch
 sys.path.insert(0, "/root/repo")
-sys.argv = ["bench.py", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-breakdown"]
+sys.argv = ["bench.py", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-configs", "--scaling", "weak", "--no-breakdown"]
 from torch.profiler import profile, ProfilerActivity
 import runpy
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
