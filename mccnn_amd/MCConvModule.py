@@ -395,7 +395,13 @@ class _SortPointsStep2(torch.autograd.Function):
                                    batchSize, nc, ptr(oP), ptr(oB), ptr(oFw), ptr(cells), ptr(inv), ptr(ws), ws.numel(),
                                    stream_handle()), "sort_points_step2")
         ctx.save_for_backward(indexs)
-        ctx.mark_non_differentiable(oB, cells)
+        if inPts.requires_grad:
+            ctx.mark_non_differentiable(oB, cells)
+        else:
+            # the sorted points are cached by the builder and handed to every later convolution over this grid: without
+            # a gradient to route they must not tie those graphs to this node (a node reached only through such an edge
+            # would still be executed -- with undefined gradients -- by every backward pass that touches a later graph)
+            ctx.mark_non_differentiable(oP, oB, cells)
         # outputs nobody differentiates through (the sorted points, usually) arrive as None in backward instead of
         # materialised zero tensors that would be permuted for nothing
         ctx.set_materialize_grads(False)
