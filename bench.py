@@ -471,7 +471,9 @@ class ConfigWorkload:
         layers = []
         for ci, c in enumerate(self.cfg.convs):
             tf, tb = [], []
-            inputs = [self.feats[ci]] + [p for n_, p in self.builder.named_parameters() if n_.startswith(c.name + "_")]
+            named = dict(self.builder.named_parameters())
+            inputs = [self.feats[ci]] + [named[c.name + sfx] for sfx in ("_weights", "_biases", "_weights2", "_biases2",
+                                                                         "_weights3", "_biases3")]
             for it in range(iters + 1):
                 torch.cuda.synchronize()
                 a, b, d = ev(), ev(), ev()

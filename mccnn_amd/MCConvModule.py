@@ -254,6 +254,89 @@ def _transposed_neighbors(packed, n):
     return hit
 
 
+#: depth-wise layers (numFeatures % 8 == 0) run the row-per-lane kernels over SELL layouts of the neighbour list
+#: (conv_rows.hip); False = the edge-streaming kernels of conv.hip for every layer
+ROW_KERNELS = os.environ.get("MCCNN_ROW_KERNELS", "1") != "0"
+_SLOT_RATIO = {}  # (device, rows, e // 1024) -> slots of the last plan of that shape (sizes the record buffers up front)
+
+
+class RowPlan:
+    """SELL-64 layout of a neighbour list (include/mccnn.h, mccnn_rowplan_*): device tensors + the slot count."""
+    __slots__ = ("rows", "slice_off", "rec", "other", "slots", "key")
+
+
+def _row_plan(packed_obj, transposed, pts, bids, pdfs, smp, st, pk, mn, mx, n, m, e, batchSize, radius, scaleInv, avg,
+              centre_points=None):
+    """The forward (rows = centres) or transposed (rows = neighbour points) row plan of a neighbour list, built on
+    first use and kept ON the neighbour-list tensor object -- like the transposed list, it lives as long as the
+    builder's cache entry and is shared by every layer over the list (same PDFs, radius and avg flag)."""
+    key = (bool(transposed), pdfs.data_ptr(), pdfs._version, bool(avg), float(radius), bool(scaleInv), pk._version, n, m)
+    plans = getattr(packed_obj, "_mccnn_rowplans", None)
+    if plans is None:
+        plans = {}
+        try:
+            packed_obj._mccnn_rowplans = plans
+        except AttributeError:
+            pass
+    hit = plans.get(key[0])
+    if hit is not None and hit.key == key:
+        return hit
+    lib = _lib.load()
+    dev = pk.device
+    perm_t = None
+    if transposed:
+        start_t, perm_t, _ = _transposed_neighbors(packed_obj, n)
+        row_start, rows, order = start_t, n, None   # the sorted list IS the cell-coherent order
+    else:
+        row_start, rows = st, m
+        order = _order_hint(centre_points) if centre_points is not None else None
+        if order is not None and order.shape[0] != m:
+            order = None
+    S = (rows + 63) // 64
+    plan = RowPlan()
+    plan.key = key
+    plan.rows = torch.empty(64 * S, dtype=torch.int32, device=dev)
+    plan.slice_off = torch.empty(S + 1, dtype=torch.int32, device=dev)
+    ws = _ws(lib.mccnn_rowplan_workspace_bytes(rows), dev)
+    check(lib.mccnn_rowplan_layout(ptr(row_start), rows, e, ptr(order), ptr(plan.rows), ptr(plan.slice_off), ptr(ws),
+                                   ws.numel(), stream_handle()), "rowplan_layout")
+    # the slot count is data dependent: the records are written into buffers sized from the last plan of this shape
+    # while the count travels to the host; too small a guess -> exact repeat
+    gkey = (dev.index, rows, e >> 10, bool(transposed))
+    guess = _SLOT_RATIO.get(gkey, 0)
+
+    def fill(cap):
+        rec = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+        oth = torch.empty(cap, dtype=torch.int32, device=dev)
+        check(lib.mccnn_rowplan_fill(int(bool(transposed)), ptr(pts), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
+                                     ptr(mn), ptr(mx), n, m, e, batchSize, float(radius), int(bool(scaleInv)),
+                                     int(bool(avg)), ptr(row_start), ptr(perm_t), ptr(plan.rows), ptr(plan.slice_off),
+                                     cap, ptr(rec), ptr(oth), stream_handle()), "rowplan_fill")
+        return rec, oth
+
+    box = _pinned_int()
+    box.copy_(plan.slice_off[S:S + 1], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    filled = None
+    if guess > 0:
+        filled = fill(guess)
+    ev.synchronize()
+    total = int(box[0])
+    if filled is None or total > guess:
+        filled = fill(max(total, 1))
+    plan.rec, plan.other, plan.slots = filled[0], filled[1], total
+    _SLOT_RATIO[gkey] = total + total // 32 + 64
+    if len(_SLOT_RATIO) > 256:
+        _SLOT_RATIO.clear()
+    plans[key[0]] = plan
+    return plan
+
+
+def _rows_shape(combin, fin, feats, m, e):
+    return ROW_KERNELS and _DEBUG_IMPL == 0 and (not combin) and fin % 8 == 0 and e > 0 and m > 0 and (feats.data_ptr() & 15) == 0
+
+
 def clear_caches():
     """Drop the per-shape launch hints (visiting orders, edge-count guesses, num_cells read-backs). They only affect
     speed, never results, and are bounded in size; call this to release the device tensors they hold."""
@@ -277,9 +360,17 @@ def check_batch_ids(inBatchIds, batchSize):
     return int(bad.item())
 
 
+_DEBUG_IMPL = 0
+
+
 def debug_conv_impl(mask):
-    """Test hook: bit 0 = VALU fallback kernels, bit 1 = general MFMA kernels for Fin = 1. Returns the previous mask."""
-    return int(_lib.load().mccnn_debug_conv_impl(int(mask)))
+    """Test hook: bit 0 = VALU fallback kernels, bit 1 = general MFMA kernels for Fin = 1, bit 2 (this layer only) = the
+    edge-streaming MFMA kernels for depth-wise layers instead of the row-per-lane ones. Returns the previous mask."""
+    global _DEBUG_IMPL
+    prev = _DEBUG_IMPL
+    _DEBUG_IMPL = int(mask)
+    _lib.load().mccnn_debug_conv_impl(int(mask) & 3)
+    return prev
 
 
 def _num_cells(aabbMin, aabbMax, batchSize, cellSize, scaleInv):
@@ -865,6 +956,22 @@ class _SpatialConv(torch.autograd.Function):
                                     numOutFeatures, combin, batchSize, radius)
         lib = _lib.load()
         outF = numOutFeatures if combin else fin
+        if _rows_shape(combin, fin, feats, m, e) and (fin + 7) // 8 <= 89:
+            # depth-wise layer on the row-per-lane kernels: forward plan of the neighbour list (built once per list)
+            plan = _row_plan(packedNeighs if pk is packedNeighs else pk, False, pts, bids, pdfs, smp, st, pk, mn, mx, n, m,
+                             e, batchSize, radius, scaleInv, avg, centre_points=inSamplePts)
+            out = torch.empty((m, outF), dtype=feats.dtype, device=pts.device)
+            check(lib.mccnn_spatial_conv_fwd_rows(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
+                                                  ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
+                                                  n, m, e, fin, batchSize, float(radius), int(bool(scaleInv)),
+                                                  int(bool(avg)), int(bf16), ptr(plan.rows), ptr(plan.slice_off),
+                                                  ptr(plan.rec), ptr(plan.other), ptr(out), stream_handle()),
+                  "spatial_conv(rows)")
+            ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3)
+            ctx.state = None
+            ctx.packed_ref = weakref.ref(packedNeighs if pk is packedNeighs else pk)
+            ctx.attrs = (numOutFeatures, bool(combin), batchSize, float(radius), bool(scaleInv), bool(avg))
+            return out
         ws = _ws(lib.mccnn_spatial_conv_fwd_workspace_bytes(m, e, fin, numOutFeatures, int(bool(combin))), pts.device)
         if bf16:
             # bf16 feature storage (extension): depth-wise layers only, rows in / rows out as bf16, f32 arithmetic
@@ -920,11 +1027,25 @@ class _SpatialConv(torch.autograd.Function):
                             dtype=w1.dtype, device=w1.device)
         dw1, db1, dw2, db2, dw3, db3 = gflat.split([w1.numel(), b1.numel(), w2.numel(), b2.numel(), w3.numel(), b3.numel()])
         dw1, dw2, dw3 = dw1.view_as(w1), dw2.view_as(w2), dw3.view_as(w3)
-        ws = _ws(lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, numOutFeatures, int(combin)), pts.device)
-        start_t = perm_t = None
         packed_obj = ctx.packed_ref()
         if packed_obj is None:  # the list object is gone (its cache entry was dropped): the saved tensor has the same rows
             packed_obj = pk
+        if _rows_shape(combin, fin, feats, m, e) and n > 0 and (og.data_ptr() & 15) == 0:
+            # depth-wise layer: ONE sweep over the transposed row plan finishes the feature gradient and the six
+            # parameter gradients (the edge-major kernels evaluate the kernel MLP twice for that)
+            plan = _row_plan(packed_obj, True, pts, bids, pdfs, smp, st, pk, mn, mx, n, m, e, batchSize, radius, scaleInv, avg)
+            ws = _ws(lib.mccnn_spatial_conv_bwd_rows_workspace_bytes(n, fin), pts.device)
+            check(lib.mccnn_spatial_conv_bwd_rows(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
+                                                  ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
+                                                  ptr(og), n, m, e, fin, batchSize, radius, int(scaleInv), int(avg),
+                                                  int(bf16), ptr(plan.rows), ptr(plan.slice_off), ptr(plan.rec),
+                                                  ptr(plan.other), ptr(fg), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2),
+                                                  ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
+                  "spatial_conv_grad(rows)")
+            return (None, fg, None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
+                    None, None, None, None, None, None)
+        ws = _ws(lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, numOutFeatures, int(combin)), pts.device)
+        start_t = perm_t = None
         if not combin and e > 0:
             start_t, perm_t, _ = _transposed_neighbors(packed_obj, n)
         elif combin and 2 <= fin <= 4 and e > 0 and getattr(packed_obj, "_mccnn_transposed", None) is not None:

@@ -995,6 +995,20 @@ static int fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_f
     return 0;
 }
 
+void launch_reduce_partials(const float* partials, int rows, int nb, float* dw1, float* db1, float* dw2, float* db2,
+                            float* dw3, float* db3, hipStream_t s) {
+    reduce_partials<<<ceil_div((long long)nb * 176, 16), 1024, 0, s>>>(partials, rows, nb, dw1, db1, dw2, db2, dw3, db3);
+}
+
+int conv_fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
+                   const float* pdfs, const float* samples, const int* start_idx, const int* packed,
+                   const float* aabb_min, const float* aabb_max, const float* w1, const float* b1, const float* w2,
+                   const float* b2, const float* w3, const float* b3, int n, int m, int e, int Fin, int Fout, int combin,
+                   int batch_size, float radius, int scale_inv, int avg) {
+    return fill_args(a, sorted_pts, sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min, aabb_max, w1,
+                     b1, w2, b2, w3, b3, n, m, e, Fin, Fout, combin, batch_size, radius, scale_inv, avg);
+}
+
 std::atomic<int>& conv_impl_override() {
     static std::atomic<int> v{(getenv("MCCNN_FORCE_VALU") ? 1 : 0) | (getenv("MCCNN_NO_F1") ? 2 : 0)};
     return v;

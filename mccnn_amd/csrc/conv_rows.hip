@@ -1,0 +1,550 @@
+// "Row per lane" convolution kernels over SELL-64-sigma layouts of the neighbour list.
+//
+// The streaming kernels of conv.hip map lanes to 64 CONSECUTIVE EDGES of the CSR list; the sum over a centre's edges is
+// then a segmented wave scan (48 fused-DPP multiply-adds per MLP block on the pipe the MFMAs share), and the feature
+// gradient of a depth-wise layer needs a second full evaluation of the kernel MLP over the transposed list. Here a lane
+// owns a ROW of the list -- a centre i for the forward pass, a neighbour point j for the backward pass -- and walks the
+// row's edges one per iteration: the sum over the row is a plain per-lane accumulator (no scan, no carry, no atomics,
+// every output row written exactly once by one lane), the 4x4x1 MFMA form still evaluates the kernel MLP for 64 edges at
+// once (it never needed the 64 edges to be neighbours in the list), and in the backward pass the SAME sweep that feeds the
+// 176 weight-gradient sums also finishes the feature-gradient row of its point: the MLP is evaluated once, not twice.
+//
+// Layout (built once per neighbour list by mccnn_rowplan_layout / _fill, shared by every layer over the list): rows are
+// grouped into windows of SELL_SIGMA rows of the cell-coherent visiting order, sorted by descending edge count inside a
+// window, and cut into slices of 64; slice s stores len_s = (largest count in the slice) x 64 slots, slot (it, lane) =
+// edge #it of the lane's row: one 16-byte record (delta, 1 / (pdf K)) and the index of the row at the other end of the
+// edge, padded with zero records (1/(pdf K) = 0 zeroes every term a padding lane feeds). Loads are perfectly coalesced;
+// padding is ~4 % on the 100k-point room at sigma = 1024 (31 % unsorted).
+#include "conv_mfma.h"
+#include <type_traits>
+
+namespace mccnn {
+
+constexpr int SELL_SIGMA = 1024;
+
+struct RowPlan {
+    const int* rows;      // [64 S] row id of (slice, lane), -1 = padding lane
+    const int* sliceOff;  // [S + 1] first slot of every slice; sliceOff[S] = total slots
+    const float4* rec;    // [slots] (delta0, delta1, delta2, 1 / (pdf K))
+    const int* other;     // [slots] the row at the other end of the edge (forward plan: neighbour j; transposed: centre i)
+    int numRows, S;
+};
+
+// ------------------------------------------------------------------------------------------------ layout
+// One workgroup per window of SELL_SIGMA rows: bitonic sort of unique keys (descending edge count, then position in the
+// visiting order) -> the layout is a deterministic function of the list, so gradients are bit-reproducible run to run.
+__global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStart, int rows, int e,
+                                                 const int* __restrict__ order, int* __restrict__ planRows,
+                                                 int* __restrict__ sliceSlots, int S) {
+    __shared__ unsigned key[SELL_SIGMA];
+    __shared__ int rowOf[SELL_SIGMA];
+    __shared__ int degOf[SELL_SIGMA];
+    const int w0 = blockIdx.x * SELL_SIGMA;
+    for (int k = threadIdx.x; k < SELL_SIGMA; k += 256) {
+        const int p = w0 + k;
+        int r = -1, deg = 0;
+        if (p < rows) {
+            r = order ? order[p] : p;
+            r = max(0, min(r, rows - 1));
+            deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
+        }
+        rowOf[k] = r;
+        degOf[k] = deg;
+        const unsigned dk = (unsigned)min(max(deg, 0), 0xFFFFF);
+        key[k] = ((p < rows ? (0xFFFFFu - dk) : 0x100000u) << 10) | (unsigned)k;  // padding positions sort last
+    }
+    __syncthreads();
+    for (int size = 2; size <= SELL_SIGMA; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < SELL_SIGMA / 2; t += 256) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int g = wave; g < SELL_SIGMA / 64; g += 4) {
+        const int slice = w0 / 64 + g;
+        if (slice >= S) break;
+        const int kk = (int)(key[g * 64 + lane] & 1023u);
+        const bool real = (key[g * 64 + lane] >> 30) == 0;
+        planRows[slice * 64 + lane] = real ? rowOf[kk] : -1;
+        int d = real ? degOf[kk] : 0;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) d = max(d, __shfl_xor(d, s, 64));
+        if (lane == 0) sliceSlots[slice] = d * 64;
+    }
+}
+
+// One wave per slice: the records of the slice in (iteration, lane) order. Same expressions as the streaming kernels'
+// edge set-up (conv.hip conv_stream / edge_records), so the records hold identical bits.
+template <bool TR>
+__global__ __launch_bounds__(256) void sell_fill(ConvArgs a, const int* __restrict__ rowStart, int rows,
+                                                 const int* __restrict__ permT, const int* __restrict__ planRows,
+                                                 const int* __restrict__ sliceOff, int S, long long cap,
+                                                 float4* __restrict__ rec, int* __restrict__ oth) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slice = blockIdx.x * 4 + wave;
+    if (slice >= S) return;
+    const int off = sliceOff[slice];
+    const int len = (sliceOff[slice + 1] - off) >> 6;
+    if ((long long)off + (long long)len * 64 > cap) return;  // the caller sees sliceOff[S] > capacity and repeats
+    const int r = planRows[slice * 64 + lane];
+    int base = 0, deg = 0;
+    if (r >= 0) {
+        base = rowStart[r];
+        deg = ((r + 1 < rows) ? rowStart[r + 1] : a.e) - base;
+    }
+    int pad = 0;
+    for (int it = 0; it < len; ++it) {
+        float4 rc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int o = pad;
+        if (it < deg) {
+            const int e = TR ? permT[base + it] : base + it;
+            const int2 pr = a.packed[e];
+            const int j = pr.x, ci = pr.y;
+            float invR = a.invRadius;
+            if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B)));
+            const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B)) : a.radius;
+            const float* pp = a.pts + (size_t)j * 3;
+            const float* cc = a.samples + (size_t)ci * 3;
+            float K = 1.0f;
+            if (a.avg) K = (float)(((ci + 1 < a.m) ? a.start[ci + 1] : a.e) - a.start[ci]);
+            rc = make_float4(div_exact(pp[0] - cc[0], R, invR), div_exact(pp[1] - cc[1], R, invR),
+                             div_exact(pp[2] - cc[2], R, invR), __builtin_amdgcn_rcpf(a.pdfs[e] * K));
+            o = TR ? ci : j;
+            if (it == 0) pad = o;
+        }
+        const size_t slot = (size_t)off + (size_t)it * 64 + lane;
+        rec[slot] = rc;
+        oth[slot] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ depth-wise forward
+// Work item = (slice, tile of 4 consecutive MLP blocks = one 128-byte line of an f32 feature row). Persistent waves:
+// a workgroup stages the layer's weights once and strides over the items. FEAT: 2 = f32 rows, 4 = bf16 rows.
+template <int FEAT>
+__global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float* __restrict__ out, int tiles, int items) {
+    extern __shared__ float lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i4 = lane & 3;
+    stage_weights<MCCNN_WQ_FWD>(a, lds);
+    __syncthreads();
+    constexpr bool BF = FEAT == 4;
+    const unsigned short* feats16 = reinterpret_cast<const unsigned short*>(a.feats);
+    unsigned short* out16 = reinterpret_cast<unsigned short*>(out);
+    const int gridWaves = gridDim.x * 4;
+    for (int w = blockIdx.x * 4 + wave; w < items; w += gridWaves) {
+        const int slice = w / tiles, tile = w - slice * tiles;
+        const int q0 = tile * 4;
+        const int nbT = min(4, a.nb - q0);
+        const int off = p.sliceOff[slice];
+        const int len = (p.sliceOff[slice + 1] - off) >> 6;
+        const int r = p.rows[slice * 64 + lane];
+        float acc[4][8];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) acc[b][n] = 0.f;
+        float4 rcN = make_float4(0.f, 0.f, 0.f, 0.f);
+        int jN = 0;
+        if (len > 0) { rcN = p.rec[(size_t)off + lane]; jN = p.other[(size_t)off + lane]; }
+        for (int it = 0; it < len; ++it) {
+            const float4 rc = rcN;
+            const int j = jN;
+            if (it + 1 < len) {
+                const size_t sn = (size_t)off + (size_t)(it + 1) * 64 + lane;
+                rcN = p.rec[sn];
+                jN = p.other[sn];
+            }
+            float f[4][8];
+            if (BF) {
+                const uint4* fp = reinterpret_cast<const uint4*>(feats16 + (size_t)j * a.Fin + q0 * 8);
+                uint4 fl[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) fl[b] = (b < nbT) ? fp[b] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bf16x8_to_f32(fl[b], f[b]);
+            } else {
+                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)j * a.Fin + q0 * 8);
+                float4 fl[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) fl[k] = (k < 2 * nbT) ? fp[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    f[b][0] = fl[2 * b].x; f[b][1] = fl[2 * b].y; f[b][2] = fl[2 * b].z; f[b][3] = fl[2 * b].w;
+                    f[b][4] = fl[2 * b + 1].x; f[b][5] = fl[2 * b + 1].y; f[b][6] = fl[2 * b + 1].z; f[b][7] = fl[2 * b + 1].w;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b < nbT) {
+                    // the LDS weight reads stay inside the loop (hoisted they would pin 44 VGPRs per block)
+                    int woff = (q0 + b) * MCCNN_WQ_FWD;
+                    asm volatile("" : "+s"(woff));
+                    float pre1[8], a1[8], pre2[8], a2[8], o[8];
+                    MCCNN_PHASE();
+                    mlp_block_mfma(lds + woff, i4, rc.x, rc.y, rc.z, pre1, a1, pre2, a2, o);
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) acc[b][n] = __builtin_fmaf(f[b][n] * rc.w, o[n], acc[b][n]);
+                }
+            }
+        }
+        if (r >= 0) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b < nbT) {
+                    if (BF) {
+                        reinterpret_cast<uint4*>(out16 + (size_t)r * a.outF)[q0 + b] = f32x8_to_bf16(acc[b]);
+                    } else {
+                        float4* dst = reinterpret_cast<float4*>(out + (size_t)r * a.outF + (q0 + b) * 8);
+                        dst[0] = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+                        dst[1] = make_float4(acc[b][4], acc[b][5], acc[b][6], acc[b][7]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ depth-wise backward
+// Transposed plan (rows = neighbour points j). A workgroup takes a group of `spw` consecutive slices and 4 consecutive MLP
+// blocks (wave k: block q0 + k, so the four 32-byte pieces of a gathered out-gradient row are one 128-byte line shared by
+// the workgroup). Per (slice, block) sweep: the block's 176 weight-gradient sums stay in VGPRs across all slices of the
+// group; the 8 feature-gradient sums of the lane's own point are finished at the end of the slice and stored once.
+// Math: spatial_conv.cu:563-680 (see conv_bwd_mfma in conv.hip for the same steps in the edge-major form).
+template <int FEAT>
+__global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, const float* __restrict__ outGrad,
+                                                      float* __restrict__ featGrad, float* __restrict__ partials, int spw) {
+    extern __shared__ float lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i4 = lane & 3;
+    const int qTiles = (a.nb + 3) >> 2;
+    const int g = blockIdx.x / qTiles, qt = blockIdx.x - g * qTiles;
+    {   // this workgroup's four blocks only
+        ConvArgs t = a;
+        const int q0 = qt * 4;
+        t.w1 = a.w1 + (size_t)q0 * 24; t.b1 = a.b1 + (size_t)q0 * 8;
+        t.w2 = a.w2 + (size_t)q0 * 64; t.b2 = a.b2 + (size_t)q0 * 8;
+        t.w3 = a.w3 + (size_t)q0 * 64; t.b3 = a.b3 + (size_t)q0 * 8;
+        t.nb = min(4, a.nb - q0);
+        stage_weights<MCCNN_WQ_BWD>(t, lds);
+    }
+    __syncthreads();
+    const int q = qt * 4 + wave;
+    if (q >= a.nb) return;
+    constexpr bool BF = FEAT == 4;
+    const unsigned short* feats16 = reinterpret_cast<const unsigned short*>(a.feats);
+    const unsigned short* og16 = reinterpret_cast<const unsigned short*>(outGrad);
+    unsigned short* fg16 = reinterpret_cast<unsigned short*>(featGrad);
+
+    float gw3[64], gb3[8], gw2[64], gb2[8], gw1[24], gb1[8];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) { gw3[k] = 0.f; gw2[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { gb3[k] = 0.f; gb2[k] = 0.f; gb1[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 24; ++k) gw1[k] = 0.f;
+
+    const int sEnd = min((g + 1) * spw, p.S);
+    for (int slice = g * spw; slice < sEnd; ++slice) {
+        const int off = p.sliceOff[slice];
+        const int len = (p.sliceOff[slice + 1] - off) >> 6;
+        const int r = p.rows[slice * 64 + lane];
+        const int jr = max(r, 0);
+        // the lane's own feature row piece is constant over the slice: parked in LDS (two conflict-free float4 planes
+        // per wave) instead of 8 VGPRs -- the 176 sums leave no room for it
+        f32x4* fpark = reinterpret_cast<f32x4*>(lds + 4 * MCCNN_WQ_BWD) + wave * 128;
+        {
+            float ff0[8];
+            if (BF) {
+                const uint4 fu = reinterpret_cast<const uint4*>(feats16 + (size_t)jr * a.Fin)[q];
+                bf16x8_to_f32(fu, ff0);
+            } else {
+                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)jr * a.Fin + q * 8);
+                const float4 fa = fp[0], fb = fp[1];
+                ff0[0] = fa.x; ff0[1] = fa.y; ff0[2] = fa.z; ff0[3] = fa.w; ff0[4] = fb.x; ff0[5] = fb.y; ff0[6] = fb.z; ff0[7] = fb.w;
+            }
+            fpark[lane] = (f32x4){ff0[0], ff0[1], ff0[2], ff0[3]};
+            fpark[64 + lane] = (f32x4){ff0[4], ff0[5], ff0[6], ff0[7]};
+        }
+        float dF[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) dF[n] = 0.f;
+        float4 rcN = make_float4(0.f, 0.f, 0.f, 0.f);
+        int iN = 0;
+        if (len > 0) { rcN = p.rec[(size_t)off + lane]; iN = p.other[(size_t)off + lane]; }
+        for (int it = 0; it < len; ++it) {
+            const float4 rc = rcN;
+            const int ci = iN;
+            const float inv = rc.w;
+            float g8[8];
+            if (BF) {
+                const uint4 gu = reinterpret_cast<const uint4*>(og16 + (size_t)ci * a.outF)[q];
+                bf16x8_to_f32(gu, g8);
+            } else {
+                const float4* gp = reinterpret_cast<const float4*>(outGrad + (size_t)ci * a.outF + q * 8);
+                const float4 ga = gp[0], gb = gp[1];
+                g8[0] = ga.x; g8[1] = ga.y; g8[2] = ga.z; g8[3] = ga.w; g8[4] = gb.x; g8[5] = gb.y; g8[6] = gb.z; g8[7] = gb.w;
+            }
+            if (it + 1 < len) {  // after this iteration's gather: vmcnt retires in order
+                const size_t sn = (size_t)off + (size_t)(it + 1) * 64 + lane;
+                rcN = p.rec[sn];
+                iN = p.other[sn];
+            }
+            float a1[8], a2[8], o[8];
+            bool p1[8], p2[8];
+            int woff = wave * MCCNN_WQ_BWD;
+            asm volatile("" : "+s"(woff));
+            const float* wq = lds + woff;
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(wq);
+            {
+                float pre1[8], pre2[8];
+                MCCNN_PHASE();
+                mlp_block_mfma(wq, i4, rc.x, rc.y, rc.z, pre1, a1, pre2, a2, o);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { p1[k] = pre1[k] >= 0.0f; p2[k] = pre2[k] >= 0.0f; }
+            }
+            // feature gradient of the lane's point: og * o / (pdf K)      (spatial_conv.cu:400)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) dF[n] = __builtin_fmaf(g8[n] * inv, o[n], dF[n]);
+            float gf[8];
+            {
+                const f32x4 f0 = fpark[lane], f1 = fpark[64 + lane];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) gf[n] = g8[n] * (n < 4 ? f0[n & 3] : f1[n & 3]);
+            }
+            // dW3 += u a2^T, db3 += u, u = g f / (pdf K)          (spatial_conv.cu:383-399)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const float u = gf[n] * inv;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) gw3[n * 8 + k] = fmaf(u, a2[k], gw3[n * 8 + k]);
+                gb3[n] += u;
+            }
+            // t3 = 1[pre2 >= 0] * W3^T (g f) / (pdf K)             (:403-414)
+            float t3[8];
+            MCCNN_PHASE();
+            layer8<false>(w4 + 62, nullptr, i4, gf, t3);
+            MCCNN_PHASE();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t3[k] = p2[k] ? t3[k] * inv : 0.f;
+            // dW2 += t3 a1^T, db2 += t3                            (:419-425)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int l = 0; l < 8; ++l) gw2[k * 8 + l] = fmaf(t3[k], a1[l], gw2[k * 8 + l]);
+                gb2[k] += t3[k];
+            }
+            // t4 = 1[pre1 >= 0] * W2^T t3                          (:428-434)
+            float t4[8];
+            size_t so = (size_t)off + (size_t)it * 64 + lane;
+            asm volatile("" : "+v"(so));
+            const float4 dl = p.rec[so];
+            MCCNN_PHASE();
+            layer8<false>(w4 + 46, nullptr, i4, t3, t4);
+            MCCNN_PHASE();
+            // dW1 += t4 delta^T, db1 += t4                         (:439-444)
+            // (delta is read again here -- an L1 hit, requested before the t4 chain -- instead of staying live in three
+            // VGPRs across the whole iteration; the address goes through an opaque register so the load is not merged
+            // with the one at the top)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                const float v = p1[l] ? t4[l] : 0.f;
+                gw1[l * 3] = fmaf(v, dl.x, gw1[l * 3]);
+                gw1[l * 3 + 1] = fmaf(v, dl.y, gw1[l * 3 + 1]);
+                gw1[l * 3 + 2] = fmaf(v, dl.z, gw1[l * 3 + 2]);
+                gb1[l] += v;
+            }
+        }
+        if (r >= 0) {
+            if (BF) {
+                reinterpret_cast<uint4*>(fg16 + (size_t)r * a.Fin)[q] = f32x8_to_bf16(dF);
+            } else {
+                float4* dst = reinterpret_cast<float4*>(featGrad + (size_t)r * a.Fin + q * 8);
+                dst[0] = make_float4(dF[0], dF[1], dF[2], dF[3]);
+                dst[1] = make_float4(dF[4], dF[5], dF[6], dF[7]);
+            }
+        }
+    }
+    // transposing wave reduction; partial row layout: w1[24] b1[8] w2[64] b2[8] w3[64] b3[8]
+    {
+        float r2 = wave_reduce64(gw2, lane);
+        float r3 = wave_reduce64(gw3, lane);
+        float misc[64];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) misc[k] = gw1[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { misc[24 + k] = gb1[k]; misc[32 + k] = gb2[k]; misc[40 + k] = gb3[k]; }
+#pragma unroll
+        for (int k = 48; k < 64; ++k) misc[k] = 0.f;
+        float rm = wave_reduce64(misc, lane);
+        float* pq = partials + ((size_t)g * a.nb + q) * 176;
+        pq[32 + lane] = r2;
+        pq[104 + lane] = r3;
+        if (lane < 32) pq[lane] = rm;                 // w1, b1
+        else if (lane < 40) pq[96 + lane - 32] = rm;  // b2
+        else if (lane < 48) pq[168 + lane - 40] = rm; // b3
+    }
+}
+
+// defined in conv.hip
+void launch_reduce_partials(const float* partials, int rows, int nb, float* dw1, float* db1, float* dw2, float* db2,
+                            float* dw3, float* db3, hipStream_t s);
+int conv_fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
+                   const float* pdfs, const float* samples, const int* start_idx, const int* packed,
+                   const float* aabb_min, const float* aabb_max, const float* w1, const float* b1, const float* w2,
+                   const float* b2, const float* w3, const float* b3, int n, int m, int e, int Fin, int Fout, int combin,
+                   int batch_size, float radius, int scale_inv, int avg);
+
+static int bwd_rows_spw(int S, int nb) {
+    long long spw = ((long long)S * nb) / 4096;  // >= ~4096 waves in the launch (2 rounds of the resident 2048)
+    if (spw > 8) spw = 8;
+    if (spw < 1) spw = 1;
+    return (int)spw;
+}
+
+}  // namespace mccnn
+
+using namespace mccnn;
+
+extern "C" {
+
+size_t mccnn_rowplan_workspace_bytes(int rows) {
+    if (rows <= 0) return 256;
+    const int S = (rows + 63) / 64;
+    return align_up((size_t)S * sizeof(int)) + scan_workspace_bytes(S) + 256;
+}
+
+int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order, int* plan_rows, int* slice_off, void* ws,
+                         size_t ws_bytes, mccnn_stream_t stream) {
+    if (rows < 0 || e < 0 || !slice_off) return MCCNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (rows == 0) {
+        MCCNN_MEMSET(hipMemsetAsync(slice_off, 0, sizeof(int), s));
+        return 0;
+    }
+    if (!row_start || !plan_rows) return MCCNN_E_BADARG;
+    if (!ws || ws_bytes < mccnn_rowplan_workspace_bytes(rows)) return MCCNN_E_WORKSPACE;
+    const int S = (rows + 63) / 64;
+    Arena ar(ws, ws_bytes);
+    int* sliceSlots = ar.take<int>((size_t)S);
+    void* scanws = ar.take<char>(scan_workspace_bytes(S));
+    if (!sliceSlots || !scanws) return MCCNN_E_WORKSPACE;
+    sell_sort<<<ceil_div(rows, SELL_SIGMA), 256, 0, s>>>(row_start, rows, e, order, plan_rows, sliceSlots, S);
+    MCCNN_LAUNCHED();
+    return exclusive_scan_i32(sliceSlots, slice_off, S, slice_off + S, scanws, s);
+}
+
+int mccnn_rowplan_fill(int transposed, const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs,
+                       const float* samples, const int* start_idx, const int* packed, const float* aabb_min,
+                       const float* aabb_max, int n, int m, int e, int batch_size, float radius, int scale_inv, int avg,
+                       const int* row_start, const int* perm_t, const int* plan_rows, const int* slice_off,
+                       long long capacity_slots, void* rec, int* other, mccnn_stream_t stream) {
+    if (n < 0 || m < 0 || e < 0 || batch_size <= 0 || !(radius > 0.0f)) return MCCNN_E_BADARG;
+    const int rows = transposed ? n : m;
+    if (rows == 0 || e == 0) return 0;
+    if (!sorted_pts || !sorted_batch_ids || !pdfs || !samples || !start_idx || !packed || !aabb_min || !aabb_max ||
+        !row_start || !plan_rows || !slice_off || !rec || !other || (transposed && !perm_t))
+        return MCCNN_E_BADARG;
+    ConvArgs a = {};
+    a.pts = sorted_pts; a.bids = sorted_batch_ids; a.pdfs = pdfs; a.samples = samples; a.start = start_idx;
+    a.packed = reinterpret_cast<const int2*>(packed); a.mn = aabb_min; a.mx = aabb_max;
+    a.n = n; a.m = m; a.e = e; a.radius = radius; a.invRadius = 1.0f / radius; a.scaleInv = scale_inv; a.avg = avg;
+    a.B = batch_size;
+    hipStream_t s = (hipStream_t)stream;
+    const int S = (rows + 63) / 64;
+    if (transposed)
+        sell_fill<true><<<ceil_div(S, 4), 256, 0, s>>>(a, row_start, rows, perm_t, plan_rows, slice_off, S, capacity_slots,
+                                                       reinterpret_cast<float4*>(rec), other);
+    else
+        sell_fill<false><<<ceil_div(S, 4), 256, 0, s>>>(a, row_start, rows, nullptr, plan_rows, slice_off, S, capacity_slots,
+                                                        reinterpret_cast<float4*>(rec), other);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+static bool rows_shape_ok(const ConvArgs& a, int combin, const void* p0, const void* p1) {
+    return !combin && a.Fin % 8 == 0 && ((((uintptr_t)p0 | (uintptr_t)p1) & 15) == 0);
+}
+
+int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feats, const int* sorted_batch_ids,
+                                const float* pdfs, const float* samples, const int* start_idx, const int* packed,
+                                const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
+                                const float* w2, const float* b2, const float* w3, const float* b3, int n, int m, int e,
+                                int num_feats, int batch_size, float radius, int scale_inv, int avg, int bf16,
+                                const int* plan_rows, const int* slice_off, const void* plan_rec, const int* plan_other,
+                                void* out, mccnn_stream_t stream) {
+    ConvArgs a;
+    int rc = conv_fill_args(a, sorted_pts, (const float*)sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed,
+                            aabb_min, aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_feats, num_feats, 0, batch_size, radius,
+                            scale_inv, avg);
+    if (rc) return rc;
+    if (m == 0) return 0;
+    if (!out || !plan_rows || !slice_off || (e > 0 && (!plan_rec || !plan_other))) return MCCNN_E_BADARG;
+    if (!rows_shape_ok(a, 0, sorted_feats, out)) return MCCNN_E_SHAPE;
+    const size_t lds = (size_t)a.nb * MCCNN_WQ_FWD * sizeof(float);
+    if (lds > 64 * 1024) return MCCNN_E_TOOLARGE;  // nb <= 89; wider layers keep the column-tiled streaming kernels
+    hipStream_t s = (hipStream_t)stream;
+    RowPlan p = {plan_rows, slice_off, reinterpret_cast<const float4*>(plan_rec), plan_other, m, (m + 63) / 64};
+    const int tiles = (a.nb + 3) / 4;
+    const long long items = (long long)p.S * tiles;
+    if (items > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
+    typedef void (*Kern)(ConvArgs, RowPlan, float*, int, int);
+    Kern fn = bf16 ? dw_fwd_rows<4> : dw_fwd_rows<2>;
+    const int perCU = cached_blocks_per_cu(reinterpret_cast<const void*>(fn), lds);
+    long long blocks = (long long)num_cus() * perCU;
+    if (blocks > (items + 3) / 4) blocks = (items + 3) / 4;
+    if (blocks < 1) blocks = 1;
+    fn<<<(int)blocks, 256, lds, s>>>(a, p, (float*)out, tiles, (int)items);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+size_t mccnn_spatial_conv_bwd_rows_workspace_bytes(int n, int num_feats) {
+    if (n <= 0 || num_feats <= 0) return 256;
+    const int S = (n + 63) / 64, nb = (num_feats + 7) / 8;
+    const int spw = bwd_rows_spw(S, nb);
+    const long long groups = (S + spw - 1) / spw;
+    return align_up((size_t)groups * nb * 176 * sizeof(float)) + 256;
+}
+
+int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feats, const int* sorted_batch_ids,
+                                const float* pdfs, const float* samples, const int* start_idx, const int* packed,
+                                const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
+                                const float* w2, const float* b2, const float* w3, const float* b3, const void* out_grad,
+                                int n, int m, int e, int num_feats, int batch_size, float radius, int scale_inv, int avg,
+                                int bf16, const int* plan_rows, const int* slice_off, const void* plan_rec,
+                                const int* plan_other, void* feat_grad, float* dw1, float* db1, float* dw2, float* db2,
+                                float* dw3, float* db3, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    ConvArgs a;
+    int rc = conv_fill_args(a, sorted_pts, (const float*)sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed,
+                            aabb_min, aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_feats, num_feats, 0, batch_size, radius,
+                            scale_inv, avg);
+    if (rc) return rc;
+    if (!dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3 || (n > 0 && !feat_grad)) return MCCNN_E_BADARG;
+    if (n == 0 || m == 0 || e == 0) return MCCNN_E_BADARG;  // empty lists take mccnn_spatial_conv_bwd
+    if (!out_grad || !plan_rows || !slice_off || !plan_rec || !plan_other) return MCCNN_E_BADARG;
+    if (!rows_shape_ok(a, 0, sorted_feats, out_grad) || (((uintptr_t)feat_grad) & 15)) return MCCNN_E_SHAPE;
+    if (!ws || ws_bytes < mccnn_spatial_conv_bwd_rows_workspace_bytes(n, num_feats)) return MCCNN_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    RowPlan p = {plan_rows, slice_off, reinterpret_cast<const float4*>(plan_rec), plan_other, n, (n + 63) / 64};
+    const int spw = bwd_rows_spw(p.S, a.nb);
+    const int groups = (p.S + spw - 1) / spw;
+    const int qTiles = (a.nb + 3) / 4;
+    const long long blocks = (long long)groups * qTiles;
+    if (blocks > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
+    float* partials = reinterpret_cast<float*>(ws);
+    const size_t lds = ((size_t)4 * MCCNN_WQ_BWD + 4 * 512) * sizeof(float);  // 4 blocks of weights + the parked feature pieces
+    if (bf16) dw_bwd_rows<4><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, partials, spw);
+    else dw_bwd_rows<2><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, partials, spw);
+    MCCNN_LAUNCHED();
+    launch_reduce_partials(partials, groups, a.nb, dw1, db1, dw2, db2, dw3, db3, s);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+}  // extern "C"

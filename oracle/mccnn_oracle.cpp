@@ -292,7 +292,12 @@ int orc_find_neighbors_fill(const float* centres, const int* cbids, int m, const
 // compute_pdf.cu:40-94. pts/bids are the *sorted* point list the packed j index.
 int orc_compute_pdf(const float* pts, const int* bids, const int* startIdx, int m,
                     const int* packed, int e, const float* mn, const float* mx, float window,
-                    float radius, int scaleInv, float* pdfs) {
+                    float radius, int scaleInv, float* pdfs, int exactCount) {
+    // exactCount: compute_pdf.cu:92 divides by `(float)end - start`, a FLOAT subtraction. Beyond 2^24 edges both offsets
+    // round to multiples of 2 (then 4, ...): rows of 1..3 neighbours get a count of 0, 2 or 4 and the reference writes
+    // inf or a value off by a factor -- a defect of the reference at sizes it was never run at (BASELINE cfg4 as one
+    // batch of 8 rooms has 36 M edges). The default (0) keeps the reference expression bit for bit; 1 subtracts the
+    // integers first, which is what the HIP kernels do at every size (identical below 2^24 edges).
 #pragma omp parallel for schedule(dynamic, 1024)
     for (int t = 0; t < e; ++t) {
         int cur = packed[2 * (size_t)t];
@@ -318,7 +323,7 @@ int orc_compute_pdf(const float* pts, const int* bids, const int* startIdx, int 
             g = (float)(g * invH * ((0.39894228) * std::exp((-0.5) * d2 * d2)));
             pdf += g;
         }
-        pdfs[t] = pdf / ((float)i1 - i0);  // compute_pdf.cu:92
+        pdfs[t] = exactCount ? pdf / (float)(i1 - i0) : pdf / ((float)i1 - i0);  // compute_pdf.cu:92
     }
     return 0;
 }

@@ -147,14 +147,16 @@ class Oracle:
         return start.reshape(-1, 1), packed
 
     def compute_pdf(self, inPts, inBatchIds, aabbMin, aabbMax, startIndexs, neighbors, window, radius, batchSize,
-                    scaleInv):
+                    scaleInv, exactCount=False):
+        """exactCount: see orc_compute_pdf -- the reference's float subtraction of the row offsets breaks beyond 2^24
+        edges; False keeps the reference expression."""
         p, b = self._f32(inPts), self._i32(inBatchIds).reshape(-1)
         mn, mx = self._f32(aabbMin), self._f32(aabbMax)
         st, pk = self._i32(startIndexs).reshape(-1), self._i32(neighbors)
         pdfs = np.empty((len(pk), 1), np.float32)
         self._chk(self.lib.orc_compute_pdf(self._p(p), self._p(b), self._p(st), len(st), self._p(pk), len(pk),
                                            self._p(mn), self._p(mx), C.c_float(window), C.c_float(radius),
-                                           int(scaleInv), self._p(pdfs)), "compute_pdf")
+                                           int(scaleInv), self._p(pdfs), int(bool(exactCount))), "compute_pdf")
         return pdfs
 
     def poisson_sampling(self, inPts, inBatchIds, cellIndexs, aabbMin, aabbMax, radius, batchSize, scaleInv):

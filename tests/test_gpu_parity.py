@@ -218,6 +218,8 @@ def test_spatial_conv_fwd_bwd(mc, oracle, case):
     others = [(1, "VALU kernels")]
     if combin and fin == 1:
         others.append((2, "general MFMA kernels"))
+    if not combin and fin % 8 == 0:
+        others.append((4, "edge-streaming MFMA kernels"))   # the default for these layers is the row-per-lane form
     for mask, label in others:
         mc.debug_conv_impl(mask)
         try:
