@@ -325,7 +325,7 @@ int mccnn_rowplan_fill(int transposed, const float* sorted_pts, const int* sorte
  * plan (rows = the n points) and evaluates the kernel MLP once per (edge, block) for the feature gradient and the six
  * parameter gradients together (the edge-major form needs a second pass over the transposed list). bf16 != 0: rows
  * (features, outputs, out-gradients, feature gradients) stored as bf16 like mccnn_spatial_conv_*_bf16. Every output
- * row is written exactly once; no atomics; bit-reproducible. Layers wider than 89 blocks: MCCNN_E_TOOLARGE (fwd). */
+ * row is written exactly once; no atomics; bit-reproducible. */
 int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feats,
                                 const int* sorted_batch_ids, const float* pdfs, const float* samples,
                                 const int* start_idx, const int* packed, const float* aabb_min,

@@ -956,7 +956,7 @@ class _SpatialConv(torch.autograd.Function):
                                     numOutFeatures, combin, batchSize, radius)
         lib = _lib.load()
         outF = numOutFeatures if combin else fin
-        if _rows_shape(combin, fin, feats, m, e) and (fin + 7) // 8 <= 89:
+        if _rows_shape(combin, fin, feats, m, e):
             # depth-wise layer on the row-per-lane kernels: forward plan of the neighbour list (built once per list)
             plan = _row_plan(packedNeighs if pk is packedNeighs else pk, False, pts, bids, pdfs, smp, st, pk, mn, mx, n, m,
                              e, batchSize, radius, scaleInv, avg, centre_points=inSamplePts)

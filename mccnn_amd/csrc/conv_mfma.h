@@ -128,6 +128,79 @@ __device__ __forceinline__ void layer8(const f32x4* __restrict__ wrows /* 16 x f
     for (int r = 0; r < 4; ++r) { y[r] = lo[r]; y[4 + r] = hi[r]; }
 }
 
+// The same layer with the lane's weight rows already in registers (kernels that keep one block's weights resident
+// across a whole sweep: no LDS traffic in the loop). al / ah: rows i4 and 4 + i4 of W, bl / bh their biases.
+template <bool BIAS>
+__device__ __forceinline__ void layer8_regs(const float* al, const float* ah, float bl, float bh, const float* x, float* y) {
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        lo = MFMA4(al[k], x[k], lo);
+        hi = MFMA4(ah[k], x[k], hi);
+    }
+    if (BIAS) {
+        const float one = opaque_one();
+        lo = MFMA4(bl, one, lo);
+        hi = MFMA4(bh, one, hi);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { y[r] = lo[r]; y[4 + r] = hi[r]; }
+}
+
+// One block's forward weights as the lane needs them for the 4x4x1 form (44 VGPRs), read straight from the flat
+// tensors (w1[nu][3], w2 / w3 [q][out][in]): rows i4 and 4 + i4 of every layer.
+struct BlockWeights {
+    float w1lo[4], w1hi[4];      // (w0, w1, w2, b1) of neurons i4 / 4 + i4
+    float w2lo[8], w2hi[8], b2lo, b2hi;
+    float w3lo[8], w3hi[8], b3lo, b3hi;
+};
+__device__ __forceinline__ void load_block_weights(const ConvArgs& a, int q, int i4, BlockWeights& w) {
+    const int nl = q * 8 + i4, nh = nl + 4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { w.w1lo[c] = a.w1[nl * 3 + c]; w.w1hi[c] = a.w1[nh * 3 + c]; }
+    w.w1lo[3] = a.b1[nl]; w.w1hi[3] = a.b1[nh];
+    const float4* r2l = reinterpret_cast<const float4*>(a.w2 + (size_t)q * 64 + i4 * 8);
+    const float4* r2h = reinterpret_cast<const float4*>(a.w2 + (size_t)q * 64 + (4 + i4) * 8);
+    const float4* r3l = reinterpret_cast<const float4*>(a.w3 + (size_t)q * 64 + i4 * 8);
+    const float4* r3h = reinterpret_cast<const float4*>(a.w3 + (size_t)q * 64 + (4 + i4) * 8);
+    const float4 a0 = r2l[0], a1 = r2l[1], b0 = r2h[0], b1 = r2h[1], c0 = r3l[0], c1 = r3l[1], d0 = r3h[0], d1 = r3h[1];
+    w.w2lo[0] = a0.x; w.w2lo[1] = a0.y; w.w2lo[2] = a0.z; w.w2lo[3] = a0.w; w.w2lo[4] = a1.x; w.w2lo[5] = a1.y; w.w2lo[6] = a1.z; w.w2lo[7] = a1.w;
+    w.w2hi[0] = b0.x; w.w2hi[1] = b0.y; w.w2hi[2] = b0.z; w.w2hi[3] = b0.w; w.w2hi[4] = b1.x; w.w2hi[5] = b1.y; w.w2hi[6] = b1.z; w.w2hi[7] = b1.w;
+    w.w3lo[0] = c0.x; w.w3lo[1] = c0.y; w.w3lo[2] = c0.z; w.w3lo[3] = c0.w; w.w3lo[4] = c1.x; w.w3lo[5] = c1.y; w.w3lo[6] = c1.z; w.w3lo[7] = c1.w;
+    w.w3hi[0] = d0.x; w.w3hi[1] = d0.y; w.w3hi[2] = d0.z; w.w3hi[3] = d0.w; w.w3hi[4] = d1.x; w.w3hi[5] = d1.y; w.w3hi[6] = d1.z; w.w3hi[7] = d1.w;
+    w.b2lo = a.b2[nl]; w.b2hi = a.b2[nh];
+    w.b3lo = a.b3[nl]; w.b3hi = a.b3[nh];
+}
+// Kernel MLP of one block from register-resident weights: identical chains (and bits) as mlp_block_mfma.
+__device__ __forceinline__ void mlp_block_regs(const BlockWeights& w, float d0, float d1, float d2, float* a1, float* a2, float* o) {
+    float pre[8];
+    {
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+        const float one = opaque_one();
+        lo = MFMA4(w.w1lo[0], d0, lo);
+        hi = MFMA4(w.w1hi[0], d0, hi);
+        lo = MFMA4(w.w1lo[1], d1, lo);
+        hi = MFMA4(w.w1hi[1], d1, hi);
+        lo = MFMA4(w.w1lo[2], d2, lo);
+        hi = MFMA4(w.w1hi[2], d2, hi);
+        lo = MFMA4(w.w1lo[3], one, lo);
+        hi = MFMA4(w.w1hi[3], one, hi);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pre[r] = lo[r]; pre[4 + r] = hi[r]; }
+    }
+    MCCNN_PHASE();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a1[r] = relu1(pre[r]);
+    MCCNN_PHASE();
+    layer8_regs<true>(w.w2lo, w.w2hi, w.b2lo, w.b2hi, a1, pre);
+    MCCNN_PHASE();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a2[r] = relu1(pre[r]);
+    MCCNN_PHASE();
+    layer8_regs<true>(w.w3lo, w.w3hi, w.b3lo, w.b3hi, a2, o);
+    MCCNN_PHASE();
+}
+
 // Layer 1 for 64 edges: pre1 = ((d0 w0 + d1 w1) + d2 w2) + b1 as fma steps (spatial_conv.cu:49-52); the LDS row of
 // neuron r is (w0, w1, w2, b1).
 __device__ __forceinline__ void layer1_mfma(const f32x4* __restrict__ w, int i4, float d0, float d1, float d2, float* pre1) {

@@ -21,6 +21,13 @@
 namespace mccnn {
 
 constexpr int SELL_SIGMA = 1024;
+#ifndef MCCNN_ROWS_ABL
+#define MCCNN_ROWS_ABL 0
+#endif
+
+// Workgroup ids are handed to the 8 XCDs round-robin (id % 8): logical index with every XCD owning one contiguous
+// eighth of [0, grid). grid must be a multiple of 8 (the launchers pad; surplus indices exit).
+__device__ __forceinline__ int xcd_contiguous(int b, int grid) { return (b & 7) * (grid >> 3) + (b >> 3); }
 
 struct RowPlan {
     const int* rows;      // [64 S] row id of (slice, lane), -1 = padding lane
@@ -125,88 +132,122 @@ __global__ __launch_bounds__(256) void sell_fill(ConvArgs a, const int* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------ staged row gather
+// The four waves of a workgroup work on four consecutive MLP blocks of the same 64 rows, so per iteration they need the
+// four 32-byte pieces of ONE 128-byte line of each of the 64 gathered rows. Gathered piece by piece (every wave its own
+// 32 bytes per lane) the L1 issues a request per (wave, lane) and keeps nothing: 4x the L1<->L2 requests the bytes
+// need, and that request rate -- not HBM, not the matrix pipe -- bounded the wide depth-wise kernels (dw256 forward on
+// the room: 1.03 ms; gather alone 1.13 ms; without it 0.66 ms). Staged: wave kp fetches the FULL lines of rows
+// 16 kp .. 16 kp + 15 (lane l: row 16 kp + (l & 15), 32-byte piece l >> 4 -- four lanes cover one line, one request),
+// parks them in LDS one iteration ahead, and after the barrier every wave reads its own piece of all 64 rows.
+// LDS image per buffer: plane h (first / second 16 bytes of a piece) x [producer kp][piece c][row r] x 16 bytes, so a
+// reader's 16 lanes of one producer group touch 256 contiguous bytes (conflict-free).
+// bf16 rows: a line of 4 blocks is 64 bytes, pieces are 16 bytes, one plane.
+struct RowStage {
+    f32x4* buf;  // [2 buffers][2 planes][256]
+    __device__ __forceinline__ f32x4* plane(int b, int h) const { return buf + (b * 2 + h) * 256; }
+};
+#define MCCNN_STAGE_FLOATS (2 * 2 * 256 * 4)
+
+// producer side: the two (f32) / one (bf16) 16-byte loads of this lane's piece; cols = row length in elements
+template <bool BF>
+__device__ __forceinline__ void stage_load(const void* __restrict__ base, int row, int cols, int col0 /* first column of the tile */,
+                                           int lane, f32x4& v0, f32x4& v1) {
+    const int c = lane >> 4;  // piece 0..3 = block col0/8 + c
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (BF) {
+        const unsigned short* rp = reinterpret_cast<const unsigned short*>(base) + (size_t)row * cols;
+        v0 = (col0 + c * 8 < cols) ? *reinterpret_cast<const f32x4*>(rp + col0 + c * 8) : z;
+        v1 = z;
+    } else {
+        const float* rp = reinterpret_cast<const float*>(base) + (size_t)row * cols;
+        const bool ok = col0 + c * 8 < cols;
+        v0 = ok ? *reinterpret_cast<const f32x4*>(rp + col0 + c * 8) : z;
+        v1 = ok ? *reinterpret_cast<const f32x4*>(rp + col0 + c * 8 + 4) : z;
+    }
+}
+template <bool BF>
+__device__ __forceinline__ void stage_store(const RowStage& st, int b, int wave, int lane, const f32x4& v0, const f32x4& v1) {
+    st.plane(b, 0)[wave * 64 + lane] = v0;
+    if (!BF) st.plane(b, 1)[wave * 64 + lane] = v1;
+}
+// reader side: the 8 values of this wave's block for the lane's row
+template <bool BF>
+__device__ __forceinline__ void stage_read(const RowStage& st, int b, int wave, int lane, float* f) {
+    const int slot = (lane >> 4) * 64 + wave * 16 + (lane & 15);
+    if (BF) {
+        const f32x4 u = st.plane(b, 0)[slot];
+        bf16x8_to_f32(make_uint4(__float_as_uint(u.x), __float_as_uint(u.y), __float_as_uint(u.z), __float_as_uint(u.w)), f);
+    } else {
+        const f32x4 u0 = st.plane(b, 0)[slot], u1 = st.plane(b, 1)[slot];
+        f[0] = u0.x; f[1] = u0.y; f[2] = u0.z; f[3] = u0.w; f[4] = u1.x; f[5] = u1.y; f[6] = u1.z; f[7] = u1.w;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ depth-wise forward
-// Work item = (slice, tile of 4 consecutive MLP blocks = one 128-byte line of an f32 feature row). Persistent waves:
-// a workgroup stages the layer's weights once and strides over the items. FEAT: 2 = f32 rows, 4 = bf16 rows.
+// Work item = (slice, MLP block q): the block's weights stay in 44 VGPRs for the whole slice -- the loop reads no
+// weights -- and the lane's 8 sums are stored once at the end. The four waves of a workgroup take four consecutive
+// blocks of one slice and gather the feature rows together (RowStage). Workgroups are dispatched in slice order =
+// windows of descending row length: fine-grained items, no tail. FEAT: 2 = f32 rows, 4 = bf16 rows.
 template <int FEAT>
-__global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float* __restrict__ out, int tiles, int items) {
-    extern __shared__ float lds[];
+__global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float* __restrict__ out, int qTiles) {
+    __shared__ float stageMem[MCCNN_STAGE_FLOATS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i4 = lane & 3;
-    stage_weights<MCCNN_WQ_FWD>(a, lds);
-    __syncthreads();
     constexpr bool BF = FEAT == 4;
-    const unsigned short* feats16 = reinterpret_cast<const unsigned short*>(a.feats);
     unsigned short* out16 = reinterpret_cast<unsigned short*>(out);
-    const int gridWaves = gridDim.x * 4;
-    for (int w = blockIdx.x * 4 + wave; w < items; w += gridWaves) {
-        const int slice = w / tiles, tile = w - slice * tiles;
-        const int q0 = tile * 4;
-        const int nbT = min(4, a.nb - q0);
-        const int off = p.sliceOff[slice];
-        const int len = (p.sliceOff[slice + 1] - off) >> 6;
-        const int r = p.rows[slice * 64 + lane];
-        float acc[4][8];
+    // Workgroup -> (block tile, slice), tile-major, every XCD a contiguous range: the workgroups resident on one XCD
+    // work on ONE 128-byte column of the feature rows for neighbouring slices, whose reuse of the lines its L2 serves.
+    const int L = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int total = p.S * qTiles;
+    if (L >= total) return;
+    const int qt = L / p.S, slice = L - qt * p.S;
+    const int q = qt * 4 + wave;
+    const bool mine = q < a.nb;  // a wave beyond the last block still gathers and meets the barriers
+    const RowStage st = {reinterpret_cast<f32x4*>(stageMem)};
+    BlockWeights w;
+    load_block_weights(a, mine ? q : 0, i4, w);
+    const int off = p.sliceOff[slice];
+    const int len = (p.sliceOff[slice + 1] - off) >> 6;
+    const int r = p.rows[slice * 64 + lane];
+    const int prow = wave * 16 + (lane & 15);  // the row of the slice this lane fetches as a producer
+    float acc[8];
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int n = 0; n < 8; ++n) acc[b][n] = 0.f;
-        float4 rcN = make_float4(0.f, 0.f, 0.f, 0.f);
-        int jN = 0;
-        if (len > 0) { rcN = p.rec[(size_t)off + lane]; jN = p.other[(size_t)off + lane]; }
-        for (int it = 0; it < len; ++it) {
-            const float4 rc = rcN;
-            const int j = jN;
-            if (it + 1 < len) {
-                const size_t sn = (size_t)off + (size_t)(it + 1) * 64 + lane;
-                rcN = p.rec[sn];
-                jN = p.other[sn];
-            }
-            float f[4][8];
-            if (BF) {
-                const uint4* fp = reinterpret_cast<const uint4*>(feats16 + (size_t)j * a.Fin + q0 * 8);
-                uint4 fl[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) fl[b] = (b < nbT) ? fp[b] : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) bf16x8_to_f32(fl[b], f[b]);
-            } else {
-                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)j * a.Fin + q0 * 8);
-                float4 fl[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) fl[k] = (k < 2 * nbT) ? fp[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    f[b][0] = fl[2 * b].x; f[b][1] = fl[2 * b].y; f[b][2] = fl[2 * b].z; f[b][3] = fl[2 * b].w;
-                    f[b][4] = fl[2 * b + 1].x; f[b][5] = fl[2 * b + 1].y; f[b][6] = fl[2 * b + 1].z; f[b][7] = fl[2 * b + 1].w;
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (b < nbT) {
-                    // the LDS weight reads stay inside the loop (hoisted they would pin 44 VGPRs per block)
-                    int woff = (q0 + b) * MCCNN_WQ_FWD;
-                    asm volatile("" : "+s"(woff));
-                    float pre1[8], a1[8], pre2[8], a2[8], o[8];
-                    MCCNN_PHASE();
-                    mlp_block_mfma(lds + woff, i4, rc.x, rc.y, rc.z, pre1, a1, pre2, a2, o);
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) acc[b][n] = __builtin_fmaf(f[b][n] * rc.w, o[n], acc[b][n]);
-                }
-            }
+    for (int n = 0; n < 8; ++n) acc[n] = 0.f;
+    float4 rcN = make_float4(0.f, 0.f, 0.f, 0.f);
+    int jP = 0;  // producer: neighbour index of row `prow`, two iterations ahead of the consumer
+    f32x4 s0, s1;
+    if (len > 0) {
+        rcN = p.rec[(size_t)off + lane];
+        stage_load<BF>(a.feats, p.other[(size_t)off + prow], a.Fin, qt * 32, lane, s0, s1);
+        if (len > 1) jP = p.other[(size_t)off + 64 + prow];
+        stage_store<BF>(st, 0, wave, lane, s0, s1);
+    }
+    __syncthreads();
+    for (int it = 0; it < len; ++it) {
+        const float4 rc = rcN;
+        const bool more = it + 1 < len;
+        if (more) {  // iteration it + 1: its lines are requested now and parked after this iteration's arithmetic
+            stage_load<BF>(a.feats, jP, a.Fin, qt * 32, lane, s0, s1);
+            rcN = p.rec[(size_t)off + (size_t)(it + 1) * 64 + lane];
+            if (it + 2 < len) jP = p.other[(size_t)off + (size_t)(it + 2) * 64 + prow];
         }
-        if (r >= 0) {
+        float f[8];
+        stage_read<BF>(st, it & 1, wave, lane, f);
+        float a1[8], a2[8], o[8];
+        MCCNN_PHASE();
+        mlp_block_regs(w, rc.x, rc.y, rc.z, a1, a2, o);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (b < nbT) {
-                    if (BF) {
-                        reinterpret_cast<uint4*>(out16 + (size_t)r * a.outF)[q0 + b] = f32x8_to_bf16(acc[b]);
-                    } else {
-                        float4* dst = reinterpret_cast<float4*>(out + (size_t)r * a.outF + (q0 + b) * 8);
-                        dst[0] = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
-                        dst[1] = make_float4(acc[b][4], acc[b][5], acc[b][6], acc[b][7]);
-                    }
-                }
-            }
+        for (int n = 0; n < 8; ++n) acc[n] = __builtin_fmaf(f[n] * rc.w, o[n], acc[n]);
+        if (more) stage_store<BF>(st, (it + 1) & 1, wave, lane, s0, s1);
+        __syncthreads();
+    }
+    if (r >= 0 && mine) {
+        if (BF) {
+            reinterpret_cast<uint4*>(out16 + (size_t)r * a.outF)[q] = f32x8_to_bf16(acc);
+        } else {
+            float4* dst = reinterpret_cast<float4*>(out + (size_t)r * a.outF + q * 8);
+            dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
         }
     }
 }
@@ -219,11 +260,15 @@ __global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float*
 // Math: spatial_conv.cu:563-680 (see conv_bwd_mfma in conv.hip for the same steps in the edge-major form).
 template <int FEAT>
 __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, const float* __restrict__ outGrad,
-                                                      float* __restrict__ featGrad, float* __restrict__ partials, int spw) {
+                                                      float* __restrict__ featGrad, float* __restrict__ partials, int spw, int groups) {
     extern __shared__ float lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i4 = lane & 3;
     const int qTiles = (a.nb + 3) >> 2;
-    const int g = blockIdx.x / qTiles, qt = blockIdx.x - g * qTiles;
+    // tile-major, XCD-contiguous (see dw_fwd_rows): the out-gradient rows a workgroup gathers are shared with the
+    // neighbouring slice groups that run beside it on the same XCD
+    const int L = xcd_contiguous(blockIdx.x, gridDim.x);
+    if (L >= groups * qTiles) return;
+    const int qt = L / groups, g = L - qt * groups;
     {   // this workgroup's four blocks only
         ConvArgs t = a;
         const int q0 = qt * 4;
@@ -236,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
     __syncthreads();
     const int q = qt * 4 + wave;
     if (q >= a.nb) return;
+    const int qq = q;
     constexpr bool BF = FEAT == 4;
     const unsigned short* feats16 = reinterpret_cast<const unsigned short*>(a.feats);
     const unsigned short* og16 = reinterpret_cast<const unsigned short*>(outGrad);
@@ -261,10 +307,10 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
         {
             float ff0[8];
             if (BF) {
-                const uint4 fu = reinterpret_cast<const uint4*>(feats16 + (size_t)jr * a.Fin)[q];
+                const uint4 fu = reinterpret_cast<const uint4*>(feats16 + (size_t)jr * a.Fin)[qq];
                 bf16x8_to_f32(fu, ff0);
             } else {
-                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)jr * a.Fin + q * 8);
+                const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)jr * a.Fin + qq * 8);
                 const float4 fa = fp[0], fb = fp[1];
                 ff0[0] = fa.x; ff0[1] = fa.y; ff0[2] = fa.z; ff0[3] = fa.w; ff0[4] = fb.x; ff0[5] = fb.y; ff0[6] = fb.z; ff0[7] = fb.w;
             }
@@ -274,6 +320,9 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
         float dF[8];
 #pragma unroll
         for (int n = 0; n < 8; ++n) dF[n] = 0.f;
+        // (Staging the out-gradient rows through LDS like the forward's feature rows was measured and dropped: parked
+        // right after the load the wait is exposed at the top of every iteration, parked late the 8 extra VGPRs spill
+        // the sums -- 3.38 ms against 2.40 ms for dw256 on the room. Each wave gathers its own 32-byte piece.)
         float4 rcN = make_float4(0.f, 0.f, 0.f, 0.f);
         int iN = 0;
         if (len > 0) { rcN = p.rec[(size_t)off + lane]; iN = p.other[(size_t)off + lane]; }
@@ -401,7 +450,9 @@ int conv_fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_fea
                    int batch_size, float radius, int scale_inv, int avg);
 
 static int bwd_rows_spw(int S, int nb) {
-    long long spw = ((long long)S * nb) / 4096;  // >= ~4096 waves in the launch (2 rounds of the resident 2048)
+    // workgroups are dispatched as slots free up: >= ~12 rounds of the 2048 resident waves keep the tail below one
+    // workgroup in twelve, while every extra slice per wave amortises the 176-value reduction at its end
+    long long spw = ((long long)S * nb) / 24576;
     if (spw > 8) spw = 8;
     if (spw < 1) spw = 1;
     return (int)spw;
@@ -486,20 +537,13 @@ int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feat
     if (m == 0) return 0;
     if (!out || !plan_rows || !slice_off || (e > 0 && (!plan_rec || !plan_other))) return MCCNN_E_BADARG;
     if (!rows_shape_ok(a, 0, sorted_feats, out)) return MCCNN_E_SHAPE;
-    const size_t lds = (size_t)a.nb * MCCNN_WQ_FWD * sizeof(float);
-    if (lds > 64 * 1024) return MCCNN_E_TOOLARGE;  // nb <= 89; wider layers keep the column-tiled streaming kernels
     hipStream_t s = (hipStream_t)stream;
     RowPlan p = {plan_rows, slice_off, reinterpret_cast<const float4*>(plan_rec), plan_other, m, (m + 63) / 64};
-    const int tiles = (a.nb + 3) / 4;
-    const long long items = (long long)p.S * tiles;
-    if (items > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
-    typedef void (*Kern)(ConvArgs, RowPlan, float*, int, int);
-    Kern fn = bf16 ? dw_fwd_rows<4> : dw_fwd_rows<2>;
-    const int perCU = cached_blocks_per_cu(reinterpret_cast<const void*>(fn), lds);
-    long long blocks = (long long)num_cus() * perCU;
-    if (blocks > (items + 3) / 4) blocks = (items + 3) / 4;
-    if (blocks < 1) blocks = 1;
-    fn<<<(int)blocks, 256, lds, s>>>(a, p, (float*)out, tiles, (int)items);
+    const int qTiles = (a.nb + 3) / 4;
+    const long long blocks = ((long long)p.S * qTiles + 7) / 8 * 8;
+    if (blocks > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
+    if (bf16) dw_fwd_rows<4><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, qTiles);
+    else dw_fwd_rows<2><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, qTiles);
     MCCNN_LAUNCHED();
     return 0;
 }
@@ -535,12 +579,12 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
     const int spw = bwd_rows_spw(p.S, a.nb);
     const int groups = (p.S + spw - 1) / spw;
     const int qTiles = (a.nb + 3) / 4;
-    const long long blocks = (long long)groups * qTiles;
+    const long long blocks = ((long long)groups * qTiles + 7) / 8 * 8;
     if (blocks > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     float* partials = reinterpret_cast<float*>(ws);
     const size_t lds = ((size_t)4 * MCCNN_WQ_BWD + 4 * 512) * sizeof(float);  // 4 blocks of weights + the parked feature pieces
-    if (bf16) dw_bwd_rows<4><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, partials, spw);
-    else dw_bwd_rows<2><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, partials, spw);
+    if (bf16) dw_bwd_rows<4><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, partials, spw, groups);
+    else dw_bwd_rows<2><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, partials, spw, groups);
     MCCNN_LAUNCHED();
     launch_reduce_partials(partials, groups, a.nb, dw1, db1, dw2, db2, dw3, db3, s);
     MCCNN_LAUNCHED();
