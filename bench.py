@@ -245,51 +245,42 @@ class Workload:
         lib = M._lib.load()
         n, m, e = sP.shape[0], P.shape[0], packed.shape[0]
         outF = fout if combin else fin
-        o = torch.empty((m, outF), dtype=torch.float32, device=device)
-        fwd_ws = torch.empty(max(256, lib.mccnn_spatial_conv_fwd_workspace_bytes(m, e, fin, fout, int(combin))),
-                             dtype=torch.uint8, device=device)
-        conv_args = (ptr(sP), ptr(sF), ptr(sB), ptr(pdfs), ptr(P), ptr(start), ptr(packed), ptr(mn), ptr(mx), ptr(w1),
-                     ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3))
-        sbytes = lib.mccnn_spatial_conv_state_bytes(m, e, fin, fout, int(combin))
-        state = torch.empty(sbytes, dtype=torch.uint8, device=device) if sbytes else None  # kept fwd -> bwd, as autograd does
-        t_fwd, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_fwd(*conv_args, n, m, e, fin, fout, int(combin), B, r, 0,
-                                                                    1, ptr(o), ptr(state), ptr(fwd_ws), fwd_ws.numel(),
-                                                                    stream_handle()), "conv_fwd"))
-        fg = torch.empty_like(sF)
-        gws = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]
-        bwd_ws = torch.empty(max(256, lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, fout, int(combin))),
-                             dtype=torch.uint8, device=device)
-        # the transposed neighbour list of depth-wise layers is built once per neighbour list and shared by the layers
-        # that convolve over it (ConvolutionBuilder caches the list the same way): timed on its own line
-        start_t = perm_t = None
+        # spatial_conv forward / backward through the PRODUCT op surface (mccnn_amd.MCConvModule.spatial_conv and its
+        # autograd node), i.e. whichever kernels the layer shape selects -- edge-streaming, factored Fin = 1, or
+        # row-per-lane over the list's plans -- with everything that is built once per neighbour list (transposed list,
+        # row plans) already cached, as every further layer over the same list sees it
+        pw = [p.detach().clone().requires_grad_(True) for p in self.builder.parameters()]
+        w1p, b1p, w2p, b2p, w3p, b3p = pw[0], pw[1], pw[2].reshape(8, -1), pw[3].reshape(-1), pw[4].reshape(8, -1), pw[5].reshape(-1)
+
+        def conv_times(sFx, ogx):
+            sFr = sFx.detach().clone().requires_grad_(True)
+
+            def fwd():
+                return M.spatial_conv(sP, sFr, sB, pdfs, P, start, packed, mn, mx, w1p, w2p, w3p, b1p, b2p, b3p, fout, combin, B,
+                                      r, False, True)
+            torch.autograd.grad([fwd()], [sFr] + pw, [ogx])  # builds the per-list structures
+            tf, _ = ev_time(fwd)
+            outs = iter([fwd() for _ in range(22)])
+            tb, gr = ev_time(lambda: torch.autograd.grad([next(outs)], [sFr] + pw, [ogx]))
+            return tf, tb, gr[0]
+        t_fwd, t_bwd, fg = conv_times(sF, self.OG)
         t_tr = None
-        if not combin:
+        if not combin:  # the transposed neighbour list of depth-wise layers: built once per neighbour list, timed on its own
             start_t = torch.empty(n + 1, dtype=torch.int32, device=device)
             perm_t = torch.empty(max(e, 1), dtype=torch.int32, device=device)
             tws = torch.empty(max(256, lib.mccnn_transpose_neighbors_workspace_bytes(n, e)), dtype=torch.uint8, device=device)
             t_tr, _ = ev_time(lambda: check(lib.mccnn_transpose_neighbors(ptr(packed), e, n, ptr(start_t), ptr(perm_t),
                                                                            ptr(tws), tws.numel(), stream_handle()),
                                             "transpose_neighbors"))
-        t_bwd, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_bwd(*conv_args, ptr(self.OG), n, m, e, fin, fout, int(combin), B,
-                                                                    r, 0, 1, ptr(state), ptr(start_t), ptr(perm_t), ptr(fg),
-                                                                    *[ptr(g) for g in gws],
-                                                                    ptr(bwd_ws), bwd_ws.numel(), stream_handle()),
-                                         "conv_bwd"))
+            del start_t, perm_t, tws
         # depth-wise layers with bf16 feature rows (extension, BASELINE cfg3): same launches, rows stored as bf16
         bf16 = None
         if not combin and fin % 8 == 0:
-            f16, og16 = sF.to(torch.bfloat16), self.OG.to(torch.bfloat16)
-            o16, fg16 = torch.empty_like(og16), torch.empty_like(f16)
-            t_f16, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_fwd_bf16(*conv_args[:1], ptr(f16), *conv_args[2:], n, m, e, fin,
-                                                                             B, r, 0, 1, ptr(o16), ptr(fwd_ws), fwd_ws.numel(),
-                                                                             stream_handle()), "conv_fwd_bf16"))
-            t_b16, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_bwd_bf16(*conv_args[:1], ptr(f16), *conv_args[2:], ptr(og16), n,
-                                                                             m, e, fin, B, r, 0, 1, ptr(start_t), ptr(perm_t),
-                                                                             ptr(fg16), *[ptr(g) for g in gws], ptr(bwd_ws),
-                                                                             bwd_ws.numel(), stream_handle()), "conv_bwd_bf16"))
+            t_f16, t_b16, _ = conv_times(sF.to(torch.bfloat16), self.OG.to(torch.bfloat16))
             bf16 = {"fwd_ms": round(t_f16, 4), "bwd_ms": round(t_b16, 4),
                     "note": "features, outputs and their gradients stored as bf16 rows; MLP and accumulation f32"}
-            del f16, og16, o16, fg16
+        plans = getattr(packed, "_mccnn_rowplans", None)
+        kernels = "row-per-lane (conv_rows.hip)" if plans else ("factored Fin = 1 (conv_f1.hip)" if (combin and fin == 1) else "edge-streaming (conv.hip)")
         t_s2g, _ = ev_time(lambda: M._gather_rows(fg, idx, n))
         C = int(np.prod(cells.shape[:4]))
         # algorithmic work per launch (stated in DESIGN.md section 6)
@@ -331,7 +322,7 @@ class Workload:
         ach = work / (ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
         roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak,
                     "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                    "ms": round(ms, 4), "edges": e, "mlp_blocks": nb}
+                    "ms": round(ms, 4), "edges": e, "mlp_blocks": nb, "conv_kernels": kernels}
         if bound == "hbm" and dom.startswith("spatial_conv_"):
             # wide depth-wise layer on ONE room: its gathered rows (SURVEY 8d prices the layer by them) are Infinity-Cache
             # hits, not HBM traffic (counter traffic is ~1/3 of the algorithmic bytes), so the HBM peak is the wrong

@@ -293,58 +293,68 @@ int mccnn_transform_indexs_dn(const int* in_idx, int s_cap, const int* s_dev, co
 
 /* ROW-PER-LANE LAYOUTS of a neighbour list (extension; no counterpart in the reference, whose kernels walk the list
  * with 8 threads per (edge, block) and float atomics -- spatial_conv.cu:104-176,477-561).
- * A plan stores a CSR list in SELL-64-sigma form: rows (centres for the forward plan, neighbour points for the
- * transposed plan) are sorted by edge count inside windows of 1024 rows of the visiting order and cut into slices
- * of 64; slice s holds (largest count in s) x 64 slots, slot (it, lane) = edge #it of the lane's row: a 16-byte
- * record (delta0, delta1, delta2, 1 / (pdf K)) and the index of the row at the other end of the edge, zero records as
- * padding. With it a lane owns a ROW: the sum over a centre's edges is a per-lane accumulator instead of a segmented
- * wave scan, and the backward pass finishes the feature-gradient row of a point in the same sweep that feeds the
- * weight-gradient sums (mccnn_spatial_conv_fwd_rows / _bwd_rows). One plan serves every layer over the same neighbour
- * list, PDFs, radius and avg flag.
- *   layout: plan_rows[64 S] (row of (slice, lane), -1 = padding lane), slice_off[S + 1] (first slot of every slice,
- *           slice_off[S] = total number of slots -- data dependent: read it back, or size the record buffers from a
- *           previous total and compare), S = ceil(rows / 64). row_start: CSR offsets of the rows (start_idx with
- *           rows = m for the forward plan; start_t of mccnn_transpose_neighbors with rows = n for the transposed
- *           one; entry rows is not read, e closes the last row). order: optional cell-coherent visiting order of
- *           the rows (a permutation; only affects locality). Deterministic.
- *   fill:   the records of every slice that fits capacity_slots (slices beyond it are skipped; the caller compares
- *           slice_off[S] with its capacity). rec: 16 bytes per slot, other: 4 bytes per slot. */
-size_t mccnn_rowplan_workspace_bytes(int rows);
-int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order, int* plan_rows,
-                         int* slice_off, void* ws, size_t ws_bytes, mccnn_stream_t stream);
+ * A plan stores a CSR list in SELL-64-sigma form. Rows (centres for the forward plan, neighbour points for the
+ * transposed plan) longer than 128 edges are cut into VIRTUAL rows of at most 128 edges; virtual rows are sorted by
+ * length inside windows of 1024 (taken in the visiting order of the rows) and cut into slices of 64; slice s holds
+ * (longest virtual row in s) x 64 slots, slot (it, lane) = edge #it of the lane's virtual row: a 16-byte record
+ * (delta0, delta1, delta2, 1 / (pdf K)) and the index of the row at the other end of the edge, zero records as padding.
+ * With it a lane owns a ROW: the sum over a centre's edges is a per-lane accumulator instead of a segmented wave scan,
+ * and the backward pass finishes the feature-gradient row of a point in the same sweep that feeds the weight-gradient
+ * sums (mccnn_spatial_conv_fwd_rows / _bwd_rows). One plan serves every layer over the same neighbour list, PDFs,
+ * radius and avg flag.
+ * Every size is a function of (rows, e) -- mccnn_rowplan_sizes: num_slices S, slot_capacity (a window's slices hold
+ * at most 64 x 128 + its edges slots, so e + 8192 x windows bounds the total), scratch_rows (bound on the number of
+ * virtual rows: pieces of cut rows leave their partial sums in one scratch row each) -- so a plan is laid out and
+ * filled WITHOUT any host read-back.
+ *   layout: plan_vrow[64 S] (row of (slice, lane), -1 = padding lane), plan_vcode[64 S] (virtual row id v of (slice,
+ *           lane) when its row is cut, ~v when it is not), slice_off[S + 1] (first slot of every slice; slices beyond
+ *           the last virtual row are empty), vpos_row[rows] (first virtual row id of every row). row_start: CSR offsets
+ *           of the rows (start_idx with rows = m for the forward plan; start_t of mccnn_transpose_neighbors with
+ *           rows = n for the transposed one; entry `rows` is not read, e closes the last row). order: optional
+ *           cell-coherent visiting order of the rows (a permutation; only affects locality). Deterministic.
+ *   fill:   rec: 16 bytes per slot, other: 4 bytes per slot, both slot_capacity long. */
+int mccnn_rowplan_sizes(int rows, int e, int* num_slices, long long* slot_capacity, long long* scratch_rows);
+size_t mccnn_rowplan_workspace_bytes(int rows, int e);
+int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order, int* plan_vrow,
+                         int* plan_vcode, int* slice_off, int* vpos_row, void* ws, size_t ws_bytes,
+                         mccnn_stream_t stream);
 int mccnn_rowplan_fill(int transposed, const float* sorted_pts, const int* sorted_batch_ids,
                        const float* pdfs, const float* samples, const int* start_idx, const int* packed,
                        const float* aabb_min, const float* aabb_max, int n, int m, int e, int batch_size,
                        float radius, int scale_inv, int avg, const int* row_start, const int* perm_t,
-                       const int* plan_rows, const int* slice_off, long long capacity_slots, void* rec,
-                       int* other, mccnn_stream_t stream);
+                       const int* plan_vrow, const int* plan_vcode, const int* slice_off,
+                       const int* vpos_row, void* rec, int* other, mccnn_stream_t stream);
 
 /* SpatialConv / SpatialConvGrad for DEPTH-WISE layers (combin == 0, num_feats % 8 == 0, 16-byte aligned rows) over a
  * row plan -- same results as mccnn_spatial_conv_fwd / _bwd (spatial_conv.cu:178-325,563-792) up to float summation
- * order. fwd_rows takes the FORWARD plan (rows = the m centres) and needs no workspace; bwd_rows takes the TRANSPOSED
- * plan (rows = the n points) and evaluates the kernel MLP once per (edge, block) for the feature gradient and the six
- * parameter gradients together (the edge-major form needs a second pass over the transposed list). bf16 != 0: rows
- * (features, outputs, out-gradients, feature gradients) stored as bf16 like mccnn_spatial_conv_*_bf16. Every output
- * row is written exactly once; no atomics; bit-reproducible. */
+ * order. fwd_rows takes the FORWARD plan (rows = the m centres); bwd_rows takes the TRANSPOSED plan (rows = the n
+ * points, start_t = its row offsets) and evaluates the kernel MLP once per (edge, block) for the feature gradient and
+ * the six parameter gradients together (the edge-major form needs a second pass over the transposed list). bf16 != 0:
+ * rows (features, outputs, out-gradients, feature gradients) stored as bf16 like mccnn_spatial_conv_*_bf16. scratch:
+ * scratch_rows x num_feats floats (mccnn_rowplan_sizes). Every output row is written exactly once; no atomics;
+ * bit-reproducible. */
 int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feats,
                                 const int* sorted_batch_ids, const float* pdfs, const float* samples,
                                 const int* start_idx, const int* packed, const float* aabb_min,
                                 const float* aabb_max, const float* w1, const float* b1, const float* w2,
                                 const float* b2, const float* w3, const float* b3, int n, int m, int e,
                                 int num_feats, int batch_size, float radius, int scale_inv, int avg,
-                                int bf16, const int* plan_rows, const int* slice_off, const void* plan_rec,
-                                const int* plan_other, void* out, mccnn_stream_t stream);
-size_t mccnn_spatial_conv_bwd_rows_workspace_bytes(int n, int num_feats);
+                                int bf16, const int* plan_vrow, const int* plan_vcode,
+                                const int* slice_off, const int* vpos_row, const void* plan_rec,
+                                const int* plan_other, void* out, float* scratch, mccnn_stream_t stream);
+size_t mccnn_spatial_conv_bwd_rows_workspace_bytes(int n, int e, int num_feats);
 int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feats,
                                 const int* sorted_batch_ids, const float* pdfs, const float* samples,
                                 const int* start_idx, const int* packed, const float* aabb_min,
                                 const float* aabb_max, const float* w1, const float* b1, const float* w2,
                                 const float* b2, const float* w3, const float* b3, const void* out_grad,
                                 int n, int m, int e, int num_feats, int batch_size, float radius,
-                                int scale_inv, int avg, int bf16, const int* plan_rows,
-                                const int* slice_off, const void* plan_rec, const int* plan_other,
-                                void* feat_grad, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
-                                float* db3, void* ws, size_t ws_bytes, mccnn_stream_t stream);
+                                int scale_inv, int avg, int bf16, const int* start_t,
+                                const int* plan_vrow, const int* plan_vcode, const int* slice_off,
+                                const int* vpos_row, const void* plan_rec, const int* plan_other,
+                                void* feat_grad, float* scratch, float* dw1, float* db1, float* dw2,
+                                float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes,
+                                mccnn_stream_t stream);
 
 /* TEST HOOK, not part of the operator surface: selects the convolution implementation for A/B
  * parity tests (bit 0: VALU fallback kernels, bit 1: general MFMA kernels for one-input-feature

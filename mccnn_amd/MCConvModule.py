@@ -257,12 +257,10 @@ def _transposed_neighbors(packed, n):
 #: depth-wise layers (numFeatures % 8 == 0) run the row-per-lane kernels over SELL layouts of the neighbour list
 #: (conv_rows.hip); False = the edge-streaming kernels of conv.hip for every layer
 ROW_KERNELS = os.environ.get("MCCNN_ROW_KERNELS", "1") != "0"
-_SLOT_RATIO = {}  # (device, rows, e // 1024) -> slots of the last plan of that shape (sizes the record buffers up front)
-
-
 class RowPlan:
-    """SELL-64 layout of a neighbour list (include/mccnn.h, mccnn_rowplan_*): device tensors + the slot count."""
-    __slots__ = ("rows", "slice_off", "rec", "other", "slots", "key")
+    """SELL-64 layout of a neighbour list (include/mccnn.h, mccnn_rowplan_*): device tensors; every size is fixed by
+    (rows, e), so building a plan involves no host read-back."""
+    __slots__ = ("vrow", "vcode", "slice_off", "vpos_row", "rec", "other", "scratch_rows", "row_start", "key")
 
 
 def _row_plan(packed_obj, transposed, pts, bids, pdfs, smp, st, pk, mn, mx, n, m, e, batchSize, radius, scaleInv, avg,
@@ -292,49 +290,39 @@ def _row_plan(packed_obj, transposed, pts, bids, pdfs, smp, st, pk, mn, mx, n, m
         order = _order_hint(centre_points) if centre_points is not None else None
         if order is not None and order.shape[0] != m:
             order = None
-    S = (rows + 63) // 64
+    S, cap, srows = C.c_int(0), C.c_longlong(0), C.c_longlong(0)
+    check(lib.mccnn_rowplan_sizes(rows, e, C.byref(S), C.byref(cap), C.byref(srows)), "rowplan_sizes")
+    S, cap = S.value, cap.value
     plan = RowPlan()
     plan.key = key
-    plan.rows = torch.empty(64 * S, dtype=torch.int32, device=dev)
+    plan.row_start = row_start
+    plan.scratch_rows = srows.value
+    plan.vrow = torch.empty(64 * S, dtype=torch.int32, device=dev)
+    plan.vcode = torch.empty(64 * S, dtype=torch.int32, device=dev)
     plan.slice_off = torch.empty(S + 1, dtype=torch.int32, device=dev)
-    ws = _ws(lib.mccnn_rowplan_workspace_bytes(rows), dev)
-    check(lib.mccnn_rowplan_layout(ptr(row_start), rows, e, ptr(order), ptr(plan.rows), ptr(plan.slice_off), ptr(ws),
-                                   ws.numel(), stream_handle()), "rowplan_layout")
-    # the slot count is data dependent: the records are written into buffers sized from the last plan of this shape
-    # while the count travels to the host; too small a guess -> exact repeat
-    gkey = (dev.index, rows, e >> 10, bool(transposed))
-    guess = _SLOT_RATIO.get(gkey, 0)
-
-    def fill(cap):
-        rec = torch.empty((cap, 4), dtype=torch.float32, device=dev)
-        oth = torch.empty(cap, dtype=torch.int32, device=dev)
-        check(lib.mccnn_rowplan_fill(int(bool(transposed)), ptr(pts), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
-                                     ptr(mn), ptr(mx), n, m, e, batchSize, float(radius), int(bool(scaleInv)),
-                                     int(bool(avg)), ptr(row_start), ptr(perm_t), ptr(plan.rows), ptr(plan.slice_off),
-                                     cap, ptr(rec), ptr(oth), stream_handle()), "rowplan_fill")
-        return rec, oth
-
-    box = _pinned_int()
-    box.copy_(plan.slice_off[S:S + 1], non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    filled = None
-    if guess > 0:
-        filled = fill(guess)
-    ev.synchronize()
-    total = int(box[0])
-    if filled is None or total > guess:
-        filled = fill(max(total, 1))
-    plan.rec, plan.other, plan.slots = filled[0], filled[1], total
-    _SLOT_RATIO[gkey] = total + total // 32 + 64
-    if len(_SLOT_RATIO) > 256:
-        _SLOT_RATIO.clear()
+    plan.vpos_row = torch.empty(rows, dtype=torch.int32, device=dev)
+    plan.rec = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+    plan.other = torch.empty(cap, dtype=torch.int32, device=dev)
+    ws = _ws(lib.mccnn_rowplan_workspace_bytes(rows, e), dev)
+    check(lib.mccnn_rowplan_layout(ptr(row_start), rows, e, ptr(order), ptr(plan.vrow), ptr(plan.vcode), ptr(plan.slice_off),
+                                   ptr(plan.vpos_row), ptr(ws), ws.numel(), stream_handle()), "rowplan_layout")
+    check(lib.mccnn_rowplan_fill(int(bool(transposed)), ptr(pts), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk), ptr(mn),
+                                 ptr(mx), n, m, e, batchSize, float(radius), int(bool(scaleInv)), int(bool(avg)),
+                                 ptr(row_start), ptr(perm_t), ptr(plan.vrow), ptr(plan.vcode), ptr(plan.slice_off),
+                                 ptr(plan.vpos_row), ptr(plan.rec), ptr(plan.other), stream_handle()), "rowplan_fill")
     plans[key[0]] = plan
     return plan
 
 
-def _rows_shape(combin, fin, feats, m, e):
-    return ROW_KERNELS and _DEBUG_IMPL == 0 and (not combin) and fin % 8 == 0 and e > 0 and m > 0 and (feats.data_ptr() & 15) == 0
+def _rows_shape(combin, fin, feats, rows, e):
+    """Row-per-lane kernels for this (layer, list)? Depth-wise rows of 8-feature blocks, and not a LARGE list of very
+    SHORT rows (centres in the forward pass, points in the backward pass): below ~16 edges per row the per-slice set-up
+    and the padding of the sorted windows outweigh the cheaper inner loop (measured on BASELINE cfg3: DeConv_1, 8.7
+    edges per row, 0.55 against 0.43 ms). Long rows are fine: the plan cuts them into pieces of 128 edges."""
+    if not (ROW_KERNELS and _DEBUG_IMPL == 0 and (not combin) and fin % 8 == 0 and e > 0 and rows > 0
+            and (feats.data_ptr() & 15) == 0):
+        return False
+    return e / float(rows) >= 16.0 or e <= 100000
 
 
 def clear_caches():
@@ -961,11 +949,13 @@ class _SpatialConv(torch.autograd.Function):
             plan = _row_plan(packedNeighs if pk is packedNeighs else pk, False, pts, bids, pdfs, smp, st, pk, mn, mx, n, m,
                              e, batchSize, radius, scaleInv, avg, centre_points=inSamplePts)
             out = torch.empty((m, outF), dtype=feats.dtype, device=pts.device)
+            scratch = torch.empty((plan.scratch_rows, outF), dtype=torch.float32, device=pts.device)
             check(lib.mccnn_spatial_conv_fwd_rows(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                                   ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
                                                   n, m, e, fin, batchSize, float(radius), int(bool(scaleInv)),
-                                                  int(bool(avg)), int(bf16), ptr(plan.rows), ptr(plan.slice_off),
-                                                  ptr(plan.rec), ptr(plan.other), ptr(out), stream_handle()),
+                                                  int(bool(avg)), int(bf16), ptr(plan.vrow), ptr(plan.vcode),
+                                                  ptr(plan.slice_off), ptr(plan.vpos_row), ptr(plan.rec), ptr(plan.other),
+                                                  ptr(out), ptr(scratch), stream_handle()),
                   "spatial_conv(rows)")
             ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3)
             ctx.state = None
@@ -1030,17 +1020,19 @@ class _SpatialConv(torch.autograd.Function):
         packed_obj = ctx.packed_ref()
         if packed_obj is None:  # the list object is gone (its cache entry was dropped): the saved tensor has the same rows
             packed_obj = pk
-        if _rows_shape(combin, fin, feats, m, e) and n > 0 and (og.data_ptr() & 15) == 0:
+        if _rows_shape(combin, fin, feats, n, e) and m > 0 and (og.data_ptr() & 15) == 0:
             # depth-wise layer: ONE sweep over the transposed row plan finishes the feature gradient and the six
             # parameter gradients (the edge-major kernels evaluate the kernel MLP twice for that)
             plan = _row_plan(packed_obj, True, pts, bids, pdfs, smp, st, pk, mn, mx, n, m, e, batchSize, radius, scaleInv, avg)
-            ws = _ws(lib.mccnn_spatial_conv_bwd_rows_workspace_bytes(n, fin), pts.device)
+            ws = _ws(lib.mccnn_spatial_conv_bwd_rows_workspace_bytes(n, e, fin), pts.device)
+            scratch = torch.empty((plan.scratch_rows, fin), dtype=torch.float32, device=pts.device)
             check(lib.mccnn_spatial_conv_bwd_rows(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                                   ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
                                                   ptr(og), n, m, e, fin, batchSize, radius, int(scaleInv), int(avg),
-                                                  int(bf16), ptr(plan.rows), ptr(plan.slice_off), ptr(plan.rec),
-                                                  ptr(plan.other), ptr(fg), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2),
-                                                  ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
+                                                  int(bf16), ptr(plan.row_start), ptr(plan.vrow), ptr(plan.vcode),
+                                                  ptr(plan.slice_off), ptr(plan.vpos_row), ptr(plan.rec), ptr(plan.other),
+                                                  ptr(fg), ptr(scratch), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(dw3),
+                                                  ptr(db3), ptr(ws), ws.numel(), stream_handle()),
                   "spatial_conv_grad(rows)")
             return (None, fg, None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
                     None, None, None, None, None, None)

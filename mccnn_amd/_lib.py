@@ -53,12 +53,13 @@ SIGNATURES = {
     "mccnn_spatial_conv_bwd": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _i, _i, _f, _i, _i] + [_vp] * 10 + [_vp, _sz, _vp]),
     "mccnn_spatial_conv_fwd_bf16": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp]),
     "mccnn_spatial_conv_bwd_bf16": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _f, _i, _i] + [_vp] * 9 + [_vp, _sz, _vp]),
-    "mccnn_rowplan_workspace_bytes": (_sz, [_i]),
-    "mccnn_rowplan_layout": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "mccnn_rowplan_fill": (_i, [_i] + [_vp] * 8 + [_i, _i, _i, _i, _f, _i, _i] + [_vp] * 4 + [C.c_longlong, _vp, _vp, _vp]),
-    "mccnn_spatial_conv_fwd_rows": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 4 + [_vp, _vp]),
-    "mccnn_spatial_conv_bwd_rows_workspace_bytes": (_sz, [_i, _i]),
-    "mccnn_spatial_conv_bwd_rows": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 4 + [_vp] * 7 + [_vp, _sz, _vp]),
+    "mccnn_rowplan_sizes": (_i, [_i, _i, C.POINTER(_i), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "mccnn_rowplan_workspace_bytes": (_sz, [_i, _i]),
+    "mccnn_rowplan_layout": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_rowplan_fill": (_i, [_i] + [_vp] * 8 + [_i, _i, _i, _i, _f, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp]),
+    "mccnn_spatial_conv_fwd_rows": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp]),
+    "mccnn_spatial_conv_bwd_rows_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mccnn_spatial_conv_bwd_rows": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 7 + [_vp] * 8 + [_vp, _sz, _vp]),
     "mccnn_transpose_neighbors_workspace_bytes": (_sz, [_i, _i]),
     "mccnn_transpose_neighbors": (_i, [_vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
 }

@@ -21,6 +21,12 @@
 namespace mccnn {
 
 constexpr int SELL_SIGMA = 1024;
+// Rows longer than ROWS_L edges (pooling / up-sampling layers: hundreds of neighbours per row) are cut into VIRTUAL rows of
+// at most ROWS_L edges, each with a lane of its own: (a) a list with few, long rows still fills the chip, and (b) the
+// number of slots has a bound the host knows -- windows are sorted by length, so a window's slices hold at most
+// 64 ROWS_L + (its edges) slots -- hence plans are laid out and filled WITHOUT any size read-back. The pieces of a cut
+// row leave their partial sums in a scratch row each; a small pass adds them in order (deterministic).
+constexpr int ROWS_L = 128;
 #ifndef MCCNN_ROWS_ABL
 #define MCCNN_ROWS_ABL 0
 #endif
@@ -30,35 +36,79 @@ constexpr int SELL_SIGMA = 1024;
 __device__ __forceinline__ int xcd_contiguous(int b, int grid) { return (b & 7) * (grid >> 3) + (b >> 3); }
 
 struct RowPlan {
-    const int* rows;      // [64 S] row id of (slice, lane), -1 = padding lane
+    const int* vrow;      // [64 S] row id of (slice, lane), -1 = padding lane
+    const int* vcode;     // [64 S] virtual row id v of (slice, lane); ~v when the row is NOT cut (its sums go straight out)
     const int* sliceOff;  // [S + 1] first slot of every slice; sliceOff[S] = total slots
+    const int* vposRow;   // [rows] first virtual row id of every row
     const float4* rec;    // [slots] (delta0, delta1, delta2, 1 / (pdf K))
     const int* other;     // [slots] the row at the other end of the edge (forward plan: neighbour j; transposed: centre i)
     int numRows, S;
 };
 
+struct PlanSizes {
+    long long vcap;   // bound on the number of virtual rows
+    int windows, S;   // windows of SELL_SIGMA virtual rows, slices of 64
+    long long slots;  // bound on the number of slots
+};
+static PlanSizes plan_sizes(int rows, int e) {
+    PlanSizes z;
+    z.vcap = (long long)rows + e / ROWS_L;
+    z.windows = (int)((z.vcap + SELL_SIGMA - 1) / SELL_SIGMA);
+    z.S = z.windows * (SELL_SIGMA / 64);
+    z.slots = (long long)e + 64LL * ROWS_L * z.windows;
+    return z;
+}
+
 // ------------------------------------------------------------------------------------------------ layout
-// One workgroup per window of SELL_SIGMA rows: bitonic sort of unique keys (descending edge count, then position in the
-// visiting order) -> the layout is a deterministic function of the list, so gradients are bit-reproducible run to run.
+// pieces per row position of the visiting order
+__global__ __launch_bounds__(256) void vr_count(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
+                                                int* __restrict__ vcnt) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= rows) return;
+    int r = order ? order[p] : p;
+    r = max(0, min(r, rows - 1));
+    const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
+    vcnt[p] = max(1, (deg + ROWS_L - 1) / ROWS_L);
+}
+// virtual row id -> row; row -> its first virtual row id
+__global__ __launch_bounds__(256) void vr_expand(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
+                                                 const int* __restrict__ vposP, int* __restrict__ vposRow,
+                                                 int* __restrict__ vlistRow) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= rows) return;
+    int r = order ? order[p] : p;
+    r = max(0, min(r, rows - 1));
+    const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
+    const int vc = max(1, (deg + ROWS_L - 1) / ROWS_L), v0 = vposP[p];
+    vposRow[r] = v0;
+    for (int k = 0; k < vc; ++k) vlistRow[v0 + k] = r;
+}
+// One workgroup per window of SELL_SIGMA virtual rows: bitonic sort of unique keys (descending length, then position) ->
+// the layout is a deterministic function of the list, so gradients are bit-reproducible run to run.
 __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStart, int rows, int e,
-                                                 const int* __restrict__ order, int* __restrict__ planRows,
-                                                 int* __restrict__ sliceSlots, int S) {
+                                                 const int* __restrict__ vlistRow, const int* __restrict__ vposRow,
+                                                 const int* __restrict__ vTotal, int* __restrict__ vrow,
+                                                 int* __restrict__ vcode, int* __restrict__ sliceSlots) {
     __shared__ unsigned key[SELL_SIGMA];
     __shared__ int rowOf[SELL_SIGMA];
-    __shared__ int degOf[SELL_SIGMA];
+    __shared__ int lenOf[SELL_SIGMA];
+    __shared__ int cutOf[SELL_SIGMA];
+    const int V = *vTotal;
     const int w0 = blockIdx.x * SELL_SIGMA;
     for (int k = threadIdx.x; k < SELL_SIGMA; k += 256) {
-        const int p = w0 + k;
-        int r = -1, deg = 0;
-        if (p < rows) {
-            r = order ? order[p] : p;
-            r = max(0, min(r, rows - 1));
-            deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
+        const int v = w0 + k;
+        int r = -1, len = 0, cut = 0;
+        if (v < V) {
+            r = vlistRow[v];
+            const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
+            const int piece = v - vposRow[r];
+            len = max(0, min(ROWS_L, deg - piece * ROWS_L));
+            cut = deg > ROWS_L;
         }
         rowOf[k] = r;
-        degOf[k] = deg;
-        const unsigned dk = (unsigned)min(max(deg, 0), 0xFFFFF);
-        key[k] = ((p < rows ? (0xFFFFFu - dk) : 0x100000u) << 10) | (unsigned)k;  // padding positions sort last
+        lenOf[k] = len;
+        cutOf[k] = cut;
+        key[k] = ((v < V ? (unsigned)(ROWS_L - len) : (unsigned)(ROWS_L + 1)) << 10) | (unsigned)k;  // padding sorts last
     }
     __syncthreads();
     for (int size = 2; size <= SELL_SIGMA; size <<= 1) {
@@ -76,11 +126,11 @@ __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStar
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int g = wave; g < SELL_SIGMA / 64; g += 4) {
         const int slice = w0 / 64 + g;
-        if (slice >= S) break;
         const int kk = (int)(key[g * 64 + lane] & 1023u);
-        const bool real = (key[g * 64 + lane] >> 30) == 0;
-        planRows[slice * 64 + lane] = real ? rowOf[kk] : -1;
-        int d = real ? degOf[kk] : 0;
+        const int r = rowOf[kk];
+        vrow[slice * 64 + lane] = r;
+        vcode[slice * 64 + lane] = (r >= 0) ? (cutOf[kk] ? (w0 + kk) : ~(w0 + kk)) : -1;
+        int d = lenOf[kk];
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) d = max(d, __shfl_xor(d, s, 64));
         if (lane == 0) sliceSlots[slice] = d * 64;
@@ -91,20 +141,23 @@ __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStar
 // edge set-up (conv.hip conv_stream / edge_records), so the records hold identical bits.
 template <bool TR>
 __global__ __launch_bounds__(256) void sell_fill(ConvArgs a, const int* __restrict__ rowStart, int rows,
-                                                 const int* __restrict__ permT, const int* __restrict__ planRows,
-                                                 const int* __restrict__ sliceOff, int S, long long cap,
+                                                 const int* __restrict__ permT, RowPlan p, long long cap,
                                                  float4* __restrict__ rec, int* __restrict__ oth) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slice = blockIdx.x * 4 + wave;
-    if (slice >= S) return;
-    const int off = sliceOff[slice];
-    const int len = (sliceOff[slice + 1] - off) >> 6;
-    if ((long long)off + (long long)len * 64 > cap) return;  // the caller sees sliceOff[S] > capacity and repeats
-    const int r = planRows[slice * 64 + lane];
+    if (slice >= p.S) return;
+    const int off = p.sliceOff[slice];
+    const int len = (p.sliceOff[slice + 1] - off) >> 6;
+    if (len == 0 || (long long)off + (long long)len * 64 > cap) return;  // (the bound of plan_sizes makes this impossible)
+    const int r = p.vrow[slice * 64 + lane];
     int base = 0, deg = 0;
     if (r >= 0) {
-        base = rowStart[r];
-        deg = ((r + 1 < rows) ? rowStart[r + 1] : a.e) - base;
+        const int code = p.vcode[slice * 64 + lane];
+        const int piece = (code < 0 ? ~code : code) - p.vposRow[r];
+        const int rb = rowStart[r];
+        const int rdeg = ((r + 1 < rows) ? rowStart[r + 1] : a.e) - rb;
+        base = rb + piece * ROWS_L;
+        deg = max(0, min(ROWS_L, rdeg - piece * ROWS_L));
     }
     int pad = 0;
     for (int it = 0; it < len; ++it) {
@@ -129,6 +182,34 @@ __global__ __launch_bounds__(256) void sell_fill(ConvArgs a, const int* __restri
         const size_t slot = (size_t)off + (size_t)it * 64 + lane;
         rec[slot] = rc;
         oth[slot] = o;
+    }
+}
+
+// The pieces of cut rows left their sums in scratch rows (one per virtual row id, `cols` 32-bit words wide -- f32 rows,
+// or bf16 rows whose pieces are kept in f32): out[r] = sum over the row's pieces, in order. One wave per 64 rows; cut rows
+// are rare (none at all on a list whose rows hold <= ROWS_L edges), a wave without one returns after two loads.
+template <bool BF>
+__global__ __launch_bounds__(256) void rows_combine(const int* __restrict__ rowStart, int rows, int e,
+                                                    const int* __restrict__ vposRow, const float* __restrict__ scratch,
+                                                    int cols, void* __restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = (blockIdx.x * 4 + wave) * 64;
+    const int r = r0 + lane;
+    int deg = 0;
+    if (r < rows) deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
+    unsigned long long cut = __ballot(deg > ROWS_L);
+    while (cut) {
+        const int l = (int)__builtin_ctzll(cut);
+        cut &= cut - 1;
+        const int rr = r0 + l;
+        const int pieces = (__builtin_amdgcn_readlane(deg, l) + ROWS_L - 1) / ROWS_L;
+        const int v0 = vposRow[rr];
+        for (int c = lane; c < cols; c += 64) {
+            float acc = 0.f;
+            for (int k = 0; k < pieces; ++k) acc += scratch[(size_t)(v0 + k) * cols + c];
+            if (BF) reinterpret_cast<__bf16*>(out)[(size_t)rr * cols + c] = (__bf16)acc;
+            else reinterpret_cast<float*>(out)[(size_t)rr * cols + c] = acc;
+        }
     }
 }
 
@@ -190,7 +271,8 @@ __device__ __forceinline__ void stage_read(const RowStage& st, int b, int wave, 
 // blocks of one slice and gather the feature rows together (RowStage). Workgroups are dispatched in slice order =
 // windows of descending row length: fine-grained items, no tail. FEAT: 2 = f32 rows, 4 = bf16 rows.
 template <int FEAT>
-__global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float* __restrict__ out, int qTiles) {
+__global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float* __restrict__ out, float* __restrict__ scratch,
+                                                   int qTiles) {
     __shared__ float stageMem[MCCNN_STAGE_FLOATS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i4 = lane & 3;
     constexpr bool BF = FEAT == 4;
@@ -208,7 +290,8 @@ __global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float*
     load_block_weights(a, mine ? q : 0, i4, w);
     const int off = p.sliceOff[slice];
     const int len = (p.sliceOff[slice + 1] - off) >> 6;
-    const int r = p.rows[slice * 64 + lane];
+    if (len == 0) return;  // slices beyond the list's last virtual row (the layout is sized by a bound)
+    const int r = p.vrow[slice * 64 + lane];
     const int prow = wave * 16 + (lane & 15);  // the row of the slice this lane fetches as a producer
     float acc[8];
 #pragma unroll
@@ -242,7 +325,12 @@ __global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float*
         __syncthreads();
     }
     if (r >= 0 && mine) {
-        if (BF) {
+        const int code = p.vcode[slice * 64 + lane];
+        if (code >= 0) {  // a piece of a cut row: its partial sums wait in the scratch row for rows_combine
+            float4* dst = reinterpret_cast<float4*>(scratch + (size_t)code * a.outF + q * 8);
+            dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        } else if (BF) {
             reinterpret_cast<uint4*>(out16 + (size_t)r * a.outF)[q] = f32x8_to_bf16(acc);
         } else {
             float4* dst = reinterpret_cast<float4*>(out + (size_t)r * a.outF + q * 8);
@@ -260,7 +348,8 @@ __global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float*
 // Math: spatial_conv.cu:563-680 (see conv_bwd_mfma in conv.hip for the same steps in the edge-major form).
 template <int FEAT>
 __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, const float* __restrict__ outGrad,
-                                                      float* __restrict__ featGrad, float* __restrict__ partials, int spw, int groups) {
+                                                      float* __restrict__ featGrad, float* __restrict__ scratch,
+                                                      float* __restrict__ partials, int spw, int groups) {
     extern __shared__ float lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i4 = lane & 3;
     const int qTiles = (a.nb + 3) >> 2;
@@ -299,7 +388,8 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
     for (int slice = g * spw; slice < sEnd; ++slice) {
         const int off = p.sliceOff[slice];
         const int len = (p.sliceOff[slice + 1] - off) >> 6;
-        const int r = p.rows[slice * 64 + lane];
+        if (len == 0) continue;  // slices beyond the list's last virtual row
+        const int r = p.vrow[slice * 64 + lane];
         const int jr = max(r, 0);
         // the lane's own feature row piece is constant over the slice: parked in LDS (two conflict-free float4 planes
         // per wave) instead of 8 VGPRs -- the 176 sums leave no room for it
@@ -409,7 +499,12 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
                 gb1[l] += v;
             }
         }
-        if (r >= 0) {
+        const int code = p.vcode[slice * 64 + lane];
+        if (r >= 0 && code >= 0) {  // a piece of a cut row
+            float4* dst = reinterpret_cast<float4*>(scratch + (size_t)code * a.Fin + q * 8);
+            dst[0] = make_float4(dF[0], dF[1], dF[2], dF[3]);
+            dst[1] = make_float4(dF[4], dF[5], dF[6], dF[7]);
+        } else if (r >= 0) {
             if (BF) {
                 reinterpret_cast<uint4*>(fg16 + (size_t)r * a.Fin)[q] = f32x8_to_bf16(dF);
             } else {
@@ -464,42 +559,64 @@ using namespace mccnn;
 
 extern "C" {
 
-size_t mccnn_rowplan_workspace_bytes(int rows) {
-    if (rows <= 0) return 256;
-    const int S = (rows + 63) / 64;
-    return align_up((size_t)S * sizeof(int)) + scan_workspace_bytes(S) + 256;
+int mccnn_rowplan_sizes(int rows, int e, int* num_slices, long long* slot_capacity, long long* scratch_rows) {
+    if (rows < 0 || e < 0 || !num_slices || !slot_capacity || !scratch_rows) return MCCNN_E_BADARG;
+    const PlanSizes z = plan_sizes(rows, e);
+    if (z.slots > 0x7fffffffLL || z.vcap > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
+    *num_slices = z.S;
+    *slot_capacity = z.slots;
+    *scratch_rows = z.vcap;
+    return 0;
 }
 
-int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order, int* plan_rows, int* slice_off, void* ws,
-                         size_t ws_bytes, mccnn_stream_t stream) {
+size_t mccnn_rowplan_workspace_bytes(int rows, int e) {
+    if (rows <= 0) return 256;
+    const PlanSizes z = plan_sizes(rows, e);
+    return align_up((size_t)(rows + 1) * sizeof(int)) * 2 + align_up((size_t)z.vcap * sizeof(int)) +
+           align_up((size_t)z.S * sizeof(int)) + scan_workspace_bytes(rows) + scan_workspace_bytes(z.S) + 512;
+}
+
+int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order, int* plan_vrow, int* plan_vcode,
+                         int* slice_off, int* vpos_row, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
     if (rows < 0 || e < 0 || !slice_off) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (rows == 0) {
         MCCNN_MEMSET(hipMemsetAsync(slice_off, 0, sizeof(int), s));
         return 0;
     }
-    if (!row_start || !plan_rows) return MCCNN_E_BADARG;
-    if (!ws || ws_bytes < mccnn_rowplan_workspace_bytes(rows)) return MCCNN_E_WORKSPACE;
-    const int S = (rows + 63) / 64;
+    if (!row_start || !plan_vrow || !plan_vcode || !vpos_row) return MCCNN_E_BADARG;
+    if (!ws || ws_bytes < mccnn_rowplan_workspace_bytes(rows, e)) return MCCNN_E_WORKSPACE;
+    const PlanSizes z = plan_sizes(rows, e);
+    if (z.slots > 0x7fffffffLL || z.vcap > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     Arena ar(ws, ws_bytes);
-    int* sliceSlots = ar.take<int>((size_t)S);
-    void* scanws = ar.take<char>(scan_workspace_bytes(S));
-    if (!sliceSlots || !scanws) return MCCNN_E_WORKSPACE;
-    sell_sort<<<ceil_div(rows, SELL_SIGMA), 256, 0, s>>>(row_start, rows, e, order, plan_rows, sliceSlots, S);
+    int* vcnt = ar.take<int>((size_t)rows + 1);
+    int* vposP = ar.take<int>((size_t)rows + 1);
+    int* vlistRow = ar.take<int>((size_t)z.vcap);
+    int* sliceSlots = ar.take<int>((size_t)z.S);
+    void* scan1 = ar.take<char>(scan_workspace_bytes(rows));
+    void* scan2 = ar.take<char>(scan_workspace_bytes(z.S));
+    if (!vcnt || !vposP || !vlistRow || !sliceSlots || !scan1 || !scan2) return MCCNN_E_WORKSPACE;
+    vr_count<<<ceil_div(rows, 256), 256, 0, s>>>(row_start, rows, e, order, vcnt);
     MCCNN_LAUNCHED();
-    return exclusive_scan_i32(sliceSlots, slice_off, S, slice_off + S, scanws, s);
+    int rc = exclusive_scan_i32(vcnt, vposP, rows, vposP + rows, scan1, s);  // vposP[rows] = number of virtual rows
+    if (rc) return rc;
+    vr_expand<<<ceil_div(rows, 256), 256, 0, s>>>(row_start, rows, e, order, vposP, vpos_row, vlistRow);
+    MCCNN_LAUNCHED();
+    sell_sort<<<z.windows, 256, 0, s>>>(row_start, rows, e, vlistRow, vpos_row, vposP + rows, plan_vrow, plan_vcode, sliceSlots);
+    MCCNN_LAUNCHED();
+    return exclusive_scan_i32(sliceSlots, slice_off, z.S, slice_off + z.S, scan2, s);
 }
 
 int mccnn_rowplan_fill(int transposed, const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs,
                        const float* samples, const int* start_idx, const int* packed, const float* aabb_min,
                        const float* aabb_max, int n, int m, int e, int batch_size, float radius, int scale_inv, int avg,
-                       const int* row_start, const int* perm_t, const int* plan_rows, const int* slice_off,
-                       long long capacity_slots, void* rec, int* other, mccnn_stream_t stream) {
+                       const int* row_start, const int* perm_t, const int* plan_vrow, const int* plan_vcode,
+                       const int* slice_off, const int* vpos_row, void* rec, int* other, mccnn_stream_t stream) {
     if (n < 0 || m < 0 || e < 0 || batch_size <= 0 || !(radius > 0.0f)) return MCCNN_E_BADARG;
     const int rows = transposed ? n : m;
     if (rows == 0 || e == 0) return 0;
     if (!sorted_pts || !sorted_batch_ids || !pdfs || !samples || !start_idx || !packed || !aabb_min || !aabb_max ||
-        !row_start || !plan_rows || !slice_off || !rec || !other || (transposed && !perm_t))
+        !row_start || !plan_vrow || !plan_vcode || !slice_off || !vpos_row || !rec || !other || (transposed && !perm_t))
         return MCCNN_E_BADARG;
     ConvArgs a = {};
     a.pts = sorted_pts; a.bids = sorted_batch_ids; a.pdfs = pdfs; a.samples = samples; a.start = start_idx;
@@ -507,13 +624,12 @@ int mccnn_rowplan_fill(int transposed, const float* sorted_pts, const int* sorte
     a.n = n; a.m = m; a.e = e; a.radius = radius; a.invRadius = 1.0f / radius; a.scaleInv = scale_inv; a.avg = avg;
     a.B = batch_size;
     hipStream_t s = (hipStream_t)stream;
-    const int S = (rows + 63) / 64;
+    const PlanSizes z = plan_sizes(rows, e);
+    RowPlan p = {plan_vrow, plan_vcode, slice_off, vpos_row, nullptr, nullptr, rows, z.S};
     if (transposed)
-        sell_fill<true><<<ceil_div(S, 4), 256, 0, s>>>(a, row_start, rows, perm_t, plan_rows, slice_off, S, capacity_slots,
-                                                       reinterpret_cast<float4*>(rec), other);
+        sell_fill<true><<<ceil_div(z.S, 4), 256, 0, s>>>(a, row_start, rows, perm_t, p, z.slots, reinterpret_cast<float4*>(rec), other);
     else
-        sell_fill<false><<<ceil_div(S, 4), 256, 0, s>>>(a, row_start, rows, nullptr, plan_rows, slice_off, S, capacity_slots,
-                                                        reinterpret_cast<float4*>(rec), other);
+        sell_fill<false><<<ceil_div(z.S, 4), 256, 0, s>>>(a, row_start, rows, nullptr, p, z.slots, reinterpret_cast<float4*>(rec), other);
     MCCNN_LAUNCHED();
     return 0;
 }
@@ -527,32 +643,39 @@ int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feat
                                 const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
                                 const float* w2, const float* b2, const float* w3, const float* b3, int n, int m, int e,
                                 int num_feats, int batch_size, float radius, int scale_inv, int avg, int bf16,
-                                const int* plan_rows, const int* slice_off, const void* plan_rec, const int* plan_other,
-                                void* out, mccnn_stream_t stream) {
+                                const int* plan_vrow, const int* plan_vcode, const int* slice_off, const int* vpos_row,
+                                const void* plan_rec, const int* plan_other, void* out, float* scratch,
+                                mccnn_stream_t stream) {
     ConvArgs a;
     int rc = conv_fill_args(a, sorted_pts, (const float*)sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed,
                             aabb_min, aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_feats, num_feats, 0, batch_size, radius,
                             scale_inv, avg);
     if (rc) return rc;
     if (m == 0) return 0;
-    if (!out || !plan_rows || !slice_off || (e > 0 && (!plan_rec || !plan_other))) return MCCNN_E_BADARG;
+    if (e == 0) return MCCNN_E_BADARG;  // empty lists take mccnn_spatial_conv_fwd
+    if (!out || !scratch || !plan_vrow || !plan_vcode || !slice_off || !vpos_row || !plan_rec || !plan_other) return MCCNN_E_BADARG;
     if (!rows_shape_ok(a, 0, sorted_feats, out)) return MCCNN_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    RowPlan p = {plan_rows, slice_off, reinterpret_cast<const float4*>(plan_rec), plan_other, m, (m + 63) / 64};
+    const PlanSizes z = plan_sizes(m, e);
+    RowPlan p = {plan_vrow, plan_vcode, slice_off, vpos_row, reinterpret_cast<const float4*>(plan_rec), plan_other, m, z.S};
     const int qTiles = (a.nb + 3) / 4;
     const long long blocks = ((long long)p.S * qTiles + 7) / 8 * 8;
     if (blocks > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
-    if (bf16) dw_fwd_rows<4><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, qTiles);
-    else dw_fwd_rows<2><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, qTiles);
+    if (bf16) dw_fwd_rows<4><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, scratch, qTiles);
+    else dw_fwd_rows<2><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, scratch, qTiles);
+    MCCNN_LAUNCHED();
+    if (bf16) rows_combine<true><<<ceil_div(m, 256), 256, 0, s>>>(start_idx, m, e, vpos_row, scratch, a.outF, out);
+    else rows_combine<false><<<ceil_div(m, 256), 256, 0, s>>>(start_idx, m, e, vpos_row, scratch, a.outF, out);
     MCCNN_LAUNCHED();
     return 0;
 }
 
-size_t mccnn_spatial_conv_bwd_rows_workspace_bytes(int n, int num_feats) {
+size_t mccnn_spatial_conv_bwd_rows_workspace_bytes(int n, int e, int num_feats) {
     if (n <= 0 || num_feats <= 0) return 256;
-    const int S = (n + 63) / 64, nb = (num_feats + 7) / 8;
-    const int spw = bwd_rows_spw(S, nb);
-    const long long groups = (S + spw - 1) / spw;
+    const PlanSizes z = plan_sizes(n, e);
+    const int nb = (num_feats + 7) / 8;
+    const int spw = bwd_rows_spw(z.S, nb);
+    const long long groups = (z.S + spw - 1) / spw;
     return align_up((size_t)groups * nb * 176 * sizeof(float)) + 256;
 }
 
@@ -561,9 +684,10 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
                                 const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
                                 const float* w2, const float* b2, const float* w3, const float* b3, const void* out_grad,
                                 int n, int m, int e, int num_feats, int batch_size, float radius, int scale_inv, int avg,
-                                int bf16, const int* plan_rows, const int* slice_off, const void* plan_rec,
-                                const int* plan_other, void* feat_grad, float* dw1, float* db1, float* dw2, float* db2,
-                                float* dw3, float* db3, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+                                int bf16, const int* start_t, const int* plan_vrow, const int* plan_vcode,
+                                const int* slice_off, const int* vpos_row, const void* plan_rec, const int* plan_other,
+                                void* feat_grad, float* scratch, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
+                                float* db3, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
     ConvArgs a;
     int rc = conv_fill_args(a, sorted_pts, (const float*)sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed,
                             aabb_min, aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_feats, num_feats, 0, batch_size, radius,
@@ -571,11 +695,13 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
     if (rc) return rc;
     if (!dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3 || (n > 0 && !feat_grad)) return MCCNN_E_BADARG;
     if (n == 0 || m == 0 || e == 0) return MCCNN_E_BADARG;  // empty lists take mccnn_spatial_conv_bwd
-    if (!out_grad || !plan_rows || !slice_off || !plan_rec || !plan_other) return MCCNN_E_BADARG;
+    if (!out_grad || !scratch || !start_t || !plan_vrow || !plan_vcode || !slice_off || !vpos_row || !plan_rec || !plan_other)
+        return MCCNN_E_BADARG;
     if (!rows_shape_ok(a, 0, sorted_feats, out_grad) || (((uintptr_t)feat_grad) & 15)) return MCCNN_E_SHAPE;
-    if (!ws || ws_bytes < mccnn_spatial_conv_bwd_rows_workspace_bytes(n, num_feats)) return MCCNN_E_WORKSPACE;
+    if (!ws || ws_bytes < mccnn_spatial_conv_bwd_rows_workspace_bytes(n, e, num_feats)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    RowPlan p = {plan_rows, slice_off, reinterpret_cast<const float4*>(plan_rec), plan_other, n, (n + 63) / 64};
+    const PlanSizes z = plan_sizes(n, e);
+    RowPlan p = {plan_vrow, plan_vcode, slice_off, vpos_row, reinterpret_cast<const float4*>(plan_rec), plan_other, n, z.S};
     const int spw = bwd_rows_spw(p.S, a.nb);
     const int groups = (p.S + spw - 1) / spw;
     const int qTiles = (a.nb + 3) / 4;
@@ -583,8 +709,11 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
     if (blocks > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     float* partials = reinterpret_cast<float*>(ws);
     const size_t lds = ((size_t)4 * MCCNN_WQ_BWD + 4 * 512) * sizeof(float);  // 4 blocks of weights + the parked feature pieces
-    if (bf16) dw_bwd_rows<4><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, partials, spw, groups);
-    else dw_bwd_rows<2><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, partials, spw, groups);
+    if (bf16) dw_bwd_rows<4><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
+    else dw_bwd_rows<2><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
+    MCCNN_LAUNCHED();
+    if (bf16) rows_combine<true><<<ceil_div(n, 256), 256, 0, s>>>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad);
+    else rows_combine<false><<<ceil_div(n, 256), 256, 0, s>>>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad);
     MCCNN_LAUNCHED();
     launch_reduce_partials(partials, groups, a.nb, dw1, db1, dw2, db2, dw3, db3, s);
     MCCNN_LAUNCHED();

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for one round from the tree as it is (run on the GPU box, from the repo root):
 #     tools/refresh_profiles.sh r02
-# 1. tools/prof.sh for the three benchmark layers, the 8-rooms-per-GPU size and the hierarchy build
+# 1. tools/prof.sh for the three benchmark layers, the 8-rooms-per-GPU size, the hierarchy build and the five
+#    BASELINE.json configurations (tools/config_time.py)
 #    (kernel-trace stats + separate PMC passes), copied to profiles/<round>_{rocprofv3_summary,kernels,pmc_traffic,command}_<tag>.*
 # 2. the default `python bench.py` line (reads the traffic files of step 1) -> profiles/<round>_bench.json
 # The copies land in gpurun_out/profiles_<round>/ as well, so that a `gpurun` call brings them home.
 set -u
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 ROOT=$PWD
 DST=$ROOT/profiles
 mkdir -p $DST gpurun_out/profiles_$ROUND
@@ -27,6 +28,11 @@ PROF_STEPS=6 PROF_WARM=2 tools/prof.sh ${ROUND}_8rooms --layer 1to64 --rooms-per
 keep 8rooms
 PROF_NO_PMC=1 PROF_CMD="python $ROOT/tools/hier_time.py" tools/prof.sh ${ROUND}_hier > /dev/null 2>&1
 keep hier
+# BASELINE.json configurations: one step = PointHierarchy + forward + backward of every convolution of the model's graph
+for cfg in cfg0 cfg1 cfg2 cfg3 cfg4; do
+    PROF_NO_PMC=1 PROF_WARM_DROP=6 PROF_CMD="python $ROOT/tools/config_time.py $cfg 20" tools/prof.sh ${ROUND}_$cfg > /dev/null 2>&1
+    keep $cfg
+done
 
 python bench.py > $DST/${ROUND}_bench.json 2> gpurun_out/profiles_$ROUND/bench.err
 cp $DST/${ROUND}_* gpurun_out/profiles_$ROUND/
