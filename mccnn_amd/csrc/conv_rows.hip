@@ -26,7 +26,7 @@ constexpr int SELL_SIGMA = 1024;
 // number of slots has a bound the host knows -- windows are sorted by length, so a window's slices hold at most
 // 64 ROWS_L + (its edges) slots -- hence plans are laid out and filled WITHOUT any size read-back. The pieces of a cut
 // row leave their partial sums in a scratch row each; a small pass adds them in order (deterministic).
-constexpr int ROWS_L = 128;
+constexpr int ROWS_L = 128;  // longest virtual row; lists with few rows use shorter ones (plan_sizes) to fill the chip
 #ifndef MCCNN_ROWS_ABL
 #define MCCNN_ROWS_ABL 0
 #endif
@@ -46,40 +46,51 @@ struct RowPlan {
 };
 
 struct PlanSizes {
+    int L;            // longest virtual row of this plan
     long long vcap;   // bound on the number of virtual rows
     int windows, S;   // windows of SELL_SIGMA virtual rows, slices of 64
     long long slots;  // bound on the number of slots
 };
 static PlanSizes plan_sizes(int rows, int e) {
     PlanSizes z;
-    z.vcap = (long long)rows + e / ROWS_L;
+    // A lane walks its virtual row serially (~1 us per edge of latency), so a list with few rows is cut finer: about
+    // 64 k virtual rows (1 k slices) when the edges allow it, pieces of 16 .. 128 edges. Large lists keep 128: a row
+    // of the usual 30 - 100 edges then stays in one piece.
+    z.L = ROWS_L;
+    if (rows < 16384) {
+        long long want = e / 65536;
+        int L = 16;
+        while (L < want && L < ROWS_L) L <<= 1;
+        z.L = L;
+    }
+    z.vcap = (long long)rows + e / z.L;
     z.windows = (int)((z.vcap + SELL_SIGMA - 1) / SELL_SIGMA);
     z.S = z.windows * (SELL_SIGMA / 64);
-    z.slots = (long long)e + 64LL * ROWS_L * z.windows;
+    z.slots = (long long)e + 64LL * z.L * z.windows;
     return z;
 }
 
 // ------------------------------------------------------------------------------------------------ layout
 // pieces per row position of the visiting order
 __global__ __launch_bounds__(256) void vr_count(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
-                                                int* __restrict__ vcnt) {
+                                                int* __restrict__ vcnt, int L) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= rows) return;
     int r = order ? order[p] : p;
     r = max(0, min(r, rows - 1));
     const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
-    vcnt[p] = max(1, (deg + ROWS_L - 1) / ROWS_L);
+    vcnt[p] = max(1, (deg + L - 1) / L);
 }
 // virtual row id -> row; row -> its first virtual row id
 __global__ __launch_bounds__(256) void vr_expand(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
                                                  const int* __restrict__ vposP, int* __restrict__ vposRow,
-                                                 int* __restrict__ vlistRow) {
+                                                 int* __restrict__ vlistRow, int L) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= rows) return;
     int r = order ? order[p] : p;
     r = max(0, min(r, rows - 1));
     const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
-    const int vc = max(1, (deg + ROWS_L - 1) / ROWS_L), v0 = vposP[p];
+    const int vc = max(1, (deg + L - 1) / L), v0 = vposP[p];
     vposRow[r] = v0;
     for (int k = 0; k < vc; ++k) vlistRow[v0 + k] = r;
 }
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(256) void vr_expand(const int* __restrict__ rowStar
 __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStart, int rows, int e,
                                                  const int* __restrict__ vlistRow, const int* __restrict__ vposRow,
                                                  const int* __restrict__ vTotal, int* __restrict__ vrow,
-                                                 int* __restrict__ vcode, int* __restrict__ sliceSlots) {
+                                                 int* __restrict__ vcode, int* __restrict__ sliceSlots, int L) {
     __shared__ unsigned key[SELL_SIGMA];
     __shared__ int rowOf[SELL_SIGMA];
     __shared__ int lenOf[SELL_SIGMA];
@@ -102,13 +113,13 @@ __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStar
             r = vlistRow[v];
             const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
             const int piece = v - vposRow[r];
-            len = max(0, min(ROWS_L, deg - piece * ROWS_L));
-            cut = deg > ROWS_L;
+            len = max(0, min(L, deg - piece * L));
+            cut = deg > L;
         }
         rowOf[k] = r;
         lenOf[k] = len;
         cutOf[k] = cut;
-        key[k] = ((v < V ? (unsigned)(ROWS_L - len) : (unsigned)(ROWS_L + 1)) << 10) | (unsigned)k;  // padding sorts last
+        key[k] = ((v < V ? (unsigned)(L - len) : (unsigned)(L + 1)) << 10) | (unsigned)k;  // padding sorts last
     }
     __syncthreads();
     for (int size = 2; size <= SELL_SIGMA; size <<= 1) {
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStar
 template <bool TR>
 __global__ __launch_bounds__(256) void sell_fill(ConvArgs a, const int* __restrict__ rowStart, int rows,
                                                  const int* __restrict__ permT, RowPlan p, long long cap,
-                                                 float4* __restrict__ rec, int* __restrict__ oth) {
+                                                 float4* __restrict__ rec, int* __restrict__ oth, int L) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slice = blockIdx.x * 4 + wave;
     if (slice >= p.S) return;
@@ -156,8 +167,8 @@ __global__ __launch_bounds__(256) void sell_fill(ConvArgs a, const int* __restri
         const int piece = (code < 0 ? ~code : code) - p.vposRow[r];
         const int rb = rowStart[r];
         const int rdeg = ((r + 1 < rows) ? rowStart[r + 1] : a.e) - rb;
-        base = rb + piece * ROWS_L;
-        deg = max(0, min(ROWS_L, rdeg - piece * ROWS_L));
+        base = rb + piece * L;
+        deg = max(0, min(L, rdeg - piece * L));
     }
     int pad = 0;
     for (int it = 0; it < len; ++it) {
@@ -191,18 +202,18 @@ __global__ __launch_bounds__(256) void sell_fill(ConvArgs a, const int* __restri
 template <bool BF>
 __global__ __launch_bounds__(256) void rows_combine(const int* __restrict__ rowStart, int rows, int e,
                                                     const int* __restrict__ vposRow, const float* __restrict__ scratch,
-                                                    int cols, void* __restrict__ out) {
+                                                    int cols, void* __restrict__ out, int L) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = (blockIdx.x * 4 + wave) * 64;
     const int r = r0 + lane;
     int deg = 0;
     if (r < rows) deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
-    unsigned long long cut = __ballot(deg > ROWS_L);
+    unsigned long long cut = __ballot(deg > L);
     while (cut) {
         const int l = (int)__builtin_ctzll(cut);
         cut &= cut - 1;
         const int rr = r0 + l;
-        const int pieces = (__builtin_amdgcn_readlane(deg, l) + ROWS_L - 1) / ROWS_L;
+        const int pieces = (__builtin_amdgcn_readlane(deg, l) + L - 1) / L;
         const int v0 = vposRow[rr];
         for (int c = lane; c < cols; c += 64) {
             float acc = 0.f;
@@ -211,6 +222,40 @@ __global__ __launch_bounds__(256) void rows_combine(const int* __restrict__ rowS
             else reinterpret_cast<float*>(out)[(size_t)rr * cols + c] = acc;
         }
     }
+}
+
+// The same for lists with few rows, whose plans use short pieces (most rows are cut): one thread per (row, 4 columns).
+template <bool BF>
+__global__ __launch_bounds__(256) void rows_combine_par(const int* __restrict__ rowStart, int rows, int e,
+                                                        const int* __restrict__ vposRow, const float* __restrict__ scratch,
+                                                        int cols, void* __restrict__ out, int L) {
+    const int c4 = cols >> 2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)rows * c4) return;
+    const int r = (int)(t / c4), c = (int)(t - (long long)r * c4) * 4;
+    const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
+    if (deg <= L) return;
+    const int pieces = (deg + L - 1) / L, v0 = vposRow[r];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < pieces; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(scratch + (size_t)(v0 + k) * cols + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (BF) {
+        unsigned* o = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(out) + (size_t)r * cols + c);
+        o[0] = f32x2_to_bf16(acc.x, acc.y);
+        o[1] = f32x2_to_bf16(acc.z, acc.w);
+    } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)r * cols + c) = acc;
+    }
+}
+template <bool BF>
+static void launch_combine(const int* rowStart, int rows, int e, const int* vposRow, const float* scratch, int cols, void* out,
+                           int L, hipStream_t s) {
+    if (rows < 16384)
+        rows_combine_par<BF><<<ceil_div((long long)rows * (cols >> 2), 256), 256, 0, s>>>(rowStart, rows, e, vposRow, scratch, cols, out, L);
+    else
+        rows_combine<BF><<<ceil_div(rows, 256), 256, 0, s>>>(rowStart, rows, e, vposRow, scratch, cols, out, L);
 }
 
 // ------------------------------------------------------------------------------------------------ staged row gather
@@ -596,13 +641,13 @@ int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order
     void* scan1 = ar.take<char>(scan_workspace_bytes(rows));
     void* scan2 = ar.take<char>(scan_workspace_bytes(z.S));
     if (!vcnt || !vposP || !vlistRow || !sliceSlots || !scan1 || !scan2) return MCCNN_E_WORKSPACE;
-    vr_count<<<ceil_div(rows, 256), 256, 0, s>>>(row_start, rows, e, order, vcnt);
+    vr_count<<<ceil_div(rows, 256), 256, 0, s>>>(row_start, rows, e, order, vcnt, z.L);
     MCCNN_LAUNCHED();
     int rc = exclusive_scan_i32(vcnt, vposP, rows, vposP + rows, scan1, s);  // vposP[rows] = number of virtual rows
     if (rc) return rc;
-    vr_expand<<<ceil_div(rows, 256), 256, 0, s>>>(row_start, rows, e, order, vposP, vpos_row, vlistRow);
+    vr_expand<<<ceil_div(rows, 256), 256, 0, s>>>(row_start, rows, e, order, vposP, vpos_row, vlistRow, z.L);
     MCCNN_LAUNCHED();
-    sell_sort<<<z.windows, 256, 0, s>>>(row_start, rows, e, vlistRow, vpos_row, vposP + rows, plan_vrow, plan_vcode, sliceSlots);
+    sell_sort<<<z.windows, 256, 0, s>>>(row_start, rows, e, vlistRow, vpos_row, vposP + rows, plan_vrow, plan_vcode, sliceSlots, z.L);
     MCCNN_LAUNCHED();
     return exclusive_scan_i32(sliceSlots, slice_off, z.S, slice_off + z.S, scan2, s);
 }
@@ -627,9 +672,9 @@ int mccnn_rowplan_fill(int transposed, const float* sorted_pts, const int* sorte
     const PlanSizes z = plan_sizes(rows, e);
     RowPlan p = {plan_vrow, plan_vcode, slice_off, vpos_row, nullptr, nullptr, rows, z.S};
     if (transposed)
-        sell_fill<true><<<ceil_div(z.S, 4), 256, 0, s>>>(a, row_start, rows, perm_t, p, z.slots, reinterpret_cast<float4*>(rec), other);
+        sell_fill<true><<<ceil_div(z.S, 4), 256, 0, s>>>(a, row_start, rows, perm_t, p, z.slots, reinterpret_cast<float4*>(rec), other, z.L);
     else
-        sell_fill<false><<<ceil_div(z.S, 4), 256, 0, s>>>(a, row_start, rows, nullptr, p, z.slots, reinterpret_cast<float4*>(rec), other);
+        sell_fill<false><<<ceil_div(z.S, 4), 256, 0, s>>>(a, row_start, rows, nullptr, p, z.slots, reinterpret_cast<float4*>(rec), other, z.L);
     MCCNN_LAUNCHED();
     return 0;
 }
@@ -664,8 +709,8 @@ int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feat
     if (bf16) dw_fwd_rows<4><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, scratch, qTiles);
     else dw_fwd_rows<2><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, scratch, qTiles);
     MCCNN_LAUNCHED();
-    if (bf16) rows_combine<true><<<ceil_div(m, 256), 256, 0, s>>>(start_idx, m, e, vpos_row, scratch, a.outF, out);
-    else rows_combine<false><<<ceil_div(m, 256), 256, 0, s>>>(start_idx, m, e, vpos_row, scratch, a.outF, out);
+    if (bf16) launch_combine<true>(start_idx, m, e, vpos_row, scratch, a.outF, out, z.L, s);
+    else launch_combine<false>(start_idx, m, e, vpos_row, scratch, a.outF, out, z.L, s);
     MCCNN_LAUNCHED();
     return 0;
 }
@@ -712,8 +757,8 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
     if (bf16) dw_bwd_rows<4><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
     else dw_bwd_rows<2><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
     MCCNN_LAUNCHED();
-    if (bf16) rows_combine<true><<<ceil_div(n, 256), 256, 0, s>>>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad);
-    else rows_combine<false><<<ceil_div(n, 256), 256, 0, s>>>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad);
+    if (bf16) launch_combine<true>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s);
+    else launch_combine<false>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s);
     MCCNN_LAUNCHED();
     launch_reduce_partials(partials, groups, a.nb, dw1, db1, dw2, db2, dw3, db3, s);
     MCCNN_LAUNCHED();
