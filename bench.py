@@ -245,25 +245,18 @@ class Workload:
         lib = M._lib.load()
         n, m, e = sP.shape[0], P.shape[0], packed.shape[0]
         outF = fout if combin else fin
-        # spatial_conv forward / backward through the PRODUCT op surface (mccnn_amd.MCConvModule.spatial_conv and its
-        # autograd node), i.e. whichever kernels the layer shape selects -- edge-streaming, factored Fin = 1, or
-        # row-per-lane over the list's plans -- with everything that is built once per neighbour list (transposed list,
-        # row plans) already cached, as every further layer over the same list sees it
-        pw = [p.detach().clone().requires_grad_(True) for p in self.builder.parameters()]
-        w1p, b1p, w2p, b2p, w3p, b3p = pw[0], pw[1], pw[2].reshape(8, -1), pw[3].reshape(-1), pw[4].reshape(8, -1), pw[5].reshape(-1)
-
-        def conv_times(sFx, ogx):
-            sFr = sFx.detach().clone().requires_grad_(True)
-
-            def fwd():
-                return M.spatial_conv(sP, sFr, sB, pdfs, P, start, packed, mn, mx, w1p, w2p, w3p, b1p, b2p, b3p, fout, combin, B,
-                                      r, False, True)
-            torch.autograd.grad([fwd()], [sFr] + pw, [ogx])  # builds the per-list structures
-            tf, _ = ev_time(fwd)
-            outs = iter([fwd() for _ in range(22)])
-            tb, gr = ev_time(lambda: torch.autograd.grad([next(outs)], [sFr] + pw, [ogx]))
-            return tf, tb, gr[0]
-        t_fwd, t_bwd, fg = conv_times(sF, self.OG)
+        # spatial_conv forward / backward: the C-ABI entries the product op surface (MCConvModule._SpatialConv) selects for
+        # this layer shape, called directly so that the HIP-event time is the kernels' own (through the Python op the
+        # same calls carry ~20 us of host work each): the row-per-lane entries over the list's plans for depth-wise
+        # layers, mccnn_spatial_conv_fwd / _bwd (edge-streaming, or factored for Fin = 1) otherwise. What is built once
+        # per neighbour list -- transposed list, row plans -- is built before the timed calls, as every further layer
+        # over the same list sees it.
+        conv_args = (ptr(sP), ptr(sF), ptr(sB), ptr(pdfs), ptr(P), ptr(start), ptr(packed), ptr(mn), ptr(mx), ptr(w1),
+                     ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3))
+        gws = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]
+        rows_fwd = M._rows_shape(combin, fin, sF, m, e)
+        rows_bwd = M._rows_shape(combin, fin, sF, n, e)
+        start_t = perm_t = None
         t_tr = None
         if not combin:  # the transposed neighbour list of depth-wise layers: built once per neighbour list, timed on its own
             start_t = torch.empty(n + 1, dtype=torch.int32, device=device)
@@ -272,15 +265,76 @@ class Workload:
             t_tr, _ = ev_time(lambda: check(lib.mccnn_transpose_neighbors(ptr(packed), e, n, ptr(start_t), ptr(perm_t),
                                                                            ptr(tws), tws.numel(), stream_handle()),
                                             "transpose_neighbors"))
-            del start_t, perm_t, tws
+
+        def plan_of(transposed):
+            t0 = time.perf_counter()
+            pl = M._row_plan(packed, transposed, sP, sB, pdfs, P, start, packed, mn, mx, n, m, e, B, r, False, True,
+                             centre_points=P)
+            torch.cuda.synchronize()
+            return pl, (time.perf_counter() - t0) * 1e3
+
+        def conv_times(feats_t, og_t, bf):
+            """(fwd ms, bwd ms, feature gradient) of this layer with rows stored as f32 (bf = 0) or bf16 (bf = 1)."""
+            o = torch.empty((m, outF), dtype=feats_t.dtype, device=device)
+            fgr = torch.empty_like(feats_t)
+            if rows_fwd:
+                pf, _ = plan_of(False)
+                scr = torch.empty((pf.scratch_rows, outF), dtype=torch.float32, device=device)
+                tf, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_fwd_rows(
+                    conv_args[0], ptr(feats_t), *conv_args[2:], n, m, e, fin, B, r, 0, 1, bf, ptr(pf.vrow), ptr(pf.vcode),
+                    ptr(pf.slice_off), ptr(pf.vpos_row), ptr(pf.rec), ptr(pf.other), ptr(o), ptr(scr), stream_handle()),
+                    "conv_fwd_rows"))
+                state = None
+            else:
+                fwd_ws = torch.empty(max(256, lib.mccnn_spatial_conv_fwd_workspace_bytes(m, e, fin, fout, int(combin))),
+                                     dtype=torch.uint8, device=device)
+                sbytes = lib.mccnn_spatial_conv_state_bytes(m, e, fin, fout, int(combin)) if not bf else 0
+                state = torch.empty(sbytes, dtype=torch.uint8, device=device) if sbytes else None  # kept fwd -> bwd, as autograd does
+                if bf:
+                    tf, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_fwd_bf16(
+                        conv_args[0], ptr(feats_t), *conv_args[2:], n, m, e, fin, B, r, 0, 1, ptr(o), ptr(fwd_ws), fwd_ws.numel(),
+                        stream_handle()), "conv_fwd_bf16"))
+                else:
+                    tf, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_fwd(
+                        *conv_args, n, m, e, fin, fout, int(combin), B, r, 0, 1, ptr(o), ptr(state), ptr(fwd_ws), fwd_ws.numel(),
+                        stream_handle()), "conv_fwd"))
+            if rows_bwd:
+                pt, _ = plan_of(True)
+                scr = torch.empty((pt.scratch_rows, fin), dtype=torch.float32, device=device)
+                bws = torch.empty(max(256, lib.mccnn_spatial_conv_bwd_rows_workspace_bytes(n, e, fin)), dtype=torch.uint8, device=device)
+                tb, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_bwd_rows(
+                    conv_args[0], ptr(feats_t), *conv_args[2:], ptr(og_t), n, m, e, fin, B, r, 0, 1, bf, ptr(pt.row_start),
+                    ptr(pt.vrow), ptr(pt.vcode), ptr(pt.slice_off), ptr(pt.vpos_row), ptr(pt.rec), ptr(pt.other), ptr(fgr),
+                    ptr(scr), *[ptr(g) for g in gws], ptr(bws), bws.numel(), stream_handle()), "conv_bwd_rows"))
+            else:
+                bwd_ws = torch.empty(max(256, lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, fout, int(combin))),
+                                     dtype=torch.uint8, device=device)
+                if bf:
+                    tb, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_bwd_bf16(
+                        conv_args[0], ptr(feats_t), *conv_args[2:], ptr(og_t), n, m, e, fin, B, r, 0, 1, ptr(start_t), ptr(perm_t),
+                        ptr(fgr), *[ptr(g) for g in gws], ptr(bwd_ws), bwd_ws.numel(), stream_handle()), "conv_bwd_bf16"))
+                else:
+                    tb, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_bwd(
+                        *conv_args, ptr(og_t), n, m, e, fin, fout, int(combin), B, r, 0, 1, ptr(state), ptr(start_t), ptr(perm_t),
+                        ptr(fgr), *[ptr(g) for g in gws], ptr(bwd_ws), bwd_ws.numel(), stream_handle()), "conv_bwd"))
+            return tf, tb, fgr
+        t_fwd, t_bwd, fg = conv_times(sF, self.OG, 0)
+        plan_ms = None
+        if rows_fwd or rows_bwd:  # one-off cost per neighbour list (host + device, synchronised): rebuilt from scratch
+            packed._mccnn_rowplans = {}
+            plan_ms = {}
+            if rows_fwd:
+                plan_ms["forward_plan_ms"] = round(plan_of(False)[1], 4)
+            if rows_bwd:
+                plan_ms["transposed_plan_ms_excl_transposed_list"] = round(plan_of(True)[1], 4)
         # depth-wise layers with bf16 feature rows (extension, BASELINE cfg3): same launches, rows stored as bf16
         bf16 = None
         if not combin and fin % 8 == 0:
-            t_f16, t_b16, _ = conv_times(sF.to(torch.bfloat16), self.OG.to(torch.bfloat16))
+            t_f16, t_b16, _ = conv_times(sF.to(torch.bfloat16), self.OG.to(torch.bfloat16), 1)
             bf16 = {"fwd_ms": round(t_f16, 4), "bwd_ms": round(t_b16, 4),
                     "note": "features, outputs and their gradients stored as bf16 rows; MLP and accumulation f32"}
-        plans = getattr(packed, "_mccnn_rowplans", None)
-        kernels = "row-per-lane (conv_rows.hip)" if plans else ("factored Fin = 1 (conv_f1.hip)" if (combin and fin == 1) else "edge-streaming (conv.hip)")
+        kernels = ("row-per-lane (conv_rows.hip)" if (rows_fwd or rows_bwd) else
+                   ("factored Fin = 1 (conv_f1.hip)" if (combin and fin == 1) else "edge-streaming (conv.hip)"))
         t_s2g, _ = ev_time(lambda: M._gather_rows(fg, idx, n))
         C = int(np.prod(cells.shape[:4]))
         # algorithmic work per launch (SURVEY 8d; stated in DESIGN.md section 6)
@@ -323,6 +377,8 @@ class Workload:
         roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak,
                     "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                     "ms": round(ms, 4), "edges": e, "mlp_blocks": nb, "conv_kernels": kernels}
+        if plan_ms:
+            roofline["row_plans_once_per_neighbour_list"] = plan_ms
         if bound == "hbm" and dom.startswith("spatial_conv_"):
             # wide depth-wise layer on ONE room: its gathered rows (SURVEY 8d prices the layer by them) are Infinity-Cache
             # hits, not HBM traffic (counter traffic is ~1/3 of the algorithmic bytes), so the HBM peak is the wrong

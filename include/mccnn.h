@@ -79,6 +79,13 @@ int mccnn_compute_aabb(const float* pts, const int* batch_ids, int n, int batch_
  * like the reference's cudaMemcpy D2H at sort_gpu.cu:417). */
 int mccnn_num_cells(const float* aabb_min, const float* aabb_max, int batch_size, float cell_size,
                     int scale_inv, int* num_cells_host, mccnn_stream_t stream);
+/* The box extent mccnn_num_cells(scale_inv = 0) divides by -- max over the axes of aabb_max[0] - aabb_min[0] (batch 0:
+ * with scale_inv = 0 every row holds the whole-batch box, aabb_gpu.cu:104-114) -- read back ONCE (24 bytes, this call
+ * synchronises the stream). A binding that builds several grids over the same boxes (every level of a PointHierarchy,
+ * every convolution radius) computes num_cells = max(1, (int)(extent / cell_size)) in float on the host from it
+ * instead of paying the reference's read-back (sort_gpu.cu:410-419) per grid. */
+int mccnn_aabb_extent(const float* aabb_min, const float* aabb_max, float* extent_host,
+                      mccnn_stream_t stream);
 
 /* SortPointsStep1 -- sort_gpu.cc:23,184-268, sort_gpu.cu:35-174,436-471.
  * keys[i] = b*nc^3 + x*nc^2 + y*nc + z; new_idx[i] = destination of point i in
@@ -312,18 +319,24 @@ int mccnn_transform_indexs_dn(const int* in_idx, int s_cap, const int* s_dev, co
  *           of the rows (start_idx with rows = m for the forward plan; start_t of mccnn_transpose_neighbors with
  *           rows = n for the transposed one; entry `rows` is not read, e closes the last row). order: optional
  *           cell-coherent visiting order of the rows (a permutation; only affects locality). Deterministic.
- *   fill:   rec: 16 bytes per slot, other: 4 bytes per slot, both slot_capacity long. */
+ *   fill:   permutes the per-edge records of mccnn_edge_records into slot order. rec: 16 bytes per slot, other: 4
+ *           bytes per slot, both slot_capacity long. */
 int mccnn_rowplan_sizes(int rows, int e, int* num_slices, long long* slot_capacity, long long* scratch_rows);
 size_t mccnn_rowplan_workspace_bytes(int rows, int e);
 int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order, int* plan_vrow,
                          int* plan_vcode, int* slice_off, int* vpos_row, void* ws, size_t ws_bytes,
                          mccnn_stream_t stream);
-int mccnn_rowplan_fill(int transposed, const float* sorted_pts, const int* sorted_batch_ids,
-                       const float* pdfs, const float* samples, const int* start_idx, const int* packed,
-                       const float* aabb_min, const float* aabb_max, int n, int m, int e, int batch_size,
-                       float radius, int scale_inv, int avg, const int* row_start, const int* perm_t,
-                       const int* plan_vrow, const int* plan_vcode, const int* slice_off,
-                       const int* vpos_row, void* rec, int* other, mccnn_stream_t stream);
+/* Per-edge records (delta0, delta1, delta2, 1 / (pdf K)) in EDGE order, 16 bytes each -- the same bits the forward
+ * pass leaves in its state buffer (mccnn_spatial_conv_state_bytes): written once per (list, PDFs, radius, avg) and
+ * permuted into both plans by mccnn_rowplan_fill. */
+int mccnn_edge_records(const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs,
+                       const float* samples, const int* start_idx, const int* packed, const float* aabb_min,
+                       const float* aabb_max, int n, int m, int e, int batch_size, float radius,
+                       int scale_inv, int avg, void* rec_edges, mccnn_stream_t stream);
+int mccnn_rowplan_fill(int transposed, const void* rec_edges, const int* packed, int rows, int e,
+                       const int* row_start, const int* perm_t, const int* plan_vrow,
+                       const int* plan_vcode, const int* slice_off, const int* vpos_row, void* rec,
+                       int* other, mccnn_stream_t stream);
 
 /* SpatialConv / SpatialConvGrad for DEPTH-WISE layers (combin == 0, num_feats % 8 == 0, 16-byte aligned rows) over a
  * row plan -- same results as mccnn_spatial_conv_fwd / _bwd (spatial_conv.cu:178-325,563-792) up to float summation

@@ -196,7 +196,7 @@ class ConvolutionBuilder(torch.nn.Module):
         self.sideStream_ = None
         self.prefetched_ = None
         self.resetEvent_ = None
-        self.prefetchTransposed_ = set()
+        self.prefetchTransposed_ = {}
         self.prefetchDummy_ = None
         self.sideTensors_ = []      # tensors of the installed prefetch (allocated on the side stream), see __retire_side_tensors__
         self.sideRecorded_ = 0      # how many of them needed the record_stream() fallback so far (tests)
@@ -275,12 +275,19 @@ class ConvolutionBuilder(torch.nn.Module):
             self.resetEvent_ = torch.cuda.Event()
             self.resetEvent_.record()
         if pf is not None:
-            for kN, kG in self.prefetchTransposed_:
+            for kN, (kG, kP, centres, mn, mx, B, radius, rel) in self.prefetchTransposed_.items():
                 if kN in neighs and kG in grids and getattr(self.ops_, "_ops", 0) is None:
                     from . import MCConvModule as _hip_ops
                     self.sideStream_.wait_event(self.resetEvent_)
-                    _hip_ops.prefetch_transposed(neighs[kN][1], grids[kG][0].shape[0], self.sideStream_)
-            self.prefetchTransposed_ = set()
+                    g = grids[kG]
+                    _hip_ops.prefetch_transposed(neighs[kN][1], g[0].shape[0], self.sideStream_)
+                    if kP in pdfs:
+                        # ... and the transposed ROW PLAN the depth-wise backward passes sweep (MCConvModule._row_plan):
+                        # under the forward convolutions as well; its consumer waits for the plan's event
+                        _hip_ops.prefetch_rowplan(neighs[kN][1], True, self.sideStream_, g[0], g[1], pdfs[kP], centres,
+                                                  neighs[kN][0], neighs[kN][1], mn, mx, g[0].shape[0], centres.shape[0],
+                                                  neighs[kN][1].shape[0], B, radius, rel, self.useAVG_)
+            self.prefetchTransposed_ = {}
 
     def __retire_side_tensors__(self):
         """Lifetime of the tensors prefetch_geometry() allocated on the side stream and the main stream reads.
@@ -296,10 +303,15 @@ class ConvolutionBuilder(torch.nn.Module):
             return
         main = torch.cuda.current_stream()
         extra = []
-        for t in tensors:  # the transposed lists built on the side stream live (and die) with their neighbour list
+        for t in tensors:  # the transposed lists / row plans built on the side stream live (and die) with their neighbour list
             hit = getattr(t, "_mccnn_transposed", None)
             if hit is not None:
                 extra.extend(hit[:2])
+            for pl in (getattr(t, "_mccnn_rowplans", None) or {}).values():
+                if getattr(pl, "event", None) is not None:  # built on the side stream (prefetch_rowplan)
+                    pl.vrow = pl.vcode = pl.slice_off = pl.vpos_row = pl.other = pl.row_start = None  # views of pl.ints
+                    extra.extend([pl.ints, pl.rec])
+                    pl.ints = pl.rec = None
         self.cacheGrids_ = self.cacheNeighs_ = self.cachePDFs_ = None  # the cache dictionaries' references go first
         # Is the builder the LAST owner? Exactly three counts answer that, and a build of torch that lacks one of them
         # takes the always-correct record_stream() path: Python references to the tensor object (this frame + the
@@ -384,7 +396,8 @@ class ConvolutionBuilder(torch.nn.Module):
                     neighs[keyNeighs] = h
                     pdfs[keyPDF] = h
             if transposed:
-                self.prefetchTransposed_ = self.prefetchTransposed_ | {(keyNeighs, keyGrid)}
+                self.prefetchTransposed_[keyNeighs] = (keyGrid, keyPDF, outPH.points_[outLevel], mn, mx, B, convRadius,
+                                                       currRelativeRadius)
             if keyNeighs not in neighs:
                 neighs[keyNeighs] = tuple(self.ops_.find_neighbors(outPH.points_[outLevel], outPH.batchIds_[outLevel], g[0],
                                                                    g[2], mn, mx, convRadius, B, currRelativeRadius))

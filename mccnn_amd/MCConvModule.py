@@ -15,6 +15,7 @@ import threading
 import time
 import weakref
 
+import numpy as _np
 import torch
 
 from . import _lib
@@ -62,8 +63,20 @@ def _i32(t, name):
     return t.contiguous()
 
 
+_WS_POOL = {}  # (thread, device, raw stream) -> grow-only scratch buffer
+
+
 def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    """Scratch memory for ONE library call (or one count / fill pair issued back to back): a grow-only buffer per host
+    thread and stream instead of an allocation per call (~120 per step of a segmentation network). Consecutive calls
+    on a stream may share it because they are stream-ordered; nothing that has to outlive the call sequence lives
+    here (lists, plans and the forward state are tensors of their own)."""
+    nbytes = max(int(nbytes), 256)
+    key = (threading.get_ident(), device.index, stream_handle())
+    buf = _WS_POOL.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _WS_POOL[key] = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, device=device)
+    return buf
 
 
 def _check_points(pts, name, op):
@@ -260,7 +273,7 @@ ROW_KERNELS = os.environ.get("MCCNN_ROW_KERNELS", "1") != "0"
 class RowPlan:
     """SELL-64 layout of a neighbour list (include/mccnn.h, mccnn_rowplan_*): device tensors; every size is fixed by
     (rows, e), so building a plan involves no host read-back."""
-    __slots__ = ("vrow", "vcode", "slice_off", "vpos_row", "rec", "other", "scratch_rows", "row_start", "key")
+    __slots__ = ("vrow", "vcode", "slice_off", "vpos_row", "rec", "other", "scratch_rows", "row_start", "key", "ints", "event")
 
 
 def _row_plan(packed_obj, transposed, pts, bids, pdfs, smp, st, pk, mn, mx, n, m, e, batchSize, radius, scaleInv, avg,
@@ -278,6 +291,8 @@ def _row_plan(packed_obj, transposed, pts, bids, pdfs, smp, st, pk, mn, mx, n, m
             pass
     hit = plans.get(key[0])
     if hit is not None and hit.key == key:
+        if hit.event is not None:  # built ahead of time on another stream (prefetch_rowplan): order this stream behind it
+            torch.cuda.current_stream().wait_event(hit.event)
         return hit
     lib = _lib.load()
     dev = pk.device
@@ -295,23 +310,57 @@ def _row_plan(packed_obj, transposed, pts, bids, pdfs, smp, st, pk, mn, mx, n, m
     S, cap = S.value, cap.value
     plan = RowPlan()
     plan.key = key
+    plan.event = None
     plan.row_start = row_start
     plan.scratch_rows = srows.value
-    plan.vrow = torch.empty(64 * S, dtype=torch.int32, device=dev)
-    plan.vcode = torch.empty(64 * S, dtype=torch.int32, device=dev)
-    plan.slice_off = torch.empty(S + 1, dtype=torch.int32, device=dev)
-    plan.vpos_row = torch.empty(rows, dtype=torch.int32, device=dev)
+    # one allocation for the five index arrays (64-int aligned pieces), one for the records
+    al = lambda k: (k + 63) // 64 * 64
+    o1 = al(64 * S)
+    o2 = o1 + al(64 * S)
+    o3 = o2 + al(S + 1)
+    o4 = o3 + al(rows)
+    ints = plan.ints = torch.empty(o4 + cap, dtype=torch.int32, device=dev)
+    plan.vrow, plan.vcode, plan.slice_off = ints[:64 * S], ints[o1:o1 + 64 * S], ints[o2:o2 + S + 1]
+    plan.vpos_row, plan.other = ints[o3:o3 + rows], ints[o4:o4 + cap]
     plan.rec = torch.empty((cap, 4), dtype=torch.float32, device=dev)
-    plan.other = torch.empty(cap, dtype=torch.int32, device=dev)
     ws = _ws(lib.mccnn_rowplan_workspace_bytes(rows, e), dev)
     check(lib.mccnn_rowplan_layout(ptr(row_start), rows, e, ptr(order), ptr(plan.vrow), ptr(plan.vcode), ptr(plan.slice_off),
                                    ptr(plan.vpos_row), ptr(ws), ws.numel(), stream_handle()), "rowplan_layout")
-    check(lib.mccnn_rowplan_fill(int(bool(transposed)), ptr(pts), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk), ptr(mn),
-                                 ptr(mx), n, m, e, batchSize, float(radius), int(bool(scaleInv)), int(bool(avg)),
-                                 ptr(row_start), ptr(perm_t), ptr(plan.vrow), ptr(plan.vcode), ptr(plan.slice_off),
-                                 ptr(plan.vpos_row), ptr(plan.rec), ptr(plan.other), stream_handle()), "rowplan_fill")
+    # the per-edge records in edge order: written once per list, permuted into both plans
+    rec_e = plans.get("rec_edges")
+    if rec_e is None or rec_e[0] != key[1:]:
+        buf = torch.empty((max(e, 1), 4), dtype=torch.float32, device=dev)
+        check(lib.mccnn_edge_records(ptr(pts), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk), ptr(mn), ptr(mx), n, m, e,
+                                     batchSize, float(radius), int(bool(scaleInv)), int(bool(avg)), ptr(buf), stream_handle()),
+              "edge_records")
+        rec_e = plans["rec_edges"] = [key[1:], buf, None]
+    elif rec_e[2] is not None:  # written on another stream (prefetch_rowplan)
+        torch.cuda.current_stream().wait_event(rec_e[2])
+    check(lib.mccnn_rowplan_fill(int(bool(transposed)), ptr(rec_e[1]), ptr(pk), rows, e, ptr(row_start), ptr(perm_t),
+                                 ptr(plan.vrow), ptr(plan.vcode), ptr(plan.slice_off), ptr(plan.vpos_row), ptr(plan.rec),
+                                 ptr(plan.other), stream_handle()), "rowplan_fill")
     plans[key[0]] = plan
     return plan
+
+
+def prefetch_rowplan(packed, transposed, stream, *args):
+    """Builds a row plan of `packed` on `stream` (a side stream) ahead of the pass that will ask for it; the consumer waits
+    for the recorded event (see _row_plan). The inputs must be ready on `stream`. args: _row_plan's after `transposed`."""
+    main = torch.cuda.current_stream()
+    with torch.cuda.stream(stream):
+        plans = getattr(packed, "_mccnn_rowplans", None) or {}
+        if plans.get(bool(transposed)) is None:
+            had_rec = plans.get("rec_edges") is not None
+            plan = _row_plan(packed, transposed, *args)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            plan.event = ev
+            rec_e = (getattr(packed, "_mccnn_rowplans", None) or {}).get("rec_edges")
+            if rec_e is not None and not had_rec:
+                # the edge-order records were written (and allocated) on this stream; the other plan of the list will read
+                # them on the caller's stream: ordered by the event, lifetime handed to the allocator
+                rec_e[2] = ev
+                rec_e[1].record_stream(main)
 
 
 def _rows_shape(combin, fin, feats, rows, e):
@@ -329,6 +378,7 @@ def clear_caches():
     """Drop the per-shape launch hints (visiting orders, edge-count guesses, num_cells read-backs). They only affect
     speed, never results, and are bounded in size; call this to release the device tensors they hold."""
     _ORDER_HINTS.clear()
+    _WS_POOL.clear()
     _NUM_CELLS_CACHE.clear()
     _EDGE_GUESS.clear()
     _EDGE_RATIO.clear()
@@ -362,26 +412,32 @@ def debug_conv_impl(mask):
 
 
 def _num_cells(aabbMin, aabbMax, batchSize, cellSize, scaleInv):
-    """determineNumCells (sort_gpu.cu:397-420). scaleInv=False costs one 24-byte read-back; it is cached per box
-    tensor OBJECT (weak reference + version counter -- never by address, the allocator recycles addresses) so that
-    step1/step2 and later grids over the same hierarchy pay it once."""
+    """determineNumCells (sort_gpu.cu:397-420). scaleInv=False needs the box extent on the host: ONE 24-byte read-back
+    per box tensor pair (mccnn_aabb_extent), cached per tensor OBJECT (weak reference + version counter -- never by
+    address, the allocator recycles addresses); every grid over the same boxes -- all levels of a hierarchy, all
+    convolution radii -- then computes its cell count on the host with the reference's float arithmetic."""
     lib = _lib.load()
-    out = C.c_int(0)
     if scaleInv:
+        out = C.c_int(0)
         check(lib.mccnn_num_cells(None, None, batchSize, float(cellSize), 1, C.byref(out), None), "num_cells")
         return out.value
-    key = (id(aabbMin), id(aabbMax), float(cellSize))
+    key = (id(aabbMin), id(aabbMax))
     hit = _NUM_CELLS_CACHE.get(key)
+    ext = None
     if hit is not None:
         rmin, rmax, vmin, vmax, val = hit
         if rmin() is aabbMin and rmax() is aabbMax and vmin == aabbMin._version and vmax == aabbMax._version:
-            return val
-    check(lib.mccnn_num_cells(ptr(aabbMin), ptr(aabbMax), batchSize, float(cellSize), 0, C.byref(out),
-                              stream_handle()), "num_cells")
-    if len(_NUM_CELLS_CACHE) > 256:
-        _NUM_CELLS_CACHE.clear()
-    _NUM_CELLS_CACHE[key] = (weakref.ref(aabbMin), weakref.ref(aabbMax), aabbMin._version, aabbMax._version, out.value)
-    return out.value
+            ext = val
+    if ext is None:
+        out = C.c_float(0.0)
+        check(lib.mccnn_aabb_extent(ptr(aabbMin), ptr(aabbMax), C.byref(out), stream_handle()), "aabb_extent")
+        ext = _np.float32(out.value)
+        if len(_NUM_CELLS_CACHE) > 256:
+            _NUM_CELLS_CACHE.clear()
+        _NUM_CELLS_CACHE[key] = (weakref.ref(aabbMin), weakref.ref(aabbMax), aabbMin._version, aabbMax._version, ext)
+    _req(cellSize > 0, "cell size must be positive")
+    nc = int(ext / _np.float32(cellSize))   # float32 divide, truncation: sort_gpu.cu:415-416
+    return nc if nc != 0 else 1
 
 
 # ---------------------------------------------------------------------------------------------

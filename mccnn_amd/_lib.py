@@ -25,6 +25,7 @@ SIGNATURES = {
     "mccnn_compute_aabb_workspace_bytes": (_sz, [_i]),
     "mccnn_compute_aabb": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_num_cells": (_i, [_vp, _vp, _i, _f, _i, C.POINTER(_i), _vp]),
+    "mccnn_aabb_extent": (_i, [_vp, _vp, C.POINTER(_f), _vp]),
     "mccnn_sort_step1_workspace_bytes": (_sz, [_i, _i, _i]),
     "mccnn_sort_step1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_sort_step2_workspace_bytes": (_sz, [_i]),
@@ -56,7 +57,8 @@ SIGNATURES = {
     "mccnn_rowplan_sizes": (_i, [_i, _i, C.POINTER(_i), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "mccnn_rowplan_workspace_bytes": (_sz, [_i, _i]),
     "mccnn_rowplan_layout": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "mccnn_rowplan_fill": (_i, [_i] + [_vp] * 8 + [_i, _i, _i, _i, _f, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp]),
+    "mccnn_edge_records": (_i, [_vp] * 8 + [_i, _i, _i, _i, _f, _i, _i, _vp, _vp]),
+    "mccnn_rowplan_fill": (_i, [_i, _vp, _vp, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp]),
     "mccnn_spatial_conv_fwd_rows": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp]),
     "mccnn_spatial_conv_bwd_rows_workspace_bytes": (_sz, [_i, _i, _i]),
     "mccnn_spatial_conv_bwd_rows": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 7 + [_vp] * 8 + [_vp, _sz, _vp]),

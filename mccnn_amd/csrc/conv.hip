@@ -995,6 +995,12 @@ static int fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_f
     return 0;
 }
 
+int launch_edge_records(const ConvArgs& a, float4* rec, hipStream_t s) {
+    edge_records<<<ceil_div(a.e, 256), 256, 0, s>>>(a, rec);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
 void launch_reduce_partials(const float* partials, int rows, int nb, float* dw1, float* db1, float* dw2, float* db2,
                             float* dw3, float* db3, hipStream_t s) {
     reduce_partials<<<ceil_div((long long)nb * 176, 16), 1024, 0, s>>>(partials, rows, nb, dw1, db1, dw2, db2, dw3, db3);

@@ -148,51 +148,56 @@ __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStar
     }
 }
 
-// One wave per slice: the records of the slice in (iteration, lane) order. Same expressions as the streaming kernels'
-// edge set-up (conv.hip conv_stream / edge_records), so the records hold identical bits.
+// The records of a slice in (iteration, lane) order: a pure PERMUTATION of the per-edge records (delta, 1 / (pdf K)) that
+// mccnn_edge_records writes once per list in edge order (coalesced reads, the gathers of points / centres / row lengths
+// paid once for both plans). Workgroup (slice, chunk of 16 iterations), wave w takes 4 consecutive iterations: in the
+// forward plan a lane's 4 edges are 64 contiguous bytes of records and 32 of pairs. (One wave per slice walking all its
+// iterations with the set-up arithmetic inline was 260 us per plan on the 100k room.)
+#define MCCNN_FILL_CHUNK 16
 template <bool TR>
-__global__ __launch_bounds__(256) void sell_fill(ConvArgs a, const int* __restrict__ rowStart, int rows,
-                                                 const int* __restrict__ permT, RowPlan p, long long cap,
-                                                 float4* __restrict__ rec, int* __restrict__ oth, int L) {
+__global__ __launch_bounds__(256) void sell_fill(const float4* __restrict__ recE, const int2* __restrict__ packed, int e,
+                                                 const int* __restrict__ rowStart, int rows, const int* __restrict__ permT,
+                                                 RowPlan p, long long cap, float4* __restrict__ rec, int* __restrict__ oth,
+                                                 int L) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slice = blockIdx.x * 4 + wave;
-    if (slice >= p.S) return;
+    const int slice = blockIdx.x;
     const int off = p.sliceOff[slice];
     const int len = (p.sliceOff[slice + 1] - off) >> 6;
-    if (len == 0 || (long long)off + (long long)len * 64 > cap) return;  // (the bound of plan_sizes makes this impossible)
+    const int it0 = blockIdx.y * MCCNN_FILL_CHUNK + wave * (MCCNN_FILL_CHUNK / 4);
+    if (it0 >= len || (long long)off + (long long)len * 64 > cap) return;  // (the bound of plan_sizes makes the latter impossible)
     const int r = p.vrow[slice * 64 + lane];
     int base = 0, deg = 0;
     if (r >= 0) {
         const int code = p.vcode[slice * 64 + lane];
         const int piece = (code < 0 ? ~code : code) - p.vposRow[r];
         const int rb = rowStart[r];
-        const int rdeg = ((r + 1 < rows) ? rowStart[r + 1] : a.e) - rb;
+        const int rdeg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rb;
         base = rb + piece * L;
         deg = max(0, min(L, rdeg - piece * L));
     }
-    int pad = 0;
-    for (int it = 0; it < len; ++it) {
-        float4 rc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int o = pad;
-        if (it < deg) {
-            const int e = TR ? permT[base + it] : base + it;
-            const int2 pr = a.packed[e];
-            const int j = pr.x, ci = pr.y;
-            float invR = a.invRadius;
-            if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B)));
-            const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B)) : a.radius;
-            const float* pp = a.pts + (size_t)j * 3;
-            const float* cc = a.samples + (size_t)ci * 3;
-            float K = 1.0f;
-            if (a.avg) K = (float)(((ci + 1 < a.m) ? a.start[ci + 1] : a.e) - a.start[ci]);
-            rc = make_float4(div_exact(pp[0] - cc[0], R, invR), div_exact(pp[1] - cc[1], R, invR),
-                             div_exact(pp[2] - cc[2], R, invR), __builtin_amdgcn_rcpf(a.pdfs[e] * K));
-            o = TR ? ci : j;
-            if (it == 0) pad = o;
+    constexpr int K = MCCNN_FILL_CHUNK / 4;
+    // all loads of the 4 iterations first (clamped indices: no branch between them)
+    int eid[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int t = base + min(it0 + k, max(deg - 1, 0));
+        eid[k] = TR ? permT[min(t, e - 1)] : min(t, e - 1);
+    }
+    const int2 p0 = packed[TR ? permT[min(base, e - 1)] : min(base, e - 1)];
+    const int pad = (deg > 0) ? (TR ? p0.y : p0.x) : 0;  // padding slots: the row's first neighbour (valid, cached; 1/(pdf K) = 0)
+    float4 rc[K];
+    int2 pr[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { rc[k] = recE[eid[k]]; pr[k] = packed[eid[k]]; }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int it = it0 + k;
+        if (it < len) {
+            const bool real = it < deg;
+            const size_t slot = (size_t)off + (size_t)it * 64 + lane;
+            rec[slot] = real ? rc[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            oth[slot] = real ? (TR ? pr[k].y : pr[k].x) : pad;
         }
-        const size_t slot = (size_t)off + (size_t)it * 64 + lane;
-        rec[slot] = rc;
-        oth[slot] = o;
     }
 }
 
@@ -583,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
 // defined in conv.hip
 void launch_reduce_partials(const float* partials, int rows, int nb, float* dw1, float* db1, float* dw2, float* db2,
                             float* dw3, float* db3, hipStream_t s);
+int launch_edge_records(const ConvArgs& a, float4* rec, hipStream_t s);
 int conv_fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
                    const float* pdfs, const float* samples, const int* start_idx, const int* packed,
                    const float* aabb_min, const float* aabb_max, const float* w1, const float* b1, const float* w2,
@@ -652,29 +658,39 @@ int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order
     return exclusive_scan_i32(sliceSlots, slice_off, z.S, slice_off + z.S, scan2, s);
 }
 
-int mccnn_rowplan_fill(int transposed, const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs,
-                       const float* samples, const int* start_idx, const int* packed, const float* aabb_min,
-                       const float* aabb_max, int n, int m, int e, int batch_size, float radius, int scale_inv, int avg,
-                       const int* row_start, const int* perm_t, const int* plan_vrow, const int* plan_vcode,
-                       const int* slice_off, const int* vpos_row, void* rec, int* other, mccnn_stream_t stream) {
+int mccnn_edge_records(const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs, const float* samples,
+                       const int* start_idx, const int* packed, const float* aabb_min, const float* aabb_max, int n, int m,
+                       int e, int batch_size, float radius, int scale_inv, int avg, void* rec_edges, mccnn_stream_t stream) {
     if (n < 0 || m < 0 || e < 0 || batch_size <= 0 || !(radius > 0.0f)) return MCCNN_E_BADARG;
-    const int rows = transposed ? n : m;
-    if (rows == 0 || e == 0) return 0;
-    if (!sorted_pts || !sorted_batch_ids || !pdfs || !samples || !start_idx || !packed || !aabb_min || !aabb_max ||
-        !row_start || !plan_vrow || !plan_vcode || !slice_off || !vpos_row || !rec || !other || (transposed && !perm_t))
+    if (e == 0) return 0;
+    if (!sorted_pts || !sorted_batch_ids || !pdfs || !samples || !start_idx || !packed || !aabb_min || !aabb_max || !rec_edges)
         return MCCNN_E_BADARG;
     ConvArgs a = {};
     a.pts = sorted_pts; a.bids = sorted_batch_ids; a.pdfs = pdfs; a.samples = samples; a.start = start_idx;
     a.packed = reinterpret_cast<const int2*>(packed); a.mn = aabb_min; a.mx = aabb_max;
     a.n = n; a.m = m; a.e = e; a.radius = radius; a.invRadius = 1.0f / radius; a.scaleInv = scale_inv; a.avg = avg;
     a.B = batch_size;
+    return launch_edge_records(a, reinterpret_cast<float4*>(rec_edges), (hipStream_t)stream);
+}
+
+int mccnn_rowplan_fill(int transposed, const void* rec_edges, const int* packed, int rows, int e, const int* row_start,
+                       const int* perm_t, const int* plan_vrow, const int* plan_vcode, const int* slice_off,
+                       const int* vpos_row, void* rec, int* other, mccnn_stream_t stream) {
+    if (rows < 0 || e < 0) return MCCNN_E_BADARG;
+    if (rows == 0 || e == 0) return 0;
+    if (!rec_edges || !packed || !row_start || !plan_vrow || !plan_vcode || !slice_off || !vpos_row || !rec || !other ||
+        (transposed && !perm_t))
+        return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const PlanSizes z = plan_sizes(rows, e);
     RowPlan p = {plan_vrow, plan_vcode, slice_off, vpos_row, nullptr, nullptr, rows, z.S};
+    const dim3 grid(z.S, ceil_div(z.L, MCCNN_FILL_CHUNK));
     if (transposed)
-        sell_fill<true><<<ceil_div(z.S, 4), 256, 0, s>>>(a, row_start, rows, perm_t, p, z.slots, reinterpret_cast<float4*>(rec), other, z.L);
+        sell_fill<true><<<grid, 256, 0, s>>>(reinterpret_cast<const float4*>(rec_edges), reinterpret_cast<const int2*>(packed), e,
+                                             row_start, rows, perm_t, p, z.slots, reinterpret_cast<float4*>(rec), other, z.L);
     else
-        sell_fill<false><<<ceil_div(z.S, 4), 256, 0, s>>>(a, row_start, rows, nullptr, p, z.slots, reinterpret_cast<float4*>(rec), other, z.L);
+        sell_fill<false><<<grid, 256, 0, s>>>(reinterpret_cast<const float4*>(rec_edges), reinterpret_cast<const int2*>(packed), e,
+                                              row_start, rows, nullptr, p, z.slots, reinterpret_cast<float4*>(rec), other, z.L);
     MCCNN_LAUNCHED();
     return 0;
 }

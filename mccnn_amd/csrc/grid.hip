@@ -332,6 +332,17 @@ int mccnn_num_cells(const float* aabb_min, const float* aabb_max, int batch_size
     return 0;
 }
 
+int mccnn_aabb_extent(const float* aabb_min, const float* aabb_max, float* extent_host, mccnn_stream_t stream) {
+    if (!aabb_min || !aabb_max || !extent_host) return MCCNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    float h[6];
+    MCCNN_HIP(hipMemcpyAsync(h, aabb_min, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    MCCNN_HIP(hipMemcpyAsync(h + 3, aabb_max, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    MCCNN_HIP(hipStreamSynchronize(s));
+    *extent_host = fmaxf(fmaxf(h[3] - h[0], h[4] - h[1]), h[5] - h[2]);
+    return 0;
+}
+
 static long long total_cells(int B, int nc) { return (long long)B * nc * nc * nc; }
 
 size_t mccnn_sort_step1_workspace_bytes(int n, int batch_size, int num_cells) {

@@ -78,5 +78,7 @@ for F in feats_list:
                                                                   ["%.1e" % rel(x, y) for x, y in zip(a[1][1:], b[1][1:])]))
     pl = getattr(packed, "_mccnn_rowplans", {})
     for k, p in pl.items():
+        if not isinstance(k, bool):
+            continue
         S = p.slice_off.shape[0] - 1
         print("   plan transposed=%s: %d slots used (%.3f x E), capacity %d" % (k, int(p.slice_off[S]), int(p.slice_off[S]) / packed.shape[0], p.other.shape[0]))
