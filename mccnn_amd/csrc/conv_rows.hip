@@ -462,7 +462,12 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
         for (int n = 0; n < 8; ++n) dF[n] = 0.f;
         // (Staging the out-gradient rows through LDS like the forward's feature rows was measured and dropped: parked
         // right after the load the wait is exposed at the top of every iteration, parked late the 8 extra VGPRs spill
-        // the sums -- 3.38 ms against 2.40 ms for dw256 on the room. Each wave gathers its own 32-byte piece.)
+        // the sums -- 3.38 ms against 2.40 ms for dw256 on the room. Each wave gathers its own 32-byte piece. Also
+        // measured and dropped: WAVE SPECIALISATION -- a producer wave per block with all five 8x8 products' weights in
+        // 76 VGPRs (MLP, feature gradient, u / t3 / t4) handing 11 float4 per lane and iteration through LDS to a
+        // consumer wave that only feeds the 176 sums, one barrier per iteration, double-buffered: parity-green, 199
+        // VGPRs, no spills, but 3.40 ms -- the producer's chain of 38 dependent MFMA steps per iteration is a latency the
+        // barrier makes every wave of the workgroup wait for, and two waves per SIMD leave nothing to fill it with.)
         float4 rcN = make_float4(0.f, 0.f, 0.f, 0.f);
         int iN = 0;
         if (len > 0) { rcN = p.rec[(size_t)off + lane]; iN = p.other[(size_t)off + lane]; }
