@@ -355,20 +355,6 @@ int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feat
                                 int bf16, const int* plan_vrow, const int* plan_vcode,
                                 const int* slice_off, const int* vpos_row, const void* plan_rec,
                                 const int* plan_other, void* out, float* scratch, mccnn_stream_t stream);
-/* SpatialConv for COMBIN layers with ONE input feature over the forward row plan (the factored algorithm of
- * mccnn_spatial_conv_fwd for these layers, its edge pass as a row-per-lane sweep). centre_state: the per-centre sums
- * (A, S) -- mccnn_spatial_conv_state_bytes(...) minus the 16 e bytes of edge records in front; handing the per-edge
- * records of mccnn_edge_records and this buffer to mccnn_spatial_conv_bwd as one state (records first) saves the
- * backward pass its pre-passes. scratch: scratch_rows x (8 nb + 4) floats. */
-int mccnn_spatial_conv_fwd_f1_rows(const float* sorted_pts, const float* sorted_feats,
-                                   const int* sorted_batch_ids, const float* pdfs, const float* samples,
-                                   const int* start_idx, const int* packed, const float* aabb_min,
-                                   const float* aabb_max, const float* w1, const float* b1, const float* w2,
-                                   const float* b2, const float* w3, const float* b3, int n, int m, int e,
-                                   int num_out_feats, int batch_size, float radius, int scale_inv, int avg,
-                                   const int* plan_vrow, const int* plan_vcode, const int* slice_off,
-                                   const int* vpos_row, const void* plan_rec, const int* plan_other,
-                                   float* out, void* centre_state, float* scratch, mccnn_stream_t stream);
 size_t mccnn_spatial_conv_bwd_rows_workspace_bytes(int n, int e, int num_feats);
 int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feats,
                                 const int* sorted_batch_ids, const float* pdfs, const float* samples,

@@ -60,7 +60,6 @@ SIGNATURES = {
     "mccnn_edge_records": (_i, [_vp] * 8 + [_i, _i, _i, _i, _f, _i, _i, _vp, _vp]),
     "mccnn_rowplan_fill": (_i, [_i, _vp, _vp, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp]),
     "mccnn_spatial_conv_fwd_rows": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp]),
-    "mccnn_spatial_conv_fwd_f1_rows": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp, _vp]),
     "mccnn_spatial_conv_bwd_rows_workspace_bytes": (_sz, [_i, _i, _i]),
     "mccnn_spatial_conv_bwd_rows": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 7 + [_vp] * 8 + [_vp, _sz, _vp]),
     "mccnn_transpose_neighbors_workspace_bytes": (_sz, [_i, _i]),

@@ -521,14 +521,6 @@ static int f1_run_edges(const ConvArgs& a, float* A, float* S, float4* recOut, h
     return 0;
 }
 
-// conv_rows.hip: the row-per-lane forward leaves (A, S) in the same buffer layout and runs the same centre pass
-void f1_state_pointers(void* state, int m, int nb, float*& A, float*& S) { f1_state_split(state, m, nb, A, S); }
-int f1_centres_launch(const ConvArgs& a, const float* A, const float* S, float* out, hipStream_t s) {
-    f1_fwd_centres<<<ceil_div((long long)a.m * a.nb, 256), 256, (size_t)a.nb * 72 * sizeof(float), s>>>(a, A, S, out);
-    MCCNN_LAUNCHED();
-    return 0;
-}
-
 size_t f1_fwd_workspace_bytes(int m, int nb) { return f1_state_bytes(m, nb) + 256; }
 
 int f1_forward(const ConvArgs& a, float* out, float4* rec_out, void* state, void* ws, size_t ws_bytes, hipStream_t s) {

@@ -390,110 +390,11 @@ __global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float*
     }
 }
 
-// ------------------------------------------------------------------------------------------------ one input feature, forward
-// Combin layers with ONE input feature (conv_f1.hip: layer 3 commutes with the sum over a centre's edges): the edge pass
-// A_i = sum_e s_e a2_e, S_i = sum_e s_e, s_e = f_j / (pdf_e K_i), as a row-per-lane sweep. Work item = (slice, block q),
-// layers 1 and 2 of the block in 26 VGPRs, the lane's 8 sums of A in registers; the scalar s of an iteration is gathered
-// once per workgroup (wave 0) and handed to the four block waves through LDS. No scan, no carry: the streaming kernel
-// spends 53 of its 199 us on the segmented scan. Cut rows leave (A piece, S) in a scratch row of 8 nb + 4 floats.
-__global__ __launch_bounds__(256) void f1_fwd_rows(ConvArgs a, RowPlan p, float* __restrict__ A, float* __restrict__ S,
-                                                   float* __restrict__ scratch, int qTiles) {
-    __shared__ float sbuf[2][64];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i4 = lane & 3;
-    const int L = xcd_contiguous(blockIdx.x, gridDim.x);
-    if (L >= p.S * qTiles) return;
-    const int qt = L / p.S, slice = L - qt * p.S;
-    const int off = p.sliceOff[slice];
-    const int len = (p.sliceOff[slice + 1] - off) >> 6;
-    if (len == 0) return;
-    const int q = qt * 4 + wave;
-    const bool mine = q < a.nb;
-    const int rowA = a.nb * 8;
-    BlockWeights w;
-    load_block_weights(a, mine ? q : 0, i4, w);
-    const int r = p.vrow[slice * 64 + lane];
-    float acc[8], accS = 0.f;
-#pragma unroll
-    for (int n = 0; n < 8; ++n) acc[n] = 0.f;
-    float4 rcN = p.rec[(size_t)off + lane];
-    float sN = 0.f;
-    if (wave == 0) {
-        sN = a.feats[p.other[(size_t)off + lane]] * rcN.w;
-        sbuf[0][lane] = sN;
-        if (len > 1) sN = a.feats[p.other[(size_t)off + 64 + lane]];  // the feature of iteration 1 (scaled when its record arrives)
-    }
-    __syncthreads();
-    for (int it = 0; it < len; ++it) {
-        const float4 rc = rcN;
-        const bool more = it + 1 < len;
-        float fNext = sN;
-        if (more) {
-            rcN = p.rec[(size_t)off + (size_t)(it + 1) * 64 + lane];
-            if (wave == 0 && it + 2 < len) sN = a.feats[p.other[(size_t)off + (size_t)(it + 2) * 64 + lane]];
-        }
-        const float s = sbuf[it & 1][lane];
-        float a1[8], a2[8];
-        {
-            float pre[8];
-            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
-            const float one = opaque_one();
-            lo = MFMA4(w.w1lo[0], rc.x, lo); hi = MFMA4(w.w1hi[0], rc.x, hi);
-            lo = MFMA4(w.w1lo[1], rc.y, lo); hi = MFMA4(w.w1hi[1], rc.y, hi);
-            lo = MFMA4(w.w1lo[2], rc.z, lo); hi = MFMA4(w.w1hi[2], rc.z, hi);
-            lo = MFMA4(w.w1lo[3], one, lo);  hi = MFMA4(w.w1hi[3], one, hi);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) { pre[rr] = lo[rr]; pre[4 + rr] = hi[rr]; }
-            MCCNN_PHASE();
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) a1[rr] = relu1(pre[rr]);
-            MCCNN_PHASE();
-            layer8_regs<true>(w.w2lo, w.w2hi, w.b2lo, w.b2hi, a1, pre);
-            MCCNN_PHASE();
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) a2[rr] = relu1(pre[rr]);
-        }
-#pragma unroll
-        for (int n = 0; n < 8; ++n) acc[n] = __builtin_fmaf(s, a2[n], acc[n]);
-        accS += s;
-        if (more && wave == 0) sbuf[(it + 1) & 1][lane] = fNext * rcN.w;
-        __syncthreads();
-    }
-    if (r >= 0 && mine) {
-        const int code = p.vcode[slice * 64 + lane];
-        float* dst = (code >= 0) ? scratch + (size_t)code * (rowA + 4) + q * 8 : A + (size_t)r * rowA + q * 8;
-        reinterpret_cast<float4*>(dst)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        reinterpret_cast<float4*>(dst)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        if (q == 0) {
-            if (code >= 0) scratch[(size_t)code * (rowA + 4) + rowA] = accS;
-            else S[r] = accS;
-        }
-    }
-}
-// cut rows: A_i and S_i from their pieces (one wave per 64 rows; rare)
-__global__ __launch_bounds__(256) void f1_rows_combine(const int* __restrict__ rowStart, int rows, int e,
-                                                       const int* __restrict__ vposRow, const float* __restrict__ scratch,
-                                                       int rowA, float* __restrict__ A, float* __restrict__ S, int L) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r0 = (blockIdx.x * 4 + wave) * 64;
-    const int r = r0 + lane;
-    int deg = 0;
-    if (r < rows) deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
-    unsigned long long cut = __ballot(deg > L);
-    while (cut) {
-        const int l = (int)__builtin_ctzll(cut);
-        cut &= cut - 1;
-        const int rr = r0 + l;
-        const int pieces = (__builtin_amdgcn_readlane(deg, l) + L - 1) / L;
-        const int v0 = vposRow[rr];
-        for (int c = lane; c <= rowA; c += 64) {
-            float acc = 0.f;
-            for (int k = 0; k < pieces; ++k) acc += scratch[(size_t)(v0 + k) * (rowA + 4) + c];
-            if (c < rowA) A[(size_t)rr * rowA + c] = acc;
-            else S[rr] = acc;
-        }
-    }
-}
-
+// (A row-per-lane edge pass for combin layers with ONE input feature -- conv_f1.hip's A_i = sum_e s_e a2_e with layers 1
+// and 2 in 26 VGPRs, the scalar s of an iteration handed to the four block waves through LDS -- was built and measured
+// on the 100k room, commit bd91ab3: 1to64 forward 0.223 ms against 0.227 ms for the streaming kernels, 1to16 0.142 against
+// 0.083 ms. With nb = 8 a slice yields only two workgroups: 3 126 workgroups of ~47 barrier-coupled iterations are 1.7
+// rounds of the 1 792 resident ones, and an iteration is ~1 us of latency. Dropped; these layers keep conv_f1.hip.)
 // ------------------------------------------------------------------------------------------------ depth-wise backward
 // Transposed plan (rows = neighbour points j). A workgroup takes a group of `spw` consecutive slices and 4 consecutive MLP
 // blocks (wave k: block q0 + k, so the four 32-byte pieces of a gathered out-gradient row are one 128-byte line shared by
@@ -698,10 +599,6 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
 void launch_reduce_partials(const float* partials, int rows, int nb, float* dw1, float* db1, float* dw2, float* db2,
                             float* dw3, float* db3, hipStream_t s);
 int launch_edge_records(const ConvArgs& a, float4* rec, hipStream_t s);
-// conv_f1.hip
-size_t f1_state_bytes(int m, int nb);
-void f1_state_pointers(void* state, int m, int nb, float*& A, float*& S);
-int f1_centres_launch(const ConvArgs& a, const float* A, const float* S, float* out, hipStream_t s);
 int conv_fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
                    const float* pdfs, const float* samples, const int* start_idx, const int* packed,
                    const float* aabb_min, const float* aabb_max, const float* w1, const float* b1, const float* w2,
@@ -842,37 +739,6 @@ int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feat
     else launch_combine<false>(start_idx, m, e, vpos_row, scratch, a.outF, out, z.L, s);
     MCCNN_LAUNCHED();
     return 0;
-}
-
-int mccnn_spatial_conv_fwd_f1_rows(const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
-                                   const float* pdfs, const float* samples, const int* start_idx, const int* packed,
-                                   const float* aabb_min, const float* aabb_max, const float* w1, const float* b1,
-                                   const float* w2, const float* b2, const float* w3, const float* b3, int n, int m, int e,
-                                   int num_out_feats, int batch_size, float radius, int scale_inv, int avg,
-                                   const int* plan_vrow, const int* plan_vcode, const int* slice_off, const int* vpos_row,
-                                   const void* plan_rec, const int* plan_other, float* out, void* centre_state,
-                                   float* scratch, mccnn_stream_t stream) {
-    ConvArgs a;
-    int rc = conv_fill_args(a, sorted_pts, sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min, aabb_max,
-                            w1, b1, w2, b2, w3, b3, n, m, e, 1, num_out_feats, 1, batch_size, radius, scale_inv, avg);
-    if (rc) return rc;
-    if (m == 0) return 0;
-    if (e == 0 || a.nb > MCCNN_LDS_MAX_NB) return MCCNN_E_BADARG;  // empty lists / very wide layers take mccnn_spatial_conv_fwd
-    if (!out || !centre_state || !scratch || !plan_vrow || !plan_vcode || !slice_off || !vpos_row || !plan_rec || !plan_other)
-        return MCCNN_E_BADARG;
-    hipStream_t s = (hipStream_t)stream;
-    const PlanSizes z = plan_sizes(m, e);
-    RowPlan p = {plan_vrow, plan_vcode, slice_off, vpos_row, reinterpret_cast<const float4*>(plan_rec), plan_other, m, z.S};
-    float *A, *S;
-    f1_state_pointers(centre_state, m, a.nb, A, S);
-    const int qTiles = (a.nb + 3) / 4;
-    const long long blocks = ((long long)p.S * qTiles + 7) / 8 * 8;
-    if (blocks > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
-    f1_fwd_rows<<<(int)blocks, 256, 0, s>>>(a, p, A, S, scratch, qTiles);
-    MCCNN_LAUNCHED();
-    f1_rows_combine<<<ceil_div(m, 256), 256, 0, s>>>(start_idx, m, e, vpos_row, scratch, a.nb * 8, A, S, z.L);
-    MCCNN_LAUNCHED();
-    return f1_centres_launch(a, A, S, out, s);
 }
 
 size_t mccnn_spatial_conv_bwd_rows_workspace_bytes(int n, int e, int num_feats) {
