@@ -16,6 +16,7 @@
 // edge, padded with zero records (1/(pdf K) = 0 zeroes every term a padding lane feeds). Loads are perfectly coalesced;
 // padding is ~4 % on the 100k-point room at sigma = 1024 (31 % unsorted).
 #include "conv_mfma.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace mccnn {
@@ -45,7 +46,9 @@ struct RowPlan {
     int numRows, S;
 };
 
+#define MCCNN_PLAN_SMALL 4096  // rows and virtual rows up to here: laid out by ONE workgroup, windows left unsorted
 struct PlanSizes {
+    bool small;       // single-workgroup layout (plan_small)
     int L;            // longest virtual row of this plan
     long long vcap;   // bound on the number of virtual rows
     int windows, S;   // windows of SELL_SIGMA virtual rows, slices of 64
@@ -67,6 +70,12 @@ static PlanSizes plan_sizes(int rows, int e) {
     z.windows = (int)((z.vcap + SELL_SIGMA - 1) / SELL_SIGMA);
     z.S = z.windows * (SELL_SIGMA / 64);
     z.slots = (long long)e + 64LL * z.L * z.windows;
+    // Small lists (the coarse levels of a hierarchy: a few hundred rows) are launch-bound: six launches of layout, 25 us
+    // of it a bitonic sort whose only purpose is less padding. One workgroup does the whole layout for them, in row
+    // order; unsorted, a slice holds at most 64 L slots.
+    static const bool allowSmall = !(getenv("MCCNN_PLAN_SMALL_OFF"));  // A/B switch, read once
+    z.small = allowSmall && rows <= MCCNN_PLAN_SMALL && z.vcap <= MCCNN_PLAN_SMALL;
+    if (z.small) z.slots = (long long)z.L * (z.vcap + 64);
     return z;
 }
 
@@ -94,6 +103,86 @@ __global__ __launch_bounds__(256) void vr_expand(const int* __restrict__ rowStar
     vposRow[r] = v0;
     for (int k = 0; k < vc; ++k) vlistRow[v0 + k] = r;
 }
+// The whole layout of a small list in one workgroup (rows, virtual rows <= MCCNN_PLAN_SMALL): pieces per row, their
+// prefix sum, the virtual rows in row order (no sort), slice lengths and offsets.
+__global__ __launch_bounds__(256) void plan_small(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
+                                                  int L, int S, int* __restrict__ vrow, int* __restrict__ vcode,
+                                                  int* __restrict__ sliceOff, int* __restrict__ vposRow) {
+    __shared__ int vlist[MCCNN_PLAN_SMALL];   // virtual row -> row
+    __shared__ int vfirst[MCCNN_PLAN_SMALL];  // virtual row -> first virtual row of its row
+    __shared__ int lens[MCCNN_PLAN_SMALL + 64];
+    __shared__ int part[256];
+    __shared__ int slen[MCCNN_PLAN_SMALL / 64 + 2];
+    const int t = threadIdx.x;
+    constexpr int PER = MCCNN_PLAN_SMALL / 256;  // 16 consecutive row positions per thread
+    int vc[PER], rr[PER], dg[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int p = t * PER + k;
+        vc[k] = 0; rr[k] = 0; dg[k] = 0;
+        if (p < rows) {
+            int r = order ? order[p] : p;
+            r = max(0, min(r, rows - 1));
+            const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
+            rr[k] = r; dg[k] = deg;
+            vc[k] = max(1, (deg + L - 1) / L);
+        }
+        sum += vc[k];
+    }
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {  // 256 partial sums: serial exclusive scan (tiny)
+        int run = 0;
+        for (int k = 0; k < 256; ++k) { const int v = part[k]; part[k] = run; run += v; }
+    }
+    __syncthreads();
+    int v0 = part[t];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int p = t * PER + k;
+        if (p < rows) {
+            vposRow[rr[k]] = v0;
+            for (int c = 0; c < vc[k]; ++c) {
+                if (v0 + c < MCCNN_PLAN_SMALL) {
+                    vlist[v0 + c] = rr[k];
+                    vfirst[v0 + c] = v0;
+                    lens[v0 + c] = max(0, min(L, dg[k] - c * L)) | (dg[k] > L ? (1 << 30) : 0);
+                }
+            }
+            v0 += vc[k];
+        }
+    }
+    __syncthreads();
+    __shared__ int totalV;
+    if (t == 255) totalV = v0;  // thread 255's running offset after its rows = number of virtual rows
+    __syncthreads();
+    const int Vt = totalV;
+    for (int v = t; v < S * 64; v += 256) {
+        if (v < Vt) {
+            const int l = lens[v];
+            vrow[v] = vlist[v];
+            vcode[v] = (l >> 30) ? v : ~v;
+            lens[v] = l & 0xFFFF;
+        } else {
+            vrow[v] = -1;
+            vcode[v] = -1;
+            if (v < MCCNN_PLAN_SMALL + 64) lens[v] = 0;
+        }
+    }
+    __syncthreads();
+    for (int sl = t; sl < S; sl += 256) {
+        int mx = 0;
+        for (int k = 0; k < 64; ++k) mx = max(mx, lens[min(sl * 64 + k, MCCNN_PLAN_SMALL + 63)]);
+        slen[sl] = mx * 64;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int sl = 0; sl < S; ++sl) { sliceOff[sl] = run; run += slen[sl]; }
+        sliceOff[S] = run;
+    }
+}
+
 // One workgroup per window of SELL_SIGMA virtual rows: bitonic sort of unique keys (descending length, then position) ->
 // the layout is a deterministic function of the list, so gradients are bit-reproducible run to run.
 __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStart, int rows, int e,
@@ -649,6 +738,11 @@ int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order
     if (!ws || ws_bytes < mccnn_rowplan_workspace_bytes(rows, e)) return MCCNN_E_WORKSPACE;
     const PlanSizes z = plan_sizes(rows, e);
     if (z.slots > 0x7fffffffLL || z.vcap > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
+    if (z.small) {
+        plan_small<<<1, 256, 0, s>>>(row_start, rows, e, order, z.L, z.S, plan_vrow, plan_vcode, slice_off, vpos_row);
+        MCCNN_LAUNCHED();
+        return 0;
+    }
     Arena ar(ws, ws_bytes);
     int* vcnt = ar.take<int>((size_t)rows + 1);
     int* vposP = ar.take<int>((size_t)rows + 1);

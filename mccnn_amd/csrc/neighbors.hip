@@ -143,12 +143,12 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                 const int cl = __builtin_ctz(mem);
                 mem &= mem - 1;
                 const int cbase = __builtin_amdgcn_readlane(base, cl), cid = __builtin_amdgcn_readlane(i, cl);
-                const unsigned long long* mrow = masks + (size_t)(g0 + cl);  // plane r at mrow + r * m (see the count pass)
+                const unsigned long long* mrow = masks + (size_t)(__builtin_amdgcn_readfirstlane(g0) + cl) * MCCNN_NW_ROUNDS;  // by visiting position (see the count pass); scalar address
                 int run = 0;
 #pragma unroll
                 for (int r = 0; r < MCCNN_NW_ROUNDS; ++r) {
                     if (r * 64 < total) {
-                        const unsigned long long bm = mrow[(size_t)r * m];  // wave-uniform address
+                        const unsigned long long bm = mrow[r];  // wave-uniform address
                         if ((bm >> lane) & 1ull) {
                             const int pos = cbase + run + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
                             if (pos < capacity) out[pos] = make_int2(jr[r], cid);  // capacity < E: see _fill
@@ -191,10 +191,11 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                     }
                     if (!FILL) {
                         const int round = (seg + r) >> 6;
-                        // one PLANE of m words per round, indexed by the centre's position in the visiting order: the 8
-                        // centres of a wave write 64 contiguous bytes per round (indexed by centre id and round they were
-                        // 8-byte pieces of 8 different 64-byte rows: a sector written per word)
-                        if (round < MCCNN_NW_ROUNDS && lane == 0) masks[(size_t)round * m + (g0 + cl)] = bm;
+                        // indexed by the centre's POSITION in the visiting order, not by its id: the 8 centres of a wave own
+                        // 512 contiguous bytes (4 lines) in both passes; by id they were 8 scattered 64-byte rows. (One plane
+                        // of m words per round cut the counter traffic further, 90.8 -> 78.1 MB on the room, but made the
+                        // fill read a line per round and centre: 36.7 instead of 27.1 us.)
+                        if (round < MCCNN_NW_ROUNDS && lane == 0) masks[(size_t)(__builtin_amdgcn_readfirstlane(g0) + cl) * MCCNN_NW_ROUNDS + round] = bm;
                     }
                     ccount += __builtin_popcountll(bm);
                 }
