@@ -8,7 +8,7 @@ std::atomic<long long> g_launches{0};
 extern "C" {
 
 int mccnn_block_size(void) { return MCCNN_MLP; }
-int mccnn_abi_version(void) { return 4; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn
+int mccnn_abi_version(void) { return 5; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn; 5: row plans, aabb_extent
 const char* mccnn_arch(void) { return "gfx950"; }
 long long mccnn_debug_launch_count(void) { return mccnn::g_launches.load(std::memory_order_relaxed); }
 
