@@ -396,12 +396,12 @@ __global__ __launch_bounds__(256) void pdf_rows_mfma(const float* __restrict__ p
                                                      int m, int e, const float* __restrict__ mn,
                                                      const float* __restrict__ mx, int B, float window, float radius,
                                                      int scaleInv, float* __restrict__ pdfs,
-                                                     const int* __restrict__ eDev) {
+                                                     const int* __restrict__ eDev, int rowsPerWave) {
     __shared__ __attribute__((aligned(16))) float planes[4][5 * MCCNN_PDF_CAP];  // per wave: ux, uy, uz, q, ones
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform: rows, tile counts and loops live in SGPRs
-    const int r0 = (blockIdx.x * 4 + wave) * MCCNN_PDF_ROWS;
+    const int r0 = (blockIdx.x * 4 + wave) * rowsPerWave;
     if (r0 >= m) return;
-    const int nr = min(MCCNN_PDF_ROWS, m - r0);
+    const int nr = min(rowsPerWave, m - r0);
     const int cap = e;
     if (eDev) e = min(e, max(*eDev, 0));
     // row bounds of this wave's rows in lanes 0..nr (a capacity below the true total cuts rows: the caller repeats)
@@ -638,9 +638,11 @@ static int compute_pdf_impl(const float* sorted_pts, const int* sorted_batch_ids
             MCCNN_LAUNCHED();
             pdf_rows<<<ceil_div(m, 4), 256, 0, s>>>(sc, start_idx, m, e, window, pdfs, e_dev);
         } else {
-            pdf_rows_mfma<<<ceil_div(m, 4 * MCCNN_PDF_ROWS), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, start_idx, m, e,
-                                                                         aabb_min, aabb_max, batch_size, window, radius,
-                                                                         scale_inv, pdfs, e_dev);
+            // rows per wave: 4 consecutive rows let the next row's points fly under this row's tiles, but a list with few
+            // (long) rows needs the waves -- 279 centres of 141 neighbours (BASELINE cfg1 Conv_2) ran 123 us on 70 waves
+            const int rpw = (m >= 16384) ? MCCNN_PDF_ROWS : 1;
+            pdf_rows_mfma<<<ceil_div(m, 4 * rpw), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, start_idx, m, e, aabb_min, aabb_max,
+                                                              batch_size, window, radius, scale_inv, pdfs, e_dev, rpw);
         }
     }
     MCCNN_LAUNCHED();
