@@ -11,6 +11,20 @@
 
 namespace mccnn {
 
+// Selection flags cross workgroups -- and XCDs, whose L2s are not coherent with each other -- inside ONE launch of the
+// dataflow form. A release / acquire FENCE at agent scope would do, but on gfx950 it is a write-back / invalidate of the
+// XCD's whole L2 (buffer_wbl2 / buffer_inv), once per cell: 100 k of them made the finest level of BASELINE cfg3 take
+// 1.5 ms, every other load of the launch missing the invalidated cache. Instead the flag BYTES themselves are written
+// and read with agent-scope atomics (they go to the coherent level and nothing else is touched), the writer waits for
+// their acknowledgement (s_waitcnt vmcnt(0)) before it publishes its `done` word.
+__device__ __forceinline__ bool sel_load(const unsigned char* sel, int j) {
+    return __hip_atomic_load(sel + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+__device__ __forceinline__ void sel_store(unsigned char* sel, int i) {
+    __hip_atomic_store(sel + i, (unsigned char)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
 struct PoissonDims {
     int nc, G, nB, D;  // cells/axis, phase groups/axis, 4-wide blocks/axis, nB*4
 };
@@ -63,7 +77,7 @@ __device__ __forceinline__ int poisson_cell_regs(const float* __restrict__ pts, 
         cx[rd] = valid ? pts[(size_t)j * 3] : 0.f;
         cy[rd] = valid ? pts[(size_t)j * 3 + 1] : 0.f;
         cz[rd] = valid ? pts[(size_t)j * 3 + 2] : 0.f;
-        cs[rd] = valid ? (sel[j] != 0) : false;
+        cs[rd] = valid ? sel_load(sel, j) : false;
     }
     // the cell's own points are candidates too (offset (0,0,0) is entry 17 of the table): their coordinates come from
     // the register copies with v_readlane instead of n dependent global loads
@@ -85,7 +99,7 @@ __device__ __forceinline__ int poisson_cell_regs(const float* __restrict__ pts, 
 #pragma unroll
         for (int rd = 0; rd < NR; ++rd) coll |= cs[rd] && (point_dist2(cx[rd], cy[rd], cz[rd], px, py, pz) < T);
         if (!__any(coll)) {
-            if (lane == 0) sel[i] = 1;
+            if (lane == 0) sel_store(sel, i);
             ++kept;
 #pragma unroll
             for (int rd = 0; rd < NR; ++rd)
@@ -132,7 +146,7 @@ __device__ __forceinline__ int poisson_cell_lanes(const float* __restrict__ pts,
     // the earlier-phase cells sits between the two, so that only the flag bytes are loaded after it
     if (!wait()) return -1;
 #pragma unroll
-    for (int rd = 0; rd < NR; ++rd) cs[rd] = (cj[rd] >= 0) ? (sel[cj[rd]] != 0) : false;
+    for (int rd = 0; rd < NR; ++rd) cs[rd] = (cj[rd] >= 0) ? sel_load(sel, cj[rd]) : false;
     bool rej = !own;
 #pragma unroll
     for (int rd = 0; rd < NR; ++rd) {
@@ -150,7 +164,7 @@ __device__ __forceinline__ int poisson_cell_lanes(const float* __restrict__ pts,
     for (int i = 0; i < k; ++i) {
         const unsigned long long rm = __ballot(rej);
         if (!((rm >> i) & 1ull)) {
-            if (lane == 0) sel[me.x + i] = 1;
+            if (lane == 0) sel_store(sel, me.x + i);
             ++kept;
             const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ox), i));
             const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oy), i));
@@ -174,6 +188,9 @@ __device__ __forceinline__ int pool_phase_of(int ox, int oy, int oz) {
 // One cell of one colour phase, one wave. `done` != nullptr is the dataflow form (poisson_dataflow below): the wave
 // first waits until the non-empty cells of its window that belong to EARLIER phases have published their selections.
 #define MCCNN_PS_SPIN_LIMIT (1 << 16)
+#ifndef MCCNN_PS_SLEEP
+#define MCCNN_PS_SLEEP 8
+#endif
 __device__ __forceinline__ void poisson_cell(const float* __restrict__ pts, const int* __restrict__ cells,
                                              const float* __restrict__ mn, const float* __restrict__ mx,
                                              const PoissonDims& d, int b, int gx, int gy, int gz, int ph, float radius,
@@ -217,14 +234,14 @@ __device__ __forceinline__ void poisson_cell(const float* __restrict__ pts, cons
             int spins = 0;
             while (__hip_atomic_load(done + waitIdx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                 if (++spins > spinLimit) { waitFailed = true; break; }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(MCCNN_PS_SLEEP);
             }
         }
         if (__any(waitFailed)) {
             if (lane == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the neighbours' sel[] bytes are visible from here on
+        // (no acquire fence: the neighbours' sel[] bytes are read with agent-scope atomic loads, see sel_load)
         return true;
     };
     const int incl = wave_incl_scan(cnt);
@@ -247,7 +264,6 @@ __device__ __forceinline__ void poisson_cell(const float* __restrict__ pts, cons
         kept = -1;
     } else {
         // dense window: stream the candidates for every point; selections of this cell are read back through memory
-        volatile unsigned char* vsel = sel;
         for (int i = me.x; i < me.y; ++i) {
             const float px = pts[(size_t)i * 3], py = pts[(size_t)i * 3 + 1], pz = pts[(size_t)i * 3 + 2];
             bool coll = false;
@@ -261,12 +277,12 @@ __device__ __forceinline__ void poisson_cell(const float* __restrict__ pts, cons
                     if (tt < 27 && e <= c) sidx = tt;
                 }
                 const int j = __shfl(r0, sidx, 64) + (c - __shfl(excl, sidx, 64));
-                if (c < total && vsel[j])
+                if (c < total && sel_load(sel, j))
                     coll |= point_dist2(pts[(size_t)j * 3], pts[(size_t)j * 3 + 1], pts[(size_t)j * 3 + 2], px, py, pz) < T;
             }
             if (!__any(coll)) {
-                if (lane == 0) vsel[i] = 1;
-                __threadfence_block();
+                if (lane == 0) sel_store(sel, i);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the cell's own later points read it back
                 ++kept;
             }
         }
@@ -274,7 +290,7 @@ __device__ __forceinline__ void poisson_cell(const float* __restrict__ pts, cons
     if (kept < 0) return;  // abandoned: a wait timed out (dataflow form only)
     if (lane == 0) slotCount[poisson_slot(d, b, ph, gx, gy, gz)] = kept;
     if (done) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // sel[] of this cell before its flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the cell's sel[] stores are acknowledged before its flag goes out
         if (lane == 0)
             __hip_atomic_store(done + cellBase + (size_t)xC * nc * nc + (size_t)yC * nc + zC, 1, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -317,6 +333,58 @@ __global__ __launch_bounds__(256) void poisson_dataflow(const float* __restrict_
     const int r = (int)(t - (long long)b * perBatch);
     poisson_cell(pts, cells, mn, mx, d, b, r % d.G, (r / d.G) % d.G, r / (d.G * d.G), ph, radius, scaleInv, sel, slotCount,
                  done, fail, spinLimit, lane);
+}
+
+// The dataflow form over the OCCUPIED cells only. A fine grid is mostly empty (BASELINE cfg3, level 1: 131 k points in
+// 1.02 M cells -- 1.18 M waves of which 8 % have work, 1.77 ms): poisson_compact lists the non-empty cells per colour
+// phase (27 lists of capacity perPhase, filled with one atomic per occupied cell; the order inside a phase is free --
+// a cell only ever waits for EARLIER phases), and the waves of this launch walk the lists phase-major. Same samples,
+// same order (slots are canonical).
+__global__ __launch_bounds__(256) void poisson_compact(const int* __restrict__ cells, int B, PoissonDims d, long long perPhase,
+                                                       int* __restrict__ cnt, int* __restrict__ list) {
+    // ranks inside the workgroup through LDS counters, ONE global atomic per (workgroup, phase): an atomic per occupied
+    // cell onto 27 addresses serialises (259 us for 131 k cells)
+    __shared__ int lcnt[27], lbase[27];
+    if (threadIdx.x < 27) lcnt[threadIdx.x] = 0;
+    __syncthreads();
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nc = d.nc;
+    const long long perBatch = (long long)nc * nc * nc;
+    int ph = -1, rank = 0;
+    if (t < perBatch * B) {
+        const int2 me = reinterpret_cast<const int2*>(cells)[t];
+        if (me.y > me.x) {
+            const int r = (int)(t % perBatch);
+            const int z = r % nc, y = (r / nc) % nc, x = r / (nc * nc);
+            ph = pool_phase_of(x % 3 - 1, y % 3 - 1, z % 3 - 1);
+            rank = atomicAdd(&lcnt[ph], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) lbase[threadIdx.x] = lcnt[threadIdx.x] ? atomicAdd(&cnt[threadIdx.x], lcnt[threadIdx.x]) : 0;
+    __syncthreads();
+    if (ph >= 0) list[(size_t)ph * perPhase + lbase[ph] + rank] = (int)t;
+}
+__global__ __launch_bounds__(256) void poisson_dataflow_c(const float* __restrict__ pts, const int* __restrict__ cells,
+                                                          const float* __restrict__ mn, const float* __restrict__ mx,
+                                                          int B, PoissonDims d, long long perPhase, const int* __restrict__ cnt,
+                                                          const int* __restrict__ list, float radius, int scaleInv,
+                                                          unsigned char* sel, int* __restrict__ slotCount, int* done,
+                                                          int* fail, int spinLimit) {
+    const int lane = threadIdx.x & 63;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = (lane < 27) ? cnt[lane] : 0;
+    const int incl = wave_incl_scan(c);
+    if (w >= __shfl(incl, 26, 64)) return;
+    const unsigned long long later = __ballot(lane < 27 && incl > w);  // phases whose cumulative count passes w
+    const int ph = (int)__builtin_ctzll(later);
+    const int idx = (int)(w - (__shfl(incl, ph, 64) - __shfl(c, ph, 64)));
+    const int t = list[(size_t)ph * perPhase + idx];
+    const int nc = d.nc;
+    const int perBatch = nc * nc * nc;
+    const int b = t / perBatch, r = t - b * perBatch;
+    const int z = r % nc, y = (r / nc) % nc, x = r / (nc * nc);
+    poisson_cell(pts, cells, mn, mx, d, b, x / 3, y / 3, z / 3, ph, radius, scaleInv, sel, slotCount, done, fail, spinLimit, lane);
 }
 
 __global__ void poisson_flag_failure(const int* __restrict__ fail, int* __restrict__ total) {
@@ -368,8 +436,11 @@ size_t mccnn_poisson_sampling_workspace_bytes(int n, int batch_size, int num_cel
     long long S = poisson_slots(batch_size, num_cells);
     if (S >= 0x7fffffffLL) return 0;
     size_t C = (size_t)batch_size * num_cells * num_cells * num_cells;
+    const PoissonDims d = poisson_dims(num_cells);
+    const size_t perPhase = (size_t)batch_size * d.G * d.G * d.G;
     return align_up((size_t)(n > 0 ? n : 1)) + align_up((size_t)S * 4) + scan_workspace_bytes((int)S) +
-           align_up((C + 1) * sizeof(int)) + 256;  // + per-cell done flags and the failure flag of the dataflow form
+           align_up((C + 1 + 32) * sizeof(int)) + align_up(27 * perPhase * sizeof(int)) +
+           256;  // + per-cell done flags, the failure flag, the phase counters and the occupied-cell lists of the dataflow form
 }
 
 int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batch_ids, int n, const int* cell_indexs,
@@ -393,21 +464,28 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
     const size_t slotBytes = align_up((size_t)S * 4);
     char* blk = a.take<char>(slotBytes + scan_workspace_bytes((int)S));
     const size_t C = (size_t)batch_size * num_cells * num_cells * num_cells;
-    int* flags = a.take<int>(C + 1);  // done[C], fail
-    if (!sel || !blk || !flags) return MCCNN_E_WORKSPACE;
+    int* flags = a.take<int>(C + 1 + 32);  // done[C], fail, cnt[27]
+    PoissonDims d = poisson_dims(num_cells);
+    const long long perPhase = (long long)batch_size * d.G * d.G * d.G;
+    int* plist = a.take<int>((size_t)27 * perPhase);
+    if (!sel || !blk || !flags || !plist) return MCCNN_E_WORKSPACE;
     int* slots = (int*)blk;
     void* scanws = blk + slotBytes;
     MCCNN_MEMSET(hipMemsetAsync(sel, 0, (size_t)n, s));
     MCCNN_MEMSET(hipMemsetAsync(blk, 0, slotBytes + scan_status_bytes((int)S), s));
-    PoissonDims d = poisson_dims(num_cells);
-    long long threads = (long long)batch_size * d.G * d.G * d.G;
+    long long threads = perPhase;
     if (mode == 1 || mode == 2) {
         // mode 2 (tests only): no spinning at all -- the first cell whose predecessor has not finished raises the
         // failure flag, which exercises the caller's fallback to the phased form
         const int spinLimit = mode == 1 ? MCCNN_PS_SPIN_LIMIT : 0;
-        MCCNN_MEMSET(hipMemsetAsync(flags, 0, (C + 1) * sizeof(int), s));
-        poisson_dataflow<<<ceil_div(threads * 27, 4), 256, 0, s>>>(sorted_pts, cell_indexs, aabb_min, aabb_max, batch_size, d,
-                                                                  radius, scale_inv, sel, slots, flags, flags + C, spinLimit);
+        MCCNN_MEMSET(hipMemsetAsync(flags, 0, (C + 1 + 32) * sizeof(int), s));
+        int* cnt = flags + C + 1;
+        poisson_compact<<<ceil_div((long long)C, 256), 256, 0, s>>>(cell_indexs, batch_size, d, perPhase, cnt, plist);
+        MCCNN_LAUNCHED();
+        // one wave per occupied cell: at most min(n, C) of them (the surplus waves return on their first load)
+        const long long waves = (long long)n < (long long)C ? (long long)n : (long long)C;
+        poisson_dataflow_c<<<ceil_div(waves, 4), 256, 0, s>>>(sorted_pts, cell_indexs, aabb_min, aabb_max, batch_size, d, perPhase,
+                                                             cnt, plist, radius, scale_inv, sel, slots, flags, flags + C, spinLimit);
         MCCNN_LAUNCHED();
         int rc = exclusive_scan_i32(slots, slots, (int)S, total_dev, scanws, s, true);
         if (rc) return rc;
