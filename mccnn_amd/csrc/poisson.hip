@@ -317,25 +317,7 @@ __global__ __launch_bounds__(256) void poisson_phase_wave(const float* __restric
 // non-empty earlier-phase cells of its window, processes its points, publishes its own flag. Independent regions of the
 // cloud run ahead of each other instead of meeting at 27 grid-wide barriers; the critical path is the longest chain of
 // dependent cells (<= 27), not 27 launches. Same samples, same order as the phased form.
-__global__ __launch_bounds__(256) void poisson_dataflow(const float* __restrict__ pts, const int* __restrict__ cells,
-                                                        const float* __restrict__ mn, const float* __restrict__ mx,
-                                                        int B, PoissonDims d, float radius, int scaleInv,
-                                                        unsigned char* sel, int* __restrict__ slotCount, int* done,
-                                                        int* fail, int spinLimit) {
-    const int lane = threadIdx.x & 63;
-    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long perPhase = (long long)d.G * d.G * d.G * B;
-    if (w >= perPhase * 27) return;
-    const int ph = (int)(w / perPhase);
-    const long long t = w - (long long)ph * perPhase;
-    const long long perBatch = (long long)d.G * d.G * d.G;
-    const int b = (int)(t / perBatch);
-    const int r = (int)(t - (long long)b * perBatch);
-    poisson_cell(pts, cells, mn, mx, d, b, r % d.G, (r / d.G) % d.G, r / (d.G * d.G), ph, radius, scaleInv, sel, slotCount,
-                 done, fail, spinLimit, lane);
-}
-
-// The dataflow form over the OCCUPIED cells only. A fine grid is mostly empty (BASELINE cfg3, level 1: 131 k points in
+// The launch runs over the OCCUPIED cells only. A fine grid is mostly empty (BASELINE cfg3, level 1: 131 k points in
 // 1.02 M cells -- 1.18 M waves of which 8 % have work, 1.77 ms): poisson_compact lists the non-empty cells per colour
 // phase (27 lists of capacity perPhase, filled with one atomic per occupied cell; the order inside a phase is free --
 // a cell only ever waits for EARLIER phases), and the waves of this launch walk the lists phase-major. Same samples,
