@@ -255,7 +255,7 @@ class Workload:
                      ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3))
         gws = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]
         rows_fwd = M._rows_shape(combin, fin, sF, m, e)
-        rows_bwd = M._rows_shape(combin, fin, sF, n, e)
+        rows_bwd = M._rows_shape(combin, fin, sF, n, e, backward=True)
         start_t = perm_t = None
         t_tr = None
         if not combin:  # the transposed neighbour list of depth-wise layers: built once per neighbour list, timed on its own

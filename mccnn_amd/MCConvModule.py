@@ -270,6 +270,9 @@ def _transposed_neighbors(packed, n):
 #: depth-wise layers (numFeatures % 8 == 0) run the row-per-lane kernels over SELL layouts of the neighbour list
 #: (conv_rows.hip); False = the edge-streaming kernels of conv.hip for every layer
 ROW_KERNELS = os.environ.get("MCCNN_ROW_KERNELS", "1") != "0"
+ROWS_MIN_DEGREE = float(os.environ.get("MCCNN_ROWS_MIN_DEGREE", "16"))
+
+
 class RowPlan:
     """SELL-64 layout of a neighbour list (include/mccnn.h, mccnn_rowplan_*): device tensors; every size is fixed by
     (rows, e), so building a plan involves no host read-back."""
@@ -363,15 +366,18 @@ def prefetch_rowplan(packed, transposed, stream, *args):
                 rec_e[1].record_stream(main)
 
 
-def _rows_shape(combin, fin, feats, rows, e):
-    """Row-per-lane kernels for this (layer, list)? Depth-wise rows of 8-feature blocks, and not a LARGE list of very
-    SHORT rows (centres in the forward pass, points in the backward pass): below ~16 edges per row the per-slice set-up
-    and the padding of the sorted windows outweigh the cheaper inner loop (measured on BASELINE cfg3: DeConv_1, 8.7
-    edges per row, 0.55 against 0.43 ms). Long rows are fine: the plan cuts them into pieces of 128 edges."""
+def _rows_shape(combin, fin, feats, rows, e, backward=False):
+    """Row-per-lane kernels for this (layer, list)? Depth-wise rows of 8-feature blocks. Forward: always (long rows are cut
+    into pieces, lists of short rows put several slices into a workgroup). Backward: not on a LARGE list of very SHORT
+    rows -- below ~16 edges per point the 176-sum sweep pays its per-slice set-up and the padding of the sorted windows
+    too often, and the edge-streaming kernels, whose waves own equal edge ranges, are faster (measured on BASELINE cfg3:
+    DeConv_1, 131 k points x 8.7 edges, 0.54 against 0.42 ms; Pool_2, 41 k x 10.2, 0.19 against 0.27 ms the other way)."""
     if not (ROW_KERNELS and _DEBUG_IMPL == 0 and (not combin) and fin % 8 == 0 and e > 0 and rows > 0
             and (feats.data_ptr() & 15) == 0):
         return False
-    return e / float(rows) >= 16.0 or e <= 100000
+    if not backward:
+        return True
+    return e / float(rows) >= ROWS_MIN_DEGREE or e <= 500000
 
 
 def clear_caches():
@@ -1076,7 +1082,7 @@ class _SpatialConv(torch.autograd.Function):
         packed_obj = ctx.packed_ref()
         if packed_obj is None:  # the list object is gone (its cache entry was dropped): the saved tensor has the same rows
             packed_obj = pk
-        if _rows_shape(combin, fin, feats, n, e) and m > 0 and (og.data_ptr() & 15) == 0:
+        if _rows_shape(combin, fin, feats, n, e, backward=True) and m > 0 and (og.data_ptr() & 15) == 0:
             # depth-wise layer: ONE sweep over the transposed row plan finishes the feature gradient and the six
             # parameter gradients (the edge-major kernels evaluate the kernel MLP twice for that)
             plan = _row_plan(packed_obj, True, pts, bids, pdfs, smp, st, pk, mn, mx, n, m, e, batchSize, radius, scaleInv, avg)

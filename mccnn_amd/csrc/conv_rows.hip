@@ -411,70 +411,71 @@ __device__ __forceinline__ void stage_read(const RowStage& st, int b, int wave, 
 // windows of descending row length: fine-grained items, no tail. FEAT: 2 = f32 rows, 4 = bf16 rows.
 template <int FEAT>
 __global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float* __restrict__ out, float* __restrict__ scratch,
-                                                   int qTiles) {
+                                                   int qTiles, int spw, int groups) {
     __shared__ float stageMem[MCCNN_STAGE_FLOATS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i4 = lane & 3;
     constexpr bool BF = FEAT == 4;
     unsigned short* out16 = reinterpret_cast<unsigned short*>(out);
-    // Workgroup -> (block tile, slice), tile-major, every XCD a contiguous range: the workgroups resident on one XCD
-    // work on ONE 128-byte column of the feature rows for neighbouring slices, whose reuse of the lines its L2 serves.
+    // Workgroup -> (block tile, group of spw consecutive slices), tile-major, every XCD a contiguous range: the
+    // workgroups resident on one XCD work on ONE 128-byte column of the feature rows for neighbouring slices, whose
+    // reuse of the lines its L2 serves. spw > 1 on lists of short rows: a slice of 9-edge rows is nine iterations, the
+    // weight loads and the prologue of a workgroup want more than that to pay for.
     const int L = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int total = p.S * qTiles;
-    if (L >= total) return;
-    const int qt = L / p.S, slice = L - qt * p.S;
+    if (L >= groups * qTiles) return;
+    const int qt = L / groups, g = L - qt * groups;
     const int q = qt * 4 + wave;
     const bool mine = q < a.nb;  // a wave beyond the last block still gathers and meets the barriers
     const RowStage st = {reinterpret_cast<f32x4*>(stageMem)};
     BlockWeights w;
     load_block_weights(a, mine ? q : 0, i4, w);
-    const int off = p.sliceOff[slice];
-    const int len = (p.sliceOff[slice + 1] - off) >> 6;
-    if (len == 0) return;  // slices beyond the list's last virtual row (the layout is sized by a bound)
-    const int r = p.vrow[slice * 64 + lane];
     const int prow = wave * 16 + (lane & 15);  // the row of the slice this lane fetches as a producer
-    float acc[8];
+    const int sEnd = min((g + 1) * spw, p.S);
+    for (int slice = g * spw; slice < sEnd; ++slice) {
+        const int off = p.sliceOff[slice];
+        const int len = (p.sliceOff[slice + 1] - off) >> 6;
+        if (len == 0) continue;  // slices beyond the list's last virtual row (the layout is sized by a bound)
+        const int r = p.vrow[slice * 64 + lane];
+        float acc[8];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) acc[n] = 0.f;
-    float4 rcN = make_float4(0.f, 0.f, 0.f, 0.f);
-    int jP = 0;  // producer: neighbour index of row `prow`, two iterations ahead of the consumer
-    f32x4 s0, s1;
-    if (len > 0) {
-        rcN = p.rec[(size_t)off + lane];
+        for (int n = 0; n < 8; ++n) acc[n] = 0.f;
+        float4 rcN = p.rec[(size_t)off + lane];
+        int jP = 0;  // producer: neighbour index of row `prow`, two iterations ahead of the consumer
+        f32x4 s0, s1;
         stage_load<BF>(a.feats, p.other[(size_t)off + prow], a.Fin, qt * 32, lane, s0, s1);
         if (len > 1) jP = p.other[(size_t)off + 64 + prow];
         stage_store<BF>(st, 0, wave, lane, s0, s1);
-    }
-    __syncthreads();
-    for (int it = 0; it < len; ++it) {
-        const float4 rc = rcN;
-        const bool more = it + 1 < len;
-        if (more) {  // iteration it + 1: its lines are requested now and parked after this iteration's arithmetic
-            stage_load<BF>(a.feats, jP, a.Fin, qt * 32, lane, s0, s1);
-            rcN = p.rec[(size_t)off + (size_t)(it + 1) * 64 + lane];
-            if (it + 2 < len) jP = p.other[(size_t)off + (size_t)(it + 2) * 64 + prow];
-        }
-        float f[8];
-        stage_read<BF>(st, it & 1, wave, lane, f);
-        float a1[8], a2[8], o[8];
-        MCCNN_PHASE();
-        mlp_block_regs(w, rc.x, rc.y, rc.z, a1, a2, o);
-#pragma unroll
-        for (int n = 0; n < 8; ++n) acc[n] = __builtin_fmaf(f[n] * rc.w, o[n], acc[n]);
-        if (more) stage_store<BF>(st, (it + 1) & 1, wave, lane, s0, s1);
         __syncthreads();
-    }
-    if (r >= 0 && mine) {
-        const int code = p.vcode[slice * 64 + lane];
-        if (code >= 0) {  // a piece of a cut row: its partial sums wait in the scratch row for rows_combine
-            float4* dst = reinterpret_cast<float4*>(scratch + (size_t)code * a.outF + q * 8);
-            dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        } else if (BF) {
-            reinterpret_cast<uint4*>(out16 + (size_t)r * a.outF)[q] = f32x8_to_bf16(acc);
-        } else {
-            float4* dst = reinterpret_cast<float4*>(out + (size_t)r * a.outF + q * 8);
-            dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        for (int it = 0; it < len; ++it) {
+            const float4 rc = rcN;
+            const bool more = it + 1 < len;
+            if (more) {  // iteration it + 1: its lines are requested now and parked after this iteration's arithmetic
+                stage_load<BF>(a.feats, jP, a.Fin, qt * 32, lane, s0, s1);
+                rcN = p.rec[(size_t)off + (size_t)(it + 1) * 64 + lane];
+                if (it + 2 < len) jP = p.other[(size_t)off + (size_t)(it + 2) * 64 + prow];
+            }
+            float f[8];
+            stage_read<BF>(st, it & 1, wave, lane, f);
+            float a1[8], a2[8], o[8];
+            MCCNN_PHASE();
+            mlp_block_regs(w, rc.x, rc.y, rc.z, a1, a2, o);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) acc[n] = __builtin_fmaf(f[n] * rc.w, o[n], acc[n]);
+            if (more) stage_store<BF>(st, (it + 1) & 1, wave, lane, s0, s1);
+            __syncthreads();  // also orders the next slice's first store behind this slice's last read
+        }
+        if (r >= 0 && mine) {
+            const int code = p.vcode[slice * 64 + lane];
+            if (code >= 0) {  // a piece of a cut row: its partial sums wait in the scratch row for rows_combine
+                float4* dst = reinterpret_cast<float4*>(scratch + (size_t)code * a.outF + q * 8);
+                dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            } else if (BF) {
+                reinterpret_cast<uint4*>(out16 + (size_t)r * a.outF)[q] = f32x8_to_bf16(acc);
+            } else {
+                float4* dst = reinterpret_cast<float4*>(out + (size_t)r * a.outF + q * 8);
+                dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            }
         }
     }
 }
@@ -694,12 +695,23 @@ int conv_fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_fea
                    const float* b2, const float* w3, const float* b3, int n, int m, int e, int Fin, int Fout, int combin,
                    int batch_size, float radius, int scale_inv, int avg);
 
-static int bwd_rows_spw(int S, int nb) {
+static int bwd_rows_spw(int S, int nb, int rows, int e) {
     // workgroups are dispatched as slots free up: >= ~12 rounds of the 2048 resident waves keep the tail below one
-    // workgroup in twelve, while every extra slice per wave amortises the 176-value reduction at its end
+    // workgroup in twelve, while every extra slice per wave amortises the 176-value reduction at its end -- and on
+    // lists of short rows (a slice of 9-edge rows is nine iterations) the set-up of a workgroup
     long long spw = ((long long)S * nb) / 24576;
+    const long long avg = rows > 0 ? (e / rows > 0 ? e / rows : 1) : 1;
     if (spw > 8) spw = 8;
+    if (spw * avg < 48 && (long long)S * nb >= 16384) spw = (48 + avg - 1) / avg;  // only when the list fills the chip anyway
+    if (spw > 16) spw = 16;
     if (spw < 1) spw = 1;
+    return (int)spw;
+}
+static int fwd_rows_spw(int S, int nb, int rows, int e) {
+    const long long avg = rows > 0 ? (e / rows > 0 ? e / rows : 1) : 1;
+    long long spw = 1;
+    if (avg < 32 && (long long)S * nb >= 16384) spw = (32 + avg - 1) / avg;
+    if (spw > 8) spw = 8;
     return (int)spw;
 }
 
@@ -824,10 +836,12 @@ int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feat
     const PlanSizes z = plan_sizes(m, e);
     RowPlan p = {plan_vrow, plan_vcode, slice_off, vpos_row, reinterpret_cast<const float4*>(plan_rec), plan_other, m, z.S};
     const int qTiles = (a.nb + 3) / 4;
-    const long long blocks = ((long long)p.S * qTiles + 7) / 8 * 8;
+    const int spw = fwd_rows_spw(p.S, a.nb, m, e);
+    const int groups = (p.S + spw - 1) / spw;
+    const long long blocks = ((long long)groups * qTiles + 7) / 8 * 8;
     if (blocks > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
-    if (bf16) dw_fwd_rows<4><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, scratch, qTiles);
-    else dw_fwd_rows<2><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, scratch, qTiles);
+    if (bf16) dw_fwd_rows<4><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, scratch, qTiles, spw, groups);
+    else dw_fwd_rows<2><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, scratch, qTiles, spw, groups);
     MCCNN_LAUNCHED();
     if (bf16) launch_combine<true>(start_idx, m, e, vpos_row, scratch, a.outF, out, z.L, s);
     else launch_combine<false>(start_idx, m, e, vpos_row, scratch, a.outF, out, z.L, s);
@@ -839,7 +853,7 @@ size_t mccnn_spatial_conv_bwd_rows_workspace_bytes(int n, int e, int num_feats) 
     if (n <= 0 || num_feats <= 0) return 256;
     const PlanSizes z = plan_sizes(n, e);
     const int nb = (num_feats + 7) / 8;
-    const int spw = bwd_rows_spw(z.S, nb);
+    const int spw = bwd_rows_spw(z.S, nb, n, e);
     const long long groups = (z.S + spw - 1) / spw;
     return align_up((size_t)groups * nb * 176 * sizeof(float)) + 256;
 }
@@ -867,7 +881,7 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
     hipStream_t s = (hipStream_t)stream;
     const PlanSizes z = plan_sizes(n, e);
     RowPlan p = {plan_vrow, plan_vcode, slice_off, vpos_row, reinterpret_cast<const float4*>(plan_rec), plan_other, n, z.S};
-    const int spw = bwd_rows_spw(p.S, a.nb);
+    const int spw = bwd_rows_spw(p.S, a.nb, n, e);
     const int groups = (p.S + spw - 1) / spw;
     const int qTiles = (a.nb + 3) / 4;
     const long long blocks = ((long long)groups * qTiles + 7) / 8 * 8;
