@@ -281,8 +281,8 @@ class Workload:
                 pf, _ = plan_of(False)
                 scr = torch.empty((pf.scratch_rows, outF), dtype=torch.float32, device=device)
                 tf, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_fwd_rows(
-                    conv_args[0], ptr(feats_t), *conv_args[2:], n, m, e, fin, B, r, 0, 1, bf, ptr(pf.vrow), ptr(pf.vcode),
-                    ptr(pf.slice_off), ptr(pf.vpos_row), ptr(pf.rec), ptr(pf.other), ptr(o), ptr(scr), stream_handle()),
+                    conv_args[0], ptr(feats_t), *conv_args[2:], n, m, e, fin, B, r, 0, 1, bf, pf.vrow, pf.vcode,
+                    pf.slice_off, pf.vpos_row, pf.rec, pf.other, ptr(o), ptr(scr), stream_handle()),
                     "conv_fwd_rows"))
                 state = None
             else:
@@ -304,7 +304,7 @@ class Workload:
                 bws = torch.empty(max(256, lib.mccnn_spatial_conv_bwd_rows_workspace_bytes(n, e, fin)), dtype=torch.uint8, device=device)
                 tb, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_bwd_rows(
                     conv_args[0], ptr(feats_t), *conv_args[2:], ptr(og_t), n, m, e, fin, B, r, 0, 1, bf, ptr(pt.row_start),
-                    ptr(pt.vrow), ptr(pt.vcode), ptr(pt.slice_off), ptr(pt.vpos_row), ptr(pt.rec), ptr(pt.other), ptr(fgr),
+                    pt.vrow, pt.vcode, pt.slice_off, pt.vpos_row, pt.rec, pt.other, ptr(fgr),
                     ptr(scr), *[ptr(g) for g in gws], ptr(bws), bws.numel(), stream_handle()), "conv_bwd_rows"))
             else:
                 bwd_ws = torch.empty(max(256, lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, fout, int(combin))),

@@ -294,6 +294,13 @@ int mccnn_sort_step2_dn(const float* pts, const int* batch_ids, const int* keys,
                         int n_cap, const int* n_dev, int batch_size, int num_cells, float* out_pts,
                         int* out_batch_ids, int* cell_indexs, void* ws, size_t ws_bytes,
                         mccnn_stream_t stream);
+/* SortPointsStep1 + SortPointsStep2 of the POINTS only in one call (extension: what a convolution builder needs of a
+ * grid is the sorted points / batch ids, the cell table and index_new_pos -- feature rows are sorted where they are
+ * consumed). Same outputs as the two ops; inv_idx (optional): the inverse permutation (sorted position -> input row). */
+size_t mccnn_build_grid_workspace_bytes(int n, int batch_size, int num_cells);
+int mccnn_build_grid(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n,
+                     int batch_size, int num_cells, int* new_idx, float* out_pts, int* out_batch_ids,
+                     int* cell_indexs, int* inv_idx, void* ws, size_t ws_bytes, mccnn_stream_t stream);
 int mccnn_transform_indexs_dn(const int* in_idx, int s_cap, const int* s_dev, const int* new_idx,
                               int n_cap, const int* n_dev, int* out_idx, void* ws, size_t ws_bytes,
                               mccnn_stream_t stream);
@@ -338,6 +345,23 @@ int mccnn_rowplan_fill(int transposed, const void* rec_edges, const int* packed,
                        const int* plan_vcode, const int* slice_off, const int* vpos_row, void* rec,
                        int* other, mccnn_stream_t stream);
 
+/* The whole plan in ONE call and ONE buffer (what a step of a network pays per neighbour list and direction is host
+ * work: five calls and seven allocations cost more than the kernels of a coarse level's list).
+ * mccnn_rowplan_buffer: byte offsets of {plan_vrow, plan_vcode, slice_off, vpos_row, plan_other, plan_rec} inside a
+ * plan buffer of total_bytes for (rows, e), plus the three sizes of mccnn_rowplan_sizes.
+ * mccnn_rowplan_build = [mccnn_transpose_neighbors] + mccnn_rowplan_layout + [mccnn_edge_records] +
+ * mccnn_rowplan_fill into that buffer. transposed != 0: rows = the n points; start_t [n + 1] / perm_t [e] are written
+ * first unless tlist_ready != 0. rec_edges [e x 16 bytes] is written unless rec_ready != 0 (it serves both plans of a
+ * list). order: optional visiting order of the rows (forward plans). */
+int mccnn_rowplan_buffer(int rows, int e, long long offsets[6], long long* total_bytes, int* num_slices,
+                         long long* slot_capacity, long long* scratch_rows);
+size_t mccnn_rowplan_build_workspace_bytes(int rows, int e, int transposed);
+int mccnn_rowplan_build(int transposed, const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs,
+                        const float* samples, const int* start_idx, const int* packed, const float* aabb_min,
+                        const float* aabb_max, int n, int m, int e, int batch_size, float radius, int scale_inv,
+                        int avg, const int* order, void* rec_edges, int rec_ready, int* start_t, int* perm_t,
+                        int tlist_ready, void* plan_buffer, void* ws, size_t ws_bytes, mccnn_stream_t stream);
+
 /* SpatialConv / SpatialConvGrad for DEPTH-WISE layers (combin == 0, num_feats % 8 == 0, 16-byte aligned rows) over a
  * row plan -- same results as mccnn_spatial_conv_fwd / _bwd (spatial_conv.cu:178-325,563-792) up to float summation
  * order. fwd_rows takes the FORWARD plan (rows = the m centres); bwd_rows takes the TRANSPOSED plan (rows = the n
@@ -378,6 +402,11 @@ int mccnn_debug_conv_impl(int mask);
 /* Diagnostics: number of kernel launches the library has issued in this process (all streams). bench.py prints the
  * difference over one step: below ~50k points a step is bound by launches, not by the kernels. */
 long long mccnn_debug_launch_count(void);
+/* TEST HOOK: small problems (coarse hierarchy levels: a few thousand points / edges) run single-workgroup forms of
+ * the grid build, the list transposition ... that replace 4 - 8 launches by one; on = 0 sends them through the
+ * multi-launch kernels of the large problems instead (same results). Returns the previous setting. Initial value: on,
+ * unless MCCNN_SMALL_OFF is set in the environment. */
+int mccnn_debug_small_kernels(int on);
 
 #ifdef __cplusplus
 }

@@ -176,9 +176,12 @@ class ConvolutionBuilder(torch.nn.Module):
     work on the builder as on any module; `forward` is create_convolution."""
 
     def __init__(self, multiFeatureConvs=False, KDEWindow=0.25, relativeRadius=True, usePDF=True, useAVG=True,
-                 decayLossCollection='weight_decay_loss', device=None, ops=None):
+                 decayLossCollection='weight_decay_loss', device=None, ops=None, fuseSort=None):
         super().__init__()
         self.ops_ = _Ops(ops)
+        # extension: grids from the points alone (MCConvModule.build_grid), feature rows sorted inside the convolution's
+        # node (spatial_conv(sortIndex=)) -- fewer op calls and graph nodes per convolution, same kernels and results
+        self.fuseSort_ = (os.environ.get("MCCNN_FUSE_SORT", "1") != "0") if fuseSort is None else bool(fuseSort)
         self.cacheGrids_ = {}
         self.cacheNeighs_ = {}
         self.cachePDFs_ = {}
@@ -309,9 +312,9 @@ class ConvolutionBuilder(torch.nn.Module):
                 extra.extend(hit[:2])
             for pl in (getattr(t, "_mccnn_rowplans", None) or {}).values():
                 if getattr(pl, "event", None) is not None:  # built on the side stream (prefetch_rowplan)
-                    pl.vrow = pl.vcode = pl.slice_off = pl.vpos_row = pl.other = pl.row_start = None  # views of pl.ints
-                    extra.extend([pl.ints, pl.rec])
-                    pl.ints = pl.rec = None
+                    pl.row_start = None
+                    extra.append(pl.buf)
+                    pl.buf = None
         self.cacheGrids_ = self.cacheNeighs_ = self.cachePDFs_ = None  # the cache dictionaries' references go first
         # Is the builder the LAST owner? Exactly three counts answer that, and a build of torch that lacks one of them
         # takes the always-correct record_stream() path: Python references to the tensor object (this frame + the
@@ -374,6 +377,9 @@ class ConvolutionBuilder(torch.nn.Module):
         if not waited and self.resetEvent_ is not None:
             side.wait_event(self.resetEvent_)  # memory retired at the last reset() is reused only behind it
         with torch.cuda.stream(side):
+            if keyGrid not in grids and self.fuseSort_ and getattr(self.ops_, "_ops", 0) is None and not pts.requires_grad:
+                from . import MCConvModule as _hip_ops
+                grids[keyGrid] = _hip_ops.build_grid(pts, bids, mn, mx, B, convRadius, currRelativeRadius)
             if keyGrid not in grids:
                 keys, indexs = self.ops_.sort_points_step1(pts, bids, mn, mx, B, convRadius, currRelativeRadius)
                 dummy = self.prefetchDummy_  # geometry only: one zero feature per point, kept
@@ -444,7 +450,26 @@ class ConvolutionBuilder(torch.nn.Module):
                                                                        currUsePDF))
 
         # grid (MCConvBuilder.py:349-363)
-        if keyGrid in self.cacheGrids_:
+        # HIP op surface, points that carry no gradient: the grid is built from the points alone (one library call) and
+        # the feature rows are sorted inside the convolution's own autograd node -- per convolution one op call and one
+        # graph node less than sort_points_step2 / sort_features + spatial_conv (same kernels, same results)
+        sortIndex = None
+        inPts = inPointHierarchy.points_[inPointLevel]
+        fused = (self.fuseSort_ and getattr(self.ops_, "_ops", 0) is None and inPts.is_cuda and not inPts.requires_grad)
+        if fused:
+            if keyGrid in self.cacheGrids_:
+                currGridTuple = self.cacheGrids_[keyGrid]
+                self._trace("sort_features", keyGrid)
+            else:
+                from . import MCConvModule as _hip_ops
+                currGridTuple = _hip_ops.build_grid(inPts, inPointHierarchy.batchIds_[inPointLevel],
+                                                     inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_,
+                                                     inPointHierarchy.batchSize_, convRadius, currRelativeRadius)
+                self.cacheGrids_[keyGrid] = currGridTuple
+                self._trace("sort_points_step1", keyGrid)
+                self._trace("sort_points_step2", keyGrid)
+            sortFeatures, sortIndex = inFeatures, currGridTuple[3]
+        elif keyGrid in self.cacheGrids_:
             currGridTuple = self.cacheGrids_[keyGrid]
             sortFeatures = self.ops_.sort_features(inFeatures, currGridTuple[3])
             self._trace("sort_features", keyGrid)
@@ -513,6 +538,13 @@ class ConvolutionBuilder(torch.nn.Module):
         biases3 = self._get_variable(convName + '_biases3', (numBlocks, blockSize), dev, zeros).reshape(nn)
 
         self._trace("spatial_conv", convName, (3, nn), currNumOutFeatures, bool(currMultiFeatureConv))
+        if sortIndex is not None:
+            from . import MCConvModule as _hip_ops
+            return _hip_ops.spatial_conv(currGridTuple[0], sortFeatures, currGridTuple[1], currPDFs,
+                                currOutPointHierarchy.points_[currOutPointLevel], currNeighTuple[0], currNeighTuple[1],
+                                inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, weights, weights2, weights3, biases,
+                                biases2, biases3, currNumOutFeatures, currMultiFeatureConv, inPointHierarchy.batchSize_,
+                                convRadius, currRelativeRadius, currUseAVG, sortIndex)
         return self.ops_.spatial_conv(currGridTuple[0], sortFeatures, currGridTuple[1], currPDFs,
                             currOutPointHierarchy.points_[currOutPointLevel], currNeighTuple[0], currNeighTuple[1],
                             inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, weights, weights2, weights3, biases,

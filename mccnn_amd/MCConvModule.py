@@ -274,17 +274,38 @@ ROWS_MIN_DEGREE = float(os.environ.get("MCCNN_ROWS_MIN_DEGREE", "16"))
 
 
 class RowPlan:
-    """SELL-64 layout of a neighbour list (include/mccnn.h, mccnn_rowplan_*): device tensors; every size is fixed by
-    (rows, e), so building a plan involves no host read-back."""
-    __slots__ = ("vrow", "vcode", "slice_off", "vpos_row", "rec", "other", "scratch_rows", "row_start", "key", "ints", "event")
+    """SELL-64 layout of a neighbour list (include/mccnn.h, mccnn_rowplan_*): ONE device buffer; vrow ... other are the
+    device ADDRESSES of its pieces (plain ints, handed to the C-ABI as they are). Every size is fixed by (rows, e), so
+    building a plan involves no host read-back."""
+    __slots__ = ("buf", "vrow", "vcode", "slice_off", "vpos_row", "rec", "other", "scratch_rows", "row_start", "key", "event",
+                 "num_slices", "slot_capacity")
+
+
+_PLAN_LAYOUTS = {}  # (rows, e, transposed) -> (offsets[6], total bytes, S, slot capacity, scratch rows, workspace bytes)
+
+
+def _plan_layout(lib, rows, e, transposed):
+    key = (rows, e, transposed)
+    hit = _PLAN_LAYOUTS.get(key)
+    if hit is None:
+        offs = (C.c_longlong * 6)()
+        total, cap, srows, S = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0), C.c_int(0)
+        check(lib.mccnn_rowplan_buffer(rows, e, offs, C.byref(total), C.byref(S), C.byref(cap), C.byref(srows)), "rowplan_buffer")
+        if len(_PLAN_LAYOUTS) > 512:
+            _PLAN_LAYOUTS.clear()
+        hit = _PLAN_LAYOUTS[key] = (tuple(offs), total.value, S.value, cap.value, srows.value,
+                                    lib.mccnn_rowplan_build_workspace_bytes(rows, e, int(transposed)))
+    return hit
 
 
 def _row_plan(packed_obj, transposed, pts, bids, pdfs, smp, st, pk, mn, mx, n, m, e, batchSize, radius, scaleInv, avg,
               centre_points=None):
     """The forward (rows = centres) or transposed (rows = neighbour points) row plan of a neighbour list, built on
-    first use and kept ON the neighbour-list tensor object -- like the transposed list, it lives as long as the
-    builder's cache entry and is shared by every layer over the list (same PDFs, radius and avg flag)."""
-    key = (bool(transposed), pdfs.data_ptr(), pdfs._version, bool(avg), float(radius), bool(scaleInv), pk._version, n, m)
+    first use -- one allocation, one library call -- and kept ON the neighbour-list tensor object: like the transposed
+    list, it lives as long as the builder's cache entry and is shared by every layer over the list (same PDFs, radius
+    and avg flag)."""
+    transposed = bool(transposed)
+    key = (transposed, pdfs.data_ptr(), pdfs._version, bool(avg), float(radius), bool(scaleInv), pk._version, n, m)
     plans = getattr(packed_obj, "_mccnn_rowplans", None)
     if plans is None:
         plans = {}
@@ -292,57 +313,56 @@ def _row_plan(packed_obj, transposed, pts, bids, pdfs, smp, st, pk, mn, mx, n, m
             packed_obj._mccnn_rowplans = plans
         except AttributeError:
             pass
-    hit = plans.get(key[0])
+    hit = plans.get(transposed)
     if hit is not None and hit.key == key:
         if hit.event is not None:  # built ahead of time on another stream (prefetch_rowplan): order this stream behind it
             torch.cuda.current_stream().wait_event(hit.event)
         return hit
     lib = _lib.load()
     dev = pk.device
-    perm_t = None
+    start_t = perm_t = order = None
+    tready = 1
     if transposed:
-        start_t, perm_t, _ = _transposed_neighbors(packed_obj, n)
-        row_start, rows, order = start_t, n, None   # the sorted list IS the cell-coherent order
+        rows = n
+        tl = getattr(packed_obj, "_mccnn_transposed", None)
+        if tl is not None and tl[2] == (packed_obj._version, n):
+            start_t, perm_t, _ = _transposed_neighbors(packed_obj, n)  # waits for its event if it was built elsewhere
+        else:  # written by the same call, ahead of the layout
+            start_t = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            perm_t = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+            tready = 0
+        row_start = start_t
     else:
-        row_start, rows = st, m
+        rows, row_start = m, st
         order = _order_hint(centre_points) if centre_points is not None else None
         if order is not None and order.shape[0] != m:
             order = None
-    S, cap, srows = C.c_int(0), C.c_longlong(0), C.c_longlong(0)
-    check(lib.mccnn_rowplan_sizes(rows, e, C.byref(S), C.byref(cap), C.byref(srows)), "rowplan_sizes")
-    S, cap = S.value, cap.value
+    offs, total, S, cap, srows, wsb = _plan_layout(lib, rows, e, transposed)
     plan = RowPlan()
-    plan.key = key
-    plan.event = None
-    plan.row_start = row_start
-    plan.scratch_rows = srows.value
-    # one allocation for the five index arrays (64-int aligned pieces), one for the records
-    al = lambda k: (k + 63) // 64 * 64
-    o1 = al(64 * S)
-    o2 = o1 + al(64 * S)
-    o3 = o2 + al(S + 1)
-    o4 = o3 + al(rows)
-    ints = plan.ints = torch.empty(o4 + cap, dtype=torch.int32, device=dev)
-    plan.vrow, plan.vcode, plan.slice_off = ints[:64 * S], ints[o1:o1 + 64 * S], ints[o2:o2 + S + 1]
-    plan.vpos_row, plan.other = ints[o3:o3 + rows], ints[o4:o4 + cap]
-    plan.rec = torch.empty((cap, 4), dtype=torch.float32, device=dev)
-    ws = _ws(lib.mccnn_rowplan_workspace_bytes(rows, e), dev)
-    check(lib.mccnn_rowplan_layout(ptr(row_start), rows, e, ptr(order), ptr(plan.vrow), ptr(plan.vcode), ptr(plan.slice_off),
-                                   ptr(plan.vpos_row), ptr(ws), ws.numel(), stream_handle()), "rowplan_layout")
+    plan.key, plan.event, plan.row_start = key, None, row_start
+    plan.scratch_rows, plan.num_slices, plan.slot_capacity = srows, S, cap
+    buf = plan.buf = torch.empty(total, dtype=torch.uint8, device=dev)
+    base = buf.data_ptr()
+    plan.vrow, plan.vcode, plan.slice_off, plan.vpos_row, plan.other, plan.rec = [base + o for o in offs]
     # the per-edge records in edge order: written once per list, permuted into both plans
     rec_e = plans.get("rec_edges")
+    rready = 1
     if rec_e is None or rec_e[0] != key[1:]:
-        buf = torch.empty((max(e, 1), 4), dtype=torch.float32, device=dev)
-        check(lib.mccnn_edge_records(ptr(pts), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk), ptr(mn), ptr(mx), n, m, e,
-                                     batchSize, float(radius), int(bool(scaleInv)), int(bool(avg)), ptr(buf), stream_handle()),
-              "edge_records")
-        rec_e = plans["rec_edges"] = [key[1:], buf, None]
+        rec_e = plans["rec_edges"] = [key[1:], torch.empty((max(e, 1), 4), dtype=torch.float32, device=dev), None]
+        rready = 0
     elif rec_e[2] is not None:  # written on another stream (prefetch_rowplan)
         torch.cuda.current_stream().wait_event(rec_e[2])
-    check(lib.mccnn_rowplan_fill(int(bool(transposed)), ptr(rec_e[1]), ptr(pk), rows, e, ptr(row_start), ptr(perm_t),
-                                 ptr(plan.vrow), ptr(plan.vcode), ptr(plan.slice_off), ptr(plan.vpos_row), ptr(plan.rec),
-                                 ptr(plan.other), stream_handle()), "rowplan_fill")
-    plans[key[0]] = plan
+    ws = _ws(wsb, dev)
+    check(lib.mccnn_rowplan_build(int(transposed), ptr(pts), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk), ptr(mn), ptr(mx),
+                                  n, m, e, batchSize, float(radius), int(bool(scaleInv)), int(bool(avg)), ptr(order),
+                                  ptr(rec_e[1]), rready, ptr(start_t), ptr(perm_t), tready, base, ptr(ws), ws.numel(),
+                                  stream_handle()), "rowplan_build")
+    if transposed and not tready:
+        try:
+            packed_obj._mccnn_transposed = (start_t, perm_t, (packed_obj._version, n))
+        except AttributeError:
+            pass
+    plans[transposed] = plan
     return plan
 
 
@@ -354,10 +374,16 @@ def prefetch_rowplan(packed, transposed, stream, *args):
         plans = getattr(packed, "_mccnn_rowplans", None) or {}
         if plans.get(bool(transposed)) is None:
             had_rec = plans.get("rec_edges") is not None
+            had_tl = getattr(packed, "_mccnn_transposed", None) is not None
             plan = _row_plan(packed, transposed, *args)
             ev = torch.cuda.Event()
             ev.record(stream)
             plan.event = ev
+            if transposed and not had_tl:  # the transposed list was written by the same call, on this stream
+                try:
+                    packed._mccnn_transposed_event = ev
+                except AttributeError:
+                    stream.synchronize()
             rec_e = (getattr(packed, "_mccnn_rowplans", None) or {}).get("rec_edges")
             if rec_e is not None and not had_rec:
                 # the edge-order records were written (and allocated) on this stream; the other plan of the list will read
@@ -486,6 +512,37 @@ def sort_points_step1(inPts, inBatchIds, aabbMin, aabbMax, batchSize, cellSize, 
     check(lib.mccnn_sort_step1(ptr(pts), ptr(bids), ptr(mn), ptr(mx), n, batchSize, nc, ptr(keys), ptr(idx), ptr(ws),
                                ws.numel(), stream_handle()), "sort_points_step1")
     return keys, idx
+
+
+def build_grid(inPts, inBatchIds, aabbMin, aabbMax, batchSize, cellSize, scaleInv):
+    """sort_points_step1 + sort_points_step2 of the points alone, in one library call (extension for
+    ConvolutionBuilder: the feature rows are sorted by the convolution that consumes them, spatial_conv(sortIndex=)).
+    -> (sortPts, sortBatchs, cellIndexs, index_new_pos), the builder's grid tuple. Not differentiable: points that
+    require a gradient take the two ops."""
+    op = "SortPointsStep1Op"
+    _req(batchSize > 0, op + " expects a positive batch size")
+    pts, bids = _f32(inPts.detach(), "points"), _i32(inBatchIds, "batch_ids")
+    mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
+    _check_points(pts, "points", op)
+    n = pts.shape[0]
+    _check_batch_ids(bids, n, op)
+    _check_aabb(mn, mx, batchSize, op)
+    lib = _lib.load()
+    dev = pts.device
+    nc = _num_cells(mn, mx, batchSize, cellSize, scaleInv)
+    wsb = lib.mccnn_build_grid_workspace_bytes(n, batchSize, nc)
+    _req(wsb > 0, op + ": batch_size * num_cells^3 does not fit 32-bit keys")
+    ws = _ws(wsb, dev)
+    # separate allocations: the builder's lifetime bookkeeping of prefetched grids counts the owners of a STORAGE
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    inv = torch.empty(n, dtype=torch.int32, device=dev)
+    oB = torch.empty((n, 1), dtype=torch.int32, device=dev)
+    oP = torch.empty_like(pts)
+    cells = torch.empty((batchSize, nc, nc, nc, 2), dtype=torch.int32, device=dev)
+    check(lib.mccnn_build_grid(ptr(pts), ptr(bids), ptr(mn), ptr(mx), n, batchSize, nc, ptr(idx), ptr(oP), ptr(oB), ptr(cells),
+                               ptr(inv), ptr(ws), ws.numel(), stream_handle()), "build_grid")
+    _remember_order(inPts, "order", inv)
+    return oP, oB, cells, idx
 
 
 def _gather_rows(src, idx, n_rows):
@@ -992,7 +1049,7 @@ class _SpatialConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inPts, inFeatures, inBatchIds, inPDFs, inSamplePts, neighStartIndexs, packedNeighs, aabbMin,
                 aabbMax, weights1, biases1, weights2, biases2, weightsOut, biasesOut, numOutFeatures, combin,
-                batchSize, radius, scaleInv, avg):
+                batchSize, radius, scaleInv, avg, sortIndex=None):
         op = "SpatialConvOp"
         pts, feats, bids = _f32(inPts, "points"), _feat(inFeatures, "features"), _i32(inBatchIds, "batch_ids")
         bf16 = feats.dtype == torch.bfloat16
@@ -1002,6 +1059,15 @@ class _SpatialConv(torch.autograd.Function):
         w1, b1 = _f32(weights1, "weight_hidden_1"), _f32(biases1, "bias_hidden_1")
         w2, b2 = _f32(weights2, "weight_hidden_2"), _f32(biases2, "bias_hidden_2")
         w3, b3 = _f32(weightsOut, "weight_out_layer"), _f32(biasesOut, "bias_out_layer")
+        sidx = None
+        if sortIndex is not None:
+            # the feature rows arrive in the order of the UNSORTED points: sort_features folded into this node (one
+            # autograd node and one op call less per convolution; same two kernels)
+            sidx = _i32(sortIndex, "index_new_pos")
+            _req(sidx.dim() == 1 and feats.dim() == 2 and feats.shape[0] == sidx.shape[0],
+                 "SortFeaturesBackGradOp expects features with dimensions (numPoints, numFeatures)")
+            feats = _scatter_rows(feats, sidx, feats.shape[0], False)
+        sx = () if sidx is None else (sidx,)  # saved with the other tensors: released when the backward pass has run
         n, m, e, fin = _conv_checks(op, pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3,
                                     numOutFeatures, combin, batchSize, radius)
         lib = _lib.load()
@@ -1015,11 +1081,11 @@ class _SpatialConv(torch.autograd.Function):
             check(lib.mccnn_spatial_conv_fwd_rows(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                                   ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
                                                   n, m, e, fin, batchSize, float(radius), int(bool(scaleInv)),
-                                                  int(bool(avg)), int(bf16), ptr(plan.vrow), ptr(plan.vcode),
-                                                  ptr(plan.slice_off), ptr(plan.vpos_row), ptr(plan.rec), ptr(plan.other),
+                                                  int(bool(avg)), int(bf16), plan.vrow, plan.vcode,
+                                                  plan.slice_off, plan.vpos_row, plan.rec, plan.other,
                                                   ptr(out), ptr(scratch), stream_handle()),
                   "spatial_conv(rows)")
-            ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3)
+            ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3, *sx)
             ctx.state = None
             ctx.packed_ref = weakref.ref(packedNeighs if pk is packedNeighs else pk)
             ctx.attrs = (numOutFeatures, bool(combin), batchSize, float(radius), bool(scaleInv), bool(avg))
@@ -1034,7 +1100,7 @@ class _SpatialConv(torch.autograd.Function):
                                                   n, m, e, fin, batchSize, float(radius), int(bool(scaleInv)),
                                                   int(bool(avg)), ptr(out), ptr(ws), ws.numel(), stream_handle()),
                   "spatial_conv(bf16)")
-            ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3)
+            ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3, *sx)
             ctx.state = None
             ctx.packed_ref = weakref.ref(packedNeighs if pk is packedNeighs else pk)
             ctx.attrs = (numOutFeatures, bool(combin), batchSize, float(radius), bool(scaleInv), bool(avg))
@@ -1044,14 +1110,14 @@ class _SpatialConv(torch.autograd.Function):
         # per-centre sums; only kept when a gradient will be asked for
         state = None
         sbytes = lib.mccnn_spatial_conv_state_bytes(m, e, fin, numOutFeatures, int(bool(combin)))
-        if KEEP_CONV_STATE and sbytes and e > 0 and any(t.requires_grad for t in (feats, w1, b1, w2, b2, w3, b3)):
+        if KEEP_CONV_STATE and sbytes and e > 0 and any(t.requires_grad for t in (inFeatures, w1, b1, w2, b2, w3, b3)):
             state = torch.empty(sbytes, dtype=torch.uint8, device=pts.device)
         check(lib.mccnn_spatial_conv_fwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                          ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), n, m,
                                          e, fin, numOutFeatures, int(bool(combin)), batchSize, float(radius),
                                          int(bool(scaleInv)), int(bool(avg)), ptr(out), ptr(state), ptr(ws), ws.numel(),
                                          stream_handle()), "spatial_conv")
-        ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3)
+        ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3, *sx)
         ctx.state = state
         # the builder's cached tensor OBJECT carries the transposed list (see _transposed_neighbors). A weak reference: the
         # graph object outlives its backward pass (as long as the caller keeps the output or the loss), and a strong one
@@ -1063,7 +1129,9 @@ class _SpatialConv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, outGrad):
         # _spatial_conv_grad (MCConvModuleSrc:74-81): grads for features and the 6 MLP tensors only
-        pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3 = saved[:15]
+        sort_index = saved[15] if len(saved) > 15 else None
         numOutFeatures, combin, batchSize, radius, scaleInv, avg = ctx.attrs
         bf16 = feats.dtype == torch.bfloat16
         og = _feat(outGrad, "out_features_grad")
@@ -1091,13 +1159,13 @@ class _SpatialConv(torch.autograd.Function):
             check(lib.mccnn_spatial_conv_bwd_rows(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                                   ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
                                                   ptr(og), n, m, e, fin, batchSize, radius, int(scaleInv), int(avg),
-                                                  int(bf16), ptr(plan.row_start), ptr(plan.vrow), ptr(plan.vcode),
-                                                  ptr(plan.slice_off), ptr(plan.vpos_row), ptr(plan.rec), ptr(plan.other),
+                                                  int(bf16), ptr(plan.row_start), plan.vrow, plan.vcode,
+                                                  plan.slice_off, plan.vpos_row, plan.rec, plan.other,
                                                   ptr(fg), ptr(scratch), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(dw3),
                                                   ptr(db3), ptr(ws), ws.numel(), stream_handle()),
                   "spatial_conv_grad(rows)")
-            return (None, fg, None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
-                    None, None, None, None, None, None)
+            return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
+                    None, None, None, None, None, None, None)
         ws = _ws(lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, numOutFeatures, int(combin)), pts.device)
         start_t = perm_t = None
         if not combin and e > 0:
@@ -1113,8 +1181,8 @@ class _SpatialConv(torch.autograd.Function):
                                                   ptr(start_t), ptr(perm_t), ptr(fg), ptr(dw1), ptr(db1), ptr(dw2),
                                                   ptr(db2), ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
                   "spatial_conv_grad(bf16)")
-            return (None, fg, None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
-                    None, None, None, None, None, None)
+            return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
+                    None, None, None, None, None, None, None)
         check(lib.mccnn_spatial_conv_bwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                          ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
                                          ptr(og), n, m, e, fin, numOutFeatures, int(combin), batchSize, radius,
@@ -1123,15 +1191,21 @@ class _SpatialConv(torch.autograd.Function):
                                          ptr(db1), ptr(dw2), ptr(db2),
                                          ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
               "spatial_conv_grad")
-        return (None, fg, None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
-                None, None, None, None, None, None)
+        return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
+                None, None, None, None, None, None, None)
+
+
+def _unsort_grad(idx, fg):
+    """Feature gradient back in the order the features arrived in (sortIndex: in[i] = sorted[index_new_pos[i]])."""
+    return fg if idx is None else _gather_rows(fg, idx, idx.shape[0])
 
 
 def spatial_conv(inPts, inFeatures, inBatchIds, inPDFs, inSamplePts, neighStartIndexs, packedNeighs, aabbMin, aabbMax,
                  weights1, weights2, weightsOut, biases1, biases2, biasesOut, numOutFeatures, combin, batchSize, radius,
-                 scaleInv, avg):
+                 scaleInv, avg, sortIndex=None):
     """SpatialConv (MCConvModuleSrc:70-81). Note the reference's argument order (weights first, then biases);
-    the op itself takes (w1, b1, w2, b2, w3, b3)."""
+    the op itself takes (w1, b1, w2, b2, w3, b3). sortIndex (extension): inFeatures are the rows of the UNSORTED points and
+    sortIndex the grid's index_new_pos -- sort_features(inFeatures, sortIndex) happens inside this op."""
     return _SpatialConv.apply(inPts, inFeatures, inBatchIds, inPDFs, inSamplePts, neighStartIndexs, packedNeighs,
                               aabbMin, aabbMax, weights1, biases1, weights2, biases2, weightsOut, biasesOut,
-                              numOutFeatures, combin, batchSize, radius, scaleInv, avg)
+                              numOutFeatures, combin, batchSize, radius, scaleInv, avg, sortIndex)

@@ -22,6 +22,7 @@ SIGNATURES = {
     "mccnn_check_batch_ids": (_i, [_vp, _i, _i, _vp, _vp]),
     "mccnn_debug_conv_impl": (_i, [_i]),
     "mccnn_debug_launch_count": (C.c_longlong, []),
+    "mccnn_debug_small_kernels": (_i, [_i]),
     "mccnn_compute_aabb_workspace_bytes": (_sz, [_i]),
     "mccnn_compute_aabb": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_num_cells": (_i, [_vp, _vp, _i, _f, _i, C.POINTER(_i), _vp]),
@@ -32,6 +33,8 @@ SIGNATURES = {
     "mccnn_sort_step2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_sort_step1_dn": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_sort_step2_dn": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_build_grid_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mccnn_build_grid": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_transform_indexs_dn": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_permute_gather": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "mccnn_permute_scatter": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
@@ -59,6 +62,10 @@ SIGNATURES = {
     "mccnn_rowplan_layout": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_edge_records": (_i, [_vp] * 8 + [_i, _i, _i, _i, _f, _i, _i, _vp, _vp]),
     "mccnn_rowplan_fill": (_i, [_i, _vp, _vp, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp]),
+    "mccnn_rowplan_buffer": (_i, [_i, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(_i),
+                                  C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "mccnn_rowplan_build_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mccnn_rowplan_build": (_i, [_i] + [_vp] * 8 + [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "mccnn_spatial_conv_fwd_rows": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp]),
     "mccnn_spatial_conv_bwd_rows_workspace_bytes": (_sz, [_i, _i, _i]),
     "mccnn_spatial_conv_bwd_rows": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 7 + [_vp] * 8 + [_vp, _sz, _vp]),

@@ -1,8 +1,10 @@
 // Version / diagnostics entry points of libmccnn_hip.
 #include "common.h"
+#include <cstdlib>
 
 namespace mccnn {
 std::atomic<long long> g_launches{0};
+std::atomic<int> g_small_off{getenv("MCCNN_SMALL_OFF") ? 1 : 0};
 }
 
 extern "C" {
@@ -10,6 +12,7 @@ extern "C" {
 int mccnn_block_size(void) { return MCCNN_MLP; }
 int mccnn_abi_version(void) { return 5; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn; 5: row plans, aabb_extent
 const char* mccnn_arch(void) { return "gfx950"; }
+int mccnn_debug_small_kernels(int on) { return mccnn::g_small_off.exchange(on ? 0 : 1) == 0 ? 1 : 0; }
 long long mccnn_debug_launch_count(void) { return mccnn::g_launches.load(std::memory_order_relaxed); }
 
 const char* mccnn_error_string(int code) {

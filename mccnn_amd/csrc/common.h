@@ -31,6 +31,10 @@ namespace mccnn {
 // kernel launches issued by the library so far (diagnostics: mccnn_debug_launch_count; the launch-bound small-batch
 // regime is measured in launches per step). Defined in api_misc.hip.
 extern std::atomic<long long> g_launches;
+// Test / A-B switch (mccnn_debug_small_kernels, MCCNN_SMALL_OFF in the environment): non-zero = small problems take
+// the multi-launch kernels of the large ones instead of their single-workgroup forms. Defined in api_misc.hip.
+extern std::atomic<int> g_small_off;
+inline bool small_kernels_on() { return g_small_off.load(std::memory_order_relaxed) == 0; }
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -132,5 +136,24 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     }
     return v;
 }
+
+// exclusive scan of one value per thread over a 1024-thread workgroup; wsum: 17 ints of LDS
+__device__ __forceinline__ int block1024_excl_scan(int v, int& total, int* wsum) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int incl = wave_incl_scan(v);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int k = 0; k < 16; ++k) { const int x = wsum[k]; wsum[k] = run; run += x; }
+        wsum[16] = run;
+    }
+    __syncthreads();
+    total = wsum[16];
+    const int ex = wsum[wave] + incl - v;
+    __syncthreads();  // wsum may be reused right away
+    return ex;
+}
+
 
 }  // namespace mccnn

@@ -764,6 +764,41 @@ __global__ __launch_bounds__(256) void tr_rank(const int2* __restrict__ packed, 
     permT[s0 + r] = v;
 }
 
+// The whole transposition of a SMALL list in one workgroup of 1024 threads (memset, tr_count, scan, tr_fill, tr_rank: five
+// launches for a few microseconds of work on the coarse levels of a hierarchy; the host pays ~6 us to issue each).
+#define MCCNN_TR_SMALL_E 8192
+#define MCCNN_TR_SMALL_N 8192
+__global__ __launch_bounds__(1024) void tr_small(const int2* __restrict__ packed, int e, int n, int* __restrict__ cnt,
+                                                 int* __restrict__ slot, int* __restrict__ tmp, int* __restrict__ startT,
+                                                 int* __restrict__ permT) {
+    __shared__ int wsum[17];
+    const int t = threadIdx.x;
+    for (int j = t; j < n; j += 1024) cnt[j] = 0;
+    __syncthreads();
+    for (int k = t; k < e; k += 1024) slot[k] = atomicAdd(&cnt[packed[k].x], 1);
+    __syncthreads();
+    {
+        const int per = (n + 1023) / 1024, j0 = min(n, t * per), j1 = min(n, j0 + per);
+        int sum = 0;
+        for (int j = j0; j < j1; ++j) sum += cnt[j];
+        int tot;
+        int run = block1024_excl_scan(sum, tot, wsum);
+        for (int j = j0; j < j1; ++j) { const int v = cnt[j]; startT[j] = run; run += v; }
+        if (t == 0) startT[n] = tot;
+    }
+    __syncthreads();
+    for (int k = t; k < e; k += 1024) tmp[startT[packed[k].x] + slot[k]] = k;
+    __syncthreads();
+    for (int p = t; p < e; p += 1024) {  // stable order inside a row: ascending edge id
+        const int v = tmp[p];
+        const int j = packed[v].x;
+        const int s0 = startT[j], s1 = startT[j + 1];
+        int r = 0;
+        for (int q = s0; q < s1; ++q) r += (tmp[q] < v) ? 1 : 0;
+        permT[s0 + r] = v;
+    }
+}
+
 // combin layers: featGrad[j, f] += dfE[e, f] (one atomic per edge and input feature)
 // (`planes` > 1: the per-edge sums of the blocks lie in separate planes of `total` floats each, added here)
 __global__ __launch_bounds__(256) void scatter_edge_featgrad(const int2* __restrict__ packed, const float* __restrict__ dfE,
@@ -1228,6 +1263,12 @@ int mccnn_transpose_neighbors(const int* packed, int e, int n, int* start_t, int
     int* cnt = (int*)blk;
     void* scanws = blk + cntBytes;
     const int2* pk = reinterpret_cast<const int2*>(packed);
+    // the rank phase is quadratic in the row length: one workgroup only when the rows are short enough for it
+    if (e <= MCCNN_TR_SMALL_E && n <= MCCNN_TR_SMALL_N && (long long)e * e / n <= (4LL << 20) && small_kernels_on()) {
+        tr_small<<<1, 1024, 0, s>>>(pk, e, n, cnt, slot, tmp, start_t, perm_t);
+        MCCNN_LAUNCHED();
+        return 0;
+    }
     MCCNN_MEMSET(hipMemsetAsync(blk, 0, cntBytes + scan_status_bytes(n), s));
     tr_count<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, cnt, slot);
     MCCNN_LAUNCHED();

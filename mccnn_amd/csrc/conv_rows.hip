@@ -60,7 +60,14 @@ static PlanSizes plan_sizes(int rows, int e) {
     // 64 k virtual rows (1 k slices) when the edges allow it, pieces of 16 .. 128 edges. Large lists keep 128: a row
     // of the usual 30 - 100 edges then stays in one piece.
     z.L = ROWS_L;
-    if (rows < 16384) {
+    static const int minL = getenv("MCCNN_PLAN_MIN_L") ? atoi(getenv("MCCNN_PLAN_MIN_L")) : 4;  // A/B switch, read once
+    if (rows <= 3072 && minL < 16) {
+        // the coarse levels of a hierarchy: the chip is empty, every iteration of a lane is exposed latency -- pieces as
+        // short as the single-workgroup layout (MCCNN_PLAN_SMALL virtual rows) allows
+        int L = minL;
+        while (L < ROWS_L && rows + e / L > 3584) L <<= 1;
+        z.L = L;
+    } else if (rows < 16384) {
         long long want = e / 65536;
         int L = 16;
         while (L < want && L < ROWS_L) L <<= 1;
@@ -809,6 +816,69 @@ int mccnn_rowplan_fill(int transposed, const void* rec_edges, const int* packed,
                                               row_start, rows, nullptr, p, z.slots, reinterpret_cast<float4*>(rec), other, z.L);
     MCCNN_LAUNCHED();
     return 0;
+}
+
+static size_t plan_al(size_t ints) { return (ints + 63) / 64 * 64; }  // 256-byte aligned pieces
+
+int mccnn_rowplan_buffer(int rows, int e, long long offsets[6], long long* total_bytes, int* num_slices,
+                         long long* slot_capacity, long long* scratch_rows) {
+    if (rows < 0 || e < 0 || !offsets || !total_bytes || !num_slices || !slot_capacity || !scratch_rows) return MCCNN_E_BADARG;
+    const PlanSizes z = plan_sizes(rows, e);
+    if (z.slots > 0x7fffffffLL || z.vcap > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
+    *num_slices = z.S;
+    *slot_capacity = z.slots;
+    *scratch_rows = z.vcap;
+    size_t o = 0;
+    offsets[0] = (long long)(o * 4); o += plan_al((size_t)64 * z.S);            // plan_vrow
+    offsets[1] = (long long)(o * 4); o += plan_al((size_t)64 * z.S);            // plan_vcode
+    offsets[2] = (long long)(o * 4); o += plan_al((size_t)z.S + 1);             // slice_off
+    offsets[3] = (long long)(o * 4); o += plan_al((size_t)(rows > 0 ? rows : 1));  // vpos_row
+    offsets[4] = (long long)(o * 4); o += plan_al((size_t)(z.slots > 0 ? z.slots : 1));  // plan_other
+    offsets[5] = (long long)(o * 4); o += plan_al((size_t)(z.slots > 0 ? z.slots : 1) * 4);  // plan_rec (16 B per slot)
+    *total_bytes = (long long)(o * 4);
+    return 0;
+}
+
+size_t mccnn_rowplan_build_workspace_bytes(int rows, int e, int transposed) {
+    size_t a = mccnn_rowplan_workspace_bytes(rows, e);
+    size_t b = transposed ? mccnn_transpose_neighbors_workspace_bytes(rows, e) : 0;
+    return a > b ? a : b;
+}
+
+int mccnn_rowplan_build(int transposed, const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs,
+                        const float* samples, const int* start_idx, const int* packed, const float* aabb_min,
+                        const float* aabb_max, int n, int m, int e, int batch_size, float radius, int scale_inv, int avg,
+                        const int* order, void* rec_edges, int rec_ready, int* start_t, int* perm_t, int tlist_ready,
+                        void* plan_buffer, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    if (n < 0 || m < 0 || e < 0 || !plan_buffer || !rec_edges) return MCCNN_E_BADARG;
+    const int rows = transposed ? n : m;
+    if (transposed && (!start_t || !perm_t)) return MCCNN_E_BADARG;
+    if (!ws || ws_bytes < mccnn_rowplan_build_workspace_bytes(rows, e, transposed)) return MCCNN_E_WORKSPACE;
+    long long off[6], total, cap, srows;
+    int S;
+    int rc = mccnn_rowplan_buffer(rows, e, off, &total, &S, &cap, &srows);
+    if (rc) return rc;
+    char* base = reinterpret_cast<char*>(plan_buffer);
+    int* vrow = reinterpret_cast<int*>(base + off[0]);
+    int* vcode = reinterpret_cast<int*>(base + off[1]);
+    int* sliceOff = reinterpret_cast<int*>(base + off[2]);
+    int* vposRow = reinterpret_cast<int*>(base + off[3]);
+    int* other = reinterpret_cast<int*>(base + off[4]);
+    void* rec = base + off[5];
+    if (transposed && !tlist_ready) {
+        rc = mccnn_transpose_neighbors(packed, e, n, start_t, perm_t, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    const int* rowStart = transposed ? start_t : start_idx;
+    rc = mccnn_rowplan_layout(rowStart, rows, e, transposed ? nullptr : order, vrow, vcode, sliceOff, vposRow, ws, ws_bytes, stream);
+    if (rc) return rc;
+    if (!rec_ready) {
+        rc = mccnn_edge_records(sorted_pts, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min, aabb_max, n, m, e,
+                                batch_size, radius, scale_inv, avg, rec_edges, stream);
+        if (rc) return rc;
+    }
+    return mccnn_rowplan_fill(transposed, rec_edges, packed, rows, e, rowStart, perm_t, vrow, vcode, sliceOff, vposRow, rec, other,
+                              stream);
 }
 
 static bool rows_shape_ok(const ConvArgs& a, int combin, const void* p0, const void* p1) {

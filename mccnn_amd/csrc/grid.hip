@@ -220,6 +220,90 @@ __global__ __launch_bounds__(256) void cell_table(const int* __restrict__ sKeys,
     if (p == n - 1 || sKeys[p + 1] != k) cells[2 * (size_t)k + 1] = p + 1;
 }
 
+// ------------------------------------------------------------------ small grids: one workgroup per op
+// A coarse level of a hierarchy (a few thousand points, a few thousand cells) spends its grid build in LAUNCHES: memset,
+// keys_hist, scan, park_ids, rank_in_cell for step 1, move_points, cell_table for step 2 -- 7 launches of 2-4 us of work
+// each, and the host pays ~6 us to issue every one of them. Up to MCCNN_GRID_SMALL_N points in at most
+// MCCNN_GRID_SMALL_C cells (beyond that one workgroup's serial trips cost more than the launches: 5 277 points took 75 us
+// against ~15 us for the seven kernels) ONE workgroup of 1024 threads runs the same phases back to back with barriers in between:
+// same arrays, same results (the order inside a cell is fixed by the ranks, not by the arrival order of the atomics).
+#define MCCNN_GRID_SMALL_N 2048
+#define MCCNN_GRID_SMALL_C 8192
+
+__global__ __launch_bounds__(1024) void grid_small_step1(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                         const float* __restrict__ mn, const float* __restrict__ mx, int n,
+                                                         int B, int nc, int C, int* __restrict__ keys,
+                                                         int* __restrict__ newIdx, int* __restrict__ cnt,
+                                                         int* __restrict__ start, int* __restrict__ slot,
+                                                         const int* __restrict__ nDev) {
+    __shared__ int wsum[17];
+    const int t = threadIdx.x;
+    if (nDev) n = *nDev;
+    for (int c = t; c < C; c += 1024) cnt[c] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {  // keys_hist
+        const int b = clamp_batch(bids[i], B);
+        const float cs = max_extent(mn, mx, b) / (float)nc;
+        const int x = cell_coord(pts[(size_t)i * 3], mn[b * 3], cs, nc);
+        const int y = cell_coord(pts[(size_t)i * 3 + 1], mn[b * 3 + 1], cs, nc);
+        const int z = cell_coord(pts[(size_t)i * 3 + 2], mn[b * 3 + 2], cs, nc);
+        const int key = b * nc * nc * nc + x * nc * nc + y * nc + z;
+        keys[i] = key;
+        newIdx[i] = atomicAdd(&cnt[key], 1);  // arrival rank, replaced by the final position below
+    }
+    __syncthreads();
+    {   // start = exclusive scan of the cell counts: a contiguous run of cells per thread
+        const int per = (C + 1023) / 1024, c0 = min(C, t * per), c1 = min(C, c0 + per);
+        int sum = 0;
+        for (int c = c0; c < c1; ++c) sum += cnt[c];
+        int tot;
+        int run = block1024_excl_scan(sum, tot, wsum);
+        for (int c = c0; c < c1; ++c) { const int v = cnt[c]; start[c] = run; run += v; }
+        if (t == 0) start[C] = tot;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) slot[start[keys[i]] + newIdx[i]] = i;  // park_ids
+    __syncthreads();
+    for (int p = t; p < n; p += 1024) {  // rank_in_cell
+        const int id = slot[p];
+        const int k = keys[id];
+        const int s0 = start[k], s1 = start[k + 1];
+        int r = 0;
+        for (int q = s0; q < s1; ++q) r += (slot[q] < id) ? 1 : 0;
+        newIdx[id] = s0 + r;
+    }
+}
+
+template <int FS>
+__global__ __launch_bounds__(1024) void grid_small_step2(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                         const float* __restrict__ feats, const int* __restrict__ keys,
+                                                         const int* __restrict__ newIdx, int n, float* __restrict__ oPts,
+                                                         int* __restrict__ oBids, float* __restrict__ oFeats,
+                                                         int* __restrict__ sKeys, int* __restrict__ inv,
+                                                         int2* __restrict__ cells, int C, const int* __restrict__ nDev) {
+    const int t = threadIdx.x;
+    if (nDev) n = *nDev;
+    for (int c = t; c < C; c += 1024) cells[c] = make_int2(0, 0);  // sort_gpu.cu:492
+    for (int i = t; i < n; i += 1024) {  // move_points
+        const int p = newIdx[i];
+        oPts[(size_t)p * 3] = pts[(size_t)i * 3];
+        oPts[(size_t)p * 3 + 1] = pts[(size_t)i * 3 + 1];
+        oPts[(size_t)p * 3 + 2] = pts[(size_t)i * 3 + 2];
+        oBids[p] = bids[i];
+        sKeys[p] = keys[i];
+        if (inv) inv[p] = i;
+#pragma unroll
+        for (int f = 0; f < FS; ++f) oFeats[(size_t)p * FS + f] = feats[(size_t)i * FS + f];
+    }
+    __syncthreads();
+    int* ct = reinterpret_cast<int*>(cells);
+    for (int p = t; p < n; p += 1024) {  // cell_table (save_indexs, sort_gpu.cu:225-248)
+        const int k = sKeys[p];
+        if (p == 0 || sKeys[p - 1] != k) ct[2 * (size_t)k] = p;
+        if (p == n - 1 || sKeys[p + 1] != k) ct[2 * (size_t)k + 1] = p + 1;
+    }
+}
+
 // ------------------------------------------------------------------ row permutations
 // One thread per VEC floats of a row; rows are F floats. GATHER: out[i] = in[idx[i]],
 // else out[idx[i]] = in[i].
@@ -371,6 +455,12 @@ static int sort_step1_impl(const float* pts, const int* batch_ids, const float* 
     if (!blk || !start || !slot) return MCCNN_E_WORKSPACE;
     int* cnt = (int*)blk;
     void* scanws = blk + cntBytes;
+    if (n <= MCCNN_GRID_SMALL_N && C <= MCCNN_GRID_SMALL_C && small_kernels_on()) {
+        grid_small_step1<<<1, 1024, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, (int)C, keys, new_idx, cnt,
+                                            start, slot, n_dev);
+        MCCNN_LAUNCHED();
+        return 0;
+    }
     MCCNN_MEMSET(hipMemsetAsync(blk, 0, cntBytes + scan_status_bytes((int)C), s));
     int blocks = ceil_div(n, 256);
     keys_hist<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, keys, cnt, new_idx, n_dev);
@@ -404,9 +494,9 @@ size_t mccnn_sort_step2_workspace_bytes(int n) { return align_up((size_t)(n > 0 
 static int sort_step2_impl(const float* pts, const int* batch_ids, const float* feats, const int* keys, const int* new_idx,
                            int n, int num_feats, int batch_size, int num_cells, float* out_pts, int* out_batch_ids,
                            float* out_feats, int* cell_indexs, int* inv_idx, void* ws, size_t ws_bytes,
-                           mccnn_stream_t stream, const int* n_dev) {
-    // num_feats == 0 (geometry only: no feature rows are moved) is accepted by the device-count form
-    if (n < 0 || batch_size <= 0 || num_cells <= 0 || num_feats < (n_dev ? 0 : 1) || !cell_indexs) return MCCNN_E_BADARG;
+                           mccnn_stream_t stream, const int* n_dev, bool geometry_only = false) {
+    // num_feats == 0 (geometry only: no feature rows are moved) is accepted by the device-count form and mccnn_build_grid
+    if (n < 0 || batch_size <= 0 || num_cells <= 0 || num_feats < ((n_dev || geometry_only) ? 0 : 1) || !cell_indexs) return MCCNN_E_BADARG;
     long long C = total_cells(batch_size, num_cells);
     if (C >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     hipStream_t s = (hipStream_t)stream;
@@ -421,6 +511,18 @@ static int sort_step2_impl(const float* pts, const int* batch_ids, const float* 
     int* skeys = (int*)ws;
     int blocks = ceil_div(n, 256);
     int2* ct = reinterpret_cast<int2*>(cell_indexs);
+    if (n <= MCCNN_GRID_SMALL_N && C <= MCCNN_GRID_SMALL_C && small_kernels_on()) {
+        switch (num_feats <= 4 ? num_feats : 0) {
+            case 1: grid_small_step2<1><<<1, 1024, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, (int)C, n_dev); break;
+            case 2: grid_small_step2<2><<<1, 1024, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, (int)C, n_dev); break;
+            case 3: grid_small_step2<3><<<1, 1024, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, (int)C, n_dev); break;
+            case 4: grid_small_step2<4><<<1, 1024, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, (int)C, n_dev); break;
+            default: grid_small_step2<0><<<1, 1024, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, (int)C, n_dev); break;
+        }
+        MCCNN_LAUNCHED();
+        if (num_feats > 4) return launch_permute<false>(feats, new_idx, n, num_feats, out_feats, s);
+        return 0;
+    }
     switch (num_feats <= 4 ? num_feats : 0) {
         case 1: move_points<1><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C, n_dev); break;
         case 2: move_points<2><<<blocks, 256, 0, s>>>(pts, batch_ids, feats, keys, new_idx, n, out_pts, out_batch_ids, out_feats, skeys, inv_idx, ct, C, n_dev); break;
@@ -452,6 +554,32 @@ int mccnn_sort_step2_dn(const float* pts, const int* batch_ids, const int* keys,
     if (!n_dev) return MCCNN_E_BADARG;
     return sort_step2_impl(pts, batch_ids, nullptr, keys, new_idx, n_cap, 0, batch_size, num_cells, out_pts, out_batch_ids,
                            nullptr, cell_indexs, nullptr, ws, ws_bytes, stream, n_dev);
+}
+
+size_t mccnn_build_grid_workspace_bytes(int n, int batch_size, int num_cells) {
+    const size_t a = mccnn_sort_step1_workspace_bytes(n, batch_size, num_cells);
+    if (a == 0) return 0;
+    const size_t b = mccnn_sort_step2_workspace_bytes(n);
+    return align_up((size_t)(n > 0 ? n : 1) * 4) + (a > b ? a : b);
+}
+
+int mccnn_build_grid(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n,
+                     int batch_size, int num_cells, int* new_idx, float* out_pts, int* out_batch_ids, int* cell_indexs,
+                     int* inv_idx, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    if (n < 0 || batch_size <= 0 || num_cells <= 0) return MCCNN_E_BADARG;
+    const size_t need = mccnn_build_grid_workspace_bytes(n, batch_size, num_cells);
+    if (need == 0) return MCCNN_E_TOOLARGE;
+    if (!ws || ws_bytes < need) return MCCNN_E_WORKSPACE;
+    Arena a(ws, ws_bytes);
+    int* keys = a.take<int>((size_t)(n > 0 ? n : 1));
+    void* rest = a.base + a.off;
+    const size_t restBytes = ws_bytes - a.off;
+    int rc = sort_step1_impl(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, keys, new_idx, rest, restBytes,
+                             stream, nullptr);
+    if (rc) return rc;
+    // geometry only (no feature rows): the device-count form of step 2 accepts that; its count is the host's here
+    return sort_step2_impl(pts, batch_ids, nullptr, keys, new_idx, n, 0, batch_size, num_cells, out_pts, out_batch_ids,
+                           nullptr, cell_indexs, inv_idx, rest, restBytes, stream, nullptr, true);
 }
 
 int mccnn_permute_gather(const float* in, const int* idx, int n_idx, int num_feats, float* out,

@@ -80,5 +80,6 @@ for F in feats_list:
     for k, p in pl.items():
         if not isinstance(k, bool):
             continue
-        S = p.slice_off.shape[0] - 1
-        print("   plan transposed=%s: %d slots used (%.3f x E), capacity %d" % (k, int(p.slice_off[S]), int(p.slice_off[S]) / packed.shape[0], p.other.shape[0]))
+        S, o = p.num_slices, p.slice_off - p.buf.data_ptr()
+        used = int(p.buf[o:o + 4 * (S + 1)].view(torch.int32)[S])
+        print("   plan transposed=%s: %d slots used (%.3f x E), capacity %d" % (k, used, used / packed.shape[0], p.slot_capacity))
