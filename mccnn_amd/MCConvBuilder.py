@@ -488,6 +488,20 @@ class ConvolutionBuilder(torch.nn.Module):
             self._trace("sort_points_step2", keyGrid)
 
         # neighbours (MCConvBuilder.py:366-376)
+        if fused and currUsePDF and keyNeighs not in self.cacheNeighs_ and keyPDF not in self.cachePDFs_:
+            # search + KDE enqueued back to back (list sizes from the last total of this shape), ONE wait for the edge
+            # count at the end instead of a wait between the two ops; None on the first call of a shape
+            from . import MCConvModule as _hip_ops
+            h = _hip_ops.find_neighbors_pdf_deferred(
+                currOutPointHierarchy.points_[currOutPointLevel], currOutPointHierarchy.batchIds_[currOutPointLevel],
+                currGridTuple[0], currGridTuple[1], currGridTuple[2], inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_,
+                convRadius, inPointHierarchy.batchSize_, currRelativeRadius, currKDEWindow)
+            if h is not None:
+                startIndexs, packedNeighs, pdfsNow = h.finalize()
+                self.cacheNeighs_[keyNeighs] = (startIndexs, packedNeighs)
+                self.cachePDFs_[keyPDF] = pdfsNow
+                self._trace("find_neighbors", keyNeighs)
+                self._trace("compute_pdf", keyPDF)
         if keyNeighs in self.cacheNeighs_:
             currNeighTuple = self.cacheNeighs_[keyNeighs]
         else:
@@ -544,7 +558,7 @@ class ConvolutionBuilder(torch.nn.Module):
                                 currOutPointHierarchy.points_[currOutPointLevel], currNeighTuple[0], currNeighTuple[1],
                                 inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, weights, weights2, weights3, biases,
                                 biases2, biases3, currNumOutFeatures, currMultiFeatureConv, inPointHierarchy.batchSize_,
-                                convRadius, currRelativeRadius, currUseAVG, sortIndex)
+                                convRadius, currRelativeRadius, currUseAVG, sortIndex, True)
         return self.ops_.spatial_conv(currGridTuple[0], sortFeatures, currGridTuple[1], currPDFs,
                             currOutPointHierarchy.points_[currOutPointLevel], currNeighTuple[0], currNeighTuple[1],
                             inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, weights, weights2, weights3, biases,

@@ -1049,16 +1049,27 @@ class _SpatialConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inPts, inFeatures, inBatchIds, inPDFs, inSamplePts, neighStartIndexs, packedNeighs, aabbMin,
                 aabbMax, weights1, biases1, weights2, biases2, weightsOut, biasesOut, numOutFeatures, combin,
-                batchSize, radius, scaleInv, avg, sortIndex=None):
+                batchSize, radius, scaleInv, avg, sortIndex=None, trusted=False):
         op = "SpatialConvOp"
-        pts, feats, bids = _f32(inPts, "points"), _feat(inFeatures, "features"), _i32(inBatchIds, "batch_ids")
+        feats = _feat(inFeatures, "features")
         bf16 = feats.dtype == torch.bfloat16
-        pdfs, smp = _f32(inPDFs, "pdfs"), _f32(inSamplePts, "sample_pts")
-        st, pk = _i32(neighStartIndexs, "start_neighs_indexs"), _i32(packedNeighs, "neighs_indexs")
-        mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
-        w1, b1 = _f32(weights1, "weight_hidden_1"), _f32(biases1, "bias_hidden_1")
-        w2, b2 = _f32(weights2, "weight_hidden_2"), _f32(biases2, "bias_hidden_2")
-        w3, b3 = _f32(weightsOut, "weight_out_layer"), _f32(biasesOut, "bias_out_layer")
+        if trusted:
+            # ConvolutionBuilder's own call: the geometry tensors are outputs of this module's ops and the kernel-MLP
+            # tensors the builder's variables -- types, layouts and the shape rules hold by construction
+            # (the sample points of level 0 are the caller's tensor, and the module may have been cast: those two are
+            # still looked at)
+            pts, bids, pdfs, st, pk, mn, mx = inPts, inBatchIds, inPDFs, neighStartIndexs, packedNeighs, aabbMin, aabbMax
+            smp, w1 = _f32(inSamplePts, "sample_pts"), _f32(weights1, "weight_hidden_1")
+            b1, w2, b2, w3, b3 = biases1, weights2, biases2, weightsOut, biasesOut
+            _req(w3.dtype == torch.float32 and w3.device == w1.device, op + " expects float32 kernel-MLP tensors on one device")
+        else:
+            pts, bids = _f32(inPts, "points"), _i32(inBatchIds, "batch_ids")
+            pdfs, smp = _f32(inPDFs, "pdfs"), _f32(inSamplePts, "sample_pts")
+            st, pk = _i32(neighStartIndexs, "start_neighs_indexs"), _i32(packedNeighs, "neighs_indexs")
+            mn, mx = _f32(aabbMin, "aabb_min"), _f32(aabbMax, "aabb_max")
+            w1, b1 = _f32(weights1, "weight_hidden_1"), _f32(biases1, "bias_hidden_1")
+            w2, b2 = _f32(weights2, "weight_hidden_2"), _f32(biases2, "bias_hidden_2")
+            w3, b3 = _f32(weightsOut, "weight_out_layer"), _f32(biasesOut, "bias_out_layer")
         sidx = None
         if sortIndex is not None:
             # the feature rows arrive in the order of the UNSORTED points: sort_features folded into this node (one
@@ -1068,8 +1079,13 @@ class _SpatialConv(torch.autograd.Function):
                  "SortFeaturesBackGradOp expects features with dimensions (numPoints, numFeatures)")
             feats = _scatter_rows(feats, sidx, feats.shape[0], False)
         sx = () if sidx is None else (sidx,)  # saved with the other tensors: released when the backward pass has run
-        n, m, e, fin = _conv_checks(op, pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3,
-                                    numOutFeatures, combin, batchSize, radius)
+        if trusted:
+            n, m, e, fin = pts.shape[0], smp.shape[0], pdfs.shape[0], feats.shape[1]
+            _req(feats.dim() == 2 and feats.shape[0] == n,
+                 op + " expects as feature inputs the following dimensions (numPoints, numFeatures)")
+        else:
+            n, m, e, fin = _conv_checks(op, pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3,
+                                        numOutFeatures, combin, batchSize, radius)
         lib = _lib.load()
         outF = numOutFeatures if combin else fin
         if _rows_shape(combin, fin, feats, m, e):
@@ -1165,7 +1181,7 @@ class _SpatialConv(torch.autograd.Function):
                                                   ptr(db3), ptr(ws), ws.numel(), stream_handle()),
                   "spatial_conv_grad(rows)")
             return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
-                    None, None, None, None, None, None, None)
+                    None, None, None, None, None, None, None, None)
         ws = _ws(lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, numOutFeatures, int(combin)), pts.device)
         start_t = perm_t = None
         if not combin and e > 0:
@@ -1182,7 +1198,7 @@ class _SpatialConv(torch.autograd.Function):
                                                   ptr(db2), ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
                   "spatial_conv_grad(bf16)")
             return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
-                    None, None, None, None, None, None, None)
+                    None, None, None, None, None, None, None, None)
         check(lib.mccnn_spatial_conv_bwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                          ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
                                          ptr(og), n, m, e, fin, numOutFeatures, int(combin), batchSize, radius,
@@ -1192,7 +1208,7 @@ class _SpatialConv(torch.autograd.Function):
                                          ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
               "spatial_conv_grad")
         return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def _unsort_grad(idx, fg):
@@ -1202,10 +1218,10 @@ def _unsort_grad(idx, fg):
 
 def spatial_conv(inPts, inFeatures, inBatchIds, inPDFs, inSamplePts, neighStartIndexs, packedNeighs, aabbMin, aabbMax,
                  weights1, weights2, weightsOut, biases1, biases2, biasesOut, numOutFeatures, combin, batchSize, radius,
-                 scaleInv, avg, sortIndex=None):
+                 scaleInv, avg, sortIndex=None, _trusted=False):
     """SpatialConv (MCConvModuleSrc:70-81). Note the reference's argument order (weights first, then biases);
     the op itself takes (w1, b1, w2, b2, w3, b3). sortIndex (extension): inFeatures are the rows of the UNSORTED points and
     sortIndex the grid's index_new_pos -- sort_features(inFeatures, sortIndex) happens inside this op."""
     return _SpatialConv.apply(inPts, inFeatures, inBatchIds, inPDFs, inSamplePts, neighStartIndexs, packedNeighs,
                               aabbMin, aabbMax, weights1, biases1, weights2, biases2, weightsOut, biasesOut,
-                              numOutFeatures, combin, batchSize, radius, scaleInv, avg, sortIndex)
+                              numOutFeatures, combin, batchSize, radius, scaleInv, avg, sortIndex, _trusted)
