@@ -327,6 +327,21 @@ class Workload:
                 plan_ms["forward_plan_ms"] = round(plan_of(False)[1], 4)
             if rows_bwd:
                 plan_ms["transposed_plan_ms_excl_transposed_list"] = round(plan_of(True)[1], 4)
+        # combin layers with 2..4 input features: with the neighbour list's transposed form at hand (a training loop gets it
+        # from ConvolutionBuilder.prefetch_geometry for free, on the side stream) the per-edge feature gradients are
+        # gathered in a fixed order instead of added with E x Fin float atomics -- deterministic; timed beside the default
+        det = None
+        if combin and 2 <= fin <= 4:
+            start_t = torch.empty(n + 1, dtype=torch.int32, device=device)
+            perm_t = torch.empty(max(e, 1), dtype=torch.int32, device=device)
+            tws = torch.empty(max(256, lib.mccnn_transpose_neighbors_workspace_bytes(n, e)), dtype=torch.uint8, device=device)
+            t_tr2, _ = ev_time(lambda: check(lib.mccnn_transpose_neighbors(ptr(packed), e, n, ptr(start_t), ptr(perm_t),
+                                                                            ptr(tws), tws.numel(), stream_handle()),
+                                             "transpose_neighbors"))
+            _, t_bdet, _ = conv_times(sF, self.OG, 0)
+            det = {"bwd_ms": round(t_bdet, 4), "transposed_list_ms_once_per_neighbour_list": round(t_tr2, 4),
+                   "note": "feature gradient gathered through the transposed list: no float atomics, bit-reproducible"}
+            start_t = perm_t = None
         # depth-wise layers with bf16 feature rows (extension, BASELINE cfg3): same launches, rows stored as bf16
         bf16 = None
         if not combin and fin % 8 == 0:
@@ -379,6 +394,8 @@ class Workload:
                     "ms": round(ms, 4), "edges": e, "mlp_blocks": nb, "conv_kernels": kernels}
         if plan_ms:
             roofline["row_plans_once_per_neighbour_list"] = plan_ms
+        if det:
+            roofline["deterministic_feature_gradient"] = det
         if bound == "hbm" and dom.startswith("spatial_conv_"):
             # wide depth-wise layer on ONE room: its gathered rows (SURVEY 8d prices the layer by them) are Infinity-Cache
             # hits, not HBM traffic (counter traffic is ~1/3 of the algorithmic bytes), so the HBM peak is the wrong
