@@ -542,22 +542,24 @@ class ConvolutionBuilder(torch.nn.Module):
         # TF fans for a rank-3 variable [numBlocks, bs, bs]: receptive field = numBlocks, fan_in = fan_out = bs*numBlocks
         weights2v = self._get_variable(convName + '_weights2', (numBlocks, blockSize, blockSize), dev,
                                        lambda t: _fan_avg_uniform_(t, numBlocks * blockSize, numBlocks * blockSize))
-        weights2 = weights2v.reshape(blockSize, numBlocks * blockSize)
         self._add_to_collection(self.decayLossCollection_, weights2v)
-        biases2 = self._get_variable(convName + '_biases2', (numBlocks, blockSize), dev, zeros).reshape(nn)
+        biases2v = self._get_variable(convName + '_biases2', (numBlocks, blockSize), dev, zeros)
         weights3v = self._get_variable(convName + '_weights3', (numBlocks, blockSize, blockSize), dev,
                                        lambda t: _fan_avg_uniform_(t, numBlocks * blockSize, numBlocks * blockSize))
-        weights3 = weights3v.reshape(blockSize, numBlocks * blockSize)
         self._add_to_collection(self.decayLossCollection_, weights3v)
-        biases3 = self._get_variable(convName + '_biases3', (numBlocks, blockSize), dev, zeros).reshape(nn)
+        biases3v = self._get_variable(convName + '_biases3', (numBlocks, blockSize), dev, zeros)
 
         self._trace("spatial_conv", convName, (3, nn), currNumOutFeatures, bool(currMultiFeatureConv))
+        if sortIndex is None:
+            weights2, weights3 = weights2v.reshape(blockSize, nn), weights3v.reshape(blockSize, nn)
+            biases2, biases3 = biases2v.reshape(nn), biases3v.reshape(nn)
         if sortIndex is not None:
             from . import MCConvModule as _hip_ops
+            # (the variables in their stored shapes: the op reinterprets them itself, see _SpatialConv.forward)
             return _hip_ops.spatial_conv(currGridTuple[0], sortFeatures, currGridTuple[1], currPDFs,
                                 currOutPointHierarchy.points_[currOutPointLevel], currNeighTuple[0], currNeighTuple[1],
-                                inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, weights, weights2, weights3, biases,
-                                biases2, biases3, currNumOutFeatures, currMultiFeatureConv, inPointHierarchy.batchSize_,
+                                inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, weights, weights2v, weights3v, biases,
+                                biases2v, biases3v, currNumOutFeatures, currMultiFeatureConv, inPointHierarchy.batchSize_,
                                 convRadius, currRelativeRadius, currUseAVG, sortIndex, True)
         return self.ops_.spatial_conv(currGridTuple[0], sortFeatures, currGridTuple[1], currPDFs,
                             currOutPointHierarchy.points_[currOutPointLevel], currNeighTuple[0], currNeighTuple[1],

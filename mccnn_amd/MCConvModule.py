@@ -1053,6 +1053,18 @@ class _SpatialConv(torch.autograd.Function):
         op = "SpatialConvOp"
         feats = _feat(inFeatures, "features")
         bf16 = feats.dtype == torch.bfloat16
+        # the kernel-MLP tensors may arrive in the shapes the builder STORES them in ([numBlocks, bs, bs] / [numBlocks, bs],
+        # MCConvBuilder.py:407-419) -- the same memory as the [bs, numBlocks*bs] / [numBlocks*bs] operands of the op, so the
+        # reshape happens here instead of as four extra nodes of every convolution's graph
+        ctx.wshapes = (weights2.shape, biases2.shape, weightsOut.shape, biasesOut.shape)
+        if weights2.dim() == 3:
+            weights2 = weights2.reshape(weights2.shape[1], -1)
+        if weightsOut.dim() == 3:
+            weightsOut = weightsOut.reshape(weightsOut.shape[1], -1)
+        if biases2.dim() == 2:
+            biases2 = biases2.reshape(-1)
+        if biasesOut.dim() == 2:
+            biasesOut = biasesOut.reshape(-1)
         if trusted:
             # ConvolutionBuilder's own call: the geometry tensors are outputs of this module's ops and the kernel-MLP
             # tensors the builder's variables -- types, layouts and the shape rules hold by construction
@@ -1163,6 +1175,7 @@ class _SpatialConv(torch.autograd.Function):
                             dtype=w1.dtype, device=w1.device)
         dw1, db1, dw2, db2, dw3, db3 = gflat.split([w1.numel(), b1.numel(), w2.numel(), b2.numel(), w3.numel(), b3.numel()])
         dw1, dw2, dw3 = dw1.view_as(w1), dw2.view_as(w2), dw3.view_as(w3)
+        ws2, bs2, ws3, bs3 = ctx.wshapes  # gradients in the shapes the tensors came in
         packed_obj = ctx.packed_ref()
         if packed_obj is None:  # the list object is gone (its cache entry was dropped): the saved tensor has the same rows
             packed_obj = pk
@@ -1180,7 +1193,7 @@ class _SpatialConv(torch.autograd.Function):
                                                   ptr(fg), ptr(scratch), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(dw3),
                                                   ptr(db3), ptr(ws), ws.numel(), stream_handle()),
                   "spatial_conv_grad(rows)")
-            return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
+            return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2.view(ws2), db2.view(bs2), dw3.view(ws3), db3.view(bs3),
                     None, None, None, None, None, None, None, None)
         ws = _ws(lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, numOutFeatures, int(combin)), pts.device)
         start_t = perm_t = None
@@ -1197,7 +1210,7 @@ class _SpatialConv(torch.autograd.Function):
                                                   ptr(start_t), ptr(perm_t), ptr(fg), ptr(dw1), ptr(db1), ptr(dw2),
                                                   ptr(db2), ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
                   "spatial_conv_grad(bf16)")
-            return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
+            return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2.view(ws2), db2.view(bs2), dw3.view(ws3), db3.view(bs3),
                     None, None, None, None, None, None, None, None)
         check(lib.mccnn_spatial_conv_bwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                          ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
@@ -1207,7 +1220,7 @@ class _SpatialConv(torch.autograd.Function):
                                          ptr(db1), ptr(dw2), ptr(db2),
                                          ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
               "spatial_conv_grad")
-        return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2, db2, dw3, db3,
+        return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2.view(ws2), db2.view(bs2), dw3.view(ws3), db3.view(bs3),
                 None, None, None, None, None, None, None, None)
 
 
