@@ -115,10 +115,19 @@ def _tensor_key(t):
     return (t.device.index, t.data_ptr(), t._version, t.shape[0])
 
 
+def _evict_oldest(cache, limit):
+    """Drop the OLDER half of a full hint cache (dicts keep insertion order): the hints of the step in flight are the
+    youngest entries and stay."""
+    if len(cache) > limit:
+        for k in list(cache)[:len(cache) // 2]:
+            del cache[k]
+
+
 def _remember_order(points, kind, payload):
-    if len(_ORDER_HINTS) > 64:
-        _ORDER_HINTS.clear()
-    _ORDER_HINTS[_tensor_key(points)] = [kind, payload, None]
+    _evict_oldest(_ORDER_HINTS, 64)
+    key = _tensor_key(points)
+    _ORDER_HINTS.pop(key, None)  # re-registered: moves to the young end
+    _ORDER_HINTS[key] = [kind, payload, None]
 
 
 def _order_hint(points):
@@ -394,16 +403,20 @@ def prefetch_rowplan(packed, transposed, stream, *args):
 
 def _rows_shape(combin, fin, feats, rows, e, backward=False):
     """Row-per-lane kernels for this (layer, list)? Depth-wise rows of 8-feature blocks. Forward: always (long rows are cut
-    into pieces, lists of short rows put several slices into a workgroup). Backward: not on a LARGE list of very SHORT
-    rows -- below ~16 edges per point the 176-sum sweep pays its per-slice set-up and the padding of the sorted windows
-    too often, and the edge-streaming kernels, whose waves own equal edge ranges, are faster (measured on BASELINE cfg3:
-    DeConv_1, 131 k points x 8.7 edges, 0.54 against 0.42 ms; Pool_2, 41 k x 10.2, 0.19 against 0.27 ms the other way)."""
+    into pieces, lists of short rows put several slices into a workgroup). Backward: the edge-streaming kernels keep
+    LARGE lists (> 500 k edges) unless the layer is wide and its rows long: their waves own equal edge ranges, while the
+    176-sum sweep of the row kernel, two waves per SIMD, has too few (slice, block) items on such a list to hide its
+    quantisation and its per-item reduction when the layer has <= 16 blocks, and pays set-up and window padding too often
+    below ~16 edges per point. Measured (rows against streaming, ms): BASELINE cfg3 Up_1_2 (128 features, 41 k points x
+    18.9 edges) 0.49 / 0.36, Conv_2 (64, 41 k x 25.4) 0.27 / 0.24, DeConv_1 (128, 131 k x 8.7) 0.54 / 0.42; the 100k room
+    (45 edges per point) 64 features 1.07 / 0.87, 128: 1.67 / 1.53, 256: 2.43 / 2.73; cfg3 Up_1_3 (256, 3 495 points x 386)
+    0.77 / 1.18; every list below 500 k edges: rows, by up to 6x on the coarse levels."""
     if not (ROW_KERNELS and _DEBUG_IMPL == 0 and (not combin) and fin % 8 == 0 and e > 0 and rows > 0
             and (feats.data_ptr() & 15) == 0):
         return False
-    if not backward:
+    if not backward or e <= 500000:
         return True
-    return e / float(rows) >= ROWS_MIN_DEGREE or e <= 500000
+    return fin >= 256 and e / float(rows) >= ROWS_MIN_DEGREE
 
 
 def clear_caches():
@@ -464,8 +477,7 @@ def _num_cells(aabbMin, aabbMax, batchSize, cellSize, scaleInv):
         out = C.c_float(0.0)
         check(lib.mccnn_aabb_extent(ptr(aabbMin), ptr(aabbMax), C.byref(out), stream_handle()), "aabb_extent")
         ext = _np.float32(out.value)
-        if len(_NUM_CELLS_CACHE) > 256:
-            _NUM_CELLS_CACHE.clear()
+        _evict_oldest(_NUM_CELLS_CACHE, 256)
         _NUM_CELLS_CACHE[key] = (weakref.ref(aabbMin), weakref.ref(aabbMax), aabbMin._version, aabbMax._version, ext)
     _req(cellSize > 0, "cell size must be positive")
     nc = int(ext / _np.float32(cellSize))   # float32 divide, truncation: sort_gpu.cu:415-416

@@ -692,267 +692,11 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
     }
 }
 
-// ------------------------------------------------------------------------------------------------ depth-wise backward, interleaved
-// The same sweep at ONE wave per SIMD (512 registers): the block's 76 weight operands (forward rows, W3^T, W2^T) stay in
-// registers -- no LDS reads in the loop -- and every iteration processes TWO chunks of 64 edges whose MFMA chains and VALU
-// phases are issued side by side, so the dependent-chain latency of one chunk is covered by the other instead of by a
-// second wave. pre1 / pre2 are kept instead of (a1, mask) pairs: ReLU and ReLU' are recomputed where they are used.
-struct BlockWeightsT {
-    float w3tlo[8], w3thi[8];  // rows i4 / 4 + i4 of W3^T
-    float w2tlo[8], w2thi[8];  // rows i4 / 4 + i4 of W2^T
-};
-__device__ __forceinline__ void load_block_weights_t(const ConvArgs& a, int q, int i4, BlockWeightsT& w) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        w.w3tlo[k] = a.w3[(size_t)q * 64 + k * 8 + i4];
-        w.w3thi[k] = a.w3[(size_t)q * 64 + k * 8 + 4 + i4];
-        w.w2tlo[k] = a.w2[(size_t)q * 64 + k * 8 + i4];
-        w.w2thi[k] = a.w2[(size_t)q * 64 + k * 8 + 4 + i4];
-    }
-}
-struct BwdChunk {
-    float4 rc;
-    float inv;
-    float g[8], pre1[8], pre2[8], x[8];  // x: gf, then t3, then t4
-};
-
-template <int FEAT>
-__global__ __launch_bounds__(256, 1) void dw_bwd_rows_il(ConvArgs a, RowPlan p, const float* __restrict__ outGrad,
-                                                         float* __restrict__ featGrad, float* __restrict__ scratch,
-                                                         float* __restrict__ partials, int spw, int groups) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i4 = lane & 3;
-    const int qTiles = (a.nb + 3) >> 2;
-    const int Lw = xcd_contiguous(blockIdx.x, gridDim.x);
-    if (Lw >= groups * qTiles) return;
-    const int qt = Lw / groups, g = Lw - qt * groups;
-    const int q = qt * 4 + wave;
-    if (q >= a.nb) return;
-    constexpr bool BF = FEAT == 4;
-    const unsigned short* feats16 = reinterpret_cast<const unsigned short*>(a.feats);
-    const unsigned short* og16 = reinterpret_cast<const unsigned short*>(outGrad);
-    unsigned short* fg16 = reinterpret_cast<unsigned short*>(featGrad);
-    BlockWeights w;
-    BlockWeightsT wt;
-    load_block_weights(a, q, i4, w);
-    load_block_weights_t(a, q, i4, wt);
-
-    float gw3[64], gb3[8], gw2[64], gb2[8], gw1[24], gb1[8];
-#pragma unroll
-    for (int k = 0; k < 64; ++k) { gw3[k] = 0.f; gw2[k] = 0.f; }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { gb3[k] = 0.f; gb2[k] = 0.f; gb1[k] = 0.f; }
-#pragma unroll
-    for (int k = 0; k < 24; ++k) gw1[k] = 0.f;
-
-    auto gather = [&](int ci, float* g8) {
-        if (BF) {
-            const uint4 gu = reinterpret_cast<const uint4*>(og16 + (size_t)ci * a.outF)[q];
-            bf16x8_to_f32(gu, g8);
-        } else {
-            const float4* gp = reinterpret_cast<const float4*>(outGrad + (size_t)ci * a.outF + q * 8);
-            const float4 ga = gp[0], gb = gp[1];
-            g8[0] = ga.x; g8[1] = ga.y; g8[2] = ga.z; g8[3] = ga.w; g8[4] = gb.x; g8[5] = gb.y; g8[6] = gb.z; g8[7] = gb.w;
-        }
-    };
-
-    const int sEnd = min((g + 1) * spw, p.S);
-    for (int slice = g * spw; slice < sEnd; ++slice) {
-        const int off = p.sliceOff[slice];
-        const int len = (p.sliceOff[slice + 1] - off) >> 6;
-        if (len == 0) continue;
-        const int r = p.vrow[slice * 64 + lane];
-        const int jr = max(r, 0);
-        float ff[8];
-        if (BF) {
-            const uint4 fu = reinterpret_cast<const uint4*>(feats16 + (size_t)jr * a.Fin)[q];
-            bf16x8_to_f32(fu, ff);
-        } else {
-            const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)jr * a.Fin + q * 8);
-            const float4 fa = fp[0], fb = fp[1];
-            ff[0] = fa.x; ff[1] = fa.y; ff[2] = fa.z; ff[3] = fa.w; ff[4] = fb.x; ff[5] = fb.y; ff[6] = fb.z; ff[7] = fb.w;
-        }
-        float dF[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) dF[n] = 0.f;
-        // records / centre indices of the NEXT pair of chunks are requested one iteration ahead
-        float4 rcA = p.rec[(size_t)off + lane], rcB = p.rec[(size_t)off + (size_t)min(1, len - 1) * 64 + lane];
-        int ciA = p.other[(size_t)off + lane], ciB = p.other[(size_t)off + (size_t)min(1, len - 1) * 64 + lane];
-        for (int it = 0; it < len; it += 2) {
-            BwdChunk A, B;
-            A.rc = rcA; B.rc = rcB;
-            A.inv = rcA.w;
-            B.inv = (it + 1 < len) ? rcB.w : 0.f;  // an odd tail: the second chunk repeats the last one with weight zero
-            gather(ciA, A.g);
-            gather(ciB, B.g);
-            {
-                const size_t sA = (size_t)off + (size_t)min(it + 2, len - 1) * 64 + lane;
-                const size_t sB = (size_t)off + (size_t)min(it + 3, len - 1) * 64 + lane;
-                rcA = p.rec[sA]; ciA = p.other[sA];
-                rcB = p.rec[sB]; ciB = p.other[sB];
-            }
-            float a1A[8], a1B[8], a2A[8], a2B[8], oA[8], oB[8];
-            // ---- layer 1 (MFMA), both chunks
-            MCCNN_PHASE();
-            {
-                const float one = opaque_one();
-                f32x4 loA = {0.f, 0.f, 0.f, 0.f}, hiA = loA, loB = loA, hiB = loA;
-                loA = MFMA4(w.w1lo[0], A.rc.x, loA); hiA = MFMA4(w.w1hi[0], A.rc.x, hiA);
-                loB = MFMA4(w.w1lo[0], B.rc.x, loB); hiB = MFMA4(w.w1hi[0], B.rc.x, hiB);
-                loA = MFMA4(w.w1lo[1], A.rc.y, loA); hiA = MFMA4(w.w1hi[1], A.rc.y, hiA);
-                loB = MFMA4(w.w1lo[1], B.rc.y, loB); hiB = MFMA4(w.w1hi[1], B.rc.y, hiB);
-                loA = MFMA4(w.w1lo[2], A.rc.z, loA); hiA = MFMA4(w.w1hi[2], A.rc.z, hiA);
-                loB = MFMA4(w.w1lo[2], B.rc.z, loB); hiB = MFMA4(w.w1hi[2], B.rc.z, hiB);
-                loA = MFMA4(w.w1lo[3], one, loA); hiA = MFMA4(w.w1hi[3], one, hiA);
-                loB = MFMA4(w.w1lo[3], one, loB); hiB = MFMA4(w.w1hi[3], one, hiB);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { A.pre1[k] = loA[k]; A.pre1[4 + k] = hiA[k]; B.pre1[k] = loB[k]; B.pre1[4 + k] = hiB[k]; }
-            }
-            MCCNN_PHASE();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { a1A[k] = relu1(A.pre1[k]); a1B[k] = relu1(B.pre1[k]); }
-            MCCNN_PHASE();
-            // ---- layer 2
-            {
-                const float one = opaque_one();
-                f32x4 loA = {0.f, 0.f, 0.f, 0.f}, hiA = loA, loB = loA, hiB = loA;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    loA = MFMA4(w.w2lo[k], a1A[k], loA); hiA = MFMA4(w.w2hi[k], a1A[k], hiA);
-                    loB = MFMA4(w.w2lo[k], a1B[k], loB); hiB = MFMA4(w.w2hi[k], a1B[k], hiB);
-                }
-                loA = MFMA4(w.b2lo, one, loA); hiA = MFMA4(w.b2hi, one, hiA);
-                loB = MFMA4(w.b2lo, one, loB); hiB = MFMA4(w.b2hi, one, hiB);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { A.pre2[k] = loA[k]; A.pre2[4 + k] = hiA[k]; B.pre2[k] = loB[k]; B.pre2[4 + k] = hiB[k]; }
-            }
-            MCCNN_PHASE();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { a2A[k] = relu1(A.pre2[k]); a2B[k] = relu1(B.pre2[k]); }
-            MCCNN_PHASE();
-            // ---- layer 3
-            {
-                const float one = opaque_one();
-                f32x4 loA = {0.f, 0.f, 0.f, 0.f}, hiA = loA, loB = loA, hiB = loA;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    loA = MFMA4(w.w3lo[k], a2A[k], loA); hiA = MFMA4(w.w3hi[k], a2A[k], hiA);
-                    loB = MFMA4(w.w3lo[k], a2B[k], loB); hiB = MFMA4(w.w3hi[k], a2B[k], hiB);
-                }
-                loA = MFMA4(w.b3lo, one, loA); hiA = MFMA4(w.b3hi, one, hiA);
-                loB = MFMA4(w.b3lo, one, loB); hiB = MFMA4(w.b3hi, one, hiB);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { oA[k] = loA[k]; oA[4 + k] = hiA[k]; oB[k] = loB[k]; oB[4 + k] = hiB[k]; }
-            }
-            MCCNN_PHASE();
-            // ---- feature gradient, gf, dW3 / db3 (VALU), chunk A then chunk B (fixed order: the sums are reproducible)
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                dF[n] = __builtin_fmaf(A.g[n] * A.inv, oA[n], dF[n]);
-                dF[n] = __builtin_fmaf(B.g[n] * B.inv, oB[n], dF[n]);
-                A.x[n] = A.g[n] * ff[n];
-                B.x[n] = B.g[n] * ff[n];
-            }
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                const float uA = A.x[n] * A.inv, uB = B.x[n] * B.inv;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    gw3[n * 8 + k] = fmaf(uA, a2A[k], gw3[n * 8 + k]);
-                    gw3[n * 8 + k] = fmaf(uB, a2B[k], gw3[n * 8 + k]);
-                }
-                gb3[n] += uA;
-                gb3[n] += uB;
-            }
-            MCCNN_PHASE();
-            // ---- t3 = 1[pre2 >= 0] W3^T (g f) / (pdf K)
-            {
-                f32x4 loA = {0.f, 0.f, 0.f, 0.f}, hiA = loA, loB = loA, hiB = loA;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    loA = MFMA4(wt.w3tlo[k], A.x[k], loA); hiA = MFMA4(wt.w3thi[k], A.x[k], hiA);
-                    loB = MFMA4(wt.w3tlo[k], B.x[k], loB); hiB = MFMA4(wt.w3thi[k], B.x[k], hiB);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { A.x[k] = loA[k]; A.x[4 + k] = hiA[k]; B.x[k] = loB[k]; B.x[4 + k] = hiB[k]; }
-            }
-            MCCNN_PHASE();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                A.x[k] = (A.pre2[k] >= 0.0f) ? A.x[k] * A.inv : 0.f;
-                B.x[k] = (B.pre2[k] >= 0.0f) ? B.x[k] * B.inv : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-#pragma unroll
-                for (int l = 0; l < 8; ++l) {
-                    gw2[k * 8 + l] = fmaf(A.x[k], a1A[l], gw2[k * 8 + l]);
-                    gw2[k * 8 + l] = fmaf(B.x[k], a1B[l], gw2[k * 8 + l]);
-                }
-                gb2[k] += A.x[k];
-                gb2[k] += B.x[k];
-            }
-            MCCNN_PHASE();
-            // ---- t4 = 1[pre1 >= 0] W2^T t3
-            {
-                f32x4 loA = {0.f, 0.f, 0.f, 0.f}, hiA = loA, loB = loA, hiB = loA;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    loA = MFMA4(wt.w2tlo[k], A.x[k], loA); hiA = MFMA4(wt.w2thi[k], A.x[k], hiA);
-                    loB = MFMA4(wt.w2tlo[k], B.x[k], loB); hiB = MFMA4(wt.w2thi[k], B.x[k], hiB);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { A.x[k] = loA[k]; A.x[4 + k] = hiA[k]; B.x[k] = loB[k]; B.x[4 + k] = hiB[k]; }
-            }
-            MCCNN_PHASE();
-#pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                const float vA = (A.pre1[l] >= 0.0f) ? A.x[l] : 0.f;
-                const float vB = (B.pre1[l] >= 0.0f) ? B.x[l] : 0.f;
-                gw1[l * 3] = fmaf(vA, A.rc.x, gw1[l * 3]);
-                gw1[l * 3 + 1] = fmaf(vA, A.rc.y, gw1[l * 3 + 1]);
-                gw1[l * 3 + 2] = fmaf(vA, A.rc.z, gw1[l * 3 + 2]);
-                gw1[l * 3] = fmaf(vB, B.rc.x, gw1[l * 3]);
-                gw1[l * 3 + 1] = fmaf(vB, B.rc.y, gw1[l * 3 + 1]);
-                gw1[l * 3 + 2] = fmaf(vB, B.rc.z, gw1[l * 3 + 2]);
-                gb1[l] += vA;
-                gb1[l] += vB;
-            }
-        }
-        const int code = p.vcode[slice * 64 + lane];
-        if (r >= 0 && code >= 0) {  // a piece of a cut row
-            float4* dst = reinterpret_cast<float4*>(scratch + (size_t)code * a.Fin + q * 8);
-            dst[0] = make_float4(dF[0], dF[1], dF[2], dF[3]);
-            dst[1] = make_float4(dF[4], dF[5], dF[6], dF[7]);
-        } else if (r >= 0) {
-            if (BF) {
-                reinterpret_cast<uint4*>(fg16 + (size_t)r * a.Fin)[q] = f32x8_to_bf16(dF);
-            } else {
-                float4* dst = reinterpret_cast<float4*>(featGrad + (size_t)r * a.Fin + q * 8);
-                dst[0] = make_float4(dF[0], dF[1], dF[2], dF[3]);
-                dst[1] = make_float4(dF[4], dF[5], dF[6], dF[7]);
-            }
-        }
-    }
-    {
-        float r2 = wave_reduce64(gw2, lane);
-        float r3 = wave_reduce64(gw3, lane);
-        float misc[64];
-#pragma unroll
-        for (int k = 0; k < 24; ++k) misc[k] = gw1[k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { misc[24 + k] = gb1[k]; misc[32 + k] = gb2[k]; misc[40 + k] = gb3[k]; }
-#pragma unroll
-        for (int k = 48; k < 64; ++k) misc[k] = 0.f;
-        float rm = wave_reduce64(misc, lane);
-        float* pq = partials + ((size_t)g * a.nb + q) * 176;
-        pq[32 + lane] = r2;
-        pq[104 + lane] = r3;
-        if (lane < 32) pq[lane] = rm;
-        else if (lane < 40) pq[96 + lane - 32] = rm;
-        else if (lane < 48) pq[168 + lane - 40] = rm;
-    }
-}
-
+// (Measured and dropped, commit before this one: the same sweep at ONE wave per SIMD -- 256 VGPRs + 166 AGPRs, the block's
+// 76 weight operands in registers instead of LDS, two chunks of 64 edges per iteration with their MFMA chains and VALU
+// phases issued side by side, pre-activations kept instead of (activation, mask) pairs: 3.90 ms against 2.43 ms for dw256
+// on the room. A second wave hides more latency than a second chunk in the same wave, whose values have to travel
+// through the accumulation registers.)
 // defined in conv.hip
 void launch_reduce_partials(const float* partials, int rows, int nb, float* dw1, float* db1, float* dw2, float* db2,
                             float* dw3, float* db3, hipStream_t s);
@@ -1219,11 +963,7 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
     if (blocks > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     float* partials = reinterpret_cast<float*>(ws);
     const size_t lds = ((size_t)4 * MCCNN_WQ_BWD + 4 * 512) * sizeof(float);  // 4 blocks of weights + the parked feature pieces
-    static const bool interleaved = getenv("MCCNN_BWD_IL") && atoi(getenv("MCCNN_BWD_IL")) != 0;  // A/B switch, read once
-    if (interleaved) {
-        if (bf16) dw_bwd_rows_il<4><<<(int)blocks, 256, 0, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
-        else dw_bwd_rows_il<2><<<(int)blocks, 256, 0, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
-    } else if (bf16) dw_bwd_rows<4><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
+    if (bf16) dw_bwd_rows<4><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
     else dw_bwd_rows<2><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
     MCCNN_LAUNCHED();
     if (bf16) launch_combine<true>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s);
