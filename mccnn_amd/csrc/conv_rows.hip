@@ -28,9 +28,6 @@ constexpr int SELL_SIGMA = 1024;
 // 64 ROWS_L + (its edges) slots -- hence plans are laid out and filled WITHOUT any size read-back. The pieces of a cut
 // row leave their partial sums in a scratch row each; a small pass adds them in order (deterministic).
 constexpr int ROWS_L = 128;  // longest virtual row; lists with few rows use shorter ones (plan_sizes) to fill the chip
-#ifndef MCCNN_ROWS_ABL
-#define MCCNN_ROWS_ABL 0
-#endif
 
 // Workgroup ids are handed to the 8 XCDs round-robin (id % 8): logical index with every XCD owning one contiguous
 // eighth of [0, grid). grid must be a multiple of 8 (the launchers pad; surplus indices exit).
@@ -190,16 +187,62 @@ __global__ __launch_bounds__(256) void plan_small(const int* __restrict__ rowSta
     }
 }
 
-// One workgroup per window of SELL_SIGMA virtual rows: bitonic sort of unique keys (descending length, then position) ->
-// the layout is a deterministic function of the list, so gradients are bit-reproducible run to run.
+// One workgroup per window of SELL_SIGMA virtual rows: a STABLE sort by descending length (ties keep the visiting order) ->
+// the layout is a deterministic function of the list, so gradients are bit-reproducible run to run. Lengths are at most
+// ROWS_L: the key (L - len, padding last) has 8 bits and the sort is two 4-bit passes of a least-significant-digit radix
+// sort -- per pass 16 ballots per element slot, one 256-entry scan, two barriers -- instead of the 55 barrier-separated
+// stages of a bitonic network over 1024 keys (27 us per launch whatever the list, 14-16 launches per step of a
+// segmentation network; ~8 us now).
+__device__ __forceinline__ void sell_radix_pass(const unsigned* __restrict__ src, unsigned* __restrict__ dst, int shift,
+                                                int* __restrict__ cnt /* [16 digits][16 = slot * 4 + wave] */,
+                                                int* __restrict__ wsum /* 5 */) {
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    unsigned key[4];
+    int rank[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        key[i] = src[i * 256 + t];
+        const int d = (int)((key[i] >> (10 + shift)) & 15u);
+        rank[i] = 0;
+#pragma unroll
+        for (int dd = 0; dd < 16; ++dd) {
+            const unsigned long long m = __ballot(d == dd);
+            if (d == dd) rank[i] = __popcll(m & lt);
+            if (lane == 0) cnt[dd * 16 + i * 4 + wave] = __popcll(m);
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the 256 counters in (digit, slot, wave) order
+        const int v = cnt[t];
+        const int incl = wave_incl_scan(v);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < wave; ++k) base += wsum[k];
+        __syncthreads();
+        cnt[t] = base + incl - v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = (int)((key[i] >> (10 + shift)) & 15u);
+        dst[cnt[d * 16 + i * 4 + wave] + rank[i]] = key[i];
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStart, int rows, int e,
                                                  const int* __restrict__ vlistRow, const int* __restrict__ vposRow,
                                                  const int* __restrict__ vTotal, int* __restrict__ vrow,
                                                  int* __restrict__ vcode, int* __restrict__ sliceSlots, int L) {
     __shared__ unsigned key[SELL_SIGMA];
+    __shared__ unsigned key2[SELL_SIGMA];
     __shared__ int rowOf[SELL_SIGMA];
     __shared__ int lenOf[SELL_SIGMA];
     __shared__ int cutOf[SELL_SIGMA];
+    __shared__ int cnt[256];
+    __shared__ int wsum[5];
     const int V = *vTotal;
     const int w0 = blockIdx.x * SELL_SIGMA;
     for (int k = threadIdx.x; k < SELL_SIGMA; k += 256) {
@@ -218,18 +261,8 @@ __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStar
         key[k] = ((v < V ? (unsigned)(L - len) : (unsigned)(L + 1)) << 10) | (unsigned)k;  // padding sorts last
     }
     __syncthreads();
-    for (int size = 2; size <= SELL_SIGMA; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < SELL_SIGMA / 2; t += 256) {
-                const int lo = ((t / stride) * stride * 2) + (t % stride);
-                const int hi = lo + stride;
-                const bool up = ((lo & size) == 0);
-                const unsigned a = key[lo], b = key[hi];
-                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
-            }
-            __syncthreads();
-        }
-    }
+    sell_radix_pass(key, key2, 0, cnt, wsum);
+    sell_radix_pass(key2, key, 4, cnt, wsum);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int g = wave; g < SELL_SIGMA / 64; g += 4) {
         const int slice = w0 / 64 + g;
