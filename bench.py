@@ -510,9 +510,11 @@ class ConfigWorkload:
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
+        t_issue = time.perf_counter() - t0   # the host has enqueued the last launch (edge-count waits included)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         launches = (self.lib.mccnn_debug_launch_count() - l0) / float(steps)
+        self.host_issue_ms = t_issue / steps * 1e3
         return el / steps * 1e3, launches
 
     def per_layer(self, iters=5):
@@ -667,7 +669,9 @@ def run_config(name, device, args, want_cpu):
     t_h, layers, sizes = cw.per_layer()
     ent = {"workload": cfg.what, "points": n, "clouds": cw.B, "level_sizes": sizes, "convolutions": len(cfg.convs),
            "steps": steps, "ms_per_step": round(ms, 4), "value": round(n / (ms * 1e-3), 1), "unit": "points/s",
-           "library_launches_per_step": round(launches, 1), "hierarchy_ms": round(t_h, 4),
+           "library_launches_per_step": round(launches, 1),
+           # when this equals ms_per_step the step is bound by the HOST issuing its launches, not by the kernels
+           "host_issue_ms_per_step": round(cw.host_issue_ms, 4), "hierarchy_ms": round(t_h, 4),
            "conv_fwd_bwd_ms_cached_geometry": round(sum(l["fwd_ms"] + l["bwd_ms"] for l in layers), 4),
            "layers": layers}
     if want_cpu:
