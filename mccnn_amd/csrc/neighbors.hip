@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                                                     float radius, int scaleInv, const int* __restrict__ order,
                                                     int* __restrict__ cnt, unsigned long long* __restrict__ masks,
                                                     const int* __restrict__ startIdx, int* __restrict__ packed,
-                                                    int capacity, unsigned long long* __restrict__ zeroWords, int numZero) {
+                                                    int capacity, unsigned long long* __restrict__ zeroWords, int numZero,
+                                                    int G /* centres per wave, 1 .. MCCNN_NW_G */) {
     constexpr bool FILL = MODE == 1;
     // the status words of the prefix sum that follows the count pass (scan.hip): cleared here, no launch of their own
     if (!FILL && blockIdx.x == 0)
@@ -82,19 +83,19 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
     __shared__ float4 win[4][MCCNN_NW_CAP];
     __shared__ int2 ctab[4][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g0 = (xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave) * MCCNN_NW_G;
+    const int g0 = (xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave) * G;
     if (g0 >= m) return;
     float4* lw = win[wave];
     int2* tab = ctab[wave];
     // lanes 0..7: one centre each
     const int ci = g0 + lane;
-    const bool own = lane < MCCNN_NW_G && ci < m;
+    const bool own = lane < G && ci < m;
     const int i = own ? (order ? order[ci] : ci) : 0;
     CentreCtx c = centre_ctx(centres, cb, mn, mx, i, B, nc, radius, scaleInv);
     const int key = own ? ((c.b * nc + c.x) * nc + c.y) * nc + c.z : -1;
     int count = 0;                                   // hits of this lane's centre so far
     const int base = (FILL && own) ? startIdx[i] : 0;
-    unsigned todo = (unsigned)(__ballot(own) & ((1ull << MCCNN_NW_G) - 1));
+    unsigned todo = (unsigned)(__ballot(own) & ((1ull << G) - 1));
     const int2* ct = reinterpret_cast<const int2*>(cells);
     int2* out = reinterpret_cast<int2*>(packed);
     while (todo) {
@@ -359,12 +360,17 @@ __device__ __forceinline__ PdfPoint pdf_gather(const float* __restrict__ pts, in
 
 // Row longer than the tile planes hold: subtract-first pair loop (the arithmetic of pdf_row_scalar) with the row staged
 // through the wave's LDS planes MCCNN_PDF_CAP points at a time (one broadcast ds_read_b128 per pair step).
-__device__ __noinline__ void pdf_row_long(const float* __restrict__ pts, const int2* __restrict__ rowpk, int k, int rowStart,
+// aBegin / aStep: the row's blocks of 64 output values are shared out over the waves of the workgroup (a row of k points
+// costs k^2 pair terms: walked by ONE wave, the longest row of a pooling list -- 6 344 centres with 218 neighbours on
+// average, some with > 1 000 -- alone set the kernel's time: 597 us on BASELINE cfg2 Pool_1).
+// (force-inlined: through a non-inlined call the LDS planes arrive as a generic pointer and every pair step became a
+// FLAT load with a full wait -- 0.58 T pair terms/s on BASELINE cfg2 Pool_1 against 3.2 T on the tile path)
+__device__ __forceinline__ void pdf_row_long(const float* __restrict__ pts, const int2* __restrict__ rowpk, int k, int rowStart,
                                           int lane, float s, float scale, float* __restrict__ P,
-                                          float* __restrict__ pdfs) {
+                                          float* __restrict__ pdfs, int aBegin, int aStep) {
     float4* __restrict__ P4 = reinterpret_cast<float4*>(P);
     const float cc = (-0.5f * 1.44269504088896f) * (s * s);
-    for (int a0 = 0; a0 < k; a0 += 64) {
+    for (int a0 = aBegin; a0 < k; a0 += aStep) {
         const int a = a0 + lane;
         const PdfPoint me = pdf_gather(pts, rowpk[min(a, k - 1)].x);
         float acc = 0.f;
@@ -379,6 +385,7 @@ __device__ __noinline__ void pdf_row_long(const float* __restrict__ pts, const i
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
             for (int t = 0; t < nb; ++t) {
                 const float4 q = P4[t];
                 const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
@@ -391,16 +398,25 @@ __device__ __noinline__ void pdf_row_long(const float* __restrict__ pts, const i
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(256) void pdf_rows_mfma(const float* __restrict__ pts, const int* __restrict__ bids,
+struct PdfLongRow { int rowStart, k; float s, scale; };
+template <int WAVES>  // 4: lists of many rows (4 rows per wave); 16: lists of few rows (one row per wave)
+__global__ __launch_bounds__(WAVES * 64) void pdf_rows_mfma(const float* __restrict__ pts, const int* __restrict__ bids,
                                                      const int2* __restrict__ packed, const int* __restrict__ startIdx,
                                                      int m, int e, const float* __restrict__ mn,
                                                      const float* __restrict__ mx, int B, float window, float radius,
                                                      int scaleInv, float* __restrict__ pdfs,
                                                      const int* __restrict__ eDev, int rowsPerWave) {
-    __shared__ __attribute__((aligned(16))) float planes[4][5 * MCCNN_PDF_CAP];  // per wave: ux, uy, uz, q, ones
+    __shared__ __attribute__((aligned(16))) float planes[WAVES][5 * MCCNN_PDF_CAP];  // per wave: ux, uy, uz, q, ones
+    // rows longer than the planes: set aside here and walked by ALL waves of the workgroup afterwards (pdf_row_long)
+    __shared__ PdfLongRow longRows[WAVES * MCCNN_PDF_ROWS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform: rows, tile counts and loops live in SGPRs
-    const int r0 = (blockIdx.x * 4 + wave) * rowsPerWave;
-    if (r0 >= m) return;
+    for (int t = threadIdx.x; t < WAVES * MCCNN_PDF_ROWS; t += WAVES * 64) longRows[t].k = 0;
+    __syncthreads();
+    const int r0 = (blockIdx.x * WAVES + wave) * rowsPerWave;
+    float* __restrict__ P = planes[wave];
+    const int c = lane >> 4, mm = lane & 15;
+    const float bscale = (c == 3) ? 1.0f : -2.0f;
+    if (r0 < m) {
     const int nr = min(rowsPerWave, m - r0);
     const int cap = e;
     if (eDev) e = min(e, max(*eDev, 0));
@@ -411,12 +427,9 @@ __global__ __launch_bounds__(256) void pdf_rows_mfma(const float* __restrict__ p
     const float invH = 1.0f / window;
     const float g1 = invH * 0.39894228f;
     const float norm = g1 * g1 * g1;
-    float* __restrict__ P = planes[wave];
-    const int c = lane >> 4, mm = lane & 15;
     const float* __restrict__ pb = P + c * MCCNN_PDF_CAP + mm;                   // B: component c of point 16 t + mm (c = 3: q)
     const float* __restrict__ pa = P + (c == 3 ? 4 : c) * MCCNN_PDF_CAP + mm;    // A: the same, with 1 in place of q
     const float* __restrict__ pq = P + 3 * MCCNN_PDF_CAP + 4 * c;                // C: q of points 16 t + 4 c + (0..3)
-    const float bscale = (c == 3) ? 1.0f : -2.0f;
     for (int t = lane; t < MCCNN_PDF_CAP; t += 64) P[4 * MCCNN_PDF_CAP + t] = 1.0f;
     // 1 / (R h): one value for all clouds with an absolute radius, per row otherwise
     float sAbs = 0.f;
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(256) void pdf_rows_mfma(const float* __restrict__ p
         }
         const float scale = norm * __builtin_amdgcn_rcpf((float)k);  // 1 ulp: this mode is not the bit-exact one
         if (k > MCCNN_PDF_CAP) {
-            pdf_row_long(pts, rowpk, k, rowStart, lane, s, scale, P, pdfs);
+            if (lane == 0) longRows[wave * MCCNN_PDF_ROWS + rr] = PdfLongRow{rowStart, k, s, scale};
             continue;
         }
 #if defined(MCCNN_PDF_ABL) && MCCNN_PDF_ABL == 2
@@ -529,6 +542,78 @@ __global__ __launch_bounds__(256) void pdf_rows_mfma(const float* __restrict__ p
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    }  // r0 < m
+    __syncthreads();
+    // A long row that fits the POOLED planes of the workgroup (WAVES x MCCNN_PDF_CAP points: 3 072 with 16 waves) is
+    // staged once by all threads and its 16 x 16 tiles are shared out by column block: the same Gram-matrix arithmetic
+    // as the short rows, at the matrix cores' rate (the subtract-first loop below runs at a third of it).
+    constexpr int LC = WAVES * MCCNN_PDF_CAP;
+    float* __restrict__ pool = &planes[0][0];
+    int item = 0;
+    for (int t = 0; t < WAVES * MCCNN_PDF_ROWS; ++t) {
+        const PdfLongRow lr = longRows[t];
+        if (lr.k <= 0) continue;
+        if (lr.k <= LC) {
+            const int k = lr.k, T = (k + 15) >> 4;
+            const int2* __restrict__ rowpk = packed + lr.rowStart;
+            const PdfPoint o = pdf_gather(pts, rowpk[0].x);  // the row's first point: every difference is within 2 R of it
+            const float sp = lr.s * 0.84932180f;
+            __syncthreads();  // the planes are free (the waves' own rows, the previous long row)
+            for (int a = threadIdx.x; a < 16 * T; a += WAVES * 64) {
+                const PdfPoint q = pdf_gather(pts, rowpk[min(a, k - 1)].x);
+                const float ux = (q.x - o.x) * sp, uy = (q.y - o.y) * sp, uz = (q.z - o.z) * sp;
+                pool[a] = ux;
+                pool[LC + a] = uy;
+                pool[2 * LC + a] = uz;
+                pool[3 * LC + a] = (a < k) ? fmaf(uz, uz, fmaf(uy, uy, ux * ux)) : 3.0e38f;
+                pool[4 * LC + a] = 1.0f;
+            }
+            __syncthreads();
+            const float* __restrict__ pbL = pool + c * LC + mm;
+            const float* __restrict__ paL = pool + (c == 3 ? 4 : c) * LC + mm;
+            const float* __restrict__ pqL = pool + 3 * LC + 4 * c;
+            for (int J = wave; J < T; J += WAVES) {
+                const float bop = pbL[16 * J] * bscale;
+                float acc0 = 0.f, acc1 = 0.f;
+                int I = 0;
+                for (; I + 2 <= T; I += 2) {
+                    const float a0 = paL[16 * I], a1 = paL[16 * I + 16];
+                    const pdf_v4f c0 = *reinterpret_cast<const pdf_v4f*>(pqL + 16 * I);
+                    const pdf_v4f c1 = *reinterpret_cast<const pdf_v4f*>(pqL + 16 * I + 16);
+                    const pdf_v4f d0 = PDF_MFMA(a0, bop, c0);
+                    const pdf_v4f d1 = PDF_MFMA(a1, bop, c1);
+                    acc0 += (PDF_EXP(-d0[0]) + PDF_EXP(-d0[1])) + (PDF_EXP(-d0[2]) + PDF_EXP(-d0[3]));
+                    acc1 += (PDF_EXP(-d1[0]) + PDF_EXP(-d1[1])) + (PDF_EXP(-d1[2]) + PDF_EXP(-d1[3]));
+                }
+                if (T & 1) {
+                    const float a0 = paL[16 * I];
+                    const pdf_v4f c0 = *reinterpret_cast<const pdf_v4f*>(pqL + 16 * I);
+                    const pdf_v4f d0 = PDF_MFMA(a0, bop, c0);
+                    acc0 += (PDF_EXP(-d0[0]) + PDF_EXP(-d0[1])) + (PDF_EXP(-d0[2]) + PDF_EXP(-d0[3]));
+                }
+                float acc = acc0 + acc1;
+                {
+                    float lo = acc, hi = acc;
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+                    acc = lo + hi;
+                    lo = acc;
+                    hi = acc;
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+                    acc = lo + hi;
+                }
+                const int a = 16 * J + mm;
+                if (c == 0 && a < k) pdfs[lr.rowStart + a] = acc * lr.scale;
+            }
+            continue;
+        }
+        // beyond the pooled planes: work items = (row, block of 64 output values) dealt round-robin to the waves, the
+        // subtract-first loop with the row streamed through each wave's own planes
+        __syncthreads();
+        const int blocks = (lr.k + 63) >> 6;
+        for (int b = (wave - item % WAVES + WAVES) % WAVES; b < blocks; b += WAVES)
+            pdf_row_long(pts, packed + lr.rowStart, lr.k, lr.rowStart, lane, lr.s, lr.scale, P, pdfs, b * 64, 1 << 30);
+        item += blocks;
+    }
 }
 
 }  // namespace mccnn
@@ -542,6 +627,11 @@ size_t mccnn_find_neighbors_workspace_bytes(int m, int n) {
     (void)n;
     return align_up(m1 * 4) + scan_workspace_bytes((int)m1) + align_up(m1 * MCCNN_NW_ROUNDS * sizeof(unsigned long long)) + 256;
 }
+
+// Centres per wave: 8 consecutive centres of the visiting order share most of their windows on a large list (~8 points
+// per cell), but a list with few centres needs the waves -- 6 344 pooling centres with ~900 candidates each ran 139 us per
+// pass on 793 waves (BASELINE cfg2 Pool_1), the coarse levels of a hierarchy 20 us on a handful.
+static int neigh_group(int m) { return m >= 32768 ? MCCNN_NW_G : (m >= 16384 ? 4 : (m >= 8192 ? 2 : 1)); }
 
 struct NeighWs {
     int* cnt;  // hits per centre
@@ -573,10 +663,11 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
         return MCCNN_E_BADARG;
     NeighWs w;
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
-    neigh_window<0><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
-                                                              aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, w.cnt,
-                                                              w.masks, nullptr, nullptr, 0, (unsigned long long*)w.scanws,
-                                                              (int)(scan_status_bytes(m) / sizeof(unsigned long long)));
+    const int G = neigh_group(m);
+    neigh_window<0><<<ceil_div(m, 4 * G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
+                                                     aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, w.cnt,
+                                                     w.masks, nullptr, nullptr, 0, (unsigned long long*)w.scanws,
+                                                     (int)(scan_status_bytes(m) / sizeof(unsigned long long)), G);
     MCCNN_LAUNCHED();
     int rc = exclusive_scan_i32(w.cnt, start_idx, m, total_dev, w.scanws, s, true);
     if (rc) return rc;
@@ -595,9 +686,10 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     NeighWs w;
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    neigh_window<1><<<ceil_div(m, 4 * MCCNN_NW_G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
-                                                              aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, nullptr,
-                                                              w.masks, start_idx, packed, e, nullptr, 0);
+    const int G = neigh_group(m);
+    neigh_window<1><<<ceil_div(m, 4 * G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
+                                                     aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, nullptr,
+                                                     w.masks, start_idx, packed, e, nullptr, 0, G);
     MCCNN_LAUNCHED();
     return 0;
 }
@@ -640,9 +732,14 @@ static int compute_pdf_impl(const float* sorted_pts, const int* sorted_batch_ids
         } else {
             // rows per wave: 4 consecutive rows let the next row's points fly under this row's tiles, but a list with few
             // (long) rows needs the waves -- 279 centres of 141 neighbours (BASELINE cfg1 Conv_2) ran 123 us on 70 waves
-            const int rpw = (m >= 16384) ? MCCNN_PDF_ROWS : 1;
-            pdf_rows_mfma<<<ceil_div(m, 4 * rpw), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, start_idx, m, e, aabb_min, aabb_max,
-                                                              batch_size, window, radius, scale_inv, pdfs, e_dev, rpw);
+            // (and 16 waves per workgroup: a row longer than the tile planes is walked by all of them)
+            if (m >= 16384)
+                pdf_rows_mfma<4><<<ceil_div(m, 4 * MCCNN_PDF_ROWS), 256, 0, s>>>(sorted_pts, sorted_batch_ids, pk, start_idx, m, e, aabb_min,
+                                                                                aabb_max, batch_size, window, radius, scale_inv, pdfs,
+                                                                                e_dev, MCCNN_PDF_ROWS);
+            else
+                pdf_rows_mfma<16><<<ceil_div(m, 16), 1024, 0, s>>>(sorted_pts, sorted_batch_ids, pk, start_idx, m, e, aabb_min, aabb_max,
+                                                                  batch_size, window, radius, scale_inv, pdfs, e_dev, 1);
         }
     }
     MCCNN_LAUNCHED();

@@ -414,7 +414,9 @@ def test_pdf_row_lengths_at_tile_and_plane_boundaries(mc, oracle):
     plane capacity of the matrix-core kernel (rows above it take its subtract-first loop): clusters of k points, each
     inside a ball of diameter < r and far from the next one, so that every centre of a cluster has the whole cluster --
     and nothing else -- as its row."""
-    ks = [1, 2, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 100, 127, 128, 129, 191, 192, 193, 257, 400]
+    # (257 .. 700: long rows on the workgroup's POOLED planes, 16 x 192 points here; rows beyond a pool take the streamed
+    # loop -- covered by the next test, where the pool is 768 points)
+    ks = [1, 2, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 100, 127, 128, 129, 191, 192, 193, 257, 400, 700]
     rng = np.random.default_rng(23)
     r = 0.1
     pts = []
@@ -432,5 +434,31 @@ def test_pdf_row_lengths_at_tile_and_plane_boundaries(mc, oracle):
     o = run_chain(oracle, _ident, _ident, pts, bids, feats, 1, r, False)
     klen = np.diff(np.append(o["startIndexs"][:, 0], len(o["packedNeighs"])))
     assert sorted(set(klen.tolist())) == sorted(ks)
+    compare_chain(g, o, pdf_rtol=2e-6)
+    _check_fast_pdf(mc, g["_handles"], o, r, 1, False)
+
+
+def test_pdf_long_rows_in_a_list_of_many_rows(mc, oracle):
+    """Lists of >= 16 384 rows take the four-wave form of the KDE kernel (four rows per wave, pooled planes of 768 points):
+    clusters of 300 / 700 (pooled) and 900 (streamed) points among 17 576 isolated ones."""
+    rng = np.random.default_rng(29)
+    r = 0.1
+    g1 = np.arange(26, dtype=np.float64) * 0.3
+    lattice = np.stack(np.meshgrid(g1, g1, g1, indexing="ij"), -1).reshape(-1, 3) + 0.02 * rng.random((26 ** 3, 3))
+    pts = [lattice]
+    ks = [300, 700, 900]
+    for n, k in enumerate(ks):
+        centre = np.array([0.15 + 0.3 * (3 + 5 * n), 0.15 + 0.3 * 7, 0.15 + 0.3 * 11])  # the middle of a lattice cube
+        d = rng.normal(size=(k, 3))
+        d *= (0.045 * rng.random((k, 1)) ** (1 / 3)) / np.linalg.norm(d, axis=1, keepdims=True)
+        pts.append(centre + d)
+    pts = np.concatenate(pts).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    bids = np.zeros((len(pts), 1), np.int32)
+    feats = np.ones((len(pts), 1), np.float32)
+    g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, 1, r, False, pdf_kwargs=dict(mode=0))
+    o = run_chain(oracle, _ident, _ident, pts, bids, feats, 1, r, False)
+    klen = np.diff(np.append(o["startIndexs"][:, 0], len(o["packedNeighs"])))
+    assert sorted(set(klen.tolist())) == [1] + ks
     compare_chain(g, o, pdf_rtol=2e-6)
     _check_fast_pdf(mc, g["_handles"], o, r, 1, False)
