@@ -410,7 +410,9 @@ __global__ __launch_bounds__(WAVES * 64) void pdf_rows_mfma(const float* __restr
     // rows longer than the planes: set aside here and walked by ALL waves of the workgroup afterwards (pdf_row_long)
     __shared__ PdfLongRow longRows[WAVES * MCCNN_PDF_ROWS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform: rows, tile counts and loops live in SGPRs
+    __shared__ int anyLong;
     for (int t = threadIdx.x; t < WAVES * MCCNN_PDF_ROWS; t += WAVES * 64) longRows[t].k = 0;
+    if (threadIdx.x == 0) anyLong = 0;
     __syncthreads();
     const int r0 = (blockIdx.x * WAVES + wave) * rowsPerWave;
     float* __restrict__ P = planes[wave];
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(WAVES * 64) void pdf_rows_mfma(const float* __restr
         }
         const float scale = norm * __builtin_amdgcn_rcpf((float)k);  // 1 ulp: this mode is not the bit-exact one
         if (k > MCCNN_PDF_CAP) {
-            if (lane == 0) longRows[wave * MCCNN_PDF_ROWS + rr] = PdfLongRow{rowStart, k, s, scale};
+            if (lane == 0) { longRows[wave * MCCNN_PDF_ROWS + rr] = PdfLongRow{rowStart, k, s, scale}; anyLong = 1; }
             continue;
         }
 #if defined(MCCNN_PDF_ABL) && MCCNN_PDF_ABL == 2
@@ -547,6 +549,7 @@ __global__ __launch_bounds__(WAVES * 64) void pdf_rows_mfma(const float* __restr
     // A long row that fits the POOLED planes of the workgroup (WAVES x MCCNN_PDF_CAP points: 3 072 with 16 waves) is
     // staged once by all threads and its 16 x 16 tiles are shared out by column block: the same Gram-matrix arithmetic
     // as the short rows, at the matrix cores' rate (the subtract-first loop below runs at a third of it).
+    if (!anyLong) return;
     constexpr int LC = WAVES * MCCNN_PDF_CAP;
     float* __restrict__ pool = &planes[0][0];
     int item = 0;
