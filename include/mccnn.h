@@ -146,6 +146,14 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
  * UNTOUCHED in between -- the count pass leaves the hit masks of every (centre, 64-candidate round)
  * there and the fill pass only compacts them (one traversal of the candidate windows, not two as in
  * find_neighbors.cu:268-372). */
+/* The same count with a SECOND destination of the total (extension): total_dev stays on the device for
+ * mccnn_compute_pdf_dn, total_host is a pinned host word the caller polls -- no device-to-host copy is enqueued. */
+int mccnn_find_neighbors_count2(const float* centres, const int* centre_batch_ids, int m,
+                                const float* sorted_pts, int n, const int* cell_indexs,
+                                const float* aabb_min, const float* aabb_max, int batch_size, int num_cells,
+                                float radius, int scale_inv, const int* centre_order, int* start_idx,
+                                int* total_dev, int* total_host, void* ws, size_t ws_bytes,
+                                mccnn_stream_t stream);
 int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m,
                               const float* sorted_pts, int n, const int* cell_indexs,
                               const float* aabb_min, const float* aabb_max, int batch_size,

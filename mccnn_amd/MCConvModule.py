@@ -172,6 +172,7 @@ def _remember_edges(gkey, e):
     if gkey[1] > 0:
         _EDGE_RATIO[(gkey[0], gkey[3], gkey[5])] = e / float(gkey[1])
 _TLS = threading.local()
+_MAILBOX_COPY = os.environ.get("MCCNN_MAILBOX_COPY", "0") == "1"
 
 
 def _pinned_int():
@@ -865,8 +866,6 @@ def find_neighbors_pdf_deferred(inPts, inBatchIds, sortedPts, sortedBatchIds, ce
         order = None
     args = (ptr(c), ptr(cb), m, ptr(p2), n2, ptr(cells), ptr(mn), ptr(mx), batchSize, nc, float(radius),
             int(bool(scaleInv)), ptr(order))
-    check(lib.mccnn_find_neighbors_count(*args, ptr(start), ptr(total_dev), ptr(ws), ws.numel(), stream_handle()),
-          "find_neighbors(count)")
     pool = _slot_pool()
     if pool:
         slot = pool.pop()
@@ -874,7 +873,15 @@ def find_neighbors_pdf_deferred(inPts, inBatchIds, sortedPts, sortedBatchIds, ce
         t = torch.empty(1, dtype=torch.int32).pin_memory()
         slot = (t, t.numpy())
     slot[1][0] = -1
-    slot[0].copy_(total_dev, non_blocking=True)  # stream-ordered behind the count; nobody waits for it here
+    # the prefix sum stores the total twice: in device memory for the KDE kernels and straight into the pinned host word
+    # (no copy is enqueued); nobody waits for it here
+    if _MAILBOX_COPY:  # A/B switch: the total travels through an enqueued device-to-host copy instead
+        check(lib.mccnn_find_neighbors_count(*args, ptr(start), ptr(total_dev), ptr(ws), ws.numel(), stream_handle()),
+              "find_neighbors(count)")
+        slot[0].copy_(total_dev, non_blocking=True)
+    else:
+        check(lib.mccnn_find_neighbors_count2(*args, ptr(start), ptr(total_dev), slot[0].data_ptr(), ptr(ws), ws.numel(),
+                                              stream_handle()), "find_neighbors(count)")
     packed = torch.empty((guess, 2), dtype=torch.int32, device=c.device)
     check(lib.mccnn_find_neighbors_fill(*args, ptr(start), guess, ptr(packed), ptr(ws), ws.numel(), stream_handle()),
           "find_neighbors(fill)")

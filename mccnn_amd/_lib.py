@@ -42,6 +42,7 @@ SIGNATURES = {
     "mccnn_transform_indexs": (_i, [_vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "mccnn_find_neighbors_workspace_bytes": (_sz, [_i, _i]),
     "mccnn_find_neighbors_count": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mccnn_find_neighbors_count2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_find_neighbors_fill": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "mccnn_invert_permutation": (_i, [_vp, _i, _vp, _vp]),
     "mccnn_compute_pdf_workspace_bytes": (_sz, [_i, _i]),

@@ -61,7 +61,8 @@ struct Arena {
 // them together with something it clears anyway, otherwise the scan issues the memset itself.
 size_t scan_workspace_bytes(int n);
 size_t scan_status_bytes(int n);
-int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t s, bool status_zeroed = false);
+int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t s, bool status_zeroed = false,
+                       int* total2 = nullptr /* a second destination of the total, e.g. a pinned host word */);
 
 // ---------------------------------------------------------------------------------------
 // Geometry helpers. The library is compiled with -ffp-contract=off, so each expression

@@ -652,14 +652,38 @@ static bool neigh_ws(void* ws, size_t ws_bytes, int m, int n, NeighWs& w) {
     return w.cnt && w.scanws && w.masks;
 }
 
+static int find_neighbors_count_impl(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
+                               int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max,
+                               int batch_size, int num_cells, float radius, int scale_inv, const int* centre_order,
+                               int* start_idx, int* total_dev, int* total_host, void* ws, size_t ws_bytes, mccnn_stream_t stream);
+
 int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
                                int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max,
                                int batch_size, int num_cells, float radius, int scale_inv, const int* centre_order,
                                int* start_idx, int* total_dev, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    return find_neighbors_count_impl(centres, centre_batch_ids, m, sorted_pts, n, cell_indexs, aabb_min, aabb_max, batch_size,
+                                     num_cells, radius, scale_inv, centre_order, start_idx, total_dev, nullptr, ws, ws_bytes, stream);
+}
+
+int mccnn_find_neighbors_count2(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
+                                int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max,
+                                int batch_size, int num_cells, float radius, int scale_inv, const int* centre_order,
+                                int* start_idx, int* total_dev, int* total_host, void* ws, size_t ws_bytes,
+                                mccnn_stream_t stream) {
+    return find_neighbors_count_impl(centres, centre_batch_ids, m, sorted_pts, n, cell_indexs, aabb_min, aabb_max, batch_size,
+                                     num_cells, radius, scale_inv, centre_order, start_idx, total_dev, total_host, ws, ws_bytes,
+                                     stream);
+}
+
+static int find_neighbors_count_impl(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
+                               int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max,
+                               int batch_size, int num_cells, float radius, int scale_inv, const int* centre_order,
+                               int* start_idx, int* total_dev, int* total_host, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
     if (m < 0 || n < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (m == 0) {
         MCCNN_MEMSET(hipMemsetAsync(total_dev, 0, sizeof(int), s));
+        if (total_host) MCCNN_MEMSET(hipMemsetAsync(total_host, 0, sizeof(int), s));
         return 0;
     }
     if (!centres || !centre_batch_ids || !cell_indexs || !aabb_min || !aabb_max || !start_idx || (n > 0 && !sorted_pts))
@@ -672,7 +696,7 @@ int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids
                                                      w.masks, nullptr, nullptr, 0, (unsigned long long*)w.scanws,
                                                      (int)(scan_status_bytes(m) / sizeof(unsigned long long)), G);
     MCCNN_LAUNCHED();
-    int rc = exclusive_scan_i32(w.cnt, start_idx, m, total_dev, w.scanws, s, true);
+    int rc = exclusive_scan_i32(w.cnt, start_idx, m, total_dev, w.scanws, s, true, total_host);
     if (rc) return rc;
     return 0;
 }

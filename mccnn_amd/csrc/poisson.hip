@@ -453,14 +453,18 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
     if (!sel || !blk || !flags || !plist) return MCCNN_E_WORKSPACE;
     int* slots = (int*)blk;
     void* scanws = blk + slotBytes;
-    MCCNN_MEMSET(hipMemsetAsync(sel, 0, (size_t)n, s));
-    MCCNN_MEMSET(hipMemsetAsync(blk, 0, slotBytes + scan_status_bytes((int)S), s));
+    // selection bytes, slot counters + scan status words and (dataflow forms) the per-cell flags are neighbours in the
+    // arena: ONE memset clears them all (three launches before; the bytes in between are scratch)
+    if (mode == 1 || mode == 2) {
+        MCCNN_MEMSET(hipMemsetAsync(sel, 0, (size_t)((char*)(flags + C + 1 + 32) - (char*)sel), s));
+    } else {
+        MCCNN_MEMSET(hipMemsetAsync(sel, 0, (size_t)((blk + slotBytes + scan_status_bytes((int)S)) - (char*)sel), s));
+    }
     long long threads = perPhase;
     if (mode == 1 || mode == 2) {
         // mode 2 (tests only): no spinning at all -- the first cell whose predecessor has not finished raises the
         // failure flag, which exercises the caller's fallback to the phased form
         const int spinLimit = mode == 1 ? MCCNN_PS_SPIN_LIMIT : 0;
-        MCCNN_MEMSET(hipMemsetAsync(flags, 0, (C + 1 + 32) * sizeof(int), s));
         int* cnt = flags + C + 1;
         poisson_compact<<<ceil_div((long long)C, 256), 256, 0, s>>>(cell_indexs, batch_size, d, perPhase, cnt, plist);
         MCCNN_LAUNCHED();

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const int* __rest
 // first barrier of block_excl_scan and stores after the last one.
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const int* in, int* out,
                                                            int n, const int* offsets,
-                                                           int* __restrict__ total, int rawSums) {
+                                                           int* __restrict__ total, int rawSums, int* __restrict__ total2) {
     __shared__ int lds[4];
     int off = 0;
     if (offsets) {
@@ -76,7 +76,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const int* in, int* o
         if (base + k < n) out[base + k] = run;
         run += v[k];
     }
-    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total = run;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) {
+        if (total) *total = run;
+        if (total2) *total2 = run;
+    }
 }
 
 // ------------------------------------------------------------------ single pass (decoupled look-back)
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const int* in, int* o
 // words must be zero on entry (the callers fold that into a memset / kernel they run anyway).
 constexpr int SCAN_CHAIN_TILES = 1024;
 __global__ __launch_bounds__(SCAN_THREADS) void scan_chained(const int* in, int* out, int n,
-                                                             unsigned long long* status, int* total) {
+                                                             unsigned long long* status, int* total, int* total2) {
     __shared__ int lds[4];
     __shared__ int sOff;
     __shared__ int sTile;
@@ -146,7 +149,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained(const int* in, int*
         if (base + k < n) out[base + k] = run;
         run += v[k];
     }
-    if (total && tile == (int)gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total = run;
+    if (tile == (int)gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) {
+        if (total) *total = run;
+        if (total2) *total2 = run;
+    }
 }
 
 size_t scan_status_bytes(int n) {
@@ -165,21 +171,22 @@ size_t scan_workspace_bytes(int n) {
     return bytes + 256;
 }
 
-int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t s, bool status_zeroed) {
+int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t s, bool status_zeroed, int* total2) {
     if (n <= 0) {
         if (total) MCCNN_MEMSET(hipMemsetAsync(total, 0, sizeof(int), s));
+        if (total2) MCCNN_MEMSET(hipMemsetAsync(total2, 0, sizeof(int), s));
         return 0;
     }
     int tiles = ceil_div(n, SCAN_TILE);
     if (tiles == 1) {
-        scan_tiles<<<1, SCAN_THREADS, 0, s>>>(in, out, n, nullptr, total, 0);
+        scan_tiles<<<1, SCAN_THREADS, 0, s>>>(in, out, n, nullptr, total, 0, total2);
         MCCNN_LAUNCHED();
         return 0;
     }
     const size_t sb = scan_status_bytes(n);
     if (sb) {  // single pass; the status words sit at the start of the workspace
         if (!status_zeroed) MCCNN_MEMSET(hipMemsetAsync(ws, 0, sb, s));
-        scan_chained<<<tiles, SCAN_THREADS, 0, s>>>(in, out, n, (unsigned long long*)ws, total);
+        scan_chained<<<tiles, SCAN_THREADS, 0, s>>>(in, out, n, (unsigned long long*)ws, total, total2);
         MCCNN_LAUNCHED();
         return 0;
     }
@@ -192,7 +199,7 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
         int rc = exclusive_scan_i32(sums, sums, tiles, nullptr, rest, s);
         if (rc) return rc;
     }
-    scan_tiles<<<tiles, SCAN_THREADS, 0, s>>>(in, out, n, sums, total, raw);
+    scan_tiles<<<tiles, SCAN_THREADS, 0, s>>>(in, out, n, sums, total, raw, total2);
     MCCNN_LAUNCHED();
     return 0;
 }
