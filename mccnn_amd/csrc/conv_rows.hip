@@ -107,66 +107,61 @@ __global__ __launch_bounds__(256) void vr_expand(const int* __restrict__ rowStar
     vposRow[r] = v0;
     for (int k = 0; k < vc; ++k) vlistRow[v0 + k] = r;
 }
-// The whole layout of a small list in one workgroup (rows, virtual rows <= MCCNN_PLAN_SMALL): pieces per row, their
-// prefix sum, the virtual rows in row order (no sort), slice lengths and offsets.
-__global__ __launch_bounds__(256) void plan_small(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
-                                                  int L, int S, int* __restrict__ vrow, int* __restrict__ vcode,
-                                                  int* __restrict__ sliceOff, int* __restrict__ vposRow) {
-    __shared__ int vlist[MCCNN_PLAN_SMALL];   // virtual row -> row
-    __shared__ int vfirst[MCCNN_PLAN_SMALL];  // virtual row -> first virtual row of its row
-    __shared__ int lens[MCCNN_PLAN_SMALL + 64];
-    __shared__ int part[256];
+// The whole layout of a small list in one workgroup of 1024 threads (rows, virtual rows <= MCCNN_PLAN_SMALL): pieces per
+// row and their prefix sum (4 row positions per thread), then one thread per VIRTUAL row -- its row found by a binary
+// search over the rows' first virtual-row ids -- so that a list of 73 rows with 150 pieces each is expanded by 1024
+// threads, not by 73 (the per-row loop of the first version took 52 us on such a list); slice lengths by one wave per
+// slice, offsets by a serial pass over <= 65 slices. No sort: the slices keep the visiting order.
+__global__ __launch_bounds__(1024) void plan_small(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
+                                                   int L, int S, int* __restrict__ vrow, int* __restrict__ vcode,
+                                                   int* __restrict__ sliceOff, int* __restrict__ vposRow) {
+    __shared__ int posV0[MCCNN_PLAN_SMALL + 1];  // row position -> first virtual row id (exclusive prefix of the pieces)
+    __shared__ int posRow[MCCNN_PLAN_SMALL];     // row position -> row id
+    __shared__ int lens[MCCNN_PLAN_SMALL + 64];  // virtual row -> length
     __shared__ int slen[MCCNN_PLAN_SMALL / 64 + 2];
-    const int t = threadIdx.x;
-    constexpr int PER = MCCNN_PLAN_SMALL / 256;  // 16 consecutive row positions per thread
-    int vc[PER], rr[PER], dg[PER], sum = 0;
+    __shared__ int wsum[17];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int PER = MCCNN_PLAN_SMALL / 1024;  // 4 consecutive row positions per thread
+    int vc[PER], sum = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int p = t * PER + k;
-        vc[k] = 0; rr[k] = 0; dg[k] = 0;
+        vc[k] = 0;
         if (p < rows) {
             int r = order ? order[p] : p;
             r = max(0, min(r, rows - 1));
             const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
-            rr[k] = r; dg[k] = deg;
+            posRow[p] = r;
             vc[k] = max(1, (deg + L - 1) / L);
         }
         sum += vc[k];
     }
-    part[t] = sum;
-    __syncthreads();
-    if (t == 0) {  // 256 partial sums: serial exclusive scan (tiny)
-        int run = 0;
-        for (int k = 0; k < 256; ++k) { const int v = part[k]; part[k] = run; run += v; }
-    }
-    __syncthreads();
-    int v0 = part[t];
+    int Vt;
+    int v0 = block1024_excl_scan(sum, Vt, wsum);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int p = t * PER + k;
         if (p < rows) {
-            vposRow[rr[k]] = v0;
-            for (int c = 0; c < vc[k]; ++c) {
-                if (v0 + c < MCCNN_PLAN_SMALL) {
-                    vlist[v0 + c] = rr[k];
-                    vfirst[v0 + c] = v0;
-                    lens[v0 + c] = max(0, min(L, dg[k] - c * L)) | (dg[k] > L ? (1 << 30) : 0);
-                }
-            }
+            posV0[p] = v0;
+            vposRow[posRow[p]] = v0;
             v0 += vc[k];
         }
     }
+    if (t == 0) posV0[rows] = Vt;
     __syncthreads();
-    __shared__ int totalV;
-    if (t == 255) totalV = v0;  // thread 255's running offset after its rows = number of virtual rows
-    __syncthreads();
-    const int Vt = totalV;
-    for (int v = t; v < S * 64; v += 256) {
-        if (v < Vt) {
-            const int l = lens[v];
-            vrow[v] = vlist[v];
-            vcode[v] = (l >> 30) ? v : ~v;
-            lens[v] = l & 0xFFFF;
+    for (int v = t; v < S * 64; v += 1024) {
+        if (v < Vt && v < MCCNN_PLAN_SMALL) {
+            int lo = 0, hi = rows - 1;  // largest position p with posV0[p] <= v
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (posV0[mid] <= v) lo = mid; else hi = mid - 1;
+            }
+            const int r = posRow[lo];
+            const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
+            const int piece = v - posV0[lo];
+            vrow[v] = r;
+            vcode[v] = (deg > L) ? v : ~v;
+            lens[v] = max(0, min(L, deg - piece * L));
         } else {
             vrow[v] = -1;
             vcode[v] = -1;
@@ -174,10 +169,11 @@ __global__ __launch_bounds__(256) void plan_small(const int* __restrict__ rowSta
         }
     }
     __syncthreads();
-    for (int sl = t; sl < S; sl += 256) {
-        int mx = 0;
-        for (int k = 0; k < 64; ++k) mx = max(mx, lens[min(sl * 64 + k, MCCNN_PLAN_SMALL + 63)]);
-        slen[sl] = mx * 64;
+    for (int sl = wave; sl < S; sl += 16) {
+        int d = lens[min(sl * 64 + lane, MCCNN_PLAN_SMALL + 63)];
+#pragma unroll
+        for (int s2 = 32; s2 >= 1; s2 >>= 1) d = max(d, __shfl_xor(d, s2, 64));
+        if (lane == 0) slen[sl] = d * 64;
     }
     __syncthreads();
     if (t == 0) {
@@ -796,7 +792,7 @@ int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order
     const PlanSizes z = plan_sizes(rows, e);
     if (z.slots > 0x7fffffffLL || z.vcap > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     if (z.small) {
-        plan_small<<<1, 256, 0, s>>>(row_start, rows, e, order, z.L, z.S, plan_vrow, plan_vcode, slice_off, vpos_row);
+        plan_small<<<1, 1024, 0, s>>>(row_start, rows, e, order, z.L, z.S, plan_vrow, plan_vcode, slice_off, vpos_row);
         MCCNN_LAUNCHED();
         return 0;
     }
