@@ -302,6 +302,17 @@ int mccnn_sort_step2_dn(const float* pts, const int* batch_ids, const int* keys,
                         int n_cap, const int* n_dev, int batch_size, int num_cells, float* out_pts,
                         int* out_batch_ids, int* cell_indexs, void* ws, size_t ws_bytes,
                         mccnn_stream_t stream);
+/* One level of a point hierarchy in one call (extension; MCConvBuilder.py:101-128 per level): mccnn_sort_step1_dn +
+ * mccnn_sort_step2_dn + mccnn_poisson_sampling_count / _fill + mccnn_transform_indexs_dn with the level's point count in
+ * device memory (n_dev) and the sample count left there (s_dev, -1 when a wait of the single-launch Poisson form timed
+ * out: the caller repeats the level op by op). Outputs are sized by n_cap. */
+size_t mccnn_hierarchy_level_workspace_bytes(int n_cap, int batch_size, int num_cells);
+int mccnn_hierarchy_level(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max,
+                          int n_cap, const int* n_dev, int batch_size, int num_cells, float radius,
+                          int scale_inv, int mode, int* new_idx, float* sorted_pts, int* sorted_batch_ids,
+                          int* cell_indexs, float* out_pts, int* out_batch_ids, int* out_indexs,
+                          int* transformed_indexs, int* s_dev, void* ws, size_t ws_bytes,
+                          mccnn_stream_t stream);
 /* SortPointsStep1 + SortPointsStep2 of the POINTS only in one call (extension: what a convolution builder needs of a
  * grid is the sorted points / batch ids, the cell table and index_new_pos -- feature rows are sorted where they are
  * consumed). Same outputs as the two ops; inv_idx (optional): the inverse permutation (sorted position -> input row). */

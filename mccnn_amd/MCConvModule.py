@@ -964,6 +964,7 @@ def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batc
     pmode = 2 if POISSON_DATAFLOW == 2 else 1
     sizes = torch.empty(L + 1, dtype=torch.int32, device=dev)
     sizes[0] = cap
+    sizes_ptr = sizes.data_ptr()
     i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
     f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     cur_pts, cur_bids, levels = pts, bids, []
@@ -971,31 +972,22 @@ def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batc
     for l, radius in enumerate(radiusList):
         _req(radius > 0.0, op + " expects positive radii")
         nc = _num_cells(mn, mx, batchSize, radius, scaleInv)
-        n_dev, s_dev = sizes[l:l + 1], sizes[l + 1:l + 2]
-        keys, idx = i32(cap), i32(cap)
-        wsb = lib.mccnn_sort_step1_workspace_bytes(cap, batchSize, nc)
+        wsb = lib.mccnn_hierarchy_level_workspace_bytes(cap, batchSize, nc)
         _req(wsb > 0, op + ": batch_size * num_cells^3 does not fit 32-bit keys")
         ws = _ws(wsb, dev)
-        check(lib.mccnn_sort_step1_dn(ptr(cur_pts), ptr(cur_bids), ptr(mn), ptr(mx), cap, ptr(n_dev), batchSize, nc,
-                                      ptr(keys), ptr(idx), ptr(ws), ws.numel(), stream_handle()), "sort_points_step1(dn)")
-        sP, sB, cells = f32(cap, 3), i32(cap, 1), i32(batchSize, nc, nc, nc, 2)
-        ws2 = _ws(lib.mccnn_sort_step2_workspace_bytes(cap), dev)
-        check(lib.mccnn_sort_step2_dn(ptr(cur_pts), ptr(cur_bids), ptr(keys), ptr(idx), cap, ptr(n_dev), batchSize, nc,
-                                      ptr(sP), ptr(sB), ptr(cells), ptr(ws2), ws2.numel(), stream_handle()),
-              "sort_points_step2(dn)")
-        wsb = lib.mccnn_poisson_sampling_workspace_bytes(cap, batchSize, nc)
-        _req(wsb > 0, op + ": grid too large")
-        wsp = _ws(wsb, dev)
-        check(lib.mccnn_poisson_sampling_count(ptr(sP), ptr(sB), cap, ptr(cells), ptr(mn), ptr(mx), batchSize, nc,
-                                               float(radius), si, pmode, ptr(s_dev), ptr(wsp), wsp.numel(), stream_handle()),
-              "poisson_sampling(count)")
-        oP, oB, oI, ti = f32(cap, 3), i32(cap, 1), i32(cap), i32(cap)
-        check(lib.mccnn_poisson_sampling_fill(ptr(sP), cap, ptr(cells), batchSize, nc, cap, ptr(oP), ptr(oB), ptr(oI),
-                                              ptr(wsp), wsp.numel(), stream_handle()), "poisson_sampling(fill)")
-        wst = _ws(lib.mccnn_transform_indexs_workspace_bytes(cap), dev)
-        check(lib.mccnn_transform_indexs_dn(ptr(oI), cap, ptr(s_dev), ptr(idx), cap, ptr(n_dev), ptr(ti), ptr(wst),
-                                            wst.numel(), stream_handle()), "transform_indexs(dn)")
-        levels.append((oP, oB, oI, ti))
+        # one call per level: both sort steps, the Poisson sampling (count + fill) and transform_indexs, every count in
+        # device memory; two allocations per level (the level's int32 and float32 rows)
+        ca = (cap + 63) // 64 * 64  # 256-byte aligned pieces (the cell table is written as int2)
+        ints = i32(5 * ca + 2 * batchSize * nc * nc * nc)  # index_new_pos | sorted batch ids | oB | oI | ti | cell table
+        flts = f32(6 * ca)                                 # sorted points | sampled points
+        oB, oI, ti = ints[2 * ca:2 * ca + cap], ints[3 * ca:3 * ca + cap], ints[4 * ca:4 * ca + cap]
+        oP = flts[3 * ca:3 * ca + 3 * cap].view(cap, 3)
+        base_i, base_f = ints.data_ptr(), flts.data_ptr()
+        check(lib.mccnn_hierarchy_level(ptr(cur_pts), ptr(cur_bids), ptr(mn), ptr(mx), cap, sizes_ptr + 4 * l, batchSize, nc,
+                                        float(radius), si, pmode, base_i, base_f, base_i + 4 * ca, base_i + 20 * ca,
+                                        base_f + 12 * ca, base_i + 8 * ca, base_i + 12 * ca, base_i + 16 * ca,
+                                        sizes_ptr + 4 * (l + 1), ptr(ws), ws.numel(), stream_handle()), "hierarchy_level")
+        levels.append((oP, oB.view(cap, 1), oI, ti))
         cur_pts, cur_bids = oP, oB
     host = sizes.cpu().tolist()  # the ONE read-back: every level's sample count
     if any(s < 0 for s in host[1:]):

@@ -508,4 +508,50 @@ int mccnn_poisson_sampling_fill(const float* sorted_pts, int n, const int* cell_
     return 0;
 }
 
+
+// One level of a point hierarchy in ONE call (extension for PointHierarchy: sort_points_step1 + step2 of the points,
+// poisson_sampling count + fill, transform_indexs -- all with device-side counts, see the *_dn entries): what a level
+// costs a network step is host work, five calls and their argument marshalling more than the kernels of a coarse level.
+size_t mccnn_hierarchy_level_workspace_bytes(int n_cap, int batch_size, int num_cells) {
+    const size_t a = mccnn_sort_step1_workspace_bytes(n_cap, batch_size, num_cells);
+    const size_t p = mccnn_poisson_sampling_workspace_bytes(n_cap, batch_size, num_cells);
+    if (a == 0 || p == 0) return 0;
+    return align_up((size_t)(n_cap > 0 ? n_cap : 1) * 4) + a + mccnn_sort_step2_workspace_bytes(n_cap) + p +
+           mccnn_transform_indexs_workspace_bytes(n_cap) + 256;
+}
+
+int mccnn_hierarchy_level(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n_cap,
+                          const int* n_dev, int batch_size, int num_cells, float radius, int scale_inv, int mode,
+                          int* new_idx, float* sorted_pts, int* sorted_batch_ids, int* cell_indexs, float* out_pts,
+                          int* out_batch_ids, int* out_indexs, int* transformed_indexs, int* s_dev, void* ws,
+                          size_t ws_bytes, mccnn_stream_t stream) {
+    if (n_cap <= 0 || !n_dev || !s_dev) return MCCNN_E_BADARG;
+    const size_t need = mccnn_hierarchy_level_workspace_bytes(n_cap, batch_size, num_cells);
+    if (need == 0) return MCCNN_E_TOOLARGE;
+    if (!ws || ws_bytes < need) return MCCNN_E_WORKSPACE;
+    Arena a(ws, ws_bytes);
+    int* keys = a.take<int>((size_t)n_cap);
+    const size_t b1 = mccnn_sort_step1_workspace_bytes(n_cap, batch_size, num_cells);
+    const size_t b2 = mccnn_sort_step2_workspace_bytes(n_cap);
+    const size_t bp = mccnn_poisson_sampling_workspace_bytes(n_cap, batch_size, num_cells);
+    const size_t bt = mccnn_transform_indexs_workspace_bytes(n_cap);
+    char* w1 = a.take<char>(b1);
+    char* w2 = a.take<char>(b2);
+    char* wp = a.take<char>(bp);
+    char* wt = a.take<char>(bt);
+    if (!keys || !w1 || !w2 || !wp || !wt) return MCCNN_E_WORKSPACE;
+    int rc = mccnn_sort_step1_dn(pts, batch_ids, aabb_min, aabb_max, n_cap, n_dev, batch_size, num_cells, keys, new_idx, w1, b1, stream);
+    if (rc) return rc;
+    rc = mccnn_sort_step2_dn(pts, batch_ids, keys, new_idx, n_cap, n_dev, batch_size, num_cells, sorted_pts, sorted_batch_ids,
+                             cell_indexs, w2, b2, stream);
+    if (rc) return rc;
+    rc = mccnn_poisson_sampling_count(sorted_pts, sorted_batch_ids, n_cap, cell_indexs, aabb_min, aabb_max, batch_size, num_cells,
+                                      radius, scale_inv, mode, s_dev, wp, bp, stream);
+    if (rc) return rc;
+    rc = mccnn_poisson_sampling_fill(sorted_pts, n_cap, cell_indexs, batch_size, num_cells, n_cap, out_pts, out_batch_ids,
+                                     out_indexs, wp, bp, stream);
+    if (rc) return rc;
+    return mccnn_transform_indexs_dn(out_indexs, n_cap, s_dev, new_idx, n_cap, n_dev, transformed_indexs, wt, bt, stream);
+}
+
 }  // extern "C"
