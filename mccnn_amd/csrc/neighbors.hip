@@ -634,7 +634,11 @@ size_t mccnn_find_neighbors_workspace_bytes(int m, int n) {
 // Centres per wave: 8 consecutive centres of the visiting order share most of their windows on a large list (~8 points
 // per cell), but a list with few centres needs the waves -- 6 344 pooling centres with ~900 candidates each ran 139 us per
 // pass on 793 waves (BASELINE cfg2 Pool_1), the coarse levels of a hierarchy 20 us on a handful.
-static int neigh_group(int m) { return m >= 32768 ? MCCNN_NW_G : (m >= 16384 ? 4 : (m >= 8192 ? 2 : 1)); }
+static int neigh_group(int m) {
+    static const int forced = getenv("MCCNN_NW_GROUP") ? atoi(getenv("MCCNN_NW_GROUP")) : 0;  // A/B switch, read once
+    if (forced >= 1 && forced <= MCCNN_NW_G) return forced;
+    return m >= 32768 ? MCCNN_NW_G : (m >= 16384 ? 4 : (m >= 8192 ? 2 : 1));
+}
 
 struct NeighWs {
     int* cnt;  // hits per centre
