@@ -403,8 +403,9 @@ def prefetch_rowplan(packed, transposed, stream, *args):
 
 
 def _rows_shape(combin, fin, feats, rows, e, backward=False):
-    """Row-per-lane kernels for this (layer, list)? Depth-wise rows of 8-feature blocks. Forward: always (long rows are cut
-    into pieces, lists of short rows put several slices into a workgroup). Backward: the edge-streaming kernels keep
+    """Row-per-lane kernels for this (layer, list)? Depth-wise rows of 8-feature blocks. Every list of <= 500 k edges: yes
+    (long rows are cut into pieces, lists of short rows put several slices into a workgroup). Forward on larger lists: see
+    below. Backward: the edge-streaming kernels keep
     LARGE lists (> 500 k edges) unless the layer is wide and its rows long: their waves own equal edge ranges, while the
     176-sum sweep of the row kernel, two waves per SIMD, has too few (slice, block) items on such a list to hide its
     quantisation and its per-item reduction when the layer has <= 16 blocks, and pays set-up and window padding too often
@@ -415,8 +416,14 @@ def _rows_shape(combin, fin, feats, rows, e, backward=False):
     if not (ROW_KERNELS and _DEBUG_IMPL == 0 and (not combin) and fin % 8 == 0 and e > 0 and rows > 0
             and (feats.data_ptr() & 15) == 0):
         return False
-    if not backward or e <= 500000:
+    if e <= 500000:
         return True
+    if not backward:
+        # the row kernel walks windows of 1 024 centres sorted by row length, the streaming kernel the centres in their
+        # cell-coherent order: on a large list whose gathered rows do not fit the L2s (>= 64 k points) and whose layer is
+        # narrow (<= 16 blocks: little arithmetic per gathered byte) the better locality wins -- room, 64 features 0.38 /
+        # 0.32 ms; cfg3 Pool_1 0.16 / 0.12, DeConv_1 0.24 / 0.21; the other way round on 41 k points (Conv_2 0.13 / 0.15)
+        return not (fin <= 128 and feats.shape[0] >= 65536)
     return fin >= 256 and e / float(rows) >= ROWS_MIN_DEGREE
 
 
