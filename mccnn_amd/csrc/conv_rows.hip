@@ -721,192 +721,12 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
     }
 }
 
-// ------------------------------------------------------------------------------------------------ EXPERIMENT: one wave per SIMD
-struct BlockWeightsT {
-    float w3tlo[8], w3thi[8];  // rows i4 / 4 + i4 of W3^T
-    float w2tlo[8], w2thi[8];  // rows i4 / 4 + i4 of W2^T
-};
-__device__ __forceinline__ void load_block_weights_t(const ConvArgs& a, int q, int i4, BlockWeightsT& w) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        w.w3tlo[k] = a.w3[(size_t)q * 64 + k * 8 + i4];
-        w.w3thi[k] = a.w3[(size_t)q * 64 + k * 8 + 4 + i4];
-        w.w2tlo[k] = a.w2[(size_t)q * 64 + k * 8 + i4];
-        w.w2thi[k] = a.w2[(size_t)q * 64 + k * 8 + 4 + i4];
-    }
-}
-template <int FEAT>
-__global__ __launch_bounds__(256, 1) void dw_bwd_rows_w1(ConvArgs a, RowPlan p, const float* __restrict__ outGrad,
-                                                         float* __restrict__ featGrad, float* __restrict__ scratch,
-                                                         float* __restrict__ partials, int spw, int groups) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i4 = lane & 3;
-    const int qTiles = (a.nb + 3) >> 2;
-    const int Lw = xcd_contiguous(blockIdx.x, gridDim.x);
-    if (Lw >= groups * qTiles) return;
-    const int qt = Lw / groups, g = Lw - qt * groups;
-    const int q = qt * 4 + wave;
-    if (q >= a.nb) return;
-    constexpr bool BF = FEAT == 4;
-    const unsigned short* feats16 = reinterpret_cast<const unsigned short*>(a.feats);
-    const unsigned short* og16 = reinterpret_cast<const unsigned short*>(outGrad);
-    unsigned short* fg16 = reinterpret_cast<unsigned short*>(featGrad);
-    BlockWeights w;
-    BlockWeightsT wt;
-    load_block_weights(a, q, i4, w);
-    load_block_weights_t(a, q, i4, wt);
-    float gw3[64], gb3[8], gw2[64], gb2[8], gw1[24], gb1[8];
-#pragma unroll
-    for (int k = 0; k < 64; ++k) { gw3[k] = 0.f; gw2[k] = 0.f; }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { gb3[k] = 0.f; gb2[k] = 0.f; gb1[k] = 0.f; }
-#pragma unroll
-    for (int k = 0; k < 24; ++k) gw1[k] = 0.f;
-    const int sEnd = min((g + 1) * spw, p.S);
-    for (int slice = g * spw; slice < sEnd; ++slice) {
-        const int off = p.sliceOff[slice];
-        const int len = (p.sliceOff[slice + 1] - off) >> 6;
-        if (len == 0) continue;
-        const int r = p.vrow[slice * 64 + lane];
-        const int jr = max(r, 0);
-        float ff[8];
-        if (BF) {
-            const uint4 fu = reinterpret_cast<const uint4*>(feats16 + (size_t)jr * a.Fin)[q];
-            bf16x8_to_f32(fu, ff);
-        } else {
-            const float4* fp = reinterpret_cast<const float4*>(a.feats + (size_t)jr * a.Fin + q * 8);
-            const float4 fa = fp[0], fb = fp[1];
-            ff[0] = fa.x; ff[1] = fa.y; ff[2] = fa.z; ff[3] = fa.w; ff[4] = fb.x; ff[5] = fb.y; ff[6] = fb.z; ff[7] = fb.w;
-        }
-        float dF[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) dF[n] = 0.f;
-        float4 rcN = p.rec[(size_t)off + lane];
-        int iN = p.other[(size_t)off + lane];
-        float gN[8];
-        auto gather = [&](int ci, float* g8) {
-            if (BF) {
-                const uint4 gu = reinterpret_cast<const uint4*>(og16 + (size_t)ci * a.outF)[q];
-                bf16x8_to_f32(gu, g8);
-            } else {
-                const float4* gp = reinterpret_cast<const float4*>(outGrad + (size_t)ci * a.outF + q * 8);
-                const float4 ga = gp[0], gb = gp[1];
-                g8[0] = ga.x; g8[1] = ga.y; g8[2] = ga.z; g8[3] = ga.w; g8[4] = gb.x; g8[5] = gb.y; g8[6] = gb.z; g8[7] = gb.w;
-            }
-        };
-        gather(iN, gN);
-        if (len > 1) iN = p.other[(size_t)off + 64 + lane];
-        for (int it = 0; it < len; ++it) {
-            const float4 rc = rcN;
-            const float inv = rc.w;
-            float g8[8];
-#pragma unroll
-            for (int n = 0; n < 8; ++n) g8[n] = gN[n];
-            if (it + 1 < len) {  // the next iteration's record and out-gradient row, the index of the one after
-                rcN = p.rec[(size_t)off + (size_t)(it + 1) * 64 + lane];
-                gather(iN, gN);
-                if (it + 2 < len) iN = p.other[(size_t)off + (size_t)(it + 2) * 64 + lane];
-            }
-            float pre1[8], pre2[8], a1[8], a2[8], o[8];
-            MCCNN_PHASE();
-            {
-                const float one = opaque_one();
-                f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
-                lo = MFMA4(w.w1lo[0], rc.x, lo); hi = MFMA4(w.w1hi[0], rc.x, hi);
-                lo = MFMA4(w.w1lo[1], rc.y, lo); hi = MFMA4(w.w1hi[1], rc.y, hi);
-                lo = MFMA4(w.w1lo[2], rc.z, lo); hi = MFMA4(w.w1hi[2], rc.z, hi);
-                lo = MFMA4(w.w1lo[3], one, lo); hi = MFMA4(w.w1hi[3], one, hi);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { pre1[k] = lo[k]; pre1[4 + k] = hi[k]; }
-            }
-            MCCNN_PHASE();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a1[k] = relu1(pre1[k]);
-            MCCNN_PHASE();
-            layer8_regs<true>(w.w2lo, w.w2hi, w.b2lo, w.b2hi, a1, pre2);
-            MCCNN_PHASE();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a2[k] = relu1(pre2[k]);
-            MCCNN_PHASE();
-            layer8_regs<true>(w.w3lo, w.w3hi, w.b3lo, w.b3hi, a2, o);
-            MCCNN_PHASE();
-            float gf[8];
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                dF[n] = __builtin_fmaf(g8[n] * inv, o[n], dF[n]);
-                gf[n] = g8[n] * ff[n];
-            }
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                const float u = gf[n] * inv;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) gw3[n * 8 + k] = fmaf(u, a2[k], gw3[n * 8 + k]);
-                gb3[n] += u;
-            }
-            float t3[8];
-            MCCNN_PHASE();
-            layer8_regs<false>(wt.w3tlo, wt.w3thi, 0.f, 0.f, gf, t3);
-            MCCNN_PHASE();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t3[k] = (pre2[k] >= 0.0f) ? t3[k] * inv : 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-#pragma unroll
-                for (int l = 0; l < 8; ++l) gw2[k * 8 + l] = fmaf(t3[k], a1[l], gw2[k * 8 + l]);
-                gb2[k] += t3[k];
-            }
-            float t4[8];
-            MCCNN_PHASE();
-            layer8_regs<false>(wt.w2tlo, wt.w2thi, 0.f, 0.f, t3, t4);
-            MCCNN_PHASE();
-#pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                const float v = (pre1[l] >= 0.0f) ? t4[l] : 0.f;
-                gw1[l * 3] = fmaf(v, rc.x, gw1[l * 3]);
-                gw1[l * 3 + 1] = fmaf(v, rc.y, gw1[l * 3 + 1]);
-                gw1[l * 3 + 2] = fmaf(v, rc.z, gw1[l * 3 + 2]);
-                gb1[l] += v;
-            }
-        }
-        const int code = p.vcode[slice * 64 + lane];
-        if (r >= 0 && code >= 0) {
-            float4* dst = reinterpret_cast<float4*>(scratch + (size_t)code * a.Fin + q * 8);
-            dst[0] = make_float4(dF[0], dF[1], dF[2], dF[3]);
-            dst[1] = make_float4(dF[4], dF[5], dF[6], dF[7]);
-        } else if (r >= 0) {
-            if (BF) {
-                reinterpret_cast<uint4*>(fg16 + (size_t)r * a.Fin)[q] = f32x8_to_bf16(dF);
-            } else {
-                float4* dst = reinterpret_cast<float4*>(featGrad + (size_t)r * a.Fin + q * 8);
-                dst[0] = make_float4(dF[0], dF[1], dF[2], dF[3]);
-                dst[1] = make_float4(dF[4], dF[5], dF[6], dF[7]);
-            }
-        }
-    }
-    {
-        float r2 = wave_reduce64(gw2, lane);
-        float r3 = wave_reduce64(gw3, lane);
-        float misc[64];
-#pragma unroll
-        for (int k = 0; k < 24; ++k) misc[k] = gw1[k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { misc[24 + k] = gb1[k]; misc[32 + k] = gb2[k]; misc[40 + k] = gb3[k]; }
-#pragma unroll
-        for (int k = 48; k < 64; ++k) misc[k] = 0.f;
-        float rm = wave_reduce64(misc, lane);
-        float* pq = partials + ((size_t)g * a.nb + q) * 176;
-        pq[32 + lane] = r2;
-        pq[104 + lane] = r3;
-        if (lane < 32) pq[lane] = rm;
-        else if (lane < 40) pq[96 + lane - 32] = rm;
-        else if (lane < 48) pq[168 + lane - 40] = rm;
-    }
-}
-
-// (Measured and dropped, commit before this one: the same sweep at ONE wave per SIMD -- 256 VGPRs + 166 AGPRs, the block's
-// 76 weight operands in registers instead of LDS, two chunks of 64 edges per iteration with their MFMA chains and VALU
-// phases issued side by side, pre-activations kept instead of (activation, mask) pairs: 3.90 ms against 2.43 ms for dw256
-// on the room. A second wave hides more latency than a second chunk in the same wave, whose values have to travel
-// through the accumulation registers.)
+// (Measured and dropped, commits 69cbed3 and the one before this text: the same sweep at ONE wave per SIMD with the block's
+// 76 weight operands in registers instead of LDS -- with two chunks of 64 edges per iteration, their MFMA chains and VALU
+// phases issued side by side (256 VGPRs + 166 AGPRs): 3.90 ms; with one chunk per iteration (256 + 107): 3.31 ms; against
+// 2.43-2.49 ms for dw256 on the room. A wave alone takes ~3 250 cycles per (64 edges, block) even without a single LDS
+// read -- VALU instructions that consume MFMA results wait for them (12 instead of 8 cycles per instruction in
+// tools/issue_probe) -- and only a second wave fills those waits; its LDS weight reads are the cheaper evil.)
 // defined in conv.hip
 void launch_reduce_partials(const float* partials, int rows, int nb, float* dw1, float* db1, float* dw2, float* db2,
                             float* dw3, float* db3, hipStream_t s);
@@ -1173,11 +993,6 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
     if (blocks > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     float* partials = reinterpret_cast<float*>(ws);
     const size_t lds = ((size_t)4 * MCCNN_WQ_BWD + 4 * 512) * sizeof(float);  // 4 blocks of weights + the parked feature pieces
-    static const bool oneWave = getenv("MCCNN_BWD_W1") && atoi(getenv("MCCNN_BWD_W1")) != 0;  // A/B switch, read once
-    if (oneWave) {
-        if (bf16) dw_bwd_rows_w1<4><<<(int)blocks, 256, 0, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
-        else dw_bwd_rows_w1<2><<<(int)blocks, 256, 0, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
-    } else
     if (bf16) dw_bwd_rows<4><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
     else dw_bwd_rows<2><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
     MCCNN_LAUNCHED();
