@@ -107,12 +107,21 @@ __device__ __forceinline__ float opaque_one() {
 template <bool BIAS>
 __device__ __forceinline__ void layer8(const f32x4* __restrict__ wrows /* 16 x f32x4: row r at [2r],[2r+1] */,
                                        const float* __restrict__ bias, int i4, const float* x, float* y) {
+#ifdef MCCNN_ABL_NOLDSW  // timing ablation (wrong results): the weight operands come from registers, no LDS read
+    f32x4 al0 = {x[0], x[1], x[2], x[3]}, al1 = {x[4], x[5], x[6], x[7]};
+    f32x4 ah0 = {x[1], x[2], x[3], x[4]}, ah1 = {x[5], x[6], x[7], x[0]};
+#else
     f32x4 al0 = wrows[2 * i4], al1 = wrows[2 * i4 + 1];
     f32x4 ah0 = wrows[2 * (4 + i4)], ah1 = wrows[2 * (4 + i4) + 1];
+#endif
     float al[8] = {al0.x, al0.y, al0.z, al0.w, al1.x, al1.y, al1.z, al1.w};
     float ah[8] = {ah0.x, ah0.y, ah0.z, ah0.w, ah1.x, ah1.y, ah1.z, ah1.w};
     float bl = 0.f, bh = 0.f;
+#ifdef MCCNN_ABL_NOLDSW
+    if (BIAS) { bl = x[0]; bh = x[1]; }
+#else
     if (BIAS) { bl = bias[i4]; bh = bias[4 + i4]; }
+#endif
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -204,7 +213,11 @@ __device__ __forceinline__ void mlp_block_regs(const BlockWeights& w, float d0, 
 // Layer 1 for 64 edges: pre1 = ((d0 w0 + d1 w1) + d2 w2) + b1 as fma steps (spatial_conv.cu:49-52); the LDS row of
 // neuron r is (w0, w1, w2, b1).
 __device__ __forceinline__ void layer1_mfma(const f32x4* __restrict__ w, int i4, float d0, float d1, float d2, float* pre1) {
+#ifdef MCCNN_ABL_NOLDSW
+    f32x4 a1lo = {d0, d1, d2, d0}, a1hi = {d1, d2, d0, d1};
+#else
     f32x4 a1lo = w[i4], a1hi = w[4 + i4];
+#endif
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
     const float one = opaque_one();
     lo = MFMA4(a1lo.x, d0, lo);

@@ -607,6 +607,13 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
             const int ci = iN;
             const float inv = rc.w;
             float g8[8];
+#ifdef MCCNN_ROWS_BWD_NOGATHER  // timing ablation (wrong results): the out-gradient rows come from registers
+            {
+                const float gv = __int_as_float(0x3f000000 | (ci & 0xffff));
+#pragma unroll
+                for (int n = 0; n < 8; ++n) g8[n] = gv;
+            }
+#else
             if (BF) {
                 const uint4 gu = reinterpret_cast<const uint4*>(og16 + (size_t)ci * a.outF)[q];
                 bf16x8_to_f32(gu, g8);
@@ -615,6 +622,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
                 const float4 ga = gp[0], gb = gp[1];
                 g8[0] = ga.x; g8[1] = ga.y; g8[2] = ga.z; g8[3] = ga.w; g8[4] = gb.x; g8[5] = gb.y; g8[6] = gb.z; g8[7] = gb.w;
             }
+#endif
             if (it + 1 < len) {  // after this iteration's gather: vmcnt retires in order
                 const size_t sn = (size_t)off + (size_t)(it + 1) * 64 + lane;
                 rcN = p.rec[sn];
