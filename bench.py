@@ -282,7 +282,7 @@ class Workload:
                 scr = torch.empty((pf.scratch_rows, outF), dtype=torch.float32, device=device)
                 tf, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_fwd_rows(
                     conv_args[0], ptr(feats_t), *conv_args[2:], n, m, e, fin, B, r, 0, 1, bf, pf.vrow, pf.vcode,
-                    pf.slice_off, pf.vpos_row, pf.rec, pf.other, ptr(o), ptr(scr), stream_handle()),
+                    pf.slice_off, pf.vpos_row, pf.rec, pf.other, ptr(o), ptr(scr), None, stream_handle()),
                     "conv_fwd_rows"))
                 state = None
             else:
@@ -305,7 +305,7 @@ class Workload:
                 tb, _ = ev_time(lambda: check(lib.mccnn_spatial_conv_bwd_rows(
                     conv_args[0], ptr(feats_t), *conv_args[2:], ptr(og_t), n, m, e, fin, B, r, 0, 1, bf, ptr(pt.row_start),
                     pt.vrow, pt.vcode, pt.slice_off, pt.vpos_row, pt.rec, pt.other, ptr(fgr),
-                    ptr(scr), *[ptr(g) for g in gws], ptr(bws), bws.numel(), stream_handle()), "conv_bwd_rows"))
+                    ptr(scr), *[ptr(g) for g in gws], None, ptr(bws), bws.numel(), stream_handle()), "conv_bwd_rows"))
             else:
                 bwd_ws = torch.empty(max(256, lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, fout, int(combin))),
                                      dtype=torch.uint8, device=device)

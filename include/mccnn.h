@@ -388,7 +388,9 @@ int mccnn_rowplan_build(int transposed, const float* sorted_pts, const int* sort
  * the six parameter gradients together (the edge-major form needs a second pass over the transposed list). bf16 != 0:
  * rows (features, outputs, out-gradients, feature gradients) stored as bf16 like mccnn_spatial_conv_*_bf16. scratch:
  * scratch_rows x num_feats floats (mccnn_rowplan_sizes). Every output row is written exactly once; no atomics;
- * bit-reproducible. */
+ * bit-reproducible. feat_index (optional, NULL = none): sorted_feats (and feat_grad) hold the rows of the points in
+ * another order -- row j of the sorted list is row feat_index[j] there (the grid's inverse permutation: the features of
+ * the UNSORTED points are read where they lie and their gradient written back in that order, no sorted copy). */
 int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feats,
                                 const int* sorted_batch_ids, const float* pdfs, const float* samples,
                                 const int* start_idx, const int* packed, const float* aabb_min,
@@ -397,7 +399,8 @@ int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feat
                                 int num_feats, int batch_size, float radius, int scale_inv, int avg,
                                 int bf16, const int* plan_vrow, const int* plan_vcode,
                                 const int* slice_off, const int* vpos_row, const void* plan_rec,
-                                const int* plan_other, void* out, float* scratch, mccnn_stream_t stream);
+                                const int* plan_other, void* out, float* scratch, const int* feat_index,
+                                mccnn_stream_t stream);
 size_t mccnn_spatial_conv_bwd_rows_workspace_bytes(int n, int e, int num_feats);
 int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feats,
                                 const int* sorted_batch_ids, const float* pdfs, const float* samples,
@@ -409,8 +412,8 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
                                 const int* plan_vrow, const int* plan_vcode, const int* slice_off,
                                 const int* vpos_row, const void* plan_rec, const int* plan_other,
                                 void* feat_grad, float* scratch, float* dw1, float* db1, float* dw2,
-                                float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes,
-                                mccnn_stream_t stream);
+                                float* db2, float* dw3, float* db3, const int* feat_index, void* ws,
+                                size_t ws_bytes, mccnn_stream_t stream);
 
 /* TEST HOOK, not part of the operator surface: selects the convolution implementation for A/B
  * parity tests (bit 0: VALU fallback kernels, bit 1: general MFMA kernels for one-input-feature

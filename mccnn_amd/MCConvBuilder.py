@@ -560,7 +560,8 @@ class ConvolutionBuilder(torch.nn.Module):
                                 currOutPointHierarchy.points_[currOutPointLevel], currNeighTuple[0], currNeighTuple[1],
                                 inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, weights, weights2v, weights3v, biases,
                                 biases2v, biases3v, currNumOutFeatures, currMultiFeatureConv, inPointHierarchy.batchSize_,
-                                convRadius, currRelativeRadius, currUseAVG, sortIndex, True)
+                                convRadius, currRelativeRadius, currUseAVG, sortIndex, True,
+                                currGridTuple[4] if len(currGridTuple) > 4 else None)
         return self.ops_.spatial_conv(currGridTuple[0], sortFeatures, currGridTuple[1], currPDFs,
                             currOutPointHierarchy.points_[currOutPointLevel], currNeighTuple[0], currNeighTuple[1],
                             inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, weights, weights2, weights3, biases,

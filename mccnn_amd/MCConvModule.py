@@ -281,6 +281,8 @@ def _transposed_neighbors(packed, n):
 #: (conv_rows.hip); False = the edge-streaming kernels of conv.hip for every layer
 ROW_KERNELS = os.environ.get("MCCNN_ROW_KERNELS", "1") != "0"
 ROWS_MIN_DEGREE = float(os.environ.get("MCCNN_ROWS_MIN_DEGREE", "16"))
+#: levels of up to this many points: the row kernels read the feature rows of the UNSORTED points in place (featIndex)
+UNSORTED_MAX_POINTS = int(os.environ.get("MCCNN_UNSORTED_MAX_POINTS", "32768"))
 
 
 class RowPlan:
@@ -537,8 +539,8 @@ def sort_points_step1(inPts, inBatchIds, aabbMin, aabbMax, batchSize, cellSize, 
 def build_grid(inPts, inBatchIds, aabbMin, aabbMax, batchSize, cellSize, scaleInv):
     """sort_points_step1 + sort_points_step2 of the points alone, in one library call (extension for
     ConvolutionBuilder: the feature rows are sorted by the convolution that consumes them, spatial_conv(sortIndex=)).
-    -> (sortPts, sortBatchs, cellIndexs, index_new_pos), the builder's grid tuple. Not differentiable: points that
-    require a gradient take the two ops."""
+    -> (sortPts, sortBatchs, cellIndexs, index_new_pos, inverse permutation), the builder's grid tuple plus the sorted ->
+    unsorted row index. Not differentiable: points that require a gradient take the two ops."""
     op = "SortPointsStep1Op"
     _req(batchSize > 0, op + " expects a positive batch size")
     pts, bids = _f32(inPts.detach(), "points"), _i32(inBatchIds, "batch_ids")
@@ -562,7 +564,7 @@ def build_grid(inPts, inBatchIds, aabbMin, aabbMax, batchSize, cellSize, scaleIn
     check(lib.mccnn_build_grid(ptr(pts), ptr(bids), ptr(mn), ptr(mx), n, batchSize, nc, ptr(idx), ptr(oP), ptr(oB), ptr(cells),
                                ptr(inv), ptr(ws), ws.numel(), stream_handle()), "build_grid")
     _remember_order(inPts, "order", inv)
-    return oP, oB, cells, idx
+    return oP, oB, cells, idx, inv
 
 
 def _gather_rows(src, idx, n_rows):
@@ -1067,7 +1069,7 @@ class _SpatialConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inPts, inFeatures, inBatchIds, inPDFs, inSamplePts, neighStartIndexs, packedNeighs, aabbMin,
                 aabbMax, weights1, biases1, weights2, biases2, weightsOut, biasesOut, numOutFeatures, combin,
-                batchSize, radius, scaleInv, avg, sortIndex=None, trusted=False):
+                batchSize, radius, scaleInv, avg, sortIndex=None, trusted=False, featIndex=None):
         op = "SpatialConvOp"
         feats = _feat(inFeatures, "features")
         bf16 = feats.dtype == torch.bfloat16
@@ -1101,14 +1103,26 @@ class _SpatialConv(torch.autograd.Function):
             w2, b2 = _f32(weights2, "weight_hidden_2"), _f32(biases2, "bias_hidden_2")
             w3, b3 = _f32(weightsOut, "weight_out_layer"), _f32(biasesOut, "bias_out_layer")
         sidx = None
+        unsorted = False
         if sortIndex is not None:
             # the feature rows arrive in the order of the UNSORTED points: sort_features folded into this node (one
             # autograd node and one op call less per convolution; same two kernels)
             sidx = _i32(sortIndex, "index_new_pos")
             _req(sidx.dim() == 1 and feats.dim() == 2 and feats.shape[0] == sidx.shape[0],
                  "SortFeaturesBackGradOp expects features with dimensions (numPoints, numFeatures)")
-            feats = _scatter_rows(feats, sidx, feats.shape[0], False)
-        sx = () if sidx is None else (sidx,)  # saved with the other tensors: released when the backward pass has run
+            # ... or no sorted copy at all: on a SMALL level whose layer takes the row kernels in both directions, those
+            # read the rows where they lie (feat_index = the grid's inverse permutation) and write the feature gradient
+            # back in the same order -- two launches and two allocations less per convolution. Large levels keep the
+            # sorted copy: its gathers follow the grid's spatial order.
+            e_ = inPDFs.shape[0]
+            unsorted = (featIndex is not None and feats.shape[0] <= UNSORTED_MAX_POINTS and e_ > 0 and inSamplePts.shape[0] > 0
+                        and _rows_shape(combin, feats.shape[1], feats, inSamplePts.shape[0], e_)
+                        and _rows_shape(combin, feats.shape[1], feats, feats.shape[0], e_, backward=True))
+            if not unsorted:
+                feats = _scatter_rows(feats, sidx, feats.shape[0], False)
+        # saved with the other tensors: released when the backward pass has run
+        sx = () if sidx is None else ((sidx, featIndex) if unsorted else (sidx,))
+        ctx.unsorted = unsorted
         if trusted:
             n, m, e, fin = pts.shape[0], smp.shape[0], pdfs.shape[0], feats.shape[1]
             _req(feats.dim() == 2 and feats.shape[0] == n,
@@ -1129,7 +1143,7 @@ class _SpatialConv(torch.autograd.Function):
                                                   n, m, e, fin, batchSize, float(radius), int(bool(scaleInv)),
                                                   int(bool(avg)), int(bf16), plan.vrow, plan.vcode,
                                                   plan.slice_off, plan.vpos_row, plan.rec, plan.other,
-                                                  ptr(out), ptr(scratch), stream_handle()),
+                                                  ptr(out), ptr(scratch), ptr(featIndex) if unsorted else None, stream_handle()),
                   "spatial_conv(rows)")
             ctx.save_for_backward(pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3, *sx)
             ctx.state = None
@@ -1178,6 +1192,7 @@ class _SpatialConv(torch.autograd.Function):
         saved = ctx.saved_tensors
         pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3 = saved[:15]
         sort_index = saved[15] if len(saved) > 15 else None
+        feat_index = saved[16] if len(saved) > 16 else None  # ctx.unsorted: `feats` are the rows of the unsorted points
         numOutFeatures, combin, batchSize, radius, scaleInv, avg = ctx.attrs
         bf16 = feats.dtype == torch.bfloat16
         og = _feat(outGrad, "out_features_grad")
@@ -1197,7 +1212,12 @@ class _SpatialConv(torch.autograd.Function):
         packed_obj = ctx.packed_ref()
         if packed_obj is None:  # the list object is gone (its cache entry was dropped): the saved tensor has the same rows
             packed_obj = pk
-        if _rows_shape(combin, fin, feats, n, e, backward=True) and m > 0 and (og.data_ptr() & 15) == 0:
+        rows_bwd = _rows_shape(combin, fin, feats, n, e, backward=True) and m > 0 and (og.data_ptr() & 15) == 0
+        if feat_index is not None and not rows_bwd:
+            # (an out-gradient the row kernel cannot take, e.g. a misaligned view: the streaming kernels want sorted rows)
+            feats = _scatter_rows(feats, sort_index, n, False)
+            feat_index = None
+        if rows_bwd:
             # depth-wise layer: ONE sweep over the transposed row plan finishes the feature gradient and the six
             # parameter gradients (the edge-major kernels evaluate the kernel MLP twice for that)
             plan = _row_plan(packed_obj, True, pts, bids, pdfs, smp, st, pk, mn, mx, n, m, e, batchSize, radius, scaleInv, avg)
@@ -1209,10 +1229,12 @@ class _SpatialConv(torch.autograd.Function):
                                                   int(bf16), ptr(plan.row_start), plan.vrow, plan.vcode,
                                                   plan.slice_off, plan.vpos_row, plan.rec, plan.other,
                                                   ptr(fg), ptr(scratch), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(dw3),
-                                                  ptr(db3), ptr(ws), ws.numel(), stream_handle()),
+                                                  ptr(db3), ptr(feat_index), ptr(ws), ws.numel(), stream_handle()),
                   "spatial_conv_grad(rows)")
+            if feat_index is not None:  # the gradient rows already lie in the order the features arrived in
+                sort_index = None
             return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2.view(ws2), db2.view(bs2), dw3.view(ws3), db3.view(bs3),
-                    None, None, None, None, None, None, None, None)
+                    None, None, None, None, None, None, None, None, None)
         ws = _ws(lib.mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, fin, numOutFeatures, int(combin)), pts.device)
         start_t = perm_t = None
         if not combin and e > 0:
@@ -1229,7 +1251,7 @@ class _SpatialConv(torch.autograd.Function):
                                                   ptr(db2), ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
                   "spatial_conv_grad(bf16)")
             return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2.view(ws2), db2.view(bs2), dw3.view(ws3), db3.view(bs3),
-                    None, None, None, None, None, None, None, None)
+                    None, None, None, None, None, None, None, None, None)
         check(lib.mccnn_spatial_conv_bwd(ptr(pts), ptr(feats), ptr(bids), ptr(pdfs), ptr(smp), ptr(st), ptr(pk),
                                          ptr(mn), ptr(mx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
                                          ptr(og), n, m, e, fin, numOutFeatures, int(combin), batchSize, radius,
@@ -1239,7 +1261,7 @@ class _SpatialConv(torch.autograd.Function):
                                          ptr(dw3), ptr(db3), ptr(ws), ws.numel(), stream_handle()),
               "spatial_conv_grad")
         return (None, _unsort_grad(sort_index, fg), None, None, None, None, None, None, None, dw1, db1, dw2.view(ws2), db2.view(bs2), dw3.view(ws3), db3.view(bs3),
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 def _unsort_grad(idx, fg):
@@ -1249,10 +1271,12 @@ def _unsort_grad(idx, fg):
 
 def spatial_conv(inPts, inFeatures, inBatchIds, inPDFs, inSamplePts, neighStartIndexs, packedNeighs, aabbMin, aabbMax,
                  weights1, weights2, weightsOut, biases1, biases2, biasesOut, numOutFeatures, combin, batchSize, radius,
-                 scaleInv, avg, sortIndex=None, _trusted=False):
+                 scaleInv, avg, sortIndex=None, _trusted=False, featIndex=None):
     """SpatialConv (MCConvModuleSrc:70-81). Note the reference's argument order (weights first, then biases);
     the op itself takes (w1, b1, w2, b2, w3, b3). sortIndex (extension): inFeatures are the rows of the UNSORTED points and
-    sortIndex the grid's index_new_pos -- sort_features(inFeatures, sortIndex) happens inside this op."""
+    sortIndex the grid's index_new_pos -- sort_features(inFeatures, sortIndex) happens inside this op. featIndex (with
+    sortIndex): the inverse permutation (sorted row -> unsorted row, build_grid's fifth output); with it the row kernels of a
+    small level read the unsorted rows in place."""
     return _SpatialConv.apply(inPts, inFeatures, inBatchIds, inPDFs, inSamplePts, neighStartIndexs, packedNeighs,
                               aabbMin, aabbMax, weights1, biases1, weights2, biases2, weightsOut, biasesOut,
-                              numOutFeatures, combin, batchSize, radius, scaleInv, avg, sortIndex, _trusted)
+                              numOutFeatures, combin, batchSize, radius, scaleInv, avg, sortIndex, _trusted, featIndex)

@@ -69,9 +69,9 @@ SIGNATURES = {
                                   C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "mccnn_rowplan_build_workspace_bytes": (_sz, [_i, _i, _i]),
     "mccnn_rowplan_build": (_i, [_i] + [_vp] * 8 + [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
-    "mccnn_spatial_conv_fwd_rows": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp]),
+    "mccnn_spatial_conv_fwd_rows": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp, _vp]),
     "mccnn_spatial_conv_bwd_rows_workspace_bytes": (_sz, [_i, _i, _i]),
-    "mccnn_spatial_conv_bwd_rows": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 7 + [_vp] * 8 + [_vp, _sz, _vp]),
+    "mccnn_spatial_conv_bwd_rows": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 7 + [_vp] * 8 + [_vp, _vp, _sz, _vp]),
     "mccnn_transpose_neighbors_workspace_bytes": (_sz, [_i, _i]),
     "mccnn_transpose_neighbors": (_i, [_vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
 }

@@ -10,7 +10,7 @@ std::atomic<int> g_small_off{getenv("MCCNN_SMALL_OFF") ? 1 : 0};
 extern "C" {
 
 int mccnn_block_size(void) { return MCCNN_MLP; }
-int mccnn_abi_version(void) { return 6; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn; 5: row plans, aabb_extent; 6: rowplan_build, build_grid
+int mccnn_abi_version(void) { return 7; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn; 5: row plans, aabb_extent; 6: rowplan_build, build_grid; 7: feat_index of the row kernels, hierarchy_level, find_neighbors_count2
 const char* mccnn_arch(void) { return "gfx950"; }
 int mccnn_debug_small_kernels(int on) { return mccnn::g_small_off.exchange(on ? 0 : 1) == 0 ? 1 : 0; }
 long long mccnn_debug_launch_count(void) { return mccnn::g_launches.load(std::memory_order_relaxed); }

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void sell_fill(const float4* __restrict__ recE
 template <bool BF>
 __global__ __launch_bounds__(256) void rows_combine(const int* __restrict__ rowStart, int rows, int e,
                                                     const int* __restrict__ vposRow, const float* __restrict__ scratch,
-                                                    int cols, void* __restrict__ out, int L) {
+                                                    int cols, void* __restrict__ out, int L, const int* __restrict__ outIdx) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = (blockIdx.x * 4 + wave) * 64;
     const int r = r0 + lane;
@@ -345,11 +345,12 @@ __global__ __launch_bounds__(256) void rows_combine(const int* __restrict__ rowS
         const int rr = r0 + l;
         const int pieces = (__builtin_amdgcn_readlane(deg, l) + L - 1) / L;
         const int v0 = vposRow[rr];
+        const int ro = outIdx ? outIdx[rr] : rr;
         for (int c = lane; c < cols; c += 64) {
             float acc = 0.f;
             for (int k = 0; k < pieces; ++k) acc += scratch[(size_t)(v0 + k) * cols + c];
-            if (BF) reinterpret_cast<__bf16*>(out)[(size_t)rr * cols + c] = (__bf16)acc;
-            else reinterpret_cast<float*>(out)[(size_t)rr * cols + c] = acc;
+            if (BF) reinterpret_cast<__bf16*>(out)[(size_t)ro * cols + c] = (__bf16)acc;
+            else reinterpret_cast<float*>(out)[(size_t)ro * cols + c] = acc;
         }
     }
 }
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void rows_combine(const int* __restrict__ rowS
 template <bool BF>
 __global__ __launch_bounds__(256) void rows_combine_par(const int* __restrict__ rowStart, int rows, int e,
                                                         const int* __restrict__ vposRow, const float* __restrict__ scratch,
-                                                        int cols, void* __restrict__ out, int L) {
+                                                        int cols, void* __restrict__ out, int L, const int* __restrict__ outIdx) {
     const int c4 = cols >> 2;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)rows * c4) return;
@@ -371,21 +372,22 @@ __global__ __launch_bounds__(256) void rows_combine_par(const int* __restrict__ 
         const float4 v = *reinterpret_cast<const float4*>(scratch + (size_t)(v0 + k) * cols + c);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
+    const int ro = outIdx ? outIdx[r] : r;
     if (BF) {
-        unsigned* o = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(out) + (size_t)r * cols + c);
+        unsigned* o = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(out) + (size_t)ro * cols + c);
         o[0] = f32x2_to_bf16(acc.x, acc.y);
         o[1] = f32x2_to_bf16(acc.z, acc.w);
     } else {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)r * cols + c) = acc;
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)ro * cols + c) = acc;
     }
 }
 template <bool BF>
 static void launch_combine(const int* rowStart, int rows, int e, const int* vposRow, const float* scratch, int cols, void* out,
-                           int L, hipStream_t s) {
+                           int L, hipStream_t s, const int* outIdx = nullptr) {
     if (rows < 16384)
-        rows_combine_par<BF><<<ceil_div((long long)rows * (cols >> 2), 256), 256, 0, s>>>(rowStart, rows, e, vposRow, scratch, cols, out, L);
+        rows_combine_par<BF><<<ceil_div((long long)rows * (cols >> 2), 256), 256, 0, s>>>(rowStart, rows, e, vposRow, scratch, cols, out, L, outIdx);
     else
-        rows_combine<BF><<<ceil_div(rows, 256), 256, 0, s>>>(rowStart, rows, e, vposRow, scratch, cols, out, L);
+        rows_combine<BF><<<ceil_div(rows, 256), 256, 0, s>>>(rowStart, rows, e, vposRow, scratch, cols, out, L, outIdx);
 }
 
 // ------------------------------------------------------------------------------------------------ staged row gather
@@ -447,7 +449,7 @@ __device__ __forceinline__ void stage_read(const RowStage& st, int b, int wave, 
 // windows of descending row length: fine-grained items, no tail. FEAT: 2 = f32 rows, 4 = bf16 rows.
 template <int FEAT>
 __global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float* __restrict__ out, float* __restrict__ scratch,
-                                                   int qTiles, int spw, int groups) {
+                                                   int qTiles, int spw, int groups, const int* __restrict__ featIdx) {
     __shared__ float stageMem[MCCNN_STAGE_FLOATS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i4 = lane & 3;
     constexpr bool BF = FEAT == 4;
@@ -477,8 +479,14 @@ __global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float*
         float4 rcN = p.rec[(size_t)off + lane];
         int jP = 0;  // producer: neighbour index of row `prow`, two iterations ahead of the consumer
         f32x4 s0, s1;
-        stage_load<BF>(a.feats, p.other[(size_t)off + prow], a.Fin, qt * 32, lane, s0, s1);
-        if (len > 1) jP = p.other[(size_t)off + 64 + prow];
+        // featIdx (optional): the feature rows lie in the order of the UNSORTED points, row j of the sorted list is
+        // featIdx[j] there -- the layer reads them where they are instead of from a sorted copy (small levels only: the
+        // gathers lose their spatial order)
+        {
+            const int j0 = p.other[(size_t)off + prow];
+            stage_load<BF>(a.feats, featIdx ? featIdx[j0] : j0, a.Fin, qt * 32, lane, s0, s1);
+        }
+        if (len > 1) { jP = p.other[(size_t)off + 64 + prow]; if (featIdx) jP = featIdx[jP]; }
         stage_store<BF>(st, 0, wave, lane, s0, s1);
         __syncthreads();
         for (int it = 0; it < len; ++it) {
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float*
             if (more) {  // iteration it + 1: its lines are requested now and parked after this iteration's arithmetic
                 stage_load<BF>(a.feats, jP, a.Fin, qt * 32, lane, s0, s1);
                 rcN = p.rec[(size_t)off + (size_t)(it + 1) * 64 + lane];
-                if (it + 2 < len) jP = p.other[(size_t)off + (size_t)(it + 2) * 64 + prow];
+                if (it + 2 < len) { jP = p.other[(size_t)off + (size_t)(it + 2) * 64 + prow]; if (featIdx) jP = featIdx[jP]; }
             }
             float f[8];
             stage_read<BF>(st, it & 1, wave, lane, f);
@@ -530,7 +538,8 @@ __global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float*
 template <int FEAT>
 __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, const float* __restrict__ outGrad,
                                                       float* __restrict__ featGrad, float* __restrict__ scratch,
-                                                      float* __restrict__ partials, int spw, int groups) {
+                                                      float* __restrict__ partials, int spw, int groups,
+                                                      const int* __restrict__ featIdx) {
     extern __shared__ float lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i4 = lane & 3;
     const int qTiles = (a.nb + 3) >> 2;
@@ -571,7 +580,8 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
         const int len = (p.sliceOff[slice + 1] - off) >> 6;
         if (len == 0) continue;  // slices beyond the list's last virtual row
         const int r = p.vrow[slice * 64 + lane];
-        const int jr = max(r, 0);
+        int jr = max(r, 0);
+        if (featIdx) jr = featIdx[jr];  // features and their gradient in the order of the unsorted points (see dw_fwd_rows)
         // the lane's own feature row piece is constant over the slice: parked in LDS (two conflict-free float4 planes
         // per wave) instead of 8 VGPRs -- the 176 sums leave no room for it
         f32x4* fpark = reinterpret_cast<f32x4*>(lds + 4 * MCCNN_WQ_BWD) + wave * 128;
@@ -700,9 +710,9 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
             dst[1] = make_float4(dF[4], dF[5], dF[6], dF[7]);
         } else if (r >= 0) {
             if (BF) {
-                reinterpret_cast<uint4*>(fg16 + (size_t)r * a.Fin)[q] = f32x8_to_bf16(dF);
+                reinterpret_cast<uint4*>(fg16 + (size_t)jr * a.Fin)[q] = f32x8_to_bf16(dF);
             } else {
-                float4* dst = reinterpret_cast<float4*>(featGrad + (size_t)r * a.Fin + q * 8);
+                float4* dst = reinterpret_cast<float4*>(featGrad + (size_t)jr * a.Fin + q * 8);
                 dst[0] = make_float4(dF[0], dF[1], dF[2], dF[3]);
                 dst[1] = make_float4(dF[4], dF[5], dF[6], dF[7]);
             }
@@ -935,7 +945,7 @@ int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feat
                                 int num_feats, int batch_size, float radius, int scale_inv, int avg, int bf16,
                                 const int* plan_vrow, const int* plan_vcode, const int* slice_off, const int* vpos_row,
                                 const void* plan_rec, const int* plan_other, void* out, float* scratch,
-                                mccnn_stream_t stream) {
+                                const int* feat_index, mccnn_stream_t stream) {
     ConvArgs a;
     int rc = conv_fill_args(a, sorted_pts, (const float*)sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed,
                             aabb_min, aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_feats, num_feats, 0, batch_size, radius,
@@ -953,8 +963,8 @@ int mccnn_spatial_conv_fwd_rows(const float* sorted_pts, const void* sorted_feat
     const int groups = (p.S + spw - 1) / spw;
     const long long blocks = ((long long)groups * qTiles + 7) / 8 * 8;
     if (blocks > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
-    if (bf16) dw_fwd_rows<4><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, scratch, qTiles, spw, groups);
-    else dw_fwd_rows<2><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, scratch, qTiles, spw, groups);
+    if (bf16) dw_fwd_rows<4><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, scratch, qTiles, spw, groups, feat_index);
+    else dw_fwd_rows<2><<<(int)blocks, 256, 0, s>>>(a, p, (float*)out, scratch, qTiles, spw, groups, feat_index);
     MCCNN_LAUNCHED();
     if (bf16) launch_combine<true>(start_idx, m, e, vpos_row, scratch, a.outF, out, z.L, s);
     else launch_combine<false>(start_idx, m, e, vpos_row, scratch, a.outF, out, z.L, s);
@@ -979,7 +989,7 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
                                 int bf16, const int* start_t, const int* plan_vrow, const int* plan_vcode,
                                 const int* slice_off, const int* vpos_row, const void* plan_rec, const int* plan_other,
                                 void* feat_grad, float* scratch, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
-                                float* db3, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+                                float* db3, const int* feat_index, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
     ConvArgs a;
     int rc = conv_fill_args(a, sorted_pts, (const float*)sorted_feats, sorted_batch_ids, pdfs, samples, start_idx, packed,
                             aabb_min, aabb_max, w1, b1, w2, b2, w3, b3, n, m, e, num_feats, num_feats, 0, batch_size, radius,
@@ -1001,11 +1011,11 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
     if (blocks > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     float* partials = reinterpret_cast<float*>(ws);
     const size_t lds = ((size_t)4 * MCCNN_WQ_BWD + 4 * 512) * sizeof(float);  // 4 blocks of weights + the parked feature pieces
-    if (bf16) dw_bwd_rows<4><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
-    else dw_bwd_rows<2><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups);
+    if (bf16) dw_bwd_rows<4><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups, feat_index);
+    else dw_bwd_rows<2><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups, feat_index);
     MCCNN_LAUNCHED();
-    if (bf16) launch_combine<true>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s);
-    else launch_combine<false>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s);
+    if (bf16) launch_combine<true>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s, feat_index);
+    else launch_combine<false>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s, feat_index);
     MCCNN_LAUNCHED();
     launch_reduce_partials(partials, groups, a.nb, dw1, db1, dw2, db2, dw3, db3, s);
     MCCNN_LAUNCHED();

@@ -63,8 +63,9 @@ def test_build_grid_equals_the_two_sort_ops(mc):
         mn, mx = mc.compute_aabb(P, Bi, B, rel)
         keys, idx = mc.sort_points_step1(P, Bi, mn, mx, B, radius, rel)
         sP, sB, _, cells = mc.sort_points_step2(P, Bi, F, keys, idx, mn, mx, B, radius, rel)
-        gP, gB, gC, gI = mc.build_grid(P, Bi, mn, mx, B, radius, rel)
+        gP, gB, gC, gI, gInv = mc.build_grid(P, Bi, mn, mx, B, radius, rel)
         assert torch.equal(gP, sP) and torch.equal(gB, sB) and torch.equal(gC, cells) and torch.equal(gI, idx)
+        assert torch.equal(gInv[gI.long()].cpu(), torch.arange(len(pts), dtype=torch.int32))  # the inverse permutation
 
 
 @pytest.mark.parametrize("fin,fout,combin", [(1, 16, True), (3, 8, True), (16, 16, False), (64, 64, False)])
@@ -76,7 +77,7 @@ def test_spatial_conv_sort_index_equals_sort_features(mc, fin, fout, combin):
     P, Bi = _t(pts), _t(bids)
     B, radius = 2, 0.15
     mn, mx = mc.compute_aabb(P, Bi, B, True)
-    sP, sB, cells, idx = mc.build_grid(P, Bi, mn, mx, B, radius, True)
+    sP, sB, cells, idx, inv = mc.build_grid(P, Bi, mn, mx, B, radius, True)
     start, packed = mc.find_neighbors(P, Bi, sP, cells, mn, mx, radius, B, True)
     pdfs = mc.compute_pdf(sP, sB, mn, mx, start, packed, 0.2, radius, B, True)
     nb = (fin * fout + 7) // 8 if combin else (fin + 7) // 8
@@ -84,10 +85,13 @@ def test_spatial_conv_sort_index_equals_sort_features(mc, fin, fout, combin):
     outF = fout if combin else fin
     og = _t(rng.random((len(pts), outF), dtype=np.float32))
     res = []
-    for fused in (False, True):
+    for fused in (False, True, "in place"):
         F = _t(rng.random((len(pts), fin), dtype=np.float32) if not res else res[0][2]).requires_grad_(True)
         ws = [_t(w[k]).requires_grad_(True) for k in ("w1", "w2", "w3", "b1", "b2", "b3")]
-        if fused:
+        if fused == "in place":  # depth-wise layers: the row kernels read the unsorted rows where they lie (featIndex)
+            out = mc.spatial_conv(sP, F, sB, pdfs, P, start, packed, mn, mx, *ws, fout, combin, B, radius, True, True,
+                                  sortIndex=idx, featIndex=inv)
+        elif fused:
             out = mc.spatial_conv(sP, F, sB, pdfs, P, start, packed, mn, mx, *ws, fout, combin, B, radius, True, True,
                                   sortIndex=idx)
         else:
@@ -95,13 +99,14 @@ def test_spatial_conv_sort_index_equals_sort_features(mc, fin, fout, combin):
                                   radius, True, True)
         grads = torch.autograd.grad([out], [F] + ws, [og])
         res.append((out.detach(), grads, F.detach().cpu().numpy()))
-    assert torch.equal(res[0][0], res[1][0])
     deterministic = not combin  # combin layers add their per-edge feature gradients with float atomics
-    for ga, gb in zip(res[0][1], res[1][1]):
-        if deterministic:
-            assert torch.equal(ga, gb)
-        else:
-            assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max())
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0])
+        for ga, gb in zip(res[0][1], other[1]):
+            if deterministic:
+                assert torch.equal(ga, gb)
+            else:
+                assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max())
 
 
 def test_builder_fused_path_equals_the_op_chain(mc):
