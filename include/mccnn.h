@@ -375,6 +375,9 @@ int mccnn_rowplan_fill(int transposed, const void* rec_edges, const int* packed,
 int mccnn_rowplan_buffer(int rows, int e, long long offsets[6], long long* total_bytes, int* num_slices,
                          long long* slot_capacity, long long* scratch_rows);
 size_t mccnn_rowplan_build_workspace_bytes(int rows, int e, int transposed);
+/* 1 when mccnn_rowplan_build evaluates the records of a plan of (rows, e) inside its fill (small lists): rec_edges may then
+ * be NULL and is neither read nor written. */
+int mccnn_rowplan_inline_records(int rows, int e);
 int mccnn_rowplan_build(int transposed, const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs,
                         const float* samples, const int* start_idx, const int* packed, const float* aabb_min,
                         const float* aabb_max, int n, int m, int e, int batch_size, float radius, int scale_inv,

@@ -306,7 +306,8 @@ def _plan_layout(lib, rows, e, transposed):
         if len(_PLAN_LAYOUTS) > 512:
             _PLAN_LAYOUTS.clear()
         hit = _PLAN_LAYOUTS[key] = (tuple(offs), total.value, S.value, cap.value, srows.value,
-                                    lib.mccnn_rowplan_build_workspace_bytes(rows, e, int(transposed)))
+                                    lib.mccnn_rowplan_build_workspace_bytes(rows, e, int(transposed)),
+                                    bool(lib.mccnn_rowplan_inline_records(rows, e)))
     return hit
 
 
@@ -349,7 +350,7 @@ def _row_plan(packed_obj, transposed, pts, bids, pdfs, smp, st, pk, mn, mx, n, m
         order = _order_hint(centre_points) if centre_points is not None else None
         if order is not None and order.shape[0] != m:
             order = None
-    offs, total, S, cap, srows, wsb = _plan_layout(lib, rows, e, transposed)
+    offs, total, S, cap, srows, wsb, inline_rec = _plan_layout(lib, rows, e, transposed)
     plan = RowPlan()
     plan.key, plan.event, plan.row_start = key, None, row_start
     plan.scratch_rows, plan.num_slices, plan.slot_capacity = srows, S, cap
@@ -359,7 +360,9 @@ def _row_plan(packed_obj, transposed, pts, bids, pdfs, smp, st, pk, mn, mx, n, m
     # the per-edge records in edge order: written once per list, permuted into both plans
     rec_e = plans.get("rec_edges")
     rready = 1
-    if rec_e is None or rec_e[0] != key[1:]:
+    if inline_rec:  # a small list: the fill evaluates the records itself, no edge-order array
+        rec_e = (None, None, None)
+    elif rec_e is None or rec_e[0] != key[1:]:
         rec_e = plans["rec_edges"] = [key[1:], torch.empty((max(e, 1), 4), dtype=torch.float32, device=dev), None]
         rready = 0
     elif rec_e[2] is not None:  # written on another stream (prefetch_rowplan)

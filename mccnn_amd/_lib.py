@@ -68,6 +68,7 @@ SIGNATURES = {
     "mccnn_rowplan_buffer": (_i, [_i, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(_i),
                                   C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "mccnn_rowplan_build_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mccnn_rowplan_inline_records": (_i, [_i, _i]),
     "mccnn_rowplan_build": (_i, [_i] + [_vp] * 8 + [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "mccnn_spatial_conv_fwd_rows": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp, _vp]),
     "mccnn_spatial_conv_bwd_rows_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -432,17 +432,7 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
 __global__ __launch_bounds__(256) void edge_records(ConvArgs a, float4* __restrict__ rec) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.e) return;
-    int2 pr = a.packed[t];
-    float invR = a.invRadius;
-    if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[pr.x], a.B)));
-    const float* p = a.pts + (size_t)pr.x * 3;
-    const float* c = a.samples + (size_t)pr.y * 3;
-    int e0 = a.start[pr.y];
-    int e1 = (pr.y < a.m - 1) ? a.start[pr.y + 1] : a.e;
-    float K = a.avg ? (float)(e1 - e0) : 1.0f;
-    const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[pr.x], a.B)) : a.radius;
-    rec[t] = make_float4(div_exact(p[0] - c[0], R, invR), div_exact(p[1] - c[1], R, invR), div_exact(p[2] - c[2], R, invR),
-                         __builtin_amdgcn_rcpf(a.pdfs[t] * K));
+    rec[t] = edge_record(a, t);
 }
 
 #ifndef MCCNN_BWD_OCC

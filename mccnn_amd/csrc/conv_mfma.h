@@ -287,6 +287,22 @@ __device__ __forceinline__ float div_exact(float x, float R, float invR) {
     return __builtin_fmaf(r, invR, q);
 }
 
+// The record of edge t: (delta0, delta1, delta2, 1 / (pdf K)) -- delta = (point - centre) / R correctly rounded
+// (spatial_conv.cu:155-158), K = the centre's neighbour count when the layer averages (spatial_conv.cu:160-166).
+__device__ __forceinline__ float4 edge_record(const ConvArgs& a, int t) {
+    const int2 pr = a.packed[t];
+    float invR = a.invRadius;
+    if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[pr.x], a.B)));
+    const float* p = a.pts + (size_t)pr.x * 3;
+    const float* c = a.samples + (size_t)pr.y * 3;
+    const int e0 = a.start[pr.y];
+    const int e1 = (pr.y < a.m - 1) ? a.start[pr.y + 1] : a.e;
+    const float K = a.avg ? (float)(e1 - e0) : 1.0f;
+    const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[pr.x], a.B)) : a.radius;
+    return make_float4(div_exact(p[0] - c[0], R, invR), div_exact(p[1] - c[1], R, invR), div_exact(p[2] - c[2], R, invR),
+                       __builtin_amdgcn_rcpf(a.pdfs[t] * K));
+}
+
 // smallest c in [0, m] with S(c) >= t, S(c) = start[c] (c < m), S(m) = e. 64-ary: three dependent loads for m < 2^18.
 __device__ __forceinline__ int wave_lower_bound(const int* __restrict__ start, int m, int e, int t, int lane) {
     int lo = 0, hi = m;

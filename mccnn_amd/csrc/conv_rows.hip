@@ -279,11 +279,13 @@ __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStar
 // forward plan a lane's 4 edges are 64 contiguous bytes of records and 32 of pairs. (One wave per slice walking all its
 // iterations with the set-up arithmetic inline was 260 us per plan on the 100k room.)
 #define MCCNN_FILL_CHUNK 16
-template <bool TR>
+// INL: the records are computed here from the geometry instead of permuted from the edge-order array -- small lists, where
+// the extra launch and buffer of mccnn_edge_records cost more than evaluating every record twice (once per plan).
+template <bool TR, bool INL>
 __global__ __launch_bounds__(256) void sell_fill(const float4* __restrict__ recE, const int2* __restrict__ packed, int e,
                                                  const int* __restrict__ rowStart, int rows, const int* __restrict__ permT,
                                                  RowPlan p, long long cap, float4* __restrict__ rec, int* __restrict__ oth,
-                                                 int L) {
+                                                 int L, ConvArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slice = blockIdx.x;
     const int off = p.sliceOff[slice];
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256) void sell_fill(const float4* __restrict__ recE
     float4 rc[K];
     int2 pr[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { rc[k] = recE[eid[k]]; pr[k] = packed[eid[k]]; }
+    for (int k = 0; k < K; ++k) { rc[k] = INL ? edge_record(a, eid[k]) : recE[eid[k]]; pr[k] = packed[eid[k]]; }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int it = it0 + k;
@@ -861,15 +863,20 @@ int mccnn_rowplan_fill(int transposed, const void* rec_edges, const int* packed,
     const PlanSizes z = plan_sizes(rows, e);
     RowPlan p = {plan_vrow, plan_vcode, slice_off, vpos_row, nullptr, nullptr, rows, z.S};
     const dim3 grid(z.S, ceil_div(z.L, MCCNN_FILL_CHUNK));
+    const ConvArgs none = {};
     if (transposed)
-        sell_fill<true><<<grid, 256, 0, s>>>(reinterpret_cast<const float4*>(rec_edges), reinterpret_cast<const int2*>(packed), e,
-                                             row_start, rows, perm_t, p, z.slots, reinterpret_cast<float4*>(rec), other, z.L);
+        sell_fill<true, false><<<grid, 256, 0, s>>>(reinterpret_cast<const float4*>(rec_edges), reinterpret_cast<const int2*>(packed), e,
+                                                    row_start, rows, perm_t, p, z.slots, reinterpret_cast<float4*>(rec), other, z.L, none);
     else
-        sell_fill<false><<<grid, 256, 0, s>>>(reinterpret_cast<const float4*>(rec_edges), reinterpret_cast<const int2*>(packed), e,
-                                              row_start, rows, nullptr, p, z.slots, reinterpret_cast<float4*>(rec), other, z.L);
+        sell_fill<false, false><<<grid, 256, 0, s>>>(reinterpret_cast<const float4*>(rec_edges), reinterpret_cast<const int2*>(packed), e,
+                                                     row_start, rows, nullptr, p, z.slots, reinterpret_cast<float4*>(rec), other, z.L, none);
     MCCNN_LAUNCHED();
     return 0;
 }
+
+// Plans of small lists evaluate their records inside the fill (no edge-order record array, one launch less per list).
+static bool plan_inline_records(int rows, int e) { return plan_sizes(rows, e).small && e <= 262144; }
+int mccnn_rowplan_inline_records(int rows, int e) { return (rows > 0 && e > 0 && plan_inline_records(rows, e)) ? 1 : 0; }
 
 static size_t plan_al(size_t ints) { return (ints + 63) / 64 * 64; }  // 256-byte aligned pieces
 
@@ -903,8 +910,10 @@ int mccnn_rowplan_build(int transposed, const float* sorted_pts, const int* sort
                         const float* aabb_max, int n, int m, int e, int batch_size, float radius, int scale_inv, int avg,
                         const int* order, void* rec_edges, int rec_ready, int* start_t, int* perm_t, int tlist_ready,
                         void* plan_buffer, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
-    if (n < 0 || m < 0 || e < 0 || !plan_buffer || !rec_edges) return MCCNN_E_BADARG;
+    if (n < 0 || m < 0 || e < 0 || !plan_buffer) return MCCNN_E_BADARG;
     const int rows = transposed ? n : m;
+    const bool inl = rows > 0 && e > 0 && plan_inline_records(rows, e);
+    if (!inl && !rec_edges) return MCCNN_E_BADARG;
     if (transposed && (!start_t || !perm_t)) return MCCNN_E_BADARG;
     if (!ws || ws_bytes < mccnn_rowplan_build_workspace_bytes(rows, e, transposed)) return MCCNN_E_WORKSPACE;
     long long off[6], total, cap, srows;
@@ -925,6 +934,28 @@ int mccnn_rowplan_build(int transposed, const float* sorted_pts, const int* sort
     const int* rowStart = transposed ? start_t : start_idx;
     rc = mccnn_rowplan_layout(rowStart, rows, e, transposed ? nullptr : order, vrow, vcode, sliceOff, vposRow, ws, ws_bytes, stream);
     if (rc) return rc;
+    if (inl) {
+        if (batch_size <= 0 || !(radius > 0.0f) || !sorted_pts || !sorted_batch_ids || !pdfs || !samples || !start_idx || !packed ||
+            !aabb_min || !aabb_max)
+            return MCCNN_E_BADARG;
+        ConvArgs a = {};
+        a.pts = sorted_pts; a.bids = sorted_batch_ids; a.pdfs = pdfs; a.samples = samples; a.start = start_idx;
+        a.packed = reinterpret_cast<const int2*>(packed); a.mn = aabb_min; a.mx = aabb_max;
+        a.n = n; a.m = m; a.e = e; a.radius = radius; a.invRadius = 1.0f / radius; a.scaleInv = scale_inv; a.avg = avg;
+        a.B = batch_size;
+        hipStream_t s = (hipStream_t)stream;
+        const PlanSizes z = plan_sizes(rows, e);
+        RowPlan p = {vrow, vcode, sliceOff, vposRow, nullptr, nullptr, rows, z.S};
+        const dim3 grid(z.S, ceil_div(z.L, MCCNN_FILL_CHUNK));
+        if (transposed)
+            sell_fill<true, true><<<grid, 256, 0, s>>>(nullptr, a.packed, e, rowStart, rows, perm_t, p, z.slots,
+                                                       reinterpret_cast<float4*>(rec), other, z.L, a);
+        else
+            sell_fill<false, true><<<grid, 256, 0, s>>>(nullptr, a.packed, e, rowStart, rows, nullptr, p, z.slots,
+                                                        reinterpret_cast<float4*>(rec), other, z.L, a);
+        MCCNN_LAUNCHED();
+        return 0;
+    }
     if (!rec_ready) {
         rc = mccnn_edge_records(sorted_pts, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min, aabb_max, n, m, e,
                                 batch_size, radius, scale_inv, avg, rec_edges, stream);
