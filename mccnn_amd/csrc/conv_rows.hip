@@ -537,7 +537,9 @@ __global__ __launch_bounds__(256) void dw_fwd_rows(ConvArgs a, RowPlan p, float*
 // the workgroup). Per (slice, block) sweep: the block's 176 weight-gradient sums stay in VGPRs across all slices of the
 // group; the 8 feature-gradient sums of the lane's own point are finished at the end of the slice and stored once.
 // Math: spatial_conv.cu:563-680 (see conv_bwd_mfma in conv.hip for the same steps in the edge-major form).
-template <int FEAT>
+// IDX (featIdx given) is a template parameter: compiled in, the extra row look-ups cost the sweep three more spilled
+// registers even when the index is absent (2.39 -> 2.78 ms for dw256 on the room); only small levels use it.
+template <int FEAT, bool IDX>
 __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, const float* __restrict__ outGrad,
                                                       float* __restrict__ featGrad, float* __restrict__ scratch,
                                                       float* __restrict__ partials, int spw, int groups,
@@ -583,7 +585,9 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
         if (len == 0) continue;  // slices beyond the list's last virtual row
         const int r = p.vrow[slice * 64 + lane];
         int jr = max(r, 0);
-        if (featIdx) jr = featIdx[jr];  // features and their gradient in the order of the unsorted points (see dw_fwd_rows)
+        if (IDX) jr = featIdx[jr];  // features and their gradient in the order of the unsorted points (see dw_fwd_rows)
+        // (jr dies with the feature load below: the row index of the gradient is looked up AGAIN at the end of the slice --
+        // kept live across the sweep it cost five more spilled registers and 16 % of the kernel's time)
         // the lane's own feature row piece is constant over the slice: parked in LDS (two conflict-free float4 planes
         // per wave) instead of 8 VGPRs -- the 176 sums leave no room for it
         f32x4* fpark = reinterpret_cast<f32x4*>(lds + 4 * MCCNN_WQ_BWD) + wave * 128;
@@ -711,10 +715,11 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
             dst[0] = make_float4(dF[0], dF[1], dF[2], dF[3]);
             dst[1] = make_float4(dF[4], dF[5], dF[6], dF[7]);
         } else if (r >= 0) {
+            const int ro = IDX ? featIdx[r] : r;
             if (BF) {
-                reinterpret_cast<uint4*>(fg16 + (size_t)jr * a.Fin)[q] = f32x8_to_bf16(dF);
+                reinterpret_cast<uint4*>(fg16 + (size_t)ro * a.Fin)[q] = f32x8_to_bf16(dF);
             } else {
-                float4* dst = reinterpret_cast<float4*>(featGrad + (size_t)jr * a.Fin + q * 8);
+                float4* dst = reinterpret_cast<float4*>(featGrad + (size_t)ro * a.Fin + q * 8);
                 dst[0] = make_float4(dF[0], dF[1], dF[2], dF[3]);
                 dst[1] = make_float4(dF[4], dF[5], dF[6], dF[7]);
             }
@@ -1042,8 +1047,11 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
     if (blocks > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     float* partials = reinterpret_cast<float*>(ws);
     const size_t lds = ((size_t)4 * MCCNN_WQ_BWD + 4 * 512) * sizeof(float);  // 4 blocks of weights + the parked feature pieces
-    if (bf16) dw_bwd_rows<4><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups, feat_index);
-    else dw_bwd_rows<2><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups, feat_index);
+    if (feat_index) {
+        if (bf16) dw_bwd_rows<4, true><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups, feat_index);
+        else dw_bwd_rows<2, true><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups, feat_index);
+    } else if (bf16) dw_bwd_rows<4, false><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups, nullptr);
+    else dw_bwd_rows<2, false><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups, nullptr);
     MCCNN_LAUNCHED();
     if (bf16) launch_combine<true>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s, feat_index);
     else launch_combine<false>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s, feat_index);
