@@ -56,9 +56,52 @@ def test_binding_covers_header_and_loads(lib_path):
     assert lib.mccnn_spatial_conv_bwd_workspace_bytes(1000, 1000, 50000, 1, 64, 1) > 50000 * 16
 
 
-def test_code_object_is_gfx950_only(lib_path):
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", lib_path], capture_output=True, text=True)
-    txt = out.stdout + out.stderr
+def _code_objects(lib_path, tmp_path):
+    """llvm-objdump --offloading EXTRACTS the bundles next to its input: work on a copy in a scratch directory.
+    -> (objdump's text, paths of the extracted gfx950 code objects)"""
+    import shutil
+    copy = os.path.join(str(tmp_path), os.path.basename(lib_path))
+    shutil.copy(lib_path, copy)
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", copy], capture_output=True, text=True,
+                         cwd=str(tmp_path))
+    cos = sorted(os.path.join(str(tmp_path), f) for f in os.listdir(str(tmp_path)) if f.endswith("gfx950"))
+    return out.stdout + out.stderr, cos
+
+
+def test_register_budget_of_the_hot_kernels(lib_path, tmp_path):
+    """Regression guard: the kernels that run at the edge of the register file must not pick up spills unnoticed (an
+    extra kernel argument once cost the depth-wise backward sweep three more spilled registers and 16 % of its time;
+    nothing but a timing of that one layer showed it). Budgets = what the shipped build uses (kernel descriptors'
+    metadata), with a little slack for compiler updates."""
+    _, cos = _code_objects(lib_path, tmp_path)
+    if not cos:
+        pytest.skip("llvm-objdump did not extract the code objects")
+    meta = {}
+    for co in cos:
+        txt = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+        for blk in txt.split("- .agpr_count")[1:] if "- .agpr_count" in txt else txt.split("  - .")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            scr = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+            if name and scr:
+                meta[name.group(1)] = int(scr.group(1))
+    assert meta, "no kernel metadata found"
+    budgets = {
+        r"dw_bwd_rowsILi[24]ELb0E": 40,      # 32 at the time of writing (7 spilled registers in the reduction epilogue)
+        r"dw_fwd_rowsILi[24]E": 0,
+        r"f1_bwd_edges": 0, r"f1_fwd_edges": 0,
+        r"conv_streamILb0ELi[24]ELb1E": 0,
+        r"conv_bwd_mfmaILb0ELi[24]ELb1E": 0,  # the depth-wise streaming backward (COOP)
+        r"conv_bwd_mfmaILb1ELi3ELb0E": 64,     # combin layers with 2..4 input features: 60 (DESIGN section 8, item 4)
+    }
+    for pat, limit in budgets.items():
+        hits = {k: v for k, v in meta.items() if re.search(pat, k)}
+        assert hits, pat
+        for k, v in hits.items():
+            assert v <= limit, "%s: %d bytes of scratch per lane (budget %d)" % (k, v, limit)
+
+
+def test_code_object_is_gfx950_only(lib_path, tmp_path):
+    txt, _ = _code_objects(lib_path, tmp_path)
     if "gfx" not in txt:
         out = subprocess.check_output(["strings", lib_path], text=True)
         txt = "\n".join(l for l in out.splitlines() if "amdgcn-amd-amdhsa" in l)
