@@ -2,6 +2,8 @@
 // estimate. Replaces tf_ops/find_neighbors.cu and tf_ops/compute_pdf.cu.
 #include "common.h"
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
 #include <type_traits>
 
 namespace mccnn {
@@ -13,7 +15,7 @@ struct CentreCtx {
 
 __device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centres, const int* __restrict__ cb,
                                                 const float* __restrict__ mn, const float* __restrict__ mx,
-                                                int i, int B, int nc, float radius, int scaleInv) {
+                                                int i, int B, int nc, float radius, int scaleInv, float Tabs) {
     CentreCtx c;
     c.b = clamp_batch(cb[i], B);
     c.cx = centres[(size_t)i * 3];
@@ -22,7 +24,7 @@ __device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centre
     float ext = max_extent(mn, mx, c.b);
     float cs = ext / (float)nc;
     c.R = scaleInv ? radius * ext : radius;  // find_neighbors.cu:73
-    c.T = sqrt_threshold(c.R);
+    c.T = scaleInv ? sqrt_threshold(c.R) : Tabs;  // an absolute radius has ONE threshold: the host computes it
     c.x = cell_coord(c.cx, mn[c.b * 3], cs, nc);
     c.y = cell_coord(c.cy, mn[c.b * 3 + 1], cs, nc);
     c.z = cell_coord(c.cz, mn[c.b * 3 + 2], cs, nc);
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                                                     int* __restrict__ cnt, unsigned long long* __restrict__ masks,
                                                     const int* __restrict__ startIdx, int* __restrict__ packed,
                                                     int capacity, unsigned long long* __restrict__ zeroWords, int numZero,
-                                                    int G /* centres per wave, 1 .. MCCNN_NW_G */) {
+                                                    int G /* centres per wave, 1 .. MCCNN_NW_G */, float Tabs) {
     constexpr bool FILL = MODE == 1;
     // the status words of the prefix sum that follows the count pass (scan.hip): cleared here, no launch of their own
     if (!FILL && blockIdx.x == 0)
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
     const int ci = g0 + lane;
     const bool own = lane < G && ci < m;
     const int i = own ? (order ? order[ci] : ci) : 0;
-    CentreCtx c = centre_ctx(centres, cb, mn, mx, i, B, nc, radius, scaleInv);
+    CentreCtx c = centre_ctx(centres, cb, mn, mx, i, B, nc, radius, scaleInv, Tabs);
     const int key = own ? ((c.b * nc + c.x) * nc + c.y) * nc + c.z : -1;
     int count = 0;                                   // hits of this lane's centre so far
     const int base = (FILL && own) ? startIdx[i] : 0;
@@ -662,6 +664,16 @@ size_t mccnn_find_neighbors_workspace_bytes(int m, int n) {
 // Centres per wave: 8 consecutive centres of the visiting order share most of their windows on a large list (~8 points
 // per cell), but a list with few centres needs the waves -- 6 344 pooling centres with ~900 candidates each ran 139 us per
 // pass on 793 waves (BASELINE cfg2 Pool_1), the coarse levels of a hierarchy 20 us on a handful.
+// sqrt_threshold (common.h) on the host: the same float operations, both square roots correctly rounded
+static float sqrt_threshold_host(float R) {
+    auto prev = [](float v) { uint32_t u; memcpy(&u, &v, 4); --u; memcpy(&v, &u, 4); return v; };
+    auto next = [](float v) { uint32_t u; memcpy(&u, &v, 4); ++u; memcpy(&v, &u, 4); return v; };
+    float t = R * R;
+    for (int it = 0; it < 8 && t > 0.0f && sqrtf(prev(t)) >= R; ++it) t = prev(t);
+    for (int it = 0; it < 8 && sqrtf(t) < R; ++it) t = next(t);
+    return t;
+}
+
 static int neigh_group(int m) {
     static const int forced = getenv("MCCNN_NW_GROUP") ? atoi(getenv("MCCNN_NW_GROUP")) : 0;  // A/B switch, read once
     if (forced >= 1 && forced <= MCCNN_NW_G) return forced;
@@ -726,7 +738,7 @@ static int find_neighbors_count_impl(const float* centres, const int* centre_bat
     neigh_window<0><<<ceil_div(m, 4 * G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
                                                      aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, w.cnt,
                                                      w.masks, nullptr, nullptr, 0, (unsigned long long*)w.scanws,
-                                                     (int)(scan_status_bytes(m) / sizeof(unsigned long long)), G);
+                                                     (int)(scan_status_bytes(m) / sizeof(unsigned long long)), G, scale_inv ? 0.0f : sqrt_threshold_host(radius));
     MCCNN_LAUNCHED();
     int rc = exclusive_scan_i32(w.cnt, start_idx, m, total_dev, w.scanws, s, true, total_host);
     if (rc) return rc;
@@ -748,7 +760,7 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     const int G = neigh_group(m);
     neigh_window<1><<<ceil_div(m, 4 * G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
                                                      aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, nullptr,
-                                                     w.masks, start_idx, packed, e, nullptr, 0, G);
+                                                     w.masks, start_idx, packed, e, nullptr, 0, G, scale_inv ? 0.0f : sqrt_threshold_host(radius));
     MCCNN_LAUNCHED();
     return 0;
 }
