@@ -676,7 +676,7 @@ static float sqrt_threshold_host(float R) {
 
 static int neigh_group(int m) {
     static const int forced = getenv("MCCNN_NW_GROUP") ? atoi(getenv("MCCNN_NW_GROUP")) : 0;  // A/B switch, read once
-    if (forced >= 1 && forced <= MCCNN_NW_G) return forced;
+    if (forced >= 1 && forced <= 32) return forced;
     return m >= 32768 ? MCCNN_NW_G : (m >= 16384 ? 4 : (m >= 8192 ? 2 : 1));
 }
 
