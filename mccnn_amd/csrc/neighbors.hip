@@ -43,13 +43,6 @@ __device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centre
 // thread per (centre, cell) 60 + 82 us, this one 31 + 37 us. FILL == false counts per centre, FILL == true writes the
 // (j, i) rows at startIdx[i].
 // Windows larger than MCCNN_NW_CAP points are processed in segments of the flat candidate list.
-// v[lane L] = val (wave-uniform), L a compile-time lane: v_writelane_b32 (no builtin in this toolchain; one SGPR operand
-// per instruction on gfx9, so the lane select is an inline constant)
-template <int L>
-__device__ __forceinline__ void writelane_u(unsigned& v, unsigned val) {
-    const unsigned sv = __builtin_amdgcn_readfirstlane(val);
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(sv), "n"(L));
-}
 __device__ __forceinline__ float readlane_f(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -178,12 +171,12 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
         for (int seg = 0; seg < total; seg += MCCNN_NW_CAP) {
             const int segN = min(MCCNN_NW_CAP, total - seg);
             // stage [seg, seg + segN) of the flat list: lane = flat position, one load and one LDS write per position
-            // (the last round is padded with points out of anybody's reach: the test loop below carries no bounds)
             for (int r = 0; r < segN; r += 64) {
                 const int j = flat_to_j(min(seg + r + lane, total - 1));
-                const float* q = pts + (size_t)j * 3;  // 12-byte rows: one dwordx3 load
-                const bool real = r + lane < segN;
-                lw[r + lane] = make_float4(real ? q[0] : 3.0e18f, q[1], q[2], __int_as_float(j));
+                if (r + lane < segN) {
+                    const float* q = pts + (size_t)j * 3;  // 12-byte rows: one dwordx3 load
+                    lw[r + lane] = make_float4(q[0], q[1], q[2], __int_as_float(j));
+                }
             }
             __builtin_amdgcn_wave_barrier();
             // every centre of this cell against the staged candidates
@@ -196,39 +189,29 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                 const int cid = __builtin_amdgcn_readlane(i, cl);
                 int cbase = 0, ccount = __builtin_amdgcn_readlane(count, cl);
                 if (FILL) cbase = __builtin_amdgcn_readlane(base, cl);
-                // The count pass keeps the ballots of a segment's (at most 4) rounds in lanes 0..3 and stores them with ONE
-                // instruction per (centre, segment): a branch, an address computation and a store per round were a third of
-                // this loop's instructions -- the search is instruction-bound.
-                unsigned mlo = 0, mhi = 0;
-                static_assert(MCCNN_NW_CAP == 256, "four rounds per segment below");
-                auto round = [&](auto kc) {
-                    constexpr int K = decltype(kc)::value;
-                    const float4 p = lw[K * 64 + lane];
-                    const bool hit = point_dist2(p.x, p.y, p.z, cx, cy, cz) < T;
+                // (Measured and withdrawn: this loop without bounds -- the last round padded with unreachable points -- unrolled
+                // over the four rounds of a segment, the ballots kept in lanes 0..3 and stored once per segment: the count pass
+                // alone 35 -> 26 us and a sequential step 0.740 -> 0.728 ms, but the PIPELINED step 0.640 -> 0.672 ms, whatever
+                // the centres per wave, the store form or the issue priority of the convolution kernels (s_setprio): beside
+                // the convolution kernels the denser LDS-read / VALU bursts cost them more than the search saves.)
+                for (int r = 0; r < segN; r += 64) {
+                    const int t = r + lane;
+                    const float4 p = lw[min(t, segN - 1)];
+                    const bool hit = t < segN && point_dist2(p.x, p.y, p.z, cx, cy, cz) < T;
                     const unsigned long long bm = __ballot(hit);
                     if (FILL && hit) {
                         const int pos = cbase + ccount + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
                         if (pos < capacity) out[pos] = make_int2(__float_as_int(p.w), cid);  // capacity < E: see _fill
                     }
                     if (!FILL) {
-                        writelane_u<K>(mlo, (unsigned)bm);
-                        writelane_u<K>(mhi, (unsigned)(bm >> 32));
+                        const int round = (seg + r) >> 6;
+                        // indexed by the centre's POSITION in the visiting order, not by its id: the 8 centres of a wave own
+                        // 512 contiguous bytes (4 lines) in both passes; by id they were 8 scattered 64-byte rows. (One plane
+                        // of m words per round cut the counter traffic further, 90.8 -> 78.1 MB on the room, but made the
+                        // fill read a line per round and centre: 36.7 instead of 27.1 us.)
+                        if (round < MCCNN_NW_ROUNDS && lane == 0) masks[(size_t)(__builtin_amdgcn_readfirstlane(g0) + cl) * MCCNN_NW_ROUNDS + round] = bm;
                     }
                     ccount += __builtin_popcountll(bm);
-                };
-                round(std::integral_constant<int, 0>{});
-                if (segN > 64) round(std::integral_constant<int, 1>{});
-                if (segN > 128) round(std::integral_constant<int, 2>{});
-                if (segN > 192) round(std::integral_constant<int, 3>{});
-                if (!FILL) {
-                    // indexed by the centre's POSITION in the visiting order, not by its id: the 8 centres of a wave own
-                    // 512 contiguous bytes (4 lines) in both passes; by id they were 8 scattered 64-byte rows. (One plane
-                    // of m words per round cut the counter traffic further, 90.8 -> 78.1 MB on the room, but made the
-                    // fill read a line per round and centre: 36.7 instead of 27.1 us.)
-                    const int round0 = seg >> 6;  // MCCNN_NW_CAP is a multiple of 64: a segment starts on a round
-                    if (lane < ((segN + 63) >> 6) && round0 + lane < MCCNN_NW_ROUNDS)
-                        masks[(size_t)(__builtin_amdgcn_readfirstlane(g0) + cl) * MCCNN_NW_ROUNDS + round0 + lane] =
-                            ((unsigned long long)mhi << 32) | mlo;
                 }
                 if (lane == cl) count = ccount;
             }
