@@ -427,6 +427,11 @@ int mccnn_debug_conv_impl(int mask);
 /* Diagnostics: number of kernel launches the library has issued in this process (all streams). bench.py prints the
  * difference over one step: below ~50k points a step is bound by launches, not by the kernels. */
 long long mccnn_debug_launch_count(void);
+/* The calling THREAD's launches are background work from now on (on != 0) / no longer (on == 0): they run on a queue of
+ * their own beside kernels a step waits for (ConvolutionBuilder.prefetch_geometry: the geometry of the next batch under
+ * the convolutions of the current one). Kernels that would fill every wave slot hold back in that mode; results do not
+ * change. Returns the previous setting. */
+int mccnn_background_launches(int on);
 /* TEST HOOK: small problems (coarse hierarchy levels: a few thousand points / edges) run single-workgroup forms of
  * the grid build, the list transposition ... that replace 4 - 8 launches by one; on = 0 sends them through the
  * multi-launch kernels of the large problems instead (same results). Returns the previous setting. Initial value: on,

@@ -376,6 +376,20 @@ class ConvolutionBuilder(torch.nn.Module):
             side.wait_event(ev)
         if not waited and self.resetEvent_ is not None:
             side.wait_event(self.resetEvent_)  # memory retired at the last reset() is reused only behind it
+        bg = None
+        if getattr(self.ops_, "_ops", 0) is None:  # the HIP surface: this thread's launches are background work for a while
+            from . import _lib as _mclib
+            bg = _mclib.load()
+            bg_prev = bg.mccnn_background_launches(1)
+        try:
+            self.__prefetch_on_side__(side, grids, neighs, pdfs, keyGrid, keyNeighs, keyPDF, pts, bids, mn, mx, B, convRadius,
+                                      currRelativeRadius, currKDEWindow, currUsePDF, outPH, outLevel, transposed)
+        finally:
+            if bg is not None:
+                bg.mccnn_background_launches(bg_prev)
+
+    def __prefetch_on_side__(self, side, grids, neighs, pdfs, keyGrid, keyNeighs, keyPDF, pts, bids, mn, mx, B, convRadius,
+                             currRelativeRadius, currKDEWindow, currUsePDF, outPH, outLevel, transposed):
         with torch.cuda.stream(side):
             if keyGrid not in grids and self.fuseSort_ and getattr(self.ops_, "_ops", 0) is None and not pts.requires_grad:
                 from . import MCConvModule as _hip_ops

@@ -134,6 +134,8 @@ def _order_hint(points):
     ent = _ORDER_HINTS.get(_tensor_key(points))
     if ent is None:
         return None
+    if ent[0] == "order_weak":
+        return ent[1]()  # None once the grid that owns the permutation is gone
     if ent[2] is None:
         kind, payload = ent[0], ent[1]
         if kind == "order":
@@ -566,7 +568,10 @@ def build_grid(inPts, inBatchIds, aabbMin, aabbMax, batchSize, cellSize, scaleIn
     cells = torch.empty((batchSize, nc, nc, nc, 2), dtype=torch.int32, device=dev)
     check(lib.mccnn_build_grid(ptr(pts), ptr(bids), ptr(mn), ptr(mx), n, batchSize, nc, ptr(idx), ptr(oP), ptr(oB), ptr(cells),
                                ptr(inv), ptr(ws), ws.numel(), stream_handle()), "build_grid")
-    _remember_order(inPts, "order", inv)
+    # a weak reference: the grid tuple owns the permutation (a strong one here would make this cache a co-owner of a
+    # tensor the builder's side-stream bookkeeping wants to be the last owner of: record_stream() fallback on every step
+    # whose next batch has other points)
+    _remember_order(inPts, "order_weak", weakref.ref(inv))
     return oP, oB, cells, idx, inv
 
 

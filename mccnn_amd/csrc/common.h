@@ -35,6 +35,10 @@ extern std::atomic<long long> g_launches;
 // the multi-launch kernels of the large ones instead of their single-workgroup forms. Defined in api_misc.hip.
 extern std::atomic<int> g_small_off;
 inline bool small_kernels_on() { return g_small_off.load(std::memory_order_relaxed) == 0; }
+// mccnn_background_launches: the calling THREAD's launches run beside more important kernels of another queue (the
+// geometry of the next batch under the convolutions of the current one). Kernels that would otherwise fill every wave
+// slot then hold back (see neighbors.hip). Defined in api_misc.hip.
+extern thread_local int g_background;
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

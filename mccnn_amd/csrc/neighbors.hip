@@ -657,6 +657,18 @@ static float sqrt_threshold_host(float R) {
     return t;
 }
 
+// Background launches (mccnn_background_launches: the geometry of the next batch on a side queue, under the convolution
+// kernels of the current one): the search kernels ask for 36 KB of LDS they do not use, which leaves 2-3 of their
+// workgroups per CU instead of 8. Beside them the convolution waves of the same SIMD wait on LDS weight reads and MFMA
+// hand-overs, and fewer neighbour waves competing for the LDS and VALU ports help them more than a slower search costs:
+// pipelined 1to64 step on the room 0.636 -> 0.621 ms (10 / 16 KB: no gain; 60 KB: the search becomes the critical chain,
+// 0.66 ms). The same limit on the KDE kernel LOSES (0.65 ms); alone the padded search is slower (sequential step 0.736 ->
+// 0.762 ms), hence only for background launches. MCCNN_NW_LDS_PAD overrides the amount (A/B).
+static size_t neigh_lds_pad() {
+    static const int forced = getenv("MCCNN_NW_LDS_PAD") ? atoi(getenv("MCCNN_NW_LDS_PAD")) : -1;
+    if (forced >= 0) return (size_t)forced;
+    return g_background ? 36000 : 0;
+}
 static int neigh_group(int m) {
     static const int forced = getenv("MCCNN_NW_GROUP") ? atoi(getenv("MCCNN_NW_GROUP")) : 0;  // A/B switch, read once
     if (forced >= 1 && forced <= 32) return forced;
@@ -718,7 +730,7 @@ static int find_neighbors_count_impl(const float* centres, const int* centre_bat
     NeighWs w;
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     const int G = neigh_group(m);
-    neigh_window<0><<<ceil_div(m, 4 * G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
+    neigh_window<0><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
                                                      aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, w.cnt,
                                                      w.masks, nullptr, nullptr, 0, (unsigned long long*)w.scanws,
                                                      (int)(scan_status_bytes(m) / sizeof(unsigned long long)), G, scale_inv ? 0.0f : sqrt_threshold_host(radius));
@@ -741,7 +753,7 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int G = neigh_group(m);
-    neigh_window<1><<<ceil_div(m, 4 * G), 256, 0, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
+    neigh_window<1><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
                                                      aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, nullptr,
                                                      w.masks, start_idx, packed, e, nullptr, 0, G, scale_inv ? 0.0f : sqrt_threshold_host(radius));
     MCCNN_LAUNCHED();

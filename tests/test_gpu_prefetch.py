@@ -259,6 +259,19 @@ def test_side_stream_tensor_lifetime(mc):
         out.backward(og)
         assert torch.equal(out.detach(), ref.detach())
     assert builder.sideRecorded_ == 0
+    # ... nor when the batches CHANGE (the visiting-order hint of the previous batch's points must not co-own its grid)
+    pts2, bids2 = make_cloud(1500, 2, 42, "clustered", True)
+    F2 = torch.from_numpy(rng.random((len(pts2), 1), dtype=np.float32)).cuda().requires_grad_(True)
+    ph2 = PointHierarchy(torch.from_numpy(pts2).cuda(), F2, torch.from_numpy(bids2).cuda(), [], "PH2", 2, True)
+    og2 = torch.from_numpy(rng.random((len(pts2), 16), dtype=np.float32)).cuda()
+    for i in range(6):
+        nxt, Fn, ogn = (ph2, F2, og2) if i % 2 == 0 else (ph, F, og)
+        builder.prefetch_geometry(nxt, 0, 0.15)
+        builder.reset()
+        Fn.grad = None
+        o2 = builder.create_convolution("Conv", nxt, 0, Fn, 1, 0.15, outNumFeatures=16, multiFeatureConv=True)
+        o2.backward(ogn)
+    assert builder.sideRecorded_ == 0
     builder.prefetch_geometry(ph, 0, 0.15)
     builder.reset()
     F.grad = None
