@@ -432,6 +432,11 @@ long long mccnn_debug_launch_count(void);
  * the convolutions of the current one). Kernels that would fill every wave slot hold back in that mode; results do not
  * change. Returns the previous setting. */
 int mccnn_background_launches(int on);
+/* TEST HOOK: combin layers with one input feature run their forward edge pass with four consecutive edges per lane
+ * (one segmented scan per 256 edges) on lists of at least `edges` edges (default 500 000; shorter lists keep 64-edge
+ * chunks: more waves to spread over the chip). 0 = always, INT_MAX = never. Same results up to float summation order.
+ * Returns the previous threshold. */
+int mccnn_debug_f1_x4_min_edges(int edges);
 /* TEST HOOK: small problems (coarse hierarchy levels: a few thousand points / edges) run single-workgroup forms of
  * the grid build, the list transposition ... that replace 4 - 8 launches by one; on = 0 sends them through the
  * multi-launch kernels of the large problems instead (same results). Returns the previous setting. Initial value: on,

@@ -23,6 +23,7 @@ SIGNATURES = {
     "mccnn_debug_conv_impl": (_i, [_i]),
     "mccnn_debug_launch_count": (C.c_longlong, []),
     "mccnn_debug_small_kernels": (_i, [_i]),
+    "mccnn_debug_f1_x4_min_edges": (_i, [_i]),
     "mccnn_background_launches": (_i, [_i]),
     "mccnn_compute_aabb_workspace_bytes": (_sz, [_i]),
     "mccnn_compute_aabb": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -6,14 +6,16 @@ namespace mccnn {
 std::atomic<long long> g_launches{0};
 thread_local int g_background = 0;
 std::atomic<int> g_small_off{getenv("MCCNN_SMALL_OFF") ? 1 : 0};
+std::atomic<int> g_f1_x4_min_edges{getenv("MCCNN_F1_X4_MIN_E") ? atoi(getenv("MCCNN_F1_X4_MIN_E")) : 500000};
 }
 
 extern "C" {
 
 int mccnn_block_size(void) { return MCCNN_MLP; }
-int mccnn_abi_version(void) { return 8; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn; 5: row plans, aabb_extent; 6: rowplan_build, build_grid; 7: feat_index of the row kernels, hierarchy_level, find_neighbors_count2; 8: background_launches
+int mccnn_abi_version(void) { return 8; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn; 5: row plans, aabb_extent; 6: rowplan_build, build_grid; 7: feat_index of the row kernels, hierarchy_level, find_neighbors_count2; 8: background_launches, debug_f1_x4_min_edges
 const char* mccnn_arch(void) { return "gfx950"; }
 int mccnn_background_launches(int on) { const int prev = mccnn::g_background; mccnn::g_background = on ? 1 : 0; return prev; }
+int mccnn_debug_f1_x4_min_edges(int edges) { return mccnn::g_f1_x4_min_edges.exchange(edges < 0 ? 0 : edges); }
 int mccnn_debug_small_kernels(int on) { return mccnn::g_small_off.exchange(on ? 0 : 1) == 0 ? 1 : 0; }
 long long mccnn_debug_launch_count(void) { return mccnn::g_launches.load(std::memory_order_relaxed); }
 

@@ -35,6 +35,9 @@ extern std::atomic<long long> g_launches;
 // the multi-launch kernels of the large ones instead of their single-workgroup forms. Defined in api_misc.hip.
 extern std::atomic<int> g_small_off;
 inline bool small_kernels_on() { return g_small_off.load(std::memory_order_relaxed) == 0; }
+// Lists of at least this many edges take the four-edges-per-lane forward pass of the Fin = 1 layers (conv_f1.hip;
+// mccnn_debug_f1_x4_min_edges, MCCNN_F1_X4_MIN_E in the environment)
+extern std::atomic<int> g_f1_x4_min_edges;
 // mccnn_background_launches: the calling THREAD's launches run beside more important kernels of another queue (the
 // geometry of the next batch under the convolutions of the current one). Kernels that would otherwise fill every wave
 // slot then hold back (see neighbors.hip). Defined in api_misc.hip.

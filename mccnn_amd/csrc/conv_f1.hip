@@ -137,6 +137,266 @@ __global__ __launch_bounds__(256) void f1_fwd_edges(ConvArgs a, float* __restric
     if (lane == 0) zero_rows(keyLast, cB);
 }
 
+// ---------------------------------------------------------------------------------------
+// Forward, edge pass with FOUR consecutive edges per lane (256 edges per iteration of a wave). The segmented sums of
+// f1_fwd_edges cost 6 fused-DPP steps per value and 64 edges; here a lane first sums its own four edges in registers
+// (3 fma per value), ONE 6-step scan runs over the lane totals, and the incoming prefix is added back to the lane's
+// edges (3 fma per value): 12 + 6 + 8 instructions per value and 256 edges instead of 24 + ..., the per-edge work
+// (MLP layers 1 and 2 on the matrix cores, ReLU, the product with s_e) is unchanged. The weights of a block are read
+// from LDS once per iteration (registers) instead of once per 64 edges. Same slices, carries and tails as above.
+// ---------------------------------------------------------------------------------------
+#define DPP_WAVE_SHR1 0x138
+#define DPP_WAVE_SHL1 0x130
+struct L12Regs {
+    f32x4 w1lo, w1hi;  // (w0, w1, w2, b1) of neurons i4 / 4 + i4
+    float w2lo[8], w2hi[8], b2lo, b2hi;
+};
+__device__ __forceinline__ void load_l12(const float* __restrict__ wq, int i4, L12Regs& w) {
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(wq);
+    w.w1lo = w4[i4];
+    w.w1hi = w4[4 + i4];
+    const f32x4 a0 = w4[10 + 2 * i4], a1 = w4[10 + 2 * i4 + 1], b0 = w4[10 + 2 * (4 + i4)], b1 = w4[10 + 2 * (4 + i4) + 1];
+    w.w2lo[0] = a0.x; w.w2lo[1] = a0.y; w.w2lo[2] = a0.z; w.w2lo[3] = a0.w; w.w2lo[4] = a1.x; w.w2lo[5] = a1.y; w.w2lo[6] = a1.z; w.w2lo[7] = a1.w;
+    w.w2hi[0] = b0.x; w.w2hi[1] = b0.y; w.w2hi[2] = b0.z; w.w2hi[3] = b0.w; w.w2hi[4] = b1.x; w.w2hi[5] = b1.y; w.w2hi[6] = b1.z; w.w2hi[7] = b1.w;
+    w.b2lo = wq[104 + i4];
+    w.b2hi = wq[104 + 4 + i4];
+}
+
+#ifndef MCCNN_F1_X4_OCC
+#define MCCNN_F1_X4_OCC 1
+#endif
+#ifndef MCCNN_F1_X4_GROUP
+#define MCCNN_F1_X4_GROUP 4
+#endif
+#ifdef MCCNN_F1_X4_NOPHASE
+#define X4_PHASE()
+#else
+#define X4_PHASE() MCCNN_PHASE()
+#endif
+__global__ __launch_bounds__(256, MCCNN_F1_X4_OCC) void f1_fwd_edges4(ConvArgs a, float* __restrict__ A, float* __restrict__ S,
+                                                     int numWaves, float4* __restrict__ recOut) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i4 = lane & 3;
+    const int rowA = a.nb * 8;
+    float* wl = lds;
+    float* carry = lds + a.nb * MCCNN_WQ_FWD + (size_t)wave * rowA;
+    stage_weights<MCCNN_WQ_FWD>(a, wl);
+    __syncthreads();
+    const int w = blockIdx.x * 4 + wave;
+    if (w >= numWaves) return;
+    const int tA = (int)(((long long)a.e * w) / numWaves);
+    const int tB = (int)(((long long)a.e * (w + 1)) / numWaves);
+    const int cA = (w == 0) ? 0 : wave_lower_bound(a.start, a.m, a.e, tA, lane);
+    const int cB = (w == numWaves - 1) ? a.m : wave_lower_bound(a.start, a.m, a.e, tB, lane);
+    if (cA >= cB) return;
+    const int eBeg = a.start[cA];
+    const int eEnd = (cB < a.m) ? a.start[cB] : a.e;
+
+    auto zero_rows = [&](int c0, int c1) {  // centres without neighbours
+        for (int c = c0; c < c1; ++c) {
+            for (int f = 0; f < rowA; ++f) A[(size_t)c * rowA + f] = 0.0f;
+            S[c] = 0.0f;
+        }
+    };
+
+    int keyLast = cA;    // key (centre + 1) of the last edge seen so far; cA before the first
+    int carryKey = -1;   // >= 0: the last centre of the previous iteration continues (its sums so far are the carry)
+    float carryS = 0.f;
+    // (Measured and dropped: a second iteration of look-ahead -- the rows the NEXT iteration's list entries point to
+    // (point, centre, feature, row bounds) gathered before this iteration's block loop: 200 VGPRs / 2 waves per SIMD, same
+    // forward time 0.175 ms, pipelined step 0.607 against 0.602 ms. The loop's skeleton -- gathers, records, tail stores --
+    // measures 60-75 us on its own (MCCNN_ABL_X4_NOSCAN + NOMLP), of which the stores are ~12 us (NOTAIL / NOREC) and the
+    // prologue 5 us (NOLOOP); kernel MLP 63 us, segmented sums 18 us.)
+    int2 prN[4];
+    float pdfN[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = min(eBeg + 4 * lane + u, a.e - 1);
+        prN[u] = a.packed[t];
+        pdfN[u] = a.pdfs[t];
+    }
+#ifdef MCCNN_ABL_X4_NOLOOP  // timing ablation only: the kernel's prologue alone
+    if (eBeg >= 0) return;
+#endif
+    for (int base = eBeg; base < eEnd; base += 256) {
+        const int lastPos = min(base + 256, eEnd) - 1;  // the last edge of this iteration
+        float d0[4], d1[4], d2[4], sE[4];
+        int key[4], ci[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = base + 4 * lane + u;
+            in[u] = t < eEnd;
+            const int2 pr = prN[u];
+            const float pdf = pdfN[u];
+            const int j = pr.x;
+            ci[u] = pr.y;
+            float invR = a.invRadius;
+            if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B)));
+            const float* pp = a.pts + (size_t)j * 3;
+            const float* cc = a.samples + (size_t)pr.y * 3;
+            const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B)) : a.radius;
+            d0[u] = div_exact(pp[0] - cc[0], R, invR);
+            d1[u] = div_exact(pp[1] - cc[1], R, invR);
+            d2[u] = div_exact(pp[2] - cc[2], R, invR);
+            float K = 1.0f;
+            if (a.avg) K = (float)(((pr.y + 1 < a.m) ? a.start[pr.y + 1] : a.e) - a.start[pr.y]);
+            const float inv = in[u] ? __builtin_amdgcn_rcpf(pdf * K) : 0.0f;
+            sE[u] = in[u] ? a.feats[j] * inv : 0.0f;
+#ifndef MCCNN_ABL_X4_NOREC
+            if (recOut && in[u]) recOut[t] = make_float4(d0[u], d1[u], d2[u], inv);  // the record f1_edge_records would compute
+#endif
+            key[u] = in[u] ? pr.y + 1 : 0;
+        }
+        if (base + 256 < eEnd) {  // the list entries of the next iteration
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(base + 256 + 4 * lane + u, a.e - 1);
+                prN[u] = a.packed[t];
+                pdfN[u] = a.pdfs[t];
+            }
+        }
+        // the centre of the last edge: does its row go on behind this iteration?
+        const int lp = lastPos - base;
+        const int lu = lp & 3;
+        const int kSel = (lu == 0) ? key[0] : (lu == 1) ? key[1] : (lu == 2) ? key[2] : key[3];
+        const int keyEnd = __builtin_amdgcn_readlane(kSel, lp >> 2);  // centre + 1
+        const int rowEnd = (keyEnd < a.m) ? a.start[keyEnd] : a.e;
+        const bool cont = rowEnd > lastPos + 1;
+        // key of the edge before / behind the lane's four (lane 0: the last edge of the previous iteration)
+        const int kPrev = __builtin_amdgcn_update_dpp(keyLast, key[3], DPP_WAVE_SHR1, 0xf, 0xf, false);
+        const int kNext = __builtin_amdgcn_update_dpp(0, key[0], DPP_WAVE_SHL1, 0xf, 0xf, true);
+        const bool haveCarry = carryKey >= 0;
+        float nh[4], op[4];  // edge u continues the segment of edge u - 1 / belongs to the segment that enters the lane
+        bool tail[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kp = (u == 0) ? kPrev : key[u - 1];
+            const int kn = (u == 3) ? kNext : key[u + 1];
+            if (in[u] && key[u] - kp > 1) zero_rows(kp, ci[u]);
+            nh[u] = (key[u] != 0 && key[u] == kp) ? 1.f : 0.f;
+            op[u] = (key[u] != 0 && key[u] == kPrev && lane != 0) ? 1.f : 0.f;
+            const int t = base + 4 * lane + u;
+            tail[u] = in[u] && ((t == lastPos) ? !cont : (key[u] != kn));
+        }
+        // lane-level masks of the scan over the lane totals: lanes l - d + 1 .. l hold no segment head
+        const int k3 = key[3];
+        const float m1 = (k3 != 0 && dpp_i<DPP_ROW_SHR(1)>(k3) == k3) ? 1.f : 0.f;
+        const float m2 = (k3 != 0 && dpp_i<DPP_ROW_SHR(2)>(k3) == k3) ? 1.f : 0.f;
+        const float m4 = (k3 != 0 && dpp_i<DPP_ROW_SHR(4)>(k3) == k3) ? 1.f : 0.f;
+        const float m8 = (k3 != 0 && dpp_i<DPP_ROW_SHR(8)>(k3) == k3) ? 1.f : 0.f;
+        const float mA = (k3 != 0 && dpp_rows_i<DPP_ROW_BCAST15, 0xA>(k3) == k3) ? 1.f : 0.f;
+        const float mB = (k3 != 0 && dpp_rows_i<DPP_ROW_BCAST31, 0xC>(k3) == k3) ? 1.f : 0.f;
+        const float mC = (haveCarry && lane == 0) ? 1.f : 0.f;  // the carry enters at the first edge of the iteration
+
+        {   // S_i = sum of s_e: the same three stages on one value
+            float r0 = fmaf(mC, carryS, sE[0]);
+            float r1 = fmaf(r0, nh[1], sE[1]);
+            float r2 = fmaf(r1, nh[2], sE[2]);
+            float r3 = fmaf(r2, nh[3], sE[3]);
+            r3 = wave_seg_scan1(r3, m1, m2, m4, m8, mA, mB);
+            const float cin = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r3), DPP_WAVE_SHR1, 0xf, 0xf, true));
+            r0 = fmaf(op[0], cin, r0);
+            r1 = fmaf(op[1], cin, r1);
+            r2 = fmaf(op[2], cin, r2);
+            if (tail[0]) S[ci[0]] = r0;
+            if (tail[1]) S[ci[1]] = r1;
+            if (tail[2]) S[ci[2]] = r2;
+            if (tail[3]) S[ci[3]] = r3;
+            carryS = __shfl(r3, 63, 64);
+        }
+
+        for (int q = 0; q < a.nb; ++q) {
+            L12Regs wr;
+            load_l12(wl + q * MCCNN_WQ_FWD, i4, wr);
+            float c[4][8];
+            X4_PHASE();
+            const float one = opaque_one();
+#ifdef MCCNN_ABL_X4_NOMLP  // timing ablation only (wrong results): no kernel MLP
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) c[u][r] = sE[u] * (r < 4 ? wr.w2lo[r] : wr.w2hi[r]) + (r & 1 ? d0[u] : d1[u]) + one;
+#else
+#pragma unroll
+            for (int g = 0; g < 4; g += MCCNN_F1_X4_GROUP) {  // MCCNN_F1_X4_GROUP edges per MFMA / VALU phase
+                float h[MCCNN_F1_X4_GROUP][8];
+#pragma unroll
+                for (int v = 0; v < MCCNN_F1_X4_GROUP; ++v) {
+                    const int u = g + v;
+                    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+                    lo = MFMA4(wr.w1lo.x, d0[u], lo);
+                    hi = MFMA4(wr.w1hi.x, d0[u], hi);
+                    lo = MFMA4(wr.w1lo.y, d1[u], lo);
+                    hi = MFMA4(wr.w1hi.y, d1[u], hi);
+                    lo = MFMA4(wr.w1lo.z, d2[u], lo);
+                    hi = MFMA4(wr.w1hi.z, d2[u], hi);
+                    lo = MFMA4(wr.w1lo.w, one, lo);
+                    hi = MFMA4(wr.w1hi.w, one, hi);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { h[v][r] = lo[r]; h[v][4 + r] = hi[r]; }
+                }
+                X4_PHASE();
+#pragma unroll
+                for (int v = 0; v < MCCNN_F1_X4_GROUP; ++v)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) h[v][r] = relu1(h[v][r]);
+                X4_PHASE();
+#pragma unroll
+                for (int v = 0; v < MCCNN_F1_X4_GROUP; ++v) layer8_regs<true>(wr.w2lo, wr.w2hi, wr.b2lo, wr.b2hi, h[v], c[g + v]);
+                X4_PHASE();
+#pragma unroll
+                for (int v = 0; v < MCCNN_F1_X4_GROUP; ++v)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) c[g + v][r] = sE[g + v] * relu1(c[g + v][r]);
+            }
+#endif
+            float* cq = carry + q * 8;
+            {
+                f32x4 cv0 = {0.f, 0.f, 0.f, 0.f}, cv1 = cv0;
+                if (haveCarry) { cv0 = *reinterpret_cast<f32x4*>(cq); cv1 = *reinterpret_cast<f32x4*>(cq + 4); }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c[0][k] = fmaf(mC, k < 4 ? cv0[k & 3] : cv1[k & 3], c[0][k]);
+            }
+#ifndef MCCNN_ABL_X4_NOSCAN  // timing ablation only (wrong results): no segmented sums
+            // the lane's own four edges, the scan over the lane totals, the prefix that enters the lane
+#pragma unroll
+            for (int u = 1; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c[u][k] = fmaf(c[u - 1][k], nh[u], c[u][k]);
+            wave_seg_scan8(c[3], m1, m2, m4, m8, mA, mB);
+            float cin[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                cin[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[3][k]), DPP_WAVE_SHR1, 0xf, 0xf, true));
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c[u][k] = fmaf(op[u], cin[k], c[u][k]);
+#endif
+            if (cont && lane == 63) {
+                *reinterpret_cast<f32x4*>(cq) = (f32x4){c[3][0], c[3][1], c[3][2], c[3][3]};
+                *reinterpret_cast<f32x4*>(cq + 4) = (f32x4){c[3][4], c[3][5], c[3][6], c[3][7]};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#ifdef MCCNN_ABL_X4_NOTAIL  // timing ablation only (wrong results): the rows are stored by the last block only
+                if (tail[u] && q == a.nb - 1) {
+#else
+                if (tail[u]) {
+#endif
+                    float4* dst = reinterpret_cast<float4*>(A + (size_t)ci[u] * rowA + q * 8);
+                    dst[0] = make_float4(c[u][0], c[u][1], c[u][2], c[u][3]);
+                    dst[1] = make_float4(c[u][4], c[u][5], c[u][6], c[u][7]);
+                }
+            }
+        }
+        carryKey = cont ? keyEnd : -1;
+        keyLast = keyEnd;
+    }
+    if (lane == 0) zero_rows(keyLast, cB);
+}
+
 // Forward, centre pass: out_i[8q+n] = W3_q[n] . A_i[q] + b3_q[n] S_i. One thread per (centre, block): consecutive lanes
 // read / write consecutive 32-byte pieces of a row; weights from LDS.
 __global__ __launch_bounds__(256) void f1_fwd_centres(ConvArgs a, const float* __restrict__ A,
@@ -511,6 +771,18 @@ static void f1_state_split(void* state, int m, int nb, float*& A, float*& S) {
 
 static int f1_run_edges(const ConvArgs& a, float* A, float* S, float4* recOut, hipStream_t s) {
     const size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * (size_t)a.nb * 8) * sizeof(float);
+    // long lists: four edges per lane (one scan per 256 edges); short ones keep 64-edge chunks (more waves to spread)
+    if (a.e >= g_f1_x4_min_edges.load(std::memory_order_relaxed)) {
+        const int perCU4 = cached_blocks_per_cu(reinterpret_cast<const void*>(f1_fwd_edges4), lds);
+        const long long iters = ((long long)a.e + 255) / 256;
+        static const int wpc = getenv("MCCNN_F1_X4_WAVES_PER_CU") ? atoi(getenv("MCCNN_F1_X4_WAVES_PER_CU")) : 0;
+        long long W4 = (long long)num_cus() * (wpc > 0 ? wpc : perCU4 * 4);
+        if (W4 > (iters + 1) / 2) W4 = (iters + 1) / 2;
+        if (W4 < 1) W4 = 1;
+        f1_fwd_edges4<<<(int)((W4 + 3) / 4), 256, lds, s>>>(a, A, S, (int)W4, recOut);
+        MCCNN_LAUNCHED();
+        return 0;
+    }
     const int perCU = cached_blocks_per_cu(reinterpret_cast<const void*>(f1_fwd_edges), lds);
     const long long chunks = ((long long)a.e + 63) / 64;
     long long W = (long long)num_cus() * perCU * 4;

@@ -109,6 +109,60 @@ def test_spatial_conv_sort_index_equals_sort_features(mc, fin, fout, combin):
                 assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max())
 
 
+@pytest.mark.parametrize("n_per,B,radius,fout,scale_inv,avg,pool", [
+    (1500, 2, 0.15, 16, True, True, False),     # ragged rows, relative radius, averaged
+    (4000, 1, 0.08, 64, False, False, False),   # absolute radius, plain sums, the headline layer's shape
+    (900, 3, 0.3, 8, True, True, True),         # pooling: centres are a subset of the points plus centres with EMPTY rows
+    (30, 1, 0.5, 16, True, False, False),       # less than one iteration of one wave
+])
+def test_f1_forward_four_edges_per_lane_equals_the_chunk_kernel(mc, n_per, B, radius, fout, scale_inv, avg, pool):
+    """Combin layers with one input feature: the forward edge pass with four edges per lane (lists of >= 500 000 edges by
+    default) against the 64-edge-chunk kernel on the same inputs -- outputs and all seven gradients within float
+    summation order (the backward pass consumes the per-edge records the forward pass wrote)."""
+    import torch
+    from mccnn_amd import _lib
+    lib = _lib.load()
+    pts, bids = make_cloud(n_per, B, 33, "clustered", True)
+    rng = np.random.default_rng(10)
+    P, Bi = _t(pts), _t(bids)
+    mn, mx = mc.compute_aabb(P, Bi, B, scale_inv)
+    sP, sB, cells, idx, inv = mc.build_grid(P, Bi, mn, mx, B, radius, scale_inv)
+    if pool:
+        sel = np.sort(rng.choice(len(pts), len(pts) // 7, replace=False))
+        far = np.full((5, 3), 40.0, dtype=np.float32) + rng.random((5, 3), dtype=np.float32)  # no neighbours at all
+        C = _t(np.concatenate([pts[sel][:50], far[:2], pts[sel][50:], far[2:]]))
+        Cb = _t(np.concatenate([bids[sel][:50], bids[:2] * 0, bids[sel][50:], bids[:3] * 0]))
+    else:
+        C, Cb = P, Bi
+    start, packed = mc.find_neighbors(C, Cb, sP, cells, mn, mx, radius, B, scale_inv)
+    pdfs = mc.compute_pdf(sP, sB, mn, mx, start, packed, 0.2, radius, B, scale_inv)
+    nb = (fout + 7) // 8
+    w = make_mlp(nb, 6)
+    og = _t(rng.random((C.shape[0], fout), dtype=np.float32))
+    f_np = rng.random((len(pts), 1), dtype=np.float32) - 0.3
+    res = []
+    prev = lib.mccnn_debug_f1_x4_min_edges(2 ** 31 - 1)
+    try:
+        for min_edges in (2 ** 31 - 1, 0):
+            lib.mccnn_debug_f1_x4_min_edges(min_edges)
+            F = _t(f_np).requires_grad_(True)
+            ws = [_t(w[k]).requires_grad_(True) for k in ("w1", "w2", "w3", "b1", "b2", "b3")]
+            out = mc.spatial_conv(sP, F, sB, pdfs, C, start, packed, mn, mx, *ws, fout, True, B, radius, scale_inv, avg)
+            grads = torch.autograd.grad([out], [F] + ws, [og])
+            res.append((out.detach(), grads))
+    finally:
+        lib.mccnn_debug_f1_x4_min_edges(prev)
+    ref, got = res
+    scale = float(ref[0].abs().max())
+    assert float((ref[0] - got[0]).abs().max()) <= 2e-5 * scale
+    if pool:  # rows without neighbours: exact zeros
+        st = torch.cat([start.flatten().long(), torch.tensor([packed.shape[0]], device=start.device)])
+        empty = (st[1:] == st[:-1]).nonzero().flatten()
+        assert empty.numel() >= 5 and float(got[0][empty].abs().max()) == 0.0
+    for ga, gb in zip(ref[1], got[1]):
+        assert float((ga - gb).abs().max()) <= 2e-5 * max(float(ga.abs().max()), 1e-20)
+
+
 def test_builder_fused_path_equals_the_op_chain(mc):
     """ConvolutionBuilder(fuseSort=True) (build_grid + search / KDE back to back + sortIndex) against fuseSort=False (the
     reference's op sequence): same outputs, same gradients, over a two-level hierarchy with shared grids."""
