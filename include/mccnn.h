@@ -433,7 +433,7 @@ long long mccnn_debug_launch_count(void);
  * change. Returns the previous setting. */
 int mccnn_background_launches(int on);
 /* TEST HOOK: combin layers with one input feature run their forward edge pass with four consecutive edges per lane
- * (one segmented scan per 256 edges) on lists of at least `edges` edges (default 500 000; shorter lists keep 64-edge
+ * (one segmented scan per 256 edges) on lists of at least `edges` edges (default 2 000 000; shorter lists keep 64-edge
  * chunks: more waves to spread over the chip). 0 = always, INT_MAX = never. Same results up to float summation order.
  * Returns the previous threshold. */
 int mccnn_debug_f1_x4_min_edges(int edges);

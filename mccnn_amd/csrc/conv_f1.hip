@@ -180,6 +180,10 @@ __global__ __launch_bounds__(256, MCCNN_F1_X4_OCC) void f1_fwd_edges4(ConvArgs a
     const int rowA = a.nb * 8;
     float* wl = lds;
     float* carry = lds + a.nb * MCCNN_WQ_FWD + (size_t)wave * rowA;
+    // the lane's four records are 64 contiguous bytes, but a store instruction of 16 B per lane at a 64-byte stride touches 64
+    // lines: they go through LDS and leave as four fully coalesced 1 KB stores (the 7 M-edge list of BASELINE cfg2, 2 blocks:
+    // forward 0.29 -> 0.23 ms; only when the caller keeps the records, i.e. a backward pass follows)
+    float4* recStage = reinterpret_cast<float4*>(lds + a.nb * MCCNN_WQ_FWD + 4 * (size_t)rowA) + (size_t)wave * 256;
     stage_weights<MCCNN_WQ_FWD>(a, wl);
     __syncthreads();
     const int w = blockIdx.x * 4 + wave;
@@ -231,11 +235,13 @@ __global__ __launch_bounds__(256, MCCNN_F1_X4_OCC) void f1_fwd_edges4(ConvArgs a
             const float pdf = pdfN[u];
             const int j = pr.x;
             ci[u] = pr.y;
-            float invR = a.invRadius;
-            if (a.scaleInv) invR = 1.0f / (a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B)));
+            float invR = a.invRadius, R = a.radius;
+            if (a.scaleInv) {
+                R = a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B));
+                invR = 1.0f / R;
+            }
             const float* pp = a.pts + (size_t)j * 3;
             const float* cc = a.samples + (size_t)pr.y * 3;
-            const float R = a.scaleInv ? a.radius * max_extent(a.mn, a.mx, clamp_batch(a.bids[j], a.B)) : a.radius;
             d0[u] = div_exact(pp[0] - cc[0], R, invR);
             d1[u] = div_exact(pp[1] - cc[1], R, invR);
             d2[u] = div_exact(pp[2] - cc[2], R, invR);
@@ -244,10 +250,19 @@ __global__ __launch_bounds__(256, MCCNN_F1_X4_OCC) void f1_fwd_edges4(ConvArgs a
             const float inv = in[u] ? __builtin_amdgcn_rcpf(pdf * K) : 0.0f;
             sE[u] = in[u] ? a.feats[j] * inv : 0.0f;
 #ifndef MCCNN_ABL_X4_NOREC
-            if (recOut && in[u]) recOut[t] = make_float4(d0[u], d1[u], d2[u], inv);  // the record f1_edge_records would compute
+            if (recOut) recStage[4 * lane + u] = make_float4(d0[u], d1[u], d2[u], inv);  // the record f1_edge_records would compute
 #endif
             key[u] = in[u] ? pr.y + 1 : 0;
         }
+#ifndef MCCNN_ABL_X4_NOREC
+        if (recOut) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = base + 64 * k + lane;
+                if (t < eEnd) recOut[t] = recStage[64 * k + lane];
+            }
+        }
+#endif
         if (base + 256 < eEnd) {  // the list entries of the next iteration
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -773,13 +788,14 @@ static int f1_run_edges(const ConvArgs& a, float* A, float* S, float4* recOut, h
     const size_t lds = ((size_t)a.nb * MCCNN_WQ_FWD + 4 * (size_t)a.nb * 8) * sizeof(float);
     // long lists: four edges per lane (one scan per 256 edges); short ones keep 64-edge chunks (more waves to spread)
     if (a.e >= g_f1_x4_min_edges.load(std::memory_order_relaxed)) {
-        const int perCU4 = cached_blocks_per_cu(reinterpret_cast<const void*>(f1_fwd_edges4), lds);
+        const size_t lds4 = lds + 4 * 256 * sizeof(float4);  // + the record stage of the four waves
+        const int perCU4 = cached_blocks_per_cu(reinterpret_cast<const void*>(f1_fwd_edges4), lds4);
         const long long iters = ((long long)a.e + 255) / 256;
         static const int wpc = getenv("MCCNN_F1_X4_WAVES_PER_CU") ? atoi(getenv("MCCNN_F1_X4_WAVES_PER_CU")) : 0;
         long long W4 = (long long)num_cus() * (wpc > 0 ? wpc : perCU4 * 4);
         if (W4 > (iters + 1) / 2) W4 = (iters + 1) / 2;
         if (W4 < 1) W4 = 1;
-        f1_fwd_edges4<<<(int)((W4 + 3) / 4), 256, lds, s>>>(a, A, S, (int)W4, recOut);
+        f1_fwd_edges4<<<(int)((W4 + 3) / 4), 256, lds4, s>>>(a, A, S, (int)W4, recOut);
         MCCNN_LAUNCHED();
         return 0;
     }

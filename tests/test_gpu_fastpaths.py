@@ -116,7 +116,7 @@ def test_spatial_conv_sort_index_equals_sort_features(mc, fin, fout, combin):
     (30, 1, 0.5, 16, True, False, False),       # less than one iteration of one wave
 ])
 def test_f1_forward_four_edges_per_lane_equals_the_chunk_kernel(mc, n_per, B, radius, fout, scale_inv, avg, pool):
-    """Combin layers with one input feature: the forward edge pass with four edges per lane (lists of >= 500 000 edges by
+    """Combin layers with one input feature: the forward edge pass with four edges per lane (lists of >= 2 000 000 edges by
     default) against the 64-edge-chunk kernel on the same inputs -- outputs and all seven gradients within float
     summation order (the backward pass consumes the per-edge records the forward pass wrote)."""
     import torch
