@@ -195,10 +195,18 @@ class Workload:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        trace = [] if os.environ.get("MCCNN_BENCH_TRACE") else None  # diagnostic: per-step times of the region to stderr
         for _ in range(steps):
             self.step()
+            if trace is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                trace.append((ev, time.perf_counter() - t0))
         torch.cuda.current_stream().synchronize()  # this rank's own kernels
         t_own = time.perf_counter() - t0
+        if trace:
+            log("per-step GPU ms: " + " ".join("%.3f" % trace[i][0].elapsed_time(trace[i + 1][0]) for i in range(len(trace) - 1))
+                + " | host issue ms: " + " ".join("%.3f" % ((trace[i + 1][1] - trace[i][1]) * 1e3) for i in range(len(trace) - 1)))
         if self.bucket is not None:
             self.bucket.wait()  # the last step's all-reduce finishes inside the timed region
         torch.cuda.synchronize()
@@ -867,8 +875,10 @@ def main():
     # the GPU needs ~20 ms of sustained load before it holds its clocks again: a block of 20 steps timed right after
     # 4 warm-up steps reads 0.827 ms/step where every later block of the same process reads 0.778 (tools/steps_probe.py).
     # So all workloads are SET UP first (host work), then the step loops run back to back -- the other layer shapes,
-    # then the headline region (W warm-up steps, exactly K timed steps between barriers) -- and the per-op breakdowns
-    # (which drain the queue around every op) come last.
+    # then the headline region (W warm-up steps, exactly K timed steps between barriers), then the 8-room batch of the
+    # strong-scaling point -- and the per-op breakdowns (which drain the queue around every op) come last. (The headline
+    # region used to follow the 8-room loop: after its 5 ms steps the 0.6 ms steps of the headline started at 0.70 ms and
+    # took more than 20 steps to settle -- 0.67 instead of 0.61 ms per step in a `--steps 20 --warmup 5` run.)
     others = {}
     if not args.no_layers:
         for name in sorted(LAYERS, reverse=True):  # the long one first: it carries the load through the ramp
@@ -883,20 +893,6 @@ def main():
     for name, w2 in others.items():
         ms, val, _ = w2.timed(max(args.steps // 2, 3), 2)
         layers[name] = {"ms_per_step": round(ms, 4), "value": round(val, 1), "unit": "points/s", "edges_per_gpu": w2.e_local}
-
-    # ------------------------------------------------------------------ strong scaling: the fixed batch split over the ranks
-    strong = None
-    if args.scaling == "both" and args.strong_rooms >= world:
-        sw = wl_strong if wl_strong is not None else wl
-        s_ms, s_val, s_total = sw.timed(max(args.steps // 4, 5) if wl_strong is not None else args.steps, 3)
-        strong = {"rooms": args.strong_rooms, "rooms_on_rank0": len(strong_seeds()), "points_total": int(s_total),
-                  "ms_per_step": round(s_ms, 4), "value": round(s_val, 1), "unit": "points/s", "scaling": "strong",
-                  "mode": "pipelined" if sw.pipeline else "sequential", "rank_stats": sw.rank_stats,
-                  "note": "fixed batch of %d rooms split cloud-per-GPU over %d rank(s); speed-up at N ranks = value(N) / "
-                          "value(1)" % (args.strong_rooms, world)}
-        if wl_strong is not None:
-            del wl_strong, sw
-            torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ the headline region
     ms_per_step, value, m_total = wl.timed(args.steps, max(args.warmup - 1, 0))
@@ -916,6 +912,22 @@ def main():
     if layers is not None:
         layers[args.layer] = {"ms_per_step": round(ms_per_step, 4), "value": round(value, 1), "unit": "points/s",
                               "edges_per_gpu": wl.e_local}
+
+    # ------------------------------------------------------------------ strong scaling: the fixed batch split over the ranks
+    strong = None
+    if args.scaling == "both" and args.strong_rooms >= world:
+        sw = wl_strong if wl_strong is not None else wl
+        s_ms, s_val, s_total = sw.timed(max(args.steps // 4, 5) if wl_strong is not None else args.steps, 3)
+        strong = {"rooms": args.strong_rooms, "rooms_on_rank0": len(strong_seeds()), "points_total": int(s_total),
+                  "ms_per_step": round(s_ms, 4), "value": round(s_val, 1), "unit": "points/s", "scaling": "strong",
+                  "mode": "pipelined" if sw.pipeline else "sequential", "rank_stats": sw.rank_stats,
+                  "note": "fixed batch of %d rooms split cloud-per-GPU over %d rank(s); speed-up at N ranks = value(N) / "
+                          "value(1)" % (args.strong_rooms, world)}
+        if wl_strong is not None:
+            # (no torch.cuda.empty_cache() here: returning gigabytes to the driver idles the GPU for tens of milliseconds,
+            # and the headline region below would start at the clocks of an idle chip -- 0.67 instead of 0.61 ms per step
+            # when the region is short, `--steps 20 --warmup 5`)
+            del wl_strong, sw
 
     # ------------------------------------------------------------------ per-op breakdowns and rooflines (rank 0)
     roofline = breakdown = None
