@@ -95,19 +95,20 @@ def make_inputs(npts, seeds, layer, device, rank):
 
 
 def ev_time(fn, iters=20):
-    """Average HIP-event duration (ms) of fn() on the current stream (the one every C-ABI call is launched on), queue
-    drained before each call; one untimed call first."""
+    """Average HIP-event duration (ms) of fn() on the current stream (the one every C-ABI call is launched on): two untimed
+    calls, then `iters` calls back to back between one pair of events -- the duration of a launch in a loop, as in the
+    step loops (a call timed alone on a drained queue runs on a chip that has just idled: +1-4 % on the 0.37 ms backward
+    pass, and noisier)."""
     r = fn()
-    ts = []
+    r = fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
     for _ in range(iters):
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
         r = fn()
-        b.record()
-        b.synchronize()
-        ts.append(a.elapsed_time(b))
-    return float(np.mean(ts)), r
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / iters, r
 
 
 class Workload:
@@ -875,8 +876,8 @@ def main():
     # the GPU needs ~20 ms of sustained load before it holds its clocks again: a block of 20 steps timed right after
     # 4 warm-up steps reads 0.827 ms/step where every later block of the same process reads 0.778 (tools/steps_probe.py).
     # So all workloads are SET UP first (host work), then the step loops run back to back -- the other layer shapes,
-    # then the headline region (W warm-up steps, exactly K timed steps between barriers), then the 8-room batch of the
-    # strong-scaling point -- and the per-op breakdowns (which drain the queue around every op) come last. (The headline
+    # then the headline region (W warm-up steps, exactly K timed steps between barriers), then the per-op breakdowns
+    # (rank 0; they drain the queue around every op), and the 8-room batch of the strong-scaling point last. (The headline
     # region used to follow the 8-room loop: after its 5 ms steps the 0.6 ms steps of the headline started at 0.70 ms and
     # took more than 20 steps to settle -- 0.67 instead of 0.61 ms per step in a `--steps 20 --warmup 5` run.)
     others = {}
@@ -913,6 +914,21 @@ def main():
         layers[args.layer] = {"ms_per_step": round(ms_per_step, 4), "value": round(value, 1), "unit": "points/s",
                               "edges_per_gpu": wl.e_local}
 
+    # ------------------------------------------------------------------ per-op breakdowns and rooflines (rank 0)
+    roofline = breakdown = None
+    if rank == 0 and not args.no_breakdown:
+        roofline, breakdown = wl.breakdown()
+        for name, w2 in list(others.items()) + ([(args.layer, wl)] if layers is not None else []):
+            rl, bd = (roofline, breakdown) if w2 is wl else w2.breakdown()
+            ent = layers[name]
+            ent["roofline"] = rl
+            ent["conv_ms"] = {"fwd": bd["spatial_conv_fwd"]["ms"], "bwd": bd["spatial_conv_bwd"]["ms"]}
+            # conv-only rate (SURVEY 8d): spatial_conv forward + backward with the neighbour list and PDFs cached, as
+            # every further layer over the same (level, radius) sees it through ConvolutionBuilder's caches
+            ent["conv_only_points_per_s"] = round(w2.P.shape[0] / ((bd["spatial_conv_fwd"]["ms"] + bd["spatial_conv_bwd"]["ms"]) * 1e-3), 1)
+            ent["conv_rate"] = {"fwd": bd["spatial_conv_fwd"], "bwd": bd["spatial_conv_bwd"]}
+            if "spatial_conv_bf16_rows" in bd:
+                ent["bf16_rows"] = bd["spatial_conv_bf16_rows"]
     # ------------------------------------------------------------------ strong scaling: the fixed batch split over the ranks
     strong = None
     if args.scaling == "both" and args.strong_rooms >= world:
@@ -929,21 +945,6 @@ def main():
             # when the region is short, `--steps 20 --warmup 5`)
             del wl_strong, sw
 
-    # ------------------------------------------------------------------ per-op breakdowns and rooflines (rank 0)
-    roofline = breakdown = None
-    if rank == 0 and not args.no_breakdown:
-        roofline, breakdown = wl.breakdown()
-        for name, w2 in list(others.items()) + ([(args.layer, wl)] if layers is not None else []):
-            rl, bd = (roofline, breakdown) if w2 is wl else w2.breakdown()
-            ent = layers[name]
-            ent["roofline"] = rl
-            ent["conv_ms"] = {"fwd": bd["spatial_conv_fwd"]["ms"], "bwd": bd["spatial_conv_bwd"]["ms"]}
-            # conv-only rate (SURVEY 8d): spatial_conv forward + backward with the neighbour list and PDFs cached, as
-            # every further layer over the same (level, radius) sees it through ConvolutionBuilder's caches
-            ent["conv_only_points_per_s"] = round(w2.P.shape[0] / ((bd["spatial_conv_fwd"]["ms"] + bd["spatial_conv_bwd"]["ms"]) * 1e-3), 1)
-            ent["conv_rate"] = {"fwd": bd["spatial_conv_fwd"], "bwd": bd["spatial_conv_bwd"]}
-            if "spatial_conv_bf16_rows" in bd:
-                ent["bf16_rows"] = bd["spatial_conv_bf16_rows"]
     others.clear()
     torch.cuda.empty_cache()
 
