@@ -663,11 +663,13 @@ static float sqrt_threshold_host(float R) {
 // hand-overs, and fewer neighbour waves competing for the LDS and VALU ports help them more than a slower search costs:
 // pipelined 1to64 step on the room 0.636 -> 0.621 ms (10 / 16 KB: no gain; 60 KB: the search becomes the critical chain,
 // 0.66 ms). The same limit on the KDE kernel LOSES (0.65 ms); alone the padded search is slower (sequential step 0.736 ->
-// 0.762 ms), hence only for background launches. MCCNN_NW_LDS_PAD overrides the amount (A/B).
+// 0.762 ms), hence only for background launches. MCCNN_NW_LDS_PAD overrides the amount (A/B). Re-tuned after the forward
+// pass of the headline layer got shorter (four edges per lane) and the background scans went to the two-launch form: 20 / 24 /
+// 28 / 32 / 36 KB read 0.605-0.634 / 0.597 / 0.599-0.614 / 0.604 / 0.605 ms per pipelined step -> 24 KB.
 static size_t neigh_lds_pad() {
     static const int forced = getenv("MCCNN_NW_LDS_PAD") ? atoi(getenv("MCCNN_NW_LDS_PAD")) : -1;
     if (forced >= 0) return (size_t)forced;
-    return g_background ? 36000 : 0;
+    return g_background ? 24000 : 0;
 }
 static int neigh_group(int m) {
     static const int forced = getenv("MCCNN_NW_GROUP") ? atoi(getenv("MCCNN_NW_GROUP")) : 0;  // A/B switch, read once

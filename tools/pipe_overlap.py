@@ -23,7 +23,7 @@ t = a.join(b, lsuffix="_pipelined", rsuffix="_sequential", how="outer").sort_val
 print("== mean kernel duration (us): pipelined region (geometry of batch k+1 on the side queue) vs sequential region")
 print(t.round(1).to_string())
 m = pipe[pipe.Queue_Id == main_q].reset_index(drop=True)
-fw = m[m.n == "f1_fwd_edges"]
+fw = m[m.n.str.startswith("f1_fwd_edges")]
 if len(fw) > 12:
     st = fw.Start_Timestamp.values
     print("\nstep period, pipelined region (profiler attached): %.1f us" % (np.diff(st)[5:-2].mean() / 1e3))
