@@ -788,8 +788,110 @@ def cpu_baseline(wl, out_gpu):
     return cpu
 
 
+LINE_LIMIT = 4096  # bytes of the final stdout line: the driver's parser gave up on the 32 KB line of round 3
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_record(rec, details_path=None):
+    """The ONE line the driver parses: headline, roofline, cpu_baseline, strong and a five-object summary of the
+    BASELINE configurations. Per-layer lists, the per-op breakdown and every explanatory string live in the details
+    record (bench_details.json and an EARLIER stdout line)."""
+    cfg = rec.get("config") or {}
+    out = {k: rec.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                   "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = _pick(cfg, ("workload", "points_total", "points_per_gpu", "edges_per_gpu", "layer", "parallelism",
+                                "headline_mode", "pipelined_ms_per_step", "sequential_ms_per_step",
+                                "collective_backend", "rccl_world_size"))
+    if isinstance(out["config"].get("workload"), str):
+        out["config"]["workload"] = out["config"]["workload"][:300]
+    rl = rec.get("roofline")
+    if isinstance(rl, dict):
+        r = _pick(rl, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ms", "executed_frac"))
+        busy = rl.get("mfma_pipe_busy") or {}
+        if busy:
+            r["mfma_pipe_busy"] = {d: busy[d].get("busy") for d in ("fwd", "bwd") if isinstance(busy.get(d), dict)}
+        fb = rl.get("fwd_bwd") or {}
+        if fb:
+            r["fwd_bwd"] = {d: _pick(fb[d], ("ms", "algorithmic_frac")) for d in ("fwd", "bwd") if d in fb}
+        if "find_neighbors" in rl:
+            r["find_neighbors"] = rl["find_neighbors"]
+        out["roofline"] = r
+    else:
+        out["roofline"] = rl
+    cb = rec.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind", "sample", "error"))
+        for k in ("sample", "error"):
+            if k in c:
+                c[k] = str(c[k])[:200]
+        if isinstance(cb.get("single_thread"), dict):
+            c["single_thread"] = _pick(cb["single_thread"], ("value", "cores"))
+        out["cpu_baseline"] = c
+    else:
+        out["cpu_baseline"] = cb
+    st = rec.get("strong")
+    out["strong"] = _pick(st, ("rooms", "points_total", "value", "ms_per_step", "unit", "scaling", "mode")) if st else st
+    ly = rec.get("layers")
+    if isinstance(ly, dict):
+        out["layers"] = {}
+        for name, ent in ly.items():
+            e = _pick(ent, ("ms_per_step", "value"))
+            if isinstance(ent.get("conv_ms"), dict):
+                e["conv_ms"] = ent["conv_ms"]
+            if isinstance(ent.get("roofline"), dict):
+                e["frac"] = ent["roofline"].get("frac")
+                e["bound"] = ent["roofline"].get("bound")
+            out["layers"][name] = e
+    cf = rec.get("configs")
+    if isinstance(cf, dict):
+        out["configs"] = {}
+        for name, ent in cf.items():
+            e = _pick(ent, ("ms_per_step", "value", "host_issue_ms_per_step", "library_launches_per_step", "points",
+                            "convolutions"))
+            if "library_launches_per_step" in e:
+                e["launches"] = e.pop("library_launches_per_step")
+            if isinstance(ent.get("cpu_baseline"), dict) and "value" in ent["cpu_baseline"]:
+                e["cpu_value"] = ent["cpu_baseline"]["value"]
+            if "error" in ent:
+                e["error"] = str(ent["error"])[:120]
+            out["configs"][name] = e
+    if details_path:
+        out["details"] = details_path
+    line = json.dumps(out, separators=(",", ":"))
+    # never let the line grow past the limit again: drop the optional objects, least important first
+    for k in ("layers", "strong", "configs"):
+        if len(line) < LINE_LIMIT:
+            break
+        out.pop(k, None)
+        line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:
+        raise AssertionError("bench line of %d bytes" % len(line))
+    return line
+
+
+def emit_record(rec, details_path):
+    """Full record -> `details_path` (and one EARLIER stdout line prefixed by `details:`), compact record -> the LAST
+    stdout line."""
+    full = json.dumps(rec)
+    written = None
+    if details_path:
+        try:
+            with open(details_path, "w") as f:
+                f.write(full + "\n")
+            written = details_path
+        except OSError as ex:
+            log("could not write %s: %r" % (details_path, ex))
+    print("details: " + full, flush=True)
+    print(compact_record(rec, written), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"),
+                    help="file for the full record (per-layer lists, per-op breakdown); '' = stdout only")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)   # 0.6 ms each: a 20-step region is too short to be stable
     ap.add_argument("--warmup", type=int, default=10)
@@ -1002,7 +1104,7 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(rec), flush=True)
+        emit_record(rec, args.details)
     if dist_on:
         dist.destroy_process_group()
 

@@ -1,0 +1,100 @@
+"""The final stdout line of bench.py is what the driver parses: it must stay small (round 3's 32 KB line was not
+parsed) and carry the contract's fields whatever the size of the full record."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _full_record(n_layers=17):
+    rl = {"kernel": "spatial_conv_bwd", "bound": "mfma", "achieved": 90.575, "peak": 157.3, "unit": "TFLOP/s",
+          "frac": 0.5758, "traffic": 1224237649, "ms": 0.366, "edges": 4543198, "mlp_blocks": 8,
+          "conv_kernels": "x" * 200, "executed_frac": 0.3576,
+          "fwd_bwd": {"fwd": {"ms": 0.1689, "algorithmic_frac": 0.4378, "executed_frac": 0.31},
+                      "bwd": {"ms": 0.366, "algorithmic_frac": 0.5758, "executed_frac": 0.36}},
+          "mfma_pipe_busy": {"bwd": {"kernel": "f1_bwd_edges", "busy": 0.24}, "fwd": {"kernel": "f", "busy": 0.31},
+                             "source": "profiles/x.json"}, "traffic_source": "profiles/y.json"}
+    layer = {"name": "Pool_0", "levels": [0, 1], "radius": 0.1, "fin": 1, "fout": 64, "fwd_ms": 0.083, "bwd_ms": 0.111,
+             "roofline_fwd": dict(rl), "roofline_bwd": dict(rl), "note": "n" * 300}
+    cfg = {"workload": "w" * 120, "points": 100000, "clouds": 1, "level_sizes": [100000, 5627, 1273, 318, 73],
+           "convolutions": n_layers, "steps": 30, "ms_per_step": 4.9454, "value": 20220717.2, "unit": "points/s",
+           "library_launches_per_step": 394.0, "host_issue_ms_per_step": 4.9373, "hierarchy_ms": 0.661,
+           "layers": [dict(layer) for _ in range(n_layers)],
+           "cpu_baseline": {"value": 10437.1, "unit": "points/s", "cores": 128, "kind": "port", "sample": "s" * 300}}
+    return {
+        "metric": "MC-convolved points/sec (fwd+bwd), 100k-pt cloud r=0.1", "value": 172722645.0, "unit": "points/s",
+        "n_gpus": 1, "steps": 100, "warmup": 10, "ms_per_step": 0.579, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ScanNet-like non-uniform room " + "c" * 150, "points_total": 100000,
+                   "points_per_gpu": 100000, "edges_per_gpu": 4543198, "layer": "1to64", "parallelism": "cloud-per-GPU dp1",
+                   "headline_mode": "pipelined", "pipeline": "p" * 400, "pipelined_ms_per_step": 0.579,
+                   "sequential_ms_per_step": 0.7005, "collective_backend": None, "rccl_world_size": 1,
+                   "rank_stats": [{"rank": r, "ms": 0.6, "x": "y" * 50} for r in range(8)]},
+        "roofline": rl,
+        "cpu_baseline": {"value": 83697.6, "unit": "points/s", "cores": 128, "kind": "port", "host": "h" * 100,
+                         "sample": "s" * 500, "single_thread": {"value": 9833.8, "unit": "points/s", "cores": 1,
+                                                                "sample": "t" * 300}},
+        "strong": {"rooms": 8, "points_total": 800000, "ms_per_step": 4.79, "value": 1.6e8, "unit": "points/s",
+                   "scaling": "strong", "mode": "pipelined", "rank_stats": None, "note": "n" * 200},
+        "layers": {n: {"ms_per_step": 1.0, "value": 1e8, "roofline": dict(rl), "conv_ms": {"fwd": 0.1, "bwd": 0.3},
+                       "conv_rate": {"x": "y" * 300}} for n in ("1to64", "3to8", "dw256")},
+        "configs": {"cfg%d" % i: dict(cfg) for i in range(5)},
+        "breakdown": {"op%d" % i: {"ms": 0.1, "note": "b" * 100} for i in range(12)},
+    }
+
+
+def test_final_line_is_small_and_complete():
+    b = _bench()
+    rec = _full_record()
+    assert len(json.dumps(rec)) > 30000  # the shape that broke the driver's parser
+    line = b.compact_record(rec, "bench_details.json")
+    assert len(line) < 4096 and "\n" not in line
+    out = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["value"] == rec["value"] and out["ms_per_step"] == rec["ms_per_step"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert out["roofline"][k] == rec["roofline"][k]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in out["cpu_baseline"]
+    assert out["config"]["workload"] == rec["config"]["workload"] and "model" not in out["config"]
+    assert out["strong"]["value"] == rec["strong"]["value"]
+    assert set(out["configs"]) == {"cfg0", "cfg1", "cfg2", "cfg3", "cfg4"}
+    for c in out["configs"].values():
+        assert {"ms_per_step", "value", "host_issue_ms_per_step", "launches"} <= set(c)
+
+
+def test_final_line_survives_errors_and_missing_objects():
+    b = _bench()
+    rec = _full_record()
+    rec.update(roofline=None, cpu_baseline={"error": "x" * 5000}, strong=None, layers=None)
+    rec["configs"] = {"cfg1": {"error": "e" * 5000}}
+    out = json.loads(b.compact_record(rec))
+    assert out["roofline"] is None and out["strong"] is None and len(out["configs"]["cfg1"]["error"]) <= 120
+
+
+def test_emit_record_prints_the_compact_line_last(tmp_path, capsys):
+    b = _bench()
+    rec = _full_record()
+    path = str(tmp_path / "d.json")
+    b.emit_record(rec, path)
+    lines = capsys.readouterr().out.strip().split("\n")
+    assert len(lines) == 2 and lines[0].startswith("details: ") and len(lines[-1]) < 4096
+    assert json.loads(lines[-1])["details"] == path
+    assert json.load(open(path)) == rec == json.loads(lines[0][len("details: "):])
+
+
+def test_last_committed_full_record_compacts():
+    p = os.path.join(ROOT, "profiles", "r03_bench.json")
+    rec = json.load(open(p))
+    line = _bench().compact_record(rec, None)
+    assert len(line) < 4096 and json.loads(line)["roofline"]["frac"] == rec["roofline"]["frac"]
