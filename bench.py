@@ -888,6 +888,25 @@ def emit_record(rec, details_path):
     print(compact_record(rec, written), flush=True)
 
 
+def self_launch(n):
+    """Re-run this command as n ranks of `python -m torch.distributed.run` on a free local port and return its exit
+    code. With fewer GPUs than ranks the ranks share the devices and the collectives go through gloo (RCCL refuses two
+    ranks on one device); that form only exercises the N > 1 code path, the driver's 8-GPU node gets RCCL."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < n:
+        env.setdefault("MCCNN_BENCH_BACKEND", "gloo")
+        log("bench.py: %d ranks on %d GPU(s): ranks share devices, collectives over gloo" % (n, torch.cuda.device_count()))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"),
@@ -921,8 +940,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: the reference has no launcher of its own (ModelNet/ModelNet.py:202-203 pins
+        # one session to one GPU), so the bench carries one -- N ranks of this very command under torch.distributed.run
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        # the N > 1 path must be impossible to mis-run: --gpus N is only valid under a launcher that started N ranks
+        # a launcher IS present and disagrees: --gpus N is only valid under a launcher that started N ranks
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d -- launch N > 1 as `python -m torch.distributed.run "
                          "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`"
                          % (args.gpus, world))

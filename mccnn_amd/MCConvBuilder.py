@@ -315,6 +315,11 @@ class ConvolutionBuilder(torch.nn.Module):
                     pl.row_start = None
                     extra.append(pl.buf)
                     pl.buf = None
+                    # the entry stays in the list's dictionary but can never be a cache hit again: a list that outlives
+                    # this reset() (a graph kept for a later backward pass) rebuilds its plan instead of sweeping freed
+                    # memory through the stale addresses
+                    pl.key = None
+                    pl.vrow = pl.vcode = pl.slice_off = pl.vpos_row = pl.rec = pl.other = 0
         self.cacheGrids_ = self.cacheNeighs_ = self.cachePDFs_ = None  # the cache dictionaries' references go first
         # Is the builder the LAST owner? Exactly three counts answer that, and a build of torch that lacks one of them
         # takes the always-correct record_stream() path: Python references to the tensor object (this frame + the

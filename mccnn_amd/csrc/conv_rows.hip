@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void sell_fill(const float4* __restrict__ recE
 // The pieces of cut rows left their sums in scratch rows (one per virtual row id, `cols` 32-bit words wide -- f32 rows,
 // or bf16 rows whose pieces are kept in f32): out[r] = sum over the row's pieces, in order. One wave per 64 rows; cut rows
 // are rare (none at all on a list whose rows hold <= ROWS_L edges), a wave without one returns after two loads.
+// Rows without any edge are written here as well (zeros).
 template <bool BF>
 __global__ __launch_bounds__(256) void rows_combine(const int* __restrict__ rowStart, int rows, int e,
                                                     const int* __restrict__ vposRow, const float* __restrict__ scratch,
@@ -340,7 +341,10 @@ __global__ __launch_bounds__(256) void rows_combine(const int* __restrict__ rowS
     const int r = r0 + lane;
     int deg = 0;
     if (r < rows) deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
-    unsigned long long cut = __ballot(deg > L);
+    // ... and rows WITHOUT an edge: zero pieces, a zero row. The row kernels store such a row only when its slice holds
+    // an edge of some other row; a slice made of empty rows alone (they sort to the end of their window) has length 0
+    // like the padding slices behind the list and is skipped there.
+    unsigned long long cut = __ballot(deg > L || (r < rows && deg == 0));
     while (cut) {
         const int l = (int)__builtin_ctzll(cut);
         cut &= cut - 1;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256) void rows_combine_par(const int* __restrict__ 
     if (t >= (long long)rows * c4) return;
     const int r = (int)(t / c4), c = (int)(t - (long long)r * c4) * 4;
     const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
-    if (deg <= L) return;
+    if (deg <= L && deg != 0) return;  // (a row without an edge: zero pieces, a zero row -- see rows_combine)
     const int pieces = (deg + L - 1) / L, v0 = vposRow[r];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = 0; k < pieces; ++k) {

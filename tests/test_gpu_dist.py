@@ -145,8 +145,11 @@ def test_bench_through_rccl_with_one_rank(mc):
                         "--no-breakdown", "--no-cpu-baseline", "--no-configs", "--strong-rooms", "2"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    # RCCL may print its version banner on stdout as well: the record is the one line that is a JSON object
-    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    # RCCL may print its version banner on stdout as well: the compact record is the one line that is a JSON object
+    # (the LAST line), the full record the earlier `details:` line
+    assert r.stdout.strip().splitlines()[-1].startswith("{") and len(r.stdout.strip().splitlines()[-1]) < 4096
+    compact, rec = _bench_records(r.stdout)
+    assert compact["value"] == rec["value"] and compact["config"]["rccl_world_size"] == 1
     assert rec["config"]["collective_backend"] == "nccl" and rec["n_gpus"] == 1
     assert rec["config"]["pipeline"] is not None and rec["config"]["pipelined_ms_per_step"] is not None
     assert rec["value"] > 5e7
@@ -154,6 +157,17 @@ def test_bench_through_rccl_with_one_rank(mc):
     # both curves in one line: the fixed batch (here 2 rooms, all on this rank) beside the one-room-per-rank headline
     assert rec["strong"]["rooms"] == 2 and rec["strong"]["points_total"] == 200000 and rec["strong"]["value"] > 5e7
     assert len(rec["config"]["rank_stats"]["own_ms_per_step"]) == 1
+
+
+def _bench_records(stdout):
+    """(compact record = the last stdout line, full record = the `details:` line before it)."""
+    import json
+    lines = stdout.strip().splitlines()
+    compact = [ln for ln in lines if ln.startswith("{")]
+    details = [ln for ln in lines if ln.startswith("details: {")]
+    assert len(compact) == 1 and len(details) == 1 and lines[-1] is not None and lines[-1] == compact[0], lines[-3:]
+    assert len(compact[0]) < 4096
+    return json.loads(compact[0]), json.loads(details[0][len("details: "):])
 
 
 def _torchrun_bench(nproc, extra, timeout=900):
@@ -169,9 +183,9 @@ def _torchrun_bench(nproc, extra, timeout=900):
            "--warmup", "2", "--points", "20000", "--no-layers", "--no-breakdown", "--no-cpu-baseline", "--no-configs"] + extra
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, lines          # rank 0 prints ONE record
-    return json.loads(lines[0])
+    compact, rec = _bench_records(r.stdout)     # rank 0 prints ONE compact record (and its details line)
+    assert compact["n_gpus"] == nproc and compact["config"]["rccl_world_size"] == nproc and compact["value"] == rec["value"]
+    return rec
 
 
 def test_bench_eight_ranks_sharing_the_gpu_weak_and_strong(mc):
@@ -199,8 +213,30 @@ def test_bench_two_ranks_strong_batch_of_four_rooms(mc):
     assert rec["strong"]["rank_stats"]["points"] == [40000, 40000]
     only = _torchrun_bench(2, ["--scaling", "strong", "--strong-rooms", "4"])
     assert only["scaling"] == "strong" and only["strong"] is None and only["config"]["points_total"] == 4 * 20000
+    # a launcher that disagrees with --gpus is refused (one rank started, two asked for) ...
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bare_bench_with_gpus_2_launches_its_own_ranks(mc):
+    """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's N = 1 command with another N): the bench
+    re-runs itself under torch.distributed.run -- two ranks sharing this box's GPU over gloo -- and prints one compact
+    line with the weak headline AND the strong object."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MCCNN_BENCH_FORCE_PG",
+                        "MCCNN_BENCH_BACKEND")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--points", "20000", "--no-layers", "--no-breakdown", "--strong-rooms", "4"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    compact, rec = _bench_records(r.stdout)
+    assert compact["n_gpus"] == 2 and compact["config"]["rccl_world_size"] == 2 and compact["scaling"] == "weak"
+    assert compact["value"] > 0 and compact["strong"]["value"] > 0 and compact["strong"]["rooms"] == 4
+    assert compact["config"]["collective_backend"] == "gloo" and compact["config"]["points_total"] == 2 * 20000

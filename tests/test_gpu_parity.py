@@ -284,6 +284,81 @@ def test_conv_centres_without_neighbours(mc, oracle, fin, fout, combin):
         assert_close(_unwrap(a), b, RTOL, nm)
 
 
+@pytest.mark.parametrize("layout", ["slice_of_empties_large", "m_mod_64_is_1_small", "run_of_64_small"])
+def test_depthwise_rows_with_whole_slices_of_empty_rows(mc, oracle, layout):
+    """Row-per-lane depth-wise kernels: a slice (64 lanes) made ONLY of rows without a single edge has length 0 like the
+    padding slices beyond the list -- its rows must still be stored as zeros (forward: centres without neighbours;
+    backward: points that are nobody's neighbour). Empty rows sort to the end of their 1 024-row window, so such a slice
+    appears whenever the window's non-empty count is a multiple of 64. The output buffers are taken from memory that
+    held NaNs, so a row nobody writes shows."""
+    import torch
+    B, radius, fin = 1, 0.2, 16
+    rng = np.random.default_rng(7)
+    if layout == "slice_of_empties_large":
+        # > 4 096 rows: the windowed layout. Window 0 = 960 centres with neighbours + 64 without
+        n_near, n_far_c, n_c = 6000, 64, 5000
+        near = rng.random((n_near, 3), dtype=np.float32)
+        c_real = near[rng.permutation(n_near)[:n_c - n_far_c]]
+        far_c = (5.0 + 3.0 * rng.random((n_far_c, 3))).astype(np.float32)
+        centres = np.concatenate([c_real[:960], far_c, c_real[960:]]).astype(np.float32)
+        lonely = (-5.0 - 3.0 * rng.random((128, 3))).astype(np.float32)   # points no centre reaches
+        pts = np.concatenate([near[:3000], lonely, near[3000:]]).astype(np.float32)
+    elif layout == "m_mod_64_is_1_small":
+        near = rng.random((700, 3), dtype=np.float32)
+        centres = np.concatenate([near[:192], np.array([[9.0, 9.0, 9.0]], np.float32)]).astype(np.float32)  # 193 rows, last empty
+        # 64 lonely points: they sort to the FRONT of the grid order (lowest cells), slice 0 of the transposed plan is empty
+        pts = np.concatenate([near, (-5.0 - rng.random((64, 3))).astype(np.float32)]).astype(np.float32)
+    else:
+        near = rng.random((900, 3), dtype=np.float32)
+        far_c = (5.0 + 3.0 * rng.random((70, 3))).astype(np.float32)
+        centres = np.concatenate([near[:128], far_c, near[128:300]]).astype(np.float32)   # 64-row slice [128, 192) all empty
+        lonely = (-5.0 - 3.0 * rng.random((70, 3))).astype(np.float32)
+        pts = np.concatenate([near[:256], lonely, near[256:]]).astype(np.float32)
+    bids = np.zeros((len(pts), 1), np.int32)
+    cb = np.zeros((len(centres), 1), np.int32)
+    feats = (2 * rng.random((len(pts), fin)) - 1).astype(np.float32)
+    o = run_chain(oracle, _ident, _ident, pts, bids, feats, B, radius, False, centres=centres, centre_bids=cb,
+                  fout=fin, combin=False)
+    g = run_chain(mc, _wrap, _unwrap, pts, bids, feats, B, radius, False, centres=centres, centre_bids=cb, fout=fin,
+                  combin=False)
+    for k in INT_KEYS:
+        assert np.array_equal(g[k], o[k]), k
+    deg = np.diff(np.append(o["startIndexs"].reshape(-1), len(o["packedNeighs"])))
+    tdeg = np.bincount(o["packedNeighs"][:, 0], minlength=len(pts))
+    assert (deg == 0).sum() >= 1 and (tdeg == 0).sum() >= 1
+    w = o["mlp"]
+    og = (2 * rng.random((len(centres), fin)) - 1).astype(np.float32)
+    args = (o["sortPts"], o["sortFeatures"], o["sortBatchs"], o["pdfs"], centres, o["startIndexs"], o["packedNeighs"],
+            o["aabbMin"], o["aabbMax"], w["w1"], w["w2"], w["w3"], w["b1"], w["b2"], w["b3"])
+    ref = oracle.spatial_conv(*args, fin, False, B, radius, False, True)
+    rg = oracle.spatial_conv_grad(*args, og, fin, False, B, radius, False, True)
+    h = g["_handles"]
+    assert mc._rows_shape(False, fin, h["sF"], len(centres), len(o["packedNeighs"]))  # the row kernels take this layer
+    tw = {k: _wrap(v).requires_grad_(True) for k, v in w.items()}
+    for rep in range(2):
+        sF = h["sF"].detach().clone().requires_grad_(True)
+        # poison the blocks the op's torch.empty() calls are about to receive
+        junk = [torch.full((len(centres), fin), float("nan"), device="cuda"), torch.full((len(pts), fin), float("nan"), device="cuda")]
+        torch.cuda.synchronize()
+        del junk
+        out = mc.spatial_conv(h["sP"], sF, h["sB"], _wrap(o["pdfs"]), h["C"], h["start"], h["packed"], h["mn"], h["mx"],
+                              tw["w1"], tw["w2"], tw["w3"], tw["b1"], tw["b2"], tw["b3"], fin, False, B, radius, False, True)
+        got = _unwrap(out)
+        assert np.isfinite(got).all() and np.all(got[deg == 0] == 0)
+        assert_close(got, ref, RTOL, "spatial_conv")
+        junk = [torch.full((len(pts), fin), float("nan"), device="cuda"), torch.full((len(centres), fin), float("nan"), device="cuda")]
+        torch.cuda.synchronize()
+        del junk
+        out.backward(_wrap(og))
+        torch.cuda.synchronize()
+        fg = _unwrap(sF.grad)
+        assert np.isfinite(fg).all() and np.all(fg[tdeg == 0] == 0)
+        assert_close(fg, rg[0], RTOL, "featGrad")
+    for nm, a, b in zip(["dw1", "db1", "dw2", "db2", "dw3", "db3"],
+                        [tw["w1"].grad, tw["b1"].grad, tw["w2"].grad, tw["b2"].grad, tw["w3"].grad, tw["b3"].grad], rg[1:]):
+        assert_close(_unwrap(a) / 2.0, b, RTOL, nm)   # two backward passes accumulated
+
+
 def test_poisson_dataflow_and_phased_forms_agree(mc, oracle):
     """All 27 colour phases in one launch (cells wait on per-cell flags) against one launch per phase and the oracle:
     uniform, clustered (cells with > 64 points, windows beyond the register path) and multi-cloud inputs."""
