@@ -418,6 +418,65 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
                                 float* db2, float* dw3, float* db3, const int* feat_index, void* ws,
                                 size_t ws_bytes, mccnn_stream_t stream);
 
+/* NATIVE STEP EXECUTOR (extension; what ConvolutionBuilder.create_convolution, MCConvBuilder.py:336-427, does around
+ * the ops): one call per convolution GEOMETRY and one per layer and direction instead of ~12 op calls, because a step of
+ * a network is bound by the host issuing its launches, not by the kernels. Built on the entry points above --
+ * identical launches, identical results.
+ *
+ * mccnn_geometry_t: the grid of the input level at the convolution radius (sort_points_step1/2 of the points), the
+ * neighbour list of the output level's points in it (find_neighbors) and its PDFs (compute_pdf) -- one cache entry each
+ * of cacheGrids_ / cacheNeighs_ / cachePDFs_ (MCConvBuilder.py:349-391) -- in ONE caller-provided device buffer of
+ * mccnn_geometry_bytes(). The host object is created / destroyed by the library (no device memory behind it).
+ * build: enqueues everything WITHOUT a host wait. e_capacity: rows of the neighbour list the buffer holds (the caller's
+ * guess, e.g. the total of the last batch of this shape); the true total E is stored by the count pass into
+ * *total_host, a PINNED host word owned by the caller that has to stay valid until the total has been read
+ * (mccnn_geometry_edges, or the first mccnn_conv_* call, which wait for it). E > e_capacity: every mccnn_conv_* call
+ * returns MCCNN_E_CAPACITY and the caller builds again with a larger buffer. grid_from: optional geometry over the same
+ * points, boxes and cell count whose grid is shared instead of built again (keyGrid hit with another output level);
+ * it has to outlive this one. use_pdf == 0: PDFs of 1 (MCConvBuilder.py:388-390). All input pointers are borrowed
+ * until the geometry is destroyed or built again. */
+#define MCCNN_E_CAPACITY (-6)   /* neighbour list longer than the e_capacity a geometry was built with */
+typedef struct mccnn_geometry mccnn_geometry_t;
+mccnn_geometry_t* mccnn_geometry_create(void);
+void mccnn_geometry_destroy(mccnn_geometry_t* g);
+size_t mccnn_geometry_bytes(int n, int m, int batch_size, int num_cells, int e_capacity, int with_grid);
+int mccnn_geometry_build(mccnn_geometry_t* g, const float* pts, const int* batch_ids, int n, const float* centres,
+                         const int* centre_batch_ids, int m, const float* aabb_min, const float* aabb_max,
+                         int batch_size, int num_cells, float radius, int scale_inv, float window, int use_pdf,
+                         int e_capacity, const mccnn_geometry_t* grid_from, void* buffer, size_t buffer_bytes,
+                         int* total_host, mccnn_stream_t stream);
+/* E, or -1 while the count pass has not retired (wait_us: 0 = look once, < 0 = wait, > 0 = wait at most that long). */
+int mccnn_geometry_edges(mccnn_geometry_t* g, int wait_us);
+/* out[0..7]: device addresses of sortPts [n,3], sortBatchs [n], cellIndexs [B,nc,nc,nc,2], index_new_pos [n], its
+ * inverse [n], startIndexs [m], packedNeighs [e_capacity,2], pdfs [e_capacity]; out[8..13]: n, m, num_cells,
+ * e_capacity, E (-1 = not read yet), batch_size; out[14]: device word holding E; out[15]: 1 = owns its grid. */
+int mccnn_geometry_info(const mccnn_geometry_t* g, long long out[16]);
+/* Further pieces a geometry keeps for the layers over it, each in a caller-provided buffer (256-byte aligned) that lives
+ * as long as the geometry: what = 1 forward row plan, 2 transposed row plan, 4 transposed neighbour list, 8 per-edge
+ * records. mccnn_conv_prepare says which are missing and how large they are. */
+int mccnn_geometry_attach(mccnn_geometry_t* g, int what, void* buffer, size_t bytes);
+/* One layer over a geometry: SpatialConv / SpatialConvGrad INCLUDING sort_features / its gradient
+ * (MCConvModuleSrc:35-45,70-81). feats [n, num_in_feats] and feat_grad are rows of the UNSORTED points (f32, or bf16
+ * with bf16 != 0: depth-wise layers, num_in_feats % 8 == 0); out [m, combin ? num_out_feats : num_in_feats].
+ * flags: bit 0 = keep the forward state for the backward pass, bit 1 = deterministic feature gradient of combin layers
+ * with 2..4 input features (gathered through the transposed list instead of float atomics).
+ * prepare (forward or backward): waits for E, then reports need_mask / need_bytes[k] (pieces to attach first, bit k),
+ * the scratch bytes of the call and -- forward -- the bytes of `saved`, which the caller keeps from forward to
+ * backward (sorted feature rows + forward state). The kernel family is chosen as the Python op surface chooses it
+ * (row-per-lane depth-wise kernels, factored one-feature kernels, edge streaming). */
+int mccnn_conv_prepare(mccnn_geometry_t* g, const void* feats, int num_in_feats, int num_out_feats, int combin, int bf16,
+                       int backward, int flags, int* need_mask, long long need_bytes[4], long long* ws_bytes,
+                       long long* saved_bytes, int* edges);
+int mccnn_conv_forward(mccnn_geometry_t* g, const void* feats, int num_in_feats, int num_out_feats, int combin, int avg,
+                       int bf16, int flags, const float* w1, const float* b1, const float* w2, const float* b2,
+                       const float* w3, const float* b3, void* out, void* saved, size_t saved_bytes, void* ws,
+                       size_t ws_bytes, mccnn_stream_t stream);
+int mccnn_conv_backward(mccnn_geometry_t* g, const void* feats, const void* saved, size_t saved_bytes,
+                        const void* out_grad, int num_in_feats, int num_out_feats, int combin, int avg, int bf16,
+                        int flags, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                        const float* b3, void* feat_grad, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
+                        float* db3, void* ws, size_t ws_bytes, mccnn_stream_t stream);
+
 /* TEST HOOK, not part of the operator surface: selects the convolution implementation for A/B
  * parity tests (bit 0: VALU fallback kernels, bit 1: general MFMA kernels for one-input-feature
  * layers; 0 = product default). Returns the previous mask. Initial value: MCCNN_FORCE_VALU /

@@ -77,6 +77,18 @@ SIGNATURES = {
     "mccnn_spatial_conv_bwd_rows": (_i, [_vp] * 16 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 7 + [_vp] * 8 + [_vp, _vp, _sz, _vp]),
     "mccnn_transpose_neighbors_workspace_bytes": (_sz, [_i, _i]),
     "mccnn_transpose_neighbors": (_i, [_vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    # native step executor (exec.hip)
+    "mccnn_geometry_create": (_vp, []),
+    "mccnn_geometry_destroy": (None, [_vp]),
+    "mccnn_geometry_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "mccnn_geometry_build": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _i, _f, _i, _i, _vp, _vp, _sz, _vp, _vp]),
+    "mccnn_geometry_edges": (_i, [_vp, _i]),
+    "mccnn_geometry_info": (_i, [_vp, C.POINTER(C.c_longlong)]),
+    "mccnn_geometry_attach": (_i, [_vp, _i, _vp, _sz]),
+    "mccnn_conv_prepare": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(C.c_longlong),
+                                C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(_i)]),
+    "mccnn_conv_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i] + [_vp] * 6 + [_vp, _vp, _sz, _vp, _sz, _vp]),
+    "mccnn_conv_backward": (_i, [_vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _i] + [_vp] * 6 + [_vp] * 7 + [_vp, _sz, _vp]),
 }
 
 

@@ -12,7 +12,7 @@ std::atomic<int> g_f1_x4_min_edges{getenv("MCCNN_F1_X4_MIN_E") ? atoi(getenv("MC
 extern "C" {
 
 int mccnn_block_size(void) { return MCCNN_MLP; }
-int mccnn_abi_version(void) { return 8; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn; 5: row plans, aabb_extent; 6: rowplan_build, build_grid; 7: feat_index of the row kernels, hierarchy_level, find_neighbors_count2; 8: background_launches, debug_f1_x4_min_edges
+int mccnn_abi_version(void) { return 9; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn; 5: row plans, aabb_extent; 6: rowplan_build, build_grid; 7: feat_index of the row kernels, hierarchy_level, find_neighbors_count2; 8: background_launches, debug_f1_x4_min_edges; 9: native step executor (mccnn_geometry_*, mccnn_conv_*)
 const char* mccnn_arch(void) { return "gfx950"; }
 int mccnn_background_launches(int on) { const int prev = mccnn::g_background; mccnn::g_background = on ? 1 : 0; return prev; }
 int mccnn_debug_f1_x4_min_edges(int edges) { return mccnn::g_f1_x4_min_edges.exchange(edges < 0 ? 0 : edges); }
@@ -27,6 +27,7 @@ const char* mccnn_error_string(int code) {
         case MCCNN_E_TOOLARGE: return "problem does not fit 32-bit indexing (B*nc^3, E or LDS tile)";
         case MCCNN_E_WORKSPACE: return "workspace missing or smaller than the *_workspace_bytes query";
         case MCCNN_E_SHAPE: return "kernel-MLP shape rule violated (spatial_conv.cc:258-300)";
+        case MCCNN_E_CAPACITY: return "neighbour list longer than the capacity the geometry was built with";
         default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);

@@ -1,0 +1,611 @@
+// exec.hip -- the native step executor: what ConvolutionBuilder.create_convolution (MCConvBuilder.py:336-427) does
+// around the kernels, behind TWO kinds of C-ABI calls instead of a dozen Python-mediated ones:
+//   * mccnn_geometry_build : sort_points_step1/2 of the input level, find_neighbors (count, scan, fill into a buffer sized by
+//     the caller's guess) and compute_pdf, enqueued back to back into ONE caller-provided device buffer, without a host
+//     wait -- the geometry one (level, radius, output level) cache entry of the builder stands for (:349-391);
+//   * mccnn_conv_forward / mccnn_conv_backward : the convolution of one layer over a geometry, INCLUDING the feature sort
+//     (sort_features / its gradient, MCConvModuleSrc:35-45), the choice of the kernel family (row-per-lane depth-wise,
+//     factored Fin = 1, edge streaming) and the row plans / transposed list a family needs, built on first use and kept
+//     with the geometry for every further layer over the same list.
+// No kernels live here: every launch goes through the op-level entry points of this library (mccnn.h), so the results are
+// those of the op-by-op chain bit for bit. The library still allocates no device memory: buffers come from the caller,
+// sized by the *_bytes queries.
+#include "common.h"
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <thread>
+
+namespace mccnn {
+std::atomic<int>& conv_impl_override();  // conv.hip (mccnn_debug_conv_impl)
+}
+
+using namespace mccnn;
+
+namespace {
+
+struct Plan {
+    char* buf = nullptr;
+    size_t bytes = 0;
+    bool built = false;
+    int avg = -1;
+    long long off[6] = {0, 0, 0, 0, 0, 0};
+    long long total = 0, slots = 0, scratch_rows = 0;
+    int S = 0;
+};
+
+inline size_t al(size_t x) { return align_up(x); }
+
+}  // namespace
+
+struct mccnn_geometry {
+    // inputs (borrowed: the caller keeps them alive as long as the geometry is used)
+    const float* pts = nullptr;
+    const int* bids = nullptr;
+    const float* centres = nullptr;
+    const int* cbids = nullptr;
+    const float* mn = nullptr;
+    const float* mx = nullptr;
+    int n = 0, m = 0, B = 0, nc = 0, scale_inv = 0, use_pdf = 1, same_level = 0;
+    float radius = 0.f, window = 0.f;
+    // the geometry buffer
+    char* buf = nullptr;
+    size_t bytes = 0;
+    float* s_pts = nullptr;
+    int *s_bids = nullptr, *cells = nullptr, *new_idx = nullptr, *inv_idx = nullptr;
+    int *start = nullptr, *packed = nullptr, *total_dev = nullptr, *order = nullptr;
+    float* pdfs = nullptr;
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    const mccnn_geometry* grid_of = nullptr;  // the grid arrays belong to another geometry (same level, radius)
+    // edge count
+    int e_cap = 0;
+    int e = -1;                      // known once the pinned word has been read
+    volatile int* total_host = nullptr;
+    bool built = false;
+    // attachments
+    Plan plan[2];                    // [0] forward (rows = centres), [1] transposed (rows = points)
+    char* tl_buf = nullptr;          // transposed list: start_t [n + 1] | perm_t [e]
+    size_t tl_bytes = 0;
+    bool tl_built = false;
+    char* rec_buf = nullptr;         // per-edge records (16 B per edge) in edge order
+    size_t rec_bytes = 0;
+    int rec_avg = -1;
+};
+
+namespace {
+
+enum { NEED_PLAN_FWD = 1, NEED_PLAN_TR = 2, NEED_TLIST = 4, NEED_RECORDS = 8 };
+
+struct GeoLayout {
+    size_t s_pts, s_bids, cells, new_idx, inv_idx, start, packed, pdfs, total, order, ws, ws_bytes, total_bytes;
+};
+
+size_t cells_of(int B, int nc) { return (size_t)B * nc * nc * nc; }
+
+// byte offsets of the pieces of a geometry buffer; total_bytes == 0: the grid does not fit 32-bit keys
+GeoLayout geo_layout(int n, int m, int B, int nc, int e_cap, bool with_grid) {
+    GeoLayout L;
+    memset(&L, 0, sizeof(L));
+    const size_t n1 = n > 0 ? n : 1, m1 = m > 0 ? m : 1, e1 = e_cap > 0 ? e_cap : 1;
+    size_t o = 0;
+    if (with_grid) {
+        L.s_pts = o; o += al(n1 * 12);
+        L.s_bids = o; o += al(n1 * 4);
+        L.cells = o; o += al(cells_of(B, nc) * 8);
+        L.new_idx = o; o += al(n1 * 4);
+        L.inv_idx = o; o += al(n1 * 4);
+    }
+    L.start = o; o += al(m1 * 4);
+    L.packed = o; o += al(e1 * 8);
+    L.pdfs = o; o += al(e1 * 4);
+    L.total = o; o += 256;
+    L.order = o; o += al(m1 * 4);
+    size_t w = mccnn_find_neighbors_workspace_bytes(m, n);
+    if (with_grid) {
+        const size_t g = mccnn_build_grid_workspace_bytes(n, B, nc);
+        if (g == 0) return L;
+        if (g > w) w = g;
+    }
+    // a visiting order for centres of another level: their destinations in this grid (sort_step1 on the centres) + keys
+    const size_t c = mccnn_sort_step1_workspace_bytes(m, B, nc);
+    if (c == 0) return L;
+    const size_t cw = c + al(m1 * 4) * 2;
+    if (cw > w) w = cw;
+    const size_t p = mccnn_compute_pdf_workspace_bytes(e_cap, 1);
+    if (p > w) w = p;
+    L.ws = o;
+    L.ws_bytes = al(w) + 256;
+    o += L.ws_bytes;
+    L.total_bytes = o;
+    return L;
+}
+
+int read_mask() { return conv_impl_override().load(std::memory_order_relaxed); }
+
+bool env_flag(const char* name, bool dflt) {
+    const char* v = getenv(name);
+    return v ? (strcmp(v, "0") != 0) : dflt;
+}
+bool row_kernels_on() { static const bool on = env_flag("MCCNN_ROW_KERNELS", true); return on; }
+float rows_min_degree() { static const float d = getenv("MCCNN_ROWS_MIN_DEGREE") ? (float)atof(getenv("MCCNN_ROWS_MIN_DEGREE")) : 16.f; return d; }
+int unsorted_max_points() { static const int v = getenv("MCCNN_UNSORTED_MAX_POINTS") ? atoi(getenv("MCCNN_UNSORTED_MAX_POINTS")) : 32768; return v; }
+
+// Row-per-lane kernels for this (layer, list, direction)? The measured rule of the Python op surface
+// (MCConvModule._rows_shape): every list of <= 500 k edges; forward of larger lists unless the layer is narrow and the
+// gathered rows miss the L2s; backward of larger lists only for wide layers with long rows.
+bool rows_shape(bool combin, int fin, const void* feats, int rows, int n_points, int e, bool backward) {
+    if (!row_kernels_on() || read_mask() != 0 || combin || fin % 8 != 0 || e <= 0 || rows <= 0 || (((uintptr_t)feats) & 15)) return false;
+    if (e <= 500000) return true;
+    if (!backward) return !(fin <= 128 && n_points >= 65536);
+    return fin >= 256 && (float)e / (float)rows >= rows_min_degree();
+}
+
+// the edge total: stored by the prefix sum of the count pass straight into the caller's pinned word
+int wait_edges(mccnn_geometry* g, int spin_us) {
+    if (g->e >= 0) return g->e;
+    if (!g->total_host) return -1;
+    int v = *g->total_host;
+    if (v < 0 && spin_us != 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int k = 0; k < 256 && v < 0; ++k) v = *g->total_host;
+            if (v >= 0) break;
+            const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (spin_us > 0 && us > spin_us) break;
+            if (us > 200) std::this_thread::yield();
+        }
+    }
+    if (v >= 0) g->e = v;
+    return v;
+}
+
+const mccnn_geometry* grid_owner(const mccnn_geometry* g) { return g->grid_of ? g->grid_of : g; }
+
+struct Shape {
+    int fin, fout, combin, bf16, outF, nb;
+    size_t elem;      // bytes per feature element
+    int words;        // 32-bit words per feature row
+};
+bool make_shape(Shape& s, int fin, int fout, int combin, int bf16) {
+    if (fin <= 0 || fout <= 0) return false;
+    s.fin = fin; s.fout = fout; s.combin = combin ? 1 : 0; s.bf16 = bf16 ? 1 : 0;
+    s.outF = combin ? fout : fin;
+    const long long neurons = combin ? (long long)fin * fout : fin;
+    s.nb = (int)((neurons + 7) / 8);
+    s.elem = bf16 ? 2 : 4;
+    if (bf16 && (combin || fin % 8 != 0)) return false;
+    s.words = bf16 ? fin / 2 : fin;
+    return true;
+}
+
+// what the forward pass of a layer does with the feature rows
+struct FwdMode {
+    bool rows_fwd, rows_bwd, unsorted;
+};
+FwdMode fwd_mode(const mccnn_geometry* g, const Shape& s, const void* feats, int e) {
+    FwdMode f;
+    // (the sorted copy of the rows lives in a 256-byte aligned buffer of this layer's own: only the unsorted mode reads
+    // the caller's rows in place and depends on their alignment)
+    f.rows_fwd = rows_shape(s.combin, s.fin, nullptr, g->m, g->n, e, false);
+    f.rows_bwd = rows_shape(s.combin, s.fin, nullptr, g->n, g->n, e, true);
+    // small levels whose layer takes the row kernels in both directions: the rows are read where they lie (feat_index)
+    f.unsorted = g->n <= unsorted_max_points() && e > 0 && g->m > 0 && f.rows_fwd && f.rows_bwd && ((((uintptr_t)feats) & 15) == 0);
+    return f;
+}
+
+int plan_prepare(mccnn_geometry* g, int tr, int e) {
+    Plan& p = g->plan[tr];
+    const int rows = tr ? g->n : g->m;
+    return mccnn_rowplan_buffer(rows, e, p.off, &p.total, &p.S, &p.slots, &p.scratch_rows);
+}
+
+size_t tlist_bytes(int n, int e) { return al((size_t)(n + 1) * 4) + al((size_t)(e > 0 ? e : 1) * 4); }
+int* tl_start(const mccnn_geometry* g) { return reinterpret_cast<int*>(g->tl_buf); }
+int* tl_perm(const mccnn_geometry* g) { return reinterpret_cast<int*>(g->tl_buf + al((size_t)(g->n + 1) * 4)); }
+
+int ensure_tlist(mccnn_geometry* g, int e, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    if (g->tl_built) return 0;
+    if (!g->tl_buf || g->tl_bytes < tlist_bytes(g->n, e)) return MCCNN_E_WORKSPACE;
+    const mccnn_geometry* go = grid_owner(g);
+    (void)go;
+    int rc = mccnn_transpose_neighbors(g->packed, e, g->n, tl_start(g), tl_perm(g), ws, ws_bytes, stream);
+    if (rc) return rc;
+    g->tl_built = true;
+    return 0;
+}
+
+int ensure_plan(mccnn_geometry* g, int tr, int e, int avg, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    Plan& p = g->plan[tr];
+    if (p.built && p.avg == avg) return 0;
+    int rc = plan_prepare(g, tr, e);
+    if (rc) return rc;
+    if (!p.buf || p.bytes < (size_t)p.total) return MCCNN_E_WORKSPACE;
+    const int rows = tr ? g->n : g->m;
+    const bool inl = mccnn_rowplan_inline_records(rows, e) != 0;
+    int rec_ready = 1;
+    void* rec = nullptr;
+    if (!inl) {
+        if (!g->rec_buf || g->rec_bytes < (size_t)e * 16) return MCCNN_E_WORKSPACE;
+        rec = g->rec_buf;
+        rec_ready = g->rec_avg == avg ? 1 : 0;
+    }
+    int tready = 1;
+    int *st = nullptr, *pt = nullptr;
+    if (tr) {
+        if (!g->tl_buf || g->tl_bytes < tlist_bytes(g->n, e)) return MCCNN_E_WORKSPACE;
+        st = tl_start(g);
+        pt = tl_perm(g);
+        tready = g->tl_built ? 1 : 0;
+    }
+    const mccnn_geometry* go = grid_owner(g);
+    // visiting order of the rows of a forward plan: the search's own centre order
+    const int* order = tr ? nullptr : (g->same_level ? go->inv_idx : (g->order ? g->order : nullptr));
+    rc = mccnn_rowplan_build(tr, go->s_pts, go->s_bids, g->pdfs, g->centres, g->start, g->packed, g->mn, g->mx, g->n, g->m, e,
+                             g->B, g->radius, g->scale_inv, avg, order, rec, rec_ready, st, pt, tready, p.buf, ws, ws_bytes,
+                             stream);
+    if (rc) return rc;
+    if (!inl) g->rec_avg = avg;
+    if (tr) g->tl_built = true;
+    p.built = true;
+    p.avg = avg;
+    return 0;
+}
+
+size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+}  // namespace
+
+extern "C" {
+
+mccnn_geometry_t* mccnn_geometry_create(void) { return new (std::nothrow) mccnn_geometry(); }
+void mccnn_geometry_destroy(mccnn_geometry_t* g) { delete g; }
+
+size_t mccnn_geometry_bytes(int n, int m, int batch_size, int num_cells, int e_capacity, int with_grid) {
+    if (n < 0 || m < 0 || batch_size <= 0 || num_cells <= 0 || e_capacity < 0) return 0;
+    if (cells_of(batch_size, num_cells) > 0x7fffffffULL) return 0;
+    return geo_layout(n, m, batch_size, num_cells, e_capacity, with_grid != 0).total_bytes;
+}
+
+int mccnn_geometry_build(mccnn_geometry_t* g, const float* pts, const int* batch_ids, int n, const float* centres,
+                         const int* centre_batch_ids, int m, const float* aabb_min, const float* aabb_max, int batch_size,
+                         int num_cells, float radius, int scale_inv, float window, int use_pdf, int e_capacity,
+                         const mccnn_geometry_t* grid_from, void* buffer, size_t buffer_bytes, int* total_host,
+                         mccnn_stream_t stream) {
+    if (!g || !pts || !batch_ids || !centres || !centre_batch_ids || !aabb_min || !aabb_max || !buffer || !total_host)
+        return MCCNN_E_BADARG;
+    if (n <= 0 || m <= 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.f) || e_capacity <= 0) return MCCNN_E_BADARG;
+    if (use_pdf && !(window > 0.f)) return MCCNN_E_BADARG;
+    if (grid_from && (grid_from->n != n || grid_from->nc != num_cells || grid_from->B != batch_size || !grid_owner(grid_from)->built))
+        return MCCNN_E_BADARG;
+    const bool with_grid = grid_from == nullptr;
+    const GeoLayout L = geo_layout(n, m, batch_size, num_cells, e_capacity, with_grid);
+    if (L.total_bytes == 0) return MCCNN_E_TOOLARGE;
+    if (buffer_bytes < L.total_bytes || (((uintptr_t)buffer) & 255)) return MCCNN_E_WORKSPACE;
+    *g = mccnn_geometry();
+    g->pts = pts; g->bids = batch_ids; g->centres = centres; g->cbids = centre_batch_ids; g->mn = aabb_min; g->mx = aabb_max;
+    g->n = n; g->m = m; g->B = batch_size; g->nc = num_cells; g->scale_inv = scale_inv ? 1 : 0; g->use_pdf = use_pdf ? 1 : 0;
+    g->radius = radius; g->window = window;
+    g->same_level = (centres == pts && m == n) ? 1 : 0;
+    g->buf = (char*)buffer; g->bytes = buffer_bytes;
+    char* b = g->buf;
+    if (with_grid) {
+        g->s_pts = (float*)(b + L.s_pts); g->s_bids = (int*)(b + L.s_bids); g->cells = (int*)(b + L.cells);
+        g->new_idx = (int*)(b + L.new_idx); g->inv_idx = (int*)(b + L.inv_idx);
+    } else {
+        g->grid_of = grid_owner(grid_from);
+    }
+    g->start = (int*)(b + L.start); g->packed = (int*)(b + L.packed); g->pdfs = (float*)(b + L.pdfs);
+    g->total_dev = (int*)(b + L.total);
+    g->ws = b + L.ws; g->ws_bytes = L.ws_bytes;
+    g->e_cap = e_capacity; g->e = -1; g->total_host = total_host;
+    *total_host = -1;  // armed: the prefix sum of the count pass overwrites it
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (with_grid) {
+        rc = mccnn_build_grid(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, g->new_idx, g->s_pts, g->s_bids,
+                              g->cells, g->inv_idx, g->ws, g->ws_bytes, stream);
+        if (rc) return rc;
+    }
+    const mccnn_geometry* go = grid_owner(g);
+    // visiting order of the centres (speed only): the grid's own order when the centres are the gridded points; for the
+    // points of another level (pooling / up-sampling: Poisson samples arrive phase by phase, all over the scene) their
+    // destinations in THIS grid, a counting sort of the library's own -- small lists are searched in ~10 us either way
+    const int* order = nullptr;
+    if (g->same_level) {
+        order = go->inv_idx;
+    } else if (m >= 16384) {
+        const size_t m1 = (size_t)m;
+        Arena a(g->ws, g->ws_bytes);
+        int* keys = a.take<int>(m1);
+        int* dest = a.take<int>(m1);
+        if (!keys || !dest) return MCCNN_E_WORKSPACE;
+        rc = mccnn_sort_step1(centres, centre_batch_ids, aabb_min, aabb_max, m, batch_size, num_cells, keys, dest, a.base + a.off,
+                              a.cap - a.off, stream);
+        if (rc) return rc;
+        g->order = (int*)(b + L.order);
+        rc = mccnn_invert_permutation(dest, m, g->order, stream);
+        if (rc) return rc;
+        order = g->order;
+    }
+    rc = mccnn_find_neighbors_count2(centres, centre_batch_ids, m, go->s_pts, n, go->cells, aabb_min, aabb_max, batch_size,
+                                     num_cells, radius, g->scale_inv, order, g->start, g->total_dev, total_host, g->ws,
+                                     g->ws_bytes, stream);
+    if (rc) return rc;
+    rc = mccnn_find_neighbors_fill(centres, centre_batch_ids, m, go->s_pts, n, go->cells, aabb_min, aabb_max, batch_size,
+                                   num_cells, radius, g->scale_inv, order, g->start, e_capacity, g->packed, g->ws, g->ws_bytes,
+                                   stream);
+    if (rc) return rc;
+    if (use_pdf) {
+        rc = mccnn_compute_pdf_dn(go->s_pts, go->s_bids, g->start, m, g->packed, e_capacity, g->total_dev, aabb_min, aabb_max,
+                                  batch_size, window, radius, g->scale_inv, g->pdfs, g->ws, g->ws_bytes, stream);
+        if (rc) return rc;
+    } else {  // MCConvBuilder.py:388-390: a tensor of ones
+        MCCNN_MEMSET(hipMemsetD32Async((hipDeviceptr_t)g->pdfs, 0x3f800000, (size_t)e_capacity, s));
+    }
+    g->built = true;
+    return 0;
+}
+
+int mccnn_geometry_edges(mccnn_geometry_t* g, int wait_us) {
+    if (!g || !g->built) return MCCNN_E_BADARG;
+    const int e = wait_edges(g, wait_us);
+    return e < 0 ? -1 : e;
+}
+
+int mccnn_geometry_info(const mccnn_geometry_t* g, long long out[16]) {
+    if (!g || !g->built || !out) return MCCNN_E_BADARG;
+    const mccnn_geometry* go = grid_owner(g);
+    out[0] = (long long)(uintptr_t)go->s_pts; out[1] = (long long)(uintptr_t)go->s_bids; out[2] = (long long)(uintptr_t)go->cells;
+    out[3] = (long long)(uintptr_t)go->new_idx; out[4] = (long long)(uintptr_t)go->inv_idx;
+    out[5] = (long long)(uintptr_t)g->start; out[6] = (long long)(uintptr_t)g->packed; out[7] = (long long)(uintptr_t)g->pdfs;
+    out[8] = g->n; out[9] = g->m; out[10] = g->nc; out[11] = g->e_cap; out[12] = g->e; out[13] = g->B;
+    out[14] = (long long)(uintptr_t)g->total_dev; out[15] = g->grid_of ? 0 : 1;
+    return 0;
+}
+
+int mccnn_geometry_attach(mccnn_geometry_t* g, int what, void* buffer, size_t bytes) {
+    if (!g || !g->built || !buffer || (((uintptr_t)buffer) & 255)) return MCCNN_E_BADARG;
+    switch (what) {
+        case NEED_PLAN_FWD: g->plan[0] = Plan(); g->plan[0].buf = (char*)buffer; g->plan[0].bytes = bytes; return 0;
+        case NEED_PLAN_TR: g->plan[1] = Plan(); g->plan[1].buf = (char*)buffer; g->plan[1].bytes = bytes; return 0;
+        case NEED_TLIST: g->tl_buf = (char*)buffer; g->tl_bytes = bytes; g->tl_built = false; return 0;
+        case NEED_RECORDS: g->rec_buf = (char*)buffer; g->rec_bytes = bytes; g->rec_avg = -1; return 0;
+        default: return MCCNN_E_BADARG;
+    }
+}
+
+// What one mccnn_conv_forward / _backward call of this layer shape needs from the caller: which pieces the geometry does
+// not hold yet (need_mask, need_bytes[k] for bit k), the scratch of the call, and (forward) what has to be kept for the
+// backward pass. Waits for the edge total of the geometry (the one host wait of a convolution).
+int mccnn_conv_prepare(mccnn_geometry_t* g, const void* feats, int num_in_feats, int num_out_feats, int combin, int bf16,
+                       int backward, int flags, int* need_mask, long long need_bytes[4], long long* ws_bytes,
+                       long long* saved_bytes, int* edges) {
+    if (!g || !g->built || !need_mask || !need_bytes || !ws_bytes || !saved_bytes || !edges) return MCCNN_E_BADARG;
+    Shape s;
+    if (!make_shape(s, num_in_feats, num_out_feats, combin, bf16)) return MCCNN_E_SHAPE;
+    const int e = wait_edges(g, -1);
+    if (e < 0) return MCCNN_E_BADARG;
+    *edges = e;
+    if (e > g->e_cap) return MCCNN_E_CAPACITY;
+    const int n = g->n, m = g->m;
+    const FwdMode f = fwd_mode(g, s, feats, e);
+    int mask = 0;
+    for (int k = 0; k < 4; ++k) need_bytes[k] = 0;
+    size_t ws = 256, saved = 0;
+    auto want_plan = [&](int tr) -> int {
+        Plan& p = g->plan[tr];
+        int rc = plan_prepare(g, tr, e);
+        if (rc) return rc;
+        if (!p.buf || p.bytes < (size_t)p.total) { mask |= tr ? NEED_PLAN_TR : NEED_PLAN_FWD; need_bytes[tr] = p.total; }
+        const int rows = tr ? n : m;
+        if (!mccnn_rowplan_inline_records(rows, e) && (!g->rec_buf || g->rec_bytes < (size_t)e * 16)) {
+            mask |= NEED_RECORDS;
+            need_bytes[3] = (long long)al((size_t)e * 16);
+        }
+        const size_t b = mccnn_rowplan_build_workspace_bytes(rows, e, tr);
+        if (b > ws) ws = b;
+        return 0;
+    };
+    auto want_tlist = [&]() {
+        if (!g->tl_buf || g->tl_bytes < tlist_bytes(n, e)) { mask |= NEED_TLIST; need_bytes[2] = (long long)tlist_bytes(n, e); }
+        const size_t b = mccnn_transpose_neighbors_workspace_bytes(n, e);
+        if (b > ws) ws = b;
+    };
+    if (!backward) {
+        if (!f.unsorted) saved += al((size_t)n * s.fin * s.elem);  // the sorted feature rows
+        if (f.rows_fwd) {
+            int rc = want_plan(0);
+            if (rc) return rc;
+            const size_t scratch = al((size_t)g->plan[0].scratch_rows * s.outF * 4);
+            // (the plan is built and its workspace released before the layer's own scratch is used: they share `ws`)
+            ws = max3(ws, scratch, 256);
+        } else if (!s.bf16) {
+            const size_t w = mccnn_spatial_conv_fwd_workspace_bytes(m, e, s.fin, s.fout, s.combin);
+            if (w > ws) ws = w;
+            if (flags & 1) saved += al(mccnn_spatial_conv_state_bytes(m, e, s.fin, s.fout, s.combin));
+        }
+    } else {
+        const bool rows_bwd = f.rows_bwd && m > 0;
+        size_t fg_sorted = f.unsorted && rows_bwd ? 0 : al((size_t)n * s.fin * s.elem);  // the gradient rows in grid order
+        size_t sort_again = 0;
+        if (rows_bwd) {
+            int rc = want_plan(1);
+            if (rc) return rc;
+            want_tlist();
+            const size_t w = al(mccnn_spatial_conv_bwd_rows_workspace_bytes(n, e, s.fin)) + al((size_t)g->plan[1].scratch_rows * s.fin * 4);
+            ws = max3(ws, w + fg_sorted, 256);
+        } else {
+            if (f.unsorted) sort_again = al((size_t)n * s.fin * s.elem);  // (an out-gradient the row kernel cannot take)
+            size_t tb = 0;
+            if (e > 0 && (!s.combin || ((flags & 2) && s.fin >= 2 && s.fin <= 4))) {
+                want_tlist();
+                tb = al(mccnn_transpose_neighbors_workspace_bytes(n, e));
+            }
+            const size_t w = al(mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, s.fin, s.fout, s.combin));
+            ws = max3(ws, (w > tb ? w : tb) + fg_sorted + sort_again, 256);
+        }
+    }
+    *need_mask = mask;
+    *ws_bytes = (long long)(ws + 512);
+    *saved_bytes = (long long)saved;
+    return 0;
+}
+
+int mccnn_conv_forward(mccnn_geometry_t* g, const void* feats, int num_in_feats, int num_out_feats, int combin, int avg,
+                       int bf16, int flags, const float* w1, const float* b1, const float* w2, const float* b2,
+                       const float* w3, const float* b3, void* out, void* saved, size_t saved_bytes, void* ws,
+                       size_t ws_bytes, mccnn_stream_t stream) {
+    if (!g || !g->built || !feats || !out || !ws) return MCCNN_E_BADARG;
+    Shape s;
+    if (!make_shape(s, num_in_feats, num_out_feats, combin, bf16)) return MCCNN_E_SHAPE;
+    const int e = wait_edges(g, -1);
+    if (e < 0) return MCCNN_E_BADARG;
+    if (e > g->e_cap) return MCCNN_E_CAPACITY;
+    const int n = g->n, m = g->m;
+    const mccnn_geometry* go = grid_owner(g);
+    const FwdMode f = fwd_mode(g, s, feats, e);
+    avg = avg ? 1 : 0;
+    // sort_features (MCConvModuleSrc:35-36): sorted[new_idx[i]] = feats[i]
+    const void* rows_in = feats;
+    char* sv = (char*)saved;
+    size_t sv_off = 0;
+    if (!f.unsorted) {
+        const size_t b = al((size_t)n * s.fin * s.elem);
+        if (!saved || saved_bytes < b) return MCCNN_E_WORKSPACE;
+        int rc = mccnn_permute_scatter((const float*)feats, go->new_idx, n, s.words, (float*)sv, n, 0, stream);
+        if (rc) return rc;
+        rows_in = sv;
+        sv_off = b;
+    }
+    if (f.rows_fwd) {
+        int rc = ensure_plan(g, 0, e, avg, ws, ws_bytes, stream);
+        if (rc) return rc;
+        const Plan& p = g->plan[0];
+        if (ws_bytes < (size_t)p.scratch_rows * s.outF * 4) return MCCNN_E_WORKSPACE;
+        char* pb = p.buf;
+        return mccnn_spatial_conv_fwd_rows(go->s_pts, rows_in, go->s_bids, g->pdfs, g->centres, g->start, g->packed, g->mn, g->mx,
+                                           w1, b1, w2, b2, w3, b3, n, m, e, s.fin, g->B, g->radius, g->scale_inv, avg, s.bf16,
+                                           (const int*)(pb + p.off[0]), (const int*)(pb + p.off[1]), (const int*)(pb + p.off[2]),
+                                           (const int*)(pb + p.off[3]), pb + p.off[5], (const int*)(pb + p.off[4]), out,
+                                           (float*)ws, f.unsorted ? go->inv_idx : nullptr, stream);
+    }
+    if (s.bf16)
+        return mccnn_spatial_conv_fwd_bf16(go->s_pts, rows_in, go->s_bids, g->pdfs, g->centres, g->start, g->packed, g->mn, g->mx, w1,
+                                           b1, w2, b2, w3, b3, n, m, e, s.fin, g->B, g->radius, g->scale_inv, avg, out, ws, ws_bytes,
+                                           stream);
+    void* state = nullptr;
+    if (flags & 1) {
+        const size_t sb = mccnn_spatial_conv_state_bytes(m, e, s.fin, s.fout, s.combin);
+        if (sb) {
+            if (!saved || saved_bytes < sv_off + sb) return MCCNN_E_WORKSPACE;
+            state = sv + sv_off;
+        }
+    }
+    return mccnn_spatial_conv_fwd(go->s_pts, (const float*)rows_in, go->s_bids, g->pdfs, g->centres, g->start, g->packed, g->mn,
+                                  g->mx, w1, b1, w2, b2, w3, b3, n, m, e, s.fin, s.fout, s.combin, g->B, g->radius, g->scale_inv,
+                                  avg, (float*)out, state, ws, ws_bytes, stream);
+}
+
+int mccnn_conv_backward(mccnn_geometry_t* g, const void* feats, const void* saved, size_t saved_bytes, const void* out_grad,
+                        int num_in_feats, int num_out_feats, int combin, int avg, int bf16, int flags, const float* w1,
+                        const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                        void* feat_grad, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, void* ws,
+                        size_t ws_bytes, mccnn_stream_t stream) {
+    if (!g || !g->built || !feats || !out_grad || !feat_grad || !ws) return MCCNN_E_BADARG;
+    Shape s;
+    if (!make_shape(s, num_in_feats, num_out_feats, combin, bf16)) return MCCNN_E_SHAPE;
+    const int e = wait_edges(g, -1);
+    if (e < 0) return MCCNN_E_BADARG;
+    if (e > g->e_cap) return MCCNN_E_CAPACITY;
+    const int n = g->n, m = g->m;
+    const mccnn_geometry* go = grid_owner(g);
+    const FwdMode f = fwd_mode(g, s, feats, e);
+    avg = avg ? 1 : 0;
+    const size_t rows_b = al((size_t)n * s.fin * s.elem);
+    const char* sv = (const char*)saved;
+    size_t sv_off = 0;
+    const void* rows_in = feats;  // unsorted mode: the rows of the unsorted points
+    if (!f.unsorted) {
+        if (!saved || saved_bytes < rows_b) return MCCNN_E_WORKSPACE;
+        rows_in = sv;
+        sv_off = rows_b;
+    }
+    Arena a(ws, ws_bytes);
+    const bool rows_bwd = f.rows_bwd && m > 0 && ((((uintptr_t)out_grad) & 15) == 0);
+    int rc;
+    if (rows_bwd) {
+        // ONE sweep over the transposed row plan: feature gradient and the six parameter gradients
+        rc = ensure_plan(g, 1, e, avg, ws, ws_bytes, stream);  // (its workspace is free again when the sweep starts)
+        if (rc) return rc;
+        const Plan& p = g->plan[1];
+        void* fg = feat_grad;
+        if (!f.unsorted) {
+            fg = a.take<char>(rows_b);
+            if (!fg) return MCCNN_E_WORKSPACE;
+        }
+        float* scratch = a.take<float>((size_t)p.scratch_rows * s.fin);
+        const size_t wb = mccnn_spatial_conv_bwd_rows_workspace_bytes(n, e, s.fin);
+        char* w = a.take<char>(wb);
+        if (!scratch || !w) return MCCNN_E_WORKSPACE;
+        char* pb = p.buf;
+        rc = mccnn_spatial_conv_bwd_rows(go->s_pts, rows_in, go->s_bids, g->pdfs, g->centres, g->start, g->packed, g->mn, g->mx, w1,
+                                         b1, w2, b2, w3, b3, out_grad, n, m, e, s.fin, g->B, g->radius, g->scale_inv, avg, s.bf16,
+                                         tl_start(g), (const int*)(pb + p.off[0]), (const int*)(pb + p.off[1]),
+                                         (const int*)(pb + p.off[2]), (const int*)(pb + p.off[3]), pb + p.off[5],
+                                         (const int*)(pb + p.off[4]), fg, scratch, dw1, db1, dw2, db2, dw3, db3,
+                                         f.unsorted ? go->inv_idx : nullptr, w, wb, stream);
+        if (rc) return rc;
+        if (!f.unsorted)  // back into the order the features arrived in: fg_in[i] = fg_sorted[new_idx[i]]
+            return mccnn_permute_gather((const float*)fg, go->new_idx, n, s.words, (float*)feat_grad, stream);
+        return 0;
+    }
+    if (f.unsorted) {  // the streaming kernels want the rows in grid order after all
+        char* sorted = a.take<char>(rows_b);
+        if (!sorted) return MCCNN_E_WORKSPACE;
+        rc = mccnn_permute_scatter((const float*)feats, go->new_idx, n, s.words, (float*)sorted, n, 0, stream);
+        if (rc) return rc;
+        rows_in = sorted;
+    }
+    char* fg = a.take<char>(rows_b);
+    if (!fg) return MCCNN_E_WORKSPACE;
+    const int *st = nullptr, *pt = nullptr;
+    if (e > 0 && (!s.combin || ((flags & 2) && s.fin >= 2 && s.fin <= 4) || (s.combin && s.fin >= 2 && s.fin <= 4 && g->tl_built))) {
+        // depth-wise layers need the transposed list; combin layers with 2..4 input features gather their feature
+        // gradient through it when the caller asks for the deterministic form or the list exists already
+        const size_t tb = mccnn_transpose_neighbors_workspace_bytes(n, e);
+        if (!g->tl_built) {
+            char* tw = a.base + a.off;  // free until the convolution's own scratch is carved out below
+            if (a.cap - a.off < tb) return MCCNN_E_WORKSPACE;
+            rc = ensure_tlist(g, e, tw, a.cap - a.off, stream);
+            if (rc) return rc;
+        }
+        st = tl_start(g);
+        pt = tl_perm(g);
+    }
+    const size_t wb = mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, s.fin, s.fout, s.combin);
+    char* w = a.take<char>(wb);
+    if (!w) return MCCNN_E_WORKSPACE;
+    if (s.bf16) {
+        rc = mccnn_spatial_conv_bwd_bf16(go->s_pts, rows_in, go->s_bids, g->pdfs, g->centres, g->start, g->packed, g->mn, g->mx, w1,
+                                         b1, w2, b2, w3, b3, out_grad, n, m, e, s.fin, g->B, g->radius, g->scale_inv, avg, st, pt,
+                                         fg, dw1, db1, dw2, db2, dw3, db3, w, wb, stream);
+    } else {
+        const void* state = nullptr;
+        if (flags & 1) {
+            const size_t sb = mccnn_spatial_conv_state_bytes(m, e, s.fin, s.fout, s.combin);
+            // (written by the forward call only when IT ran the edge-streaming / factored kernels)
+            if (sb && saved && saved_bytes >= sv_off + sb && !f.unsorted && !f.rows_fwd) state = sv + sv_off;
+        }
+        rc = mccnn_spatial_conv_bwd(go->s_pts, (const float*)rows_in, go->s_bids, g->pdfs, g->centres, g->start, g->packed, g->mn,
+                                    g->mx, w1, b1, w2, b2, w3, b3, (const float*)out_grad, n, m, e, s.fin, s.fout, s.combin, g->B,
+                                    g->radius, g->scale_inv, avg, state, st, pt, (float*)fg, dw1, db1, dw2, db2, dw3, db3, w, wb,
+                                    stream);
+    }
+    if (rc) return rc;
+    return mccnn_permute_gather((const float*)fg, go->new_idx, n, s.words, (float*)feat_grad, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+"""Native step executor (csrc/exec.hip, include/mccnn.h "NATIVE STEP EXECUTOR"): what
+ConvolutionBuilder.create_convolution does around the kernels -- grid, neighbour list, PDFs, feature sort, kernel
+choice, row plans -- behind one library call per convolution GEOMETRY and one per layer and direction.
+
+A step of a network is bound by the host issuing its launches: ~12 us of Python per launch against 3 us for
+the launch itself. This module is the thin remainder: it owns the device buffers the library asks for (the library
+never allocates), the pinned word the edge total arrives in, and the autograd node of a layer.
+"""
+import ctypes as C
+import threading
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_handle
+
+E_CAPACITY = -6
+NEED_PLAN_FWD, NEED_PLAN_TR, NEED_TLIST, NEED_RECORDS = 1, 2, 4, 8
+
+_TLS = threading.local()
+_EDGE_GUESS = {}   # (device, n, m, radius, B, scaleInv) -> capacity to try first
+_EDGE_RATIO = {}   # (device, radius, scaleInv) -> edges per centre of the last search with this radius
+
+
+def _slot():
+    """A pinned int32 the count pass stores the edge total into (device-accessible host memory: no copy is enqueued);
+    pooled per host thread."""
+    pool = getattr(_TLS, "slots", None)
+    if pool is None:
+        pool = _TLS.slots = []
+    if pool:
+        return pool.pop()
+    return torch.empty(1, dtype=torch.int32).pin_memory()
+
+
+def _release_slot(t):
+    pool = getattr(_TLS, "slots", None)
+    if pool is not None and len(pool) < 64:
+        pool.append(t)
+
+
+def _ws(nbytes, device):
+    from .MCConvModule import _ws as pool_ws
+    return pool_ws(nbytes, device)
+
+
+def _capacity_guess(gkey, m):
+    g = _EDGE_GUESS.get(gkey, 0)
+    if g <= 0:
+        ratio = _EDGE_RATIO.get((gkey[0], gkey[3], gkey[5]), 0.0)
+        g = int(ratio * m * 1.25) + 1024 if ratio > 0.0 else 48 * m + 1024  # first search of a radius: a plain guess
+    return g
+
+
+def _remember(gkey, m, e):
+    if len(_EDGE_GUESS) > 256:
+        _EDGE_GUESS.clear()
+    _EDGE_GUESS[gkey] = e + e // 16 + 64
+    if m > 0:
+        _EDGE_RATIO[(gkey[0], gkey[3], gkey[5])] = e / float(m)
+
+
+class Geometry:
+    """One convolution geometry: the grid of the input level at the convolution radius, the neighbour list of the
+    output level's points in it and its PDFs, in ONE device buffer (mccnn_geometry_t). Tensor views of its arrays are
+    made on demand (grid(), neighbors(), pdfs()) -- the layers themselves only hand the handle to the library."""
+
+    def __init__(self):
+        self.handle = None
+        self.buf = None
+        self.slot = None
+        self.keep = None        # the input tensors the library borrowed pointers of
+        self.attached = []      # plan / list buffers handed to the library
+        self.grid_owner = None
+        self.n = self.m = self.nc = self.B = self.e_cap = 0
+        self.e = -1
+        self.gkey = None
+        self.args = None
+
+    def __del__(self):
+        h, self.handle = self.handle, None
+        if h is not None:
+            try:
+                _lib.load().mccnn_geometry_destroy(h)
+            except Exception:
+                pass
+        if self.slot is not None and self.e >= 0:  # (a total that never arrived keeps its word: the kernel may still write it)
+            _release_slot(self.slot)
+
+    # ------------------------------------------------------------------ sizes
+    def edges(self):
+        """E (waits for the count pass of the build)."""
+        if self.e < 0:
+            e = _lib.load().mccnn_geometry_edges(self.handle, -1)
+            if e < 0:
+                raise _lib.MCCNNError("geometry: edge total not available")
+            self.e = e
+            _remember(self.gkey, self.m, e)
+            if e > self.e_cap:
+                self._rebuild(e + e // 16 + 64)
+        return self.e
+
+    def _rebuild(self, capacity):
+        """The neighbour list was longer than the guess: exact repeat (first batch of a shape)."""
+        inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF = self.args
+        _build_into(self, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, capacity,
+                    self.grid_owner)
+        e = _lib.load().mccnn_geometry_edges(self.handle, -1)
+        if e < 0 or e > self.e_cap:
+            raise _lib.MCCNNError("geometry: rebuilt list still does not fit (%d > %d)" % (e, self.e_cap))
+        self.e = e
+
+    # ------------------------------------------------------------------ views (tests, the builder's cache tuples)
+    def _info(self):
+        out = (C.c_longlong * 16)()
+        check(_lib.load().mccnn_geometry_info(self.handle, out), "geometry_info")
+        return list(out)
+
+    def _view(self, owner_buf, addr, nbytes, dtype, shape):
+        off = addr - owner_buf.data_ptr()
+        return owner_buf[off:off + nbytes].view(dtype).view(shape)
+
+    def grid(self):
+        """(sortPts [n,3], sortBatchs [n,1], cellIndexs [B,nc,nc,nc,2], index_new_pos [n], inverse [n])"""
+        i = self._info()
+        ob = (self.grid_owner or self).buf
+        n, nc, B = self.n, self.nc, self.B
+        return (self._view(ob, i[0], n * 12, torch.float32, (n, 3)), self._view(ob, i[1], n * 4, torch.int32, (n, 1)),
+                self._view(ob, i[2], B * nc ** 3 * 8, torch.int32, (B, nc, nc, nc, 2)),
+                self._view(ob, i[3], n * 4, torch.int32, (n,)), self._view(ob, i[4], n * 4, torch.int32, (n,)))
+
+    def neighbors(self):
+        """(startIndexs [m,1], packedNeighs [E,2])"""
+        e = self.edges()
+        i = self._info()
+        return (self._view(self.buf, i[5], self.m * 4, torch.int32, (self.m, 1)),
+                self._view(self.buf, i[6], e * 8, torch.int32, (e, 2)))
+
+    def pdfs(self):
+        e = self.edges()
+        i = self._info()
+        return self._view(self.buf, i[7], e * 4, torch.float32, (e, 1))
+
+
+def _build_into(g, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, capacity, grid_from):
+    lib = _lib.load()
+    n, m = inPts.shape[0], centres.shape[0]
+    dev = inPts.device
+    with_grid = 0 if grid_from is not None else 1
+    nbytes = lib.mccnn_geometry_bytes(n, m, B, nc, capacity, with_grid)
+    if nbytes == 0:
+        raise _lib.MCCNNError("geometry: batch_size * num_cells^3 does not fit 32-bit keys")
+    if g.handle is None:
+        g.handle = lib.mccnn_geometry_create()
+        if not g.handle:
+            raise MemoryError("mccnn_geometry_create")
+    if g.slot is None:
+        g.slot = _slot()
+    g.buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    g.attached = []
+    g.keep = (inPts, inBids, centres, cbids, mn, mx)
+    g.grid_owner = grid_from
+    g.n, g.m, g.nc, g.B, g.e_cap, g.e = n, m, nc, B, capacity, -1
+    g.args = (inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF)
+    check(lib.mccnn_geometry_build(g.handle, ptr(inPts), ptr(inBids), n, ptr(centres), ptr(cbids), m, ptr(mn), ptr(mx), B, nc,
+                                   float(radius), int(bool(scaleInv)), float(window), int(bool(usePDF)), capacity,
+                                   grid_from.handle if grid_from is not None else None, g.buf.data_ptr(), nbytes,
+                                   g.slot.data_ptr(), stream_handle()), "geometry_build")
+
+
+def build_geometry(inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, grid_from=None):
+    """Enqueues grid + search + KDE of one convolution geometry on the current stream; no host wait. nc: cells per axis
+    (MCConvModule._num_cells). grid_from: a Geometry over the same points / radius whose grid is shared."""
+    n, m = inPts.shape[0], centres.shape[0]
+    gkey = (inPts.device.index, n, m, float(radius), int(B), bool(scaleInv))
+    g = Geometry()
+    g.gkey = gkey
+    if grid_from is not None and grid_from.grid_owner is not None:
+        grid_from = grid_from.grid_owner
+    _build_into(g, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF,
+                _capacity_guess(gkey, m), grid_from)
+    return g
+
+
+_I0 = C.c_int
+_LL = C.c_longlong
+
+
+def _prepare(geo, feats, fin, fout, combin, bf16, backward, flags):
+    """-> (ws bytes, saved bytes); attaches whatever the geometry lacks for this call."""
+    lib = _lib.load()
+    mask, edges = _I0(0), _I0(0)
+    need = (_LL * 4)()
+    wsb, svb = _LL(0), _LL(0)
+    rc = lib.mccnn_conv_prepare(geo.handle, feats.data_ptr(), fin, fout, combin, bf16, backward, flags, C.byref(mask), need,
+                                C.byref(wsb), C.byref(svb), C.byref(edges))
+    if rc == E_CAPACITY:
+        geo.edges()  # rebuilds with the exact size
+        rc = lib.mccnn_conv_prepare(geo.handle, feats.data_ptr(), fin, fout, combin, bf16, backward, flags, C.byref(mask),
+                                    need, C.byref(wsb), C.byref(svb), C.byref(edges))
+    check(rc, "conv_prepare")
+    if geo.e < 0:
+        geo.e = edges.value
+        _remember(geo.gkey, geo.m, geo.e)
+    if mask.value:
+        for k, bit in enumerate((NEED_PLAN_FWD, NEED_PLAN_TR, NEED_TLIST, NEED_RECORDS)):
+            if mask.value & bit:
+                t = torch.empty(max(int(need[k]), 256), dtype=torch.uint8, device=feats.device)
+                check(lib.mccnn_geometry_attach(geo.handle, bit, t.data_ptr(), t.numel()), "geometry_attach")
+                geo.attached.append(t)
+    return wsb.value, svb.value
+
+
+class _Conv(torch.autograd.Function):
+    """SpatialConv with sort_features folded in (MCConvModuleSrc:35-45,70-81) over a native Geometry."""
+
+    @staticmethod
+    def forward(ctx, feats, w1, b1, w2, b2, w3, b3, geo, fout, combin, avg, deterministic):
+        lib = _lib.load()
+        fin = feats.shape[1]
+        bf16 = 1 if feats.dtype == torch.bfloat16 else 0
+        need_grad = any(t.requires_grad for t in (feats, w1, b1, w2, b2, w3, b3))
+        flags = (1 if need_grad else 0) | (2 if deterministic else 0)
+        combin = 1 if combin else 0
+        wsb, svb = _prepare(geo, feats, fin, fout, combin, bf16, 0, flags)
+        dev = feats.device
+        out = torch.empty((geo.m, fout if combin else fin), dtype=feats.dtype, device=dev)
+        saved = torch.empty(svb, dtype=torch.uint8, device=dev) if svb else None
+        ws = _ws(wsb, dev)
+        check(lib.mccnn_conv_forward(geo.handle, feats.data_ptr(), fin, fout, combin, int(bool(avg)), bf16, flags,
+                                     w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(),
+                                     out.data_ptr(), ptr(saved), svb, ws.data_ptr(), ws.numel(), stream_handle()),
+              "conv_forward")
+        if need_grad:
+            ctx.save_for_backward(feats, w1, b1, w2, b2, w3, b3)
+            ctx.saved_buf = saved
+            ctx.geo = geo
+            ctx.attrs = (fin, fout, combin, int(bool(avg)), bf16, flags)
+        return out
+
+    @staticmethod
+    def backward(ctx, outGrad):
+        feats, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
+        geo, saved = ctx.geo, ctx.saved_buf
+        fin, fout, combin, avg, bf16, flags = ctx.attrs
+        lib = _lib.load()
+        og = outGrad if outGrad.is_contiguous() else outGrad.contiguous()
+        if og.dtype != feats.dtype:
+            og = og.to(feats.dtype)
+        wsb, _ = _prepare(geo, feats, fin, fout, combin, bf16, 1, flags)
+        dev = feats.device
+        fg = torch.empty_like(feats)
+        # the six MLP gradients: consecutive slices of ONE buffer in the order the builder creates the variables (a
+        # data-parallel step all-reduces that buffer as it is, dist.GradBucket)
+        sizes = [w1.numel(), b1.numel(), w2.numel(), b2.numel(), w3.numel(), b3.numel()]
+        gflat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        dw1, db1, dw2, db2, dw3, db3 = gflat.split(sizes)
+        ws = _ws(wsb, dev)
+        check(lib.mccnn_conv_backward(geo.handle, feats.data_ptr(), ptr(saved), saved.numel() if saved is not None else 0,
+                                      og.data_ptr(), fin, fout, combin, avg, bf16, flags, w1.data_ptr(), b1.data_ptr(),
+                                      w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), fg.data_ptr(), dw1.data_ptr(),
+                                      db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), dw3.data_ptr(), db3.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), stream_handle()), "conv_backward")
+        return (fg, dw1.view_as(w1), db1.view_as(b1), dw2.view_as(w2), db2.view_as(b2), dw3.view_as(w3), db3.view_as(b3),
+                None, None, None, None, None)
+
+
+def conv(geo, feats, w1, b1, w2, b2, w3, b3, numOutFeatures, combin, avg, deterministic=False):
+    """One MC convolution over `geo`: feats are the rows of the UNSORTED input points ([n, Fin] f32, or bf16 for
+    depth-wise layers); the kernel-MLP tensors in any shape over the reference's flat layout."""
+    return _Conv.apply(feats, w1, b1, w2, b2, w3, b3, geo, numOutFeatures, combin, avg, deterministic)
