@@ -76,6 +76,33 @@ def _storage_baseline():
 _STORAGE_BASE = None
 
 
+class _LazyEntry:
+    """A cache entry of the native path (mccnn_amd.native.Geometry): behaves like the tuple / tensor the reference's
+    cache holds (MCConvBuilder.py:349-391), but the tensor views are only made when somebody looks -- the layers
+    themselves hand the geometry's handle to the library."""
+    __slots__ = ("geo", "_val", "_make")
+
+    def __init__(self, geo, make):
+        self.geo, self._val, self._make = geo, None, make
+
+    def value(self):
+        if self._val is None:
+            self._val = self._make()
+        return self._val
+
+    def __getitem__(self, i):
+        return self.value()[i]
+
+    def __iter__(self):
+        return iter(self.value())
+
+    def __len__(self):
+        return len(self.value())
+
+    def __getattr__(self, name):  # (cachePDFs_ entries are tensors: .shape, .data_ptr() ...)
+        return getattr(self.value(), name)
+
+
 class PointHierarchy(torch.nn.Module):
     """Point hierarchy built by successive Poisson-disk sampling (MCConvBuilder.py:24-131).
 
@@ -176,15 +203,21 @@ class ConvolutionBuilder(torch.nn.Module):
     work on the builder as on any module; `forward` is create_convolution."""
 
     def __init__(self, multiFeatureConvs=False, KDEWindow=0.25, relativeRadius=True, usePDF=True, useAVG=True,
-                 decayLossCollection='weight_decay_loss', device=None, ops=None, fuseSort=None):
+                 decayLossCollection='weight_decay_loss', device=None, ops=None, fuseSort=None, native=None):
         super().__init__()
         self.ops_ = _Ops(ops)
         # extension: grids from the points alone (MCConvModule.build_grid), feature rows sorted inside the convolution's
         # node (spatial_conv(sortIndex=)) -- fewer op calls and graph nodes per convolution, same kernels and results
         self.fuseSort_ = (os.environ.get("MCCNN_FUSE_SORT", "1") != "0") if fuseSort is None else bool(fuseSort)
+        # extension: the whole geometry of a convolution (grid, search, KDE) in one library call and the layer itself in
+        # one per direction (mccnn_amd.native, csrc/exec.hip) -- a step is bound by the host's work per launch
+        self.native_ = (os.environ.get("MCCNN_NATIVE", "1") != "0") if native is None else bool(native)
         self.cacheGrids_ = {}
         self.cacheNeighs_ = {}
         self.cachePDFs_ = {}
+        self.cacheGeo_ = {}         # keyPDF -> native.Geometry; keyGrid -> the Geometry that owns the grid
+        self.cacheGeoGrid_ = {}
+        self.layers_ = {}           # convName -> (spec, variables): the fast path of a repeated create_convolution
         self.multiFeatureConvs_ = multiFeatureConvs
         self.KDEWindow_ = KDEWindow
         self.relativeRadius_ = relativeRadius
@@ -236,7 +269,9 @@ class ConvolutionBuilder(torch.nn.Module):
 
     def _add_to_collection(self, name, p):
         lst = self.collections_.setdefault(name, [])
-        if not any(q is p for q in lst):
+        seen = self.__dict__.setdefault("_collection_ids", {}).setdefault(name, set())
+        if id(p) not in seen:
+            seen.add(id(p))
             lst.append(p)
 
     # ------------------------------------------------------------------ caches
@@ -256,6 +291,8 @@ class ConvolutionBuilder(torch.nn.Module):
         self.cacheGrids_ = {}
         self.cacheNeighs_ = {}
         self.cachePDFs_ = {}
+        self.cacheGeo_ = {}
+        self.cacheGeoGrid_ = {}
         pf, self.prefetched_ = self.prefetched_, None
         if pf is not None:
             grids, neighs, pdfs, event = pf
@@ -441,6 +478,98 @@ class ConvolutionBuilder(torch.nn.Module):
         if self.opTrace_ is not None:
             self.opTrace_.append(rec)
 
+    def __layer_variables__(self, convName, inNumFeatures, currNumOutFeatures, currMultiFeatureConv, dev):
+        """The six kernel-MLP variables of `convName` (MCConvBuilder.py:394-419), created on first use."""
+        blockSize = self.ops_.get_block_size()
+        numOutNeurons = inNumFeatures * currNumOutFeatures if currMultiFeatureConv else inNumFeatures
+        numBlocks = int(numOutNeurons / blockSize)
+        if numOutNeurons % blockSize != 0:
+            numBlocks = numBlocks + 1
+        zeros = lambda t: t.zero_()
+        nn = blockSize * numBlocks
+        weights = self._get_variable(convName + '_weights', (3, nn), dev, lambda t: _fan_avg_uniform_(t, 3, nn))
+        self._add_to_collection(self.decayLossCollection_, weights)
+        biases = self._get_variable(convName + '_biases', (nn,), dev, zeros)
+        # TF fans for a rank-3 variable [numBlocks, bs, bs]: receptive field = numBlocks, fan_in = fan_out = bs*numBlocks
+        weights2v = self._get_variable(convName + '_weights2', (numBlocks, blockSize, blockSize), dev,
+                                       lambda t: _fan_avg_uniform_(t, numBlocks * blockSize, numBlocks * blockSize))
+        self._add_to_collection(self.decayLossCollection_, weights2v)
+        biases2v = self._get_variable(convName + '_biases2', (numBlocks, blockSize), dev, zeros)
+        weights3v = self._get_variable(convName + '_weights3', (numBlocks, blockSize, blockSize), dev,
+                                       lambda t: _fan_avg_uniform_(t, numBlocks * blockSize, numBlocks * blockSize))
+        self._add_to_collection(self.decayLossCollection_, weights3v)
+        biases3v = self._get_variable(convName + '_biases3', (numBlocks, blockSize), dev, zeros)
+        return weights, biases, weights2v, biases2v, weights3v, biases3v, nn
+
+    def __native_convolution__(self, convName, inPH, inLevel, inFeatures, inNumFeatures, convRadius, outPH, outLevel,
+                               multiFeatureConv, numOutFeatures, KDEWindow, relativeRadius, usePDF, useAVG, keyGrid,
+                               keyNeighs, keyPDF):
+        """create_convolution on the native step executor (mccnn_amd.native): the geometry of (keyGrid, keyNeighs, keyPDF)
+        is ONE library call (no host wait), the layer one call per direction with the feature sort inside. Returns None
+        when this call has to take the op-by-op path: a cache entry of that path exists already (prefetch_geometry), the
+        level is empty, or the features are not rows the library reads in place."""
+        from . import native as _native
+        from . import MCConvModule as _hip_ops
+        geo = self.cacheGeo_.get(keyPDF)
+        if geo is None:
+            if keyGrid in self.cacheGrids_ and keyGrid not in self.cacheGeoGrid_:
+                return None   # the op-by-op path (or a prefetch) owns this grid
+            if keyNeighs in self.cacheNeighs_ or keyPDF in self.cachePDFs_:
+                return None
+            inPts, inBids = inPH.points_[inLevel], inPH.batchIds_[inLevel]
+            centres, cBids = outPH.points_[outLevel], outPH.batchIds_[outLevel]
+            if inPts.shape[0] == 0 or centres.shape[0] == 0 or int(_hip_ops.PDF_MODE) != 1:
+                return None
+            for t, dt in ((inPts, torch.float32), (centres, torch.float32), (inBids, torch.int32), (cBids, torch.int32)):
+                if t.dtype != dt or not t.is_contiguous() or not t.is_cuda:
+                    return None
+            mn, mx, B = inPH.aabbMin_, inPH.aabbMax_, inPH.batchSize_
+            nc = _hip_ops._num_cells(mn, mx, B, convRadius, relativeRadius)
+            owner = self.cacheGeoGrid_.get(keyGrid)
+            geo = _native.build_geometry(inPts, inBids, centres, cBids, mn, mx, B, nc, convRadius, relativeRadius, KDEWindow,
+                                         usePDF, owner)
+            geo.uses = 0
+            self.cacheGeo_[keyPDF] = geo
+            if owner is None:
+                self.cacheGeoGrid_[keyGrid] = geo
+                self.cacheGrids_[keyGrid] = _LazyEntry(geo, geo.grid)
+                self._trace("sort_points_step1", keyGrid)
+                self._trace("sort_points_step2", keyGrid)
+            else:
+                self._trace("sort_features", keyGrid)
+            self.cacheNeighs_[keyNeighs] = _LazyEntry(geo, geo.neighbors)
+            self.cachePDFs_[keyPDF] = _LazyEntry(geo, geo.pdfs)
+            self._trace("find_neighbors", keyNeighs)
+            if usePDF:
+                self._trace("compute_pdf", keyPDF)
+        else:
+            self._trace("sort_features", keyGrid)
+        feats = inFeatures
+        if (not feats.is_cuda or feats.dim() != 2 or feats.shape[0] != geo.n or feats.shape[1] != inNumFeatures
+                or feats.dtype not in (torch.float32, torch.bfloat16)):
+            return None
+        if feats.dtype == torch.bfloat16 and (multiFeatureConv or inNumFeatures % 8 != 0):
+            return None
+        if not feats.is_contiguous():
+            feats = feats.contiguous()
+        # the op's shape rules (spatial_conv.cc:290-296)
+        neurons = inNumFeatures * numOutFeatures if multiFeatureConv else inNumFeatures
+        if ((neurons + 7) // 8 * 8) % inNumFeatures != 0:
+            raise _hip_ops.InvalidArgumentError("SpatialConvOp expects a number of output neurons multiple of the number of features.")
+        if not multiFeatureConv and inNumFeatures % 8 != 0:
+            raise _hip_ops.InvalidArgumentError("SpatialConvOp expects the same number of features in the input and the output")
+        lay = self.layers_.get(convName)
+        spec = (inNumFeatures, numOutFeatures, bool(multiFeatureConv))
+        if lay is None or lay[0] != spec:
+            dev = self.device_ or inFeatures.device
+            v = self.__layer_variables__(convName, inNumFeatures, numOutFeatures, multiFeatureConv, dev)
+            lay = self.layers_[convName] = (spec, v)
+        weights, biases, weights2v, biases2v, weights3v, biases3v, nn = lay[1]
+        self._trace("spatial_conv", convName, (3, nn), numOutFeatures, bool(multiFeatureConv))
+        geo.uses += 1
+        return _native.conv(geo, feats, weights, biases, weights2v, biases2v, weights3v, biases3v, numOutFeatures,
+                            bool(multiFeatureConv), bool(useAVG))
+
     # ------------------------------------------------------------------ create_convolution
     def create_convolution(self, convName, inPointHierarchy, inPointLevel, inFeatures, inNumFeatures, convRadius,
                            outPointHierarchy=None, outPointLevel=None, multiFeatureConv=None, outNumFeatures=None,
@@ -467,6 +596,16 @@ class ConvolutionBuilder(torch.nn.Module):
         _log("Convolution: %s (KDE: %s | MF: %s | Rel: %s | PDF: %s)" % (convName, currKDEWindow,
                                                                        currMultiFeatureConv, currRelativeRadius,
                                                                        currUsePDF))
+
+        inPts = inPointHierarchy.points_[inPointLevel]
+        if (self.native_ and self.fuseSort_ and getattr(self.ops_, "_ops", 0) is None and inPts.is_cuda
+                and not inPts.requires_grad):
+            out = self.__native_convolution__(convName, inPointHierarchy, inPointLevel, inFeatures, inNumFeatures, convRadius,
+                                              currOutPointHierarchy, currOutPointLevel, currMultiFeatureConv,
+                                              currNumOutFeatures, currKDEWindow, currRelativeRadius, currUsePDF, currUseAVG,
+                                              keyGrid, keyNeighs, keyPDF)
+            if out is not None:
+                return out
 
         # grid (MCConvBuilder.py:349-363)
         # HIP op surface, points that carry no gradient: the grid is built from the points alone (one library call) and
@@ -548,25 +687,9 @@ class ConvolutionBuilder(torch.nn.Module):
 
         # variables (MCConvBuilder.py:394-419)
         blockSize = self.ops_.get_block_size()
-        numOutNeurons = inNumFeatures * currNumOutFeatures if currMultiFeatureConv else inNumFeatures
-        numBlocks = int(numOutNeurons / blockSize)
-        if numOutNeurons % blockSize != 0:
-            numBlocks = numBlocks + 1
         dev = self.device_ or inFeatures.device
-        zeros = lambda t: t.zero_()
-        nn = blockSize * numBlocks
-        weights = self._get_variable(convName + '_weights', (3, nn), dev, lambda t: _fan_avg_uniform_(t, 3, nn))
-        self._add_to_collection(self.decayLossCollection_, weights)
-        biases = self._get_variable(convName + '_biases', (nn,), dev, zeros)
-        # TF fans for a rank-3 variable [numBlocks, bs, bs]: receptive field = numBlocks, fan_in = fan_out = bs*numBlocks
-        weights2v = self._get_variable(convName + '_weights2', (numBlocks, blockSize, blockSize), dev,
-                                       lambda t: _fan_avg_uniform_(t, numBlocks * blockSize, numBlocks * blockSize))
-        self._add_to_collection(self.decayLossCollection_, weights2v)
-        biases2v = self._get_variable(convName + '_biases2', (numBlocks, blockSize), dev, zeros)
-        weights3v = self._get_variable(convName + '_weights3', (numBlocks, blockSize, blockSize), dev,
-                                       lambda t: _fan_avg_uniform_(t, numBlocks * blockSize, numBlocks * blockSize))
-        self._add_to_collection(self.decayLossCollection_, weights3v)
-        biases3v = self._get_variable(convName + '_biases3', (numBlocks, blockSize), dev, zeros)
+        weights, biases, weights2v, biases2v, weights3v, biases3v, nn = self.__layer_variables__(
+            convName, inNumFeatures, currNumOutFeatures, currMultiFeatureConv, dev)
 
         self._trace("spatial_conv", convName, (3, nn), currNumOutFeatures, bool(currMultiFeatureConv))
         if sortIndex is None:

@@ -1135,6 +1135,9 @@ class _SpatialConv(torch.autograd.Function):
             n, m, e, fin = pts.shape[0], smp.shape[0], pdfs.shape[0], feats.shape[1]
             _req(feats.dim() == 2 and feats.shape[0] == n,
                  op + " expects as feature inputs the following dimensions (numPoints, numFeatures)")
+            # the two shape rules that depend on the CALLER's layer shape (spatial_conv.cc:290-296)
+            _req(w3.shape[1] % fin == 0, op + " expects a number of output neurons multiple of the number of features.")
+            _req(combin or w3.shape[1] == fin, op + " expects the same number of features in the input and the output")
         else:
             n, m, e, fin = _conv_checks(op, pts, feats, bids, pdfs, smp, st, pk, mn, mx, w1, b1, w2, b2, w3, b3,
                                         numOutFeatures, combin, batchSize, radius)

@@ -334,7 +334,9 @@ __global__ __launch_bounds__(256) void conv_stream(ConvArgs a, float* __restrict
                         reinterpret_cast<uint4*>(out16 + (size_t)ci * outF)[q] = f32x8_to_bf16(c);
                     } else {
                     float* dst = orow + q * 8;
-                    if (vecOut) {
+                    // (a block whose last neurons are padding -- depth-wise rows of 4 features, Fout % 8 == 4 -- must
+                    // not store its 8 lanes: the padded half would land in the NEXT row)
+                    if (vecOut && q * 8 + 8 <= a.neuronsOut) {
                         reinterpret_cast<float4*>(dst)[0] = make_float4(c[0], c[1], c[2], c[3]);
                         reinterpret_cast<float4*>(dst)[1] = make_float4(c[4], c[5], c[6], c[7]);
                     } else {

@@ -77,6 +77,7 @@ class Geometry:
         self.e = -1
         self.gkey = None
         self.args = None
+        self.uses = 0           # layers convolved over this geometry so far (the builder counts)
 
     def __del__(self):
         h, self.handle = self.handle, None
@@ -244,6 +245,11 @@ class _Conv(torch.autograd.Function):
         feats, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
         geo, saved = ctx.geo, ctx.saved_buf
         fin, fout, combin, avg, bf16, flags = ctx.attrs
+        if geo.uses > 1:
+            # several layers share this neighbour list: its transposed form is built once and the feature gradient of
+            # combin layers with 2..4 input features is gathered through it in a fixed order (bit-reproducible) instead
+            # of added with float atomics; a bare single call keeps the atomics (the list would cost more than they do)
+            flags |= 2
         lib = _lib.load()
         og = outGrad if outGrad.is_contiguous() else outGrad.contiguous()
         if og.dtype != feats.dtype:

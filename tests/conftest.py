@@ -19,6 +19,13 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def oracle_omp():
+    """The OpenMP build of the oracle: identical integer outputs, parameter gradients summed in double."""
+    from oracle.oracle import Oracle
+    return Oracle(omp=True)
+
+
+@pytest.fixture(scope="session")
 def mc():
     """The product op surface; importing it on a box without the built HIP library must fail loudly."""
     import torch

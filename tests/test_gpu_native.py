@@ -1,0 +1,195 @@
+"""The native step executor (csrc/exec.hip, mccnn_amd/native.py: one library call per convolution geometry, one per layer
+and direction) against the op-by-op chain of the same builder and against the oracle: same integer outputs bit for bit,
+float outputs within the feature-path tolerance (they are the same kernels; only the row order of a plan may differ)."""
+import numpy as np
+import pytest
+
+from tests.helpers import make_cloud, make_room
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def _t(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def _close(a, b, tol, what):
+    a, b = a.detach().float().cpu().numpy().astype(np.float64), b.detach().float().cpu().numpy().astype(np.float64)
+    assert a.shape == b.shape, what
+    scale = max(np.abs(b).max(), 1e-30)
+    assert np.abs(a - b).max() <= tol * scale, (what, np.abs(a - b).max() / scale)
+    # per element, with an absolute floor (values that cancel to ~0 carry the rounding noise of the largest terms)
+    assert np.all(np.abs(a - b) <= tol * np.abs(b) + 100 * tol * 1e-2 * scale), what
+
+
+LAYERS = [  # name, lin, lout, fin, fout, combin, radius, bf16
+    ("Conv_f1", 0, 0, 1, 16, True, 0.12, False),
+    ("Conv_3to8", 0, 0, 3, 8, True, 0.12, False),
+    ("Conv_3to8_b", 0, 0, 3, 8, True, 0.12, False),    # second combin layer on the same list: deterministic feature gradient
+    ("Conv_dw", 0, 0, 16, 16, False, 0.12, False),
+    ("Pool_dw", 0, 1, 16, 16, False, 0.2, False),       # another output level: new list, own grid
+    ("Pool_f1", 0, 1, 1, 8, True, 0.12, False),         # same grid as Conv_* (radius 0.12), another list: grid shared
+    ("Conv_l1", 1, 1, 32, 32, False, 0.3, False),
+    ("Up_dw", 1, 0, 16, 16, False, 0.3, False),         # same grid as Conv_l1, centres of level 0
+    ("Conv_bf16", 0, 0, 16, 16, False, 0.12, True),
+    ("Conv_2to5", 0, 0, 2, 5, True, 0.12, False),       # combin with padded neurons (10 -> 16)
+]
+
+
+def _run(mc, native, pts, bids, B, relative, feats, ogs, state=None, radius_scale=1.0):
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    P, Bi = _t(pts), _t(bids)
+    F0 = torch.ones((len(pts), 1), dtype=torch.float32, device="cuda")
+    ph = PointHierarchy(P, F0, Bi, [0.1 * radius_scale], "PH", B, relative)
+    torch.manual_seed(99)
+    cb = ConvolutionBuilder(KDEWindow=0.25, relativeRadius=relative, native=native)
+    if state is not None:
+        cb.load_state_dict(state)
+    cb.reset()
+    outs, fts = [], []
+    for (name, lin, lout, fin, fout, combin, radius, bf16) in LAYERS:
+        n = ph.points_[lin].shape[0]
+        f = feats.setdefault(name, (2 * torch.rand((n, fin), device="cuda") - 1))
+        if bf16:
+            f = f.to(torch.bfloat16)
+        f = f.detach().clone().requires_grad_(True)
+        fts.append(f)
+        outs.append(cb.create_convolution(name, ph, lin, f, fin, radius * radius_scale, ph, lout, combin, fout))
+    for o, (name, *_rest) in zip(outs, LAYERS):
+        ogs.setdefault(name, (2 * torch.rand(o.shape, device="cuda") - 1))
+    params = list(cb.parameters())
+    grads = torch.autograd.grad(outs, fts + params, [ogs[l[0]].to(o.dtype) for l, o in zip(LAYERS, outs)])
+    torch.cuda.synchronize()
+    return cb, ph, outs, grads, [n_ for n_, _ in cb.named_parameters()]
+
+
+@pytest.mark.parametrize("relative", [True, False], ids=["relative", "absolute"])
+def test_native_executor_equals_the_op_chain(mc, relative):
+    import torch
+    pts, bids = make_cloud(3000, 3, 5, "clustered", True)
+    feats, ogs = {}, {}
+    scale = 1.0 if relative else 0.6
+    cb0, ph0, outs0, grads0, names0 = _run(mc, False, pts, bids, 3, relative, feats, ogs, radius_scale=scale)
+    assert not cb0.cacheGeo_
+    sd = {k: v.detach().clone() for k, v in cb0.state_dict().items()}
+    cb1, ph1, outs1, grads1, names1 = _run(mc, True, pts, bids, 3, relative, feats, ogs, state=sd, radius_scale=scale)
+    assert len(cb1.cacheGeo_) == 5 and len(cb1.cacheGeoGrid_) == 3   # five lists over three grids
+    assert names0 == names1
+    assert list(cb0.cacheGrids_) == list(cb1.cacheGrids_) and list(cb0.cacheNeighs_) == list(cb1.cacheNeighs_)
+    assert list(cb0.cachePDFs_) == list(cb1.cachePDFs_)
+    # the geometry: same grids, lists and PDFs as the op chain's cache entries
+    for k in cb0.cacheGrids_:
+        for a, b in zip(cb0.cacheGrids_[k][:4], cb1.cacheGrids_[k][:4]):
+            assert torch.equal(a.reshape(-1), b.reshape(-1)), k
+    for k in cb0.cacheNeighs_:
+        (s0, p0), (s1, p1) = cb0.cacheNeighs_[k], cb1.cacheNeighs_[k]
+        assert torch.equal(s0, s1) and torch.equal(p0, p1), k
+    for k in cb0.cachePDFs_:
+        assert torch.equal(cb0.cachePDFs_[k], cb1.cachePDFs_[k].value()), k
+    for l, a, b in zip(LAYERS, outs0, outs1):
+        _close(b, a, 2e-5 if not l[7] else 1e-2, l[0])
+    for i, (a, b) in enumerate(zip(grads0, grads1)):
+        what = LAYERS[i][0] + ":featGrad" if i < len(LAYERS) else names0[i - len(LAYERS)]
+        bf = i < len(LAYERS) and LAYERS[i][7]
+        _close(b, a, 2e-5 if not bf else 1e-2, what)
+
+
+def test_native_capacity_overflow_and_changing_batches(mc, oracle):
+    """First batch of a shape: the neighbour list is sized by a plain guess; a list that does not fit is rebuilt with
+    the exact size (dense cloud: ~200 neighbours per point against the guess of 48). Later batches of other sizes reuse
+    the edges-per-centre ratio. Every batch is checked against the oracle's list."""
+    import torch
+    from mccnn_amd import native
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    native._EDGE_GUESS.clear()
+    native._EDGE_RATIO.clear()
+    cb = ConvolutionBuilder(KDEWindow=0.25, relativeRadius=True, native=True)
+    torch.manual_seed(3)
+    for n_per, seed in ((900, 1), (1100, 2), (500, 3)):
+        pts, bids = make_cloud(n_per, 2, seed, "uniform", False)
+        P, Bi = _t(pts), _t(bids)
+        F = (2 * torch.rand((len(pts), 2), device="cuda") - 1).requires_grad_(True)
+        ph = PointHierarchy(P, F, Bi, [], "PH", 2, True)
+        cb.reset()
+        out = cb.create_convolution("Conv", ph, 0, F, 2, 0.45, outNumFeatures=4, multiFeatureConv=True)
+        out.sum().backward()
+        geo = next(iter(cb.cacheGeo_.values()))
+        mn, mx = oracle.compute_aabb(pts, bids, 2, True)
+        k_, i_ = oracle.sort_points_step1(pts, bids, mn, mx, 2, 0.45, True)
+        sp, sb, _, cl = oracle.sort_points_step2(pts, bids, np.zeros((len(pts), 1), np.float32), k_, i_, mn, mx, 2, 0.45, True)
+        st, pk = oracle.find_neighbors(pts, bids, sp, cl, mn, mx, 0.45, 2, True)
+        gs, gp = cb.cacheNeighs_["PH|0|0.45|True|PH|0"]
+        assert geo.e == len(pk) and geo.e <= geo.e_cap
+        assert np.array_equal(gs.cpu().numpy(), st) and np.array_equal(gp.cpu().numpy(), pk)
+        if seed == 1:
+            assert len(pk) > 48 * len(pts) + 1024   # the first guess could not hold it: the rebuild ran
+    torch.cuda.synchronize()
+
+
+def test_native_room_layers_against_the_oracle(mc, oracle_omp):
+    """The three layer shapes of the headline workload on a 20k-point room through the native executor, against the
+    OpenMP oracle: outputs and all seven gradients."""
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    from tests.helpers import make_mlp, conv_nb
+    pts = make_room(20000, 20180601)
+    bids = np.zeros((len(pts), 1), np.int32)
+    B, R = 1, 0.1
+    P, Bi = _t(pts), _t(bids)
+    orc = oracle_omp
+    mn, mx = orc.compute_aabb(pts, bids, B, False)
+    k_, i_ = orc.sort_points_step1(pts, bids, mn, mx, B, R, False)
+    rng = np.random.default_rng(2)
+    for name, fin, fout, combin in (("1to64", 1, 64, True), ("3to8", 3, 8, True), ("dw64", 64, 64, False)):
+        feats = (2 * rng.random((len(pts), fin)) - 1).astype(np.float32)
+        sp, sb, sf, cl = orc.sort_points_step2(pts, bids, feats, k_, i_, mn, mx, B, R, False)
+        st, pk = orc.find_neighbors(pts, bids, sp, cl, mn, mx, R, B, False)
+        pdf = orc.compute_pdf(sp, sb, mn, mx, st, pk, 0.2, R, B, False)
+        w = make_mlp(conv_nb(fin, fout, combin), 7)
+        outF = fout if combin else fin
+        og = (2 * rng.random((len(pts), outF)) - 1).astype(np.float32)
+        args = (sp, sf, sb, pdf, pts, st, pk, mn, mx, w["w1"], w["w2"], w["w3"], w["b1"], w["b2"], w["b3"])
+        ref = orc.spatial_conv(*args, fout, combin, B, R, False, True)
+        rg = orc.spatial_conv_grad(*args, og, fout, combin, B, R, False, True)
+        fg_ref = orc.sort_points_step2_grad(i_, np.zeros_like(sp), rg[0])[1]
+        F = _t(feats).requires_grad_(True)
+        ph = PointHierarchy(P, F, Bi, [], "PH", B, False)
+        cb = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=False, native=True)
+        nb = conv_nb(fin, fout, combin)
+        sd = {"C_weights": _t(w["w1"]).reshape(3, 8 * nb), "C_biases": _t(w["b1"]), "C_weights2": _t(w["w2"]).reshape(nb, 8, 8),
+              "C_biases2": _t(w["b2"]).reshape(nb, 8), "C_weights3": _t(w["w3"]).reshape(nb, 8, 8),
+              "C_biases3": _t(w["b3"]).reshape(nb, 8)}
+        cb.load_state_dict(sd)
+        cb.reset()
+        out = cb.create_convolution("C", ph, 0, F, fin, R, outNumFeatures=fout, multiFeatureConv=combin)
+        assert cb.cacheGeo_
+        out.backward(_t(og))
+        torch.cuda.synchronize()
+        gs, gp = cb.cacheNeighs_["PH|0|%s|False|PH|0" % R]
+        assert np.array_equal(gs.cpu().numpy(), st) and np.array_equal(gp.cpu().numpy(), pk)
+        _close(out, torch.from_numpy(ref), RTOL, name + ":out")
+        _close(F.grad, torch.from_numpy(fg_ref), RTOL, name + ":featGrad")
+        named = dict(cb.named_parameters())
+        for key, r in (("C_weights", rg[1]), ("C_biases", rg[2]), ("C_weights2", rg[3]), ("C_biases2", rg[4]),
+                       ("C_weights3", rg[5]), ("C_biases3", rg[6])):
+            _close(named[key].grad.reshape(-1), torch.from_numpy(np.asarray(r).reshape(-1)), RTOL, name + ":" + key)
+
+
+def test_native_path_keeps_the_ops_shape_rules(mc):
+    """spatial_conv.cc:290-296: the output neurons must be a multiple of the input features, and a depth-wise layer needs
+    exactly numInFeatures neurons (numInFeatures % 8 == 0) -- the native path raises like the op does."""
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    from mccnn_amd.MCConvModule import InvalidArgumentError
+    pts, bids = make_cloud(500, 1, 3, "uniform", False)
+    P, Bi = _t(pts), _t(bids)
+    ph = PointHierarchy(P, torch.ones((len(pts), 1), device="cuda"), Bi, [], "PH", 1, True)
+    for fin, fout, combin in ((4, 4, False), (3, 5, True)):
+        for native in (True, False):
+            cb = ConvolutionBuilder(relativeRadius=True, native=native)
+            F = torch.rand((len(pts), fin), device="cuda")
+            with pytest.raises(InvalidArgumentError):
+                cb.create_convolution("C", ph, 0, F, fin, 0.2, outNumFeatures=fout, multiFeatureConv=combin)
