@@ -515,15 +515,20 @@ class ConfigWorkload:
         for _ in range(warmup):
             self.step()
         torch.cuda.synchronize()
+        from mccnn_amd import MCConvModule as _M
         l0 = self.lib.mccnn_debug_launch_count()
+        w0 = self.lib.mccnn_debug_wait_ns() * 1e-9 + _M.HOST_WAIT_S[0]
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
         t_issue = time.perf_counter() - t0   # the host has enqueued the last launch (edge-count waits included)
+        waits = self.lib.mccnn_debug_wait_ns() * 1e-9 + _M.HOST_WAIT_S[0] - w0
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         launches = (self.lib.mccnn_debug_launch_count() - l0) / float(steps)
         self.host_issue_ms = t_issue / steps * 1e3
+        # ... of which the host WAITED for sizes computed on the device (edge totals, sample counts): the rest is its own work
+        self.host_wait_ms = waits / steps * 1e3
         return el / steps * 1e3, launches
 
     def per_layer(self, iters=5):
@@ -680,7 +685,9 @@ def run_config(name, device, args, want_cpu):
            "steps": steps, "ms_per_step": round(ms, 4), "value": round(n / (ms * 1e-3), 1), "unit": "points/s",
            "library_launches_per_step": round(launches, 1),
            # when this equals ms_per_step the step is bound by the HOST issuing its launches, not by the kernels
-           "host_issue_ms_per_step": round(cw.host_issue_ms, 4), "hierarchy_ms": round(t_h, 4),
+           "host_issue_ms_per_step": round(cw.host_issue_ms, 4),
+           # the host's OWN work per step: issue time minus the time it sat waiting for device-side sizes
+           "host_busy_ms_per_step": round(cw.host_issue_ms - cw.host_wait_ms, 4), "hierarchy_ms": round(t_h, 4),
            "conv_fwd_bwd_ms_cached_geometry": round(sum(l["fwd_ms"] + l["bwd_ms"] for l in layers), 4),
            "layers": layers}
     if want_cpu:
@@ -849,8 +856,8 @@ def compact_record(rec, details_path=None):
     if isinstance(cf, dict):
         out["configs"] = {}
         for name, ent in cf.items():
-            e = _pick(ent, ("ms_per_step", "value", "host_issue_ms_per_step", "library_launches_per_step", "points",
-                            "convolutions"))
+            e = _pick(ent, ("ms_per_step", "value", "host_issue_ms_per_step", "host_busy_ms_per_step",
+                            "library_launches_per_step", "points", "convolutions"))
             if "library_launches_per_step" in e:
                 e["launches"] = e.pop("library_launches_per_step")
             if isinstance(ent.get("cpu_baseline"), dict) and "value" in ent["cpu_baseline"]:

@@ -486,6 +486,10 @@ int mccnn_debug_conv_impl(int mask);
 /* Diagnostics: number of kernel launches the library has issued in this process (all streams). bench.py prints the
  * difference over one step: below ~50k points a step is bound by launches, not by the kernels. */
 long long mccnn_debug_launch_count(void);
+/* Diagnostics: nanoseconds the host has spent so far inside the library WAITING for an edge total (mccnn_geometry_edges /
+ * the first mccnn_conv_* call over a geometry). bench.py subtracts it from a step's host time: what is left is the
+ * host's own work per step. */
+long long mccnn_debug_wait_ns(void);
 /* The calling THREAD's launches are background work from now on (on != 0) / no longer (on == 0): they run on a queue of
  * their own beside kernels a step waits for (ConvolutionBuilder.prefetch_geometry: the geometry of the next batch under
  * the convolutions of the current one). Kernels that would fill every wave slot hold back in that mode; results do not

@@ -205,7 +205,23 @@ _MAILBOX_SPIN_S = 200e-6  # tight polling for this long (the producing kernel re
 _MAILBOX_YIELD_S = 0.25   # ... then polling that hands the GIL to other threads between reads, then a synchronisation
 
 
+#: seconds this process has spent WAITING for sizes computed on the device (edge totals through the mailbox, the sample
+#: counts of a hierarchy); diagnostics only (bench.py: host work per step = issue time - waits)
+HOST_WAIT_S = [0.0]
+
+
 def _await_mailbox(view):
+    v = int(view[0])
+    if v >= 0:
+        return v
+    t0 = time.perf_counter()
+    try:
+        return _await_mailbox_slow(view)
+    finally:
+        HOST_WAIT_S[0] += time.perf_counter() - t0
+
+
+def _await_mailbox_slow(view):
     """Value a kernel of the current stream wrote to the mailbox (armed with -1 by the caller before the launch). The
     tight spin is bounded by TIME: a data-loader or autograd thread of the same process is not starved for longer than
     a fraction of a millisecond; after that every read is followed by time.sleep(0), which releases the GIL."""
@@ -1006,7 +1022,9 @@ def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batc
                                         sizes_ptr + 4 * (l + 1), ptr(ws), ws.numel(), stream_handle()), "hierarchy_level")
         levels.append((oP, oB.view(cap, 1), oI, ti))
         cur_pts, cur_bids = oP, oB
+    t_wait = time.perf_counter()
     host = sizes.cpu().tolist()  # the ONE read-back: every level's sample count
+    HOST_WAIT_S[0] += time.perf_counter() - t_wait
     if any(s < 0 for s in host[1:]):
         return None
     out = []

@@ -22,6 +22,7 @@ SIGNATURES = {
     "mccnn_check_batch_ids": (_i, [_vp, _i, _i, _vp, _vp]),
     "mccnn_debug_conv_impl": (_i, [_i]),
     "mccnn_debug_launch_count": (C.c_longlong, []),
+    "mccnn_debug_wait_ns": (C.c_longlong, []),
     "mccnn_debug_small_kernels": (_i, [_i]),
     "mccnn_debug_f1_x4_min_edges": (_i, [_i]),
     "mccnn_background_launches": (_i, [_i]),

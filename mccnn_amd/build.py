@@ -25,6 +25,41 @@ FLAGS = [
 ]
 
 
+TORCH_EXT = os.path.join(LIB_DIR, "_mccnn_torch.so")   # the PyTorch-ROCm extension over the C-ABI (csrc/torch_ext.cpp)
+TORCH_EXT_SRC = os.path.join(CSRC, "torch_ext.cpp")
+
+
+def torch_ext_needs_build():
+    if not os.path.exists(TORCH_EXT):
+        return True
+    t = os.path.getmtime(TORCH_EXT)
+    return any(os.path.getmtime(d) > t for d in (TORCH_EXT_SRC, os.path.join(ROOT, "include", "mccnn.h")))
+
+
+def build_torch_ext(force=False, verbose=False):
+    """csrc/torch_ext.cpp -> lib/_mccnn_torch.so: host-only C++ (autograd node, buffers, streams) against the torch
+    headers of THIS interpreter, linked to libmccnn_hip.so next to it. g++ -- there is no device code in it."""
+    if not force and not torch_ext_needs_build():
+        return TORCH_EXT
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    inc = ce.include_paths() + [sysconfig.get_paths()["include"], "/opt/rocm/include", os.path.join(ROOT, "include")]
+    cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-deprecated-declarations", TORCH_EXT_SRC, "-o", TORCH_EXT + ".tmp",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_mccnn_torch",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-DTORCH_API_INCLUDE_EXTENSION_H"]
+    cmd += ["-I" + i for i in inc]
+    cmd += ["-L" + tlib, "-L" + LIB_DIR, "-l:" + os.path.basename(LIB), "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch",
+            "-ltorch_python", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(TORCH_EXT + ".tmp", TORCH_EXT)
+    return TORCH_EXT
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -37,7 +72,7 @@ def sources():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or (os.environ.get("MCCNN_LIB_NAME") is None and torch_ext_needs_build()):
         return True
     t = os.path.getmtime(LIB)
     deps = sources() + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "mccnn.h")]
@@ -69,6 +104,8 @@ def build(force=False, verbose=False):
     for f in os.listdir(LIB_DIR):
         if f.startswith(os.path.basename(LIB) + ".") and ("hipv4-" in f or ".host-" in f):
             os.remove(os.path.join(LIB_DIR, f))
+    if os.environ.get("MCCNN_LIB_NAME") is None:  # (A/B builds of the kernels keep the extension of the default library)
+        build_torch_ext(force=True, verbose=verbose)
     return LIB
 
 

@@ -143,6 +143,8 @@ bool rows_shape(bool combin, int fin, const void* feats, int rows, int n_points,
     return fin >= 256 && (float)e / (float)rows >= rows_min_degree();
 }
 
+std::atomic<long long> g_wait_ns{0};  // host time spent waiting for edge totals (mccnn_debug_wait_ns)
+
 // the edge total: stored by the prefix sum of the count pass straight into the caller's pinned word
 int wait_edges(mccnn_geometry* g, int spin_us) {
     if (g->e >= 0) return g->e;
@@ -150,6 +152,10 @@ int wait_edges(mccnn_geometry* g, int spin_us) {
     int v = *g->total_host;
     if (v < 0 && spin_us != 0) {
         const auto t0 = std::chrono::steady_clock::now();
+        struct Acc {
+            std::chrono::steady_clock::time_point t;
+            ~Acc() { g_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(), std::memory_order_relaxed); }
+        } acc{t0};
         for (;;) {
             for (int k = 0; k < 256 && v < 0; ++k) v = *g->total_host;
             if (v >= 0) break;
@@ -349,6 +355,8 @@ int mccnn_geometry_build(mccnn_geometry_t* g, const float* pts, const int* batch
     return 0;
 }
 
+long long mccnn_debug_wait_ns(void) { return g_wait_ns.load(std::memory_order_relaxed); }
+
 int mccnn_geometry_edges(mccnn_geometry_t* g, int wait_us) {
     if (!g || !g->built) return MCCNN_E_BADARG;
     const int e = wait_edges(g, wait_us);
@@ -378,41 +386,41 @@ int mccnn_geometry_attach(mccnn_geometry_t* g, int what, void* buffer, size_t by
 }
 
 // What one mccnn_conv_forward / _backward call of this layer shape needs from the caller: which pieces the geometry does
-// not hold yet (need_mask, need_bytes[k] for bit k), the scratch of the call, and (forward) what has to be kept for the
-// backward pass. Waits for the edge total of the geometry (the one host wait of a convolution).
-int mccnn_conv_prepare(mccnn_geometry_t* g, const void* feats, int num_in_feats, int num_out_feats, int combin, int bf16,
-                       int backward, int flags, int* need_mask, long long need_bytes[4], long long* ws_bytes,
-                       long long* saved_bytes, int* edges) {
-    if (!g || !g->built || !need_mask || !need_bytes || !ws_bytes || !saved_bytes || !edges) return MCCNN_E_BADARG;
-    Shape s;
-    if (!make_shape(s, num_in_feats, num_out_feats, combin, bf16)) return MCCNN_E_SHAPE;
-    const int e = wait_edges(g, -1);
-    if (e < 0) return MCCNN_E_BADARG;
-    *edges = e;
-    if (e > g->e_cap) return MCCNN_E_CAPACITY;
+// not hold yet (mask, need_bytes[k] for bit k), the scratch of the call, and (forward) what has to be kept for the
+// backward pass.
+struct Req {
+    int mask;
+    long long need_bytes[4];
+    size_t ws, saved;
+};
+static int requirements(mccnn_geometry* g, const Shape& s, const void* feats, int backward, int flags, int e, Req& r) {
     const int n = g->n, m = g->m;
     const FwdMode f = fwd_mode(g, s, feats, e);
     int mask = 0;
-    for (int k = 0; k < 4; ++k) need_bytes[k] = 0;
+    for (int k = 0; k < 4; ++k) r.need_bytes[k] = 0;
     size_t ws = 256, saved = 0;
     auto want_plan = [&](int tr) -> int {
         Plan& p = g->plan[tr];
         int rc = plan_prepare(g, tr, e);
         if (rc) return rc;
-        if (!p.buf || p.bytes < (size_t)p.total) { mask |= tr ? NEED_PLAN_TR : NEED_PLAN_FWD; need_bytes[tr] = p.total; }
+        if (!p.buf || p.bytes < (size_t)p.total) { mask |= tr ? NEED_PLAN_TR : NEED_PLAN_FWD; r.need_bytes[tr] = p.total; }
         const int rows = tr ? n : m;
         if (!mccnn_rowplan_inline_records(rows, e) && (!g->rec_buf || g->rec_bytes < (size_t)e * 16)) {
             mask |= NEED_RECORDS;
-            need_bytes[3] = (long long)al((size_t)e * 16);
+            r.need_bytes[3] = (long long)al((size_t)e * 16);
         }
-        const size_t b = mccnn_rowplan_build_workspace_bytes(rows, e, tr);
-        if (b > ws) ws = b;
+        if (!(p.built && p.buf)) {
+            const size_t b = mccnn_rowplan_build_workspace_bytes(rows, e, tr);
+            if (b > ws) ws = b;
+        }
         return 0;
     };
     auto want_tlist = [&]() {
-        if (!g->tl_buf || g->tl_bytes < tlist_bytes(n, e)) { mask |= NEED_TLIST; need_bytes[2] = (long long)tlist_bytes(n, e); }
-        const size_t b = mccnn_transpose_neighbors_workspace_bytes(n, e);
-        if (b > ws) ws = b;
+        if (!g->tl_buf || g->tl_bytes < tlist_bytes(n, e)) { mask |= NEED_TLIST; r.need_bytes[2] = (long long)tlist_bytes(n, e); }
+        if (!g->tl_built) {
+            const size_t b = mccnn_transpose_neighbors_workspace_bytes(n, e);
+            if (b > ws) ws = b;
+        }
     };
     if (!backward) {
         if (!f.unsorted) saved += al((size_t)n * s.fin * s.elem);  // the sorted feature rows
@@ -448,9 +456,30 @@ int mccnn_conv_prepare(mccnn_geometry_t* g, const void* feats, int num_in_feats,
             ws = max3(ws, (w > tb ? w : tb) + fg_sorted + sort_again, 256);
         }
     }
-    *need_mask = mask;
-    *ws_bytes = (long long)(ws + 512);
-    *saved_bytes = (long long)saved;
+    r.mask = mask;
+    r.ws = ws + 512;
+    r.saved = saved;
+    return 0;
+}
+
+// Waits for the edge total of the geometry (the one host wait of a convolution).
+int mccnn_conv_prepare(mccnn_geometry_t* g, const void* feats, int num_in_feats, int num_out_feats, int combin, int bf16,
+                       int backward, int flags, int* need_mask, long long need_bytes[4], long long* ws_bytes,
+                       long long* saved_bytes, int* edges) {
+    if (!g || !g->built || !need_mask || !need_bytes || !ws_bytes || !saved_bytes || !edges) return MCCNN_E_BADARG;
+    Shape s;
+    if (!make_shape(s, num_in_feats, num_out_feats, combin, bf16)) return MCCNN_E_SHAPE;
+    const int e = wait_edges(g, -1);
+    if (e < 0) return MCCNN_E_BADARG;
+    *edges = e;
+    if (e > g->e_cap) return MCCNN_E_CAPACITY;
+    Req r;
+    int rc = requirements(g, s, feats, backward, flags, e, r);
+    if (rc) return rc;
+    *need_mask = r.mask;
+    for (int k = 0; k < 4; ++k) need_bytes[k] = r.need_bytes[k];
+    *ws_bytes = (long long)r.ws;
+    *saved_bytes = (long long)r.saved;
     return 0;
 }
 
@@ -468,6 +497,13 @@ int mccnn_conv_forward(mccnn_geometry_t* g, const void* feats, int num_in_feats,
     const mccnn_geometry* go = grid_owner(g);
     const FwdMode f = fwd_mode(g, s, feats, e);
     avg = avg ? 1 : 0;
+    {   // nothing is launched unless everything this call needs is there (the caller may call optimistically, with the
+        // sizes of the last batch, and only ask mccnn_conv_prepare when this says no)
+        Req r;
+        int rc = requirements(g, s, feats, 0, flags, e, r);
+        if (rc) return rc;
+        if (r.mask || ws_bytes < r.ws || (r.saved && (!saved || saved_bytes < r.saved))) return MCCNN_E_WORKSPACE;
+    }
     // sort_features (MCConvModuleSrc:35-36): sorted[new_idx[i]] = feats[i]
     const void* rows_in = feats;
     char* sv = (char*)saved;
@@ -524,6 +560,12 @@ int mccnn_conv_backward(mccnn_geometry_t* g, const void* feats, const void* save
     const mccnn_geometry* go = grid_owner(g);
     const FwdMode f = fwd_mode(g, s, feats, e);
     avg = avg ? 1 : 0;
+    {
+        Req r;
+        int rc = requirements(g, s, feats, 1, flags, e, r);
+        if (rc) return rc;
+        if (r.mask || ws_bytes < r.ws) return MCCNN_E_WORKSPACE;
+    }
     const size_t rows_b = al((size_t)n * s.fin * s.elem);
     const char* sv = (const char*)saved;
     size_t sv_off = 0;

@@ -1,0 +1,290 @@
+// torch_ext.cpp -- the PyTorch-ROCm side of the native step executor: autograd node, device buffers and streams for
+// mccnn_geometry_* / mccnn_conv_* (include/mccnn.h), so that a convolution costs the host ONE Python -> C++ call in the
+// forward pass and NONE in the backward pass (the autograd engine calls the C++ node directly).
+//
+// torch only supplies what the C-ABI leaves to its caller: device memory (at::empty -- the library never allocates), the
+// current HIP stream and the autograd graph. Every kernel launch goes through libmccnn_hip.so. Built by
+// mccnn_amd/build.py with g++ against the torch headers (host code only, no kernels here); mccnn_amd/native.py falls
+// back to the ctypes form of the same calls when this module is not built.
+#include <torch/extension.h>
+#include <torch/csrc/autograd/function.h>
+#include <torch/csrc/autograd/functions/utils.h>
+#include <torch/csrc/autograd/saved_variable.h>
+#include <c10/hip/HIPStream.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "mccnn.h"
+
+namespace {
+
+using at::Tensor;
+
+struct CapacityError : std::runtime_error {
+    int edges;
+    CapacityError(int e) : std::runtime_error("neighbour list longer than the geometry's capacity"), edges(e) {}
+};
+
+void check(int rc, const char* what) {
+    if (rc == 0) return;
+    throw std::runtime_error(std::string(what) + " failed: " + mccnn_error_string(rc) + " (code " + std::to_string(rc) + ")");
+}
+
+void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+// grow-only scratch per (thread, device, stream): consecutive calls on a stream are stream-ordered and may share it
+Tensor& scratch(size_t bytes, const Tensor& like, void* stream) {
+    thread_local std::map<std::pair<int, void*>, Tensor> pool;
+    Tensor& t = pool[{(int)like.device().index(), stream}];
+    if (bytes < 256) bytes = 256;
+    if (!t.defined() || (size_t)t.numel() < bytes)
+        t = at::empty({(int64_t)(bytes + bytes / 4)}, like.options().dtype(at::kByte));
+    return t;
+}
+
+// pinned words the count pass stores the edge total into (device-accessible host memory: no copy is enqueued)
+std::mutex g_slot_mutex;
+std::vector<Tensor> g_slots;
+Tensor take_slot() {
+    {
+        std::lock_guard<std::mutex> lk(g_slot_mutex);
+        if (!g_slots.empty()) {
+            Tensor t = g_slots.back();
+            g_slots.pop_back();
+            return t;
+        }
+    }
+    return at::empty({1}, at::TensorOptions().dtype(at::kInt).pinned_memory(true));
+}
+void give_slot(Tensor t) {
+    std::lock_guard<std::mutex> lk(g_slot_mutex);
+    if (g_slots.size() < 256) g_slots.push_back(std::move(t));
+}
+
+struct Geo {
+    mccnn_geometry_t* h = nullptr;
+    Tensor buf, slot;
+    std::vector<Tensor> keep, attached;
+    std::shared_ptr<Geo> grid_owner;
+    int n = 0, m = 0, nc = 0, B = 0;
+    int64_t e_cap = 0;
+    int e = -1;
+    int uses = 0;  // layers convolved over this geometry so far (the builder counts)
+    ~Geo() {
+        if (h) mccnn_geometry_destroy(h);
+        if (slot.defined() && e >= 0) give_slot(std::move(slot));  // (a total that never arrived keeps its word)
+    }
+    int edges(int wait_us) {
+        if (e < 0 && h) {
+            const int v = mccnn_geometry_edges(h, wait_us);
+            if (v >= 0) e = v;
+        }
+        return e;
+    }
+    std::vector<int64_t> info() const {
+        long long out[16];
+        check(mccnn_geometry_info(h, out), "geometry_info");
+        return std::vector<int64_t>(out, out + 16);
+    }
+};
+
+void check_dev(const Tensor& t, at::ScalarType dt, const char* name) {
+    TORCH_CHECK(t.defined() && t.is_cuda() && t.scalar_type() == dt && t.is_contiguous(), name,
+                ": expected a contiguous device tensor of the op's type");
+}
+
+std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const Tensor& centres, const Tensor& cbids,
+                                    const Tensor& mn, const Tensor& mx, int64_t B, int64_t nc, double radius, bool scale_inv,
+                                    double window, bool use_pdf, int64_t capacity, std::shared_ptr<Geo> grid_from) {
+    check_dev(pts, at::kFloat, "points");
+    check_dev(centres, at::kFloat, "sample points");
+    check_dev(bids, at::kInt, "batch ids");
+    check_dev(cbids, at::kInt, "sample batch ids");
+    check_dev(mn, at::kFloat, "aabb_min");
+    check_dev(mx, at::kFloat, "aabb_max");
+    const int n = (int)pts.size(0), m = (int)centres.size(0);
+    if (grid_from && grid_from->grid_owner) grid_from = grid_from->grid_owner;
+    const size_t bytes = mccnn_geometry_bytes(n, m, (int)B, (int)nc, (int)capacity, grid_from ? 0 : 1);
+    TORCH_CHECK(bytes > 0, "geometry: batch_size * num_cells^3 does not fit 32-bit keys");
+    auto g = std::make_shared<Geo>();
+    g->h = mccnn_geometry_create();
+    TORCH_CHECK(g->h, "mccnn_geometry_create failed");
+    g->slot = take_slot();
+    g->buf = at::empty({(int64_t)bytes}, pts.options().dtype(at::kByte));
+    g->keep = {pts, bids, centres, cbids, mn, mx};
+    g->grid_owner = grid_from;
+    g->n = n; g->m = m; g->nc = (int)nc; g->B = (int)B; g->e_cap = capacity;
+    check(mccnn_geometry_build(g->h, pts.data_ptr<float>(), bids.data_ptr<int>(), n, centres.data_ptr<float>(),
+                               cbids.data_ptr<int>(), m, mn.data_ptr<float>(), mx.data_ptr<float>(), (int)B, (int)nc,
+                               (float)radius, scale_inv ? 1 : 0, (float)window, use_pdf ? 1 : 0, (int)capacity,
+                               grid_from ? grid_from->h : nullptr, g->buf.data_ptr(), bytes, g->slot.data_ptr<int>(),
+                               cur_stream(pts)),
+          "geometry_build");
+    return g;
+}
+
+struct Layer {
+    int fin, fout, combin, avg, bf16, flags;
+};
+
+// mccnn_conv_prepare + the attachments it asks for; -> scratch bytes, saved bytes
+void prepare(Geo& g, const Tensor& feats, const Layer& L, int backward, int flags, long long& ws_bytes, long long& saved_bytes) {
+    int mask = 0, edges = 0;
+    long long need[4] = {0, 0, 0, 0};
+    int rc = mccnn_conv_prepare(g.h, feats.data_ptr(), L.fin, L.fout, L.combin, L.bf16, backward, flags, &mask, need, &ws_bytes,
+                                &saved_bytes, &edges);
+    if (rc == MCCNN_E_CAPACITY) {
+        g.e = edges;
+        throw CapacityError(edges);
+    }
+    check(rc, "conv_prepare");
+    g.e = edges;
+    for (int k = 0; k < 4 && mask; ++k) {
+        const int bit = 1 << k;
+        if (!(mask & bit)) continue;
+        Tensor t = at::empty({(int64_t)(need[k] > 256 ? need[k] : 256)}, feats.options().dtype(at::kByte));
+        check(mccnn_geometry_attach(g.h, bit, t.data_ptr(), (size_t)t.numel()), "geometry_attach");
+        g.attached.push_back(std::move(t));
+    }
+}
+
+struct ConvBackward : public torch::autograd::Node {
+    std::shared_ptr<Geo> geo;
+    torch::autograd::SavedVariable feats_, w1_, b1_, w2_, b2_, w3_, b3_;
+    Tensor saved;
+    Layer L;
+
+    torch::autograd::variable_list apply(torch::autograd::variable_list&& grads) override {
+        TORCH_CHECK(geo, "MC convolution: backward through a graph whose buffers have been freed (retain_graph=True?)");
+        const Tensor feats = feats_.unpack(), w1 = w1_.unpack(), b1 = b1_.unpack(), w2 = w2_.unpack(), b2 = b2_.unpack(),
+                     w3 = w3_.unpack(), b3 = b3_.unpack();
+        Tensor og = grads[0];
+        if (!og.defined()) og = at::zeros({geo->m, L.combin ? L.fout : L.fin}, feats.options());
+        if (!og.is_contiguous()) og = og.contiguous();
+        if (og.scalar_type() != feats.scalar_type()) og = og.to(feats.scalar_type());
+        int flags = L.flags;
+        // several layers share this neighbour list: its transposed form is built once and the feature gradient of combin
+        // layers with 2..4 input features is gathered through it in a fixed order (bit-reproducible) instead of added
+        // with float atomics; a bare single call keeps the atomics (the list would cost more than they do)
+        if (geo->uses > 1) flags |= 2;
+        long long wsb = 0, svb = 0;
+        prepare(*geo, feats, L, 1, flags, wsb, svb);
+        Tensor fg = at::empty_like(feats);
+        // the six MLP gradients: consecutive slices of ONE buffer in the order the builder creates the variables (a
+        // data-parallel step all-reduces that buffer as it is, dist.GradBucket)
+        const int64_t n1 = w1.numel(), n2 = b1.numel(), n3 = w2.numel(), n4 = b2.numel(), n5 = w3.numel(), n6 = b3.numel();
+        Tensor gflat = at::empty({n1 + n2 + n3 + n4 + n5 + n6}, w1.options());
+        float* base = gflat.data_ptr<float>();
+        void* st = cur_stream(feats);
+        Tensor& ws = scratch((size_t)wsb, feats, st);
+        check(mccnn_conv_backward(geo->h, feats.data_ptr(), saved.defined() ? saved.data_ptr() : nullptr,
+                                  saved.defined() ? (size_t)saved.numel() : 0, og.data_ptr(), L.fin, L.fout, L.combin, L.avg,
+                                  L.bf16, flags, w1.data_ptr<float>(), b1.data_ptr<float>(), w2.data_ptr<float>(),
+                                  b2.data_ptr<float>(), w3.data_ptr<float>(), b3.data_ptr<float>(), fg.data_ptr(), base,
+                                  base + n1, base + n1 + n2, base + n1 + n2 + n3, base + n1 + n2 + n3 + n4,
+                                  base + n1 + n2 + n3 + n4 + n5, ws.data_ptr(), (size_t)ws.numel(), st),
+              "conv_backward");
+        int64_t o = 0;
+        auto piece = [&](int64_t cnt, const Tensor& like) {
+            Tensor t = gflat.narrow(0, o, cnt).view(like.sizes());
+            o += cnt;
+            return t;
+        };
+        torch::autograd::variable_list out(7);
+        out[0] = fg;
+        out[1] = piece(n1, w1); out[2] = piece(n2, b1); out[3] = piece(n3, w2); out[4] = piece(n4, b2);
+        out[5] = piece(n5, w3); out[6] = piece(n6, b3);
+        return out;
+    }
+
+    void release_variables() override {
+        feats_.reset_data(); w1_.reset_data(); b1_.reset_data(); w2_.reset_data(); b2_.reset_data(); w3_.reset_data();
+        b3_.reset_data();
+        saved.reset();
+        geo.reset();
+    }
+};
+
+// One MC convolution over `geo` (SpatialConv with sort_features folded in, MCConvModuleSrc:35-45,70-81): feats are the
+// rows of the UNSORTED input points ([n, Fin] f32, or bf16 for depth-wise layers); the kernel-MLP tensors in any shape
+// over the reference's flat layout.
+Tensor conv(std::shared_ptr<Geo> geo, const Tensor& feats, const Tensor& w1, const Tensor& b1, const Tensor& w2,
+            const Tensor& b2, const Tensor& w3, const Tensor& b3, int64_t fout, bool combin, bool avg) {
+    TORCH_CHECK(geo && geo->h, "conv: no geometry");
+    TORCH_CHECK(feats.defined() && feats.is_cuda() && feats.dim() == 2 && feats.size(0) == geo->n && feats.is_contiguous(),
+                "SpatialConvOp expects as feature inputs the following dimensions (numPoints, numFeatures)");
+    const bool bf = feats.scalar_type() == at::kBFloat16;
+    TORCH_CHECK(bf || feats.scalar_type() == at::kFloat, "features must be float32 or bfloat16");
+    for (const Tensor* t : {&w1, &b1, &w2, &b2, &w3, &b3}) check_dev(*t, at::kFloat, "kernel-MLP tensor");
+    Layer L;
+    L.fin = (int)feats.size(1); L.fout = (int)fout; L.combin = combin ? 1 : 0; L.avg = avg ? 1 : 0; L.bf16 = bf ? 1 : 0;
+    const bool need_grad = at::GradMode::is_enabled() &&
+                           (feats.requires_grad() || w1.requires_grad() || b1.requires_grad() || w2.requires_grad() ||
+                            b2.requires_grad() || w3.requires_grad() || b3.requires_grad());
+    L.flags = need_grad ? 1 : 0;
+    Tensor out, saved;
+    {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        long long wsb = 0, svb = 0;
+        prepare(*geo, feats, L, 0, L.flags, wsb, svb);
+        out = at::empty({geo->m, combin ? fout : (int64_t)L.fin}, feats.options());
+        if (svb > 0) saved = at::empty({(int64_t)svb}, feats.options().dtype(at::kByte));
+        void* st = cur_stream(feats);
+        Tensor& ws = scratch((size_t)wsb, feats, st);
+        check(mccnn_conv_forward(geo->h, feats.data_ptr(), L.fin, L.fout, L.combin, L.avg, L.bf16, L.flags, w1.data_ptr<float>(),
+                                 b1.data_ptr<float>(), w2.data_ptr<float>(), b2.data_ptr<float>(), w3.data_ptr<float>(),
+                                 b3.data_ptr<float>(), out.data_ptr(), saved.defined() ? saved.data_ptr() : nullptr,
+                                 (size_t)svb, ws.data_ptr(), (size_t)ws.numel(), st),
+              "conv_forward");
+    }
+    if (need_grad) {
+        auto node = std::shared_ptr<ConvBackward>(new ConvBackward(), torch::autograd::deleteNode);
+        node->set_next_edges(torch::autograd::collect_next_edges(feats, w1, b1, w2, b2, w3, b3));
+        node->geo = geo;
+        node->feats_ = torch::autograd::SavedVariable(feats, false);
+        node->w1_ = torch::autograd::SavedVariable(w1, false);
+        node->b1_ = torch::autograd::SavedVariable(b1, false);
+        node->w2_ = torch::autograd::SavedVariable(w2, false);
+        node->b2_ = torch::autograd::SavedVariable(b2, false);
+        node->w3_ = torch::autograd::SavedVariable(w3, false);
+        node->b3_ = torch::autograd::SavedVariable(b3, false);
+        node->saved = saved;
+        node->L = L;
+        torch::autograd::set_history(out, node);
+    }
+    return out;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
+    mod.doc() = "PyTorch-ROCm side of the native step executor of libmccnn_hip.so";
+    static py::exception<CapacityError> cap_exc(mod, "CapacityError");
+    py::register_exception_translator([](std::exception_ptr p) {
+        try {
+            if (p) std::rethrow_exception(p);
+        } catch (const CapacityError& e) {
+            PyErr_SetObject(cap_exc.ptr(), py::int_(e.edges).ptr());
+        }
+    });
+    py::class_<Geo, std::shared_ptr<Geo>>(mod, "Geometry")
+        .def_readonly("buf", &Geo::buf)
+        .def_readonly("n", &Geo::n)
+        .def_readonly("m", &Geo::m)
+        .def_readonly("nc", &Geo::nc)
+        .def_readonly("B", &Geo::B)
+        .def_readonly("e_cap", &Geo::e_cap)
+        .def_readonly("e", &Geo::e)
+        .def_readonly("grid_owner", &Geo::grid_owner)
+        .def_readwrite("uses", &Geo::uses)
+        .def("edges", &Geo::edges, py::arg("wait_us") = -1)
+        .def("info", &Geo::info);
+    mod.def("build_geometry", &build_geometry, py::arg("pts"), py::arg("bids"), py::arg("centres"), py::arg("cbids"),
+            py::arg("mn"), py::arg("mx"), py::arg("B"), py::arg("nc"), py::arg("radius"), py::arg("scale_inv"),
+            py::arg("window"), py::arg("use_pdf"), py::arg("capacity"), py::arg("grid_from").none(true));
+    mod.def("conv", &conv);
+}

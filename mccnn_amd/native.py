@@ -15,6 +15,26 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_handle
 
+def _load_ext():
+    """mccnn_amd/lib/_mccnn_torch.so (csrc/torch_ext.cpp): the same calls as below from C++, with the autograd node on the
+    C++ side -- a convolution then costs the host one Python -> C++ call forward and none backward. MCCNN_TORCH_EXT=0 (or a
+    tree without the built module) keeps the ctypes form."""
+    import importlib.util
+    import os
+    if os.environ.get("MCCNN_TORCH_EXT", "1") == "0":
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "_mccnn_torch.so")
+    if not os.path.exists(path):
+        return None
+    _lib.load()  # libmccnn_hip.so first: the module links against it
+    spec = importlib.util.spec_from_file_location("_mccnn_torch", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_EXT = _load_ext()
+
 E_CAPACITY = -6
 NEED_PLAN_FWD, NEED_PLAN_TR, NEED_TLIST, NEED_RECORDS = 1, 2, 4, 8
 
@@ -67,6 +87,7 @@ class Geometry:
     made on demand (grid(), neighbors(), pdfs()) -- the layers themselves only hand the handle to the library."""
 
     def __init__(self):
+        self.core = None        # the C++ object of the torch extension (owns handle / buffers), when that is in use
         self.handle = None
         self.buf = None
         self.slot = None
@@ -93,7 +114,7 @@ class Geometry:
     def edges(self):
         """E (waits for the count pass of the build)."""
         if self.e < 0:
-            e = _lib.load().mccnn_geometry_edges(self.handle, -1)
+            e = self.core.edges(-1) if self.core is not None else _lib.load().mccnn_geometry_edges(self.handle, -1)
             if e < 0:
                 raise _lib.MCCNNError("geometry: edge total not available")
             self.e = e
@@ -107,13 +128,15 @@ class Geometry:
         inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF = self.args
         _build_into(self, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, capacity,
                     self.grid_owner)
-        e = _lib.load().mccnn_geometry_edges(self.handle, -1)
+        e = self.core.edges(-1) if self.core is not None else _lib.load().mccnn_geometry_edges(self.handle, -1)
         if e < 0 or e > self.e_cap:
             raise _lib.MCCNNError("geometry: rebuilt list still does not fit (%d > %d)" % (e, self.e_cap))
         self.e = e
 
     # ------------------------------------------------------------------ views (tests, the builder's cache tuples)
     def _info(self):
+        if self.core is not None:
+            return self.core.info()
         out = (C.c_longlong * 16)()
         check(_lib.load().mccnn_geometry_info(self.handle, out), "geometry_info")
         return list(out)
@@ -145,8 +168,18 @@ class Geometry:
 
 
 def _build_into(g, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, capacity, grid_from):
-    lib = _lib.load()
     n, m = inPts.shape[0], centres.shape[0]
+    if _EXT is not None:
+        uses = g.core.uses if g.core is not None else 0
+        g.core = _EXT.build_geometry(inPts, inBids, centres, cbids, mn, mx, B, nc, float(radius), bool(scaleInv), float(window),
+                                     bool(usePDF), capacity, grid_from.core if grid_from is not None else None)
+        g.core.uses = uses
+        g.buf = g.core.buf
+        g.grid_owner = grid_from
+        g.n, g.m, g.nc, g.B, g.e_cap, g.e = n, m, nc, B, capacity, -1
+        g.args = (inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF)
+        return
+    lib = _lib.load()
     dev = inPts.device
     with_grid = 0 if grid_from is not None else 1
     nbytes = lib.mccnn_geometry_bytes(n, m, B, nc, capacity, with_grid)
@@ -213,31 +246,60 @@ def _prepare(geo, feats, fin, fout, combin, bf16, backward, flags):
     return wsb.value, svb.value
 
 
+E_WORKSPACE = -4
+_SIZES = {}   # (direction, fin, fout, combin, bf16, n, m) -> (scratch bytes, saved bytes) of the last call of this shape
+
+
 class _Conv(torch.autograd.Function):
-    """SpatialConv with sort_features folded in (MCConvModuleSrc:35-45,70-81) over a native Geometry."""
+    """SpatialConv with sort_features folded in (MCConvModuleSrc:35-45,70-81) over a native Geometry. The calls are made
+    OPTIMISTICALLY with the buffer sizes of the last call of the same shape; only when the library says something is
+    missing (first batch of a shape, a longer list, a plan to attach) mccnn_conv_prepare is asked and the call repeated --
+    nothing has been launched by then."""
 
     @staticmethod
     def forward(ctx, feats, w1, b1, w2, b2, w3, b3, geo, fout, combin, avg, deterministic):
         lib = _lib.load()
         fin = feats.shape[1]
         bf16 = 1 if feats.dtype == torch.bfloat16 else 0
-        need_grad = any(t.requires_grad for t in (feats, w1, b1, w2, b2, w3, b3))
+        need_grad = feats.requires_grad or w1.requires_grad or w3.requires_grad or w2.requires_grad or b1.requires_grad \
+            or b2.requires_grad or b3.requires_grad
         flags = (1 if need_grad else 0) | (2 if deterministic else 0)
         combin = 1 if combin else 0
-        wsb, svb = _prepare(geo, feats, fin, fout, combin, bf16, 0, flags)
+        avg = 1 if avg else 0
         dev = feats.device
         out = torch.empty((geo.m, fout if combin else fin), dtype=feats.dtype, device=dev)
-        saved = torch.empty(svb, dtype=torch.uint8, device=dev) if svb else None
-        ws = _ws(wsb, dev)
-        check(lib.mccnn_conv_forward(geo.handle, feats.data_ptr(), fin, fout, combin, int(bool(avg)), bf16, flags,
-                                     w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(),
-                                     out.data_ptr(), ptr(saved), svb, ws.data_ptr(), ws.numel(), stream_handle()),
-              "conv_forward")
+        skey = (flags & 1, fin, fout, combin, bf16, geo.n, geo.m)
+        wsb, svb = _SIZES.get(skey, (0, -1))
+        if svb < 0:
+            wsb, svb = _prepare(geo, feats, fin, fout, combin, bf16, 0, flags)
+            svb += svb // 16   # a little head room: the lists of a shape vary from batch to batch
+        tried = False
+        while True:
+            saved = torch.empty(svb, dtype=torch.uint8, device=dev) if svb else None
+            ws = _ws(wsb, dev)
+            rc = lib.mccnn_conv_forward(geo.handle, feats.data_ptr(), fin, fout, combin, avg, bf16, flags, w1.data_ptr(),
+                                        b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(),
+                                        out.data_ptr(), ptr(saved), svb, ws.data_ptr(), ws.numel(), stream_handle())
+            if rc == 0:
+                break
+            if rc not in (E_WORKSPACE, E_CAPACITY):
+                check(rc, "conv_forward")
+            w2_, s2_ = _prepare(geo, feats, fin, fout, combin, bf16, 0, flags)
+            if s2_ <= svb and rc == E_WORKSPACE and ws.numel() >= w2_ and tried:
+                check(rc, "conv_forward")  # the library asked twice for what it was given
+            tried = True
+            wsb, svb = w2_, s2_ + s2_ // 16
+        if geo.e < 0:
+            geo.e = lib.mccnn_geometry_edges(geo.handle, 0)
+            _remember(geo.gkey, geo.m, geo.e)
+        if len(_SIZES) > 1024:
+            _SIZES.clear()
+        _SIZES[skey] = (wsb, svb)
         if need_grad:
             ctx.save_for_backward(feats, w1, b1, w2, b2, w3, b3)
             ctx.saved_buf = saved
             ctx.geo = geo
-            ctx.attrs = (fin, fout, combin, int(bool(avg)), bf16, flags)
+            ctx.attrs = (fin, fout, combin, avg, bf16, flags)
         return out
 
     @staticmethod
@@ -254,25 +316,55 @@ class _Conv(torch.autograd.Function):
         og = outGrad if outGrad.is_contiguous() else outGrad.contiguous()
         if og.dtype != feats.dtype:
             og = og.to(feats.dtype)
-        wsb, _ = _prepare(geo, feats, fin, fout, combin, bf16, 1, flags)
         dev = feats.device
         fg = torch.empty_like(feats)
         # the six MLP gradients: consecutive slices of ONE buffer in the order the builder creates the variables (a
         # data-parallel step all-reduces that buffer as it is, dist.GradBucket)
-        sizes = [w1.numel(), b1.numel(), w2.numel(), b2.numel(), w3.numel(), b3.numel()]
-        gflat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-        dw1, db1, dw2, db2, dw3, db3 = gflat.split(sizes)
-        ws = _ws(wsb, dev)
-        check(lib.mccnn_conv_backward(geo.handle, feats.data_ptr(), ptr(saved), saved.numel() if saved is not None else 0,
-                                      og.data_ptr(), fin, fout, combin, avg, bf16, flags, w1.data_ptr(), b1.data_ptr(),
-                                      w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), fg.data_ptr(), dw1.data_ptr(),
-                                      db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), dw3.data_ptr(), db3.data_ptr(),
-                                      ws.data_ptr(), ws.numel(), stream_handle()), "conv_backward")
-        return (fg, dw1.view_as(w1), db1.view_as(b1), dw2.view_as(w2), db2.view_as(b2), dw3.view_as(w3), db3.view_as(b3),
+        n1, n2, n3, n4, n5, n6 = w1.numel(), b1.numel(), w2.numel(), b2.numel(), w3.numel(), b3.numel()
+        gflat = torch.empty(n1 + n2 + n3 + n4 + n5 + n6, dtype=torch.float32, device=dev)
+        dw1, db1, dw2, db2, dw3, db3 = gflat.split((n1, n2, n3, n4, n5, n6))
+        base = gflat.data_ptr()
+        skey = (2 | (flags & 2), fin, fout, combin, bf16, geo.n, geo.m)
+        wsb = _SIZES.get(skey, (-1, 0))[0]
+        if wsb < 0:
+            wsb, _ = _prepare(geo, feats, fin, fout, combin, bf16, 1, flags)
+        svn = saved.numel() if saved is not None else 0
+        tried = False
+        while True:
+            ws = _ws(wsb, dev)
+            rc = lib.mccnn_conv_backward(geo.handle, feats.data_ptr(), ptr(saved), svn, og.data_ptr(), fin, fout, combin, avg,
+                                         bf16, flags, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
+                                         b3.data_ptr(), fg.data_ptr(), base, base + 4 * n1, base + 4 * (n1 + n2),
+                                         base + 4 * (n1 + n2 + n3), base + 4 * (n1 + n2 + n3 + n4),
+                                         base + 4 * (n1 + n2 + n3 + n4 + n5), ws.data_ptr(), ws.numel(), stream_handle())
+            if rc == 0:
+                break
+            if rc not in (E_WORKSPACE, E_CAPACITY):
+                check(rc, "conv_backward")
+            w2_, _ = _prepare(geo, feats, fin, fout, combin, bf16, 1, flags)
+            if tried and ws.numel() >= w2_:
+                check(rc, "conv_backward")
+            tried = True
+            wsb = w2_
+        _SIZES[skey] = (wsb, 0)
+        return (fg, dw1.view_as(w1), db1, dw2.view_as(w2), db2.view_as(b2), dw3.view_as(w3), db3.view_as(b3),
                 None, None, None, None, None)
 
 
 def conv(geo, feats, w1, b1, w2, b2, w3, b3, numOutFeatures, combin, avg, deterministic=False):
     """One MC convolution over `geo`: feats are the rows of the UNSORTED input points ([n, Fin] f32, or bf16 for
     depth-wise layers); the kernel-MLP tensors in any shape over the reference's flat layout."""
+    core = geo.core
+    if core is not None:
+        core.uses = geo.uses
+        try:
+            out = _EXT.conv(core, feats, w1, b1, w2, b2, w3, b3, numOutFeatures, bool(combin), bool(avg))
+        except _EXT.CapacityError:
+            geo.edges()   # the list did not fit the guess (first batch of a shape): exact rebuild, then the layer
+            geo.core.uses = geo.uses
+            out = _EXT.conv(geo.core, feats, w1, b1, w2, b2, w3, b3, numOutFeatures, bool(combin), bool(avg))
+        if geo.e < 0:
+            geo.e = geo.core.e
+            _remember(geo.gkey, geo.m, geo.e)
+        return out
     return _Conv.apply(feats, w1, b1, w2, b2, w3, b3, geo, numOutFeatures, combin, avg, deterministic)
