@@ -1,9 +1,11 @@
 // Stand-alone consumer of the C-ABI (include/mccnn.h): no Python, no torch -- only the HIP runtime for memory.
-// Runs compute_aabb -> sort -> find_neighbors -> compute_pdf -> spatial_conv forward on a random cloud and prints
-// a checksum; tests/test_gpu_capi_example.py compares the checksum path against the oracle on the same input.
+// Runs compute_aabb -> sort -> find_neighbors -> compute_pdf -> spatial_conv forward AND backward on a random cloud, prints
+// per-tensor sums and (third argument) dumps every result tensor; then runs the same layer through the native step
+// executor (mccnn_geometry_* / mccnn_conv_*) and prints how far the two are apart. tests/test_gpu_capi_example.py compares
+// the dumped tensors with the oracle on the same input, element by element.
 //
 //   hipcc --offload-arch=gfx950 -O2 -Iinclude examples/capi_example.cpp -Lmccnn_amd/lib -lmccnn_hip \
-//         -Wl,-rpath,$PWD/mccnn_amd/lib -o examples/capi_example && ./examples/capi_example 4096 0.1
+//         -Wl,-rpath,$PWD/mccnn_amd/lib -o examples/capi_example && ./examples/capi_example 4096 0.1 [dump.bin]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -65,5 +67,77 @@ int main(int argc, char** argv) {
     double sum = 0, asum = 0;
     for (float v : hout) { sum += v; asum += v < 0 ? -v : v; }
     printf("arch=%s block=%d n=%d nc=%d E=%d out_sum=%.6e out_abs_sum=%.6e\n", mccnn_arch(), mccnn_block_size(), n, nc, E, sum, asum);
+
+    // ---- SpatialConvGrad: feature gradient + the six kernel-MLP gradients for a deterministic out-gradient
+    std::vector<float> og((size_t)n * Fout);
+    for (auto& v : og) v = 2 * rnd() - 1;
+    float* dOG = dalloc<float>(og.size());
+    HK(hipMemcpy(dOG, og.data(), og.size() * 4, hipMemcpyHostToDevice));
+    float *fgS = dalloc<float>((size_t)n * Fin), *fg = dalloc<float>((size_t)n * Fin);
+    float *gw1 = dalloc<float>(w1.size()), *gb1 = dalloc<float>(b1.size()), *gw2 = dalloc<float>(w2.size()), *gb2 = dalloc<float>(b2.size()),
+          *gw3 = dalloc<float>(w3.size()), *gb3 = dalloc<float>(b3.size());
+    size_t wsg = mccnn_spatial_conv_bwd_workspace_bytes(n, n, E, Fin, Fout, 1); void* ws6 = dalloc<char>(wsg);
+    CK(mccnn_spatial_conv_bwd(sP, sF, sB, pdfs, dP, start, packed, mn, mx, dw1, db1, dw2, db2, dw3, db3, dOG, n, n, E, Fin, Fout, 1, B,
+                              radius, scaleInv, 1, /*state=*/nullptr, /*start_t=*/nullptr, /*perm_t=*/nullptr, fgS, gw1, gb1, gw2, gb2,
+                              gw3, gb3, ws6, wsg, s));
+    CK(mccnn_permute_gather(fgS, idx, n, Fin, fg, s));  // SortPointsStep2Grad: back into the order of the input points
+    struct Piece { const char* name; float* dev; size_t count; };
+    const Piece pieces[] = {{"out", out, (size_t)n * Fout}, {"feat_grad", fg, (size_t)n * Fin}, {"dw1", gw1, w1.size()},
+                            {"db1", gb1, b1.size()}, {"dw2", gw2, w2.size()}, {"db2", gb2, b2.size()}, {"dw3", gw3, w3.size()},
+                            {"db3", gb3, b3.size()}};
+    FILE* dump = argc > 3 ? fopen(argv[3], "wb") : nullptr;
+    std::vector<std::vector<float>> host;
+    for (const Piece& p : pieces) {
+        std::vector<float> h(p.count);
+        HK(hipMemcpyAsync(h.data(), p.dev, p.count * 4, hipMemcpyDeviceToHost, s)); HK(hipStreamSynchronize(s));
+        double sm = 0;
+        for (float v : h) sm += v;
+        printf("%s_sum=%.6e ", p.name, sm);
+        if (dump) fwrite(h.data(), 4, h.size(), dump);
+        host.push_back(std::move(h));
+    }
+    printf("\n");
+    if (dump) fclose(dump);
+
+    // ---- the same layer through the native step executor: ONE call for the geometry, one per direction
+    const int cap = E + E / 16 + 64;
+    int* totalHost = nullptr; HK(hipHostMalloc((void**)&totalHost, sizeof(int), hipHostMallocDefault));
+    mccnn_geometry_t* g = mccnn_geometry_create();
+    size_t gb = mccnn_geometry_bytes(n, n, B, nc, cap, 1); void* gbuf = dalloc<char>(gb);
+    CK(mccnn_geometry_build(g, dP, dB, n, dP, dB, n, mn, mx, B, nc, radius, scaleInv, 0.2f, 1, cap, nullptr, gbuf, gb, totalHost, s));
+    if (mccnn_geometry_edges(g, -1) != E) { fprintf(stderr, "geometry: E differs\n"); return 1; }
+    float *out2 = dalloc<float>((size_t)n * Fout), *fg2 = dalloc<float>((size_t)n * Fin);
+    for (int dir = 0; dir < 2; ++dir) {
+        int mask = 0, edges = 0; long long need[4], wsb2 = 0, svb = 0;
+        static void* saved = nullptr; static size_t savedBytes = 0;
+        CK(mccnn_conv_prepare(g, dF, Fin, Fout, 1, 0, dir, 1, &mask, need, &wsb2, &svb, &edges));
+        for (int k = 0; k < 4; ++k)
+            if (mask & (1 << k)) CK(mccnn_geometry_attach(g, 1 << k, dalloc<char>((size_t)need[k]), (size_t)need[k]));
+        void* wsx = dalloc<char>((size_t)wsb2);
+        if (dir == 0) {
+            saved = dalloc<char>((size_t)svb); savedBytes = (size_t)svb;
+            CK(mccnn_conv_forward(g, dF, Fin, Fout, 1, 1, 0, 1, dw1, db1, dw2, db2, dw3, db3, out2, saved, savedBytes, wsx, (size_t)wsb2, s));
+        } else {
+            CK(mccnn_conv_backward(g, dF, saved, savedBytes, dOG, Fin, Fout, 1, 1, 0, 1, dw1, db1, dw2, db2, dw3, db3, fg2, gw1, gb1, gw2,
+                                   gb2, gw3, gb3, wsx, (size_t)wsb2, s));
+        }
+    }
+    double worst = 0;
+    const Piece again[] = {{"out", out2, (size_t)n * Fout}, {"feat_grad", fg2, (size_t)n * Fin}, {"dw1", gw1, w1.size()},
+                           {"db1", gb1, b1.size()}, {"dw2", gw2, w2.size()}, {"db2", gb2, b2.size()}, {"dw3", gw3, w3.size()},
+                           {"db3", gb3, b3.size()}};
+    for (size_t k = 0; k < 8; ++k) {
+        std::vector<float> h(again[k].count);
+        HK(hipMemcpyAsync(h.data(), again[k].dev, h.size() * 4, hipMemcpyDeviceToHost, s)); HK(hipStreamSynchronize(s));
+        double scale = 1e-30, d = 0;
+        for (size_t t = 0; t < h.size(); ++t) {
+            const double a = host[k][t] < 0 ? -host[k][t] : host[k][t], e = h[t] - host[k][t];
+            if (a > scale) scale = a;
+            if ((e < 0 ? -e : e) > d) d = e < 0 ? -e : e;
+        }
+        if (d / scale > worst) worst = d / scale;
+    }
+    printf("executor_vs_ops_max_rel=%.3e\n", worst);
+    mccnn_geometry_destroy(g);
     return 0;
 }

@@ -145,10 +145,12 @@ def _order_hint(points):
             check(_lib.load().mccnn_invert_permutation(ptr(payload), payload.shape[0], ptr(inv), stream_handle()),
                   "invert_permutation")
             ent[2] = inv
-        elif payload.shape[0] < 16384:
-            return None  # a small sample set is searched in ~10 us either way: the argsort would cost more than it saves
-        else:  # "sorted_pos": position of every point in some cell-sorted list
-            ent[2] = torch.argsort(payload).to(torch.int32)
+        else:
+            # "sorted_pos" (Poisson samples: their positions in the sampling grid's sorted list). The op-by-op surface has
+            # no cell-coherent order for them without a sort of its own; the native path (csrc/exec.hip) derives one from
+            # the SEARCH grid with the library's counting sort (sort_step1 on the centres + invert_permutation). Here the
+            # centres are visited in the order given -- results never depend on it.
+            return None
     return ent[2]
 
 

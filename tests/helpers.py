@@ -68,3 +68,36 @@ def run_chain(ops, wrap, unwrap, pts, bids, feats, B, radius, scaleInv, window=0
         r.update(samplePts=unwrap(sp), sampleBatchs=unwrap(sb), sampleIndexs=unwrap(si), sampleFeatures=unwrap(sf),
                  transformedIndexs=unwrap(ti), poissonSortPts=unwrap(p2), poissonCells=unwrap(c2))
     return r
+
+
+# ---------------------------------------------------------------------------------------------- tolerances
+#: Per ELEMENT: |got - ref| <= rtol |ref| + FLOOR max|ref|. The absolute floor is for elements that cancel to ~0: a sum of k
+#: terms of size ~max|ref| carries rounding noise of ~1e-7 k^(1/2) max|ref| whatever its own value (measured worst case over
+#: every test: 2.4e-6 max|ref|, float atomics in the feature gradient); 1e-5 leaves a factor of four.
+ELEMENT_FLOOR = 1e-5
+
+
+def elementwise_excess(got, ref, rtol=1e-4, floor=ELEMENT_FLOOR):
+    """max over the elements of |got - ref| / (rtol |ref| + floor max|ref|); <= 1 passes. Next to every norm-wise bound
+    (max|diff| / max|ref| <= rtol) the float tests hold this one, so that "within 1e-4 relative" is true of every value
+    that is not noise-level small, not only of the largest ones."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if ref.size == 0:
+        return 0.0
+    scale = max(float(np.abs(ref).max()), 1e-30)
+    return float((np.abs(got - ref) / (rtol * np.abs(ref) + floor * scale)).max())
+
+
+def assert_float_close(got, ref, rtol=1e-4, what="", floor=ELEMENT_FLOOR):
+    """norm-wise AND element-wise (see elementwise_excess)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    if ref.size == 0:
+        return 0.0
+    scale = max(float(np.abs(ref).max()), 1e-30)
+    err = float(np.abs(got - ref).max() / scale)
+    assert err <= rtol, "%s: max |diff| / max |ref| = %.3e > %.1e" % (what, err, rtol)
+    ex = elementwise_excess(got, ref, rtol, floor)
+    assert ex <= 1.0, "%s: an element is %.2f x outside |d| <= %.0e |ref| + %.0e max|ref|" % (what, ex, rtol, floor)
+    return err

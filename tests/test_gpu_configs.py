@@ -14,7 +14,7 @@ import math
 import numpy as np
 import pytest
 
-from tests.helpers import make_mlp, conv_nb
+from tests.helpers import make_mlp, conv_nb, elementwise_excess
 from mccnn_amd.workloads import modelnet_like, mcclass_s, mcclass_h, mcseg
 
 pytestmark = pytest.mark.gpu
@@ -110,8 +110,11 @@ def run_conv(ops, wrap, unwrap, mn, mx, levels, B, spec, seed, is_gpu, bf16=Fals
 
 
 def rel_err(got, ref):
+    """max |diff| / max |ref| (the caller holds it to RTOL); every ELEMENT is held to |d| <= RTOL |ref| + 1e-5 max |ref| here."""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (got.shape, ref.shape)
+    ex = elementwise_excess(got, ref, RTOL)
+    assert ex <= 1.0, "an element is %.2f x outside |d| <= 1e-4 |ref| + 1e-5 max|ref|" % ex
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)) if ref.size else 0.0
 
 
@@ -225,3 +228,73 @@ MCSEG_K32 = _specs(mcseg(32))  # models/MCSeg.py:36-198, grow 32 (BASELINE cfg3)
 def test_cfg3_mcseg_16x8192_bf16_rows(mc, oracle_omp):
     sizes, worst = check_config(mc, oracle_omp, 8192, 16, [0.025, 0.1, 0.4], MCSEG_K32, 47)
     print("cfg3 level sizes", sizes, "worst", {k: "%.1e" % v for k, v in worst.items()})
+
+
+def test_cfg4_mcsegscannet_room(mc, oracle_omp):
+    """BASELINE cfg4's GRAPH (models/MCSegScanNet.py:29-249, mccnn_amd.workloads.mcseg_scannet(64)): one 100 000-point
+    non-uniform room, hierarchy [0.1, 0.2, 0.4, 0.8] ABSOLUTE, all 17 convolutions -- Pool_* / Up_* cross levels, Up_1_3 and
+    Up_1_4 skip levels, rows up to 512 features -- through the builder API on both sides: the product's default path
+    (native step executor on the GPU) against the identical graph on the oracle ops (ops=, CPU tensors). Hierarchy and
+    every grid / neighbour list bit-exact, PDFs, outputs and all seven gradients of every layer within 1e-4, norm-wise
+    and per element."""
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    from mccnn_amd.workloads import CONFIGS, config_points
+    from tests.oracle_ops import OracleOps
+    cfg = CONFIGS["cfg4"]
+    pts, bids, B = config_points(cfg, 1)
+    assert len(pts) == 100000 and B == 1 and not cfg.relative and list(cfg.hierarchy) == [0.1, 0.2, 0.4, 0.8]
+    oo = OracleOps(oracle_omp)
+    P, Bi = _wrap(pts), _wrap(bids)
+    Pc, Bc = torch.from_numpy(pts), torch.from_numpy(bids)
+    ph = PointHierarchy(P, torch.ones((len(pts), 1), device="cuda"), Bi, list(cfg.hierarchy), "PH", B, False)
+    phc = PointHierarchy(Pc, torch.ones((len(pts), 1)), Bc, list(cfg.hierarchy), "PH", B, False, ops=oo)
+    sizes = [int(p.shape[0]) for p in ph.points_]
+    assert len(sizes) == 5 and sizes[0] == 100000 and all(a > b for a, b in zip(sizes, sizes[1:]))
+    for l in range(1, 5):
+        assert np.array_equal(_unwrap(ph.points_[l]), phc.points_[l].numpy()), l
+        assert np.array_equal(_unwrap(ph.batchIds_[l]), phc.batchIds_[l].numpy()), l
+        assert np.array_equal(_unwrap(ph.sampledIndexs_[l - 1]), phc.sampledIndexs_[l - 1].numpy()), l
+    torch.manual_seed(17)
+    cb = ConvolutionBuilder(KDEWindow=0.25, relativeRadius=False)
+    cbc = ConvolutionBuilder(KDEWindow=0.25, relativeRadius=False, ops=oo)
+    cb.reset()
+    cbc.reset()
+    assert cb.native_
+    rng = np.random.default_rng(5)
+    worst = {}
+    for ci, c in enumerate(cfg.convs):
+        n, m = sizes[c.lin], sizes[c.lout]
+        outF = c.fout if c.combin else c.fin
+        f = (2 * rng.random((n, c.fin)) - 1).astype(np.float32)
+        og = (2 * rng.random((m, outF)) - 1).astype(np.float32)
+        F = _wrap(f).requires_grad_(True)
+        out = cb.create_convolution(c.name, ph, c.lin, F, c.fin, c.radius, ph, c.lout, c.combin, c.fout, c.window)
+        names = [c.name + s for s in ("_weights", "_biases", "_weights2", "_biases2", "_weights3", "_biases3")]
+        gp = dict(cb.named_parameters())
+        cbc.load_state_dict({k: gp[k].detach().cpu().clone() for k in names}, strict=False)
+        Fc = torch.from_numpy(f).requires_grad_(True)
+        outc = cbc.create_convolution(c.name, phc, c.lin, Fc, c.fin, c.radius, phc, c.lout, c.combin, c.fout, c.window)
+        cp = dict(cbc.named_parameters())
+        g_gpu = torch.autograd.grad([out], [F] + [gp[k] for k in names], [_wrap(og)])
+        g_cpu = torch.autograd.grad([outc], [Fc] + [cp[k] for k in names], [torch.from_numpy(og)])
+        torch.cuda.synchronize()
+        e = {"out": rel_err(_unwrap(out), outc.detach().numpy())}
+        for nm, a, b in zip(GRADS, g_gpu, g_cpu):
+            e[nm] = rel_err(_unwrap(a), b.numpy())
+        for nm, v in e.items():
+            assert v <= RTOL, "%s: %s max |diff| / max |ref| = %.3e" % (c.name, nm, v)
+            worst[nm] = max(worst.get(nm, 0.0), v)
+    assert len(cb.cacheGeo_) == len(cbc.cacheNeighs_) and list(cb.cacheNeighs_) == list(cbc.cacheNeighs_)
+    assert list(cb.cacheGrids_) == list(cbc.cacheGrids_) and list(cb.cachePDFs_) == list(cbc.cachePDFs_)
+    for k in cbc.cacheGrids_:     # sortPts, sortBatchs, cellIndexs, index_new_pos
+        for a, b in zip(cb.cacheGrids_[k][:4], cbc.cacheGrids_[k][:4]):
+            assert np.array_equal(_unwrap(a).reshape(-1), b.detach().numpy().reshape(-1)), k
+    edges = 0
+    for k in cbc.cacheNeighs_:
+        (s0, p0), (s1, p1) = cb.cacheNeighs_[k], cbc.cacheNeighs_[k]
+        assert np.array_equal(_unwrap(s0), s1.detach().numpy()) and np.array_equal(_unwrap(p0), p1.detach().numpy()), k
+        edges += len(p1)
+    for k in cbc.cachePDFs_:
+        assert rel_err(_unwrap(cb.cachePDFs_[k].value()), cbc.cachePDFs_[k].detach().numpy()) <= RTOL, k
+    print("cfg4 graph: levels", sizes, "lists", len(cbc.cacheNeighs_), "edges", edges, {k: "%.1e" % v for k, v in worst.items()})

@@ -7,7 +7,7 @@ oracle's OpenMP build, for one room and for a two-room batch."""
 import numpy as np
 import pytest
 
-from tests.helpers import make_room, make_mlp
+from tests.helpers import make_room, make_mlp, assert_float_close
 
 pytestmark = pytest.mark.gpu
 N, R, B = 100000, 0.1, 1
@@ -244,10 +244,10 @@ def _check_conv(mc, orc, c, fin, fout, combin, seed):
          _np(c["mx"]), w["w1"], w["w2"], w["w3"], w["b1"], w["b2"], w["b3"])
     ref = orc.spatial_conv(*a, fout, combin, B, R, False, True)
     rg = orc.spatial_conv_grad(*a, og, fout, combin, B, R, False, True)
-    errs = {"out": float(np.abs(_np(out) - ref).max() / np.abs(ref).max())}
+    errs = {"out": assert_float_close(_np(out), ref, RTOL, "out")}   # norm-wise and per element
     got = [sF.grad, tw["w1"].grad, tw["b1"].grad, tw["w2"].grad, tw["b2"].grad, tw["w3"].grad, tw["b3"].grad]
     for nm, g, r_ in zip(["featGrad", "dw1", "db1", "dw2", "db2", "dw3", "db3"], got, rg):
-        errs[nm] = float(np.abs(_np(g).astype(np.float64) - r_).max() / max(np.abs(r_).max(), 1e-30))
+        errs[nm] = assert_float_close(_np(g), r_, RTOL, nm)
     print("E=%d Fin=%d Fout=%d combin=%s" % (c["packed"].shape[0], fin, fout, combin), {k: "%.1e" % v for k, v in errs.items()})
     for nm, e in errs.items():
         assert e <= RTOL, (nm, e)

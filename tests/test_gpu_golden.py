@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.helpers import run_chain
+from tests.helpers import run_chain, assert_float_close
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -25,7 +25,8 @@ def test_hip_matches_golden(mc, path):
     for k in ("keys", "indexs", "cellIndexs", "startIndexs", "packedNeighs", "sampleIndexs", "transformedIndexs",
               "sampleBatchs", "sortBatchs"):
         assert np.array_equal(o[k], g[k]), k
-    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+    def rel(a, b):  # norm-wise for the caller, per element here
+        return assert_float_close(a, b, RTOL, "golden")
     assert rel(o["pdfs"], g["pdfs"]) <= RTOL
     h = o["_handles"]
     tw = {k: wrap(g["mlp_" + k]).requires_grad_(True) for k in ("w1", "b1", "w2", "b2", "w3", "b3")}

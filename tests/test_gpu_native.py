@@ -4,7 +4,7 @@ float outputs within the feature-path tolerance (they are the same kernels; only
 import numpy as np
 import pytest
 
-from tests.helpers import make_cloud, make_room
+from tests.helpers import make_cloud, make_room, assert_float_close
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -16,12 +16,9 @@ def _t(x):
 
 
 def _close(a, b, tol, what):
-    a, b = a.detach().float().cpu().numpy().astype(np.float64), b.detach().float().cpu().numpy().astype(np.float64)
-    assert a.shape == b.shape, what
-    scale = max(np.abs(b).max(), 1e-30)
-    assert np.abs(a - b).max() <= tol * scale, (what, np.abs(a - b).max() / scale)
-    # per element, with an absolute floor (values that cancel to ~0 carry the rounding noise of the largest terms)
-    assert np.all(np.abs(a - b) <= tol * np.abs(b) + 100 * tol * 1e-2 * scale), what
+    """norm-wise and per element (tests/helpers.py)"""
+    assert_float_close(a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy(), tol, what,
+                       floor=1e-5 if tol <= 1e-3 else 1e-2)
 
 
 LAYERS = [  # name, lin, lout, fin, fout, combin, radius, bf16

@@ -6,7 +6,7 @@ neighbour lists, Poisson samples); float outputs within 1e-4 relative.
 import numpy as np
 import pytest
 
-from tests.helpers import make_cloud, make_room, make_mlp, conv_nb, run_chain
+from tests.helpers import make_cloud, make_room, make_mlp, conv_nb, run_chain, assert_float_close
 
 pytestmark = pytest.mark.gpu
 
@@ -27,11 +27,8 @@ def _ident(x):
 
 
 def assert_close(got, ref, rtol=RTOL, what=""):
-    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
-    assert got.shape == ref.shape, (what, got.shape, ref.shape)
-    scale = max(np.abs(ref).max(), 1e-30) if ref.size else 1.0
-    err = np.abs(got - ref).max() / scale if ref.size else 0.0
-    assert err <= rtol, "%s: max |diff| / max |ref| = %.3e > %.1e" % (what, err, rtol)
+    """norm-wise (max |diff| / max |ref| <= rtol) and per element (|d| <= rtol |ref| + 1e-5 max |ref|, tests/helpers.py)"""
+    assert_float_close(got, ref, rtol, what)
 
 
 INT_KEYS = ["keys", "indexs", "sortBatchs", "cellIndexs", "startIndexs", "packedNeighs"]
