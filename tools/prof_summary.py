@@ -47,7 +47,7 @@ for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), r
 if rows:
     allc = pd.concat(rows)
     piv = allc.pivot_table(index="Kernel_Name", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
-    tags = ("conv_", "f1_", "neigh", "pdf_", "edge_rec", "scatter_edge", "keys_", "grid_", "sort_", "cell_", "poisson", "tr_", "scan", "rank_", "move_")
+    tags = ("conv_", "f1_", "neigh", "pdf_", "edge_rec", "scatter_edge", "keys_", "grid_", "sort_", "cell_", "poisson", "tr_", "scan", "rank_", "move_", "dw_", "sell_", "rows_", "vr_", "plan_", "reduce_", "permute_", "park_", "aabb_")
     keep = [k for k in piv.index if any(t in k for t in tags)]
     pd.set_option("display.max_columns", 60)
     pd.set_option("display.max_rows", 200)
