@@ -218,6 +218,12 @@ class ConvolutionBuilder(torch.nn.Module):
         self.cacheGeo_ = {}         # keyPDF -> native.Geometry; keyGrid -> the Geometry that owns the grid
         self.cacheGeoGrid_ = {}
         self.layers_ = {}           # convName -> (spec, variables): the fast path of a repeated create_convolution
+        # learned prefetch (native path): the geometries a step asked for, in order; the next step builds them ALL at its
+        # first create_convolution, round-robin on side streams -- they depend on the points only, their chains of small
+        # kernels run side by side and under the first layers instead of one after the other between them
+        self.geoPrefetch_ = os.environ.get("MCCNN_GEO_PREFETCH", "1") != "0"
+        self.geoLog_ = []
+        self.geoPlan_ = []
         self.multiFeatureConvs_ = multiFeatureConvs
         self.KDEWindow_ = KDEWindow
         self.relativeRadius_ = relativeRadius
@@ -293,6 +299,8 @@ class ConvolutionBuilder(torch.nn.Module):
         self.cachePDFs_ = {}
         self.cacheGeo_ = {}
         self.cacheGeoGrid_ = {}
+        if self.geoLog_:
+            self.geoPlan_, self.geoLog_ = self.geoLog_, []
         pf, self.prefetched_ = self.prefetched_, None
         if pf is not None:
             grids, neighs, pdfs, event = pf
@@ -501,6 +509,53 @@ class ConvolutionBuilder(torch.nn.Module):
         biases3v = self._get_variable(convName + '_biases3', (numBlocks, blockSize), dev, zeros)
         return weights, biases, weights2v, biases2v, weights3v, biases3v, nn
 
+    def __prebuild_geometries__(self, ph):
+        """Learned prefetch: every geometry the previous step built over a hierarchy of this name, issued now -- before the
+        first layer of this step -- on side streams. A step whose graph differs simply builds what is missing when it is
+        asked for; a geometry nobody asks for is dropped at the next reset()."""
+        from . import native as _native
+        from . import MCConvModule as _hip_ops
+        plan, name = self.geoPlan_, ph.hierarchyName_
+        levels = len(ph.points_)
+        mn, mx, B = ph.aabbMin_, ph.aabbMax_, ph.batchSize_
+        if int(_hip_ops.PDF_MODE) != 1:
+            return
+        k = 0
+        for (hname, inLevel, outLevel, radius, window, rel, usePDF) in plan:
+            if hname != name or inLevel >= levels or outLevel >= levels:
+                continue
+            keyGrid, keyNeighs, keyPDF = self.__compute_dic_keys__(ph, ph, inLevel, outLevel, radius, window, rel, usePDF)
+            if keyPDF in self.cacheGeo_:
+                continue
+            inPts, inBids = ph.points_[inLevel], ph.batchIds_[inLevel]
+            centres, cBids = ph.points_[outLevel], ph.batchIds_[outLevel]
+            if inPts.shape[0] == 0 or centres.shape[0] == 0 or inPts.requires_grad:
+                continue
+            ok = True
+            for t, dt in ((inPts, torch.float32), (centres, torch.float32), (inBids, torch.int32), (cBids, torch.int32)):
+                if t.dtype != dt or not t.is_contiguous() or not t.is_cuda:
+                    ok = False
+            if not ok:
+                continue
+            nc = _hip_ops._num_cells(mn, mx, B, radius, rel)
+            owner = self.cacheGeoGrid_.get(keyGrid)
+            geo = _native.build_geometry(inPts, inBids, centres, cBids, mn, mx, B, nc, radius, rel, window, usePDF, owner,
+                                         side=k, fork=(k == 0))
+            k += 1
+            geo.uses = 0
+            self.cacheGeo_[keyPDF] = geo
+            self.geoLog_.append((name, inLevel, outLevel, radius, window, rel, usePDF))
+            if owner is None:
+                self.cacheGeoGrid_[keyGrid] = geo
+                self.cacheGrids_[keyGrid] = _LazyEntry(geo, geo.grid)
+                self._trace("sort_points_step1", keyGrid)
+                self._trace("sort_points_step2", keyGrid)
+            self.cacheNeighs_[keyNeighs] = _LazyEntry(geo, geo.neighbors)
+            self.cachePDFs_[keyPDF] = _LazyEntry(geo, geo.pdfs)
+            self._trace("find_neighbors", keyNeighs)
+            if usePDF:
+                self._trace("compute_pdf", keyPDF)
+
     def __native_convolution__(self, convName, inPH, inLevel, inFeatures, inNumFeatures, convRadius, outPH, outLevel,
                                multiFeatureConv, numOutFeatures, KDEWindow, relativeRadius, usePDF, useAVG, keyGrid,
                                keyNeighs, keyPDF):
@@ -510,6 +565,11 @@ class ConvolutionBuilder(torch.nn.Module):
         level is empty, or the features are not rows the library reads in place."""
         from . import native as _native
         from . import MCConvModule as _hip_ops
+        # (a step with a handful of geometries gains nothing: the hops between the streams cost what the overlap saves --
+        # measured: BASELINE cfg1, three lists, 0.93 -> 0.97 ms; cfg2, seven, 2.59 -> 2.18)
+        if (not self.cacheGeo_ and self.geoPrefetch_ and len(self.geoPlan_) >= 5 and inPH is outPH and self.prefetched_ is None
+                and not self.cacheGrids_ and _native.side_streams_available()):
+            self.__prebuild_geometries__(inPH)
         geo = self.cacheGeo_.get(keyPDF)
         if geo is None:
             if keyGrid in self.cacheGrids_ and keyGrid not in self.cacheGeoGrid_:
@@ -530,6 +590,8 @@ class ConvolutionBuilder(torch.nn.Module):
                                          usePDF, owner)
             geo.uses = 0
             self.cacheGeo_[keyPDF] = geo
+            if inPH is outPH:
+                self.geoLog_.append((inPH.hierarchyName_, inLevel, outLevel, convRadius, KDEWindow, relativeRadius, usePDF))
             if owner is None:
                 self.cacheGeoGrid_[keyGrid] = geo
                 self.cacheGrids_[keyGrid] = _LazyEntry(geo, geo.grid)

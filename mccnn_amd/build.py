@@ -52,7 +52,7 @@ def build_torch_ext(force=False, verbose=False):
            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-DTORCH_API_INCLUDE_EXTENSION_H"]
     cmd += ["-I" + i for i in inc]
     cmd += ["-L" + tlib, "-L" + LIB_DIR, "-l:" + os.path.basename(LIB), "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch",
-            "-ltorch_python", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+            "-ltorch_python", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -278,6 +278,13 @@ __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStar
 // paid once for both plans). Workgroup (slice, chunk of 16 iterations), wave w takes 4 consecutive iterations: in the
 // forward plan a lane's 4 edges are 64 contiguous bytes of records and 32 of pairs. (One wave per slice walking all its
 // iterations with the set-up arithmetic inline was 260 us per plan on the 100k room.)
+// The lane id read from the hardware again (two VALU instructions) instead of a value kept live -- or spilled -- across a
+// sweep that needs every register.
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 #define MCCNN_FILL_CHUNK 16
 // INL: the records are computed here from the geometry instead of permuted from the edge-order array -- small lists, where
 // the extra launch and buffer of mccnn_edge_records cost more than evaluating every record twice (once per plan).
@@ -587,8 +594,11 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
         const int off = p.sliceOff[slice];
         const int len = (p.sliceOff[slice + 1] - off) >> 6;
         if (len == 0) continue;  // slices beyond the list's last virtual row
-        const int r = p.vrow[slice * 64 + lane];
-        int jr = max(r, 0);
+        // (the row id is looked up AGAIN after the sweep: kept live across it, it -- and the addresses derived from it --
+        // were spilled to scratch around every slice; likewise the lane id is read afresh per slice, so that nothing
+        // derived from it has to survive from one slice to the next)
+        const int lane = fresh_lane();
+        int jr = max(p.vrow[slice * 64 + lane], 0);
         if (IDX) jr = featIdx[jr];  // features and their gradient in the order of the unsorted points (see dw_fwd_rows)
         // (jr dies with the feature load below: the row index of the gradient is looked up AGAIN at the end of the slice --
         // kept live across the sweep it cost five more spilled registers and 16 % of the kernel's time)
@@ -713,7 +723,9 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
                 gb1[l] += v;
             }
         }
-        const int code = p.vcode[slice * 64 + lane];
+        const int slot = slice * 64 + fresh_lane();  // (opaque: not merged with the look-up above the sweep)
+        const int r = p.vrow[slot];
+        const int code = p.vcode[slot];
         if (r >= 0 && code >= 0) {  // a piece of a cut row
             float4* dst = reinterpret_cast<float4*>(scratch + (size_t)code * a.Fin + q * 8);
             dst[0] = make_float4(dF[0], dF[1], dF[2], dF[3]);
@@ -731,6 +743,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_rows(ConvArgs a, RowPlan p, con
     }
     // transposing wave reduction; partial row layout: w1[24] b1[8] w2[64] b2[8] w3[64] b3[8]
     {
+        const int lane = fresh_lane();
         float r2 = wave_reduce64(gw2, lane);
         float r3 = wave_reduce64(gw3, lane);
         float misc[64];

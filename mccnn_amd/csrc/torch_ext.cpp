@@ -11,6 +11,7 @@
 #include <torch/csrc/autograd/functions/utils.h>
 #include <torch/csrc/autograd/saved_variable.h>
 #include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
 
 #include <map>
 #include <memory>
@@ -65,8 +66,50 @@ void give_slot(Tensor t) {
     if (g_slots.size() < 256) g_slots.push_back(std::move(t));
 }
 
+// Side streams for geometry builds issued ahead of their first use (ConvolutionBuilder's learned prefetch): the chains of
+// a step's geometries are independent of each other and of the features, so they run side by side -- each is a dozen
+// small dependent kernels that leave the chip nearly empty -- and the layer that consumes one waits for its event.
+constexpr int kSideStreams = 4;
+hipStream_t side_stream(int k) {
+    static hipStream_t streams[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int i = 0; i < kSideStreams; ++i)
+            if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess) streams[i] = nullptr;
+    });
+    return streams[((k % kSideStreams) + kSideStreams) % kSideStreams];
+}
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// events are pooled: creating and destroying one per geometry cost more than the record and the wait together
+std::mutex g_event_mutex;
+std::vector<hipEvent_t> g_events;
+hipEvent_t take_event() {
+    {
+        std::lock_guard<std::mutex> lk(g_event_mutex);
+        if (!g_events.empty()) {
+            hipEvent_t e = g_events.back();
+            g_events.pop_back();
+            return e;
+        }
+    }
+    hipEvent_t e = nullptr;
+    hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    return e;
+}
+void give_event(hipEvent_t e) {
+    std::lock_guard<std::mutex> lk(g_event_mutex);
+    if (g_events.size() < 256) g_events.push_back(e);
+    else (void)hipEventDestroy(e);
+}
+
 struct Geo {
     mccnn_geometry_t* h = nullptr;
+    hipEvent_t event = nullptr;    // recorded behind a build on a side stream; its consumers wait for it once
+    bool needs_wait = false;
+    int side = -1;                 // index of the side stream the build ran on (-1: the caller's stream)
     Tensor buf, slot;
     std::vector<Tensor> keep, attached;
     std::shared_ptr<Geo> grid_owner;
@@ -74,7 +117,20 @@ struct Geo {
     int64_t e_cap = 0;
     int e = -1;
     int uses = 0;  // layers convolved over this geometry so far (the builder counts)
+    // order `stream` behind the side-stream build (once: every later use of the geometry is on that stream as well)
+    void join(void* stream) {
+        if (needs_wait && event) {
+            hip_check(hipStreamWaitEvent((hipStream_t)stream, event, 0), "hipStreamWaitEvent");
+            needs_wait = false;
+        }
+    }
     ~Geo() {
+        if (event) {
+            // never consumed: the buffers go back to the allocator of the stream they were taken on -- order that
+            // stream behind the build first, or the next owner of the memory could race with it
+            if (needs_wait && buf.defined()) (void)hipStreamWaitEvent(c10::hip::getCurrentHIPStream(buf.device().index()).stream(), event, 0);
+            give_event(event);
+        }
         if (h) mccnn_geometry_destroy(h);
         if (slot.defined() && e >= 0) give_slot(std::move(slot));  // (a total that never arrived keeps its word)
     }
@@ -99,7 +155,8 @@ void check_dev(const Tensor& t, at::ScalarType dt, const char* name) {
 
 std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const Tensor& centres, const Tensor& cbids,
                                     const Tensor& mn, const Tensor& mx, int64_t B, int64_t nc, double radius, bool scale_inv,
-                                    double window, bool use_pdf, int64_t capacity, std::shared_ptr<Geo> grid_from) {
+                                    double window, bool use_pdf, int64_t capacity, std::shared_ptr<Geo> grid_from,
+                                    int64_t side, bool fork) {
     check_dev(pts, at::kFloat, "points");
     check_dev(centres, at::kFloat, "sample points");
     check_dev(bids, at::kInt, "batch ids");
@@ -118,12 +175,42 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
     g->keep = {pts, bids, centres, cbids, mn, mx};
     g->grid_owner = grid_from;
     g->n = n; g->m = m; g->nc = (int)nc; g->B = (int)B; g->e_cap = capacity;
+    void* stream = cur_stream(pts);
+    if (side >= 0) {
+        // a geometry that shares another one's grid runs behind it on the same side stream
+        if (grid_from && grid_from->side >= 0 && grid_from->needs_wait) side = grid_from->side;
+        hipStream_t ss = side_stream((int)side);
+        if (ss) {
+            if (fork) {
+                // the side streams start behind everything the calling stream holds now (the point hierarchy; whatever
+                // used the memory the allocator hands out from here on)
+                static thread_local hipEvent_t fork_ev = nullptr;
+                if (!fork_ev) hip_check(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming), "hipEventCreate");
+                hip_check(hipEventRecord(fork_ev, (hipStream_t)stream), "hipEventRecord");
+                for (int k = 0; k < kSideStreams; ++k) hip_check(hipStreamWaitEvent(side_stream(k), fork_ev, 0), "hipStreamWaitEvent");
+            }
+            // (a grid owner on another side stream -- its build has been joined by the caller's stream already, or it
+            // would have pulled this build onto its own stream above: order this stream behind it without consuming the
+            // owner's one-time join)
+            if (grid_from && grid_from->event && grid_from->side != (int)(((side % kSideStreams) + kSideStreams) % kSideStreams))
+                hip_check(hipStreamWaitEvent(ss, grid_from->event, 0), "hipStreamWaitEvent");
+            g->side = (int)(((side % kSideStreams) + kSideStreams) % kSideStreams);
+            stream = ss;
+        }
+    } else if (grid_from) {
+        grid_from->join(stream);
+    }
     check(mccnn_geometry_build(g->h, pts.data_ptr<float>(), bids.data_ptr<int>(), n, centres.data_ptr<float>(),
                                cbids.data_ptr<int>(), m, mn.data_ptr<float>(), mx.data_ptr<float>(), (int)B, (int)nc,
                                (float)radius, scale_inv ? 1 : 0, (float)window, use_pdf ? 1 : 0, (int)capacity,
                                grid_from ? grid_from->h : nullptr, g->buf.data_ptr(), bytes, g->slot.data_ptr<int>(),
-                               cur_stream(pts)),
+                               stream),
           "geometry_build");
+    if (g->side >= 0) {
+        g->event = take_event();
+        hip_check(hipEventRecord(g->event, (hipStream_t)stream), "hipEventRecord");
+        g->needs_wait = true;
+    }
     return g;
 }
 
@@ -229,6 +316,8 @@ Tensor conv(std::shared_ptr<Geo> geo, const Tensor& feats, const Tensor& w1, con
     Tensor out, saved;
     {
         at::AutoDispatchBelowADInplaceOrView guard;
+        geo->join(cur_stream(feats));
+        if (geo->grid_owner) geo->grid_owner->join(cur_stream(feats));
         long long wsb = 0, svb = 0;
         prepare(*geo, feats, L, 0, L.flags, wsb, svb);
         out = at::empty({geo->m, combin ? fout : (int64_t)L.fin}, feats.options());
@@ -281,10 +370,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
         .def_readonly("e", &Geo::e)
         .def_readonly("grid_owner", &Geo::grid_owner)
         .def_readwrite("uses", &Geo::uses)
+        .def_readonly("side", &Geo::side)
+        .def("join", [](Geo& g, const at::Tensor& like) { g.join(cur_stream(like)); })
         .def("edges", &Geo::edges, py::arg("wait_us") = -1)
         .def("info", &Geo::info);
     mod.def("build_geometry", &build_geometry, py::arg("pts"), py::arg("bids"), py::arg("centres"), py::arg("cbids"),
             py::arg("mn"), py::arg("mx"), py::arg("B"), py::arg("nc"), py::arg("radius"), py::arg("scale_inv"),
-            py::arg("window"), py::arg("use_pdf"), py::arg("capacity"), py::arg("grid_from").none(true));
+            py::arg("window"), py::arg("use_pdf"), py::arg("capacity"), py::arg("grid_from").none(true),
+            py::arg("side") = -1, py::arg("fork") = false);
     mod.def("conv", &conv);
 }

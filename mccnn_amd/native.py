@@ -145,8 +145,15 @@ class Geometry:
         off = addr - owner_buf.data_ptr()
         return owner_buf[off:off + nbytes].view(dtype).view(shape)
 
+    def _join(self):
+        """A build issued on a side stream: whoever READS the arrays through tensor views does so on the current stream."""
+        for g in (self, self.grid_owner):
+            if g is not None and g.core is not None and g.buf is not None:
+                g.core.join(g.buf)
+
     def grid(self):
         """(sortPts [n,3], sortBatchs [n,1], cellIndexs [B,nc,nc,nc,2], index_new_pos [n], inverse [n])"""
+        self._join()
         i = self._info()
         ob = (self.grid_owner or self).buf
         n, nc, B = self.n, self.nc, self.B
@@ -157,22 +164,25 @@ class Geometry:
     def neighbors(self):
         """(startIndexs [m,1], packedNeighs [E,2])"""
         e = self.edges()
+        self._join()
         i = self._info()
         return (self._view(self.buf, i[5], self.m * 4, torch.int32, (self.m, 1)),
                 self._view(self.buf, i[6], e * 8, torch.int32, (e, 2)))
 
     def pdfs(self):
         e = self.edges()
+        self._join()
         i = self._info()
         return self._view(self.buf, i[7], e * 4, torch.float32, (e, 1))
 
 
-def _build_into(g, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, capacity, grid_from):
+def _build_into(g, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, capacity, grid_from,
+                side=-1, fork=False):
     n, m = inPts.shape[0], centres.shape[0]
     if _EXT is not None:
         uses = g.core.uses if g.core is not None else 0
         g.core = _EXT.build_geometry(inPts, inBids, centres, cbids, mn, mx, B, nc, float(radius), bool(scaleInv), float(window),
-                                     bool(usePDF), capacity, grid_from.core if grid_from is not None else None)
+                                     bool(usePDF), capacity, grid_from.core if grid_from is not None else None, side, fork)
         g.core.uses = uses
         g.buf = g.core.buf
         g.grid_owner = grid_from
@@ -203,9 +213,17 @@ def _build_into(g, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleIn
                                    g.slot.data_ptr(), stream_handle()), "geometry_build")
 
 
-def build_geometry(inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, grid_from=None):
-    """Enqueues grid + search + KDE of one convolution geometry on the current stream; no host wait. nc: cells per axis
-    (MCConvModule._num_cells). grid_from: a Geometry over the same points / radius whose grid is shared."""
+def side_streams_available():
+    """Geometry builds on side streams need the torch extension (events and streams live on its side)."""
+    return _EXT is not None
+
+
+def build_geometry(inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, grid_from=None,
+                   side=-1, fork=False):
+    """Enqueues grid + search + KDE of one convolution geometry; no host wait. nc: cells per axis
+    (MCConvModule._num_cells). grid_from: a Geometry over the same points / radius whose grid is shared. side >= 0
+    (torch extension only): the build runs on side stream `side` -- behind everything the current stream holds at the
+    first call that says fork=True -- and the first layer that uses the geometry orders its stream behind it."""
     n, m = inPts.shape[0], centres.shape[0]
     gkey = (inPts.device.index, n, m, float(radius), int(B), bool(scaleInv))
     g = Geometry()
@@ -213,7 +231,7 @@ def build_geometry(inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleIn
     if grid_from is not None and grid_from.grid_owner is not None:
         grid_from = grid_from.grid_owner
     _build_into(g, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF,
-                _capacity_guess(gkey, m), grid_from)
+                _capacity_guess(gkey, m), grid_from, side if _EXT is not None else -1, fork)
     return g
 
 

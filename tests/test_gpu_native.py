@@ -190,3 +190,64 @@ def test_native_path_keeps_the_ops_shape_rules(mc):
             F = torch.rand((len(pts), fin), device="cuda")
             with pytest.raises(InvalidArgumentError):
                 cb.create_convolution("C", ph, 0, F, fin, 0.2, outNumFeatures=fout, multiFeatureConv=combin)
+
+
+def test_learned_geometry_prefetch_on_side_streams(mc):
+    """From the second step on the builder issues ALL geometries of the step at its first create_convolution, on side
+    streams (the list is learned from the previous step). Same outputs and gradients as the first (inline) step bit for
+    bit -- also when the batch changes between steps and when a step asks for a geometry the plan does not hold."""
+    import torch
+    from mccnn_amd import native
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    if not native.side_streams_available():
+        pytest.skip("torch extension not built")
+    layers = [l for l in LAYERS if not l[7]]
+    clouds = [make_cloud(2500, 3, s, "clustered", True) for s in (5, 6)]
+    torch.manual_seed(1)
+    cb = ConvolutionBuilder(KDEWindow=0.25, relativeRadius=True)
+    feats, ogs = {}, {}
+
+    def step(ci, extra=False):
+        pts, bids = clouds[ci]
+        P, Bi = _t(pts), _t(bids)
+        ph = PointHierarchy(P, torch.ones((len(pts), 1), device="cuda"), Bi, [0.1], "PH", 3, True)
+        cb.reset()
+        outs, fts = [], []
+        for (name, lin, lout, fin, fout, combin, radius, _bf) in layers:
+            n = ph.points_[lin].shape[0]
+            f = feats.setdefault((ci, name), 2 * torch.rand((n, fin), device="cuda") - 1).detach().clone().requires_grad_(True)
+            fts.append(f)
+            outs.append(cb.create_convolution(name, ph, lin, f, fin, radius, ph, lout, combin, fout))
+        if extra:   # a geometry no earlier step asked for
+            f = feats.setdefault((ci, "extra"), 2 * torch.rand((ph.points_[1].shape[0], 8), device="cuda") - 1).detach().clone().requires_grad_(True)
+            fts.append(f)
+            outs.append(cb.create_convolution("Extra", ph, 1, f, 8, 0.45, ph, 1, False, 8))
+        for k, o in enumerate(outs):
+            ogs.setdefault((ci, k), 2 * torch.rand(o.shape, device="cuda") - 1)
+        grads = torch.autograd.grad(outs, fts + list(cb.parameters()), [ogs[(ci, k)] for k in range(len(outs))], allow_unused=True)
+        sides = [g.core.side for g in cb.cacheGeo_.values()]
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in outs], [g.detach().clone() for g in grads if g is not None], sides
+
+    ref0 = step(0)
+    assert all(s < 0 for s in ref0[2])                  # nothing to learn from yet: built where they were asked for
+    ref1 = step(1)
+    # learned: issued on side streams, several of them (a list that outgrew the capacity guessed from the other batch is
+    # built again where it is used: the first time a shape is seen)
+    assert sum(1 for s in ref1[2] if s >= 0) >= 3 and len(set(s for s in ref1[2] if s >= 0)) > 1
+    for rep in range(3):
+        for ci, ref in ((0, ref0), (1, ref1)):
+            got = step(ci)
+            assert all(s >= 0 for s in got[2])
+            for a, b in zip(got[0], ref[0]):
+                assert torch.equal(a, b)
+            for a, b in zip(got[1], ref[1]):   # (feature gradients of one-feature layers are summed with float atomics)
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    # a step with one more geometry than the plan holds, then the plain graph again
+    got = step(0, extra=True)
+    assert sum(1 for s in got[2] if s < 0) == 1
+    for a, b in zip(got[0][:len(ref0[0])], ref0[0]):
+        assert torch.equal(a, b)
+    got = step(1)
+    for a, b in zip(got[0], ref1[0]):
+        assert torch.equal(a, b)
