@@ -977,6 +977,12 @@ def poisson_sampling(inPts, inBatchIds, cellIndexs, aabbMin, aabbMax, radius, ba
     return oP, oB, oI
 
 
+def _torch_ext():
+    """The torch extension over the C-ABI (mccnn_amd/lib/_mccnn_torch.so) when it is built and enabled."""
+    from . import native
+    return native._EXT
+
+
 def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batchSize, scaleInv):
     """Geometry of ALL levels of a point hierarchy (MCConvBuilder.py:101-128: sort_points_step1/2 -> poisson_sampling ->
     transform_indexs per level) with ONE host read-back at the end instead of one per level: every level takes its point
@@ -997,6 +1003,18 @@ def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batc
     if cap == 0 or not POISSON_DATAFLOW:
         return None  # an empty cloud, or the single-launch Poisson kernel switched off: the op-by-op chain handles it
     pmode = 2 if POISSON_DATAFLOW == 2 else 1
+    for radius in radiusList:
+        _req(radius > 0.0, op + " expects positive radii")
+    ext = _torch_ext()
+    if ext is not None:
+        # the same sequence from C++ (csrc/torch_ext.cpp): no Python between the levels, sizes through a pinned buffer
+        ncs = [_num_cells(mn, mx, batchSize, r, scaleInv) for r in radiusList]
+        w0 = ext.wait_ns()
+        lv = ext.hierarchy_levels(pts, bids, mn, mx, [float(r) for r in radiusList], ncs, batchSize, bool(scaleInv), pmode)
+        HOST_WAIT_S[0] += (ext.wait_ns() - w0) * 1e-9
+        if not lv:
+            return None
+        return [tuple(x) for x in lv]
     sizes = torch.empty(L + 1, dtype=torch.int32, device=dev)
     sizes[0] = cap
     sizes_ptr = sizes.data_ptr()

@@ -593,6 +593,20 @@ int mccnn_sort_step2_dn(const float* pts, const int* batch_ids, const int* keys,
                            nullptr, cell_indexs, nullptr, ws, ws_bytes, stream, n_dev);
 }
 
+}  // extern "C"
+namespace mccnn {
+// sort_step2_dn that also leaves the inverse permutation (sorted position -> input row): mccnn_hierarchy_level hands it
+// to the Poisson emit kernel, which then writes the transformed indices itself (poisson.hip)
+int sort_step2_dn_inv(const float* pts, const int* batch_ids, const int* keys, const int* new_idx, int n_cap,
+                      const int* n_dev, int batch_size, int num_cells, float* out_pts, int* out_batch_ids,
+                      int* cell_indexs, int* inv_idx, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    if (!n_dev) return MCCNN_E_BADARG;
+    return sort_step2_impl(pts, batch_ids, nullptr, keys, new_idx, n_cap, 0, batch_size, num_cells, out_pts, out_batch_ids,
+                           nullptr, cell_indexs, inv_idx, ws, ws_bytes, stream, n_dev);
+}
+}  // namespace mccnn
+extern "C" {
+
 size_t mccnn_build_grid_workspace_bytes(int n, int batch_size, int num_cells) {
     const size_t a = mccnn_sort_step1_workspace_bytes(n, batch_size, num_cells);
     if (a == 0) return 0;

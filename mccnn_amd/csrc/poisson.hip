@@ -374,12 +374,18 @@ __global__ void poisson_flag_failure(const int* __restrict__ fail, int* __restri
 }
 
 
-// One thread per grid cell: emit its kept points at the cell's canonical output base.
+// One thread per grid cell: emit its kept points at the cell's canonical output base. Optional (one hierarchy level in
+// one call): inv / tIdx -- the sample's index in the level's INPUT order, transform_indexs (sort_gpu.cu:332-362) folded
+// in: tIdx[o] = inv[i]; fail / total -- the failure flag of the single-launch sampling turned into *total = -1 here
+// instead of by a launch of its own.
 __global__ __launch_bounds__(256) void poisson_emit(const float* __restrict__ pts, const int* __restrict__ cells,
                                                     int B, PoissonDims d, const unsigned char* __restrict__ sel,
                                                     const int* __restrict__ slotBase, float* __restrict__ oPts,
-                                                    int* __restrict__ oBids, int* __restrict__ oIdx) {
+                                                    int* __restrict__ oBids, int* __restrict__ oIdx,
+                                                    const int* __restrict__ inv, int* __restrict__ tIdx,
+                                                    const int* __restrict__ fail, int* __restrict__ total) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (fail && t == 0 && *fail) *total = -1;
     int nc = d.nc;
     long long perBatch = (long long)nc * nc * nc;
     if (t >= perBatch * B) return;
@@ -398,9 +404,14 @@ __global__ __launch_bounds__(256) void poisson_emit(const float* __restrict__ pt
         oPts[(size_t)o * 3 + 2] = pts[(size_t)i * 3 + 2];
         oBids[o] = b;
         oIdx[o] = i;
+        if (inv) tIdx[o] = inv[i];
         ++o;
     }
 }
+
+int sort_step2_dn_inv(const float* pts, const int* batch_ids, const int* keys, const int* new_idx, int n_cap,
+                      const int* n_dev, int batch_size, int num_cells, float* out_pts, int* out_batch_ids,
+                      int* cell_indexs, int* inv_idx, void* ws, size_t ws_bytes, mccnn_stream_t stream);  // grid.hip
 
 static long long poisson_slots(int B, int nc) {
     PoissonDims d = poisson_dims(nc);
@@ -425,11 +436,27 @@ size_t mccnn_poisson_sampling_workspace_bytes(int n, int batch_size, int num_cel
            256;  // + per-cell done flags, the failure flag, the phase counters and the occupied-cell lists of the dataflow form
 }
 
+static int poisson_count_impl(const float* sorted_pts, const int* sorted_batch_ids, int n, const int* cell_indexs,
+                              const float* aabb_min, const float* aabb_max, int batch_size, int num_cells, float radius,
+                              int scale_inv, int mode, int* total_dev, void* ws, size_t ws_bytes, mccnn_stream_t stream,
+                              const int** fail_out);
+
 int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batch_ids, int n, const int* cell_indexs,
                                  const float* aabb_min, const float* aabb_max, int batch_size, int num_cells,
                                  float radius, int scale_inv, int mode, int* total_dev, void* ws, size_t ws_bytes,
                                  mccnn_stream_t stream) {
+    return poisson_count_impl(sorted_pts, sorted_batch_ids, n, cell_indexs, aabb_min, aabb_max, batch_size, num_cells, radius,
+                              scale_inv, mode, total_dev, ws, ws_bytes, stream, nullptr);
+}
+
+// fail_out != NULL: the caller turns the failure flag into *total_dev = -1 itself (poisson_emit of the same call chain);
+// *fail_out = the flag's address, or NULL when this mode has none
+static int poisson_count_impl(const float* sorted_pts, const int* sorted_batch_ids, int n, const int* cell_indexs,
+                              const float* aabb_min, const float* aabb_max, int batch_size, int num_cells, float radius,
+                              int scale_inv, int mode, int* total_dev, void* ws, size_t ws_bytes, mccnn_stream_t stream,
+                              const int** fail_out) {
     (void)sorted_batch_ids;
+    if (fail_out) *fail_out = nullptr;
     if (n < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
@@ -475,8 +502,12 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
         MCCNN_LAUNCHED();
         int rc = exclusive_scan_i32(slots, slots, (int)S, total_dev, scanws, s, true);
         if (rc) return rc;
-        poisson_flag_failure<<<1, 1, 0, s>>>(flags + C, total_dev);  // *total_dev = -1: repeat the call with mode 0
-        MCCNN_LAUNCHED();
+        if (fail_out) {
+            *fail_out = flags + C;
+        } else {
+            poisson_flag_failure<<<1, 1, 0, s>>>(flags + C, total_dev);  // *total_dev = -1: repeat the call with mode 0
+            MCCNN_LAUNCHED();
+        }
         return 0;
     }
     for (int ph = 0; ph < 27; ++ph) {
@@ -487,9 +518,20 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
     return exclusive_scan_i32(slots, slots, (int)S, total_dev, scanws, s, true);
 }
 
+static int poisson_fill_impl(const float* sorted_pts, int n, const int* cell_indexs, int batch_size, int num_cells,
+                             int s_count, float* out_pts, int* out_batch_ids, int* out_indexs, void* ws, size_t ws_bytes,
+                             mccnn_stream_t stream, const int* inv, int* t_idx, const int* fail, int* total);
+
 int mccnn_poisson_sampling_fill(const float* sorted_pts, int n, const int* cell_indexs, int batch_size, int num_cells,
                                 int s_count, float* out_pts, int* out_batch_ids, int* out_indexs, void* ws,
                                 size_t ws_bytes, mccnn_stream_t stream) {
+    return poisson_fill_impl(sorted_pts, n, cell_indexs, batch_size, num_cells, s_count, out_pts, out_batch_ids, out_indexs, ws,
+                             ws_bytes, stream, nullptr, nullptr, nullptr, nullptr);
+}
+
+static int poisson_fill_impl(const float* sorted_pts, int n, const int* cell_indexs, int batch_size, int num_cells,
+                             int s_count, float* out_pts, int* out_batch_ids, int* out_indexs, void* ws, size_t ws_bytes,
+                             mccnn_stream_t stream, const int* inv, int* t_idx, const int* fail, int* total) {
     if (n < 0 || s_count < 0 || batch_size <= 0 || num_cells <= 0) return MCCNN_E_BADARG;
     if (n == 0 || s_count == 0) return 0;
     if (!sorted_pts || !cell_indexs || !out_pts || !out_batch_ids || !out_indexs) return MCCNN_E_BADARG;
@@ -503,7 +545,7 @@ int mccnn_poisson_sampling_fill(const float* sorted_pts, int n, const int* cell_
     PoissonDims d = poisson_dims(num_cells);
     long long cellsTotal = (long long)batch_size * num_cells * num_cells * num_cells;
     poisson_emit<<<ceil_div(cellsTotal, 256), 256, 0, s>>>(sorted_pts, cell_indexs, batch_size, d, sel, slots, out_pts,
-                                                           out_batch_ids, out_indexs);
+                                                           out_batch_ids, out_indexs, inv, t_idx, fail, total);
     MCCNN_LAUNCHED();
     return 0;
 }
@@ -542,16 +584,19 @@ int mccnn_hierarchy_level(const float* pts, const int* batch_ids, const float* a
     if (!keys || !w1 || !w2 || !wp || !wt) return MCCNN_E_WORKSPACE;
     int rc = mccnn_sort_step1_dn(pts, batch_ids, aabb_min, aabb_max, n_cap, n_dev, batch_size, num_cells, keys, new_idx, w1, b1, stream);
     if (rc) return rc;
-    rc = mccnn_sort_step2_dn(pts, batch_ids, keys, new_idx, n_cap, n_dev, batch_size, num_cells, sorted_pts, sorted_batch_ids,
-                             cell_indexs, w2, b2, stream);
+    // three launches less per level than the op chain: the second sort step leaves the inverse permutation (in the
+    // transform's own scratch), and the emit kernel of the sampling writes the transformed indices (transform_indexs:
+    // inv[sampled index]) and turns a timed-out wait into *s_dev = -1 -- no invert / map / flag kernels of their own
+    int* inv = reinterpret_cast<int*>(wt);
+    rc = sort_step2_dn_inv(pts, batch_ids, keys, new_idx, n_cap, n_dev, batch_size, num_cells, sorted_pts, sorted_batch_ids,
+                           cell_indexs, inv, w2, b2, stream);
     if (rc) return rc;
-    rc = mccnn_poisson_sampling_count(sorted_pts, sorted_batch_ids, n_cap, cell_indexs, aabb_min, aabb_max, batch_size, num_cells,
-                                      radius, scale_inv, mode, s_dev, wp, bp, stream);
+    const int* fail = nullptr;
+    rc = poisson_count_impl(sorted_pts, sorted_batch_ids, n_cap, cell_indexs, aabb_min, aabb_max, batch_size, num_cells, radius,
+                            scale_inv, mode, s_dev, wp, bp, stream, &fail);
     if (rc) return rc;
-    rc = mccnn_poisson_sampling_fill(sorted_pts, n_cap, cell_indexs, batch_size, num_cells, n_cap, out_pts, out_batch_ids,
-                                     out_indexs, wp, bp, stream);
-    if (rc) return rc;
-    return mccnn_transform_indexs_dn(out_indexs, n_cap, s_dev, new_idx, n_cap, n_dev, transformed_indexs, wt, bt, stream);
+    return poisson_fill_impl(sorted_pts, n_cap, cell_indexs, batch_size, num_cells, n_cap, out_pts, out_batch_ids, out_indexs,
+                             wp, bp, stream, inv, transformed_indexs, fail, s_dev);
 }
 
 }  // extern "C"

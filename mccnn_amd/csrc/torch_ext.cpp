@@ -13,6 +13,8 @@
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -348,6 +350,74 @@ Tensor conv(std::shared_ptr<Geo> geo, const Tensor& feats, const Tensor& w1, con
     return out;
 }
 
+std::atomic<long long> g_wait_ns{0};  // host time spent waiting for the level sizes (diagnostics: wait_ns())
+
+// Geometry of ALL levels of a point hierarchy (MCConvBuilder.py:101-128 per level: sort_points_step1/2 -> poisson_sampling
+// -> transform_indexs) with device-side point counts and ONE read-back of the level sizes at the end: the C++ form of
+// MCConvModule.point_hierarchy_levels (one library call per level, two allocations, no Python in between).
+// -> per level (sampledPts [S,3], sampledBatchIds [S,1], sampledIndexs [S], transformedIndexs [S]); an empty vector when a
+// wait of the single-launch Poisson kernel timed out (the caller then runs the op-by-op chain).
+std::vector<std::vector<Tensor>> hierarchy_levels(const Tensor& pts, const Tensor& bids, const Tensor& mn, const Tensor& mx,
+                                                  const std::vector<double>& radii, const std::vector<int64_t>& ncs,
+                                                  int64_t B, bool scale_inv, int64_t pmode) {
+    check_dev(pts, at::kFloat, "points");
+    check_dev(bids, at::kInt, "batch ids");
+    check_dev(mn, at::kFloat, "aabb_min");
+    check_dev(mx, at::kFloat, "aabb_max");
+    const int L = (int)radii.size();
+    const int cap = (int)pts.size(0);
+    TORCH_CHECK(L > 0 && (int)ncs.size() == L && cap > 0, "hierarchy_levels: bad arguments");
+    void* st = cur_stream(pts);
+    auto iopt = pts.options().dtype(at::kInt);
+    Tensor sizes = at::empty({L + 1}, iopt);
+    hip_check(hipMemcpyAsync(sizes.data_ptr(), &cap, sizeof(int), hipMemcpyHostToDevice, (hipStream_t)st), "hipMemcpyAsync");
+    const int64_t ca = (cap + 63) / 64 * 64;  // 256-byte aligned pieces (the cell table is written as int2)
+    std::vector<Tensor> ints(L), flts(L);
+    const float* cur_pts = pts.data_ptr<float>();
+    const int* cur_bids = bids.data_ptr<int>();
+    int* sz = sizes.data_ptr<int>();
+    for (int l = 0; l < L; ++l) {
+        const int nc = (int)ncs[l];
+        const size_t wsb = mccnn_hierarchy_level_workspace_bytes(cap, (int)B, nc);
+        TORCH_CHECK(wsb > 0, "PointHierarchy: batch_size * num_cells^3 does not fit 32-bit keys");
+        Tensor& ws = scratch(wsb, pts, st);
+        // index_new_pos | sorted batch ids | oB | oI | ti | cell table          and          sorted points | sampled points
+        ints[l] = at::empty({5 * ca + 2 * B * nc * nc * nc}, iopt);
+        flts[l] = at::empty({6 * ca}, pts.options());
+        int* bi = ints[l].data_ptr<int>();
+        float* bf = flts[l].data_ptr<float>();
+        check(mccnn_hierarchy_level(cur_pts, cur_bids, mn.data_ptr<float>(), mx.data_ptr<float>(), cap, sz + l, (int)B, nc,
+                                    (float)radii[l], scale_inv ? 1 : 0, (int)pmode, bi, bf, bi + ca, bi + 5 * ca, bf + 3 * ca,
+                                    bi + 2 * ca, bi + 3 * ca, bi + 4 * ca, sz + l + 1, ws.data_ptr(), (size_t)ws.numel(), st),
+              "hierarchy_level");
+        cur_pts = bf + 3 * ca;
+        cur_bids = bi + 2 * ca;
+    }
+    // the ONE read-back: every level's sample count
+    static thread_local Tensor host;
+    if (!host.defined() || host.numel() < L + 1) host = at::empty({L + 65}, at::TensorOptions().dtype(at::kInt).pinned_memory(true));
+    hip_check(hipMemcpyAsync(host.data_ptr(), sz, (size_t)(L + 1) * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)st), "hipMemcpyAsync");
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        hip_check(hipStreamSynchronize((hipStream_t)st), "hipStreamSynchronize");
+        g_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+                            std::memory_order_relaxed);
+    }
+    const int* hs = host.data_ptr<int>();
+    std::vector<std::vector<Tensor>> out;
+    for (int l = 1; l <= L; ++l)
+        if (hs[l] < 0) return out;
+    for (int l = 0; l < L; ++l) {
+        const int64_t sN = hs[l + 1];
+        Tensor oP = flts[l].narrow(0, 3 * ca, 3 * sN).view({sN, 3});
+        Tensor oB = ints[l].narrow(0, 2 * ca, sN).view({sN, 1});
+        Tensor oI = ints[l].narrow(0, 3 * ca, sN);
+        Tensor ti = ints[l].narrow(0, 4 * ca, sN);
+        out.push_back({oP, oB, oI, ti});
+    }
+    return out;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
@@ -379,4 +449,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
             py::arg("window"), py::arg("use_pdf"), py::arg("capacity"), py::arg("grid_from").none(true),
             py::arg("side") = -1, py::arg("fork") = false);
     mod.def("conv", &conv);
+    mod.def("hierarchy_levels", &hierarchy_levels, py::call_guard<py::gil_scoped_release>());
+    mod.def("wait_ns", [] { return (long long)g_wait_ns.load(std::memory_order_relaxed); });
 }
