@@ -130,6 +130,15 @@ __device__ __forceinline__ void pool_offset(int o, int& dx, int& dy, int& dz) {
     dz = (int)((v >> 4) & 3) - 1;
 }
 
+// Workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only): hand every XCD one CONTIGUOUS run of
+// tiles. Tiles follow the cell-coherent visiting order, so an XCD then works on one region of space and its private L2
+// holds that region's points and cell ranges once -- with the default interleaving every one of the 8 L2s pulled the
+// whole point set through the fabric (22 + 28 MB fetched for 3 MB of inputs on the 100k room). Bijective for any n.
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
 // every kernel clamps a batch id before it indexes a per-cloud table (mccnn_check_batch_ids reports invalid ids)
 __device__ __forceinline__ int clamp_batch(int b, int B) { return max(0, min(b, B - 1)); }
 

@@ -29,9 +29,9 @@ constexpr int SELL_SIGMA = 1024;
 // row leave their partial sums in a scratch row each; a small pass adds them in order (deterministic).
 constexpr int ROWS_L = 128;  // longest virtual row; lists with few rows use shorter ones (plan_sizes) to fill the chip
 
-// Workgroup ids are handed to the 8 XCDs round-robin (id % 8): logical index with every XCD owning one contiguous
-// eighth of [0, grid). grid must be a multiple of 8 (the launchers pad; surplus indices exit).
-__device__ __forceinline__ int xcd_contiguous(int b, int grid) { return (b & 7) * (grid >> 3) + (b >> 3); }
+// (Workgroup ids are handed to the 8 XCDs round-robin, id % 8: xcd_contiguous() of common.h gives the logical index with
+// every XCD owning one contiguous run of [0, grid) -- a bijection for any grid size; the launchers here still pad the
+// grid to a multiple of 8 and surplus indices exit.)
 
 struct RowPlan {
     const int* vrow;      // [64 S] row id of (slice, lane), -1 = padding lane

@@ -58,15 +58,7 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 #define MCCNN_NW_ROUNDS 8
 #endif
 
-// Workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only): hand every XCD one CONTIGUOUS run of
-// tiles. Tiles follow the cell-coherent visiting order, so an XCD then works on one region of space and its private L2
-// holds that region's points and cell ranges once -- with the default interleaving every one of the 8 L2s pulled the
-// whole point set through the fabric (22 + 28 MB fetched for 3 MB of inputs on the 100k room). Bijective for any n.
-__device__ __forceinline__ int xcd_contiguous(int b, int n) {
-    const int q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
-
+// (xcd_contiguous: common.h)
 // MODE 0 = count: hits per centre, and the ballot of every 64-candidate round is saved (`masks`).
 // MODE 1 = fill: writes the (j, i) rows at startIdx[i]. Windows whose rounds fit the saved masks are a pure
 //          compaction -- no point is loaded and no distance evaluated a second time; larger windows are searched again.

@@ -377,6 +377,40 @@ def test_poisson_dataflow_and_phased_forms_agree(mc, oracle):
             assert np.array_equal(outs[0][k], outs[1][k])
 
 
+def test_poisson_dataflow_stress_on_a_large_fine_grid(mc, oracle):
+    """The single-launch sampling hands selection bytes between cells of different XCDs through relaxed agent-scope
+    atomics ordered by s_waitcnt (no L2-wide fences). Stress: BASELINE cfg3's finest level -- 131 072
+    points in 16 x 40^3 = 1.02 M cells, thousands of dependent cells in flight -- ten times in a row beside other work on
+    the GPU; every run must give the phased form's (and the oracle's) sample set and order."""
+    import torch
+    from mccnn_amd.workloads import modelnet_like
+    pts, bids = modelnet_like(8192, 16, 47)
+    B, radius = 16, 0.025
+    P, Bi = _wrap(pts), _wrap(bids)
+    mn, mx = mc.compute_aabb(P, Bi, B, True)
+    keys, idx = mc.sort_points_step1(P, Bi, mn, mx, B, radius, True)
+    feats = torch.zeros((len(pts), 1), device="cuda")
+    sP, sB, _, cells = mc.sort_points_step2(P, Bi, feats, keys, idx, mn, mx, B, radius, True)
+    omn, omx = oracle.compute_aabb(pts, bids, B, True)
+    ok, oi = oracle.sort_points_step1(pts, bids, omn, omx, B, radius, True)
+    osp, osb, _, ocl = oracle.sort_points_step2(pts, bids, np.zeros((len(pts), 1), np.float32), ok, oi, omn, omx, B, radius, True)
+    rp, rb, ri = oracle.poisson_sampling(osp, osb, ocl, omn, omx, radius, B, True)
+    mc.POISSON_DATAFLOW = False
+    try:
+        pp, pb, pi = mc.poisson_sampling(sP, sB, cells, mn, mx, radius, B, True)
+    finally:
+        mc.POISSON_DATAFLOW = True
+    assert np.array_equal(_unwrap(pi), ri) and np.array_equal(_unwrap(pp), rp)
+    before = mc.POISSON_FALLBACKS
+    noise = torch.rand((4096, 4096), device="cuda")
+    for rep in range(10):
+        noise = noise @ noise.t() * 1e-4      # uneven load beside the sampling
+        dp, db, di = mc.poisson_sampling(sP, sB, cells, mn, mx, radius, B, True)
+        assert torch.equal(di, pi) and torch.equal(dp, pp) and torch.equal(db, pb), rep
+    assert mc.POISSON_FALLBACKS == before      # ... and by the single-launch form, not its fallback
+    torch.cuda.synchronize()
+
+
 def test_poisson_timeout_falls_back_to_phased_form(mc, oracle):
     """The dataflow kernel relies on earlier-phase cells finishing while later ones wait (bounded spin). Mode 2 removes
     the spin altogether: a cell whose predecessor is not done yet raises the failure flag, the count reports -1 and the

@@ -34,6 +34,7 @@ for cfg in cfg0 cfg1 cfg2 cfg3 cfg4; do
     keep $cfg
 done
 
-python bench.py > $DST/${ROUND}_bench.json 2> gpurun_out/profiles_$ROUND/bench.err
+# the full record (bench_details.json) and the compact line the driver parses (the LAST stdout line)
+python bench.py --details $DST/${ROUND}_bench.json 2> gpurun_out/profiles_$ROUND/bench.err | tail -n 1 > $DST/${ROUND}_bench_line.json
 cp $DST/${ROUND}_* gpurun_out/profiles_$ROUND/
-tail -c 600 $DST/${ROUND}_bench.json
+tail -c 600 $DST/${ROUND}_bench_line.json
