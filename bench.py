@@ -441,7 +441,7 @@ class Workload:
         if dom == "spatial_conv_bwd" and os.path.exists(tfile) and a.points == 100000 and B == 1:
             with open(tfile) as fh:
                 for kname, tr in json.load(fh).items():
-                    if kname.startswith("conv_bwd_mfma") or kname.startswith("f1_bwd_edges"):
+                    if kname.startswith(("conv_bwd_mfma", "f1_bwd_edges", "dw_bwd_rows")):
                         roofline["traffic"] = int(tr["bytes"])
                         roofline["traffic_source"] = "profiles/" + os.path.basename(tfile)
         return roofline, breakdown
@@ -716,7 +716,7 @@ def mfma_busy_from_profile(layer):
     for name, rec in ks.items():
         if "mfma_busy" not in rec:
             continue
-        if name.startswith(("f1_fwd_edges", "conv_stream")) and "fwd" not in out:
+        if name.startswith(("f1_fwd_edges", "conv_stream", "dw_fwd")) and "fwd" not in out:
             out["fwd"] = {"kernel": name.split("(")[0][:60], "busy": rec["mfma_busy"]}
         if name.startswith(("f1_bwd_edges", "conv_bwd_mfma", "dw_bwd")) and "bwd" not in out:
             out["bwd"] = {"kernel": name.split("(")[0][:60], "busy": rec["mfma_busy"]}
