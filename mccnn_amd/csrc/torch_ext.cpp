@@ -15,7 +15,12 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <deque>
+#include <functional>
 #include <map>
+#include <thread>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -107,11 +112,68 @@ void give_event(hipEvent_t e) {
     else (void)hipEventDestroy(e);
 }
 
+// The launches of a side-stream build are ISSUED by a helper thread: a step's geometries are a dozen launches each
+// (~35 us of host time), and the calling thread has the layers to issue. One thread, jobs in order (a geometry that
+// shares another one's grid is queued behind it). MCCNN_ISSUE_THREAD=0: the calling thread issues them itself.
+class Issuer {
+public:
+    static Issuer& get() {
+        static Issuer inst;
+        return inst;
+    }
+    static bool enabled() {
+        static const bool on = !(getenv("MCCNN_ISSUE_THREAD") && std::string(getenv("MCCNN_ISSUE_THREAD")) == "0");
+        return on;
+    }
+    void push(std::function<void()> job) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (!started_) {
+                th_ = std::thread([this] { run(); });
+                started_ = true;
+            }
+            q_.push_back(std::move(job));
+        }
+        cv_.notify_one();
+    }
+    ~Issuer() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (started_ && th_.joinable()) th_.join();
+    }
+
+private:
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                job = std::move(q_.front());
+                q_.pop_front();
+            }
+            job();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> q_;
+    std::thread th_;
+    bool started_ = false, stop_ = false;
+};
+
 struct Geo {
     mccnn_geometry_t* h = nullptr;
+    std::atomic<int> issued{1};    // 0 while the helper thread has not issued this geometry's build yet
+    int build_rc = 0;
     hipEvent_t event = nullptr;    // recorded behind a build on a side stream; its consumers wait for it once
     bool needs_wait = false;
     int side = -1;                 // index of the side stream the build ran on (-1: the caller's stream)
+    void* alloc_stream = nullptr;  // the stream the buffers were allocated on (the caller's at build time)
     Tensor buf, slot;
     std::vector<Tensor> keep, attached;
     std::shared_ptr<Geo> grid_owner;
@@ -119,31 +181,54 @@ struct Geo {
     int64_t e_cap = 0;
     int e = -1;
     int uses = 0;  // layers convolved over this geometry so far (the builder counts)
+    void wait_issued_nothrow() {
+        int spins = 0;
+        while (!issued.load(std::memory_order_acquire))
+            if (++spins > 2000) std::this_thread::yield();
+    }
+    // the build's launches (and its event record) have been issued: nothing of the handle is touched before
+    void wait_issued() {
+        if (!issued.load(std::memory_order_acquire)) {
+            int spins = 0;
+            while (!issued.load(std::memory_order_acquire))
+                if (++spins > 2000) std::this_thread::yield();
+        }
+        if (build_rc) {
+            const int rc = build_rc;
+            build_rc = 0;
+            check(rc, "geometry_build");
+        }
+    }
     // order `stream` behind the side-stream build (once: every later use of the geometry is on that stream as well)
     void join(void* stream) {
+        wait_issued();
         if (needs_wait && event) {
             hip_check(hipStreamWaitEvent((hipStream_t)stream, event, 0), "hipStreamWaitEvent");
             needs_wait = false;
         }
     }
     ~Geo() {
+        wait_issued_nothrow();
         if (event) {
             // never consumed: the buffers go back to the allocator of the stream they were taken on -- order that
             // stream behind the build first, or the next owner of the memory could race with it
-            if (needs_wait && buf.defined()) (void)hipStreamWaitEvent(c10::hip::getCurrentHIPStream(buf.device().index()).stream(), event, 0);
+            // (this destructor may run on the helper thread: the allocation stream is the one remembered at build time)
+            if (needs_wait && buf.defined() && build_rc == 0) (void)hipStreamWaitEvent((hipStream_t)alloc_stream, event, 0);
             give_event(event);
         }
         if (h) mccnn_geometry_destroy(h);
         if (slot.defined() && e >= 0) give_slot(std::move(slot));  // (a total that never arrived keeps its word)
     }
     int edges(int wait_us) {
+        wait_issued();
         if (e < 0 && h) {
             const int v = mccnn_geometry_edges(h, wait_us);
             if (v >= 0) e = v;
         }
         return e;
     }
-    std::vector<int64_t> info() const {
+    std::vector<int64_t> info() {
+        wait_issued();
         long long out[16];
         check(mccnn_geometry_info(h, out), "geometry_info");
         return std::vector<int64_t>(out, out + 16);
@@ -178,6 +263,7 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
     g->grid_owner = grid_from;
     g->n = n; g->m = m; g->nc = (int)nc; g->B = (int)B; g->e_cap = capacity;
     void* stream = cur_stream(pts);
+    g->alloc_stream = stream;
     if (side >= 0) {
         // a geometry that shares another one's grid runs behind it on the same side stream
         if (grid_from && grid_from->side >= 0 && grid_from->needs_wait) side = grid_from->side;
@@ -194,14 +280,42 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
             // (a grid owner on another side stream -- its build has been joined by the caller's stream already, or it
             // would have pulled this build onto its own stream above: order this stream behind it without consuming the
             // owner's one-time join)
-            if (grid_from && grid_from->event && grid_from->side != (int)(((side % kSideStreams) + kSideStreams) % kSideStreams))
+            if (grid_from && grid_from->event && grid_from->side != (int)(((side % kSideStreams) + kSideStreams) % kSideStreams)) {
+                grid_from->wait_issued();
                 hip_check(hipStreamWaitEvent(ss, grid_from->event, 0), "hipStreamWaitEvent");
+            }
             g->side = (int)(((side % kSideStreams) + kSideStreams) % kSideStreams);
             stream = ss;
         }
     } else if (grid_from) {
         grid_from->join(stream);
     }
+    if (g->side >= 0 && Issuer::enabled()) {
+        // the helper thread issues the launches and records the event; whoever touches the geometry waits for `issued`
+        g->event = take_event();
+        g->needs_wait = true;
+        g->issued.store(0, std::memory_order_release);
+        const float* p0 = pts.data_ptr<float>();
+        const int* p1 = bids.data_ptr<int>();
+        const float* p2 = centres.data_ptr<float>();
+        const int* p3 = cbids.data_ptr<int>();
+        const float* p4 = mn.data_ptr<float>();
+        const float* p5 = mx.data_ptr<float>();
+        void* bufp = g->buf.data_ptr();
+        int* slotp = g->slot.data_ptr<int>();
+        const int iB = (int)B, inc = (int)nc, icap = (int)capacity, isi = scale_inv ? 1 : 0, ipdf = use_pdf ? 1 : 0;
+        const float fr = (float)radius, fw = (float)window;
+        Issuer::get().push([g, grid_from, p0, p1, p2, p3, p4, p5, bufp, slotp, n, m, iB, inc, icap, isi, ipdf, fr, fw, bytes, stream] {
+            if (grid_from) grid_from->wait_issued_nothrow();
+            int rc = mccnn_geometry_build(g->h, p0, p1, n, p2, p3, m, p4, p5, iB, inc, fr, isi, fw, ipdf, icap,
+                                          grid_from ? grid_from->h : nullptr, bufp, bytes, slotp, stream);
+            if (rc == 0 && hipEventRecord(g->event, (hipStream_t)stream) != hipSuccess) rc = (int)hipErrorUnknown;
+            g->build_rc = rc;
+            g->issued.store(1, std::memory_order_release);
+        });
+        return g;
+    }
+    if (grid_from) grid_from->wait_issued();
     check(mccnn_geometry_build(g->h, pts.data_ptr<float>(), bids.data_ptr<int>(), n, centres.data_ptr<float>(),
                                cbids.data_ptr<int>(), m, mn.data_ptr<float>(), mx.data_ptr<float>(), (int)B, (int)nc,
                                (float)radius, scale_inv ? 1 : 0, (float)window, use_pdf ? 1 : 0, (int)capacity,
