@@ -103,7 +103,7 @@ def get_block_size():
 # ---------------------------------------------------------------------------------------------
 # Visiting-order hints for find_neighbors. The op surface of the reference has no such argument, so the shim
 # remembers, per point tensor, a permutation that walks the points cell by cell: for the points a grid was built
-# from it is the inverse of index_new_pos, for Poisson samples the argsort of their indices in the sorted list.
+# from it is the inverse of index_new_pos (Poisson samples get theirs from the native path's counting sort, csrc/exec.hip).
 # A hint only changes the order in which GPU threads visit the centres (speed), never the result.
 _ORDER_HINTS = {}
 
@@ -146,10 +146,6 @@ def _order_hint(points):
                   "invert_permutation")
             ent[2] = inv
         else:
-            # "sorted_pos" (Poisson samples: their positions in the sampling grid's sorted list). The op-by-op surface has
-            # no cell-coherent order for them without a sort of its own; the native path (csrc/exec.hip) derives one from
-            # the SEARCH grid with the library's counting sort (sort_step1 on the centres + invert_permutation). Here the
-            # centres are visited in the order given -- results never depend on it.
             return None
     return ent[2]
 
@@ -973,7 +969,6 @@ def poisson_sampling(inPts, inBatchIds, cellIndexs, aabbMin, aabbMax, radius, ba
     oI = torch.empty(s, dtype=torch.int32, device=p.device)
     check(lib.mccnn_poisson_sampling_fill(ptr(p), n, ptr(cells), batchSize, nc, s, ptr(oP), ptr(oB), ptr(oI), ptr(ws),
                                           ws.numel(), stream_handle()), "poisson_sampling(fill)")
-    _remember_order(oP, "sorted_pos", oI)
     return oP, oB, oI
 
 
@@ -1050,7 +1045,6 @@ def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batc
     out = []
     for (oP, oB, oI, ti), s in zip(levels, host[1:]):
         sp, sb, si_, t_ = oP[:s], oB[:s], oI[:s], ti[:s]
-        _remember_order(sp, "sorted_pos", si_)
         out.append((sp, sb, si_, t_))
     return out
 

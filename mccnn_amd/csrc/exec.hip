@@ -215,8 +215,6 @@ int* tl_perm(const mccnn_geometry* g) { return reinterpret_cast<int*>(g->tl_buf 
 int ensure_tlist(mccnn_geometry* g, int e, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
     if (g->tl_built) return 0;
     if (!g->tl_buf || g->tl_bytes < tlist_bytes(g->n, e)) return MCCNN_E_WORKSPACE;
-    const mccnn_geometry* go = grid_owner(g);
-    (void)go;
     int rc = mccnn_transpose_neighbors(g->packed, e, g->n, tl_start(g), tl_perm(g), ws, ws_bytes, stream);
     if (rc) return rc;
     g->tl_built = true;

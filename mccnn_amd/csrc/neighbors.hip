@@ -32,7 +32,7 @@ __device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centre
 }
 
 // One wave per 8 consecutive centres of the visiting order (`order`, identity when null; a cell-coherent order --
-// the inverse sort permutation / argsort of the Poisson indices -- makes neighbouring centres share a cell, and never
+// the inverse sort permutation, or the centres' own counting-sort order in this grid -- makes neighbouring centres share a cell, and never
 // changes results). Centres of one grid cell share their 27-cell window: the
 // wave stages the window's candidates ONCE in LDS (canonical order: table order of find_neighbors.cu:282-291, ascending
 // j inside a cell; the neighbour index travels in the .w lane of the staged point), then tests every centre of that
