@@ -133,6 +133,9 @@ class Workload:
         self.params = []
         self.pipeline = False
         self.skip_allreduce = False
+        from mccnn_amd import native as _native
+        self.native_prefetch = bool(self.builder.native_ and _native.side_streams_available()
+                                    and os.environ.get("MCCNN_NATIVE_PREFETCH", "1") != "0")
         self.out = self.step()  # creates the variables (strictly sequential step)
         self.params = list(self.builder.parameters())
         ok = not getattr(args, "no_pipeline", False)
@@ -152,6 +155,7 @@ class Workload:
             self.skip_allreduce = False
             self.pipeline = False
             self.builder.prefetched_ = None
+            self.builder.prefetchedGeo_ = {}
             torch.cuda.synchronize()
         if self.dist_on:
             flag = torch.tensor([1.0 if ok else 0.0], device=device)
@@ -169,12 +173,22 @@ class Workload:
         self.F.grad = None
         for p in self.params:
             p.grad = None
+        early = self.pipeline and self.native_prefetch
+        mid = early and os.environ.get("MCCNN_PF_PLACE", "0") == "1"  # (A/B: between forward and backward -- measured slower)
+        if early and not mid:
+            # geometry of the NEXT batch (grid build, neighbour search, KDE: it depends on the points only) on a side
+            # stream, under the convolution kernels of THIS batch; the next reset() installs it. On the native path the
+            # side stream forks behind what the calling stream holds at the call, so the call comes before this batch's
+            # convolutions are launched (ConvolutionBuilder.__prefetch_native__)
+            self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window, transposed=not self.combin)
         out = self.builder.create_convolution("Conv", self.ph, 0, self.F, self.fin, a.radius, outNumFeatures=self.fout,
                                               multiFeatureConv=self.combin, KDEWindow=a.window)
+        if mid:
+            self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window, transposed=not self.combin)
         out.backward(self.OG)
-        if self.pipeline:
-            # geometry of the NEXT batch (grid build, neighbour search, KDE: it depends on the points only) on a side
-            # stream, under the convolution kernels just launched; the next reset() installs it
+        if self.pipeline and not early:
+            # (op-by-op prefetch, MCCNN_NATIVE=0 / no torch extension: its side stream waits for the hierarchy's and the
+            # last reset()'s events only, and its host work is better spent after this batch's launches)
             self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window, transposed=not self.combin)
         if self.dist_on and not self.skip_allreduce:
             if self.bucket is None:  # the variables exist after the first create_convolution

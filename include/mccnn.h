@@ -455,6 +455,13 @@ int mccnn_geometry_info(const mccnn_geometry_t* g, long long out[16]);
  * as long as the geometry: what = 1 forward row plan, 2 transposed row plan, 4 transposed neighbour list, 8 per-edge
  * records. mccnn_conv_prepare says which are missing and how large they are. */
 int mccnn_geometry_attach(mccnn_geometry_t* g, int what, void* buffer, size_t bytes);
+/* Pieces built ahead of the layers that need them (the transposed list and the transposed row plan of a depth-wise
+ * layer's backward pass on a side stream, under the forward passes): piece_bytes waits for E and gives the size of the
+ * buffer to attach for ONE piece (what = 1, 2, 4 or 8) and the scratch its build needs; prebuild builds the attached
+ * pieces named by the mask `what` (row plans need their records / transposed list attached as mccnn_conv_prepare would
+ * ask; avg: the flag of the layers that will use the plans). */
+int mccnn_geometry_piece_bytes(mccnn_geometry_t* g, int what, long long* bytes, long long* ws_bytes);
+int mccnn_geometry_prebuild(mccnn_geometry_t* g, int what, int avg, void* ws, size_t ws_bytes, mccnn_stream_t stream);
 /* One layer over a geometry: SpatialConv / SpatialConvGrad INCLUDING sort_features / its gradient
  * (MCConvModuleSrc:35-45,70-81). feats [n, num_in_feats] and feat_grad are rows of the UNSORTED points (f32, or bf16
  * with bf16 != 0: depth-wise layers, num_in_feats % 8 == 0); out [m, combin ? num_out_feats : num_in_feats].

@@ -224,6 +224,7 @@ class ConvolutionBuilder(torch.nn.Module):
         self.geoPrefetch_ = os.environ.get("MCCNN_GEO_PREFETCH", "1") != "0"
         self.geoLog_ = []
         self.geoPlan_ = []
+        self.prefetchedGeo_ = {}    # prefetch_geometry() on the native path: keyPDF -> (Geometry, keyGrid, keyNeighs, usePDF, transposed)
         self.multiFeatureConvs_ = multiFeatureConvs
         self.KDEWindow_ = KDEWindow
         self.relativeRadius_ = relativeRadius
@@ -301,6 +302,8 @@ class ConvolutionBuilder(torch.nn.Module):
         self.cacheGeoGrid_ = {}
         if self.geoLog_:
             self.geoPlan_, self.geoLog_ = self.geoLog_, []
+        if self.prefetchedGeo_:
+            self.__install_prefetched_geometries__()
         pf, self.prefetched_ = self.prefetched_, None
         if pf is not None:
             grids, neighs, pdfs, event = pf
@@ -406,6 +409,9 @@ class ConvolutionBuilder(torch.nn.Module):
         mn, mx, B = inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_, inPointHierarchy.batchSize_
         if not pts.is_cuda:
             return  # host tensors (a CPU checker behind `ops=`): nothing to overlap, create_convolution computes inline
+        if self.__prefetch_native__(inPointHierarchy, inPointLevel, convRadius, outPH, outLevel, currKDEWindow,
+                                    currRelativeRadius, currUsePDF, keyGrid, keyNeighs, keyPDF, transposed):
+            return
         if self.sideStream_ is None:
             self.sideStream_ = torch.cuda.Stream(device=pts.device)
         pf = self.prefetched_
@@ -508,6 +514,62 @@ class ConvolutionBuilder(torch.nn.Module):
         self._add_to_collection(self.decayLossCollection_, weights3v)
         biases3v = self._get_variable(convName + '_biases3', (numBlocks, blockSize), dev, zeros)
         return weights, biases, weights2v, biases2v, weights3v, biases3v, nn
+
+    def __prefetch_native__(self, inPH, inLevel, convRadius, outPH, outLevel, KDEWindow, relativeRadius, usePDF, keyGrid,
+                            keyNeighs, keyPDF, transposed):
+        """prefetch_geometry() on the native step executor: the geometry is ONE buffer, allocated on the CALLER's stream and
+        written on a side stream that starts behind everything the caller's stream holds at this moment; the layers that
+        use it order their stream behind its event. No reference counting decides anything: the buffer goes back to the
+        caller's stream's allocator when the geometry dies, after every reader. For the build to run UNDER the current
+        batch's convolutions, call prefetch_geometry() BEFORE they are launched (right after reset()); called after them
+        it is still correct, the build then simply waits for them. Returns False when this call has to take the op-by-op
+        prefetch (no torch extension, points with a gradient, ...)."""
+        from . import native as _native
+        from . import MCConvModule as _hip_ops
+        if not (self.native_ and self.fuseSort_ and getattr(self.ops_, "_ops", 0) is None and _native.side_streams_available()
+                and int(_hip_ops.PDF_MODE) == 1 and self.prefetched_ is None
+                and os.environ.get("MCCNN_NATIVE_PREFETCH", "1") != "0"):
+            return False
+        inPts, inBids = inPH.points_[inLevel], inPH.batchIds_[inLevel]
+        centres, cBids = outPH.points_[outLevel], outPH.batchIds_[outLevel]
+        if inPts.requires_grad or inPts.shape[0] == 0 or centres.shape[0] == 0:
+            return False
+        for t, dt in ((inPts, torch.float32), (centres, torch.float32), (inBids, torch.int32), (cBids, torch.int32)):
+            if t.dtype != dt or not t.is_contiguous() or not t.is_cuda:
+                return False
+        if keyPDF in self.prefetchedGeo_:
+            if transposed:
+                ent = self.prefetchedGeo_[keyPDF]
+                self.prefetchedGeo_[keyPDF] = ent[:4] + (True,)
+            return True
+        mn, mx, B = inPH.aabbMin_, inPH.aabbMax_, inPH.batchSize_
+        nc = _hip_ops._num_cells(mn, mx, B, convRadius, relativeRadius)
+        owner = None
+        for (g2, kG2, _kN2, _u2, _t2) in self.prefetchedGeo_.values():
+            if kG2 == keyGrid and g2.grid_owner is None:
+                owner = g2
+        k = len(self.prefetchedGeo_)
+        geo = _native.build_geometry(inPts, inBids, centres, cBids, mn, mx, B, nc, convRadius, relativeRadius, KDEWindow,
+                                     usePDF, owner, side=k, fork=True, background=True)
+        geo.uses = 0
+        self.prefetchedGeo_[keyPDF] = (geo, keyGrid, keyNeighs, usePDF, bool(transposed))
+        return True
+
+    def __install_prefetched_geometries__(self):
+        """reset(): the geometries prefetch_geometry() built since the last reset() become the cache content; for those
+        asked for with transposed=True the transposed list and the transposed row plan of the depth-wise backward pass are
+        started on their side stream now (their edge totals arrived long ago), under the forward passes to come."""
+        from . import native as _native
+        parked, self.prefetchedGeo_ = self.prefetchedGeo_, {}
+        for keyPDF, (geo, keyGrid, keyNeighs, usePDF, transposed) in parked.items():
+            self.cacheGeo_[keyPDF] = geo
+            if geo.grid_owner is None:
+                self.cacheGeoGrid_[keyGrid] = geo
+                self.cacheGrids_[keyGrid] = _LazyEntry(geo, geo.grid)
+            self.cacheNeighs_[keyNeighs] = _LazyEntry(geo, geo.neighbors)
+            self.cachePDFs_[keyPDF] = _LazyEntry(geo, geo.pdfs)
+            if transposed:
+                geo.prebuild(_native.NEED_PLAN_TR, self.useAVG_, 0, geo.buf)
 
     def __prebuild_geometries__(self, ph):
         """Learned prefetch: every geometry the previous step built over a hierarchy of this name, issued now -- before the

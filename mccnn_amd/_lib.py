@@ -86,6 +86,8 @@ SIGNATURES = {
     "mccnn_geometry_edges": (_i, [_vp, _i]),
     "mccnn_geometry_info": (_i, [_vp, C.POINTER(C.c_longlong)]),
     "mccnn_geometry_attach": (_i, [_vp, _i, _vp, _sz]),
+    "mccnn_geometry_piece_bytes": (_i, [_vp, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "mccnn_geometry_prebuild": (_i, [_vp, _i, _i, _vp, _sz, _vp]),
     "mccnn_conv_prepare": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(C.c_longlong),
                                 C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(_i)]),
     "mccnn_conv_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i] + [_vp] * 6 + [_vp, _vp, _sz, _vp, _sz, _vp]),

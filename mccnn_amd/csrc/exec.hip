@@ -383,6 +383,50 @@ int mccnn_geometry_attach(mccnn_geometry_t* g, int what, void* buffer, size_t by
     }
 }
 
+// Pieces built AHEAD of the layers that need them (ConvolutionBuilder.prefetch_geometry(transposed=True): the transposed
+// list and the transposed row plan of a depth-wise layer's backward pass on a side stream, under the forward passes).
+}  // extern "C"
+namespace {
+size_t piece_bytes(mccnn_geometry* g, int what, int e) {
+    switch (what) {
+        case NEED_PLAN_FWD: return plan_prepare(g, 0, e) ? 0 : (size_t)g->plan[0].total;
+        case NEED_PLAN_TR: return plan_prepare(g, 1, e) ? 0 : (size_t)g->plan[1].total;
+        case NEED_TLIST: return tlist_bytes(g->n, e);
+        case NEED_RECORDS: return al((size_t)e * 16);
+        default: return 0;
+    }
+}
+}  // namespace
+extern "C" {
+
+int mccnn_geometry_piece_bytes(mccnn_geometry_t* g, int what, long long* bytes, long long* ws_bytes) {
+    if (!g || !g->built || !bytes || !ws_bytes) return MCCNN_E_BADARG;
+    const int e = wait_edges(g, -1);
+    if (e < 0) return MCCNN_E_BADARG;
+    if (e > g->e_cap) return MCCNN_E_CAPACITY;
+    *bytes = (long long)piece_bytes(g, what, e);
+    size_t w = 256;
+    if (what == NEED_TLIST) w = mccnn_transpose_neighbors_workspace_bytes(g->n, e);
+    if (what == NEED_PLAN_FWD) w = mccnn_rowplan_build_workspace_bytes(g->m, e, 0);
+    if (what == NEED_PLAN_TR) w = mccnn_rowplan_build_workspace_bytes(g->n, e, 1);
+    *ws_bytes = (long long)(al(w) + 512);
+    return *bytes > 0 ? 0 : MCCNN_E_BADARG;
+}
+
+int mccnn_geometry_prebuild(mccnn_geometry_t* g, int what, int avg, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    if (!g || !g->built || !ws) return MCCNN_E_BADARG;
+    const int e = wait_edges(g, -1);
+    if (e < 0) return MCCNN_E_BADARG;
+    if (e > g->e_cap) return MCCNN_E_CAPACITY;
+    if (e == 0) return 0;
+    avg = avg ? 1 : 0;
+    int rc = 0;
+    if (what & NEED_TLIST) rc = ensure_tlist(g, e, ws, ws_bytes, stream);
+    if (!rc && (what & NEED_PLAN_FWD)) rc = ensure_plan(g, 0, e, avg, ws, ws_bytes, stream);
+    if (!rc && (what & NEED_PLAN_TR)) rc = ensure_plan(g, 1, e, avg, ws, ws_bytes, stream);
+    return rc;
+}
+
 // What one mccnn_conv_forward / _backward call of this layer shape needs from the caller: which pieces the geometry does
 // not hold yet (mask, need_bytes[k] for bit k), the scratch of the call, and (forward) what has to be kept for the
 // backward pass.

@@ -206,6 +206,10 @@ struct Geo {
             hip_check(hipStreamWaitEvent((hipStream_t)stream, event, 0), "hipStreamWaitEvent");
             needs_wait = false;
         }
+        if (plan_wait && plan_event) {
+            hip_check(hipStreamWaitEvent((hipStream_t)stream, plan_event, 0), "hipStreamWaitEvent");
+            plan_wait = false;
+        }
     }
     ~Geo() {
         wait_issued_nothrow();
@@ -216,9 +220,57 @@ struct Geo {
             if (needs_wait && buf.defined() && build_rc == 0) (void)hipStreamWaitEvent((hipStream_t)alloc_stream, event, 0);
             give_event(event);
         }
+        if (plan_event) {
+            if (plan_wait && buf.defined()) (void)hipStreamWaitEvent((hipStream_t)alloc_stream, plan_event, 0);
+            give_event(plan_event);
+        }
         if (h) mccnn_geometry_destroy(h);
         if (slot.defined() && e >= 0) give_slot(std::move(slot));  // (a total that never arrived keeps its word)
     }
+    hipEvent_t plan_event = nullptr;   // recorded behind pieces prebuilt on a side stream (prebuild)
+    bool plan_wait = false;
+    int have = 0;                      // pieces attached so far (mask)
+
+    // Builds the pieces of `what` (1 forward row plan, 2 transposed row plan, 4 transposed list; the per-edge records
+    // come with a plan) on side stream `side_k`, behind this geometry's own build and behind whatever the calling stream
+    // holds now (`like`'s stream: the buffers are allocated there). Waits for the edge total. The layers that use the
+    // geometry order their stream behind the pieces' event.
+    void prebuild(int what, bool avg, int side_k, const Tensor& like) {
+        wait_issued();
+        const int E = edges(-1);
+        if (E <= 0 || E > e_cap) return;   // (an overflowing list is rebuilt by the first layer: nothing to build ahead)
+        if (what & 3) what |= 8;           // a plan permutes the per-edge records
+        if (what & 2) what |= 4;           // the transposed plan is laid out over the transposed list
+        what &= ~have;
+        if (!what) return;
+        void* main_stream = cur_stream(like);
+        hipStream_t ss = side >= 0 ? side_stream(side) : side_stream(side_k);   // behind the build: its own side stream
+        if (!ss) return;
+        size_t wsb = 256;
+        for (int bit = 1; bit <= 8; bit <<= 1) {
+            if (!(what & bit)) continue;
+            long long bytes = 0, w = 0;
+            check(mccnn_geometry_piece_bytes(h, bit, &bytes, &w), "geometry_piece_bytes");
+            Tensor t = at::empty({(int64_t)(bytes > 256 ? bytes : 256)}, like.options().dtype(at::kByte));
+            check(mccnn_geometry_attach(h, bit, t.data_ptr(), (size_t)t.numel()), "geometry_attach");
+            attached.push_back(std::move(t));
+            have |= bit;
+            if ((size_t)w > wsb) wsb = (size_t)w;
+        }
+        Tensor& ws = scratch(wsb, like, (void*)ss);
+        // the side stream starts behind the calling stream (the memory just allocated may have had readers there) and,
+        // being the build's own stream, behind the geometry itself
+        static thread_local hipEvent_t fork_ev = nullptr;
+        if (!fork_ev) hip_check(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming), "hipEventCreate");
+        hip_check(hipEventRecord(fork_ev, (hipStream_t)main_stream), "hipEventRecord");
+        hip_check(hipStreamWaitEvent(ss, fork_ev, 0), "hipStreamWaitEvent");
+        if (event && side < 0) hip_check(hipStreamWaitEvent(ss, event, 0), "hipStreamWaitEvent");
+        check(mccnn_geometry_prebuild(h, what & 7, avg ? 1 : 0, ws.data_ptr(), (size_t)ws.numel(), (void*)ss), "geometry_prebuild");
+        if (!plan_event) plan_event = take_event();
+        hip_check(hipEventRecord(plan_event, ss), "hipEventRecord");
+        plan_wait = true;
+    }
+
     int edges(int wait_us) {
         wait_issued();
         if (e < 0 && h) {
@@ -243,7 +295,7 @@ void check_dev(const Tensor& t, at::ScalarType dt, const char* name) {
 std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const Tensor& centres, const Tensor& cbids,
                                     const Tensor& mn, const Tensor& mx, int64_t B, int64_t nc, double radius, bool scale_inv,
                                     double window, bool use_pdf, int64_t capacity, std::shared_ptr<Geo> grid_from,
-                                    int64_t side, bool fork) {
+                                    int64_t side, bool fork, bool background) {
     check_dev(pts, at::kFloat, "points");
     check_dev(centres, at::kFloat, "sample points");
     check_dev(bids, at::kInt, "batch ids");
@@ -269,14 +321,16 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
         if (grid_from && grid_from->side >= 0 && grid_from->needs_wait) side = grid_from->side;
         hipStream_t ss = side_stream((int)side);
         if (ss) {
-            if (fork) {
-                // the side streams start behind everything the calling stream holds now (the point hierarchy; whatever
-                // used the memory the allocator hands out from here on)
-                static thread_local hipEvent_t fork_ev = nullptr;
-                if (!fork_ev) hip_check(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming), "hipEventCreate");
-                hip_check(hipEventRecord(fork_ev, (hipStream_t)stream), "hipEventRecord");
-                for (int k = 0; k < kSideStreams; ++k) hip_check(hipStreamWaitEvent(side_stream(k), fork_ev, 0), "hipStreamWaitEvent");
+            // the side stream starts behind everything the calling stream held at the last fork (the point hierarchy;
+            // whatever used the memory the allocator hands out from there on). Only the stream that gets work waits:
+            // a wait packet on an idle queue keeps that queue in the command processor's rotation for nothing
+            static thread_local hipEvent_t fork_ev = nullptr;
+            if (!fork_ev) {
+                hip_check(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming), "hipEventCreate");
+                fork = true;
             }
+            if (fork) hip_check(hipEventRecord(fork_ev, (hipStream_t)stream), "hipEventRecord");
+            hip_check(hipStreamWaitEvent(ss, fork_ev, 0), "hipStreamWaitEvent");
             // (a grid owner on another side stream -- its build has been joined by the caller's stream already, or it
             // would have pulled this build onto its own stream above: order this stream behind it without consuming the
             // owner's one-time join)
@@ -305,10 +359,14 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
         int* slotp = g->slot.data_ptr<int>();
         const int iB = (int)B, inc = (int)nc, icap = (int)capacity, isi = scale_inv ? 1 : 0, ipdf = use_pdf ? 1 : 0;
         const float fr = (float)radius, fw = (float)window;
-        Issuer::get().push([g, grid_from, p0, p1, p2, p3, p4, p5, bufp, slotp, n, m, iB, inc, icap, isi, ipdf, fr, fw, bytes, stream] {
+        Issuer::get().push([g, grid_from, p0, p1, p2, p3, p4, p5, bufp, slotp, n, m, iB, inc, icap, isi, ipdf, fr, fw, bytes, stream, background] {
             if (grid_from) grid_from->wait_issued_nothrow();
+            // background: these launches run beside kernels a step waits for (the convolutions of the current batch) --
+            // the search kernels then hold back (mccnn_background_launches, thread-local: set on THIS thread)
+            const int prev = background ? mccnn_background_launches(1) : 0;
             int rc = mccnn_geometry_build(g->h, p0, p1, n, p2, p3, m, p4, p5, iB, inc, fr, isi, fw, ipdf, icap,
                                           grid_from ? grid_from->h : nullptr, bufp, bytes, slotp, stream);
+            if (background) mccnn_background_launches(prev);
             if (rc == 0 && hipEventRecord(g->event, (hipStream_t)stream) != hipSuccess) rc = (int)hipErrorUnknown;
             g->build_rc = rc;
             g->issued.store(1, std::memory_order_release);
@@ -316,6 +374,11 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
         return g;
     }
     if (grid_from) grid_from->wait_issued();
+    const int prev_bg = (background && g->side >= 0) ? mccnn_background_launches(1) : 0;
+    struct Restore {
+        bool on; int prev;
+        ~Restore() { if (on) mccnn_background_launches(prev); }
+    } restore{background && g->side >= 0, prev_bg};
     check(mccnn_geometry_build(g->h, pts.data_ptr<float>(), bids.data_ptr<int>(), n, centres.data_ptr<float>(),
                                cbids.data_ptr<int>(), m, mn.data_ptr<float>(), mx.data_ptr<float>(), (int)B, (int)nc,
                                (float)radius, scale_inv ? 1 : 0, (float)window, use_pdf ? 1 : 0, (int)capacity,
@@ -352,6 +415,7 @@ void prepare(Geo& g, const Tensor& feats, const Layer& L, int backward, int flag
         Tensor t = at::empty({(int64_t)(need[k] > 256 ? need[k] : 256)}, feats.options().dtype(at::kByte));
         check(mccnn_geometry_attach(g.h, bit, t.data_ptr(), (size_t)t.numel()), "geometry_attach");
         g.attached.push_back(std::move(t));
+        g.have |= bit;
     }
 }
 
@@ -555,13 +619,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
         .def_readonly("grid_owner", &Geo::grid_owner)
         .def_readwrite("uses", &Geo::uses)
         .def_readonly("side", &Geo::side)
+        .def_readonly("have", &Geo::have)
         .def("join", [](Geo& g, const at::Tensor& like) { g.join(cur_stream(like)); })
+        .def("prebuild", &Geo::prebuild, py::arg("what"), py::arg("avg"), py::arg("side"), py::arg("like"))
         .def("edges", &Geo::edges, py::arg("wait_us") = -1)
         .def("info", &Geo::info);
     mod.def("build_geometry", &build_geometry, py::arg("pts"), py::arg("bids"), py::arg("centres"), py::arg("cbids"),
             py::arg("mn"), py::arg("mx"), py::arg("B"), py::arg("nc"), py::arg("radius"), py::arg("scale_inv"),
             py::arg("window"), py::arg("use_pdf"), py::arg("capacity"), py::arg("grid_from").none(true),
-            py::arg("side") = -1, py::arg("fork") = false);
+            py::arg("side") = -1, py::arg("fork") = false, py::arg("background") = false);
     mod.def("conv", &conv);
     mod.def("hierarchy_levels", &hierarchy_levels, py::call_guard<py::gil_scoped_release>());
     mod.def("wait_ns", [] { return (long long)g_wait_ns.load(std::memory_order_relaxed); });

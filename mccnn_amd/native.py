@@ -133,6 +133,13 @@ class Geometry:
             raise _lib.MCCNNError("geometry: rebuilt list still does not fit (%d > %d)" % (e, self.e_cap))
         self.e = e
 
+    def prebuild(self, what, avg, side, like):
+        """Row plans / transposed list ahead of the layers that need them, on a side stream (torch extension only);
+        what: NEED_* mask. Waits for the edge total."""
+        if self.core is not None:
+            self.edges()
+            self.core.prebuild(int(what), bool(avg), int(side), like)
+
     # ------------------------------------------------------------------ views (tests, the builder's cache tuples)
     def _info(self):
         if self.core is not None:
@@ -177,12 +184,13 @@ class Geometry:
 
 
 def _build_into(g, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, capacity, grid_from,
-                side=-1, fork=False):
+                side=-1, fork=False, background=False):
     n, m = inPts.shape[0], centres.shape[0]
     if _EXT is not None:
         uses = g.core.uses if g.core is not None else 0
         g.core = _EXT.build_geometry(inPts, inBids, centres, cbids, mn, mx, B, nc, float(radius), bool(scaleInv), float(window),
-                                     bool(usePDF), capacity, grid_from.core if grid_from is not None else None, side, fork)
+                                     bool(usePDF), capacity, grid_from.core if grid_from is not None else None, side, fork,
+                                     background)
         g.core.uses = uses
         g.buf = g.core.buf
         g.grid_owner = grid_from
@@ -219,7 +227,7 @@ def side_streams_available():
 
 
 def build_geometry(inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, grid_from=None,
-                   side=-1, fork=False):
+                   side=-1, fork=False, background=False):
     """Enqueues grid + search + KDE of one convolution geometry; no host wait. nc: cells per axis
     (MCConvModule._num_cells). grid_from: a Geometry over the same points / radius whose grid is shared. side >= 0
     (torch extension only): the build runs on side stream `side` -- behind everything the current stream holds at the
@@ -231,7 +239,7 @@ def build_geometry(inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleIn
     if grid_from is not None and grid_from.grid_owner is not None:
         grid_from = grid_from.grid_owner
     _build_into(g, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF,
-                _capacity_guess(gkey, m), grid_from, side if _EXT is not None else -1, fork)
+                _capacity_guess(gkey, m), grid_from, side if _EXT is not None else -1, fork, background)
     return g
 
 

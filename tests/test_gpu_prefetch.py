@@ -7,10 +7,28 @@ from tests.helpers import make_cloud
 
 pytestmark = pytest.mark.gpu
 
+# Two prefetch protocols: "native" -- the geometry is one buffer of the native step executor, allocated on the caller's
+# stream and written on a side stream forked behind it (ConvolutionBuilder.__prefetch_native__, the default) -- and "ops" --
+# the op-by-op geometry on the builder's side stream with its tensor-lifetime bookkeeping (ConvolutionBuilder(native=False)).
+PROTOCOLS = ["native", "ops"]
 
-def test_prefetched_geometry_equals_inline(mc):
+
+def _builder(protocol, **kw):
+    from mccnn_amd.MCConvBuilder import ConvolutionBuilder
+    from mccnn_amd import native
+    if protocol == "native" and not native.side_streams_available():
+        pytest.skip("torch extension not built")
+    return ConvolutionBuilder(native=(protocol == "native"), **kw)
+
+
+def _parked(builder):
+    return builder.prefetched_ is not None or bool(builder.prefetchedGeo_)
+
+
+@pytest.mark.parametrize("protocol", PROTOCOLS)
+def test_prefetched_geometry_equals_inline(mc, protocol):
     import torch
-    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    from mccnn_amd.MCConvBuilder import PointHierarchy
     pts, bids = make_cloud(3000, 3, 23, "clustered", True)
     rng = np.random.default_rng(5)
     P = torch.from_numpy(pts).cuda()
@@ -19,7 +37,7 @@ def test_prefetched_geometry_equals_inline(mc):
     og = torch.from_numpy(rng.random((len(pts), 16), dtype=np.float32)).cuda()
     ph = PointHierarchy(P, F, Bi, [], "PH", 3, True)
     torch.manual_seed(3)
-    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True)
+    builder = _builder(protocol, KDEWindow=0.2, relativeRadius=True)
 
     def run():
         F.grad = None
@@ -35,9 +53,11 @@ def test_prefetched_geometry_equals_inline(mc):
     ref = run()                                   # inline geometry
     for _ in range(3):                            # three pipelined steps: prefetch under the convolution, install, use
         builder.prefetch_geometry(ph, 0, 0.15)
-        assert builder.prefetched_ is not None
+        assert _parked(builder)
         builder.reset()
-        assert builder.prefetched_ is None and len(builder.cacheNeighs_) == 1 and len(builder.cachePDFs_) == 1
+        assert not _parked(builder) and len(builder.cacheNeighs_) == 1 and len(builder.cachePDFs_) == 1
+        if protocol == "native":
+            assert next(iter(builder.cacheGeo_.values())).core.side >= 0     # built on a side stream
         got = run()
         assert np.array_equal(got[3], ref[3]) and np.array_equal(got[4], ref[4])      # start indices, packed neighbours
         assert np.array_equal(got[0], ref[0])                                          # forward: deterministic
@@ -48,7 +68,8 @@ def test_prefetched_geometry_equals_inline(mc):
     torch.cuda.synchronize()
 
 
-def test_prefetched_transposed_list_depthwise(mc):
+@pytest.mark.parametrize("protocol", PROTOCOLS)
+def test_prefetched_transposed_list_depthwise(mc, protocol):
     """Depth-wise layer: the transposed neighbour list its backward needs is built on the side stream at reset();
     the gradients equal the inline path's (the transposed gather is deterministic: bit for bit)."""
     import torch
@@ -61,7 +82,7 @@ def test_prefetched_transposed_list_depthwise(mc):
     og = torch.from_numpy(rng.random((len(pts), 16), dtype=np.float32)).cuda()
     ph = PointHierarchy(P, F, Bi, [], "PH", 2, True)
     torch.manual_seed(4)
-    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True)
+    builder = _builder(protocol, KDEWindow=0.2, relativeRadius=True)
 
     def run():
         F.grad = None
@@ -76,12 +97,45 @@ def test_prefetched_transposed_list_depthwise(mc):
     for _ in range(2):
         builder.prefetch_geometry(ph, 0, 0.2, transposed=True)
         builder.reset()
-        packed = next(iter(builder.cacheNeighs_.values()))[1]
-        assert getattr(packed, "_mccnn_transposed", None) is not None  # started at reset(), on the side stream
+        if protocol == "ops":
+            packed = next(iter(builder.cacheNeighs_.values()))[1]
+            assert getattr(packed, "_mccnn_transposed", None) is not None  # started at reset(), on the side stream
+        else:   # transposed list (4) and transposed row plan (2) attached and started at reset()
+            assert next(iter(builder.cacheGeo_.values())).core.have & 6 == 6
         got = run()
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
         for g, r in zip(got[2], ref[2]):
             assert np.array_equal(g, r)
+    torch.cuda.synchronize()
+
+
+def test_native_prefetch_with_too_small_size_guess_is_repaired(mc):
+    """Native protocol: a prefetched geometry whose list outgrew the guessed capacity is built again -- inline, exact -- by
+    the first layer that uses it."""
+    import torch
+    from mccnn_amd import native
+    from mccnn_amd.MCConvBuilder import PointHierarchy
+    pts, bids = make_cloud(2000, 2, 31, "uniform")
+    rng = np.random.default_rng(8)
+    P = torch.from_numpy(pts).cuda()
+    Bi = torch.from_numpy(bids).cuda()
+    F = torch.from_numpy(rng.random((len(pts), 1), dtype=np.float32)).cuda()
+    ph = PointHierarchy(P, F, Bi, [], "PH", 2, True)
+    torch.manual_seed(5)
+    builder = _builder("native", KDEWindow=0.2, relativeRadius=True)
+    builder.reset()
+    ref = builder.create_convolution("Conv", ph, 0, F, 1, 0.2, outNumFeatures=8, multiFeatureConv=True).detach().cpu().numpy()
+    e_ref = next(iter(builder.cacheNeighs_.values()))[1].shape[0]
+    for k in list(native._EDGE_GUESS):
+        native._EDGE_GUESS[k] = 16                # far below the ~1e5 edges of this cloud
+    builder.prefetch_geometry(ph, 0, 0.2)
+    geo = next(iter(builder.prefetchedGeo_.values()))[0]
+    assert geo.e_cap == 16
+    builder.reset()
+    got = builder.create_convolution("Conv", ph, 0, F, 1, 0.2, outNumFeatures=8, multiFeatureConv=True).detach().cpu().numpy()
+    st, pk = next(iter(builder.cacheNeighs_.values()))
+    assert pk.shape[0] == e_ref and geo.e_cap >= e_ref
+    assert np.array_equal(got, ref)
     torch.cuda.synchronize()
 
 
@@ -97,7 +151,7 @@ def test_prefetch_with_too_small_size_guess_is_repaired(mc):
     F = torch.from_numpy(rng.random((len(pts), 1), dtype=np.float32)).cuda()
     ph = PointHierarchy(P, F, Bi, [], "PH", 2, True)
     torch.manual_seed(5)
-    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True)
+    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True, native=False)
     builder.reset()
     ref = builder.create_convolution("Conv", ph, 0, F, 1, 0.2, outNumFeatures=8, multiFeatureConv=True).detach().cpu().numpy()
     e_ref = next(iter(builder.cacheNeighs_.values()))[1].shape[0]
@@ -138,7 +192,8 @@ def test_deferred_search_and_kde_equal_the_two_ops(mc):
     assert torch.equal(st2, start) and torch.equal(pk2, packed) and torch.equal(pdf2, pdfs)
 
 
-def test_combin_feature_gradient_through_the_transposed_list(mc):
+@pytest.mark.parametrize("protocol", PROTOCOLS)
+def test_combin_feature_gradient_through_the_transposed_list(mc, protocol):
     """Combin layer with 3 input features: with a (prefetched) transposed list the feature gradient is gathered in a
     fixed order instead of added with float atomics -- equal to the atomic form within float-sum noise, and bit-identical
     from run to run."""
@@ -152,7 +207,7 @@ def test_combin_feature_gradient_through_the_transposed_list(mc):
     og = torch.from_numpy(rng.random((len(pts), 8), dtype=np.float32)).cuda()
     ph = PointHierarchy(P, F, Bi, [], "PH", 2, True)
     torch.manual_seed(6)
-    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True)
+    builder = _builder(protocol, KDEWindow=0.2, relativeRadius=True)
 
     def run():
         F.grad = None
@@ -174,7 +229,8 @@ def test_combin_feature_gradient_through_the_transposed_list(mc):
     torch.cuda.synchronize()
 
 
-def test_pipeline_over_changing_batches(mc):
+@pytest.mark.parametrize("protocol", PROTOCOLS)
+def test_pipeline_over_changing_batches(mc, protocol):
     """A training loop's shape: every step convolves a DIFFERENT batch while the geometry of the next one is prefetched.
     Batch sizes and edge counts change from step to step (the deferred search sizes its lists from the last total of
     the same shape, so some guesses are too small and finalize() repairs them): every step must reproduce what the
@@ -192,7 +248,7 @@ def test_pipeline_over_changing_batches(mc):
         og = torch.from_numpy(rng.random((len(pts), 16), dtype=np.float32)).cuda()
         batches.append((PointHierarchy(P, F, Bi, [], "PH", B, False), F, og))
     torch.manual_seed(5)
-    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=False)
+    builder = _builder(protocol, KDEWindow=0.2, relativeRadius=False)
 
     def conv(ph, F, og):
         F.grad = None
@@ -214,7 +270,7 @@ def test_pipeline_over_changing_batches(mc):
     for step, b in enumerate(order):
         ph, F, og = batches[b]
         builder.reset()                            # installs the geometry prefetched for THIS batch
-        assert builder.prefetched_ is None and len(builder.cacheNeighs_) == 1 and len(builder.cachePDFs_) == 1
+        assert not _parked(builder) and len(builder.cacheNeighs_) == 1 and len(builder.cachePDFs_) == 1
         out = conv(ph, F, og)
         assert len(builder.cacheNeighs_) == 1      # the convolution used the installed lists, it searched nothing itself
         if step + 1 < len(order):
@@ -242,7 +298,7 @@ def test_side_stream_tensor_lifetime(mc):
     og = torch.from_numpy(rng.random((len(pts), 16), dtype=np.float32)).cuda()
     ph = PointHierarchy(P, F, Bi, [], "PH", 2, True)
     torch.manual_seed(6)
-    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True)
+    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True, native=False)   # the op-by-op protocol's bookkeeping
 
     def conv():
         return builder.create_convolution("Conv", ph, 0, F, 1, 0.15, outNumFeatures=16, multiFeatureConv=True)
@@ -285,7 +341,57 @@ def test_side_stream_tensor_lifetime(mc):
     torch.cuda.synchronize()
 
 
-def test_prefetch_waits_for_a_hierarchy_built_after_reset(mc):
+def test_native_prefetch_and_a_graph_kept_across_resets(mc):
+    """Native protocol: a prefetched geometry is one buffer taken from the CALLER's stream's allocator and only written on
+    the side stream; nothing about its lifetime is decided by reference counts. A graph that outlives two reset()s (and a
+    prefetch of the same shape in between, whose buffers could take the memory if it were released early) still computes
+    the right gradients; changing batches and a prefetch nobody uses leave nothing behind."""
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy
+    pts, bids = make_cloud(2000, 2, 41, "uniform", True)
+    rng = np.random.default_rng(8)
+    P = torch.from_numpy(pts).cuda()
+    Bi = torch.from_numpy(bids).cuda()
+    F = torch.from_numpy(rng.random((len(pts), 1), dtype=np.float32)).cuda().requires_grad_(True)
+    og = torch.from_numpy(rng.random((len(pts), 16), dtype=np.float32)).cuda()
+    ph = PointHierarchy(P, F, Bi, [], "PH", 2, True)
+    torch.manual_seed(6)
+    builder = _builder("native", KDEWindow=0.2, relativeRadius=True)
+
+    def conv():
+        return builder.create_convolution("Conv", ph, 0, F, 1, 0.15, outNumFeatures=16, multiFeatureConv=True)
+
+    builder.reset()
+    ref = conv()
+    ref.backward(og)
+    ref_grad = F.grad.clone()
+    for _ in range(3):
+        builder.reset()
+        builder.prefetch_geometry(ph, 0, 0.15)      # the recommended place: before this batch's convolutions
+        F.grad = None
+        out = conv()
+        out.backward(og)
+        assert torch.equal(out.detach(), ref.detach())
+    builder.reset()
+    F.grad = None
+    late = conv()                                   # graph kept alive ...
+    for _ in range(2):                              # ... across two more steps that prefetch and convolve the same shape
+        builder.prefetch_geometry(ph, 0, 0.15)
+        builder.reset()
+        conv().backward(og)
+    F.grad = None
+    late.backward(og)
+    assert torch.equal(late.detach(), ref.detach())
+    assert float((F.grad - ref_grad).abs().max()) <= 1e-5 * float(ref_grad.abs().max())
+    builder.prefetch_geometry(ph, 0, 0.15)          # a prefetch nobody uses: dropped by the next resets
+    builder.reset()
+    builder.reset()
+    assert not builder.cacheGeo_ and not _parked(builder)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("protocol", PROTOCOLS)
+def test_prefetch_waits_for_a_hierarchy_built_after_reset(mc, protocol):
     """A real training loop builds the NEXT batch's PointHierarchy (host-to-device copies, compute_aabb, Poisson levels)
     on the calling stream AFTER the last reset(). prefetch_geometry() has to order the side stream behind that work
     (PointHierarchy.readyEvent_), not merely behind the reset: every step must reproduce the inline result although the
@@ -300,7 +406,7 @@ def test_prefetch_waits_for_a_hierarchy_built_after_reset(mc):
                      torch.from_numpy(rng.random((len(pts), 1), dtype=np.float32)).pin_memory(),
                      torch.from_numpy(rng.random((len(pts), 16), dtype=np.float32)).cuda()))
     torch.manual_seed(5)
-    builder = ConvolutionBuilder(KDEWindow=0.2, relativeRadius=True)
+    builder = _builder(protocol, KDEWindow=0.2, relativeRadius=True)
     R = 0.03
 
     def upload(b):
