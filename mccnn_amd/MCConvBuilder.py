@@ -394,10 +394,16 @@ class ConvolutionBuilder(torch.nn.Module):
         parks them until the next reset(). Geometry depends on the points only, not on the network, so in a training
         loop the grid build / search / KDE of batch k + 1 runs under the convolution kernels of batch k: those hold
         two waves per SIMD (VGPR-bound) and leave issue slots and wave slots that the light geometry kernels fill
-        (100k room: 0.74 -> 0.63 ms per step). Call it after the backward pass of the current batch has been launched;
-        several calls between two reset()s accumulate. transposed=True (depth-wise layers will convolve over this
-        neighbour list): reset() also starts the list's transposition for their backward pass on the side stream, where
-        it runs under the forward convolutions."""
+        (100k room: 0.70 -> 0.58 ms per step). Several calls between two reset()s accumulate.
+
+        When to call it: on the native step executor (the default) the side stream starts behind what the calling stream
+        holds at the moment of the call, so call it right after reset() -- BEFORE the current batch's convolutions are
+        launched -- once the next batch's hierarchy has been enqueued; called later it is still correct, the build then
+        starts later. The op-by-op protocol (MCCNN_NATIVE_PREFETCH=0, a builder without the executor) waits for the
+        hierarchies' own events instead and is called after the backward pass has been launched.
+
+        transposed=True (depth-wise layers will convolve over this neighbour list): reset() also starts the list's
+        transposition for their backward pass on the side stream, where it runs under the forward convolutions."""
         currKDEWindow = self.KDEWindow_ if KDEWindow is None else KDEWindow
         currRelativeRadius = self.relativeRadius_ if relativeRadius is None else relativeRadius
         currUsePDF = self.usePDF_ if usePDF is None else usePDF
