@@ -483,14 +483,31 @@ class ConfigWorkload:
         self.builder = ConvolutionBuilder(KDEWindow=0.25, relativeRadius=cfg.relative)
         self.lib = _lib.load()
         self.feats = self.ogs = None
+        # pipelined steps: the hierarchy of the NEXT batch is requested as soon as the one of this batch is adopted
+        # (PointHierarchy.prefetch: own stream, helper thread) and runs under this batch's convolutions; every step still
+        # builds one hierarchy and runs every convolution
+        self.pipeline = False
+        self.next_ph = None
         torch.manual_seed(4321)
         self.outs = self.step()  # creates variables, features and out-gradients
         self.params = list(self.builder.parameters())
 
-    def hierarchy(self):
+    def hierarchy(self, prefetched=None):
         from mccnn_amd.MCConvBuilder import PointHierarchy
         return PointHierarchy(self.P, self.F0, self.Bi, list(self.cfg.hierarchy), "PH_" + self.cfg.name, self.B,
-                              self.cfg.relative)
+                              self.cfg.relative, prefetched=prefetched)
+
+    def request_next(self):
+        from mccnn_amd.MCConvBuilder import PointHierarchy
+        self.next_ph = PointHierarchy.prefetch(self.P, self.Bi, list(self.cfg.hierarchy), self.B, self.cfg.relative)
+        return self.next_ph is not None
+
+    def set_pipeline(self, on):
+        """-> whether pipelined steps are active. Switching on requests the first hierarchy ahead."""
+        self.pipeline = bool(on) and self.request_next()
+        if not self.pipeline:
+            self.next_ph = None
+        return self.pipeline
 
     def _make_rows(self, ph):
         self.feats_np, self.ogs_np, self.feats, self.ogs = [], [], [], []
@@ -516,7 +533,11 @@ class ConfigWorkload:
 
     def step(self):
         self.builder.reset()
-        ph = self.ph = self.hierarchy()
+        if self.pipeline:
+            ph = self.ph = self.hierarchy(self.next_ph)
+            self.request_next()
+        else:
+            ph = self.ph = self.hierarchy()
         if self.feats is None:
             self._make_rows(ph)
         outs = [self.conv(ph, ci) for ci in range(len(self.cfg.convs))]
@@ -692,11 +713,36 @@ def run_config(name, device, args, want_cpu):
     cfg = CONFIGS[name]
     cw = ConfigWorkload(cfg, device)
     steps = {"cfg0": 200, "cfg1": 100, "cfg2": 40, "cfg3": 30, "cfg4": 30}[name]
-    ms, launches = cw.timed(steps, 5)
+    ms_seq, launches = cw.timed(steps, 5)
+    seq_issue, seq_wait = cw.host_issue_ms, cw.host_wait_ms
+    ms, mode = ms_seq, "sequential"
+    if not getattr(args, "no_pipeline", False) and cfg.hierarchy:
+        # the same steps with the hierarchy of the next batch requested one step ahead -- accepted when the outputs of
+        # every convolution are bit-identical to the sequential step's and the steps are not slower
+        try:
+            ref = [o.detach().clone() for o in cw.step()]
+            if cw.set_pipeline(True):
+                same = True
+                for _ in range(3):
+                    same = same and all(torch.equal(a, b) for a, b in zip(cw.step(), ref))
+                if same:
+                    ms_p, launches_p = cw.timed(steps, 5)
+                    if ms_p < ms_seq:
+                        ms, launches, mode = ms_p, launches_p, "pipelined"
+                if mode != "pipelined":
+                    cw.host_issue_ms, cw.host_wait_ms = seq_issue, seq_wait
+        except Exception as ex:  # the sequential numbers stand
+            print("bench: pipelined %s steps failed: %r" % (name, ex), file=sys.stderr)
+            cw.host_issue_ms, cw.host_wait_ms = seq_issue, seq_wait
+        cw.set_pipeline(False)
+        torch.cuda.synchronize()
     n = int(cw.P.shape[0])
     t_h, layers, sizes = cw.per_layer()
     ent = {"workload": cfg.what, "points": n, "clouds": cw.B, "level_sizes": sizes, "convolutions": len(cfg.convs),
            "steps": steps, "ms_per_step": round(ms, 4), "value": round(n / (ms * 1e-3), 1), "unit": "points/s",
+           # "pipelined": the next batch's PointHierarchy is requested one step ahead (PointHierarchy.prefetch) and built
+           # under this batch's convolutions; sequential_ms_per_step: hierarchy, then convolutions, nothing carried over
+           "mode": mode, "sequential_ms_per_step": round(ms_seq, 4),
            "library_launches_per_step": round(launches, 1),
            # when this equals ms_per_step the step is bound by the HOST issuing its launches, not by the kernels
            "host_issue_ms_per_step": round(cw.host_issue_ms, 4),
@@ -870,8 +916,8 @@ def compact_record(rec, details_path=None):
     if isinstance(cf, dict):
         out["configs"] = {}
         for name, ent in cf.items():
-            e = _pick(ent, ("ms_per_step", "value", "host_issue_ms_per_step", "host_busy_ms_per_step",
-                            "library_launches_per_step", "points", "convolutions"))
+            e = _pick(ent, ("ms_per_step", "value", "mode", "sequential_ms_per_step", "host_issue_ms_per_step",
+                            "host_busy_ms_per_step", "library_launches_per_step", "points", "convolutions"))
             if "library_launches_per_step" in e:
                 e["launches"] = e.pop("library_launches_per_step")
             if isinstance(ent.get("cpu_baseline"), dict) and "value" in ent["cpu_baseline"]:

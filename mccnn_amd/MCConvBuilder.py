@@ -13,6 +13,7 @@ import math
 
 import os
 import sys
+import time
 import torch
 
 from .MCConvModule import (compute_aabb, sort_points_step1, sort_points_step2, sort_features, sort_features_back,
@@ -103,6 +104,33 @@ class _LazyEntry:
         return getattr(self.value(), name)
 
 
+_GEO_PREFETCH_MIN = int(os.environ.get("MCCNN_GEO_PREFETCH_MIN", "5"))
+
+
+class _PrefetchedHierarchy:
+    """Handle of PointHierarchy.prefetch(): the future of the extension and what it was requested for."""
+
+    def __init__(self, future, points, batchIds, radiusList, batchSize, relativeRadius):
+        self.future, self.points, self.batchIds = future, points, batchIds
+        self.radiusList, self.batchSize, self.relativeRadius = [float(r) for r in radiusList], int(batchSize), bool(relativeRadius)
+        self.version = (points._version, batchIds._version)
+
+    def done(self):
+        return self.future.done()
+
+    def check(self, points, batchIds, radiusList, batchSize, relativeRadius):
+        same = (points is self.points or (points.data_ptr() == self.points.data_ptr() and points.shape == self.points.shape)) \
+            and (batchIds is self.batchIds or (batchIds.data_ptr() == self.batchIds.data_ptr()
+                                              and batchIds.shape == self.batchIds.shape)) \
+            and (self.points._version, self.batchIds._version) == self.version \
+            and [float(r) for r in radiusList] == self.radiusList and int(batchSize) == self.batchSize \
+            and bool(relativeRadius) == self.relativeRadius
+        if not same:
+            from .MCConvModule import InvalidArgumentError
+            raise InvalidArgumentError("PointHierarchy: `prefetched` was requested for other points, batch ids, radii, "
+                                       "batch size or radius mode (or the tensors were modified since)")
+
+
 class PointHierarchy(torch.nn.Module):
     """Point hierarchy built by successive Poisson-disk sampling (MCConvBuilder.py:24-131).
 
@@ -112,9 +140,30 @@ class PointHierarchy(torch.nn.Module):
     hierarchy once all levels are enqueued -- ConvolutionBuilder.prefetch_geometry() orders its side stream behind it.
     """
 
+    @staticmethod
+    def prefetch(inPoints, inBatchIds, radiusList, batchSize=32, relativeRadius=True):
+        """Extension (no counterpart in the reference): starts the geometry of a hierarchy -- the boxes and every level's
+        Poisson-disk samples, which depend on the points only -- on a stream of its own, issued by a helper thread, and
+        returns a handle for `PointHierarchy(..., prefetched=handle)`. In a training loop: request the hierarchy of batch
+        k + 1 right after the one of batch k has been constructed; its chain of small dependent kernels and its two
+        read-backs then run under the convolutions of batch k instead of in front of those of batch k + 1, and the calling
+        thread never waits for the device. The build starts behind what the calling stream holds at the moment of the call
+        (the upload of the batch). Returns None when there is nothing to run ahead (host tensors, no extension): the
+        constructor then builds inline, as without the argument."""
+        from . import MCConvModule as _M
+        if not FUSED_HIERARCHY or not poisson_sampling.__module__.endswith("MCConvModule"):
+            return None
+        fut = _M.point_hierarchy_prefetch(inPoints, inBatchIds, list(radiusList), batchSize, relativeRadius)
+        if fut is None:
+            return None
+        return _PrefetchedHierarchy(fut, inPoints, inBatchIds, radiusList, batchSize, relativeRadius)
+
     def __init__(self, inPoints, inFeatures, inBatchIds, radiusList, hierarchyName="Point_Hierarchy", batchSize=32,
-                 relativeRadius=True, aabbReduceGroup=None, ops=None):
-        """aabbReduceGroup (extension, data-parallel shards only): with relativeRadius=False the reference uses ONE box
+                 relativeRadius=True, aabbReduceGroup=None, ops=None, prefetched=None):
+        """prefetched (extension): the handle PointHierarchy.prefetch() returned for these very points, batch ids, radii,
+        batch size and radius mode.
+
+        aabbReduceGroup (extension, data-parallel shards only): with relativeRadius=False the reference uses ONE box
         for the whole batch (aabb_gpu.cu:104-114). A shard that holds part of the batch passes its process group here
         (`True` = the default group) and the MIN/MAX all-reduce of the box runs between compute_aabb and the first
         sort, so every level of the sharded hierarchy -- cells, keys, Poisson samples -- equals the corresponding
@@ -131,6 +180,10 @@ class PointHierarchy(torch.nn.Module):
         self.relativeRadius_ = relativeRadius
         self.hierarchyName_ = hierarchyName
 
+        if prefetched is not None:
+            prefetched.check(inPoints, inBatchIds, radiusList, batchSize, relativeRadius)
+            if aabbReduceGroup is None and ops._ops is None and self.__adopt_prefetched__(prefetched, inFeatures, ops):
+                return
         aabbMin, aabbMax = ops.compute_aabb(inPoints, inBatchIds, batchSize, self.relativeRadius_)
         if aabbReduceGroup is not None and not self.relativeRadius_:
             from .dist import allreduce_aabb
@@ -178,6 +231,30 @@ class PointHierarchy(torch.nn.Module):
             self.radiusList_.append(currRadius)
             currPts, currBatchIds, currFeatures = sampledPts, sampledBatchsIds, sampledFeatures
         self.__mark_ready__()
+
+    def __adopt_prefetched__(self, prefetched, inFeatures, ops):
+        """The levels a helper thread built ahead (PointHierarchy.prefetch): the current stream is ordered behind them, the
+        feature rows of every level are gathered now. False when the single-launch Poisson form gave up somewhere."""
+        from . import MCConvModule as _M
+        w0 = time.perf_counter()
+        aabbMin, aabbMax, extent, levels = prefetched.future.result()
+        _M.HOST_WAIT_S[0] += time.perf_counter() - w0
+        if not levels:
+            return False
+        self.aabbMin_, self.aabbMax_ = aabbMin, aabbMax
+        if not self.relativeRadius_:
+            _M._seed_num_cells(aabbMin, aabbMax, extent)
+        _log("########## Point Hierarchy: %s (Rel: %s, prefetched)" % (self.hierarchyName_, self.relativeRadius_))
+        currFeatures = inFeatures
+        for (sampledPts, sampledBatchsIds, _sortedIdx, transformedIndexs), currRadius in zip(levels, prefetched.radiusList):
+            currFeatures = ops.get_sampled_features(transformedIndexs, currFeatures)
+            self.points_.append(sampledPts)
+            self.batchIds_.append(sampledBatchsIds)
+            self.features_.append(currFeatures)
+            self.sampledIndexs_.append(transformedIndexs)
+            self.radiusList_.append(currRadius)
+        self.__mark_ready__()
+        return True
 
     def __mark_ready__(self):
         """Everything the hierarchy holds (points of every level, boxes) has been enqueued on the current stream."""
@@ -635,7 +712,7 @@ class ConvolutionBuilder(torch.nn.Module):
         from . import MCConvModule as _hip_ops
         # (a step with a handful of geometries gains nothing: the hops between the streams cost what the overlap saves --
         # measured: BASELINE cfg1, three lists, 0.93 -> 0.97 ms; cfg2, seven, 2.59 -> 2.18)
-        if (not self.cacheGeo_ and self.geoPrefetch_ and len(self.geoPlan_) >= 5 and inPH is outPH and self.prefetched_ is None
+        if (not self.cacheGeo_ and self.geoPrefetch_ and len(self.geoPlan_) >= _GEO_PREFETCH_MIN and inPH is outPH and self.prefetched_ is None
                 and not self.cacheGrids_ and _native.side_streams_available()):
             self.__prebuild_geometries__(inPH)
         geo = self.cacheGeo_.get(keyPDF)

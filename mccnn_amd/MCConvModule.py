@@ -513,6 +513,14 @@ def _num_cells(aabbMin, aabbMax, batchSize, cellSize, scaleInv):
     return nc if nc != 0 else 1
 
 
+def _seed_num_cells(aabbMin, aabbMax, extent):
+    """The box extent of a prefetched hierarchy (read back on its helper thread): later grids over these boxes compute their
+    cell counts from it without a read-back of their own."""
+    _evict_oldest(_NUM_CELLS_CACHE, 256)
+    _NUM_CELLS_CACHE[(id(aabbMin), id(aabbMax))] = (weakref.ref(aabbMin), weakref.ref(aabbMax), aabbMin._version,
+                                                    aabbMax._version, _np.float32(extent))
+
+
 # ---------------------------------------------------------------------------------------------
 def compute_aabb(inPts, inBatchIds, batchSize, scaleInv=True):
     """ComputeAabb (MCConvModuleSrc:20, aabb_gpu.cc:22-86). Non differentiable."""
@@ -976,6 +984,29 @@ def _torch_ext():
     """The torch extension over the C-ABI (mccnn_amd/lib/_mccnn_torch.so) when it is built and enabled."""
     from . import native
     return native._EXT
+
+
+def point_hierarchy_prefetch(inPts, inBatchIds, radiusList, batchSize, scaleInv):
+    """Boxes and level geometry of a point hierarchy (compute_aabb + point_hierarchy_levels) started on a stream of its own,
+    issued by a helper thread of the PyTorch-ROCm extension (csrc/torch_ext.cpp: hierarchy_prefetch): the call returns at once
+    with a future, `future.result()` -> (aabbMin, aabbMax, extent, levels) orders the calling stream behind the build. The
+    build starts behind what the calling stream holds NOW. None when the extension (or the single-launch Poisson form) is
+    not available -- the caller then builds the hierarchy inline."""
+    ext = _torch_ext()
+    if ext is None or not POISSON_DATAFLOW or len(radiusList) == 0 or not getattr(inPts, "is_cuda", False):
+        return None
+    op = "PointHierarchy"
+    pts, bids = inPts.detach(), inBatchIds
+    if pts.dtype != torch.float32 or bids.dtype != torch.int32 or not pts.is_contiguous() or not bids.is_contiguous() \
+            or pts.shape[0] == 0:
+        return None
+    _check_points(pts, "points", op)
+    _check_batch_ids(bids, pts.shape[0], op)
+    _req(batchSize > 0, op + " expects a positive batch size")
+    for radius in radiusList:
+        _req(radius > 0.0, op + " expects positive radii")
+    return ext.hierarchy_prefetch(pts, bids, [float(r) for r in radiusList], int(batchSize), bool(scaleInv),
+                                  2 if POISSON_DATAFLOW == 2 else 1)
 
 
 def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batchSize, scaleInv):

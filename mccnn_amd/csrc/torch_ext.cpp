@@ -49,8 +49,12 @@ Tensor& scratch(size_t bytes, const Tensor& like, void* stream) {
     thread_local std::map<std::pair<int, void*>, Tensor> pool;
     Tensor& t = pool[{(int)like.device().index(), stream}];
     if (bytes < 256) bytes = 256;
-    if (!t.defined() || (size_t)t.numel() < bytes)
+    if (!t.defined() || (size_t)t.numel() < bytes) {
+        // the old block goes back to the allocator of the CALLING thread's current stream, which need not be `stream`:
+        // what `stream` still runs on it has to be over first (rare: the scratch only grows)
+        if (t.defined()) (void)hipStreamSynchronize((hipStream_t)stream);
         t = at::empty({(int64_t)(bytes + bytes / 4)}, like.options().dtype(at::kByte));
+    }
     return t;
 }
 
@@ -117,9 +121,10 @@ void give_event(hipEvent_t e) {
 // shares another one's grid is queued behind it). MCCNN_ISSUE_THREAD=0: the calling thread issues them itself.
 class Issuer {
 public:
-    static Issuer& get() {
-        static Issuer inst;
-        return inst;
+    // 0: geometry builds of the step in flight; 1: point hierarchies of the NEXT batch (those jobs block on read-backs)
+    static Issuer& get(int which = 0) {
+        static Issuer inst[2];
+        return inst[which];
     }
     static bool enabled() {
         static const bool on = !(getenv("MCCNN_ISSUE_THREAD") && std::string(getenv("MCCNN_ISSUE_THREAD")) == "0");
@@ -596,6 +601,187 @@ std::vector<std::vector<Tensor>> hierarchy_levels(const Tensor& pts, const Tenso
     return out;
 }
 
+
+// ---- point hierarchy of the NEXT batch, built on a stream of its own by a helper thread -------------------------------
+// A hierarchy depends on the points only. Built inline it is a chain of ~13 small dependent kernels per level that ends in
+// a read-back of the level sizes (and, for an absolute radius, starts with one of the box extent): the host cannot issue
+// anything of the step while it waits, and the GPU has nothing else to run. Requested one step ahead the chain runs under
+// the convolutions of the batch in flight, and the calling thread never waits for the device.
+// Memory: everything the caller will read (boxes, level rows) is allocated HERE, on the calling thread and its current
+// stream, sized by the capacity (level 0's point count) -- the helper's stream starts behind an event recorded on the
+// caller's stream at this moment, and the caller's stream joins the helper's event before the first use, so the blocks
+// go back to the allocator they came from after every reader. Temporaries (sorted copies, cell tables, scan words) live
+// in the helper thread's own scratch.
+hipStream_t hier_stream() {
+    static hipStream_t s = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    });
+    return s;
+}
+
+struct HierFuture {
+    Tensor pts, bids, mn, mx, sizes;
+    std::vector<Tensor> ints, flts;  // per level: sampled batch ids | sampled indexs | transformed indexs   and   sampled points
+    std::vector<double> radii;
+    std::vector<int> ncs, hs;
+    int B = 0, L = 0, cap = 0, pmode = 1;
+    int64_t ca = 0;
+    bool scale_inv = true;
+    float extent = 0.f;
+    std::atomic<int> done{1};
+    int rc = 0;
+    std::string what;
+    hipEvent_t event = nullptr;
+    void* alloc_stream = nullptr;
+    bool joined = false;
+
+    void wait_done() {
+        int spins = 0;
+        while (!done.load(std::memory_order_acquire)) {
+            if (++spins < 2000) continue;
+            if (spins < 4000) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+    ~HierFuture() {
+        wait_done();
+        if (event) {
+            if (!joined && rc == 0) (void)hipStreamWaitEvent((hipStream_t)alloc_stream, event, 0);
+            give_event(event);
+        }
+    }
+
+    // the helper thread's part: boxes, cell counts, the levels, ONE read-back of the sizes
+    void run(hipStream_t ss) {
+        try {
+            const float* P = pts.data_ptr<float>();
+            const int* Bi = bids.data_ptr<int>();
+            float* pmn = mn.data_ptr<float>();
+            float* pmx = mx.data_ptr<float>();
+            const size_t aw = mccnn_compute_aabb_workspace_bytes(B);
+            check(mccnn_compute_aabb(P, Bi, cap, B, scale_inv ? 1 : 0, pmn, pmx, scratch(aw, pts, (void*)ss).data_ptr(),
+                                     (size_t)scratch(aw, pts, (void*)ss).numel(), (void*)ss),
+                  "compute_aabb");
+            ncs.assign(L, 1);
+            if (scale_inv) {
+                for (int l = 0; l < L; ++l)
+                    check(mccnn_num_cells(nullptr, nullptr, B, (float)radii[l], 1, &ncs[l], nullptr), "num_cells");
+            } else {
+                // determineNumCells with an absolute cell size (sort_gpu.cu:410-419): ONE read-back of the extent for all levels
+                check(mccnn_aabb_extent(pmn, pmx, &extent, (void*)ss), "aabb_extent");
+                for (int l = 0; l < L; ++l) {
+                    const int nc = (int)(extent / (float)radii[l]);
+                    ncs[l] = nc ? nc : 1;
+                }
+            }
+            size_t need = 256;
+            std::vector<size_t> wsb(L);
+            for (int l = 0; l < L; ++l) {
+                wsb[l] = mccnn_hierarchy_level_workspace_bytes(cap, B, ncs[l]);
+                if (!wsb[l]) throw std::runtime_error("PointHierarchy: batch_size * num_cells^3 does not fit 32-bit keys");
+                wsb[l] = (wsb[l] + 255) / 256 * 256;
+                const size_t tmp = (size_t)(5 * ca) * 4 + (size_t)2 * B * ncs[l] * ncs[l] * ncs[l] * 4;
+                if (wsb[l] + tmp > need) need = wsb[l] + tmp;
+            }
+            Tensor& ws = scratch(need, pts, (void*)ss);
+            int* sz = sizes.data_ptr<int>();
+            hip_check(hipMemcpyAsync(sz, &cap, sizeof(int), hipMemcpyHostToDevice, ss), "hipMemcpyAsync");
+            const float* cur_pts = P;
+            const int* cur_bids = Bi;
+            for (int l = 0; l < L; ++l) {
+                char* base = (char*)ws.data_ptr();
+                int* ti_ = (int*)(base + wsb[l]);           // index_new_pos | sorted batch ids | cell table
+                float* tf_ = (float*)(ti_ + 2 * ca);        // sorted points
+                int* cells = (int*)(tf_ + 3 * ca);
+                int* bi = ints[l].data_ptr<int>();
+                float* bf = flts[l].data_ptr<float>();
+                check(mccnn_hierarchy_level(cur_pts, cur_bids, pmn, pmx, cap, sz + l, B, ncs[l], (float)radii[l],
+                                            scale_inv ? 1 : 0, pmode, ti_, tf_, ti_ + ca, cells, bf, bi, bi + ca, bi + 2 * ca,
+                                            sz + l + 1, base, wsb[l], (void*)ss),
+                      "hierarchy_level");
+                cur_pts = bf;
+                cur_bids = bi;
+            }
+            static thread_local Tensor host;
+            if (!host.defined() || host.numel() < L + 1)
+                host = at::empty({L + 65}, at::TensorOptions().dtype(at::kInt).pinned_memory(true));
+            hip_check(hipMemcpyAsync(host.data_ptr(), sz, (size_t)(L + 1) * sizeof(int), hipMemcpyDeviceToHost, ss), "hipMemcpyAsync");
+            hip_check(hipEventRecord(event, ss), "hipEventRecord");
+            hip_check(hipStreamSynchronize(ss), "hipStreamSynchronize");
+            hs.assign(host.data_ptr<int>(), host.data_ptr<int>() + L + 1);
+        } catch (const std::exception& e) {
+            rc = 1;
+            what = e.what();
+        }
+        done.store(1, std::memory_order_release);
+    }
+
+    // -> (aabbMin, aabbMax, extent, levels) on the calling thread's current stream; levels empty when a wait of the
+    // single-launch Poisson kernel timed out (the caller then builds the hierarchy op by op)
+    py::tuple result() {
+        {
+            py::gil_scoped_release nogil;
+            const auto t0 = std::chrono::steady_clock::now();
+            wait_done();
+            g_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+                                std::memory_order_relaxed);
+        }
+        if (rc) throw std::runtime_error("PointHierarchy prefetch: " + what);
+        if (!joined) {
+            hip_check(hipStreamWaitEvent((hipStream_t)cur_stream(pts), event, 0), "hipStreamWaitEvent");
+            joined = true;
+        }
+        std::vector<std::vector<Tensor>> out;
+        bool ok = true;
+        for (int l = 1; l <= L; ++l) ok = ok && hs[l] >= 0;
+        for (int l = 0; ok && l < L; ++l) {
+            const int64_t sN = hs[l + 1];
+            out.push_back({flts[l].narrow(0, 0, 3 * sN).view({sN, 3}), ints[l].narrow(0, 0, sN).view({sN, 1}),
+                           ints[l].narrow(0, ca, sN), ints[l].narrow(0, 2 * ca, sN)});
+        }
+        return py::make_tuple(mn, mx, extent, out);
+    }
+};
+
+std::shared_ptr<HierFuture> hierarchy_prefetch(const Tensor& pts, const Tensor& bids, const std::vector<double>& radii,
+                                               int64_t B, bool scale_inv, int64_t pmode) {
+    check_dev(pts, at::kFloat, "points");
+    check_dev(bids, at::kInt, "batch ids");
+    const int L = (int)radii.size();
+    const int cap = (int)pts.size(0);
+    TORCH_CHECK(L > 0 && cap > 0 && B > 0, "hierarchy_prefetch: bad arguments");
+    hipStream_t ss = hier_stream();
+    TORCH_CHECK(ss, "hierarchy_prefetch: no side stream");
+    auto f = std::make_shared<HierFuture>();
+    f->pts = pts; f->bids = bids; f->radii = radii;
+    f->B = (int)B; f->L = L; f->cap = cap; f->pmode = (int)pmode; f->scale_inv = scale_inv;
+    f->ca = (cap + 63) / 64 * 64;
+    auto iopt = pts.options().dtype(at::kInt);
+    f->mn = at::empty({B, 3}, pts.options());
+    f->mx = at::empty({B, 3}, pts.options());
+    f->sizes = at::empty({L + 1}, iopt);
+    for (int l = 0; l < L; ++l) {
+        f->ints.push_back(at::empty({3 * f->ca}, iopt));
+        f->flts.push_back(at::empty({3 * f->ca}, pts.options()));
+    }
+    void* stream = cur_stream(pts);
+    f->alloc_stream = stream;
+    f->event = take_event();
+    static thread_local hipEvent_t fork_ev = nullptr;
+    if (!fork_ev) hip_check(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventRecord(fork_ev, (hipStream_t)stream), "hipEventRecord");
+    hip_check(hipStreamWaitEvent(ss, fork_ev, 0), "hipStreamWaitEvent");
+    if (Issuer::enabled()) {
+        f->done.store(0, std::memory_order_release);
+        Issuer::get(1).push([f, ss] { f->run(ss); });
+    } else {
+        f->run(ss);
+    }
+    return f;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
@@ -630,5 +816,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
             py::arg("side") = -1, py::arg("fork") = false, py::arg("background") = false);
     mod.def("conv", &conv);
     mod.def("hierarchy_levels", &hierarchy_levels, py::call_guard<py::gil_scoped_release>());
+    py::class_<HierFuture, std::shared_ptr<HierFuture>>(mod, "HierarchyFuture")
+        .def("result", &HierFuture::result)
+        .def("done", [](HierFuture& f) { return f.done.load(std::memory_order_acquire) != 0; });
+    mod.def("hierarchy_prefetch", &hierarchy_prefetch);
     mod.def("wait_ns", [] { return (long long)g_wait_ns.load(std::memory_order_relaxed); });
 }

@@ -93,3 +93,64 @@ def test_fused_hierarchy_honours_the_poisson_switch_and_falls_back(mc, dataflow)
         assert torch.equal(a, b)
     assert mc.point_hierarchy_levels(P[:0], Bi[:0], mn, mx, radii, B, True) is None   # empty cloud: op-by-op chain
     assert mc.point_hierarchy_levels(P, Bi, mn, mx, [], B, True) == []
+
+
+@pytest.mark.parametrize("case", ["relative_batched", "room_absolute"])
+def test_prefetched_hierarchy_equals_the_inline_one(mc, case):
+    """PointHierarchy.prefetch(): boxes and levels built on a stream of their own by the extension's helper thread, under
+    other work of the calling stream -- same tensors as the inline build, bit for bit; several requests in flight; a
+    request nobody adopts; a handle offered to the wrong inputs."""
+    import torch
+    import mccnn_amd.MCConvBuilder as MB
+    from mccnn_amd.MCConvModule import InvalidArgumentError
+    if case == "relative_batched":
+        pts, bids = make_cloud(3000, 5, 3, "clustered", True)
+        B, radii, rel = 5, [0.1, 0.4, math.sqrt(3.0) + 0.1], True
+    else:
+        pts = make_room(100000, 20180601)
+        bids = np.zeros((len(pts), 1), np.int32)
+        B, radii, rel = 1, [0.1, 0.2, 0.4, 0.8], False
+    feats = np.random.default_rng(1).random((len(pts), 3), dtype=np.float32)
+    P, Bi = torch.from_numpy(pts).cuda(), torch.from_numpy(bids).cuda()
+    F = torch.from_numpy(feats).cuda().requires_grad_(True)
+    ref = MB.PointHierarchy(P, F, Bi, radii, "PH", B, rel)
+    (ref.features_[-1] * torch.linspace(1, 2, 3, device="cuda")).sum().backward()
+    g_ref = F.grad.clone()
+    (lv_r, idx_r) = _levels(ref)
+    busy = torch.randn(2048, 2048, device="cuda")
+    for rep in range(3):
+        h = MB.PointHierarchy.prefetch(P, Bi, radii, B, rel)
+        assert h is not None
+        h2 = MB.PointHierarchy.prefetch(P, Bi, radii, B, rel)       # a second request in flight, never adopted
+        for _ in range(4):
+            busy = torch.tanh(busy @ busy * 1e-3)                     # work of the calling stream the build runs under
+        F.grad = None
+        ph = MB.PointHierarchy(P, F, Bi, radii, "PH", B, rel, prefetched=h)
+        del h2
+        (ph.features_[-1] * torch.linspace(1, 2, 3, device="cuda")).sum().backward()
+        (lv, idx) = _levels(ph)
+        assert len(lv) == len(radii) + 1
+        for (pf, bf, ff), (po, bo, fo) in zip(lv, lv_r):
+            assert np.array_equal(pf, po) and np.array_equal(bf, bo) and np.array_equal(ff, fo)
+        for a, b in zip(idx, idx_r):
+            assert np.array_equal(a, b)
+        assert torch.equal(ph.aabbMin_, ref.aabbMin_) and torch.equal(ph.aabbMax_, ref.aabbMax_)
+        assert torch.equal(F.grad, g_ref)
+    # the adopted hierarchy serves a convolution builder like any other (cell counts of absolute radii come from the
+    # extent the helper thread read back)
+    builder = MB.ConvolutionBuilder(KDEWindow=0.25, relativeRadius=rel)
+    ref_b = MB.ConvolutionBuilder(KDEWindow=0.25, relativeRadius=rel)
+    f1 = torch.ones((len(pts), 1), device="cuda")
+    o1 = builder.create_convolution("c", ph, 0, f1, 1, radii[0] * (1.0 if rel else 1.0), ph, 1, True, 8)
+    ref_b.load_state_dict(builder.state_dict(), strict=False)
+    o2 = ref_b.create_convolution("c", ref, 0, f1, 1, radii[0], ref, 1, True, 8)
+    assert torch.equal(o1, o2)
+    # a handle is bound to its request
+    h = MB.PointHierarchy.prefetch(P, Bi, radii, B, rel)
+    with pytest.raises(InvalidArgumentError):
+        MB.PointHierarchy(P, F, Bi, radii[:-1], "PH", B, rel, prefetched=h)
+    P2 = P.clone()
+    with pytest.raises(InvalidArgumentError):
+        MB.PointHierarchy(P2, F, Bi, radii, "PH", B, rel, prefetched=h)
+    del h
+    torch.cuda.synchronize()

@@ -8,6 +8,8 @@ torch.cuda.set_device(0)
 torch.autograd.set_multithreading_enabled(False)
 name = sys.argv[1]
 cw = bench.ConfigWorkload(CONFIGS[name], torch.device("cuda", 0))
+if os.environ.get("PIPE", "1") == "1":
+    print("pipelined:", cw.set_pipeline(True))
 for _ in range(5): cw.step()
 torch.cuda.synchronize()
 pr = cProfile.Profile()
