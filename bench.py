@@ -136,6 +136,12 @@ class Workload:
         from mccnn_amd import native as _native
         self.native_prefetch = bool(self.builder.native_ and _native.side_streams_available()
                                     and os.environ.get("MCCNN_NATIVE_PREFETCH", "1") != "0")
+        # what the prefetch also starts for the backward pass: depth-wise layers sweep the transposed row plan. Combin layers
+        # with 2..4 input features CAN gather their feature gradient through the transposed list (no float atomics,
+        # bit-reproducible: MCCNN_PF_TLIST=1) -- measured on 3to8: pipelined step 0.590 -> 0.739 ms (the transposition's
+        # atomics run beside the convolutions), so the scatter stays the default of a single layer
+        self.pf_transposed = True if not self.combin else ("list" if 2 <= self.fin <= 4 and os.environ.get(
+            "MCCNN_PF_TLIST", "0") == "1" else False)
         self.out = self.step()  # creates the variables (strictly sequential step)
         self.params = list(self.builder.parameters())
         ok = not getattr(args, "no_pipeline", False)
@@ -180,16 +186,16 @@ class Workload:
             # stream, under the convolution kernels of THIS batch; the next reset() installs it. On the native path the
             # side stream forks behind what the calling stream holds at the call, so the call comes before this batch's
             # convolutions are launched (ConvolutionBuilder.__prefetch_native__)
-            self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window, transposed=not self.combin)
+            self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window, transposed=self.pf_transposed)
         out = self.builder.create_convolution("Conv", self.ph, 0, self.F, self.fin, a.radius, outNumFeatures=self.fout,
                                               multiFeatureConv=self.combin, KDEWindow=a.window)
         if mid:
-            self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window, transposed=not self.combin)
+            self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window, transposed=self.pf_transposed)
         out.backward(self.OG)
         if self.pipeline and not early:
             # (op-by-op prefetch, MCCNN_NATIVE=0 / no torch extension: its side stream waits for the hierarchy's and the
             # last reset()'s events only, and its host work is better spent after this batch's launches)
-            self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window, transposed=not self.combin)
+            self.builder.prefetch_geometry(self.ph, 0, a.radius, KDEWindow=a.window, transposed=self.pf_transposed)
         if self.dist_on and not self.skip_allreduce:
             if self.bucket is None:  # the variables exist after the first create_convolution
                 self.bucket = GradBucket(list(self.builder.parameters()), single_rank=True)

@@ -480,7 +480,9 @@ class ConvolutionBuilder(torch.nn.Module):
         hierarchies' own events instead and is called after the backward pass has been launched.
 
         transposed=True (depth-wise layers will convolve over this neighbour list): reset() also starts the list's
-        transposition for their backward pass on the side stream, where it runs under the forward convolutions."""
+        transposition for their backward pass on the side stream, where it runs under the forward convolutions.
+        transposed="list" (layers with 2..4 input features and multiFeatureConv=True will): the transposed list alone --
+        their feature gradient is then gathered through it instead of scattered with float atomics (bit-reproducible)."""
         currKDEWindow = self.KDEWindow_ if KDEWindow is None else KDEWindow
         currRelativeRadius = self.relativeRadius_ if relativeRadius is None else relativeRadius
         currUsePDF = self.usePDF_ if usePDF is None else usePDF
@@ -620,10 +622,10 @@ class ConvolutionBuilder(torch.nn.Module):
         for t, dt in ((inPts, torch.float32), (centres, torch.float32), (inBids, torch.int32), (cBids, torch.int32)):
             if t.dtype != dt or not t.is_contiguous() or not t.is_cuda:
                 return False
+        want = 0 if not transposed else (1 if transposed == "list" else 2)   # nothing | transposed list | + transposed row plan
         if keyPDF in self.prefetchedGeo_:
-            if transposed:
-                ent = self.prefetchedGeo_[keyPDF]
-                self.prefetchedGeo_[keyPDF] = ent[:4] + (True,)
+            ent = self.prefetchedGeo_[keyPDF]
+            self.prefetchedGeo_[keyPDF] = ent[:4] + (max(ent[4], want),)
             return True
         mn, mx, B = inPH.aabbMin_, inPH.aabbMax_, inPH.batchSize_
         nc = _hip_ops._num_cells(mn, mx, B, convRadius, relativeRadius)
@@ -635,7 +637,7 @@ class ConvolutionBuilder(torch.nn.Module):
         geo = _native.build_geometry(inPts, inBids, centres, cBids, mn, mx, B, nc, convRadius, relativeRadius, KDEWindow,
                                      usePDF, owner, side=k, fork=True, background=True)
         geo.uses = 0
-        self.prefetchedGeo_[keyPDF] = (geo, keyGrid, keyNeighs, usePDF, bool(transposed))
+        self.prefetchedGeo_[keyPDF] = (geo, keyGrid, keyNeighs, usePDF, want)
         return True
 
     def __install_prefetched_geometries__(self):
@@ -652,7 +654,7 @@ class ConvolutionBuilder(torch.nn.Module):
             self.cacheNeighs_[keyNeighs] = _LazyEntry(geo, geo.neighbors)
             self.cachePDFs_[keyPDF] = _LazyEntry(geo, geo.pdfs)
             if transposed:
-                geo.prebuild(_native.NEED_PLAN_TR, self.useAVG_, 0, geo.buf)
+                geo.prebuild(_native.NEED_PLAN_TR if transposed == 2 else _native.NEED_TLIST, self.useAVG_, 0, geo.buf)
 
     def __prebuild_geometries__(self, ph):
         """Learned prefetch: every geometry the previous step built over a hierarchy of this name, issued now -- before the
