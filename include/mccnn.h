@@ -375,6 +375,9 @@ int mccnn_rowplan_fill(int transposed, const void* rec_edges, const int* packed,
 int mccnn_rowplan_buffer(int rows, int e, long long offsets[6], long long* total_bytes, int* num_slices,
                          long long* slot_capacity, long long* scratch_rows);
 size_t mccnn_rowplan_build_workspace_bytes(int rows, int e, int transposed);
+/* Sizes of the plan buffer and of the build's workspace that hold for EVERY edge count 0 .. e_cap (for a caller that
+ * allocates before the list's true size is known). */
+int mccnn_rowplan_bound(int rows, int e_cap, int transposed, long long* buffer_bytes, long long* ws_bytes);
 /* 1 when mccnn_rowplan_build evaluates the records of a plan of (rows, e) inside its fill (small lists): rec_edges may then
  * be NULL and is neither read nor written. */
 int mccnn_rowplan_inline_records(int rows, int e);
@@ -461,6 +464,10 @@ int mccnn_geometry_attach(mccnn_geometry_t* g, int what, void* buffer, size_t by
  * pieces named by the mask `what` (row plans need their records / transposed list attached as mccnn_conv_prepare would
  * ask; avg: the flag of the layers that will use the plans). */
 int mccnn_geometry_piece_bytes(mccnn_geometry_t* g, int what, long long* bytes, long long* ws_bytes);
+/* The same two sizes WITHOUT a geometry and without waiting: bounds for ONE piece over n points, m centres and any list
+ * of at most e_cap edges -- for a caller that allocates the pieces when it queues the geometry's build (another thread
+ * attaches and prebuilds them once E has arrived). */
+int mccnn_geometry_piece_bound(int n, int m, int e_cap, int what, long long* bytes, long long* ws_bytes);
 int mccnn_geometry_prebuild(mccnn_geometry_t* g, int what, int avg, void* ws, size_t ws_bytes, mccnn_stream_t stream);
 /* One layer over a geometry: SpatialConv / SpatialConvGrad INCLUDING sort_features / its gradient
  * (MCConvModuleSrc:35-45,70-81). feats [n, num_in_feats] and feat_grad are rows of the UNSORTED points (f32, or bf16
@@ -497,6 +504,9 @@ long long mccnn_debug_launch_count(void);
  * the first mccnn_conv_* call over a geometry). bench.py subtracts it from a step's host time: what is left is the
  * host's own work per step. */
 long long mccnn_debug_wait_ns(void);
+/* ... of the CALLING thread only when it says so: a helper thread that waits in the caller's place switches its own
+ * accounting off (returns the previous setting; thread-local, default on). */
+int mccnn_debug_wait_accounting(int on);
 /* The calling THREAD's launches are background work from now on (on != 0) / no longer (on == 0): they run on a queue of
  * their own beside kernels a step waits for (ConvolutionBuilder.prefetch_geometry: the geometry of the next batch under
  * the convolutions of the current one). Kernels that would fill every wave slot hold back in that mode; results do not

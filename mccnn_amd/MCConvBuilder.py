@@ -105,6 +105,7 @@ class _LazyEntry:
 
 
 _GEO_PREFETCH_MIN = int(os.environ.get("MCCNN_GEO_PREFETCH_MIN", "5"))
+_PLAN_PREFETCH_MAX_E = int(float(os.environ.get("MCCNN_PLAN_PREFETCH_MAX_E", "1e12")))
 
 
 class _PrefetchedHierarchy:
@@ -375,10 +376,16 @@ class ConvolutionBuilder(torch.nn.Module):
         self.cacheGrids_ = {}
         self.cacheNeighs_ = {}
         self.cachePDFs_ = {}
+        if self.geoLog_:
+            # the step's geometries AND the pieces its layers attached to each (row plans, transposed list): the next
+            # step asks for them together with the build (native.Geometry.prebuild_async)
+            plan = []
+            for ent in self.geoLog_:
+                geo = self.cacheGeo_.get(ent[7])
+                plan.append(ent[:7] + ((geo.have & 7) if geo is not None else 0,))
+            self.geoPlan_, self.geoLog_ = plan, []
         self.cacheGeo_ = {}
         self.cacheGeoGrid_ = {}
-        if self.geoLog_:
-            self.geoPlan_, self.geoLog_ = self.geoLog_, []
         if self.prefetchedGeo_:
             self.__install_prefetched_geometries__()
         pf, self.prefetched_ = self.prefetched_, None
@@ -668,7 +675,8 @@ class ConvolutionBuilder(torch.nn.Module):
         if int(_hip_ops.PDF_MODE) != 1:
             return
         k = 0
-        for (hname, inLevel, outLevel, radius, window, rel, usePDF) in plan:
+        pieces = os.environ.get("MCCNN_PLAN_PREFETCH", "1") != "0"
+        for (hname, inLevel, outLevel, radius, window, rel, usePDF, have) in plan:
             if hname != name or inLevel >= levels or outLevel >= levels:
                 continue
             keyGrid, keyNeighs, keyPDF = self.__compute_dic_keys__(ph, ph, inLevel, outLevel, radius, window, rel, usePDF)
@@ -690,8 +698,10 @@ class ConvolutionBuilder(torch.nn.Module):
                                          side=k, fork=(k == 0))
             k += 1
             geo.uses = 0
+            if have and pieces and geo.e_cap <= _PLAN_PREFETCH_MAX_E:
+                geo.prebuild_async(have, self.useAVG_)
             self.cacheGeo_[keyPDF] = geo
-            self.geoLog_.append((name, inLevel, outLevel, radius, window, rel, usePDF))
+            self.geoLog_.append((name, inLevel, outLevel, radius, window, rel, usePDF, keyPDF))
             if owner is None:
                 self.cacheGeoGrid_[keyGrid] = geo
                 self.cacheGrids_[keyGrid] = _LazyEntry(geo, geo.grid)
@@ -738,7 +748,8 @@ class ConvolutionBuilder(torch.nn.Module):
             geo.uses = 0
             self.cacheGeo_[keyPDF] = geo
             if inPH is outPH:
-                self.geoLog_.append((inPH.hierarchyName_, inLevel, outLevel, convRadius, KDEWindow, relativeRadius, usePDF))
+                self.geoLog_.append((inPH.hierarchyName_, inLevel, outLevel, convRadius, KDEWindow, relativeRadius, usePDF,
+                                     keyPDF))
             if owner is None:
                 self.cacheGeoGrid_[keyGrid] = geo
                 self.cacheGrids_[keyGrid] = _LazyEntry(geo, geo.grid)

@@ -23,6 +23,7 @@ SIGNATURES = {
     "mccnn_debug_conv_impl": (_i, [_i]),
     "mccnn_debug_launch_count": (C.c_longlong, []),
     "mccnn_debug_wait_ns": (C.c_longlong, []),
+    "mccnn_debug_wait_accounting": (_i, [_i]),
     "mccnn_debug_small_kernels": (_i, [_i]),
     "mccnn_debug_f1_x4_min_edges": (_i, [_i]),
     "mccnn_background_launches": (_i, [_i]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "mccnn_rowplan_buffer": (_i, [_i, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(_i),
                                   C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "mccnn_rowplan_build_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mccnn_rowplan_bound": (_i, [_i, _i, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "mccnn_rowplan_inline_records": (_i, [_i, _i]),
     "mccnn_rowplan_build": (_i, [_i] + [_vp] * 8 + [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "mccnn_spatial_conv_fwd_rows": (_i, [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _i, _i, _i] + [_vp] * 6 + [_vp, _vp, _vp, _vp]),
@@ -87,6 +89,7 @@ SIGNATURES = {
     "mccnn_geometry_info": (_i, [_vp, C.POINTER(C.c_longlong)]),
     "mccnn_geometry_attach": (_i, [_vp, _i, _vp, _sz]),
     "mccnn_geometry_piece_bytes": (_i, [_vp, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "mccnn_geometry_piece_bound": (_i, [_i, _i, _i, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "mccnn_geometry_prebuild": (_i, [_vp, _i, _i, _vp, _sz, _vp]),
     "mccnn_conv_prepare": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(C.c_longlong),
                                 C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(_i)]),

@@ -921,6 +921,38 @@ int mccnn_rowplan_buffer(int rows, int e, long long offsets[6], long long* total
     return 0;
 }
 
+// Sizes that hold for EVERY edge count up to e_cap (the capacity a neighbour list was guessed at): a caller that allocates
+// a plan before the list's true size is known -- ahead of the build, on another thread -- takes these. The longest
+// virtual row L is a step function of (rows, e) and the layout's arrays are monotone in e for a fixed L: the maximum over
+// the possible L at e_cap bounds them all.
+int mccnn_rowplan_bound(int rows, int e_cap, int transposed, long long* buffer_bytes, long long* ws_bytes) {
+    if (rows < 0 || e_cap < 0 || !buffer_bytes || !ws_bytes) return MCCNN_E_BADARG;
+    size_t buf = 0, ws = 256;
+    for (int L = 1; L <= ROWS_L; L <<= 1) {
+        const long long vcap = (long long)rows + e_cap / L;
+        const long long windows = (vcap + SELL_SIGMA - 1) / SELL_SIGMA;
+        const long long S = windows * (SELL_SIGMA / 64);
+        long long slots = (long long)e_cap + 64LL * L * windows;
+        const long long small = (long long)L * (vcap + 64);
+        if (rows <= MCCNN_PLAN_SMALL && small > slots) slots = small;
+        if (slots > 0x7fffffffLL || vcap > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
+        size_t o = 0;
+        o += plan_al((size_t)64 * S) * 2 + plan_al((size_t)S + 1) + plan_al((size_t)(rows > 0 ? rows : 1));
+        o += plan_al((size_t)(slots > 0 ? slots : 1)) + plan_al((size_t)(slots > 0 ? slots : 1) * 4);
+        if (o * 4 > buf) buf = o * 4;
+        const size_t w = align_up((size_t)(rows + 1) * sizeof(int)) * 2 + align_up((size_t)vcap * sizeof(int)) +
+                         align_up((size_t)S * sizeof(int)) + scan_workspace_bytes(rows > 0 ? rows : 1) + scan_workspace_bytes((int)S) + 512;
+        if (w > ws) ws = w;
+    }
+    if (transposed) {
+        const size_t t = mccnn_transpose_neighbors_workspace_bytes(rows, e_cap);
+        if (t > ws) ws = t;
+    }
+    *buffer_bytes = (long long)buf;
+    *ws_bytes = (long long)ws;
+    return 0;
+}
+
 size_t mccnn_rowplan_build_workspace_bytes(int rows, int e, int transposed) {
     size_t a = mccnn_rowplan_workspace_bytes(rows, e);
     size_t b = transposed ? mccnn_transpose_neighbors_workspace_bytes(rows, e) : 0;

@@ -146,6 +146,8 @@ bool rows_shape(bool combin, int fin, const void* feats, int rows, int n_points,
 std::atomic<long long> g_wait_ns{0};  // host time spent waiting for edge totals (mccnn_debug_wait_ns)
 
 // the edge total: stored by the prefix sum of the count pass straight into the caller's pinned word
+thread_local bool t_count_waits = true;  // (helper threads that wait instead of the caller's thread switch it off)
+
 int wait_edges(mccnn_geometry* g, int spin_us) {
     if (g->e >= 0) return g->e;
     if (!g->total_host) return -1;
@@ -154,7 +156,7 @@ int wait_edges(mccnn_geometry* g, int spin_us) {
         const auto t0 = std::chrono::steady_clock::now();
         struct Acc {
             std::chrono::steady_clock::time_point t;
-            ~Acc() { g_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(), std::memory_order_relaxed); }
+            ~Acc() { if (t_count_waits) g_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(), std::memory_order_relaxed); }
         } acc{t0};
         for (;;) {
             for (int k = 0; k < 256 && v < 0; ++k) v = *g->total_host;
@@ -355,6 +357,12 @@ int mccnn_geometry_build(mccnn_geometry_t* g, const float* pts, const int* batch
 
 long long mccnn_debug_wait_ns(void) { return g_wait_ns.load(std::memory_order_relaxed); }
 
+int mccnn_debug_wait_accounting(int on) {
+    const int prev = t_count_waits ? 1 : 0;
+    t_count_waits = on != 0;
+    return prev;
+}
+
 int mccnn_geometry_edges(mccnn_geometry_t* g, int wait_us) {
     if (!g || !g->built) return MCCNN_E_BADARG;
     const int e = wait_edges(g, wait_us);
@@ -411,6 +419,25 @@ int mccnn_geometry_piece_bytes(mccnn_geometry_t* g, int what, long long* bytes, 
     if (what == NEED_PLAN_TR) w = mccnn_rowplan_build_workspace_bytes(g->n, e, 1);
     *ws_bytes = (long long)(al(w) + 512);
     return *bytes > 0 ? 0 : MCCNN_E_BADARG;
+}
+
+// The same sizes for a geometry that is not built yet (n points, m centres, a list of at most e_cap edges): what a caller
+// allocates when it asks for pieces before the edge total exists.
+int mccnn_geometry_piece_bound(int n, int m, int e_cap, int what, long long* bytes, long long* ws_bytes) {
+    if (n < 0 || m < 0 || e_cap < 0 || !bytes || !ws_bytes) return MCCNN_E_BADARG;
+    long long b = 0, w = 256;
+    int rc = 0;
+    switch (what) {
+        case NEED_PLAN_FWD: rc = mccnn_rowplan_bound(m, e_cap, 0, &b, &w); break;
+        case NEED_PLAN_TR: rc = mccnn_rowplan_bound(n, e_cap, 1, &b, &w); break;
+        case NEED_TLIST: b = (long long)tlist_bytes(n, e_cap); w = (long long)mccnn_transpose_neighbors_workspace_bytes(n, e_cap); break;
+        case NEED_RECORDS: b = (long long)al((size_t)(e_cap > 0 ? e_cap : 1) * 16); break;
+        default: return MCCNN_E_BADARG;
+    }
+    if (rc) return rc;
+    *bytes = (long long)al((size_t)b);
+    *ws_bytes = (long long)(al((size_t)w) + 512);
+    return 0;
 }
 
 int mccnn_geometry_prebuild(mccnn_geometry_t* g, int what, int avg, void* ws, size_t ws_bytes, mccnn_stream_t stream) {

@@ -121,9 +121,10 @@ void give_event(hipEvent_t e) {
 // shares another one's grid is queued behind it). MCCNN_ISSUE_THREAD=0: the calling thread issues them itself.
 class Issuer {
 public:
-    // 0: geometry builds of the step in flight; 1: point hierarchies of the NEXT batch (those jobs block on read-backs)
+    // 0: geometry builds of the step in flight; 1: point hierarchies of the NEXT batch (those jobs block on read-backs);
+    // 2: row plans / transposed lists of the step's geometries (those jobs wait for edge totals)
     static Issuer& get(int which = 0) {
-        static Issuer inst[2];
+        static Issuer inst[3];
         return inst[which];
     }
     static bool enabled() {
@@ -186,18 +187,22 @@ struct Geo {
     int64_t e_cap = 0;
     int e = -1;
     int uses = 0;  // layers convolved over this geometry so far (the builder counts)
-    void wait_issued_nothrow() {
+    std::atomic<int> pieces_issued{1};  // 0 while the helper thread still has pieces of this geometry to attach / issue
+    void wait_build_issued_nothrow() {
         int spins = 0;
         while (!issued.load(std::memory_order_acquire))
             if (++spins > 2000) std::this_thread::yield();
     }
-    // the build's launches (and its event record) have been issued: nothing of the handle is touched before
+    void wait_issued_nothrow() {
+        wait_build_issued_nothrow();
+        int spins = 0;
+        while (!pieces_issued.load(std::memory_order_acquire))
+            if (++spins > 2000) std::this_thread::yield();
+    }
+    // the build's launches (and its event record) have been issued, and so have the pieces asked for with it: nothing
+    // of the handle is touched before
     void wait_issued() {
-        if (!issued.load(std::memory_order_acquire)) {
-            int spins = 0;
-            while (!issued.load(std::memory_order_acquire))
-                if (++spins > 2000) std::this_thread::yield();
-        }
+        wait_issued_nothrow();
         if (build_rc) {
             const int rc = build_rc;
             build_rc = 0;
@@ -205,7 +210,11 @@ struct Geo {
         }
     }
     // order `stream` behind the side-stream build (once: every later use of the geometry is on that stream as well)
-    void join(void* stream) {
+    // Pieces prebuilt on the side stream come in two stages with an event each: the forward row plan (and the records),
+    // then the transposed list and the transposed row plan. A forward pass waits for the first only -- unless it would
+    // have to build something itself (no forward plan among the pieces, another `avg`), which must not overlap the
+    // second stage: both write the shared records. A backward pass waits for both.
+    void join(void* stream, bool everything = true) {
         wait_issued();
         if (needs_wait && event) {
             hip_check(hipStreamWaitEvent((hipStream_t)stream, event, 0), "hipStreamWaitEvent");
@@ -214,6 +223,10 @@ struct Geo {
         if (plan_wait && plan_event) {
             hip_check(hipStreamWaitEvent((hipStream_t)stream, plan_event, 0), "hipStreamWaitEvent");
             plan_wait = false;
+        }
+        if (tr_wait && tr_event && (everything || !(have & 1))) {
+            hip_check(hipStreamWaitEvent((hipStream_t)stream, tr_event, 0), "hipStreamWaitEvent");
+            tr_wait = false;
         }
     }
     ~Geo() {
@@ -229,12 +242,42 @@ struct Geo {
             if (plan_wait && buf.defined()) (void)hipStreamWaitEvent((hipStream_t)alloc_stream, plan_event, 0);
             give_event(plan_event);
         }
+        if (tr_event) {
+            if (tr_wait && buf.defined()) (void)hipStreamWaitEvent((hipStream_t)alloc_stream, tr_event, 0);
+            give_event(tr_event);
+        }
         if (h) mccnn_geometry_destroy(h);
         if (slot.defined() && e >= 0) give_slot(std::move(slot));  // (a total that never arrived keeps its word)
     }
-    hipEvent_t plan_event = nullptr;   // recorded behind pieces prebuilt on a side stream (prebuild)
+    hipEvent_t plan_event = nullptr;   // recorded behind the forward row plan prebuilt on a side stream (prebuild)
     bool plan_wait = false;
+    hipEvent_t tr_event = nullptr;     // ... behind the transposed list / transposed row plan
+    bool tr_wait = false;
+    int pre_avg = -1;                  // the `avg` the prebuilt plans were made for
     int have = 0;                      // pieces attached so far (mask)
+
+    // The attached pieces of `what` (1 | 2 | 4) on stream ss, forward stage first; one event per stage.
+    int issue_pieces(int what, bool avg, hipStream_t ss, void* ws, size_t wsb) {
+        int rc = 0;
+        if (what & 1) {
+            rc = mccnn_geometry_prebuild(h, 1, avg ? 1 : 0, ws, wsb, (void*)ss);
+            if (!rc) {
+                if (!plan_event) plan_event = take_event();
+                if (hipEventRecord(plan_event, ss) != hipSuccess) rc = (int)hipErrorUnknown;
+                plan_wait = true;
+            }
+        }
+        if (!rc && (what & 6)) {
+            rc = mccnn_geometry_prebuild(h, what & 6, avg ? 1 : 0, ws, wsb, (void*)ss);
+            if (!rc) {
+                if (!tr_event) tr_event = take_event();
+                if (hipEventRecord(tr_event, ss) != hipSuccess) rc = (int)hipErrorUnknown;
+                tr_wait = true;
+            }
+        }
+        pre_avg = avg ? 1 : 0;
+        return rc;
+    }
 
     // Builds the pieces of `what` (1 forward row plan, 2 transposed row plan, 4 transposed list; the per-edge records
     // come with a plan) on side stream `side_k`, behind this geometry's own build and behind whatever the calling stream
@@ -270,10 +313,7 @@ struct Geo {
         hip_check(hipEventRecord(fork_ev, (hipStream_t)main_stream), "hipEventRecord");
         hip_check(hipStreamWaitEvent(ss, fork_ev, 0), "hipStreamWaitEvent");
         if (event && side < 0) hip_check(hipStreamWaitEvent(ss, event, 0), "hipStreamWaitEvent");
-        check(mccnn_geometry_prebuild(h, what & 7, avg ? 1 : 0, ws.data_ptr(), (size_t)ws.numel(), (void*)ss), "geometry_prebuild");
-        if (!plan_event) plan_event = take_event();
-        hip_check(hipEventRecord(plan_event, ss), "hipEventRecord");
-        plan_wait = true;
+        check(issue_pieces(what & 7, avg, ss, ws.data_ptr(), (size_t)ws.numel()), "geometry_prebuild");
     }
 
     int edges(int wait_us) {
@@ -398,6 +438,58 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
     return g;
 }
 
+// Pieces of a geometry whose build has just been queued on a side stream (learned prefetch: the layers of the previous
+// step over this list used them): the buffers are allocated HERE -- on the calling thread and its stream, sized by bounds
+// that hold for any list within the capacity -- and the helper thread attaches and issues them behind the build once the
+// edge total has arrived. The calling thread neither waits for the total nor issues the ~20 launches of a list's plans.
+void prebuild_async(std::shared_ptr<Geo> g, int what, bool avg) {
+    if (!g || g->side < 0 || !Issuer::enabled() || g->e_cap <= 0) return;
+    if (what & 3) what |= 8;
+    if (what & 2) what |= 4;
+    what &= 15 & ~g->have;
+    if (!what) return;
+    long long off[4] = {0, 0, 0, 0}, len[4] = {0, 0, 0, 0}, total = 0, wsb = 256;
+    for (int k = 0; k < 4; ++k) {
+        if (!(what & (1 << k))) continue;
+        long long b = 0, w = 0;
+        check(mccnn_geometry_piece_bound(g->n, g->m, (int)g->e_cap, 1 << k, &b, &w), "geometry_piece_bound");
+        off[k] = total;
+        len[k] = b;
+        total += (b + 255) / 256 * 256;
+        if (w > wsb) wsb = w;
+    }
+    Tensor block = at::empty({(int64_t)total}, g->buf.options());
+    g->attached.push_back(block);
+    hipStream_t ss = side_stream(g->side);
+    g->pieces_issued.store(0, std::memory_order_release);
+    char* base = (char*)block.data_ptr();
+    Tensor like = g->buf;
+    Issuer::get(2).push([g, what, avg, base, off, len, wsb, ss, like]() mutable {
+        g->wait_build_issued_nothrow();
+        if (g->build_rc == 0) {
+            const int prev = mccnn_debug_wait_accounting(0);
+            const int E = mccnn_geometry_edges(g->h, -1);
+            mccnn_debug_wait_accounting(prev);
+            if (E > 0 && E <= g->e_cap) {
+                int rc = 0;
+                for (int k = 0; k < 4 && !rc; ++k)
+                    if (what & (1 << k)) rc = mccnn_geometry_attach(g->h, 1 << k, base + off[k], (size_t)len[k]);
+                if (!rc) {
+                    g->have |= what;
+                    try {
+                        Tensor& ws = scratch((size_t)wsb, like, (void*)ss);
+                        rc = g->issue_pieces(what & 7, avg, ss, ws.data_ptr(), (size_t)ws.numel());
+                    } catch (const std::exception&) {
+                        rc = (int)hipErrorUnknown;
+                    }
+                }
+                // (a failure here leaves the pieces attached but unbuilt: the layer that needs one builds it, and reports)
+            }
+        }
+        g->pieces_issued.store(1, std::memory_order_release);
+    });
+}
+
 struct Layer {
     int fin, fout, combin, avg, bf16, flags;
 };
@@ -443,6 +535,7 @@ struct ConvBackward : public torch::autograd::Node {
         // layers with 2..4 input features is gathered through it in a fixed order (bit-reproducible) instead of added
         // with float atomics; a bare single call keeps the atomics (the list would cost more than they do)
         if (geo->uses > 1) flags |= 2;
+        geo->join(cur_stream(feats), true);
         long long wsb = 0, svb = 0;
         prepare(*geo, feats, L, 1, flags, wsb, svb);
         Tensor fg = at::empty_like(feats);
@@ -501,7 +594,7 @@ Tensor conv(std::shared_ptr<Geo> geo, const Tensor& feats, const Tensor& w1, con
     Tensor out, saved;
     {
         at::AutoDispatchBelowADInplaceOrView guard;
-        geo->join(cur_stream(feats));
+        geo->join(cur_stream(feats), geo->pre_avg != L.avg);
         if (geo->grid_owner) geo->grid_owner->join(cur_stream(feats));
         long long wsb = 0, svb = 0;
         prepare(*geo, feats, L, 0, L.flags, wsb, svb);
@@ -814,6 +907,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
             py::arg("mn"), py::arg("mx"), py::arg("B"), py::arg("nc"), py::arg("radius"), py::arg("scale_inv"),
             py::arg("window"), py::arg("use_pdf"), py::arg("capacity"), py::arg("grid_from").none(true),
             py::arg("side") = -1, py::arg("fork") = false, py::arg("background") = false);
+    mod.def("prebuild_async", &prebuild_async, py::arg("geometry"), py::arg("what"), py::arg("avg"));
     mod.def("conv", &conv);
     mod.def("hierarchy_levels", &hierarchy_levels, py::call_guard<py::gil_scoped_release>());
     py::class_<HierFuture, std::shared_ptr<HierFuture>>(mod, "HierarchyFuture")

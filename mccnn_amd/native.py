@@ -140,6 +140,18 @@ class Geometry:
             self.edges()
             self.core.prebuild(int(what), bool(avg), int(side), like)
 
+    @property
+    def have(self):
+        """Mask of the pieces attached so far (NEED_*)."""
+        return int(self.core.have) if self.core is not None else 0
+
+    def prebuild_async(self, what, avg):
+        """Pieces of a geometry whose build has just been queued on a side stream: buffers allocated now (bounds over
+        the capacity), attached and issued by the extension's helper thread once the edge total has arrived -- the
+        calling thread does not wait."""
+        if self.core is not None:
+            _EXT.prebuild_async(self.core, int(what), bool(avg))
+
     # ------------------------------------------------------------------ views (tests, the builder's cache tuples)
     def _info(self):
         if self.core is not None:
