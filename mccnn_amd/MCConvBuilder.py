@@ -661,7 +661,9 @@ class ConvolutionBuilder(torch.nn.Module):
             self.cacheNeighs_[keyNeighs] = _LazyEntry(geo, geo.neighbors)
             self.cachePDFs_[keyPDF] = _LazyEntry(geo, geo.pdfs)
             if transposed:
-                geo.prebuild(_native.NEED_PLAN_TR if transposed == 2 else _native.NEED_TLIST, self.useAVG_, 0, geo.buf)
+                # (depth-wise layers: both row plans -- the forward pass then waits for the first stage only)
+                geo.prebuild((_native.NEED_PLAN_FWD | _native.NEED_PLAN_TR) if transposed == 2 else _native.NEED_TLIST,
+                             self.useAVG_, 0, geo.buf)
 
     def __prebuild_geometries__(self, ph):
         """Learned prefetch: every geometry the previous step built over a hierarchy of this name, issued now -- before the
