@@ -42,6 +42,21 @@ void check(int rc, const char* what) {
     throw std::runtime_error(std::string(what) + " failed: " + mccnn_error_string(rc) + " (code " + std::to_string(rc) + ")");
 }
 
+// The HIP runtime's current device for the length of a call: the library launches on streams of its tensors' device and
+// that device has to be current on the launching thread (a caller working with several devices may have another one set).
+struct DevGuard {
+    int prev = 0;
+    bool changed = false;
+    explicit DevGuard(int d) {
+        if (hipGetDevice(&prev) == hipSuccess && d != prev && d >= 0) changed = hipSetDevice(d) == hipSuccess;
+    }
+    ~DevGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
+
 void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
 // grow-only scratch per (thread, device, stream): consecutive calls on a stream are stream-ordered and may share it
@@ -81,14 +96,25 @@ void give_slot(Tensor t) {
 // a step's geometries are independent of each other and of the features, so they run side by side -- each is a dozen
 // small dependent kernels that leave the chip nearly empty -- and the layer that consumes one waits for its event.
 constexpr int kSideStreams = 4;
+constexpr int kMaxDevices = 16;
+int device_now() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return (d >= 0 && d < kMaxDevices) ? d : 0;
+}
+// (streams of the CURRENT device: every entry point below runs under a guard of its tensors' device)
 hipStream_t side_stream(int k) {
-    static hipStream_t streams[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
-    static std::once_flag once;
-    std::call_once(once, [] {
+    static hipStream_t streams[kMaxDevices][kSideStreams] = {};
+    static bool made[kMaxDevices] = {};
+    static std::mutex m;
+    const int d = device_now();
+    std::lock_guard<std::mutex> lk(m);
+    if (!made[d]) {
         for (int i = 0; i < kSideStreams; ++i)
-            if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess) streams[i] = nullptr;
-    });
-    return streams[((k % kSideStreams) + kSideStreams) % kSideStreams];
+            if (hipStreamCreateWithFlags(&streams[d][i], hipStreamNonBlocking) != hipSuccess) streams[d][i] = nullptr;
+        made[d] = true;
+    }
+    return streams[d][((k % kSideStreams) + kSideStreams) % kSideStreams];
 }
 void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -114,6 +140,14 @@ void give_event(hipEvent_t e) {
     std::lock_guard<std::mutex> lk(g_event_mutex);
     if (g_events.size() < 256) g_events.push_back(e);
     else (void)hipEventDestroy(e);
+}
+
+// A helper thread starts with device 0 current; every job names the device of its tensors first (one process per GPU sets
+// its device on the calling thread only -- kernel launches, memsets and event records of a job go to streams of THAT
+// device and need it current on the issuing thread as well).
+void enter_device(int dev) {
+    thread_local int current = -1;
+    if (dev != current && hipSetDevice(dev) == hipSuccess) current = dev;
 }
 
 // The launches of a side-stream build are ISSUED by a helper thread: a step's geometries are a dozen launches each
@@ -284,6 +318,7 @@ struct Geo {
     // holds now (`like`'s stream: the buffers are allocated there). Waits for the edge total. The layers that use the
     // geometry order their stream behind the pieces' event.
     void prebuild(int what, bool avg, int side_k, const Tensor& like) {
+        const DevGuard device_guard((int)like.device().index());
         wait_issued();
         const int E = edges(-1);
         if (E <= 0 || E > e_cap) return;   // (an overflowing list is rebuilt by the first layer: nothing to build ahead)
@@ -347,6 +382,7 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
     check_dev(cbids, at::kInt, "sample batch ids");
     check_dev(mn, at::kFloat, "aabb_min");
     check_dev(mx, at::kFloat, "aabb_max");
+    const DevGuard device_guard((int)pts.device().index());
     const int n = (int)pts.size(0), m = (int)centres.size(0);
     if (grid_from && grid_from->grid_owner) grid_from = grid_from->grid_owner;
     const size_t bytes = mccnn_geometry_bytes(n, m, (int)B, (int)nc, (int)capacity, grid_from ? 0 : 1);
@@ -404,7 +440,9 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
         int* slotp = g->slot.data_ptr<int>();
         const int iB = (int)B, inc = (int)nc, icap = (int)capacity, isi = scale_inv ? 1 : 0, ipdf = use_pdf ? 1 : 0;
         const float fr = (float)radius, fw = (float)window;
-        Issuer::get().push([g, grid_from, p0, p1, p2, p3, p4, p5, bufp, slotp, n, m, iB, inc, icap, isi, ipdf, fr, fw, bytes, stream, background] {
+        const int dev = (int)pts.device().index();
+        Issuer::get().push([g, grid_from, p0, p1, p2, p3, p4, p5, bufp, slotp, n, m, iB, inc, icap, isi, ipdf, fr, fw, bytes, stream, background, dev] {
+            enter_device(dev);
             if (grid_from) grid_from->wait_issued_nothrow();
             // background: these launches run beside kernels a step waits for (the convolutions of the current batch) --
             // the search kernels then hold back (mccnn_background_launches, thread-local: set on THIS thread)
@@ -444,6 +482,7 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
 // edge total has arrived. The calling thread neither waits for the total nor issues the ~20 launches of a list's plans.
 void prebuild_async(std::shared_ptr<Geo> g, int what, bool avg) {
     if (!g || g->side < 0 || !Issuer::enabled() || g->e_cap <= 0) return;
+    const DevGuard device_guard((int)g->buf.device().index());
     if (what & 3) what |= 8;
     if (what & 2) what |= 4;
     what &= 15 & ~g->have;
@@ -465,6 +504,7 @@ void prebuild_async(std::shared_ptr<Geo> g, int what, bool avg) {
     char* base = (char*)block.data_ptr();
     Tensor like = g->buf;
     Issuer::get(2).push([g, what, avg, base, off, len, wsb, ss, like]() mutable {
+        enter_device((int)like.device().index());
         g->wait_build_issued_nothrow();
         if (g->build_rc == 0) {
             const int prev = mccnn_debug_wait_accounting(0);
@@ -524,6 +564,7 @@ struct ConvBackward : public torch::autograd::Node {
 
     torch::autograd::variable_list apply(torch::autograd::variable_list&& grads) override {
         TORCH_CHECK(geo, "MC convolution: backward through a graph whose buffers have been freed (retain_graph=True?)");
+        const DevGuard device_guard((int)geo->buf.device().index());
         const Tensor feats = feats_.unpack(), w1 = w1_.unpack(), b1 = b1_.unpack(), w2 = w2_.unpack(), b2 = b2_.unpack(),
                      w3 = w3_.unpack(), b3 = b3_.unpack();
         Tensor og = grads[0];
@@ -580,6 +621,7 @@ struct ConvBackward : public torch::autograd::Node {
 Tensor conv(std::shared_ptr<Geo> geo, const Tensor& feats, const Tensor& w1, const Tensor& b1, const Tensor& w2,
             const Tensor& b2, const Tensor& w3, const Tensor& b3, int64_t fout, bool combin, bool avg) {
     TORCH_CHECK(geo && geo->h, "conv: no geometry");
+    const DevGuard device_guard((int)feats.device().index());
     TORCH_CHECK(feats.defined() && feats.is_cuda() && feats.dim() == 2 && feats.size(0) == geo->n && feats.is_contiguous(),
                 "SpatialConvOp expects as feature inputs the following dimensions (numPoints, numFeatures)");
     const bool bf = feats.scalar_type() == at::kBFloat16;
@@ -640,6 +682,7 @@ std::vector<std::vector<Tensor>> hierarchy_levels(const Tensor& pts, const Tenso
     check_dev(bids, at::kInt, "batch ids");
     check_dev(mn, at::kFloat, "aabb_min");
     check_dev(mx, at::kFloat, "aabb_max");
+    const DevGuard device_guard((int)pts.device().index());
     const int L = (int)radii.size();
     const int cap = (int)pts.size(0);
     TORCH_CHECK(L > 0 && (int)ncs.size() == L && cap > 0, "hierarchy_levels: bad arguments");
@@ -706,12 +749,16 @@ std::vector<std::vector<Tensor>> hierarchy_levels(const Tensor& pts, const Tenso
 // go back to the allocator they came from after every reader. Temporaries (sorted copies, cell tables, scan words) live
 // in the helper thread's own scratch.
 hipStream_t hier_stream() {
-    static hipStream_t s = nullptr;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
-    });
-    return s;
+    static hipStream_t streams[kMaxDevices] = {};
+    static bool made[kMaxDevices] = {};
+    static std::mutex m;
+    const int d = device_now();
+    std::lock_guard<std::mutex> lk(m);
+    if (!made[d]) {
+        if (hipStreamCreateWithFlags(&streams[d], hipStreamNonBlocking) != hipSuccess) streams[d] = nullptr;
+        made[d] = true;
+    }
+    return streams[d];
 }
 
 struct HierFuture {
@@ -749,6 +796,7 @@ struct HierFuture {
     // the helper thread's part: boxes, cell counts, the levels, ONE read-back of the sizes
     void run(hipStream_t ss) {
         try {
+            enter_device((int)pts.device().index());
             const float* P = pts.data_ptr<float>();
             const int* Bi = bids.data_ptr<int>();
             float* pmn = mn.data_ptr<float>();
@@ -822,6 +870,7 @@ struct HierFuture {
                                 std::memory_order_relaxed);
         }
         if (rc) throw std::runtime_error("PointHierarchy prefetch: " + what);
+        const DevGuard device_guard((int)pts.device().index());
         if (!joined) {
             hip_check(hipStreamWaitEvent((hipStream_t)cur_stream(pts), event, 0), "hipStreamWaitEvent");
             joined = true;
@@ -842,6 +891,7 @@ std::shared_ptr<HierFuture> hierarchy_prefetch(const Tensor& pts, const Tensor& 
                                                int64_t B, bool scale_inv, int64_t pmode) {
     check_dev(pts, at::kFloat, "points");
     check_dev(bids, at::kInt, "batch ids");
+    const DevGuard device_guard((int)pts.device().index());
     const int L = (int)radii.size();
     const int cap = (int)pts.size(0);
     TORCH_CHECK(L > 0 && cap > 0 && B > 0, "hierarchy_prefetch: bad arguments");

@@ -2,7 +2,7 @@
 
   cfg1  ModelNet40 MCClassS, 32 clouds x 1 024 points, grow 16   (models/MCClassS.py:29-71)
   cfg2  ModelNet40 MCClassH, 32 clouds x 4 096 points, 3 Poisson levels (models/MCClassH.py:30-187)
-  cfg3  ShapeNet-Part MCSeg, 16 clouds x 8 192 points, grow 32, bf16 feature rows in the depth-wise layers
+  cfg3  ShapeNet-Part MCSeg, 16 clouds x 8 192 points, grow 32, bf16 feature rows in the depth-wise layers (and again with f32 rows)
         (models/MCSeg.py:29-198; encoder, decoder and the two skip up-samplings)
 
 For every level of the point hierarchy and every convolution of the graph: ALL integer outputs (keys, sort order, cell
@@ -222,12 +222,18 @@ def test_cfg2_mcclass_h_32x4096(mc, oracle_omp):
     print("cfg2 level sizes", sizes, "worst rel errs", {k: "%.1e" % v for k, v in worst.items()})
 
 
-MCSEG_K32 = _specs(mcseg(32))  # models/MCSeg.py:36-198, grow 32 (BASELINE cfg3), bf16 feature storage for the depth-wise layers
+MCSEG_K32 = _specs(mcseg(32))  # models/MCSeg.py:36-198, grow 32 (BASELINE cfg3: "bf16 features" -- bf16 feature storage in the depth-wise layers)
+MCSEG_K32_F32 = _specs(mcseg(32, bf16=False))  # the same graph with the reference's own f32 rows
 
 
 def test_cfg3_mcseg_16x8192_bf16_rows(mc, oracle_omp):
     sizes, worst = check_config(mc, oracle_omp, 8192, 16, [0.025, 0.1, 0.4], MCSEG_K32, 47)
     print("cfg3 level sizes", sizes, "worst", {k: "%.1e" % v for k, v in worst.items()})
+
+
+def test_cfg3_mcseg_16x8192_f32_rows(mc, oracle_omp):
+    sizes, worst = check_config(mc, oracle_omp, 8192, 16, [0.025, 0.1, 0.4], MCSEG_K32_F32, 47)
+    print("cfg3 (f32 rows) level sizes", sizes, "worst", {k: "%.1e" % v for k, v in worst.items()})
 
 
 def test_cfg4_mcsegscannet_room(mc, oracle_omp):
