@@ -30,13 +30,20 @@ class MCClassS(torch.nn.Module):
         self.ops = ops  # None = the HIP op surface; the parity tests pass the CPU checker's
         self.convBuilder = ConvolutionBuilder(KDEWindow=0.2, device=device, ops=ops)
 
+    RADII = [0.1, 0.4, math.sqrt(3.0) + 0.1]
+
+    def prefetch_hierarchy(self, points, batchIds):
+        """Extension: starts the point hierarchy of a batch on a stream of its own (PointHierarchy.prefetch) -- call it for
+        batch k + 1 before the forward pass of batch k and hand the result to forward(prefetched=...)."""
+        return PointHierarchy.prefetch(points, batchIds, self.RADII, self.args[1])
+
     def forward(self, points, batchIds, features, isTraining, keepProbConv=1.0, keepProbFull=0.5, useConvDropOut=False,
-                 useDropOutFull=True):
+                 useDropOutFull=True, prefetched=None):
         numInputFeatures, batchSize, k, numOutCat = self.args
         st, mConvBuilder = self.store, self.convBuilder
         mConvBuilder.reset()
-        mPointHierarchy = PointHierarchy(points, features, batchIds, [0.1, 0.4, math.sqrt(3.0) + 0.1], "MCClassS_PH",
-                                         batchSize, ops=self.ops)
+        mPointHierarchy = PointHierarchy(points, features, batchIds, self.RADII, "MCClassS_PH", batchSize, ops=self.ops,
+                                         prefetched=prefetched)
         convFeatures1 = mConvBuilder.create_convolution(
             convName="Conv_1", inPointHierarchy=mPointHierarchy, inPointLevel=0, outPointLevel=1, inFeatures=features,
             inNumFeatures=numInputFeatures, outNumFeatures=k, convRadius=0.2, multiFeatureConv=True)
@@ -114,9 +121,14 @@ def main():
     P, Bi, F, y = synthetic_batch(args.batch, args.points, 4, rng, device)
     net(P, Bi, F, True)  # creates the variables
     opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    nxt = synthetic_batch(args.batch, args.points, 4, rng, device)
     for step in range(args.steps):
-        P, Bi, F, y = synthetic_batch(args.batch, args.points, 4, rng, device)
-        logits = net(P, Bi, F, True)
+        P, Bi, F, y = nxt
+        ahead = net.prefetch_hierarchy(P, Bi) if step == 0 else ahead_next
+        # the loader's next batch, and its point hierarchy under this batch's forward / backward pass
+        nxt = synthetic_batch(args.batch, args.points, 4, rng, device)
+        ahead_next = net.prefetch_hierarchy(nxt[0], nxt[1])
+        logits = net(P, Bi, F, True, prefetched=ahead)
         loss = torch.nn.functional.cross_entropy(logits, y)
         opt.zero_grad(set_to_none=True)
         loss.backward()

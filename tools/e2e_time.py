@@ -19,8 +19,14 @@ net(P, Bi, F, True)
 opt = torch.optim.Adam(net.parameters(), lr=1e-3)
 
 
-def step():
-    logits = net(P, Bi, F, True)
+AHEAD = [None]
+
+
+def step(pipelined=False):
+    ahead = AHEAD[0]
+    if pipelined:  # the next batch's point hierarchy one step ahead (here: the same batch again)
+        AHEAD[0] = net.prefetch_hierarchy(P, Bi)
+    logits = net(P, Bi, F, True, prefetched=ahead if pipelined else None)
     loss = torch.nn.functional.cross_entropy(logits, y)
     opt.zero_grad(set_to_none=True)
     loss.backward()
@@ -39,3 +45,13 @@ for mt in (True, False):
     dt = (time.perf_counter() - t0) / 20
     print("MCClassS cfg1 (32 x 1024 pts, k=16), autograd multithreading %s: %.2f ms/step, %.0f clouds/s, levels %s"
           % (mt, dt * 1e3, B / dt, [int(p.shape[0]) for p in net.lastHierarchy.points_]))
+AHEAD[0] = net.prefetch_hierarchy(P, Bi)
+for _ in range(5):
+    step(True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    step(True)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 20
+print("... with the next batch's hierarchy one step ahead (PointHierarchy.prefetch): %.2f ms/step, %.0f clouds/s" % (dt * 1e3, B / dt))
