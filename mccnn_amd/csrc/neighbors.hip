@@ -43,6 +43,13 @@ __device__ __forceinline__ CentreCtx centre_ctx(const float* __restrict__ centre
 // thread per (centre, cell) 60 + 82 us, this one 31 + 37 us. FILL == false counts per centre, FILL == true writes the
 // (j, i) rows at startIdx[i].
 // Windows larger than MCCNN_NW_CAP points are processed in segments of the flat candidate list.
+// v[lane L] = val (wave-uniform), L a compile-time lane: v_writelane_b32 (one SGPR operand per instruction on gfx9, so the
+// lane select is an inline constant)
+template <int L>
+__device__ __forceinline__ void writelane_u(unsigned& v, unsigned val) {
+    const unsigned sv = __builtin_amdgcn_readfirstlane(val);
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(sv), "n"(L));
+}
 __device__ __forceinline__ float readlane_f(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -62,7 +69,12 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 // MODE 0 = count: hits per centre, and the ballot of every 64-candidate round is saved (`masks`).
 // MODE 1 = fill: writes the (j, i) rows at startIdx[i]. Windows whose rounds fit the saved masks are a pure
 //          compaction -- no point is loaded and no distance evaluated a second time; larger windows are searched again.
-template <int MODE>
+// LEAN (foreground launches): the test loop carries no bounds -- the last round of a segment is padded with points out of
+// anybody's reach --, is unrolled over the four rounds of a segment, and the count pass keeps their ballots in lanes 0..3
+// and stores them with ONE instruction per (centre, segment). Faster alone (count pass on the room 35 -> 26 us), but its
+// denser LDS-read / VALU bursts cost the convolution kernels it runs beside more than the search saves (pipelined step
+// 0.640 -> 0.672 ms): background launches (mccnn_background_launches) keep the plain loop.
+template <int MODE, bool LEAN>
 __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ centres, const int* __restrict__ cb, int m,
                                                     const float* __restrict__ pts, const int* __restrict__ cells,
                                                     const float* __restrict__ mn, const float* __restrict__ mx, int B, int nc,
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                                                     int* __restrict__ cnt, unsigned long long* __restrict__ masks,
                                                     const int* __restrict__ startIdx, int* __restrict__ packed,
                                                     int capacity, unsigned long long* __restrict__ zeroWords, int numZero,
-                                                    int G /* centres per wave, 1 .. MCCNN_NW_G */, float Tabs) {
+                                                    int G /* centres per wave, 1 .. 32 */, float Tabs) {
     constexpr bool FILL = MODE == 1;
     // the status words of the prefix sum that follows the count pass (scan.hip): cleared here, no launch of their own
     if (!FILL && blockIdx.x == 0)
@@ -165,14 +177,63 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
             // stage [seg, seg + segN) of the flat list: lane = flat position, one load and one LDS write per position
             for (int r = 0; r < segN; r += 64) {
                 const int j = flat_to_j(min(seg + r + lane, total - 1));
-                if (r + lane < segN) {
-                    const float* q = pts + (size_t)j * 3;  // 12-byte rows: one dwordx3 load
+                const float* q = pts + (size_t)j * 3;  // 12-byte rows: one dwordx3 load
+                if (LEAN) {
+                    const bool real = r + lane < segN;
+                    lw[r + lane] = make_float4(real ? q[0] : 3.0e18f, q[1], q[2], __int_as_float(j));
+                } else if (r + lane < segN) {
                     lw[r + lane] = make_float4(q[0], q[1], q[2], __int_as_float(j));
                 }
             }
             __builtin_amdgcn_wave_barrier();
             // every centre of this cell against the staged candidates
             unsigned mem = members;
+            if constexpr (LEAN && !FILL) {
+                // the count pass of foreground launches tests TWO centres per candidate: packed f32 arithmetic (8
+                // v_pk_* + 2 compares per 64 candidates and centre pair instead of 2 x 9 instructions; the same
+                // operations in the same order per half, so the same decisions) and one LDS read serves both
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                while (mem) {
+                    const int c0 = __builtin_ctz(mem);
+                    mem &= mem - 1;
+                    const bool two = mem != 0;
+                    const int c1 = two ? __builtin_ctz(mem) : c0;
+                    mem &= mem - 1;   // (0 & anything stays 0)
+                    const f32x2 CX = {readlane_f(c.cx, c0), readlane_f(c.cx, c1)};
+                    const f32x2 CY = {readlane_f(c.cy, c0), readlane_f(c.cy, c1)};
+                    const f32x2 CZ = {readlane_f(c.cz, c0), readlane_f(c.cz, c1)};
+                    const float T0 = readlane_f(c.T, c0), T1 = readlane_f(c.T, c1);
+                    int n0 = __builtin_amdgcn_readlane(count, c0), n1 = __builtin_amdgcn_readlane(count, c1);
+                    unsigned lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+                    auto round = [&](auto kc) {
+                        constexpr int K = decltype(kc)::value;
+                        const float4 p = lw[K * 64 + lane];
+                        const f32x2 X = {p.x, p.x}, Y = {p.y, p.y}, Z = {p.z, p.z};
+                        const f32x2 dx = X - CX, dy = Y - CY, dz = Z - CZ;
+                        const f32x2 d2 = dx * dx + dy * dy + dz * dz;   // point_dist2, both halves (no contraction: -ffp-contract=off)
+                        const unsigned long long b0 = __ballot(d2.x < T0), b1 = __ballot(d2.y < T1);
+                        writelane_u<K>(lo0, (unsigned)b0);
+                        writelane_u<K>(hi0, (unsigned)(b0 >> 32));
+                        writelane_u<K>(lo1, (unsigned)b1);
+                        writelane_u<K>(hi1, (unsigned)(b1 >> 32));
+                        n0 += __builtin_popcountll(b0);
+                        n1 += __builtin_popcountll(b1);
+                    };
+                    static_assert(MCCNN_NW_CAP == 256, "four rounds per segment below");
+                    round(std::integral_constant<int, 0>{});
+                    if (segN > 64) round(std::integral_constant<int, 1>{});
+                    if (segN > 128) round(std::integral_constant<int, 2>{});
+                    if (segN > 192) round(std::integral_constant<int, 3>{});
+                    const int round0 = seg >> 6;  // MCCNN_NW_CAP is a multiple of 64: a segment starts on a round
+                    if (lane < ((segN + 63) >> 6) && round0 + lane < MCCNN_NW_ROUNDS) {
+                        unsigned long long* row = masks + (size_t)__builtin_amdgcn_readfirstlane(g0) * MCCNN_NW_ROUNDS + round0 + lane;
+                        row[(size_t)c0 * MCCNN_NW_ROUNDS] = ((unsigned long long)hi0 << 32) | lo0;
+                        if (two) row[(size_t)c1 * MCCNN_NW_ROUNDS] = ((unsigned long long)hi1 << 32) | lo1;
+                    }
+                    if (lane == c0) count = n0;
+                    if (two && lane == c1) count = n1;
+                }
+            } else
             while (mem) {
                 const int cl = __builtin_ctz(mem);
                 mem &= mem - 1;
@@ -186,6 +247,43 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                 // alone 35 -> 26 us and a sequential step 0.740 -> 0.728 ms, but the PIPELINED step 0.640 -> 0.672 ms, whatever
                 // the centres per wave, the store form or the issue priority of the convolution kernels (s_setprio): beside
                 // the convolution kernels the denser LDS-read / VALU bursts cost them more than the search saves.)
+                if (LEAN) {
+                    unsigned mlo = 0, mhi = 0;
+                    static_assert(MCCNN_NW_CAP % 64 == 0 && MCCNN_NW_CAP <= 512, "rounds of a segment: lanes 0..7 below");
+                    auto round = [&](auto kc) {
+                        constexpr int K = decltype(kc)::value;
+                        const float4 p = lw[K * 64 + lane];
+                        const bool hit = point_dist2(p.x, p.y, p.z, cx, cy, cz) < T;
+                        const unsigned long long bm = __ballot(hit);
+                        if (FILL && hit) {
+                            const int pos = cbase + ccount + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+                            if (pos < capacity) out[pos] = make_int2(__float_as_int(p.w), cid);  // capacity < E: see _fill
+                        }
+                        if (!FILL) {
+                            writelane_u<K>(mlo, (unsigned)bm);
+                            writelane_u<K>(mhi, (unsigned)(bm >> 32));
+                        }
+                        ccount += __builtin_popcountll(bm);
+                    };
+                    round(std::integral_constant<int, 0>{});
+                    if (segN > 64) round(std::integral_constant<int, 1>{});
+                    if (segN > 128) round(std::integral_constant<int, 2>{});
+                    if (segN > 192) round(std::integral_constant<int, 3>{});
+                    if constexpr (MCCNN_NW_CAP > 256) {
+                        if (segN > 256) round(std::integral_constant<int, 4>{});
+                        if (segN > 320) round(std::integral_constant<int, 5>{});
+                    }
+                    if constexpr (MCCNN_NW_CAP > 384) {
+                        if (segN > 384) round(std::integral_constant<int, 6>{});
+                        if (segN > 448) round(std::integral_constant<int, 7>{});
+                    }
+                    if (!FILL) {
+                        const int round0 = seg >> 6;  // MCCNN_NW_CAP is a multiple of 64: a segment starts on a round
+                        if (lane < ((segN + 63) >> 6) && round0 + lane < MCCNN_NW_ROUNDS)
+                            masks[(size_t)(__builtin_amdgcn_readfirstlane(g0) + cl) * MCCNN_NW_ROUNDS + round0 + lane] =
+                                ((unsigned long long)mhi << 32) | mlo;
+                    }
+                } else
                 for (int r = 0; r < segN; r += 64) {
                     const int t = r + lane;
                     const float4 p = lw[min(t, segN - 1)];
@@ -663,10 +761,19 @@ static size_t neigh_lds_pad() {
     if (forced >= 0) return (size_t)forced;
     return g_background ? 24000 : 0;
 }
+static bool neigh_lean() {
+    static const int forced = getenv("MCCNN_NW_LEAN") ? atoi(getenv("MCCNN_NW_LEAN")) : -1;  // A/B switch, read once
+    if (forced >= 0) return forced != 0;
+    return !g_background;
+}
 static int neigh_group(int m) {
     static const int forced = getenv("MCCNN_NW_GROUP") ? atoi(getenv("MCCNN_NW_GROUP")) : 0;  // A/B switch, read once
     if (forced >= 1 && forced <= 32) return forced;
-    return m >= 32768 ? MCCNN_NW_G : (m >= 16384 ? 4 : (m >= 8192 ? 2 : 1));
+    // centres per wave: more of them share a window's staging and the per-wave set-up (8 rooms, 800 k centres: 0.309 ms at
+    // 8, 0.274 at 16, 0.269 at 24) -- as long as the launch still fills the chip (100 k centres: 0.0588 / 0.0580 / 0.0650)
+    // (background launches keep 8: beside the convolution kernels the pipelined step of the room reads 0.596 ms at 8, 0.602-0.610 at 16)
+    if (g_background) return m >= 32768 ? MCCNN_NW_G : (m >= 16384 ? 4 : (m >= 8192 ? 2 : 1));
+    return m >= 400000 ? 24 : (m >= 65536 ? 16 : (m >= 32768 ? MCCNN_NW_G : (m >= 16384 ? 4 : (m >= 8192 ? 2 : 1))));
 }
 
 struct NeighWs {
@@ -724,10 +831,17 @@ static int find_neighbors_count_impl(const float* centres, const int* centre_bat
     NeighWs w;
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     const int G = neigh_group(m);
-    neigh_window<0><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
-                                                     aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, w.cnt,
-                                                     w.masks, nullptr, nullptr, 0, (unsigned long long*)w.scanws,
-                                                     (int)(scan_status_bytes(m) / sizeof(unsigned long long)), G, scale_inv ? 0.0f : sqrt_threshold_host(radius));
+    const float Tabs = scale_inv ? 0.0f : sqrt_threshold_host(radius);
+    unsigned long long* zw = (unsigned long long*)w.scanws;
+    const int nz = (int)(scan_status_bytes(m) / sizeof(unsigned long long));
+    if (neigh_lean())
+        neigh_window<0, true><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs,
+                                                     aabb_min, aabb_max, batch_size, num_cells, radius, scale_inv, centre_order,
+                                                     w.cnt, w.masks, nullptr, nullptr, 0, zw, nz, G, Tabs);
+    else
+        neigh_window<0, false><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs,
+                                                     aabb_min, aabb_max, batch_size, num_cells, radius, scale_inv, centre_order,
+                                                     w.cnt, w.masks, nullptr, nullptr, 0, zw, nz, G, Tabs);
     MCCNN_LAUNCHED();
     int rc = exclusive_scan_i32(w.cnt, start_idx, m, total_dev, w.scanws, s, true, total_host);
     if (rc) return rc;
@@ -747,9 +861,15 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int G = neigh_group(m);
-    neigh_window<1><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs, aabb_min,
-                                                     aabb_max, batch_size, num_cells, radius, scale_inv, centre_order, nullptr,
-                                                     w.masks, start_idx, packed, e, nullptr, 0, G, scale_inv ? 0.0f : sqrt_threshold_host(radius));
+    const float Tabs = scale_inv ? 0.0f : sqrt_threshold_host(radius);
+    if (neigh_lean())
+        neigh_window<1, true><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs,
+                                                     aabb_min, aabb_max, batch_size, num_cells, radius, scale_inv, centre_order,
+                                                     nullptr, w.masks, start_idx, packed, e, nullptr, 0, G, Tabs);
+    else
+        neigh_window<1, false><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs,
+                                                     aabb_min, aabb_max, batch_size, num_cells, radius, scale_inv, centre_order,
+                                                     nullptr, w.masks, start_idx, packed, e, nullptr, 0, G, Tabs);
     MCCNN_LAUNCHED();
     return 0;
 }
