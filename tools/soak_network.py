@@ -1,0 +1,95 @@
+"""Soak test of a whole network's pipelined loop on the native executor: thousands of MCClassH-graph steps (three-level
+hierarchy, 10 convolutions over 7 neighbour lists, depth-wise layers with row plans) over batches of DIFFERENT sizes in
+random order, with everything that runs ahead switched on -- the next batch's PointHierarchy on its helper thread, the
+learned geometry prefetch on side streams, the row plans / transposed lists on the third helper thread -- and no host
+synchronisation inside the loop. Every step's outputs and gradients are compared ON the GPU with the per-batch reference
+computed with all of it switched off; capacity guesses overflow whenever a larger batch follows a smaller one.
+    SOAK_STEPS=2000 python tools/soak_network.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder  # noqa: E402
+from mccnn_amd.workloads import CONFIGS, config_points  # noqa: E402
+
+torch.cuda.set_device(0)
+torch.autograd.set_multithreading_enabled(False)
+STEPS = int(os.environ.get("SOAK_STEPS", "2000"))
+cfg = CONFIGS["cfg2"]
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(7)
+
+
+class Batch:
+    def __init__(self, clouds, points, seed):
+        c = cfg._replace(clouds=clouds, points=points, seed=seed)
+        p, b, self.B = config_points(c)
+        self.P, self.Bi = torch.from_numpy(p).to(dev), torch.from_numpy(b).to(dev)
+        self.F0 = torch.ones((len(p), 1), device=dev)
+        self.feats = self.ogs = None
+
+    def hierarchy(self, prefetched=None):
+        return PointHierarchy(self.P, self.F0, self.Bi, list(cfg.hierarchy), "PH", self.B, cfg.relative, prefetched=prefetched)
+
+    def request(self):
+        return PointHierarchy.prefetch(self.P, self.Bi, list(cfg.hierarchy), self.B, cfg.relative)
+
+    def rows(self, ph):
+        if self.feats is None:
+            self.feats, self.ogs = [], []
+            for ci, c in enumerate(cfg.convs):
+                g = torch.Generator(device="cpu").manual_seed(100 + ci)
+                n, m = int(ph.points_[c.lin].shape[0]), int(ph.points_[c.lout].shape[0])
+                self.feats.append((2 * torch.rand((n, c.fin), generator=g) - 1).to(dev).requires_grad_(True))
+                self.ogs.append((2 * torch.rand((m, c.fout if c.combin else c.fin), generator=g) - 1).to(dev))
+
+
+def step(builder, batch, prefetched=None):
+    builder.reset()
+    ph = batch.hierarchy(prefetched)
+    batch.rows(ph)
+    outs = [builder.create_convolution(c.name, ph, c.lin, batch.feats[ci], c.fin, c.radius, ph, c.lout, c.combin, c.fout, c.window)
+            for ci, c in enumerate(cfg.convs)]
+    grads = torch.autograd.grad(outs, batch.feats + list(builder.parameters()), batch.ogs, allow_unused=True)
+    return outs, grads
+
+
+batches = [Batch(c, p, s) for c, p, s in ((8, 4096, 43), (5, 3000, 44), (12, 2048, 45), (6, 4096, 46), (3, 8192, 47), (10, 1024, 48))]
+torch.manual_seed(3)
+builder = ConvolutionBuilder(KDEWindow=0.25, relativeRadius=cfg.relative)
+step(builder, batches[0])  # creates the variables
+# references: nothing runs ahead
+builder.geoPrefetch_ = False
+refs = []
+for b in batches:
+    outs, grads = step(builder, b)
+    refs.append(([o.detach().clone() for o in outs], [None if g is None else g.clone() for g in grads]))
+builder.geoPrefetch_ = True
+order = rng.integers(0, len(batches), STEPS)
+bad = torch.zeros((), dtype=torch.int64, device=dev)
+worst = torch.zeros((), dtype=torch.float32, device=dev)
+ahead = batches[order[0]].request()
+torch.cuda.synchronize()
+torch.cuda.reset_peak_memory_stats()
+m0 = torch.cuda.memory_allocated()
+t0 = time.perf_counter()
+for s in range(STEPS):
+    b = batches[order[s]]
+    cur, ahead = ahead, (batches[order[s + 1]].request() if s + 1 < STEPS else None)
+    outs, grads = step(builder, b, cur)
+    r_out, r_grad = refs[order[s]]
+    for o, r in zip(outs, r_out):
+        bad += (o.detach() != r).sum()
+    for g, r in zip(grads, r_grad):
+        if g is not None:
+            worst = torch.maximum(worst, (g - r).abs().max() / r.abs().max().clamp_min(1e-30))
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("soak_network: %d steps in %.1f s (%.2f ms/step), forward mismatches %d, worst relative gradient deviation %.2e, "
+      "memory now %.0f MB (start %.0f), peak %.0f MB" % (STEPS, dt, dt / STEPS * 1e3, int(bad.item()), float(worst.item()),
+                                                        torch.cuda.memory_allocated() / 1e6, m0 / 1e6,
+                                                        torch.cuda.max_memory_allocated() / 1e6))
+assert int(bad.item()) == 0 and float(worst.item()) < 1e-4
