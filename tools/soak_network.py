@@ -86,6 +86,8 @@ for s in range(STEPS):
     for g, r in zip(grads, r_grad):
         if g is not None:
             worst = torch.maximum(worst, (g - r).abs().max() / r.abs().max().clamp_min(1e-30))
+    if os.environ.get("SOAK_MEM") and s % 5000 == 4999:
+        print("  step %d: %.1f MB allocated" % (s + 1, torch.cuda.memory_allocated() / 1e6), flush=True)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print("soak_network: %d steps in %.1f s (%.2f ms/step), forward mismatches %d, worst relative gradient deviation %.2e, "
