@@ -558,12 +558,12 @@ class ConfigWorkload:
         torch.cuda.synchronize()
         from mccnn_amd import MCConvModule as _M
         l0 = self.lib.mccnn_debug_launch_count()
-        w0 = self.lib.mccnn_debug_wait_ns() * 1e-9 + _M.HOST_WAIT_S[0]
+        w0 = _M.host_wait_seconds()
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
         t_issue = time.perf_counter() - t0   # the host has enqueued the last launch (edge-count waits included)
-        waits = self.lib.mccnn_debug_wait_ns() * 1e-9 + _M.HOST_WAIT_S[0] - w0
+        waits = _M.host_wait_seconds() - w0
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         launches = (self.lib.mccnn_debug_launch_count() - l0) / float(steps)

@@ -237,9 +237,7 @@ class PointHierarchy(torch.nn.Module):
         """The levels a helper thread built ahead (PointHierarchy.prefetch): the current stream is ordered behind them, the
         feature rows of every level are gathered now. False when the single-launch Poisson form gave up somewhere."""
         from . import MCConvModule as _M
-        w0 = time.perf_counter()
-        aabbMin, aabbMax, extent, levels = prefetched.future.result()
-        _M.HOST_WAIT_S[0] += time.perf_counter() - w0
+        aabbMin, aabbMax, extent, levels = prefetched.future.result()   # (its wait is counted by the extension: wait_ns)
         if not levels:
             return False
         self.aabbMin_, self.aabbMax_ = aabbMin, aabbMax

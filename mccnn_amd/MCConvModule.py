@@ -205,7 +205,18 @@ _MAILBOX_YIELD_S = 0.25   # ... then polling that hands the GIL to other threads
 
 #: seconds this process has spent WAITING for sizes computed on the device (edge totals through the mailbox, the sample
 #: counts of a hierarchy); diagnostics only (bench.py: host work per step = issue time - waits)
-HOST_WAIT_S = [0.0]
+HOST_WAIT_S = [0.0]   # ... measured by this module (the op-by-op paths)
+
+
+def host_wait_seconds():
+    """Seconds the calling side has spent so far WAITING for device-side sizes or for a helper thread that waits for them:
+    this module's own waits + the library's (mccnn_debug_wait_ns) + the extension's (wait_ns). A step's host time minus the
+    increase of this number is the host's own work."""
+    total = HOST_WAIT_S[0] + _lib.load().mccnn_debug_wait_ns() * 1e-9
+    ext = _torch_ext()
+    if ext is not None:
+        total += ext.wait_ns() * 1e-9
+    return total
 
 
 def _await_mailbox(view):
@@ -1035,9 +1046,7 @@ def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batc
     if ext is not None:
         # the same sequence from C++ (csrc/torch_ext.cpp): no Python between the levels, sizes through a pinned buffer
         ncs = [_num_cells(mn, mx, batchSize, r, scaleInv) for r in radiusList]
-        w0 = ext.wait_ns()
         lv = ext.hierarchy_levels(pts, bids, mn, mx, [float(r) for r in radiusList], ncs, batchSize, bool(scaleInv), pmode)
-        HOST_WAIT_S[0] += (ext.wait_ns() - w0) * 1e-9
         if not lv:
             return None
         return [tuple(x) for x in lv]

@@ -153,6 +153,8 @@ void enter_device(int dev) {
 // The launches of a side-stream build are ISSUED by a helper thread: a step's geometries are a dozen launches each
 // (~35 us of host time), and the calling thread has the layers to issue. One thread, jobs in order (a geometry that
 // shares another one's grid is queued behind it). MCCNN_ISSUE_THREAD=0: the calling thread issues them itself.
+thread_local bool t_helper_thread = false;
+
 class Issuer {
 public:
     // 0: geometry builds of the step in flight; 1: point hierarchies of the NEXT batch (those jobs block on read-backs);
@@ -187,6 +189,8 @@ public:
 
 private:
     void run() {
+        t_helper_thread = true;
+        mccnn_debug_wait_accounting(0);
         for (;;) {
             std::function<void()> job;
             {
@@ -205,6 +209,8 @@ private:
     std::thread th_;
     bool started_ = false, stop_ = false;
 };
+
+void count_wait(std::chrono::steady_clock::time_point t0);
 
 struct Geo {
     mccnn_geometry_t* h = nullptr;
@@ -228,10 +234,15 @@ struct Geo {
             if (++spins > 2000) std::this_thread::yield();
     }
     void wait_issued_nothrow() {
+        if (issued.load(std::memory_order_acquire) && pieces_issued.load(std::memory_order_acquire)) return;
+        // (time spent here is a WAIT for a helper thread, which in turn waits for the device: counted with the waits for
+        // device-side sizes, not with the calling thread's own work -- wait_ns())
+        const auto t0 = std::chrono::steady_clock::now();
         wait_build_issued_nothrow();
         int spins = 0;
         while (!pieces_issued.load(std::memory_order_acquire))
             if (++spins > 2000) std::this_thread::yield();
+        count_wait(t0);
     }
     // the build's launches (and its event record) have been issued, and so have the pieces asked for with it: nothing
     // of the handle is touched before
@@ -669,6 +680,11 @@ Tensor conv(std::shared_ptr<Geo> geo, const Tensor& feats, const Tensor& w1, con
 }
 
 std::atomic<long long> g_wait_ns{0};  // host time spent waiting for the level sizes (diagnostics: wait_ns())
+void count_wait(std::chrono::steady_clock::time_point t0) {
+    if (t_helper_thread) return;   // (only the calling side's waits: a helper thread waiting is the point of having it)
+    g_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+                        std::memory_order_relaxed);
+}
 
 // Geometry of ALL levels of a point hierarchy (MCConvBuilder.py:101-128 per level: sort_points_step1/2 -> poisson_sampling
 // -> transform_indexs) with device-side point counts and ONE read-back of the level sizes at the end: the C++ form of

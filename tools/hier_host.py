@@ -20,7 +20,7 @@ M._lib.load = lambda: L()
 for _ in range(5): cw.hierarchy()
 torch.cuda.synchronize()
 acc["c"] = 0.0; acc["n"] = 0
-w0 = M.HOST_WAIT_S[0]
+w0 = M.host_wait_seconds()
 t0 = time.perf_counter()
 N = 50
 for _ in range(N):
@@ -28,4 +28,4 @@ for _ in range(N):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 print("%s hierarchy: %.3f ms per build on the host, of which %.3f in %d mccnn_hierarchy_level calls, %.3f waiting for the sizes"
-      % (name, (t1 - t0) / N * 1e3, acc["c"] / N * 1e3, acc["n"] // N, (M.HOST_WAIT_S[0] - w0) / N * 1e3))
+      % (name, (t1 - t0) / N * 1e3, acc["c"] / N * 1e3, acc["n"] // N, (M.host_wait_seconds() - w0) / N * 1e3))
