@@ -29,9 +29,12 @@ keep 8rooms
 PROF_NO_PMC=1 PROF_CMD="python $ROOT/tools/hier_time.py" tools/prof.sh ${ROUND}_hier > /dev/null 2>&1
 keep hier
 # BASELINE.json configurations: one step = PointHierarchy + forward + backward of every convolution of the model's graph
+# (PIPE=1: the next batch's hierarchy one step ahead, as bench.py runs the configurations by default; the per-queue view of
+# the same trace -- which kernels share the chip, how busy the convolutions' queue is -- goes beside the summary)
 for cfg in cfg0 cfg1 cfg2 cfg3 cfg4; do
-    PROF_NO_PMC=1 PROF_WARM_DROP=6 PROF_CMD="python $ROOT/tools/config_time.py $cfg 20" tools/prof.sh ${ROUND}_$cfg > /dev/null 2>&1
+    PIPE=1 PROF_NO_PMC=1 PROF_WARM_DROP=6 PROF_CMD="python $ROOT/tools/config_time.py $cfg 20" tools/prof.sh ${ROUND}_$cfg > /dev/null 2>&1
     keep $cfg
+    python tools/queues.py gpurun_out/prof_${ROUND}_$cfg/trace 0.3 > $DST/${ROUND}_queues_$cfg.txt 2>&1
 done
 
 # the full record (bench_details.json) and the compact line the driver parses (the LAST stdout line)
