@@ -508,11 +508,20 @@ class ConfigWorkload:
         self.next_ph = PointHierarchy.prefetch(self.P, self.Bi, list(self.cfg.hierarchy), self.B, self.cfg.relative)
         return self.next_ph is not None
 
-    def set_pipeline(self, on):
-        """-> whether pipelined steps are active. Switching on requests the first hierarchy ahead."""
+    def set_pipeline(self, on, geometry=False):
+        """-> whether pipelined steps are active. Switching on requests the first hierarchy ahead. geometry=True: the
+        hierarchy runs TWO batches ahead, so that the one of the next batch is complete when a step starts and
+        everything the step after this one needs -- grids, neighbour lists, PDFs, row plans -- is started on side streams
+        under this step's convolutions (ConvolutionBuilder.prefetch_step)."""
         self.pipeline = bool(on) and self.request_next()
+        self.deep = False
+        self.ready_ph = None
         if not self.pipeline:
             self.next_ph = None
+        elif geometry:
+            self.ready_ph = self.hierarchy(self.next_ph)   # the hierarchy of the first pipelined step
+            self.request_next()
+            self.deep = True
         return self.pipeline
 
     def _make_rows(self, ph):
@@ -539,7 +548,13 @@ class ConfigWorkload:
 
     def step(self):
         self.builder.reset()
-        if self.pipeline:
+        if self.pipeline and getattr(self, "deep", False):
+            ph = self.ph = self.ready_ph
+            nxt = self.hierarchy(self.next_ph)      # the next batch's hierarchy, requested a step ago: complete by now
+            self.request_next()                     # ... and the one after it
+            self.builder.prefetch_step(nxt)         # the next batch's geometry and row plans, under this batch's layers
+            self.ready_ph = nxt
+        elif self.pipeline:
             ph = self.ph = self.hierarchy(self.next_ph)
             self.request_next()
         else:
@@ -727,16 +742,26 @@ def run_config(name, device, args, want_cpu):
         # every convolution are bit-identical to the sequential step's and the steps are not slower
         try:
             ref = [o.detach().clone() for o in cw.step()]
-            if cw.set_pipeline(True):
+            best_issue, best_wait = seq_issue, seq_wait
+            for deep in (False, True):
+                if deep and os.environ.get("MCCNN_BENCH_DEEP", "1") == "0":
+                    break
+                cw.set_pipeline(False)
+                torch.cuda.synchronize()
+                if not cw.set_pipeline(True, geometry=deep):
+                    break
                 same = True
-                for _ in range(3):
+                for _ in range(4):
                     same = same and all(torch.equal(a, b) for a, b in zip(cw.step(), ref))
                 if same:
                     ms_p, launches_p = cw.timed(steps, 5)
-                    if ms_p < ms_seq:
-                        ms, launches, mode = ms_p, launches_p, "pipelined"
-                if mode != "pipelined":
-                    cw.host_issue_ms, cw.host_wait_ms = seq_issue, seq_wait
+                    if ms_p < ms:
+                        ms, launches, mode = ms_p, launches_p, ("pipelined+geometry" if deep else "pipelined")
+                        best_issue, best_wait = cw.host_issue_ms, cw.host_wait_ms
+                else:
+                    print("bench: %s steps of %s do not reproduce the sequential outputs" % (
+                        "pipelined+geometry" if deep else "pipelined", name), file=sys.stderr)
+            cw.host_issue_ms, cw.host_wait_ms = best_issue, best_wait
         except Exception as ex:  # the sequential numbers stand
             print("bench: pipelined %s steps failed: %r" % (name, ex), file=sys.stderr)
             cw.host_issue_ms, cw.host_wait_ms = seq_issue, seq_wait
@@ -747,7 +772,9 @@ def run_config(name, device, args, want_cpu):
     ent = {"workload": cfg.what, "points": n, "clouds": cw.B, "level_sizes": sizes, "convolutions": len(cfg.convs),
            "steps": steps, "ms_per_step": round(ms, 4), "value": round(n / (ms * 1e-3), 1), "unit": "points/s",
            # "pipelined": the next batch's PointHierarchy is requested one step ahead (PointHierarchy.prefetch) and built
-           # under this batch's convolutions; sequential_ms_per_step: hierarchy, then convolutions, nothing carried over
+           # under this batch's convolutions; "pipelined+geometry": two batches ahead, and the next batch's grids / lists /
+           # PDFs / row plans are started under this batch's convolutions as well (ConvolutionBuilder.prefetch_step);
+           # sequential_ms_per_step: hierarchy, then convolutions, nothing carried over
            "mode": mode, "sequential_ms_per_step": round(ms_seq, 4),
            "library_launches_per_step": round(launches, 1),
            # when this equals ms_per_step the step is bound by the HOST issuing its launches, not by the kernels

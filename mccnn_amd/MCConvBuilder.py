@@ -380,8 +380,12 @@ class ConvolutionBuilder(torch.nn.Module):
             plan = []
             for ent in self.geoLog_:
                 geo = self.cacheGeo_.get(ent[7])
-                plan.append(ent[:7] + ((geo.have & 7) if geo is not None else 0,))
+                plan.append(ent[:7] + ((geo.have & 7) if geo is not None else 0, ent[7]))
             self.geoPlan_, self.geoLog_ = plan, []
+        elif self.geoPlan_ and self.cacheGeo_:
+            # (a step whose geometries all came from prefetch_step() logs no build: its layers may still have attached more)
+            self.geoPlan_ = [ent[:7] + (ent[7] | ((self.cacheGeo_[ent[8]].have & 7) if ent[8] in self.cacheGeo_ else 0), ent[8])
+                             for ent in self.geoPlan_]
         self.cacheGeo_ = {}
         self.cacheGeoGrid_ = {}
         if self.prefetchedGeo_:
@@ -606,7 +610,7 @@ class ConvolutionBuilder(torch.nn.Module):
         return weights, biases, weights2v, biases2v, weights3v, biases3v, nn
 
     def __prefetch_native__(self, inPH, inLevel, convRadius, outPH, outLevel, KDEWindow, relativeRadius, usePDF, keyGrid,
-                            keyNeighs, keyPDF, transposed):
+                            keyNeighs, keyPDF, transposed, fork=True, pieces=0):
         """prefetch_geometry() on the native step executor: the geometry is ONE buffer, allocated on the CALLER's stream and
         written on a side stream that starts behind everything the caller's stream holds at this moment; the layers that
         use it order their stream behind its event. No reference counting decides anything: the buffer goes back to the
@@ -640,10 +644,37 @@ class ConvolutionBuilder(torch.nn.Module):
                 owner = g2
         k = len(self.prefetchedGeo_)
         geo = _native.build_geometry(inPts, inBids, centres, cBids, mn, mx, B, nc, convRadius, relativeRadius, KDEWindow,
-                                     usePDF, owner, side=k, fork=True, background=True)
+                                     usePDF, owner, side=k, fork=fork, background=True)
         geo.uses = 0
+        if pieces:   # row plans / transposed list the layers of the last step used: attached and issued by a helper thread
+            geo.prebuild_async(pieces, self.useAVG_)
         self.prefetchedGeo_[keyPDF] = (geo, keyGrid, keyNeighs, usePDF, want)
         return True
+
+    def prefetch_step(self, pointHierarchy):
+        """Extension: everything the LAST step built over a hierarchy of this name -- every grid, neighbour list and PDF, and
+        the row plans / transposed lists its layers used -- started now for `pointHierarchy`, the NEXT batch's hierarchy, on
+        side streams under the current batch's convolutions; parked until the next reset(). The learned form of
+        prefetch_geometry(): no argument lists to repeat, the builder remembers the graph. A training loop that has the
+        next batch's hierarchy at hand (PointHierarchy.prefetch two batches ahead) calls this right after reset(); the
+        step after it then finds its geometry built and runs its convolutions back to back. Returns the number of
+        geometries started (0 on the first steps, while there is nothing to replay, and wherever the native path does
+        not apply: nothing is lost, the next step builds what it needs itself)."""
+        started = 0
+        name, levels = pointHierarchy.hierarchyName_, len(pointHierarchy.points_)
+        pieces = os.environ.get("MCCNN_PLAN_PREFETCH", "1") != "0"
+        for ent in self.geoPlan_:
+            hname, inLevel, outLevel, radius, window, rel, usePDF, have = ent[:8]
+            if hname != name or inLevel >= levels or outLevel >= levels:
+                continue
+            keyGrid, keyNeighs, keyPDF = self.__compute_dic_keys__(pointHierarchy, pointHierarchy, inLevel, outLevel, radius,
+                                                                   window, rel, usePDF)
+            if keyPDF in self.prefetchedGeo_:
+                continue
+            if self.__prefetch_native__(pointHierarchy, inLevel, radius, pointHierarchy, outLevel, window, rel, usePDF, keyGrid,
+                                        keyNeighs, keyPDF, False, fork=(started == 0), pieces=(have if pieces else 0)):
+                started += 1
+        return started
 
     def __install_prefetched_geometries__(self):
         """reset(): the geometries prefetch_geometry() built since the last reset() become the cache content; for those
@@ -676,7 +707,7 @@ class ConvolutionBuilder(torch.nn.Module):
             return
         k = 0
         pieces = os.environ.get("MCCNN_PLAN_PREFETCH", "1") != "0"
-        for (hname, inLevel, outLevel, radius, window, rel, usePDF, have) in plan:
+        for (hname, inLevel, outLevel, radius, window, rel, usePDF, have, _key) in plan:
             if hname != name or inLevel >= levels or outLevel >= levels:
                 continue
             keyGrid, keyNeighs, keyPDF = self.__compute_dic_keys__(ph, ph, inLevel, outLevel, radius, window, rel, usePDF)

@@ -13,8 +13,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_network_soak_with_everything_running_ahead(mc):
-    env = dict(os.environ, SOAK_STEPS="400")
+@pytest.mark.parametrize("deep", ["0", "1"], ids=["hierarchy_ahead", "hierarchy_and_geometry_ahead"])
+def test_network_soak_with_everything_running_ahead(mc, deep):
+    """deep: the hierarchy two batches ahead and ConvolutionBuilder.prefetch_step() for the next batch's geometry and plans."""
+    env = dict(os.environ, SOAK_STEPS="400", SOAK_DEEP=deep)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_network.py")], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

@@ -47,9 +47,13 @@ class Batch:
                 self.ogs.append((2 * torch.rand((m, c.fout if c.combin else c.fin), generator=g) - 1).to(dev))
 
 
-def step(builder, batch, prefetched=None):
+def step(builder, batch, prefetched=None, ready=None, then=None):
+    """ready: this batch's hierarchy, constructed a step ago; then: called after reset() (the deep pipeline starts the next
+    batch's geometry there)."""
     builder.reset()
-    ph = batch.hierarchy(prefetched)
+    if then is not None:
+        then()
+    ph = ready if ready is not None else batch.hierarchy(prefetched)
     batch.rows(ph)
     outs = [builder.create_convolution(c.name, ph, c.lin, batch.feats[ci], c.fin, c.radius, ph, c.lout, c.combin, c.fout, c.window)
             for ci, c in enumerate(cfg.convs)]
@@ -71,15 +75,30 @@ builder.geoPrefetch_ = True
 order = rng.integers(0, len(batches), STEPS)
 bad = torch.zeros((), dtype=torch.int64, device=dev)
 worst = torch.zeros((), dtype=torch.float32, device=dev)
+DEEP = os.environ.get("SOAK_DEEP", "0") == "1"   # hierarchy two batches ahead + ConvolutionBuilder.prefetch_step for the next
 ahead = batches[order[0]].request()
+if DEEP:
+    ready = batches[order[0]].hierarchy(ahead)
+    ahead = batches[order[1]].request()
 torch.cuda.synchronize()
 torch.cuda.reset_peak_memory_stats()
 m0 = torch.cuda.memory_allocated()
 t0 = time.perf_counter()
 for s in range(STEPS):
     b = batches[order[s]]
-    cur, ahead = ahead, (batches[order[s + 1]].request() if s + 1 < STEPS else None)
-    outs, grads = step(builder, b, cur)
+    if DEEP:
+        state = {}
+
+        def start_next():
+            if s + 1 < STEPS:
+                state["nxt"] = batches[order[s + 1]].hierarchy(ahead)
+                builder.prefetch_step(state["nxt"])
+        outs, grads = step(builder, b, ready=ready, then=start_next)
+        ready = state.get("nxt")
+        ahead = batches[order[s + 2]].request() if s + 2 < STEPS else None
+    else:
+        cur, ahead = ahead, (batches[order[s + 1]].request() if s + 1 < STEPS else None)
+        outs, grads = step(builder, b, cur)
     r_out, r_grad = refs[order[s]]
     for o, r in zip(outs, r_out):
         bad += (o.detach() != r).sum()
@@ -90,8 +109,8 @@ for s in range(STEPS):
         print("  step %d: %.1f MB allocated" % (s + 1, torch.cuda.memory_allocated() / 1e6), flush=True)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("soak_network: %d steps in %.1f s (%.2f ms/step), forward mismatches %d, worst relative gradient deviation %.2e, "
-      "memory now %.0f MB (start %.0f), peak %.0f MB" % (STEPS, dt, dt / STEPS * 1e3, int(bad.item()), float(worst.item()),
+print("soak_network%s: %d steps in %.1f s (%.2f ms/step), forward mismatches %d, worst relative gradient deviation %.2e, "
+      "memory now %.0f MB (start %.0f), peak %.0f MB" % (" (deep)" if DEEP else "", STEPS, dt, dt / STEPS * 1e3, int(bad.item()), float(worst.item()),
                                                         torch.cuda.memory_allocated() / 1e6, m0 / 1e6,
                                                         torch.cuda.max_memory_allocated() / 1e6))
 assert int(bad.item()) == 0 and float(worst.item()) < 1e-4
