@@ -495,8 +495,8 @@ class ConfigWorkload:
         self.pipeline = False
         self.next_ph = None
         torch.manual_seed(4321)
+        self.params = None
         self.outs = self.step()  # creates variables, features and out-gradients
-        self.params = list(self.builder.parameters())
 
     def hierarchy(self, prefetched=None):
         from mccnn_amd.MCConvBuilder import PointHierarchy
@@ -562,7 +562,9 @@ class ConfigWorkload:
         if self.feats is None:
             self._make_rows(ph)
         outs = [self.conv(ph, ci) for ci in range(len(self.cfg.convs))]
-        inputs = self.feats + list(self.builder.parameters())
+        if getattr(self, "params", None) is None:
+            self.params = list(self.builder.parameters())   # (created by the first step's layers)
+        inputs = self.feats + self.params
         # gradients of every convolution w.r.t. its features and its six kernel-MLP tensors, nothing accumulated
         self.grads = torch.autograd.grad(outs, inputs, self.ogs, allow_unused=True)
         return outs

@@ -132,7 +132,19 @@ class _PrefetchedHierarchy:
                                        "batch size or radius mode (or the tensors were modified since)")
 
 
-class PointHierarchy(torch.nn.Module):
+class _PlainState:
+    """Attributes whose names end in '_' are plain state (caches, lists, tensors the class merely holds): they bypass
+    torch.nn.Module.__setattr__, whose parameter / buffer / sub-module bookkeeping costs ~5 us per assignment -- a reset()
+    and a hierarchy make thirty of them per step."""
+
+    def __setattr__(self, name, value):
+        if name.endswith("_") and not isinstance(value, (torch.nn.Parameter, torch.nn.Module)):
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
+
+class PointHierarchy(_PlainState, torch.nn.Module):
     """Point hierarchy built by successive Poisson-disk sampling (MCConvBuilder.py:24-131).
 
     Attributes (same names as the reference): points_, features_, batchIds_, sampledIndexs_,
@@ -271,7 +283,7 @@ def _fan_avg_uniform_(t, fan_in, fan_out):
     return t
 
 
-class ConvolutionBuilder(torch.nn.Module):
+class ConvolutionBuilder(_PlainState, torch.nn.Module):
     """Creates MC convolutions on point hierarchies, caching grids / neighbours / pdfs
     (MCConvBuilder.py:133-427). A torch.nn.Module: the kernel-MLP variables are registered parameters under the
     reference's names (`<convName>_weights`, `_biases`, `_weights2`, ... MCConvBuilder.py:407-419), created on first use

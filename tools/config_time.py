@@ -19,7 +19,7 @@ torch.cuda.set_device(0)
 torch.autograd.set_multithreading_enabled(False)
 cw = bench.ConfigWorkload(CONFIGS[name], torch.device("cuda", 0))
 if os.environ.get("PIPE", "0") == "1":   # the next batch's hierarchy one step ahead (bench.run_config's pipelined mode)
-    print("pipelined:", cw.set_pipeline(True))
+    print("pipelined:", cw.set_pipeline(True, geometry=os.environ.get("DEEP", "1") == "1"))
 ms, launches = cw.timed(steps, 5)
 print("%s: %d points, %.4f ms/step, %.1f M points/s, %.1f library launches/step" % (
     name, cw.P.shape[0], ms, cw.P.shape[0] / ms / 1e3, launches))

@@ -9,7 +9,7 @@ torch.autograd.set_multithreading_enabled(False)
 name = sys.argv[1]
 cw = bench.ConfigWorkload(CONFIGS[name], torch.device("cuda", 0))
 if os.environ.get("PIPE", "1") == "1":
-    print("pipelined:", cw.set_pipeline(True))
+    print("pipelined:", cw.set_pipeline(True, geometry=os.environ.get("DEEP", "1") == "1"))
 for _ in range(5): cw.step()
 torch.cuda.synchronize()
 pr = cProfile.Profile()
