@@ -695,6 +695,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         from . import native as _native
         parked, self.prefetchedGeo_ = self.prefetchedGeo_, {}
         for keyPDF, (geo, keyGrid, keyNeighs, usePDF, transposed) in parked.items():
+            geo.unverified = True   # (checked against the hierarchy's tensors at its first use)
             self.cacheGeo_[keyPDF] = geo
             if geo.grid_owner is None:
                 self.cacheGeoGrid_[keyGrid] = geo
@@ -771,6 +772,24 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                 and not self.cacheGrids_ and _native.side_streams_available()):
             self.__prebuild_geometries__(inPH)
         geo = self.cacheGeo_.get(keyPDF)
+        if geo is not None and getattr(geo, "unverified", False):
+            # a geometry started ahead (prefetch_geometry / prefetch_step) is filed under the reference's cache keys -- names,
+            # levels, radii -- like everything else; before its first use it is checked against the tensors it was built
+            # from, so that a DIFFERENT hierarchy of the same name cannot be served another batch's lists
+            a = geo.args
+            cen = outPH.points_[outLevel]
+            pin = inPH.points_[inLevel]
+            if (a[0] is pin or (a[0].data_ptr() == pin.data_ptr() and a[0].shape == pin.shape)) and \
+                    (a[2] is cen or (a[2].data_ptr() == cen.data_ptr() and a[2].shape == cen.shape)):
+                geo.unverified = False
+            else:
+                self.cacheGeo_.pop(keyPDF, None)
+                self.cachePDFs_.pop(keyPDF, None)
+                self.cacheNeighs_.pop(keyNeighs, None)
+                if self.cacheGeoGrid_.get(keyGrid) is geo:
+                    self.cacheGeoGrid_.pop(keyGrid, None)
+                    self.cacheGrids_.pop(keyGrid, None)
+                geo = None
         if geo is None:
             if keyGrid in self.cacheGrids_ and keyGrid not in self.cacheGeoGrid_:
                 return None   # the op-by-op path (or a prefetch) owns this grid
@@ -786,6 +805,13 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
             mn, mx, B = inPH.aabbMin_, inPH.aabbMax_, inPH.batchSize_
             nc = _hip_ops._num_cells(mn, mx, B, convRadius, relativeRadius)
             owner = self.cacheGeoGrid_.get(keyGrid)
+            if owner is not None and getattr(owner, "unverified", False):
+                # (a grid started ahead for another hierarchy of this name is not shared either)
+                a0 = owner.args[0]
+                if not (a0 is inPts or (a0.data_ptr() == inPts.data_ptr() and a0.shape == inPts.shape)):
+                    self.cacheGeoGrid_.pop(keyGrid, None)
+                    self.cacheGrids_.pop(keyGrid, None)
+                    owner = None
             geo = _native.build_geometry(inPts, inBids, centres, cBids, mn, mx, B, nc, convRadius, relativeRadius, KDEWindow,
                                          usePDF, owner)
             geo.uses = 0

@@ -445,3 +445,56 @@ def test_prefetch_waits_for_a_hierarchy_built_after_reset(mc, protocol):
         assert torch.equal(next(iter(builder.cacheNeighs_.values()))[1], refs[b][1]), (step, b)
         assert torch.equal(out.detach(), refs[b][0]), (step, b)
     torch.cuda.synchronize()
+
+
+def test_geometry_started_ahead_is_not_served_to_another_hierarchy(mc):
+    """prefetch_step() / prefetch_geometry() file what they build under the reference's cache keys (hierarchy NAME, levels,
+    radii). A different hierarchy of the same name used after the next reset() must not be served those lists: the builder
+    checks a parked geometry against the tensors it was built from before its first use."""
+    import torch
+    import mccnn_amd.MCConvBuilder as MB
+    from tests.helpers import make_cloud
+    out = {}
+    pa, ba = make_cloud(3000, 3, 11, "clustered", True)
+    pb, bb = make_cloud(3000, 3, 12, "uniform", True)
+    PA, BA = torch.from_numpy(pa).cuda(), torch.from_numpy(ba).cuda()
+    PB, BB = torch.from_numpy(pb).cuda(), torch.from_numpy(bb).cuda()
+    radii = [0.1, 0.4]
+
+    def net(builder, ph):
+        f = torch.ones((ph.points_[0].shape[0], 1), device="cuda")
+        o1 = builder.create_convolution("c1", ph, 0, f, 1, 0.2, ph, 1, True, 16)
+        o2 = builder.create_convolution("c2", ph, 1, o1, 16, 0.8, ph, 2, False)
+        o3 = builder.create_convolution("c3", ph, 1, o1, 16, 0.4, ph, 1, False)
+        o4 = builder.create_convolution("c4", ph, 0, f, 1, 0.1, ph, 0, True, 8)
+        o5 = builder.create_convolution("c5", ph, 1, o1, 16, 0.8, ph, 1, False)
+        return [o1, o2, o3, o4, o5]
+
+    torch.manual_seed(0)
+    b = MB.ConvolutionBuilder(KDEWindow=0.2)
+    phA = MB.PointHierarchy(PA, torch.ones((len(pa), 1), device="cuda"), BA, radii, "PH", 3)
+    phB = MB.PointHierarchy(PB, torch.ones((len(pb), 1), device="cuda"), BB, radii, "PH", 3)
+    for _ in range(2):   # the builder learns the graph
+        b.reset()
+        refA = [o.detach().clone() for o in net(b, phA)]
+    b.reset()
+    refB = [o.detach().clone() for o in net(b, phB)]
+    # geometry of A started ahead ... and then B (same name, same levels, same radii) is what the next step convolves
+    b.reset()
+    assert b.prefetch_step(phA) == 5
+    net(b, phB)
+    b.reset()
+    got = net(b, phB)
+    for g, r in zip(got, refB):
+        assert torch.equal(g, r)
+    # ... and A itself is served what was built for it
+    b.reset()
+    assert b.prefetch_step(phA) == 5
+    net(b, phB)
+    b.reset()
+    used = {k: g for k, g in b.cacheGeo_.items()}
+    got = net(b, phA)
+    for g, r in zip(got, refA):
+        assert torch.equal(g, r)
+    assert all(b.cacheGeo_[k] is g for k, g in used.items())   # nothing was rebuilt
+    torch.cuda.synchronize()
