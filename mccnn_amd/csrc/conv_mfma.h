@@ -471,4 +471,44 @@ int f1_forward(const ConvArgs& a, float* out, float4* rec_out, void* state, void
 int f1_backward(const ConvArgs& a, const float* out_grad, const float4* rec_in, const void* state, float* feat_grad, float* dw1, float* db1,
                 float* dw2, float* db2, float* dw3, float* db3, void* ws, size_t ws_bytes, hipStream_t s);
 
+// Sums the per-wave partial rows in a fixed order and scatters them to the six gradient tensors: the work of workgroup
+// `bid` of 1024 threads (the reduce_partials kernel of conv.hip, and the first workgroups of rows_combine_reduce).
+__device__ __forceinline__ void reduce_partials_body(int bid, const float* __restrict__ partials, int numWaves, int nb,
+                                                        float* __restrict__ dw1, float* __restrict__ db1,
+                                                        float* __restrict__ dw2, float* __restrict__ db2,
+                                                        float* __restrict__ dw3, float* __restrict__ db3) {
+    // 16 consecutive parameters x 64 row slices per workgroup, 4 independent accumulators per thread: the sum over
+    // ~2000 rows is a chain of dependent load latencies, 256 rows in flight per parameter make it 8 links long
+    __shared__ float acc[64][17];
+    const int K = nb * 176;
+    const int kk = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int k = bid * 16 + kk;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (k < K) {
+        int w = sl;
+        for (; w + 192 < numWaves; w += 256) {
+            s0 += partials[(size_t)w * K + k];
+            s1 += partials[(size_t)(w + 64) * K + k];
+            s2 += partials[(size_t)(w + 128) * K + k];
+            s3 += partials[(size_t)(w + 192) * K + k];
+        }
+        for (; w < numWaves; w += 64) s0 += partials[(size_t)w * K + k];
+    }
+    acc[sl][kk] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && k < K) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) v += acc[i][kk];
+        int q = k / 176, r = k - q * 176;
+        if (r < 24) dw1[q * 24 + r] = v;
+        else if (r < 32) db1[q * 8 + r - 24] = v;
+        else if (r < 96) dw2[q * 64 + r - 32] = v;
+        else if (r < 104) db2[q * 8 + r - 96] = v;
+        else if (r < 168) dw3[q * 64 + r - 104] = v;
+        else db3[q * 8 + r - 168] = v;
+    }
+}
+
+
 }  // namespace mccnn

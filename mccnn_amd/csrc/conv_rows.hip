@@ -340,11 +340,11 @@ __global__ __launch_bounds__(256) void sell_fill(const float4* __restrict__ recE
 // are rare (none at all on a list whose rows hold <= ROWS_L edges), a wave without one returns after two loads.
 // Rows without any edge are written here as well (zeros).
 template <bool BF>
-__global__ __launch_bounds__(256) void rows_combine(const int* __restrict__ rowStart, int rows, int e,
-                                                    const int* __restrict__ vposRow, const float* __restrict__ scratch,
-                                                    int cols, void* __restrict__ out, int L, const int* __restrict__ outIdx) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r0 = (blockIdx.x * 4 + wave) * 64;
+__device__ __forceinline__ void rows_combine_body(int bid, int tid, const int* __restrict__ rowStart, int rows, int e,
+                                                  const int* __restrict__ vposRow, const float* __restrict__ scratch,
+                                                  int cols, void* __restrict__ out, int L, const int* __restrict__ outIdx) {
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r0 = (bid * 4 + wave) * 64;
     const int r = r0 + lane;
     int deg = 0;
     if (r < rows) deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
@@ -368,13 +368,19 @@ __global__ __launch_bounds__(256) void rows_combine(const int* __restrict__ rowS
     }
 }
 
+template <bool BF>
+__global__ __launch_bounds__(256) void rows_combine(const int* __restrict__ rowStart, int rows, int e,
+                                                    const int* __restrict__ vposRow, const float* __restrict__ scratch,
+                                                    int cols, void* __restrict__ out, int L, const int* __restrict__ outIdx) {
+    rows_combine_body<BF>(blockIdx.x, threadIdx.x, rowStart, rows, e, vposRow, scratch, cols, out, L, outIdx);
+}
+
 // The same for lists with few rows, whose plans use short pieces (most rows are cut): one thread per (row, 4 columns).
 template <bool BF>
-__global__ __launch_bounds__(256) void rows_combine_par(const int* __restrict__ rowStart, int rows, int e,
-                                                        const int* __restrict__ vposRow, const float* __restrict__ scratch,
-                                                        int cols, void* __restrict__ out, int L, const int* __restrict__ outIdx) {
+__device__ __forceinline__ void rows_combine_par_body(long long t, const int* __restrict__ rowStart, int rows, int e,
+                                                      const int* __restrict__ vposRow, const float* __restrict__ scratch,
+                                                      int cols, void* __restrict__ out, int L, const int* __restrict__ outIdx) {
     const int c4 = cols >> 2;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)rows * c4) return;
     const int r = (int)(t / c4), c = (int)(t - (long long)r * c4) * 4;
     const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
@@ -394,6 +400,44 @@ __global__ __launch_bounds__(256) void rows_combine_par(const int* __restrict__ 
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)ro * cols + c) = acc;
     }
 }
+template <bool BF>
+__global__ __launch_bounds__(256) void rows_combine_par(const int* __restrict__ rowStart, int rows, int e,
+                                                        const int* __restrict__ vposRow, const float* __restrict__ scratch,
+                                                        int cols, void* __restrict__ out, int L, const int* __restrict__ outIdx) {
+    rows_combine_par_body<BF>((long long)blockIdx.x * blockDim.x + threadIdx.x, rowStart, rows, e, vposRow, scratch, cols, out, L, outIdx);
+}
+
+// The two small kernels that follow the backward row kernel in ONE launch (workgroups of 1024 threads): the first `nRed`
+// sum the weight-gradient partials (reduce_partials_body), the rest combine the cut / empty rows of the feature gradient,
+// four 256-thread pieces per workgroup. A depth-wise layer's backward pass is 2 launches instead of 3 -- on the coarse
+// levels of a network every launch is ~5 us on both sides of the queue.
+template <bool BF>
+__global__ __launch_bounds__(1024) void rows_combine_reduce(const int* __restrict__ rowStart, int rows, int e,
+                                                            const int* __restrict__ vposRow, const float* __restrict__ scratch,
+                                                            int cols, void* __restrict__ out, int L, const int* __restrict__ outIdx,
+                                                            int par, int nRed, const float* __restrict__ partials, int numWaves, int nb,
+                                                            float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                            float* __restrict__ db2, float* __restrict__ dw3, float* __restrict__ db3) {
+    if ((int)blockIdx.x < nRed) {
+        reduce_partials_body(blockIdx.x, partials, numWaves, nb, dw1, db1, dw2, db2, dw3, db3);
+        return;
+    }
+    const int vb = ((int)blockIdx.x - nRed) * 4 + (threadIdx.x >> 8), vt = threadIdx.x & 255;
+    if (par) rows_combine_par_body<BF>((long long)vb * 256 + vt, rowStart, rows, e, vposRow, scratch, cols, out, L, outIdx);
+    else rows_combine_body<BF>(vb, vt, rowStart, rows, e, vposRow, scratch, cols, out, L, outIdx);
+}
+
+template <bool BF>
+static void launch_combine_reduce(const int* rowStart, int rows, int e, const int* vposRow, const float* scratch, int cols, void* out,
+                                  int L, hipStream_t s, const int* outIdx, const float* partials, int numWaves, int nb, float* dw1,
+                                  float* db1, float* dw2, float* db2, float* dw3, float* db3) {
+    const int par = rows < 16384 ? 1 : 0;
+    const long long units = par ? ceil_div((long long)rows * (cols >> 2), 256) : ceil_div(rows, 256);   // 256-thread pieces
+    const int nRed = (int)ceil_div((long long)nb * 176, 16);
+    rows_combine_reduce<BF><<<(int)(nRed + ceil_div(units, 4)), 1024, 0, s>>>(rowStart, rows, e, vposRow, scratch, cols, out, L, outIdx,
+                                                                           par, nRed, partials, numWaves, nb, dw1, db1, dw2, db2, dw3, db3);
+}
+
 template <bool BF>
 static void launch_combine(const int* rowStart, int rows, int e, const int* vposRow, const float* scratch, int cols, void* out,
                            int L, hipStream_t s, const int* outIdx = nullptr) {
@@ -1102,10 +1146,10 @@ int mccnn_spatial_conv_bwd_rows(const float* sorted_pts, const void* sorted_feat
     } else if (bf16) dw_bwd_rows<4, false><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups, nullptr);
     else dw_bwd_rows<2, false><<<(int)blocks, 256, lds, s>>>(a, p, (const float*)out_grad, (float*)feat_grad, scratch, partials, spw, groups, nullptr);
     MCCNN_LAUNCHED();
-    if (bf16) launch_combine<true>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s, feat_index);
-    else launch_combine<false>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s, feat_index);
-    MCCNN_LAUNCHED();
-    launch_reduce_partials(partials, groups, a.nb, dw1, db1, dw2, db2, dw3, db3, s);
+    if (bf16) launch_combine_reduce<true>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s, feat_index, partials, groups, a.nb,
+                                          dw1, db1, dw2, db2, dw3, db3);
+    else launch_combine_reduce<false>(start_t, n, e, vpos_row, scratch, a.Fin, feat_grad, z.L, s, feat_index, partials, groups, a.nb,
+                                      dw1, db1, dw2, db2, dw3, db3);
     MCCNN_LAUNCHED();
     return 0;
 }
