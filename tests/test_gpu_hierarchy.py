@@ -102,7 +102,10 @@ def test_prefetched_hierarchy_equals_the_inline_one(mc, case):
     request nobody adopts; a handle offered to the wrong inputs."""
     import torch
     import mccnn_amd.MCConvBuilder as MB
+    from mccnn_amd import native
     from mccnn_amd.MCConvModule import InvalidArgumentError
+    if not native.side_streams_available():
+        pytest.skip("PointHierarchy.prefetch() needs the torch extension (it returns None without it: inline build)")
     if case == "relative_batched":
         pts, bids = make_cloud(3000, 5, 3, "clustered", True)
         B, radii, rel = 5, [0.1, 0.4, math.sqrt(3.0) + 0.1], True
