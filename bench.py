@@ -464,6 +464,11 @@ class Workload:
                     if kname.startswith(("conv_bwd_mfma", "f1_bwd_edges", "dw_bwd_rows")):
                         roofline["traffic"] = int(tr["bytes"])
                         roofline["traffic_source"] = "profiles/" + os.path.basename(tfile)
+        # the north star's second kernel: the neighbour search against the HBM roofline (algorithmic bytes of SURVEY 8d)
+        fn = breakdown.get("find_neighbors") if isinstance(breakdown, dict) else None
+        if isinstance(fn, dict) and fn.get("unit") == "GB/s":
+            roofline["find_neighbors"] = {"bound": "hbm", "ms": fn["ms"], "achieved": fn["achieved"], "peak": HBM_PEAK_GBS,
+                                          "unit": "GB/s", "frac": round(fn["achieved"] / HBM_PEAK_GBS, 4)}
         return roofline, breakdown
 
 
