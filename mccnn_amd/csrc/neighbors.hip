@@ -876,7 +876,12 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     NeighWs w;
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    const int G = neigh_group(m);
+    static const int forcedFill = getenv("MCCNN_NW_GROUP_FILL") ? atoi(getenv("MCCNN_NW_GROUP_FILL")) : 0;  // A/B switch
+    // (mask rows are indexed by visiting position: the two passes may group differently -- the compaction gains little
+    // from more centres per wave: 100 k centres 0.0612 ms at 8, 0.0622 at 16; 800 k centres 0.305 at 8, 0.295 at 24)
+    int G = neigh_group(m);
+    if (G == 16) G = MCCNN_NW_G;
+    if (forcedFill >= 1 && forcedFill <= 32) G = forcedFill;
     const float Tabs = scale_inv ? 0.0f : sqrt_threshold_host(radius);
     if (neigh_lean())
         neigh_window<1, true><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs,
