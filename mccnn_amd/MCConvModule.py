@@ -1108,6 +1108,13 @@ class _GetSampledFeatures(torch.autograd.Function):
 
 
 def get_sampled_features(inSampledIndexs, pInFeatures):
+    ext = _torch_ext()
+    if (ext is not None and torch.is_tensor(pInFeatures) and pInFeatures.is_cuda and pInFeatures.dim() == 2
+            and pInFeatures.is_contiguous() and torch.is_tensor(inSampledIndexs) and inSampledIndexs.is_cuda
+            and inSampledIndexs.dtype == torch.int32 and inSampledIndexs.dim() == 1 and inSampledIndexs.is_contiguous()
+            and (pInFeatures.dtype == torch.float32 or (pInFeatures.dtype == torch.bfloat16 and pInFeatures.shape[1] % 2 == 0))
+            and pInFeatures.shape[1] > 0):
+        return ext.sampled_features(inSampledIndexs, pInFeatures)   # the same two library calls, the autograd node in C++
     return _GetSampledFeatures.apply(inSampledIndexs, pInFeatures)
 
 

@@ -754,6 +754,52 @@ std::vector<std::vector<Tensor>> hierarchy_levels(const Tensor& pts, const Tenso
 }
 
 
+// ---- GetSampledFeatures (+Grad), MCConvModuleSrc:63-68: out[i, :] = feats[idx[i], :]; the gradient scatters into zeros.
+// The C++ form of MCConvModule.get_sampled_features: a hierarchy gathers the feature rows of every level, one call each.
+struct GatherBackward : public torch::autograd::Node {
+    Tensor idx;
+    int64_t n = 0;
+    torch::autograd::variable_list apply(torch::autograd::variable_list&& grads) override {
+        Tensor g = grads[0];
+        TORCH_CHECK(g.defined() && idx.defined(), "GetSampledFeaturesGrad: no gradient / released buffers");
+        if (!g.is_contiguous()) g = g.contiguous();
+        const DevGuard device_guard((int)g.device().index());
+        const int64_t words = g.size(1) * (int64_t)g.element_size() / 4;
+        Tensor out = at::empty({n, g.size(1)}, g.options());
+        check(mccnn_permute_scatter((const float*)g.data_ptr(), idx.data_ptr<int>(), (int)g.size(0), (int)words,
+                                    (float*)out.data_ptr(), (int)n, 1, cur_stream(g)),
+              "permute_scatter");
+        return {out};
+    }
+    void release_variables() override { idx.reset(); }
+};
+
+Tensor sampled_features(const Tensor& idx, const Tensor& feats) {
+    check_dev(idx, at::kInt, "sampled indexs");
+    TORCH_CHECK(idx.dim() == 1, "GetSampledFeaturesOp expects indexs with the following dimensions (numSamples)");
+    TORCH_CHECK(feats.defined() && feats.is_cuda() && feats.dim() == 2 && feats.size(1) > 0 && feats.is_contiguous() &&
+                    (feats.scalar_type() == at::kFloat || (feats.scalar_type() == at::kBFloat16 && feats.size(1) % 2 == 0)),
+                "GetSampledFeaturesOp expects features with dimensions (numPoints, numFeatures)");
+    const DevGuard device_guard((int)feats.device().index());
+    const int64_t words = feats.size(1) * (int64_t)feats.element_size() / 4;
+    Tensor out;
+    {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        out = at::empty({idx.size(0), feats.size(1)}, feats.options());
+        check(mccnn_permute_gather((const float*)feats.data_ptr(), idx.data_ptr<int>(), (int)idx.size(0), (int)words,
+                                   (float*)out.data_ptr(), cur_stream(feats)),
+              "permute_gather");
+    }
+    if (at::GradMode::is_enabled() && feats.requires_grad()) {
+        auto node = std::shared_ptr<GatherBackward>(new GatherBackward(), torch::autograd::deleteNode);
+        node->set_next_edges(torch::autograd::collect_next_edges(feats));
+        node->idx = idx;
+        node->n = feats.size(0);
+        torch::autograd::set_history(out, node);
+    }
+    return out;
+}
+
 // ---- point hierarchy of the NEXT batch, built on a stream of its own by a helper thread -------------------------------
 // A hierarchy depends on the points only. Built inline it is a chain of ~13 small dependent kernels per level that ends in
 // a read-back of the level sizes (and, for an absolute radius, starts with one of the box extent): the host cannot issue
@@ -973,6 +1019,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
             py::arg("mn"), py::arg("mx"), py::arg("B"), py::arg("nc"), py::arg("radius"), py::arg("scale_inv"),
             py::arg("window"), py::arg("use_pdf"), py::arg("capacity"), py::arg("grid_from").none(true),
             py::arg("side") = -1, py::arg("fork") = false, py::arg("background") = false);
+    mod.def("sampled_features", &sampled_features);
     mod.def("prebuild_async", &prebuild_async, py::arg("geometry"), py::arg("what"), py::arg("avg"));
     mod.def("conv", &conv);
     mod.def("hierarchy_levels", &hierarchy_levels, py::call_guard<py::gil_scoped_release>());
