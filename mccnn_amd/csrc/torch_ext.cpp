@@ -569,15 +569,25 @@ void prepare(Geo& g, const Tensor& feats, const Layer& L, int backward, int flag
 
 struct ConvBackward : public torch::autograd::Node {
     std::shared_ptr<Geo> geo;
-    torch::autograd::SavedVariable feats_, w1_, b1_, w2_, b2_, w3_, b3_;
+    // the seven inputs, held as plain tensors with the version each had in the forward pass (they are INPUTS of this node,
+    // so holding them makes no cycle; SavedVariable::unpack builds a fresh Variable per tensor and call, ~5 us per node --
+    // what it guards against, an input modified in place since the forward pass, is checked here directly)
+    Tensor feats_, w1_, b1_, w2_, b2_, w3_, b3_;
+    uint32_t versions[7] = {0, 0, 0, 0, 0, 0, 0};
     Tensor saved;
     Layer L;
 
     torch::autograd::variable_list apply(torch::autograd::variable_list&& grads) override {
-        TORCH_CHECK(geo, "MC convolution: backward through a graph whose buffers have been freed (retain_graph=True?)");
+        TORCH_CHECK(geo && feats_.defined(), "MC convolution: backward through a graph whose buffers have been freed (retain_graph=True?)");
         const DevGuard device_guard((int)geo->buf.device().index());
-        const Tensor feats = feats_.unpack(), w1 = w1_.unpack(), b1 = b1_.unpack(), w2 = w2_.unpack(), b2 = b2_.unpack(),
-                     w3 = w3_.unpack(), b3 = b3_.unpack();
+        const Tensor &feats = feats_, &w1 = w1_, &b1 = b1_, &w2 = w2_, &b2 = b2_, &w3 = w3_, &b3 = b3_;
+        {
+            const Tensor* in[7] = {&feats_, &w1_, &b1_, &w2_, &b2_, &w3_, &b3_};
+            for (int k = 0; k < 7; ++k)
+                TORCH_CHECK(in[k]->_version() == versions[k],
+                            "one of the variables needed for gradient computation has been modified by an inplace operation "
+                            "(MC convolution input ", k, ")");
+        }
         Tensor og = grads[0];
         if (!og.defined()) og = at::zeros({geo->m, L.combin ? L.fout : L.fin}, feats.options());
         if (!og.is_contiguous()) og = og.contiguous();
@@ -607,7 +617,7 @@ struct ConvBackward : public torch::autograd::Node {
               "conv_backward");
         int64_t o = 0;
         auto piece = [&](int64_t cnt, const Tensor& like) {
-            Tensor t = gflat.narrow(0, o, cnt).view(like.sizes());
+            Tensor t = gflat.as_strided(like.sizes(), like.strides(), o);   // (contiguous variables: checked in conv())
             o += cnt;
             return t;
         };
@@ -619,8 +629,7 @@ struct ConvBackward : public torch::autograd::Node {
     }
 
     void release_variables() override {
-        feats_.reset_data(); w1_.reset_data(); b1_.reset_data(); w2_.reset_data(); b2_.reset_data(); w3_.reset_data();
-        b3_.reset_data();
+        feats_.reset(); w1_.reset(); b1_.reset(); w2_.reset(); b2_.reset(); w3_.reset(); b3_.reset();
         saved.reset();
         geo.reset();
     }
@@ -665,13 +674,11 @@ Tensor conv(std::shared_ptr<Geo> geo, const Tensor& feats, const Tensor& w1, con
         auto node = std::shared_ptr<ConvBackward>(new ConvBackward(), torch::autograd::deleteNode);
         node->set_next_edges(torch::autograd::collect_next_edges(feats, w1, b1, w2, b2, w3, b3));
         node->geo = geo;
-        node->feats_ = torch::autograd::SavedVariable(feats, false);
-        node->w1_ = torch::autograd::SavedVariable(w1, false);
-        node->b1_ = torch::autograd::SavedVariable(b1, false);
-        node->w2_ = torch::autograd::SavedVariable(w2, false);
-        node->b2_ = torch::autograd::SavedVariable(b2, false);
-        node->w3_ = torch::autograd::SavedVariable(w3, false);
-        node->b3_ = torch::autograd::SavedVariable(b3, false);
+        node->feats_ = feats; node->w1_ = w1; node->b1_ = b1; node->w2_ = w2; node->b2_ = b2; node->w3_ = w3; node->b3_ = b3;
+        {
+            const Tensor* in[7] = {&feats, &w1, &b1, &w2, &b2, &w3, &b3};
+            for (int k = 0; k < 7; ++k) node->versions[k] = in[k]->_version();
+        }
         node->saved = saved;
         node->L = L;
         torch::autograd::set_history(out, node);

@@ -251,3 +251,27 @@ def test_learned_geometry_prefetch_on_side_streams(mc):
     got = step(1)
     for a, b in zip(got[0], ref1[0]):
         assert torch.equal(a, b)
+
+
+def test_backward_detects_inputs_modified_in_place(mc):
+    """The extension's autograd node holds its inputs as plain tensors and checks their versions itself: an in-place update
+    of a kernel-MLP variable between forward and backward is an error, as with any autograd function; retain_graph works."""
+    import torch
+    import mccnn_amd.MCConvBuilder as MB
+    from mccnn_amd import native
+    from tests.helpers import make_cloud
+    if not native.side_streams_available():
+        pytest.skip("torch extension not built")
+    pts, bids = make_cloud(2000, 2, 5, "uniform", True)
+    P, Bi = torch.from_numpy(pts).cuda(), torch.from_numpy(bids).cuda()
+    ph = MB.PointHierarchy(P, torch.ones((len(pts), 1), device="cuda"), Bi, [], "PH", 2)
+    b = MB.ConvolutionBuilder(KDEWindow=0.2)
+    f = torch.rand((len(pts), 1), device="cuda", requires_grad=True)
+    out = b.create_convolution("c", ph, 0, f, 1, 0.15, outNumFeatures=8, multiFeatureConv=True)
+    g1 = torch.autograd.grad(out.sum(), [f], retain_graph=True)[0]
+    g2 = torch.autograd.grad(out.sum(), [f], retain_graph=True)[0]
+    assert torch.allclose(g1, g2, rtol=1e-5, atol=1e-7)
+    with torch.no_grad():
+        next(iter(b.parameters())).mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out.sum().backward()
