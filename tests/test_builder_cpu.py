@@ -118,6 +118,30 @@ def test_prefetch_geometry_is_a_no_op_on_host_tensors(shimmed_builder):
     assert out.shape == (B * 64, 8) and len(cb.cacheNeighs_) == 1
 
 
+def test_running_ahead_is_a_no_op_on_host_tensors(shimmed_builder):
+    """PointHierarchy.prefetch() / ConvolutionBuilder.prefetch_step() exist for device tensors and the native executor: with
+    host tensors they return None / 0, run no op, and the constructor treats prefetched=None as absent. Attributes whose
+    names end in '_' are plain state of the two modules (no parameter / buffer bookkeeping), variables still register."""
+    MB, calls = shimmed_builder
+    B = 2
+    rng = np.random.default_rng(2)
+    pts = torch.from_numpy(rng.random((B * 64, 3), dtype=np.float32))
+    bids = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), 64).reshape(-1, 1))
+    feats = torch.ones((B * 64, 1), dtype=torch.float32)
+    before = len(calls)
+    assert MB.PointHierarchy.prefetch(pts, bids, [0.4], B) is None and len(calls) == before
+    ph = MB.PointHierarchy(pts, feats, bids, [0.4], "PH", B, prefetched=None)
+    assert len(ph.points_) == 2
+    cb = MB.ConvolutionBuilder(KDEWindow=0.2)
+    out = cb.create_convolution("Conv", ph, 0, feats, 1, 0.3, outNumFeatures=8, multiFeatureConv=True)
+    cb.reset()
+    n = len(calls)
+    assert cb.prefetch_step(ph) == 0 and len(calls) == n
+    assert out.shape == (B * 64, 8)
+    assert "cacheGrids_" in cb.__dict__ and "points_" in ph.__dict__          # plain attributes ...
+    assert "Conv_weights" in dict(cb.named_parameters())                        # ... and registered variables
+
+
 def test_builder_is_a_torch_module_with_reference_variable_names(shimmed_builder):
     """ConvolutionBuilder / PointHierarchy as torch.nn.Modules -- the kernel-MLP variables are
     registered parameters under the reference's names (MCConvBuilder.py:407-419), so parameters(), state_dict(),
