@@ -217,8 +217,16 @@ class Workload:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         trace = [] if os.environ.get("MCCNN_BENCH_TRACE") else None  # diagnostic: per-step times of the region to stderr
+        hlag = int(os.environ.get("MCCNN_BENCH_LAG_HEADLINE", "0"))  # A/B: the host at most `hlag` steps ahead of the GPU
+        hevs = []
         for _ in range(steps):
+            if hlag and len(hevs) >= hlag:
+                hevs[-hlag].synchronize()
             self.step()
+            if hlag:
+                e_ = torch.cuda.Event()
+                e_.record()
+                hevs.append(e_)
             if trace is not None:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
@@ -581,11 +589,25 @@ class ConfigWorkload:
         from mccnn_amd import MCConvModule as _M
         l0 = self.lib.mccnn_debug_launch_count()
         w0 = _M.host_wait_seconds()
+        # the host at most `lag` steps ahead of the GPU (0 = unbounded): a GPU-bound step of hundreds of small launches on
+        # several queues runs ~5 % faster when the next step is not enqueued on top of it (cfg3 6.26 -> 5.93 ms); a step
+        # bound by the issuing thread loses from any wait (cfg2 1.40 -> 1.62) -- run_config() tries it where it can pay
+        lag = getattr(self, "lag", 0) or int(os.environ.get("MCCNN_BENCH_LAG", "0"))
+        evs = []
         t0 = time.perf_counter()
+        lag_wait = 0.0
         for _ in range(steps):
+            if lag and len(evs) >= lag:
+                tw = time.perf_counter()
+                evs[-lag].synchronize()
+                lag_wait += time.perf_counter() - tw   # (a wait for the GPU, not host work)
             self.step()
+            if lag:
+                e_ = torch.cuda.Event()
+                e_.record()
+                evs.append(e_)
         t_issue = time.perf_counter() - t0   # the host has enqueued the last launch (edge-count waits included)
-        waits = _M.host_wait_seconds() - w0
+        waits = _M.host_wait_seconds() - w0 + lag_wait
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         launches = (self.lib.mccnn_debug_launch_count() - l0) / float(steps)
@@ -743,7 +765,7 @@ def run_config(name, device, args, want_cpu):
     steps = {"cfg0": 200, "cfg1": 100, "cfg2": 40, "cfg3": 30, "cfg4": 30}[name]
     ms_seq, launches = cw.timed(steps, 5)
     seq_issue, seq_wait = cw.host_issue_ms, cw.host_wait_ms
-    ms, mode = ms_seq, "sequential"
+    ms, mode, lag_used = ms_seq, "sequential", 0
     if not getattr(args, "no_pipeline", False) and cfg.hierarchy:
         # the same steps with the hierarchy of the next batch requested one step ahead -- accepted when the outputs of
         # every convolution are bit-identical to the sequential step's and the steps are not slower
@@ -769,6 +791,25 @@ def run_config(name, device, args, want_cpu):
                     print("bench: %s steps of %s do not reproduce the sequential outputs" % (
                         "pipelined+geometry" if deep else "pipelined", name), file=sys.stderr)
             cw.host_issue_ms, cw.host_wait_ms = best_issue, best_wait
+            if mode != "sequential" and os.environ.get("MCCNN_BENCH_LAG_TRY", "1") != "0":
+                # the same steps with the host kept at most ONE step ahead of the GPU (an event wait per step): kept when faster
+                want_deep = mode == "pipelined+geometry"
+                if not (cw.pipeline and bool(getattr(cw, "deep", False)) == want_deep):
+                    cw.set_pipeline(False)
+                    torch.cuda.synchronize()
+                    cw.set_pipeline(True, geometry=want_deep)
+                if cw.pipeline:
+                    cw.lag = 1
+                    for _ in range(3):
+                        cw.step()
+                    ms_l, launches_l = cw.timed(steps, 5)
+                    cw.lag = 0
+                    if os.environ.get("MCCNN_BENCH_VERBOSE"):
+                        print("bench: %s host lag 1: %.4f ms against %.4f" % (name, ms_l, ms), file=sys.stderr)
+                    if ms_l < ms:
+                        ms, launches, lag_used = ms_l, launches_l, 1
+                    else:
+                        cw.host_issue_ms, cw.host_wait_ms = best_issue, best_wait
         except Exception as ex:  # the sequential numbers stand
             print("bench: pipelined %s steps failed: %r" % (name, ex), file=sys.stderr)
             cw.host_issue_ms, cw.host_wait_ms = seq_issue, seq_wait
@@ -783,6 +824,8 @@ def run_config(name, device, args, want_cpu):
            # PDFs / row plans are started under this batch's convolutions as well (ConvolutionBuilder.prefetch_step);
            # sequential_ms_per_step: hierarchy, then convolutions, nothing carried over
            "mode": mode, "sequential_ms_per_step": round(ms_seq, 4),
+           # 1: the host waits for the end of the previous step before it issues the next (tried on GPU-bound steps only)
+           "host_lag_steps": lag_used,
            "library_launches_per_step": round(launches, 1),
            # when this equals ms_per_step the step is bound by the HOST issuing its launches, not by the kernels
            "host_issue_ms_per_step": round(cw.host_issue_ms, 4),
