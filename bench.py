@@ -593,21 +593,14 @@ class ConfigWorkload:
         # several queues runs ~5 % faster when the next step is not enqueued on top of it (cfg3 6.26 -> 5.93 ms); a step
         # bound by the issuing thread loses from any wait (cfg2 1.40 -> 1.62) -- run_config() tries it where it can pay
         lag = getattr(self, "lag", 0) or int(os.environ.get("MCCNN_BENCH_LAG", "0"))
-        evs = []
+        self.builder.hostStepsAhead_ = (lag - 1) if lag else None   # (ConvolutionBuilder.reset() does the waiting)
+        self.builder.__dict__.pop("stepEvents_", None)
         t0 = time.perf_counter()
-        lag_wait = 0.0
         for _ in range(steps):
-            if lag and len(evs) >= lag:
-                tw = time.perf_counter()
-                evs[-lag].synchronize()
-                lag_wait += time.perf_counter() - tw   # (a wait for the GPU, not host work)
             self.step()
-            if lag:
-                e_ = torch.cuda.Event()
-                e_.record()
-                evs.append(e_)
         t_issue = time.perf_counter() - t0   # the host has enqueued the last launch (edge-count waits included)
-        waits = _M.host_wait_seconds() - w0 + lag_wait
+        waits = _M.host_wait_seconds() - w0
+        self.builder.hostStepsAhead_ = None
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         launches = (self.lib.mccnn_debug_launch_count() - l0) / float(steps)
@@ -824,7 +817,8 @@ def run_config(name, device, args, want_cpu):
            # PDFs / row plans are started under this batch's convolutions as well (ConvolutionBuilder.prefetch_step);
            # sequential_ms_per_step: hierarchy, then convolutions, nothing carried over
            "mode": mode, "sequential_ms_per_step": round(ms_seq, 4),
-           # 1: the host waits for the end of the previous step before it issues the next (tried on GPU-bound steps only)
+           # 1: the host waits for the end of the previous step before it issues the next (ConvolutionBuilder.hostStepsAhead_
+           # = 0); tried after the pipelined modes, kept when faster
            "host_lag_steps": lag_used,
            "library_launches_per_step": round(launches, 1),
            # when this equals ms_per_step the step is bound by the HOST issuing its launches, not by the kernels
