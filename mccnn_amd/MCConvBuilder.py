@@ -310,7 +310,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         # first create_convolution, round-robin on side streams -- they depend on the points only, their chains of small
         # kernels run side by side and under the first layers instead of one after the other between them
         self.geoPrefetch_ = os.environ.get("MCCNN_GEO_PREFETCH", "1") != "0"
-        self.geoLog_ = []
+        self.geoSeen_ = {}
         self.geoPlan_ = []
         self.prefetchedGeo_ = {}    # prefetch_geometry() on the native path: keyPDF -> (Geometry, keyGrid, keyNeighs, usePDF, transposed)
         self.multiFeatureConvs_ = multiFeatureConvs
@@ -405,18 +405,14 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         self.cacheGrids_ = {}
         self.cacheNeighs_ = {}
         self.cachePDFs_ = {}
-        if self.geoLog_:
-            # the step's geometries AND the pieces its layers attached to each (row plans, transposed list): the next
-            # step asks for them together with the build (native.Geometry.prebuild_async)
+        if self.geoSeen_:
+            # the geometries the step's layers USED (built by them, prebuilt, or started a step ago by prefetch_step) and
+            # the pieces they attached to each (row plans, transposed list): what the next step asks for ahead
             plan = []
-            for ent in self.geoLog_:
-                geo = self.cacheGeo_.get(ent[7])
-                plan.append(ent[:7] + ((geo.have & 7) if geo is not None else 0, ent[7]))
-            self.geoPlan_, self.geoLog_ = plan, []
-        elif self.geoPlan_ and self.cacheGeo_:
-            # (a step whose geometries all came from prefetch_step() logs no build: its layers may still have attached more)
-            self.geoPlan_ = [ent[:7] + (ent[7] | ((self.cacheGeo_[ent[8]].have & 7) if ent[8] in self.cacheGeo_ else 0), ent[8])
-                             for ent in self.geoPlan_]
+            for key, ent in self.geoSeen_.items():
+                geo = self.cacheGeo_.get(key)
+                plan.append(ent + ((geo.have & 7) if geo is not None else 0, key))
+            self.geoPlan_, self.geoSeen_ = plan, {}
         self.cacheGeo_ = {}
         self.cacheGeoGrid_ = {}
         if self.prefetchedGeo_:
@@ -764,7 +760,6 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
             if have and pieces and geo.e_cap <= _PLAN_PREFETCH_MAX_E:
                 geo.prebuild_async(have, self.useAVG_)
             self.cacheGeo_[keyPDF] = geo
-            self.geoLog_.append((name, inLevel, outLevel, radius, window, rel, usePDF, keyPDF))
             if owner is None:
                 self.cacheGeoGrid_[keyGrid] = geo
                 self.cacheGrids_[keyGrid] = _LazyEntry(geo, geo.grid)
@@ -835,9 +830,6 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                                          usePDF, owner)
             geo.uses = 0
             self.cacheGeo_[keyPDF] = geo
-            if inPH is outPH:
-                self.geoLog_.append((inPH.hierarchyName_, inLevel, outLevel, convRadius, KDEWindow, relativeRadius, usePDF,
-                                     keyPDF))
             if owner is None:
                 self.cacheGeoGrid_[keyGrid] = geo
                 self.cacheGrids_[keyGrid] = _LazyEntry(geo, geo.grid)
@@ -852,6 +844,8 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                 self._trace("compute_pdf", keyPDF)
         else:
             self._trace("sort_features", keyGrid)
+        if inPH is outPH and keyPDF not in self.geoSeen_:
+            self.geoSeen_[keyPDF] = (inPH.hierarchyName_, inLevel, outLevel, convRadius, KDEWindow, relativeRadius, usePDF)
         feats = inFeatures
         if (not feats.is_cuda or feats.dim() != 2 or feats.shape[0] != geo.n or feats.shape[1] != inNumFeatures
                 or feats.dtype not in (torch.float32, torch.bfloat16)):
