@@ -776,33 +776,23 @@ def run_config(name, device, args, want_cpu):
                 for _ in range(4):
                     same = same and all(torch.equal(a, b) for a, b in zip(cw.step(), ref))
                 if same:
-                    ms_p, launches_p = cw.timed(steps, 5)
-                    if ms_p < ms:
-                        ms, launches, mode = ms_p, launches_p, ("pipelined+geometry" if deep else "pipelined")
-                        best_issue, best_wait = cw.host_issue_ms, cw.host_wait_ms
+                    # ... each also with the host kept one step at a time (ConvolutionBuilder.hostStepsAhead_ = 0)
+                    for lag in ((0, 1) if os.environ.get("MCCNN_BENCH_LAG_TRY", "1") != "0" else (0,)):
+                        cw.lag = lag
+                        if lag:
+                            for _ in range(3):
+                                cw.step()
+                        ms_p, launches_p = cw.timed(steps, 5)
+                        cw.lag = 0
+                        if os.environ.get("MCCNN_BENCH_VERBOSE"):
+                            print("bench: %s %s host lag %d: %.4f ms" % (name, "deep" if deep else "pipelined", lag, ms_p), file=sys.stderr)
+                        if ms_p < ms:
+                            ms, launches, mode, lag_used = ms_p, launches_p, ("pipelined+geometry" if deep else "pipelined"), lag
+                            best_issue, best_wait = cw.host_issue_ms, cw.host_wait_ms
                 else:
                     print("bench: %s steps of %s do not reproduce the sequential outputs" % (
                         "pipelined+geometry" if deep else "pipelined", name), file=sys.stderr)
             cw.host_issue_ms, cw.host_wait_ms = best_issue, best_wait
-            if mode != "sequential" and os.environ.get("MCCNN_BENCH_LAG_TRY", "1") != "0":
-                # the same steps with the host kept at most ONE step ahead of the GPU (an event wait per step): kept when faster
-                want_deep = mode == "pipelined+geometry"
-                if not (cw.pipeline and bool(getattr(cw, "deep", False)) == want_deep):
-                    cw.set_pipeline(False)
-                    torch.cuda.synchronize()
-                    cw.set_pipeline(True, geometry=want_deep)
-                if cw.pipeline:
-                    cw.lag = 1
-                    for _ in range(3):
-                        cw.step()
-                    ms_l, launches_l = cw.timed(steps, 5)
-                    cw.lag = 0
-                    if os.environ.get("MCCNN_BENCH_VERBOSE"):
-                        print("bench: %s host lag 1: %.4f ms against %.4f" % (name, ms_l, ms), file=sys.stderr)
-                    if ms_l < ms:
-                        ms, launches, lag_used = ms_l, launches_l, 1
-                    else:
-                        cw.host_issue_ms, cw.host_wait_ms = best_issue, best_wait
         except Exception as ex:  # the sequential numbers stand
             print("bench: pipelined %s steps failed: %r" % (name, ex), file=sys.stderr)
             cw.host_issue_ms, cw.host_wait_ms = seq_issue, seq_wait
