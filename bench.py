@@ -989,7 +989,7 @@ def compact_record(rec, details_path=None):
     if isinstance(cf, dict):
         out["configs"] = {}
         for name, ent in cf.items():
-            e = _pick(ent, ("ms_per_step", "value", "mode", "sequential_ms_per_step", "host_issue_ms_per_step",
+            e = _pick(ent, ("ms_per_step", "value", "mode", "host_lag_steps", "sequential_ms_per_step", "host_issue_ms_per_step",
                             "host_busy_ms_per_step", "library_launches_per_step", "points", "convolutions"))
             if "library_launches_per_step" in e:
                 e["launches"] = e.pop("library_launches_per_step")
