@@ -138,6 +138,8 @@ int unsorted_max_points() { static const int v = getenv("MCCNN_UNSORTED_MAX_POIN
 // gathered rows miss the L2s; backward of larger lists only for wide layers with long rows.
 bool rows_shape(bool combin, int fin, const void* feats, int rows, int n_points, int e, bool backward) {
     if (!row_kernels_on() || read_mask() != 0 || combin || fin % 8 != 0 || e <= 0 || rows <= 0 || (((uintptr_t)feats) & 15)) return false;
+    static const int force = getenv("MCCNN_ROWS_FORCE") ? atoi(getenv("MCCNN_ROWS_FORCE")) : 0;  // A/B: 1 = rows wherever they apply
+    if (force == 1) return true;
     if (e <= 500000) return true;
     if (!backward) return !(fin <= 128 && n_points >= 65536);
     return fin >= 256 && (float)e / (float)rows >= rows_min_degree();

@@ -72,6 +72,8 @@ for b in batches:
     outs, grads = step(builder, b)
     refs.append(([o.detach().clone() for o in outs], [None if g is None else g.clone() for g in grads]))
 builder.geoPrefetch_ = True
+if os.environ.get("SOAK_LAG"):   # the steps issued one at a time (ConvolutionBuilder.hostStepsAhead_ = 0)
+    builder.hostStepsAhead_ = int(os.environ["SOAK_LAG"])
 order = rng.integers(0, len(batches), STEPS)
 bad = torch.zeros((), dtype=torch.int64, device=dev)
 worst = torch.zeros((), dtype=torch.float32, device=dev)
