@@ -37,13 +37,22 @@ class MCClassS(torch.nn.Module):
         batch k + 1 before the forward pass of batch k and hand the result to forward(prefetched=...)."""
         return PointHierarchy.prefetch(points, batchIds, self.RADII, self.args[1])
 
+    def hierarchy(self, points, batchIds, features, prefetched=None):
+        """The network's point hierarchy for a batch (prefetched: what prefetch_hierarchy() returned for it)."""
+        return PointHierarchy(points, features, batchIds, self.RADII, "MCClassS_PH", self.args[1], ops=self.ops,
+                              prefetched=prefetched)
+
     def forward(self, points, batchIds, features, isTraining, keepProbConv=1.0, keepProbFull=0.5, useConvDropOut=False,
-                 useDropOutFull=True, prefetched=None):
+                 useDropOutFull=True, prefetched=None, hierarchy=None, nextHierarchy=None):
+        """hierarchy (extension): this batch's hierarchy, built a step ago with self.hierarchy(); nextHierarchy: the NEXT
+        batch's -- its grids, neighbour lists, PDFs and row plans are then started under this batch's layers
+        (ConvolutionBuilder.prefetch_step) and the next forward pass finds them built."""
         numInputFeatures, batchSize, k, numOutCat = self.args
         st, mConvBuilder = self.store, self.convBuilder
         mConvBuilder.reset()
-        mPointHierarchy = PointHierarchy(points, features, batchIds, self.RADII, "MCClassS_PH", batchSize, ops=self.ops,
-                                         prefetched=prefetched)
+        if nextHierarchy is not None:
+            mConvBuilder.prefetch_step(nextHierarchy)
+        mPointHierarchy = hierarchy if hierarchy is not None else self.hierarchy(points, batchIds, features, prefetched)
         convFeatures1 = mConvBuilder.create_convolution(
             convName="Conv_1", inPointHierarchy=mPointHierarchy, inPointLevel=0, outPointLevel=1, inFeatures=features,
             inNumFeatures=numInputFeatures, outNumFeatures=k, convRadius=0.2, multiFeatureConv=True)
@@ -121,14 +130,19 @@ def main():
     P, Bi, F, y = synthetic_batch(args.batch, args.points, 4, rng, device)
     net(P, Bi, F, True)  # creates the variables
     opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    # the loader runs two batches ahead: the hierarchy of batch k + 2 is requested (helper thread, own stream) while batch
+    # k trains; the one of batch k + 1 is complete by then, and its geometry is started under batch k's layers
+    cur = synthetic_batch(args.batch, args.points, 4, rng, device)
     nxt = synthetic_batch(args.batch, args.points, 4, rng, device)
+    ph_cur = net.hierarchy(cur[0], cur[1], cur[2])
+    fut_nxt = net.prefetch_hierarchy(nxt[0], nxt[1])
     for step in range(args.steps):
-        P, Bi, F, y = nxt
-        ahead = net.prefetch_hierarchy(P, Bi) if step == 0 else ahead_next
-        # the loader's next batch, and its point hierarchy under this batch's forward / backward pass
-        nxt = synthetic_batch(args.batch, args.points, 4, rng, device)
-        ahead_next = net.prefetch_hierarchy(nxt[0], nxt[1])
-        logits = net(P, Bi, F, True, prefetched=ahead)
+        P, Bi, F, y = cur
+        ph_nxt = net.hierarchy(nxt[0], nxt[1], nxt[2], prefetched=fut_nxt)
+        after = synthetic_batch(args.batch, args.points, 4, rng, device)
+        fut_after = net.prefetch_hierarchy(after[0], after[1])
+        logits = net(P, Bi, F, True, hierarchy=ph_cur, nextHierarchy=ph_nxt)
+        cur, nxt, ph_cur, fut_nxt = nxt, after, ph_nxt, fut_after
         loss = torch.nn.functional.cross_entropy(logits, y)
         opt.zero_grad(set_to_none=True)
         loss.backward()

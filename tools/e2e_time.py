@@ -55,3 +55,31 @@ for _ in range(20):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 20
 print("... with the next batch's hierarchy one step ahead (PointHierarchy.prefetch): %.2f ms/step, %.0f clouds/s" % (dt * 1e3, B / dt))
+
+# ... and two batches ahead: the next batch's hierarchy is complete when a step starts, its geometry and row plans are started
+# under this batch's layers (ConvolutionBuilder.prefetch_step through forward(nextHierarchy=...))
+ph_cur = net.hierarchy(P, Bi, F)
+fut = net.prefetch_hierarchy(P, Bi)
+
+
+def deep_step():
+    global ph_cur, fut
+    ph_nxt = net.hierarchy(P, Bi, F, prefetched=fut)
+    fut = net.prefetch_hierarchy(P, Bi)
+    logits = net(P, Bi, F, True, hierarchy=ph_cur, nextHierarchy=ph_nxt)
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+    ph_cur = ph_nxt
+
+
+for _ in range(5):
+    deep_step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    deep_step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 20
+print("... hierarchy two batches ahead + prefetch_step: %.2f ms/step, %.0f clouds/s" % (dt * 1e3, B / dt))
