@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                 // (Measured and dropped: the cell of a flat position from a bit plane of cell ends -- ds_or per non-empty
                 // cell, a population count and one v_mbcnt per round instead of the 5-step binary search: the plane's set-up
                 // per window (two more wave barriers, an LDS atomic, a scan) eats what the searches cost, -1 % on one box.
-                // MCCNN_NW_NO_INVB: the per-lane bit test instead of the inverse ballot, +2.7 % on the room.)
+                // MCCNN_NW_NO_INVB: the per-lane bit test instead of the inverse ballot, +2.7 % on the room. The mask words of
+                // the NEXT centre requested while this one is compacted (and the first before the cell searches): +3 %.)
             }
             continue;
         }
