@@ -797,6 +797,9 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                     (a[2] is cen or (a[2].data_ptr() == cen.data_ptr() and a[2].shape == cen.shape)):
                 geo.unverified = False
             else:
+                if os.environ.get("MCCNN_DEBUG_GEO"):
+                    print("native conv %s: parked geometry %s not for this hierarchy (built from %s / %s, asked %s / %s)" % (
+                        convName, keyPDF, tuple(a[0].shape), tuple(a[2].shape), tuple(pin.shape), tuple(cen.shape)), file=sys.stderr)
                 self.cacheGeo_.pop(keyPDF, None)
                 self.cachePDFs_.pop(keyPDF, None)
                 self.cacheNeighs_.pop(keyNeighs, None)
@@ -806,8 +809,14 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                 geo = None
         if geo is None:
             if keyGrid in self.cacheGrids_ and keyGrid not in self.cacheGeoGrid_:
+                if os.environ.get("MCCNN_DEBUG_GEO"):
+                    print("native conv %s: grid %s owned by the op path" % (convName, keyGrid), file=sys.stderr)
                 return None   # the op-by-op path (or a prefetch) owns this grid
             if keyNeighs in self.cacheNeighs_ or keyPDF in self.cachePDFs_:
+                if os.environ.get("MCCNN_DEBUG_GEO"):
+                    print("native conv %s: list %s / pdf %s cached without a geometry (%s %s); geometries: %s" % (
+                        convName, keyNeighs, keyPDF, keyNeighs in self.cacheNeighs_, keyPDF in self.cachePDFs_,
+                        sorted(self.cacheGeo_)), file=sys.stderr)
                 return None
             inPts, inBids = inPH.points_[inLevel], inPH.batchIds_[inLevel]
             centres, cBids = outPH.points_[outLevel], outPH.batchIds_[outLevel]
@@ -847,6 +856,10 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         if inPH is outPH and keyPDF not in self.geoSeen_:
             self.geoSeen_[keyPDF] = (inPH.hierarchyName_, inLevel, outLevel, convRadius, KDEWindow, relativeRadius, usePDF)
         feats = inFeatures
+        if os.environ.get("MCCNN_DEBUG_GEO") and feats.dim() == 2 and feats.shape[0] != geo.n:
+            print("native conv %s: %d feature rows for a geometry over %d points (key %s, unverified %s, built from %s, level has %s)" % (
+                convName, feats.shape[0], geo.n, keyPDF, getattr(geo, "unverified", None), tuple(geo.args[0].shape),
+                tuple(inPH.points_[inLevel].shape)), file=sys.stderr)
         if (not feats.is_cuda or feats.dim() != 2 or feats.shape[0] != geo.n or feats.shape[1] != inNumFeatures
                 or feats.dtype not in (torch.float32, torch.bfloat16)):
             return None

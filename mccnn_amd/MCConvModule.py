@@ -1016,8 +1016,8 @@ def point_hierarchy_prefetch(inPts, inBatchIds, radiusList, batchSize, scaleInv)
     _req(batchSize > 0, op + " expects a positive batch size")
     for radius in radiusList:
         _req(radius > 0.0, op + " expects positive radii")
-    return ext.hierarchy_prefetch(pts, bids, [float(r) for r in radiusList], int(batchSize), bool(scaleInv),
-                                  2 if POISSON_DATAFLOW == 2 else 1)
+    pmode = 2 if POISSON_DATAFLOW == 2 else int(os.environ.get("MCCNN_HIER_PREFETCH_PMODE", "1"))
+    return ext.hierarchy_prefetch(pts, bids, [float(r) for r in radiusList], int(batchSize), bool(scaleInv), pmode)
 
 
 def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batchSize, scaleInv):

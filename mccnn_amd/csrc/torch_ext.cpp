@@ -59,6 +59,9 @@ struct DevGuard {
 
 void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
+hipEvent_t take_event_fwd();
+void give_event_fwd(hipEvent_t e);
+
 // grow-only scratch per (thread, device, stream): consecutive calls on a stream are stream-ordered and may share it
 Tensor& scratch(size_t bytes, const Tensor& like, void* stream) {
     thread_local std::map<std::pair<int, void*>, Tensor> pool;
@@ -69,6 +72,18 @@ Tensor& scratch(size_t bytes, const Tensor& like, void* stream) {
         // what `stream` still runs on it has to be over first (rare: the scratch only grows)
         if (t.defined()) (void)hipStreamSynchronize((hipStream_t)stream);
         t = at::empty({(int64_t)(bytes + bytes / 4)}, like.options().dtype(at::kByte));
+        // ... and the NEW block comes from the caching allocator's pool of the calling thread's current stream: the
+        // allocator hands out a block its last owner freed a moment ago, because work enqueued on THAT stream is ordered
+        // behind the old owner's. Work on `stream` is not -- a helper thread's scratch used to be written on its side
+        // stream while convolution kernels still read the block as THEIR scratch (wrong level sizes of a prefetched
+        // hierarchy, wrong outputs: tools/soak_network.py SOAK_CFG=cfg4 SOAK_DEEP=1). `stream` first waits for what
+        // the allocation stream holds now.
+        void* alloc = cur_stream(like);
+        if (alloc != stream) {
+            hipEvent_t ev = take_event_fwd();
+            if (hipEventRecord(ev, (hipStream_t)alloc) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)stream, ev, 0);
+            give_event_fwd(ev);
+        }
     }
     return t;
 }
@@ -141,6 +156,8 @@ void give_event(hipEvent_t e) {
     if (g_events.size() < 256) g_events.push_back(e);
     else (void)hipEventDestroy(e);
 }
+hipEvent_t take_event_fwd() { return take_event(); }
+void give_event_fwd(hipEvent_t e) { give_event(e); }
 
 // A helper thread starts with device 0 current; every job names the device of its tensors first (one process per GPU sets
 // its device on the calling thread only -- kernel launches, memsets and event records of a job go to streams of THAT
@@ -161,13 +178,24 @@ public:
     // 2: row plans / transposed lists of the step's geometries (those jobs wait for edge totals)
     static Issuer& get(int which = 0) {
         static Issuer inst[3];
+        inst[which].which_ = which;
         return inst[which];
     }
     static bool enabled() {
         static const bool on = !(getenv("MCCNN_ISSUE_THREAD") && std::string(getenv("MCCNN_ISSUE_THREAD")) == "0");
         return on;
     }
+    // (debugging: MCCNN_ISSUE_INLINE = mask of the issuers whose jobs run on the calling thread instead)
+    static bool inline_jobs(int which) {
+        static const int mask = getenv("MCCNN_ISSUE_INLINE") ? atoi(getenv("MCCNN_ISSUE_INLINE")) : 0;
+        return (mask >> which) & 1;
+    }
+    int which_ = 0;
     void push(std::function<void()> job) {
+        if (inline_jobs(which_)) {
+            job();
+            return;
+        }
         {
             std::lock_guard<std::mutex> lk(m_);
             if (!started_) {
@@ -200,6 +228,8 @@ private:
                 job = std::move(q_.front());
                 q_.pop_front();
             }
+            static const int delay_us = getenv("MCCNN_DEBUG_JOB_DELAY_US") ? atoi(getenv("MCCNN_DEBUG_JOB_DELAY_US")) : 0;
+            if (delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));   // (widens race windows)
             job();
         }
     }
@@ -921,6 +951,13 @@ struct HierFuture {
             hip_check(hipEventRecord(event, ss), "hipEventRecord");
             hip_check(hipStreamSynchronize(ss), "hipStreamSynchronize");
             hs.assign(host.data_ptr<int>(), host.data_ptr<int>() + L + 1);
+            if (getenv("MCCNN_DEBUG_HIER")) {
+                std::string line = "hier job: cap " + std::to_string(cap) + " extent " + std::to_string(extent) + " nc";
+                for (int l = 0; l < L; ++l) line += " " + std::to_string(ncs[l]);
+                line += " sizes";
+                for (int l = 0; l <= L; ++l) line += " " + std::to_string(hs[l]);
+                fprintf(stderr, "%s\n", line.c_str());
+            }
         } catch (const std::exception& e) {
             rc = 1;
             what = e.what();

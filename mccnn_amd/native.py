@@ -6,6 +6,7 @@ A step of a network is bound by the host issuing its launches: ~12 u
 the launch itself. This module is the thin remainder: it owns the device buffers the library asks for (the library
 never allocates), the pinned word the edge total arrives in, and the autograd node of a layer.
 """
+import os
 import ctypes as C
 import threading
 import weakref
@@ -65,7 +66,16 @@ def _ws(nbytes, device):
     return pool_ws(nbytes, device)
 
 
+_ECAP_SCALE = float(os.environ.get("MCCNN_ECAP_SCALE", "1"))   # (debugging: generous / starved capacity guesses)
+
+
 def _capacity_guess(gkey, m):
+    if _ECAP_SCALE != 1.0:
+        return int(_capacity_guess_(gkey, m) * _ECAP_SCALE) + 1024
+    return _capacity_guess_(gkey, m)
+
+
+def _capacity_guess_(gkey, m):
     g = _EDGE_GUESS.get(gkey, 0)
     if g <= 0:
         ratio = _EDGE_RATIO.get((gkey[0], gkey[3], gkey[5]), 0.0)

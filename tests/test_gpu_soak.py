@@ -24,3 +24,16 @@ def test_network_soak_with_everything_running_ahead(mc, deep):
     assert m, out.stdout
     assert int(m.group(1)) == 0 and float(m.group(2)) < 1e-4
     assert int(m.group(3)) <= int(m.group(4)) + 64   # nothing accumulates over the steps
+
+
+def test_room_network_soak_with_changing_room_sizes(mc):
+    """The MCSegScanNet graph (absolute radii, 17 layers, 5 levels) over rooms of 30 k .. 100 k points and a two-room batch in
+    random order, hierarchy two batches ahead + prefetch_step, the prefetched hierarchy on the phased Poisson form (most
+    launches on its stream). This is the run that exposed a helper thread's scratch being taken from the caching allocator's
+    pool of ANOTHER stream without ordering (level sizes of a prefetched hierarchy overwritten by convolution kernels)."""
+    env = dict(os.environ, SOAK_STEPS="500", SOAK_DEEP="1", SOAK_CFG="cfg4", MCCNN_HIER_PREFETCH_PMODE="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_network.py")], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    m = re.search(r"forward mismatches (\d+), worst relative gradient deviation (\S+),", out.stdout)
+    assert m and int(m.group(1)) == 0 and float(m.group(2)) < 1e-4, out.stdout

@@ -18,7 +18,7 @@ from mccnn_amd.workloads import CONFIGS, config_points  # noqa: E402
 torch.cuda.set_device(0)
 torch.autograd.set_multithreading_enabled(False)
 STEPS = int(os.environ.get("SOAK_STEPS", "2000"))
-cfg = CONFIGS["cfg2"]
+cfg = CONFIGS[os.environ.get("SOAK_CFG", "cfg2")]   # cfg4: absolute radii (box extent read back per hierarchy), 17 layers
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(7)
 
@@ -61,7 +61,11 @@ def step(builder, batch, prefetched=None, ready=None, then=None):
     return outs, grads
 
 
-batches = [Batch(c, p, s) for c, p, s in ((8, 4096, 43), (5, 3000, 44), (12, 2048, 45), (6, 4096, 46), (3, 8192, 47), (10, 1024, 48))]
+if cfg.cloud_kind == "room":
+    SHAPES = ((1, 100000, 20180601), (1, 60000, 7), (2, 40000, 11), (1, 80000, 19), (1, 30000, 23))
+else:
+    SHAPES = ((8, 4096, 43), (5, 3000, 44), (12, 2048, 45), (6, 4096, 46), (3, 8192, 47), (10, 1024, 48))
+batches = [Batch(c, p, s) for c, p, s in SHAPES]
 torch.manual_seed(3)
 builder = ConvolutionBuilder(KDEWindow=0.25, relativeRadius=cfg.relative)
 step(builder, batches[0])  # creates the variables
@@ -77,6 +81,7 @@ if os.environ.get("SOAK_LAG"):   # the steps issued one at a time (ConvolutionBu
 order = rng.integers(0, len(batches), STEPS)
 bad = torch.zeros((), dtype=torch.int64, device=dev)
 worst = torch.zeros((), dtype=torch.float32, device=dev)
+TRACE = torch.zeros((STEPS, len(cfg.convs)), dtype=torch.int64, device=dev) if os.environ.get("SOAK_TRACE") else None
 DEEP = os.environ.get("SOAK_DEEP", "0") == "1"   # hierarchy two batches ahead + ConvolutionBuilder.prefetch_step for the next
 ahead = batches[order[0]].request()
 if DEEP:
@@ -102,14 +107,33 @@ for s in range(STEPS):
         cur, ahead = ahead, (batches[order[s + 1]].request() if s + 1 < STEPS else None)
         outs, grads = step(builder, b, cur)
     r_out, r_grad = refs[order[s]]
-    for o, r in zip(outs, r_out):
-        bad += (o.detach() != r).sum()
+    if os.environ.get("SOAK_DEBUG"):   # (synchronises every step: which layer of which batch differs first, and its list)
+        for ci, (o, r) in enumerate(zip(outs, r_out)):
+            if not torch.equal(o.detach(), r):
+                c = cfg.convs[ci]
+                print("step %d batch %d (previous %d): layer %s (levels %d -> %d, radius %g) differs: %d of %d values" % (
+                    s, order[s], order[s - 1] if s else -1, c.name, c.lin, c.lout, c.radius, int((o.detach() != r).sum()), r.numel()))
+                for key, g in builder.cacheGeo_.items():
+                    print("   ", key, "n", g.n, "m", g.m, "e", g.e, "e_cap", g.e_cap, "side", getattr(g.core, "side", None))
+                sys.exit(1)
+    for ci, (o, r) in enumerate(zip(outs, r_out)):
+        nb_ = (o.detach() != r).sum()
+        bad += nb_
+        if TRACE is not None:
+            TRACE[s, ci] = nb_
     for g, r in zip(grads, r_grad):
         if g is not None:
             worst = torch.maximum(worst, (g - r).abs().max() / r.abs().max().clamp_min(1e-30))
     if os.environ.get("SOAK_MEM") and s % 5000 == 4999:
         print("  step %d: %.1f MB allocated" % (s + 1, torch.cuda.memory_allocated() / 1e6), flush=True)
 torch.cuda.synchronize()
+if TRACE is not None:
+    nz = TRACE.nonzero().cpu().numpy()
+    for st_, ci in nz[:12]:
+        c = cfg.convs[ci]
+        print("  mismatch: step %d batch %d (previous %d, next %d) layer %s (levels %d -> %d, r %g): %d values" % (
+            st_, order[st_], order[st_ - 1] if st_ else -1, order[st_ + 1] if st_ + 1 < STEPS else -1, c.name, c.lin, c.lout, c.radius,
+            int(TRACE[st_, ci])))
 dt = time.perf_counter() - t0
 print("soak_network%s: %d steps in %.1f s (%.2f ms/step), forward mismatches %d, worst relative gradient deviation %.2e, "
       "memory now %.0f MB (start %.0f), peak %.0f MB" % (" (deep)" if DEEP else "", STEPS, dt, dt / STEPS * 1e3, int(bad.item()), float(worst.item()),
