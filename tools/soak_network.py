@@ -24,6 +24,7 @@ rng = np.random.default_rng(7)
 
 
 VARY_GRAPH = False                     # switched on after the references (SOAK_VARY_GRAPH=1)
+SKIP_BWD = False                       # (SOAK_SKIP_BWD=1)
 vrng = np.random.default_rng(11)
 
 
@@ -68,6 +69,8 @@ def step(builder, batch, prefetched=None, ready=None, then=None):
     for ci in use:
         c = cfg.convs[ci]
         outs[ci] = builder.create_convolution(c.name, ph, c.lin, batch.feats[ci], c.fin, c.radius, ph, c.lout, c.combin, c.fout, c.window)
+    if SKIP_BWD and vrng.random() < 0.3:         # a step without a backward pass (pieces prebuilt for it are never consumed)
+        return outs, [None] * (len(batch.feats) + len(list(builder.parameters())))
     grads = torch.autograd.grad([outs[ci] for ci in use], batch.feats + list(builder.parameters()), [batch.ogs[ci] for ci in use],
                                 allow_unused=True)
     return outs, grads
@@ -89,6 +92,7 @@ for b in batches:
     refs.append(([o.detach().clone() for o in outs], [None if g is None else g.clone() for g in grads]))
 builder.geoPrefetch_ = True
 VARY_GRAPH = os.environ.get("SOAK_VARY_GRAPH") == "1"
+SKIP_BWD = os.environ.get("SOAK_SKIP_BWD") == "1"
 if os.environ.get("SOAK_LAG"):   # the steps issued one at a time (ConvolutionBuilder.hostStepsAhead_ = 0)
     builder.hostStepsAhead_ = int(os.environ["SOAK_LAG"])
 order = rng.integers(0, len(batches), STEPS)
