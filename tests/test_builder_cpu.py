@@ -138,6 +138,9 @@ def test_running_ahead_is_a_no_op_on_host_tensors(shimmed_builder):
     n = len(calls)
     assert cb.prefetch_step(ph) == 0 and len(calls) == n
     assert out.shape == (B * 64, 8)
+    cb.hostStepsAhead_ = 0            # (waits for the GPU between steps: nothing to wait for without one)
+    cb.reset()
+    cb.reset()
     assert "cacheGrids_" in cb.__dict__ and "points_" in ph.__dict__          # plain attributes ...
     assert "Conv_weights" in dict(cb.named_parameters())                        # ... and registered variables
 
