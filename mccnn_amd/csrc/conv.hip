@@ -753,9 +753,12 @@ __global__ __launch_bounds__(256) void tr_count_lds(const int2* __restrict__ pac
     __syncthreads();
     if (t < e) slot[t] = bins[j] + local;
 }
+// (Workgroups in XCD-contiguous order: the 4-byte scatters of one row come from centres of one region of space, i.e. from
+// one run of edge ids -- handed to ONE XCD, the lines of `tmp` fill up inside that XCD's L2 instead of leaving eight L2s
+// as 32-byte partial writes: 137 MB of fabric writes for 18 MB of payload with the default interleaving.)
 __global__ __launch_bounds__(256) void tr_fill(const int2* __restrict__ packed, int e, const int* __restrict__ startT,
                                                const int* __restrict__ slot, int* __restrict__ tmp) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int t = xcd_contiguous(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (t < e) tmp[startT[packed[t].x] + slot[t]] = t;
 }
 // stable order inside a row: ascending edge id (the arrival order above is arbitrary). One thread per POSITION of
@@ -763,7 +766,7 @@ __global__ __launch_bounds__(256) void tr_fill(const int2* __restrict__ packed, 
 // a thread per edge id would make every lane scan a different row (64 cache lines per load).
 __global__ __launch_bounds__(256) void tr_rank(const int2* __restrict__ packed, int e, const int* __restrict__ startT,
                                                const int* __restrict__ tmp, int* __restrict__ permT) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int p = xcd_contiguous(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (p >= e) return;
     int v = tmp[p];
     int j = packed[v].x;
@@ -1039,6 +1042,28 @@ std::atomic<int>& conv_impl_override() {
     return v;
 }
 
+bool transpose_small(int e, int n) {
+    return e <= MCCNN_TR_SMALL_E && n <= MCCNN_TR_SMALL_N && (long long)e * e / n <= (4LL << 20) && small_kernels_on();
+}
+// The first half of a transposition (large lists), shared with the fused plan build of conv_rows.hip: row counts with
+// every edge's arrival slot, their prefix sums (start_t[n] = e). blk = [align_up(4 n) counters][scan workspace].
+size_t transpose_count_bytes(int n) { return align_up((size_t)n * 4) + scan_workspace_bytes(n); }
+int transpose_count(const int2* pk, int e, int n, int* start_t, char* blk, int* slot, hipStream_t s) {
+    const size_t cntBytes = align_up((size_t)n * 4);
+    int* cnt = (int*)blk;
+    MCCNN_MEMSET(hipMemsetAsync(blk, 0, cntBytes + scan_status_bytes(n), s));
+    if (n <= MCCNN_TR_LDS_BINS && e >= 4 * n) tr_count_lds<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, n, cnt, slot);
+    else tr_count<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, cnt, slot);
+    MCCNN_LAUNCHED();
+    return exclusive_scan_i32(cnt, start_t, n, start_t + n, blk + cntBytes, s, true);
+}
+// ... and the second: edge ids grouped by row, arrival order inside a row
+int transpose_fill(const int2* pk, int e, const int* start_t, const int* slot, int* tmp, hipStream_t s) {
+    tr_fill<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, start_t, slot, tmp);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
 }  // namespace mccnn
 
 using namespace mccnn;
@@ -1245,22 +1270,17 @@ int mccnn_transpose_neighbors(const int* packed, int e, int n, int* start_t, int
     int* tmp = ar.take<int>((size_t)e);
     if (!blk || !slot || !tmp) return MCCNN_E_WORKSPACE;
     int* cnt = (int*)blk;
-    void* scanws = blk + cntBytes;
     const int2* pk = reinterpret_cast<const int2*>(packed);
     // the rank phase is quadratic in the row length: one workgroup only when the rows are short enough for it
-    if (e <= MCCNN_TR_SMALL_E && n <= MCCNN_TR_SMALL_N && (long long)e * e / n <= (4LL << 20) && small_kernels_on()) {
+    if (transpose_small(e, n)) {
         tr_small<<<1, 1024, 0, s>>>(pk, e, n, cnt, slot, tmp, start_t, perm_t);
         MCCNN_LAUNCHED();
         return 0;
     }
-    MCCNN_MEMSET(hipMemsetAsync(blk, 0, cntBytes + scan_status_bytes(n), s));
-    if (n <= MCCNN_TR_LDS_BINS && e >= 4 * n) tr_count_lds<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, n, cnt, slot);
-    else tr_count<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, cnt, slot);
-    MCCNN_LAUNCHED();
-    int rc = exclusive_scan_i32(cnt, start_t, n, start_t + n, scanws, s, true);
+    int rc = transpose_count(pk, e, n, start_t, blk, slot, s);
     if (rc) return rc;
-    tr_fill<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, start_t, slot, tmp);
-    MCCNN_LAUNCHED();
+    rc = transpose_fill(pk, e, start_t, slot, tmp, s);
+    if (rc) return rc;
     tr_rank<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, start_t, tmp, perm_t);
     MCCNN_LAUNCHED();
     return 0;

@@ -335,6 +335,166 @@ __global__ __launch_bounds__(256) void sell_fill(const float4* __restrict__ recE
     }
 }
 
+// ------------------------------------------------------------------------------------------------ scatter fill (transposed plan)
+// Large lists (every plan that is not laid out by plan_small). sell_fill above GATHERS: a lane owns a row, so the three
+// reads of a slot (perm_t, record, pair) all touch a line of their own -- the transposed plan of the 100k room fetched
+// 1.01 GB to write 94 MB in 168 us, behind 54 us of tr_rank. plan_scatter_tr turns it round: a thread owns a POSITION of
+// the row-grouped list, looks up where its row's piece lies (vinfo: first slot and slice length per virtual row, written
+// by plan_bases) and stores one record and one index. The stores of one row are 1 KB apart, but the eight rows that share
+// a 128-byte line are rows of one window of SELL_SIGMA points, i.e. of one run of positions: with the workgroups in
+// XCD-contiguous order every line fills up inside ONE L2. RANK = true is the last phase of the transposition itself
+// (tr_rank of conv.hip: ascending edge id inside a row) with the plan written in the same pass -- 120 us for both on the
+// room (ablations: no rank scan 94, no record gather 112, linear instead of scattered stores 92); RANK = false starts from
+// a finished perm_t.
+// Padding: the thread that owns the LAST edge of a virtual row fills the row's remaining slots of its slice (zero
+// records, its own index: a line the sweep has just used); virtual rows without any edge and the padding lanes behind the
+// last row are filled by plan_bases (index 0).
+// (Measured and dropped for the FORWARD plan: the same scatter with threads in edge order -- 189 us against 30 + 89 us:
+// centres are listed in the caller's order, the windows in the cell-coherent visiting order, so the eight rows of a line
+// are far apart in edge order. The forward plan takes plan_fill_tiles below. And for the transposed plan: tr_rank +
+// plan_fill_tiles over perm_t, 54 + 118 us.)
+__device__ __forceinline__ int row_len(const int* __restrict__ rowStart, int rows, int e, int r) {
+    return ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
+}
+__global__ __launch_bounds__(256) void plan_bases(RowPlan p, const int* __restrict__ rowStart, int rows, int e, int L, long long cap,
+                                                  int2* __restrict__ vinfo, float4* __restrict__ rec, int* __restrict__ oth) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= p.S * 64) return;
+    const int slice = pos >> 6, lane = pos & 63;
+    const int off = p.sliceOff[slice];
+    int len = (p.sliceOff[slice + 1] - off) >> 6;
+    if ((long long)off + (long long)len * 64 > cap) len = 0;  // (the bound of plan_sizes makes this impossible)
+    const int r = p.vrow[pos];
+    int deg = 0;
+    if (r >= 0) {
+        const int code = p.vcode[pos];
+        const int vid = code < 0 ? ~code : code;
+        vinfo[vid] = make_int2(off + lane, len);
+        deg = max(0, min(L, row_len(rowStart, rows, e, r) - (vid - p.vposRow[r]) * L));
+    }
+    if (deg == 0) {
+        for (int it = 0; it < len; ++it) {
+            const size_t slot = (size_t)off + (size_t)it * 64 + lane;
+            rec[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            oth[slot] = 0;
+        }
+    }
+}
+// the slot of edge #r of row `row` (deg edges), and the padding behind the row's last edge
+__device__ __forceinline__ void plan_put(int row, int r, int deg, int L, const int* __restrict__ vposRow,
+                                         const int2* __restrict__ vinfo, float4* __restrict__ rec, int* __restrict__ oth,
+                                         const float4& rc, int other) {
+    const int pc = r / L, it = r - pc * L;
+    const int2 vi = vinfo[vposRow[row] + pc];
+    const int plen = min(L, deg - pc * L);
+    if (it >= vi.y) return;  // (only a layout cut off by its capacity)
+    const size_t slot = (size_t)vi.x + (size_t)it * 64;
+    rec[slot] = rc;
+    oth[slot] = other;
+    if (it == plen - 1) {
+        for (int k = plen; k < vi.y; ++k) {
+            const size_t sp = (size_t)vi.x + (size_t)k * 64;
+            rec[sp] = make_float4(0.f, 0.f, 0.f, 0.f);
+            oth[sp] = other;
+        }
+    }
+}
+template <bool RANK>
+__global__ __launch_bounds__(256) void plan_scatter_tr(const float4* __restrict__ recE, const int2* __restrict__ packed, int e, int n,
+                                                       const int* __restrict__ startT, const int* __restrict__ tmp,
+                                                       int* __restrict__ permT, const int* __restrict__ vposRow,
+                                                       const int2* __restrict__ vinfo, int L, float4* __restrict__ rec,
+                                                       int* __restrict__ oth) {
+    const int p = xcd_contiguous(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    if (p >= e) return;
+    const int v = RANK ? tmp[p] : permT[p];
+    const int2 pr = packed[v];
+    const int j = max(0, min(pr.x, n - 1));
+    const int s0 = startT[j], s1 = startT[j + 1];
+    int r = p - s0;
+    if (RANK) {  // stable order inside a row: ascending edge id (see tr_rank)
+        r = 0;
+        int q = s0;
+        for (; q + 4 <= s1; q += 4) {
+            const int a0 = tmp[q], a1 = tmp[q + 1], a2 = tmp[q + 2], a3 = tmp[q + 3];
+            r += (a0 < v) + (a1 < v) + (a2 < v) + (a3 < v);
+        }
+        for (; q < s1; ++q) r += (tmp[q] < v) ? 1 : 0;
+        permT[s0 + r] = v;
+    }
+    plan_put(j, r, s1 - s0, L, vposRow, vinfo, rec, oth, recE[v], pr.y);
+}
+
+// ------------------------------------------------------------------------------------------------ tile fill (forward plan)
+// The permutation of sell_fill with BOTH sides coalesced: a workgroup owns (slice, 16 iterations) as in sell_fill, but reads the
+// tile row by row -- 16 consecutive lanes take 16 consecutive edges of one row (128 contiguous bytes of pairs; the record
+// is evaluated on the spot, EVAL, and its edge-order copy written as 256 contiguous bytes, or read from the edge-order
+// array) -- parks it in LDS and writes it out iteration by iteration: 1 KB per wave store.
+// LDS tile [it][row] with a row stride of 65 float4: the 8 lanes one ds_write_b128 group serves hold 8 iterations of a
+// row = 8 x 4 distinct banks.
+template <bool EVAL>
+__global__ __launch_bounds__(256) void plan_fill_tiles(ConvArgs a, const float4* __restrict__ recIn, float4* __restrict__ recOut,
+                                                       const int* __restrict__ rowStart, int rows, RowPlan p, long long cap, float4* __restrict__ rec, int* __restrict__ oth,
+                                                       int L) {
+    __shared__ float4 tRec[MCCNN_FILL_CHUNK][65];
+    __shared__ int tOth[MCCNN_FILL_CHUNK][65];
+    // workgroups in XCD-contiguous order, the chunks of a slice side by side: the slices of a window -- rows of one region of
+    // space, whose gathered lines they share -- stay on one XCD
+    const int chunks = (L + MCCNN_FILL_CHUNK - 1) / MCCNN_FILL_CHUNK;
+    const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int slice = lin / chunks;
+    if (slice >= p.S) return;
+    const int off = p.sliceOff[slice];
+    const int len = (p.sliceOff[slice + 1] - off) >> 6;
+    const int it0 = (lin - slice * chunks) * MCCNN_FILL_CHUNK;
+    if (it0 >= len || (long long)off + (long long)len * 64 > cap) return;
+    const int e = a.e;
+    const int itl = threadIdx.x & 15, it = it0 + itl;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int rl = pass * 16 + (threadIdx.x >> 4);
+        const int r = p.vrow[slice * 64 + rl];
+        int base = 0, deg = 0;
+        if (r >= 0) {
+            const int code = p.vcode[slice * 64 + rl];
+            const int piece = (code < 0 ? ~code : code) - p.vposRow[r];
+            const int rb = rowStart[r];
+            const int rdeg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rb;
+            base = rb + piece * L;
+            deg = max(0, min(L, rdeg - piece * L));
+        }
+        float4 rc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int other = 0;
+        if (deg > 0) {
+            const bool real = it < deg;
+            const int t = min(base + (real ? it : 0), e - 1);  // padding slots: the row's first neighbour (valid, cached)
+            const int eid = t;
+            const int2 pr = a.packed[eid];
+            other = pr.x;
+            if (real) {
+                if (EVAL) {
+                    rc = edge_record(a, eid);
+                    if (recOut) recOut[eid] = rc;
+                } else {
+                    rc = recIn[eid];
+                }
+            }
+        }
+        tRec[itl][rl] = rc;
+        tOth[itl][rl] = other;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MCCNN_FILL_CHUNK / 4; ++k) {
+        const int il = k * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (it0 + il < len) {
+            const size_t slot = (size_t)off + (size_t)(it0 + il) * 64 + lane;
+            rec[slot] = tRec[il][lane];
+            oth[slot] = tOth[il][lane];
+        }
+    }
+}
+
 // The pieces of cut rows left their sums in scratch rows (one per virtual row id, `cols` 32-bit words wide -- f32 rows,
 // or bf16 rows whose pieces are kept in f32): out[r] = sum over the row's pieces, in order. One wave per 64 rows; cut rows
 // are rare (none at all on a list whose rows hold <= ROWS_L edges), a wave without one returns after two loads.
@@ -985,23 +1145,115 @@ int mccnn_rowplan_bound(int rows, int e_cap, int transposed, long long* buffer_b
         o += plan_al((size_t)(slots > 0 ? slots : 1)) + plan_al((size_t)(slots > 0 ? slots : 1) * 4);
         if (o * 4 > buf) buf = o * 4;
         const size_t w = align_up((size_t)(rows + 1) * sizeof(int)) * 2 + align_up((size_t)vcap * sizeof(int)) +
-                         align_up((size_t)S * sizeof(int)) + scan_workspace_bytes(rows > 0 ? rows : 1) + scan_workspace_bytes((int)S) + 512;
+                         align_up((size_t)S * sizeof(int)) + scan_workspace_bytes(rows > 0 ? rows : 1) + scan_workspace_bytes((int)S) + 512 +
+                         align_up((size_t)vcap * sizeof(int2));
         if (w > ws) ws = w;
     }
-    if (transposed) {
-        const size_t t = mccnn_transpose_neighbors_workspace_bytes(rows, e_cap);
-        if (t > ws) ws = t;
-    }
+    if (transposed) ws += mccnn_transpose_neighbors_workspace_bytes(rows, e_cap);  // (see build_ws_bytes)
     *buffer_bytes = (long long)buf;
     *ws_bytes = (long long)ws;
     return 0;
 }
 
-size_t mccnn_rowplan_build_workspace_bytes(int rows, int e, int transposed) {
-    size_t a = mccnn_rowplan_workspace_bytes(rows, e);
-    size_t b = transposed ? mccnn_transpose_neighbors_workspace_bytes(rows, e) : 0;
-    return a > b ? a : b;
+// Workspace of a plan build. Small plans: the layout and the transposition run one after the other over the same bytes.
+// Large plans: [layout | vinfo (8 bytes per virtual row) | transposition] -- the layout sits between the two halves of
+// the transposition (it needs the row lengths only), so everything is alive at once.
+static size_t build_ws_bytes(int rows, int e, int transposed, const PlanSizes& z) {
+    const size_t a = mccnn_rowplan_workspace_bytes(rows, e);
+    const size_t b = transposed ? mccnn_transpose_neighbors_workspace_bytes(rows, e) : 0;
+    if (z.small || rows <= 0 || e <= 0) return a > b ? a : b;
+    return a + align_up((size_t)z.vcap * sizeof(int2)) + b;
 }
+size_t mccnn_rowplan_build_workspace_bytes(int rows, int e, int transposed) {
+    return build_ws_bytes(rows, e, transposed, plan_sizes(rows > 0 ? rows : 0, e > 0 ? e : 0));
+}
+
+}  // extern "C"
+
+namespace mccnn {
+bool transpose_small(int e, int n);
+size_t transpose_count_bytes(int n);
+int transpose_count(const int2* pk, int e, int n, int* start_t, char* blk, int* slot, hipStream_t s);
+int transpose_fill(const int2* pk, int e, const int* start_t, const int* slot, int* tmp, hipStream_t s);
+}
+// A large plan: layout, then ONE scattering pass in the order its source is read (see plan_scatter_*). For a transposed
+// plan whose list does not exist yet the transposition is part of the build: count -> layout -> fill -> rank + scatter.
+static int build_large(int transposed, const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs, const float* samples,
+                       const int* start_idx, const int* packed, const float* aabb_min, const float* aabb_max, int n, int m, int e,
+                       int batch_size, float radius, int scale_inv, int avg, const int* order, void* rec_edges, int rec_ready,
+                       int* start_t, int* perm_t, int tlist_ready, void* plan_buffer, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int rows = transposed ? n : m;
+    if (!rec_edges || batch_size <= 0 || !(radius > 0.0f) || !sorted_pts || !sorted_batch_ids || !pdfs || !samples || !start_idx ||
+        !packed || !aabb_min || !aabb_max)
+        return MCCNN_E_BADARG;
+    long long off[6], total, cap, srows;
+    int S;
+    int rc = mccnn_rowplan_buffer(rows, e, off, &total, &S, &cap, &srows);
+    if (rc) return rc;
+    char* base = reinterpret_cast<char*>(plan_buffer);
+    int* vrow = reinterpret_cast<int*>(base + off[0]);
+    int* vcode = reinterpret_cast<int*>(base + off[1]);
+    int* sliceOff = reinterpret_cast<int*>(base + off[2]);
+    int* vposRow = reinterpret_cast<int*>(base + off[3]);
+    int* other = reinterpret_cast<int*>(base + off[4]);
+    float4* rec = reinterpret_cast<float4*>(base + off[5]);
+    const PlanSizes z = plan_sizes(rows, e);
+    const size_t lay = mccnn_rowplan_workspace_bytes(rows, e);
+    Arena ar(ws, ws_bytes);
+    char* layWs = ar.take<char>(lay);
+    int2* vinfo = ar.take<int2>((size_t)z.vcap);
+    if (!layWs || !vinfo) return MCCNN_E_WORKSPACE;
+    ConvArgs a = {};
+    a.pts = sorted_pts; a.bids = sorted_batch_ids; a.pdfs = pdfs; a.samples = samples; a.start = start_idx;
+    a.packed = reinterpret_cast<const int2*>(packed); a.mn = aabb_min; a.mx = aabb_max;
+    a.n = n; a.m = m; a.e = e; a.radius = radius; a.invRadius = 1.0f / radius; a.scaleInv = scale_inv; a.avg = avg;
+    a.B = batch_size;
+    RowPlan p = {vrow, vcode, sliceOff, vposRow, nullptr, nullptr, rows, z.S};
+    const int eb = ceil_div(e, 256);
+    float4* recE = reinterpret_cast<float4*>(rec_edges);
+    if (!transposed) {
+        rc = mccnn_rowplan_layout(start_idx, rows, e, order, vrow, vcode, sliceOff, vposRow, layWs, lay, s);
+        if (rc) return rc;
+        const int grid = z.S * ceil_div(z.L, MCCNN_FILL_CHUNK);
+        if (rec_ready) plan_fill_tiles<false><<<grid, 256, 0, s>>>(a, recE, nullptr, start_idx, rows, p, z.slots, rec, other, z.L);
+        else plan_fill_tiles<true><<<grid, 256, 0, s>>>(a, nullptr, recE, start_idx, rows, p, z.slots, rec, other, z.L);
+        MCCNN_LAUNCHED();
+        return 0;
+    }
+    int *slot = nullptr, *tmp = nullptr;
+    const bool fused = !tlist_ready && !transpose_small(e, n);
+    if (fused) {
+        char* blk = ar.take<char>(transpose_count_bytes(n));
+        slot = ar.take<int>((size_t)e);
+        tmp = ar.take<int>((size_t)e);
+        if (!blk || !slot || !tmp) return MCCNN_E_WORKSPACE;
+        rc = transpose_count(a.packed, e, n, start_t, blk, slot, s);
+        if (rc) return rc;
+    } else if (!tlist_ready) {
+        char* tws = ar.take<char>(mccnn_transpose_neighbors_workspace_bytes(n, e));
+        if (!tws) return MCCNN_E_WORKSPACE;
+        rc = mccnn_transpose_neighbors(packed, e, n, start_t, perm_t, tws, mccnn_transpose_neighbors_workspace_bytes(n, e), s);
+        if (rc) return rc;
+    }
+    rc = mccnn_rowplan_layout(start_t, rows, e, nullptr, vrow, vcode, sliceOff, vposRow, layWs, lay, s);
+    if (rc) return rc;
+    if (fused) {
+        rc = transpose_fill(a.packed, e, start_t, slot, tmp, s);
+        if (rc) return rc;
+    }
+    plan_bases<<<ceil_div((long long)z.S * 64, 256), 256, 0, s>>>(p, start_t, rows, e, z.L, z.slots, vinfo, rec, other);
+    MCCNN_LAUNCHED();
+    if (!rec_ready) {
+        rc = launch_edge_records(a, recE, s);
+        if (rc) return rc;
+    }
+    if (fused) plan_scatter_tr<true><<<eb, 256, 0, s>>>(recE, a.packed, e, n, start_t, tmp, perm_t, vposRow, vinfo, z.L, rec, other);
+    else plan_scatter_tr<false><<<eb, 256, 0, s>>>(recE, a.packed, e, n, start_t, nullptr, perm_t, vposRow, vinfo, z.L, rec, other);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+extern "C" {
 
 int mccnn_rowplan_build(int transposed, const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs,
                         const float* samples, const int* start_idx, const int* packed, const float* aabb_min,
@@ -1014,6 +1266,10 @@ int mccnn_rowplan_build(int transposed, const float* sorted_pts, const int* sort
     if (!inl && !rec_edges) return MCCNN_E_BADARG;
     if (transposed && (!start_t || !perm_t)) return MCCNN_E_BADARG;
     if (!ws || ws_bytes < mccnn_rowplan_build_workspace_bytes(rows, e, transposed)) return MCCNN_E_WORKSPACE;
+    if (rows > 0 && e > 0 && !plan_sizes(rows, e).small)
+        return build_large(transposed, sorted_pts, sorted_batch_ids, pdfs, samples, start_idx, packed, aabb_min, aabb_max, n, m, e,
+                           batch_size, radius, scale_inv, avg, order, rec_edges, rec_ready, start_t, perm_t, tlist_ready,
+                           plan_buffer, ws, ws_bytes, (hipStream_t)stream);
     long long off[6], total, cap, srows;
     int S;
     int rc = mccnn_rowplan_buffer(rows, e, off, &total, &S, &cap, &srows);
