@@ -133,9 +133,9 @@ class Workload:
         self.params = []
         self.pipeline = False
         self.skip_allreduce = False
-        from mccnn_amd import native as _native
+        from mccnn_amd import _env as _menv, native as _native
         self.native_prefetch = bool(self.builder.native_ and _native.side_streams_available()
-                                    and os.environ.get("MCCNN_NATIVE_PREFETCH", "1") != "0")
+                                    and _menv.debug("native_prefetch", True))
         # what the prefetch also starts for the backward pass: depth-wise layers sweep the transposed row plan. Combin layers
         # with 2..4 input features CAN gather their feature gradient through the transposed list (no float atomics,
         # bit-reproducible: MCCNN_PF_TLIST=1) -- measured on 3to8: pipelined step 0.590 -> 0.739 ms (the transposition's
@@ -1116,8 +1116,8 @@ def main():
         torch.autograd.set_multithreading_enabled(False)
 
     from mccnn_amd import build as mbuild
-    if rank == 0 and mbuild.needs_build():
-        mbuild.build()
+    if rank == 0:
+        mbuild.build()   # (no-op when the library and the extension are newer than their sources)
     if dist_on:
         dist.barrier()
 

@@ -16,6 +16,8 @@ import sys
 import time
 import torch
 
+from . import _env
+
 from .MCConvModule import (compute_aabb, sort_points_step1, sort_points_step2, sort_features, sort_features_back,
                            compute_pdf, poisson_sampling, get_sampled_features, spatial_conv, get_block_size,
                            transform_indexs, find_neighbors)
@@ -50,7 +52,8 @@ def _log(msg):
         print(msg)
 
 
-_RECORD_STREAMS = os.environ.get("MCCNN_PREFETCH_RECORD_STREAM", "0") == "1"
+_RECORD_STREAMS = _env.debug("record_stream", False)
+_GEO_TRACE = _env.debug("geo_trace", False)
 
 
 def _storage_users(t):
@@ -104,8 +107,8 @@ class _LazyEntry:
         return getattr(self.value(), name)
 
 
-_GEO_PREFETCH_MIN = int(os.environ.get("MCCNN_GEO_PREFETCH_MIN", "5"))
-_PLAN_PREFETCH_MAX_E = int(float(os.environ.get("MCCNN_PLAN_PREFETCH_MAX_E", "1e12")))
+_GEO_PREFETCH_MIN = _env.debug("geo_prefetch_min", 5)
+_PLAN_PREFETCH_MAX_E = _env.debug("plan_prefetch_max_e", 10 ** 12)
 
 
 class _PrefetchedHierarchy:
@@ -296,10 +299,10 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         self.ops_ = _Ops(ops)
         # extension: grids from the points alone (MCConvModule.build_grid), feature rows sorted inside the convolution's
         # node (spatial_conv(sortIndex=)) -- fewer op calls and graph nodes per convolution, same kernels and results
-        self.fuseSort_ = (os.environ.get("MCCNN_FUSE_SORT", "1") != "0") if fuseSort is None else bool(fuseSort)
+        self.fuseSort_ = _env.debug("fuse_sort", True) if fuseSort is None else bool(fuseSort)
         # extension: the whole geometry of a convolution (grid, search, KDE) in one library call and the layer itself in
         # one per direction (mccnn_amd.native, csrc/exec.hip) -- a step is bound by the host's work per launch
-        self.native_ = (os.environ.get("MCCNN_NATIVE", "1") != "0") if native is None else bool(native)
+        self.native_ = _env.flag("NATIVE") if native is None else bool(native)
         self.cacheGrids_ = {}
         self.cacheNeighs_ = {}
         self.cachePDFs_ = {}
@@ -309,7 +312,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         # learned prefetch (native path): the geometries a step asked for, in order; the next step builds them ALL at its
         # first create_convolution, round-robin on side streams -- they depend on the points only, their chains of small
         # kernels run side by side and under the first layers instead of one after the other between them
-        self.geoPrefetch_ = os.environ.get("MCCNN_GEO_PREFETCH", "1") != "0"
+        self.geoPrefetch_ = _env.flag("GEO_PREFETCH")
         self.geoSeen_ = {}
         self.geoPlan_ = []
         self.prefetchedGeo_ = {}    # prefetch_geometry() on the native path: keyPDF -> (Geometry, keyGrid, keyNeighs, usePDF, transposed)
@@ -649,7 +652,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         from . import MCConvModule as _hip_ops
         if not (self.native_ and self.fuseSort_ and getattr(self.ops_, "_ops", 0) is None and _native.side_streams_available()
                 and int(_hip_ops.PDF_MODE) == 1 and self.prefetched_ is None
-                and os.environ.get("MCCNN_NATIVE_PREFETCH", "1") != "0"):
+                and _env.debug("native_prefetch", True)):
             return False
         inPts, inBids = inPH.points_[inLevel], inPH.batchIds_[inLevel]
         centres, cBids = outPH.points_[outLevel], outPH.batchIds_[outLevel]
@@ -689,7 +692,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         not apply: nothing is lost, the next step builds what it needs itself)."""
         started = 0
         name, levels = pointHierarchy.hierarchyName_, len(pointHierarchy.points_)
-        pieces = os.environ.get("MCCNN_PLAN_PREFETCH", "1") != "0"
+        pieces = _env.debug("plan_prefetch", True)
         for ent in self.geoPlan_:
             hname, inLevel, outLevel, radius, window, rel, usePDF, have = ent[:8]
             if hname != name or inLevel >= levels or outLevel >= levels:
@@ -734,7 +737,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         if int(_hip_ops.PDF_MODE) != 1:
             return
         k = 0
-        pieces = os.environ.get("MCCNN_PLAN_PREFETCH", "1") != "0"
+        pieces = _env.debug("plan_prefetch", True)
         for (hname, inLevel, outLevel, radius, window, rel, usePDF, have, _key) in plan:
             if hname != name or inLevel >= levels or outLevel >= levels:
                 continue
@@ -797,7 +800,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                     (a[2] is cen or (a[2].data_ptr() == cen.data_ptr() and a[2].shape == cen.shape)):
                 geo.unverified = False
             else:
-                if os.environ.get("MCCNN_DEBUG_GEO"):
+                if _GEO_TRACE:
                     print("native conv %s: parked geometry %s not for this hierarchy (built from %s / %s, asked %s / %s)" % (
                         convName, keyPDF, tuple(a[0].shape), tuple(a[2].shape), tuple(pin.shape), tuple(cen.shape)), file=sys.stderr)
                 self.cacheGeo_.pop(keyPDF, None)
@@ -809,11 +812,11 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                 geo = None
         if geo is None:
             if keyGrid in self.cacheGrids_ and keyGrid not in self.cacheGeoGrid_:
-                if os.environ.get("MCCNN_DEBUG_GEO"):
+                if _GEO_TRACE:
                     print("native conv %s: grid %s owned by the op path" % (convName, keyGrid), file=sys.stderr)
                 return None   # the op-by-op path (or a prefetch) owns this grid
             if keyNeighs in self.cacheNeighs_ or keyPDF in self.cachePDFs_:
-                if os.environ.get("MCCNN_DEBUG_GEO"):
+                if _GEO_TRACE:
                     print("native conv %s: list %s / pdf %s cached without a geometry (%s %s); geometries: %s" % (
                         convName, keyNeighs, keyPDF, keyNeighs in self.cacheNeighs_, keyPDF in self.cachePDFs_,
                         sorted(self.cacheGeo_)), file=sys.stderr)
@@ -856,7 +859,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         if inPH is outPH and keyPDF not in self.geoSeen_:
             self.geoSeen_[keyPDF] = (inPH.hierarchyName_, inLevel, outLevel, convRadius, KDEWindow, relativeRadius, usePDF)
         feats = inFeatures
-        if os.environ.get("MCCNN_DEBUG_GEO") and feats.dim() == 2 and feats.shape[0] != geo.n:
+        if _GEO_TRACE and feats.dim() == 2 and feats.shape[0] != geo.n:
             print("native conv %s: %d feature rows for a geometry over %d points (key %s, unverified %s, built from %s, level has %s)" % (
                 convName, feats.shape[0], geo.n, keyPDF, getattr(geo, "unverified", None), tuple(geo.args[0].shape),
                 tuple(inPH.points_[inLevel].shape)), file=sys.stderr)

@@ -18,7 +18,7 @@ import weakref
 import numpy as _np
 import torch
 
-from . import _lib
+from . import _env, _lib
 from ._lib import check, ptr, stream_handle
 
 
@@ -172,7 +172,7 @@ def _remember_edges(gkey, e):
     if gkey[1] > 0:
         _EDGE_RATIO[(gkey[0], gkey[3], gkey[5])] = e / float(gkey[1])
 _TLS = threading.local()
-_MAILBOX_COPY = os.environ.get("MCCNN_MAILBOX_COPY", "0") == "1"
+_MAILBOX_COPY = _env.debug("mailbox_copy", False)
 
 
 def _pinned_int():
@@ -198,7 +198,7 @@ def _host_mailbox():
 
 # find_neighbors: True = the count kernel stores the edge total into the pinned mailbox and the host polls it;
 # False = total in device memory + an asynchronous copy + an event wait
-COUNT_MAILBOX = os.environ.get("MCCNN_COUNT_MAILBOX", "1") != "0"
+COUNT_MAILBOX = _env.debug("count_mailbox", True)
 _MAILBOX_SPIN_S = 200e-6  # tight polling for this long (the producing kernel retires within tens of microseconds) ...
 _MAILBOX_YIELD_S = 0.25   # ... then polling that hands the GIL to other threads between reads, then a synchronisation
 
@@ -283,7 +283,7 @@ def _transposed_neighbors(packed, n):
         ev = getattr(packed, "_mccnn_transposed_event", None)
         if ev is not None:  # built ahead of time on another stream (prefetch_transposed): order this stream behind it
             torch.cuda.current_stream().wait_event(ev)
-            if os.environ.get("MCCNN_PREFETCH_RECORD_STREAM", "0") == "1":
+            if _env.debug("record_stream", False):
                 for t in hit[:2]:
                     t.record_stream(torch.cuda.current_stream())
             # the event stays with the list: a later consumer on another stream has to wait for it, too (waiting for an
@@ -306,10 +306,10 @@ def _transposed_neighbors(packed, n):
 
 #: depth-wise layers (numFeatures % 8 == 0) run the row-per-lane kernels over SELL layouts of the neighbour list
 #: (conv_rows.hip); False = the edge-streaming kernels of conv.hip for every layer
-ROW_KERNELS = os.environ.get("MCCNN_ROW_KERNELS", "1") != "0"
-ROWS_MIN_DEGREE = float(os.environ.get("MCCNN_ROWS_MIN_DEGREE", "16"))
+ROW_KERNELS = _env.flag("ROW_KERNELS")
+ROWS_MIN_DEGREE = _env.debug("rows_min_degree", 16.0)
 #: levels of up to this many points: the row kernels read the feature rows of the UNSORTED points in place (featIndex)
-UNSORTED_MAX_POINTS = int(os.environ.get("MCCNN_UNSORTED_MAX_POINTS", "32768"))
+UNSORTED_MAX_POINTS = _env.debug("unsorted_max_points", 32768)
 
 
 class RowPlan:
@@ -763,7 +763,7 @@ def find_neighbors(inPts, inBatchIds, inPts2, cellIndexs, aabbMin, aabbMax, radi
     n2 = p2.shape[0]
     ws = _ws(lib.mccnn_find_neighbors_workspace_bytes(m, n2), c.device)
     order = _order_hint(inPts)
-    if order is not None and order.shape[0] != m:
+    if order is not None and (order.shape[0] != m or _env.debug("nw_no_order", False)):
         order = None
     args = (ptr(c), ptr(cb), m, ptr(p2), n2, ptr(cells), ptr(mn), ptr(mx), batchSize, nc, float(radius),
             int(bool(scaleInv)), ptr(order))
@@ -912,7 +912,7 @@ def find_neighbors_pdf_deferred(inPts, inBatchIds, sortedPts, sortedBatchIds, ce
     total_dev = torch.empty(1, dtype=torch.int32, device=c.device)
     ws = _ws(lib.mccnn_find_neighbors_workspace_bytes(m, n2), c.device)
     order = _order_hint(inPts)
-    if order is not None and order.shape[0] != m:
+    if order is not None and (order.shape[0] != m or _env.debug("nw_no_order", False)):
         order = None
     args = (ptr(c), ptr(cb), m, ptr(p2), n2, ptr(cells), ptr(mn), ptr(mx), batchSize, nc, float(radius),
             int(bool(scaleInv)), ptr(order))
@@ -1016,7 +1016,7 @@ def point_hierarchy_prefetch(inPts, inBatchIds, radiusList, batchSize, scaleInv)
     _req(batchSize > 0, op + " expects a positive batch size")
     for radius in radiusList:
         _req(radius > 0.0, op + " expects positive radii")
-    pmode = 2 if POISSON_DATAFLOW == 2 else int(os.environ.get("MCCNN_HIER_PREFETCH_PMODE", "1"))
+    pmode = 2 if POISSON_DATAFLOW == 2 else _env.debug("hier_pmode", 1)
     return ext.hierarchy_prefetch(pts, bids, [float(r) for r in radiusList], int(batchSize), bool(scaleInv), pmode)
 
 

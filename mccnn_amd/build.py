@@ -14,7 +14,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, os.environ.get("MCCNN_LIB_NAME", "libmccnn_hip.so"))  # override only for A/B experiments
 SOURCES = ["api_misc.hip", "scan.hip", "grid.hip", "neighbors.hip", "poisson.hip", "conv.hip", "conv_f1.hip", "conv_rows.hip", "exec.hip"]
-HEADERS = ["common.h", "conv_mfma.h"]
+HEADERS = ["common.h", "conv_mfma.h", "debug_opts.h"]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # bit-exact geometry: no FMA contraction, correctly rounded f32 divide / sqrt (see csrc/common.h)
@@ -33,7 +33,7 @@ def torch_ext_needs_build():
     if not os.path.exists(TORCH_EXT):
         return True
     t = os.path.getmtime(TORCH_EXT)
-    return any(os.path.getmtime(d) > t for d in (TORCH_EXT_SRC, os.path.join(ROOT, "include", "mccnn.h")))
+    return any(os.path.getmtime(d) > t for d in (TORCH_EXT_SRC, os.path.join(ROOT, "include", "mccnn.h"), os.path.join(CSRC, "debug_opts.h")))
 
 
 def build_torch_ext(force=False, verbose=False):
@@ -45,7 +45,7 @@ def build_torch_ext(force=False, verbose=False):
     import torch
     from torch.utils import cpp_extension as ce
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
-    inc = ce.include_paths() + [sysconfig.get_paths()["include"], "/opt/rocm/include", os.path.join(ROOT, "include")]
+    inc = ce.include_paths() + [sysconfig.get_paths()["include"], "/opt/rocm/include", os.path.join(ROOT, "include"), CSRC]
     cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
     cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-deprecated-declarations", TORCH_EXT_SRC, "-o", TORCH_EXT + ".tmp",
            "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_mccnn_torch",
@@ -72,15 +72,32 @@ def sources():
 
 
 def needs_build():
-    if not os.path.exists(LIB) or (os.environ.get("MCCNN_LIB_NAME") is None and torch_ext_needs_build()):
+    """The HIP library is older than one of its sources (the torch extension is checked on its own: ensure_torch_ext)."""
+    if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = sources() + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "mccnn.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def ensure_torch_ext(force=False, verbose=False):
+    """Builds lib/_mccnn_torch.so when it is missing or stale. A failure (no g++, other torch headers, ABI) is reported
+    and leaves the ctypes binding of the HIP library in charge (mccnn_amd.native falls back to it) -- it never fails the
+    build of the library itself."""
+    if os.environ.get("MCCNN_LIB_NAME") is not None:  # (A/B builds of the kernels keep the extension of the default library)
+        return None
+    if not force and not torch_ext_needs_build():
+        return TORCH_EXT
+    try:
+        return build_torch_ext(force=True, verbose=verbose)
+    except Exception as err:  # noqa: BLE001 -- anything the host toolchain can throw
+        print("mccnn_amd.build: torch extension not built (%s); mccnn_amd.native will use the ctypes binding" % err, file=sys.stderr)
+        return None
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
+        ensure_torch_ext(verbose=verbose)
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = _hipcc()
@@ -104,8 +121,7 @@ def build(force=False, verbose=False):
     for f in os.listdir(LIB_DIR):
         if f.startswith(os.path.basename(LIB) + ".") and ("hipv4-" in f or ".host-" in f):
             os.remove(os.path.join(LIB_DIR, f))
-    if os.environ.get("MCCNN_LIB_NAME") is None:  # (A/B builds of the kernels keep the extension of the default library)
-        build_torch_ext(force=True, verbose=verbose)
+    ensure_torch_ext(force=True, verbose=verbose)
     return LIB
 
 

@@ -5,8 +5,8 @@
 namespace mccnn {
 std::atomic<long long> g_launches{0};
 thread_local int g_background = 0;
-std::atomic<int> g_small_off{getenv("MCCNN_SMALL_OFF") ? 1 : 0};
-std::atomic<int> g_f1_x4_min_edges{getenv("MCCNN_F1_X4_MIN_E") ? atoi(getenv("MCCNN_F1_X4_MIN_E")) : 2000000};
+std::atomic<int> g_small_off{debug_int("small_off", 0) ? 1 : 0};
+std::atomic<int> g_f1_x4_min_edges{debug_int("f1_x4_min_e", 2000000)};
 }
 
 extern "C" {

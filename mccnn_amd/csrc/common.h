@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cstdint>
 #include "mccnn.h"
+#include "debug_opts.h"
 
 #define MCCNN_MLP 8        // BLOCK_MLP_SIZE (genCompileScript.py:20)
 #define MCCNN_WAVE 64      // CDNA wavefront

@@ -1038,7 +1038,7 @@ int conv_fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_fea
 }
 
 std::atomic<int>& conv_impl_override() {
-    static std::atomic<int> v{(getenv("MCCNN_FORCE_VALU") ? 1 : 0) | (getenv("MCCNN_NO_F1") ? 2 : 0)};
+    static std::atomic<int> v{(debug_int("force_valu", 0) ? 1 : 0) | (debug_int("no_f1", 0) ? 2 : 0)};
     return v;
 }
 

@@ -791,7 +791,7 @@ static int f1_run_edges(const ConvArgs& a, float* A, float* S, float4* recOut, h
         const size_t lds4 = lds + 4 * 256 * sizeof(float4);  // + the record stage of the four waves
         const int perCU4 = cached_blocks_per_cu(reinterpret_cast<const void*>(f1_fwd_edges4), lds4);
         const long long iters = ((long long)a.e + 255) / 256;
-        static const int wpc = getenv("MCCNN_F1_X4_WAVES_PER_CU") ? atoi(getenv("MCCNN_F1_X4_WAVES_PER_CU")) : 0;
+        static const int wpc = debug_int("f1_x4_waves_per_cu", 0);
         long long W4 = (long long)num_cus() * (wpc > 0 ? wpc : perCU4 * 4);
         if (W4 > (iters + 1) / 2) W4 = (iters + 1) / 2;
         if (W4 < 1) W4 = 1;

@@ -57,7 +57,7 @@ static PlanSizes plan_sizes(int rows, int e) {
     // 64 k virtual rows (1 k slices) when the edges allow it, pieces of 16 .. 128 edges. Large lists keep 128: a row
     // of the usual 30 - 100 edges then stays in one piece.
     z.L = ROWS_L;
-    static const int minL = getenv("MCCNN_PLAN_MIN_L") ? atoi(getenv("MCCNN_PLAN_MIN_L")) : 4;  // A/B switch, read once
+    static const int minL = debug_int("plan_min_l", 4);  // A/B switch, read once
     if (rows <= 3072 && minL < 16) {
         // the coarse levels of a hierarchy: the chip is empty, every iteration of a lane is exposed latency -- pieces as
         // short as the single-workgroup layout (MCCNN_PLAN_SMALL virtual rows) allows
@@ -77,7 +77,7 @@ static PlanSizes plan_sizes(int rows, int e) {
     // Small lists (the coarse levels of a hierarchy: a few hundred rows) are launch-bound: six launches of layout, 25 us
     // of it a bitonic sort whose only purpose is less padding. One workgroup does the whole layout for them, in row
     // order; unsorted, a slice holds at most 64 L slots.
-    static const bool allowSmall = !(getenv("MCCNN_PLAN_SMALL_OFF"));  // A/B switch, read once
+    static const bool allowSmall = !debug_int("plan_small_off", 0);  // A/B switch, read once
     z.small = allowSmall && rows <= MCCNN_PLAN_SMALL && z.vcap <= MCCNN_PLAN_SMALL;
     if (z.small) z.slots = (long long)z.L * (z.vcap + 64);
     return z;

@@ -130,15 +130,15 @@ bool env_flag(const char* name, bool dflt) {
     return v ? (strcmp(v, "0") != 0) : dflt;
 }
 bool row_kernels_on() { static const bool on = env_flag("MCCNN_ROW_KERNELS", true); return on; }
-float rows_min_degree() { static const float d = getenv("MCCNN_ROWS_MIN_DEGREE") ? (float)atof(getenv("MCCNN_ROWS_MIN_DEGREE")) : 16.f; return d; }
-int unsorted_max_points() { static const int v = getenv("MCCNN_UNSORTED_MAX_POINTS") ? atoi(getenv("MCCNN_UNSORTED_MAX_POINTS")) : 32768; return v; }
+float rows_min_degree() { static const float d = (float)debug_float("rows_min_degree", 16.0); return d; }
+int unsorted_max_points() { static const int v = debug_int("unsorted_max_points", 32768); return v; }
 
 // Row-per-lane kernels for this (layer, list, direction)? The measured rule of the Python op surface
 // (MCConvModule._rows_shape): every list of <= 500 k edges; forward of larger lists unless the layer is narrow and the
 // gathered rows miss the L2s; backward of larger lists only for wide layers with long rows.
 bool rows_shape(bool combin, int fin, const void* feats, int rows, int n_points, int e, bool backward) {
     if (!row_kernels_on() || read_mask() != 0 || combin || fin % 8 != 0 || e <= 0 || rows <= 0 || (((uintptr_t)feats) & 15)) return false;
-    static const int force = getenv("MCCNN_ROWS_FORCE") ? atoi(getenv("MCCNN_ROWS_FORCE")) : 0;  // A/B: 1 = rows wherever they apply
+    static const int force = debug_int("rows_force", 0);  // A/B: 1 = rows wherever they apply
     if (force == 1) return true;
     if (e <= 500000) return true;
     if (!backward) return !(fin <= 128 && n_points >= 65536);
@@ -480,10 +480,10 @@ static int requirements(mccnn_geometry* g, const Shape& s, const void* feats, in
             mask |= NEED_RECORDS;
             r.need_bytes[3] = (long long)al((size_t)e * 16);
         }
-        if (!(p.built && p.buf)) {
-            const size_t b = mccnn_rowplan_build_workspace_bytes(rows, e, tr);
-            if (b > ws) ws = b;
-        }
+        // (budgeted even when a plan exists: a layer with another `avg` flag rebuilds it -- ensure_plan -- and the flag is
+        // not known here; the caller's scratch only ever grows, so this costs one allocation per process)
+        const size_t b = mccnn_rowplan_build_workspace_bytes(rows, e, tr);
+        if (b > ws) ws = b;
         return 0;
     };
     auto want_tlist = [&]() {
@@ -516,6 +516,12 @@ static int requirements(mccnn_geometry* g, const Shape& s, const void* feats, in
             want_tlist();
             const size_t w = al(mccnn_spatial_conv_bwd_rows_workspace_bytes(n, e, s.fin)) + al((size_t)g->plan[1].scratch_rows * s.fin * 4);
             ws = max3(ws, w + fg_sorted, 256);
+            // mccnn_conv_backward leaves the row kernels when the out-gradient it is handed is not 16-byte aligned (the
+            // pointer is not known here): the scratch covers the streaming path of the same layer as well
+            const size_t w2 = al(mccnn_spatial_conv_bwd_workspace_bytes(n, m, e, s.fin, s.fout, s.combin));
+            const size_t tb = e > 0 ? al(mccnn_transpose_neighbors_workspace_bytes(n, e)) : 0;
+            const size_t full = al((size_t)n * s.fin * s.elem);
+            ws = max3(ws, (w2 > tb ? w2 : tb) + full + (f.unsorted ? full : 0), 256);
         } else {
             if (f.unsorted) sort_again = al((size_t)n * s.fin * s.elem);  // (an out-gradient the row kernel cannot take)
             size_t tb = 0;

@@ -181,6 +181,12 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                         run += __builtin_popcountll(bm);
                     }
                 }
+                // (Round 5, measured and dropped -- 8 rooms, fill pass 167-170 us: the hits of a centre gathered in LDS and
+                // written with ONE store per centre instead of one per round, double-buffered: 170 us, the pass is not bound
+                // by store issue; on top of it the ballots of all centres of a wave loaded up front with coalesced vector
+                // loads instead of a scalar load per centre: 162 us, but 30.6 instead of 28.1 us on one room; the pass with
+                // the centres in index order, so that every 128-byte line of `packed` has one writer: 288 us -- without
+                // the cell-coherent order every centre pays for its own window table, far more than the partial lines cost.)
                 // (Measured and dropped: the cell of a flat position from a bit plane of cell ends -- ds_or per non-empty
                 // cell, a population count and one v_mbcnt per round instead of the 5-step binary search: the plane's set-up
                 // per window (two more wave barriers, an LDS atomic, a scan) eats what the searches cost, -1 % on one box.
@@ -774,17 +780,17 @@ static float sqrt_threshold_host(float R) {
 // pass of the headline layer got shorter (four edges per lane) and the background scans went to the two-launch form: 20 / 24 /
 // 28 / 32 / 36 KB read 0.605-0.634 / 0.597 / 0.599-0.614 / 0.604 / 0.605 ms per pipelined step -> 24 KB.
 static size_t neigh_lds_pad() {
-    static const int forced = getenv("MCCNN_NW_LDS_PAD") ? atoi(getenv("MCCNN_NW_LDS_PAD")) : -1;
+    static const int forced = debug_int("nw_lds_pad", -1);
     if (forced >= 0) return (size_t)forced;
     return g_background ? 24000 : 0;
 }
 static bool neigh_lean() {
-    static const int forced = getenv("MCCNN_NW_LEAN") ? atoi(getenv("MCCNN_NW_LEAN")) : -1;  // A/B switch, read once
+    static const int forced = debug_int("nw_lean", -1);  // A/B switch, read once
     if (forced >= 0) return forced != 0;
     return !g_background;
 }
 static int neigh_group(int m) {
-    static const int forced = getenv("MCCNN_NW_GROUP") ? atoi(getenv("MCCNN_NW_GROUP")) : 0;  // A/B switch, read once
+    static const int forced = debug_int("nw_group", 0);  // A/B switch, read once
     if (forced >= 1 && forced <= 32) return forced;
     // centres per wave: more of them share a window's staging and the per-wave set-up (8 rooms, 800 k centres: 0.309 ms at
     // 8, 0.274 at 16, 0.269 at 24) -- as long as the launch still fills the chip (100 k centres: 0.0588 / 0.0580 / 0.0650)
@@ -877,7 +883,7 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     NeighWs w;
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    static const int forcedFill = getenv("MCCNN_NW_GROUP_FILL") ? atoi(getenv("MCCNN_NW_GROUP_FILL")) : 0;  // A/B switch
+    static const int forcedFill = debug_int("nw_group_fill", 0);  // A/B switch
     // (mask rows are indexed by visiting position: the two passes may group differently -- the compaction gains little
     // from more centres per wave: 100 k centres 0.0612 ms at 8, 0.0622 at 16; 800 k centres 0.305 at 8, 0.295 at 24)
     int G = neigh_group(m);

@@ -16,7 +16,14 @@ namespace mccnn {
 // XCD's whole L2 (buffer_wbl2 / buffer_inv), once per cell: 100 k of them made the finest level of BASELINE cfg3 take
 // 1.5 ms, every other load of the launch missing the invalidated cache. Instead the flag BYTES themselves are written
 // and read with agent-scope atomics (they go to the coherent level and nothing else is touched), the writer waits for
-// their acknowledgement (s_waitcnt vmcnt(0)) before it publishes its `done` word.
+// their acknowledgement (s_waitcnt vmcnt(0)) before it publishes its `done` word. That is the "sc1 payload -> asm
+// vmcnt(0) -> sc1 flag, sc1 loads on the reading side" hand-off of the MI355X guide's list of valid forms: every byte
+// that crosses workgroups is written and read at the coherent level, so no cache has to be written back or invalidated;
+// it is NOT a C++ release / acquire pair -- the ordering rests on the hardware executing one wave's vector-memory
+// operations to the same level in order and on the explicit wait. The formal pair (-DMCCNN_PS_RELACQ: agent-scope release
+// fence before the flag store, relaxed polls, one agent-scope acquire fence after them) gives the same samples and costs
+// 0.110 -> 0.267 ms (cfg1), 0.239 -> 1.475 ms (cfg3), 0.136 -> 0.277 ms (cfg4) per poisson_sampling call of the finest level
+// (round 5, tools/poisson_time.py); tests/test_gpu_hierarchy.py stresses the shipped form on 1.02 M cells under load.
 __device__ __forceinline__ bool sel_load(const unsigned char* sel, int j) {
     return __hip_atomic_load(sel + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
@@ -241,6 +248,9 @@ __device__ __forceinline__ void poisson_cell(const float* __restrict__ pts, cons
             if (lane == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
+#ifdef MCCNN_PS_RELACQ   // A/B build: formal release / acquire fences (see the note at the flag store below)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         // (no acquire fence: the neighbours' sel[] bytes are read with agent-scope atomic loads, see sel_load)
         return true;
     };
@@ -290,6 +300,9 @@ __device__ __forceinline__ void poisson_cell(const float* __restrict__ pts, cons
     if (kept < 0) return;  // abandoned: a wait timed out (dataflow form only)
     if (lane == 0) slotCount[poisson_slot(d, b, ph, gx, gy, gz)] = kept;
     if (done) {
+#ifdef MCCNN_PS_RELACQ
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the cell's sel[] stores are acknowledged before its flag goes out
         if (lane == 0)
             __hip_atomic_store(done + cellBase + (size_t)xC * nc * nc + (size_t)yC * nc + zC, 1, __ATOMIC_RELAXED,

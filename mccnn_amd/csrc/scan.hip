@@ -187,7 +187,7 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
     // Background launches (the geometry of the next batch beside the convolution kernels of this one) take the two-launch
     // form: there the look-back's polls travel through an L2 the convolution kernels keep busy, and the 106-tile scan of
     // the room's cell table took 112 us of the side queue's chain instead of 6 (profiles/r03_pipeline_overlap.txt).
-    static const int bgTiles = getenv("MCCNN_SCAN_BG_TILES") ? atoi(getenv("MCCNN_SCAN_BG_TILES")) : 8;
+    static const int bgTiles = debug_int("scan_bg_tiles", 8);
     if (g_background && bgTiles > 0 && tiles >= bgTiles) sb = 0;
     if (sb) {  // single pass; the status words sit at the start of the workspace
         if (!status_zeroed) MCCNN_MEMSET(hipMemsetAsync(ws, 0, sb, s));

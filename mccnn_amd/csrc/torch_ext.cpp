@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "mccnn.h"
+#include "debug_opts.h"
 
 namespace {
 
@@ -91,7 +92,9 @@ Tensor& scratch(size_t bytes, const Tensor& like, void* stream) {
 // pinned words the count pass stores the edge total into (device-accessible host memory: no copy is enqueued)
 std::mutex g_slot_mutex;
 std::vector<Tensor> g_slots;
+void poll_parked();
 Tensor take_slot() {
+    poll_parked();
     {
         std::lock_guard<std::mutex> lk(g_slot_mutex);
         if (!g_slots.empty()) {
@@ -105,6 +108,36 @@ Tensor take_slot() {
 void give_slot(Tensor t) {
     std::lock_guard<std::mutex> lk(g_slot_mutex);
     if (g_slots.size() < 256) g_slots.push_back(std::move(t));
+}
+// A geometry destroyed before its edge total arrived (dropped right after being queued, or on an exception path): the count
+// pass may still WRITE the word, so the slot is neither reused nor returned to the host allocator until the build has
+// retired -- parked with an event recorded behind the build, polled whenever a slot is taken.
+hipEvent_t take_event();
+void give_event(hipEvent_t e);
+struct ParkedSlot { Tensor slot; hipEvent_t ev; };
+std::vector<ParkedSlot> g_parked;   // (under g_slot_mutex)
+void park_slot(Tensor t, hipEvent_t ev) {
+    std::lock_guard<std::mutex> lk(g_slot_mutex);
+    g_parked.push_back({std::move(t), ev});
+}
+void poll_parked() {
+    std::vector<hipEvent_t> done;
+    {
+        std::lock_guard<std::mutex> lk(g_slot_mutex);
+        for (size_t k = 0; k < g_parked.size();) {
+            ParkedSlot& p = g_parked[k];
+            const bool arrived = *reinterpret_cast<volatile int*>(p.slot.data_ptr()) >= 0;
+            if (arrived || !p.ev || hipEventQuery(p.ev) == hipSuccess) {
+                if (p.ev) done.push_back(p.ev);
+                if (g_slots.size() < 256) g_slots.push_back(std::move(p.slot));
+                g_parked[k] = std::move(g_parked.back());
+                g_parked.pop_back();
+            } else {
+                ++k;
+            }
+        }
+    }
+    for (hipEvent_t e : done) give_event(e);
 }
 
 // Side streams for geometry builds issued ahead of their first use (ConvolutionBuilder's learned prefetch): the chains of
@@ -182,12 +215,12 @@ public:
         return inst[which];
     }
     static bool enabled() {
-        static const bool on = !(getenv("MCCNN_ISSUE_THREAD") && std::string(getenv("MCCNN_ISSUE_THREAD")) == "0");
+        static const bool on = mccnn::debug_int("issue_thread", 1) != 0;
         return on;
     }
     // (debugging: MCCNN_ISSUE_INLINE = mask of the issuers whose jobs run on the calling thread instead)
     static bool inline_jobs(int which) {
-        static const int mask = getenv("MCCNN_ISSUE_INLINE") ? atoi(getenv("MCCNN_ISSUE_INLINE")) : 0;
+        static const int mask = mccnn::debug_int("issue_inline", 0);
         return (mask >> which) & 1;
     }
     int which_ = 0;
@@ -228,8 +261,12 @@ private:
                 job = std::move(q_.front());
                 q_.pop_front();
             }
-            static const int delay_us = getenv("MCCNN_DEBUG_JOB_DELAY_US") ? atoi(getenv("MCCNN_DEBUG_JOB_DELAY_US")) : 0;
-            if (delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));   // (widens race windows)
+            static const int delay_us = mccnn::debug_int("job_delay_us", 0);
+            if (delay_us > 0) {   // fault injection of the soak tests: a random pause of 0 .. delay_us before every job
+                static thread_local unsigned lcg = 12345u + (unsigned)(uintptr_t)this;
+                lcg = lcg * 1664525u + 1013904223u;
+                std::this_thread::sleep_for(std::chrono::microseconds((lcg >> 8) % (unsigned)(delay_us + 1)));
+            }
             job();
         }
     }
@@ -255,7 +292,7 @@ struct Geo {
     std::shared_ptr<Geo> grid_owner;
     int n = 0, m = 0, nc = 0, B = 0;
     int64_t e_cap = 0;
-    int e = -1;
+    std::atomic<int> e{-1};   // (also set by the helper thread that reads the total for the pieces it issues)
     int uses = 0;  // layers convolved over this geometry so far (the builder counts)
     std::atomic<int> pieces_issued{1};  // 0 while the helper thread still has pieces of this geometry to attach / issue
     void wait_build_issued_nothrow() {
@@ -306,12 +343,24 @@ struct Geo {
     }
     ~Geo() {
         wait_issued_nothrow();
+        const bool total_pending = slot.defined() && e.load(std::memory_order_relaxed) < 0 &&
+                                   *reinterpret_cast<volatile int*>(slot.data_ptr()) < 0;
+        hipEvent_t slot_ev = nullptr;
         if (event) {
             // never consumed: the buffers go back to the allocator of the stream they were taken on -- order that
             // stream behind the build first, or the next owner of the memory could race with it
             // (this destructor may run on the helper thread: the allocation stream is the one remembered at build time)
             if (needs_wait && buf.defined() && build_rc == 0) (void)hipStreamWaitEvent((hipStream_t)alloc_stream, event, 0);
-            give_event(event);
+            if (total_pending && build_rc == 0) slot_ev = event;   // (the event of the build: the parked slot keeps it)
+            else give_event(event);
+        } else if (total_pending && build_rc == 0 && buf.defined()) {
+            // built on the caller's stream: an event recorded there now lies behind the count pass
+            try {
+                slot_ev = take_event();
+                if (hipEventRecord(slot_ev, (hipStream_t)alloc_stream) != hipSuccess) { give_event(slot_ev); slot_ev = nullptr; }
+            } catch (const std::exception&) {
+                slot_ev = nullptr;
+            }
         }
         if (plan_event) {
             if (plan_wait && buf.defined()) (void)hipStreamWaitEvent((hipStream_t)alloc_stream, plan_event, 0);
@@ -322,7 +371,12 @@ struct Geo {
             give_event(tr_event);
         }
         if (h) mccnn_geometry_destroy(h);
-        if (slot.defined() && e >= 0) give_slot(std::move(slot));  // (a total that never arrived keeps its word)
+        if (slot.defined()) {
+            if (!total_pending) give_slot(std::move(slot));
+            else if (slot_ev) park_slot(std::move(slot), slot_ev);   // the count pass may still write the word
+            else if (build_rc != 0) give_slot(std::move(slot));     // the build never ran: nobody writes it
+            else park_slot(std::move(slot), nullptr);                // (no event to be had: recycled on the next poll)
+        }
     }
     hipEvent_t plan_event = nullptr;   // recorded behind the forward row plan prebuilt on a side stream (prebuild)
     bool plan_wait = false;
@@ -551,6 +605,7 @@ void prebuild_async(std::shared_ptr<Geo> g, int what, bool avg) {
             const int prev = mccnn_debug_wait_accounting(0);
             const int E = mccnn_geometry_edges(g->h, -1);
             mccnn_debug_wait_accounting(prev);
+            if (E >= 0) g->e.store(E, std::memory_order_relaxed);
             if (E > 0 && E <= g->e_cap) {
                 int rc = 0;
                 for (int k = 0; k < 4 && !rc; ++k)
@@ -669,7 +724,7 @@ struct ConvBackward : public torch::autograd::Node {
 // rows of the UNSORTED input points ([n, Fin] f32, or bf16 for depth-wise layers); the kernel-MLP tensors in any shape
 // over the reference's flat layout.
 Tensor conv(std::shared_ptr<Geo> geo, const Tensor& feats, const Tensor& w1, const Tensor& b1, const Tensor& w2,
-            const Tensor& b2, const Tensor& w3, const Tensor& b3, int64_t fout, bool combin, bool avg) {
+            const Tensor& b2, const Tensor& w3, const Tensor& b3, int64_t fout, bool combin, bool avg, bool deterministic) {
     TORCH_CHECK(geo && geo->h, "conv: no geometry");
     const DevGuard device_guard((int)feats.device().index());
     TORCH_CHECK(feats.defined() && feats.is_cuda() && feats.dim() == 2 && feats.size(0) == geo->n && feats.is_contiguous(),
@@ -682,7 +737,9 @@ Tensor conv(std::shared_ptr<Geo> geo, const Tensor& feats, const Tensor& w1, con
     const bool need_grad = at::GradMode::is_enabled() &&
                            (feats.requires_grad() || w1.requires_grad() || b1.requires_grad() || w2.requires_grad() ||
                             b2.requires_grad() || w3.requires_grad() || b3.requires_grad());
-    L.flags = need_grad ? 1 : 0;
+    // bit 1: the caller asks for bit-reproducible feature gradients (combin layers with 2..4 input features gather them
+    // through the transposed list instead of adding them with float atomics)
+    L.flags = (need_grad ? 1 : 0) | (deterministic ? 2 : 0);
     Tensor out, saved;
     {
         at::AutoDispatchBelowADInplaceOrView guard;
@@ -951,7 +1008,7 @@ struct HierFuture {
             hip_check(hipEventRecord(event, ss), "hipEventRecord");
             hip_check(hipStreamSynchronize(ss), "hipStreamSynchronize");
             hs.assign(host.data_ptr<int>(), host.data_ptr<int>() + L + 1);
-            if (getenv("MCCNN_DEBUG_HIER")) {
+            if (mccnn::debug_int("hier_trace", 0)) {
                 std::string line = "hier job: cap " + std::to_string(cap) + " extent " + std::to_string(extent) + " nc";
                 for (int l = 0; l < L; ++l) line += " " + std::to_string(ncs[l]);
                 line += " sizes";
@@ -1050,26 +1107,35 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
         .def_readonly("nc", &Geo::nc)
         .def_readonly("B", &Geo::B)
         .def_readonly("e_cap", &Geo::e_cap)
-        .def_readonly("e", &Geo::e)
+        .def_property_readonly("e", [](const Geo& g) { return g.e.load(std::memory_order_relaxed); })
         .def_readonly("grid_owner", &Geo::grid_owner)
         .def_readwrite("uses", &Geo::uses)
         .def_readonly("side", &Geo::side)
         .def_readonly("have", &Geo::have)
-        .def("join", [](Geo& g, const at::Tensor& like) { g.join(cur_stream(like)); })
-        .def("prebuild", &Geo::prebuild, py::arg("what"), py::arg("avg"), py::arg("side"), py::arg("like"))
-        .def("edges", &Geo::edges, py::arg("wait_us") = -1)
-        .def("info", &Geo::info);
+        // (none of the calls below touches a Python object, and all of them may wait -- for a helper thread's job, which can
+        // in turn wait for a device-side edge total, or for the device itself: the GIL is released for their whole
+        // duration, so data-loader threads keep running and a helper thread that drops the last reference to a tensor
+        // with a Python wrapper can take the GIL in its destructor instead of dead-locking against a spinning caller)
+        .def("join", [](Geo& g, const at::Tensor& like) { g.join(cur_stream(like)); }, py::call_guard<py::gil_scoped_release>())
+        .def("prebuild", &Geo::prebuild, py::arg("what"), py::arg("avg"), py::arg("side"), py::arg("like"),
+             py::call_guard<py::gil_scoped_release>())
+        .def("edges", &Geo::edges, py::arg("wait_us") = -1, py::call_guard<py::gil_scoped_release>())
+        .def("info", &Geo::info, py::call_guard<py::gil_scoped_release>());
     mod.def("build_geometry", &build_geometry, py::arg("pts"), py::arg("bids"), py::arg("centres"), py::arg("cbids"),
             py::arg("mn"), py::arg("mx"), py::arg("B"), py::arg("nc"), py::arg("radius"), py::arg("scale_inv"),
             py::arg("window"), py::arg("use_pdf"), py::arg("capacity"), py::arg("grid_from").none(true),
-            py::arg("side") = -1, py::arg("fork") = false, py::arg("background") = false);
-    mod.def("sampled_features", &sampled_features);
-    mod.def("prebuild_async", &prebuild_async, py::arg("geometry"), py::arg("what"), py::arg("avg"));
-    mod.def("conv", &conv);
+            py::arg("side") = -1, py::arg("fork") = false, py::arg("background") = false,
+            py::call_guard<py::gil_scoped_release>());
+    mod.def("sampled_features", &sampled_features, py::call_guard<py::gil_scoped_release>());
+    mod.def("prebuild_async", &prebuild_async, py::arg("geometry"), py::arg("what"), py::arg("avg"),
+            py::call_guard<py::gil_scoped_release>());
+    mod.def("conv", &conv, py::arg("geometry"), py::arg("feats"), py::arg("w1"), py::arg("b1"), py::arg("w2"), py::arg("b2"),
+            py::arg("w3"), py::arg("b3"), py::arg("fout"), py::arg("combin"), py::arg("avg"), py::arg("deterministic") = false,
+            py::call_guard<py::gil_scoped_release>());
     mod.def("hierarchy_levels", &hierarchy_levels, py::call_guard<py::gil_scoped_release>());
     py::class_<HierFuture, std::shared_ptr<HierFuture>>(mod, "HierarchyFuture")
         .def("result", &HierFuture::result)
         .def("done", [](HierFuture& f) { return f.done.load(std::memory_order_acquire) != 0; });
-    mod.def("hierarchy_prefetch", &hierarchy_prefetch);
+    mod.def("hierarchy_prefetch", &hierarchy_prefetch, py::call_guard<py::gil_scoped_release>());
     mod.def("wait_ns", [] { return (long long)g_wait_ns.load(std::memory_order_relaxed); });
 }

@@ -13,7 +13,7 @@ import weakref
 
 import torch
 
-from . import _lib
+from . import _env, _lib
 from ._lib import check, ptr, stream_handle
 
 def _load_ext():
@@ -22,15 +22,22 @@ def _load_ext():
     tree without the built module) keeps the ctypes form."""
     import importlib.util
     import os
-    if os.environ.get("MCCNN_TORCH_EXT", "1") == "0":
+    from ._env import flag
+    if not flag("TORCH_EXT"):
         return None
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "_mccnn_torch.so")
     if not os.path.exists(path):
         return None
-    _lib.load()  # libmccnn_hip.so first: the module links against it
-    spec = importlib.util.spec_from_file_location("_mccnn_torch", path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    _lib.load()  # libmccnn_hip.so first: the module links against it (a missing HIP library raises: no fallback for that)
+    try:
+        spec = importlib.util.spec_from_file_location("_mccnn_torch", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    except (ImportError, OSError) as err:  # built against another torch: the ctypes binding of the SAME library takes over
+        import sys
+        print("mccnn_amd.native: lib/_mccnn_torch.so does not load (%s); using the ctypes binding of libmccnn_hip.so" % err,
+              file=sys.stderr)
+        return None
     return mod
 
 
@@ -66,7 +73,7 @@ def _ws(nbytes, device):
     return pool_ws(nbytes, device)
 
 
-_ECAP_SCALE = float(os.environ.get("MCCNN_ECAP_SCALE", "1"))   # (debugging: generous / starved capacity guesses)
+_ECAP_SCALE = _env.debug("ecap_scale", 1.0)   # (debugging: generous / starved capacity guesses)
 
 
 def _capacity_guess(gkey, m):
@@ -372,7 +379,7 @@ class _Conv(torch.autograd.Function):
         gflat = torch.empty(n1 + n2 + n3 + n4 + n5 + n6, dtype=torch.float32, device=dev)
         dw1, db1, dw2, db2, dw3, db3 = gflat.split((n1, n2, n3, n4, n5, n6))
         base = gflat.data_ptr()
-        skey = (2 | (flags & 2), fin, fout, combin, bf16, geo.n, geo.m)
+        skey = (2, flags & 2, fin, fout, combin, bf16, geo.n, geo.m)   # (deterministic and atomic backward passes differ in scratch)
         wsb = _SIZES.get(skey, (-1, 0))[0]
         if wsb < 0:
             wsb, _ = _prepare(geo, feats, fin, fout, combin, bf16, 1, flags)
@@ -406,11 +413,11 @@ def conv(geo, feats, w1, b1, w2, b2, w3, b3, numOutFeatures, combin, avg, determ
     if core is not None:
         core.uses = geo.uses
         try:
-            out = _EXT.conv(core, feats, w1, b1, w2, b2, w3, b3, numOutFeatures, bool(combin), bool(avg))
+            out = _EXT.conv(core, feats, w1, b1, w2, b2, w3, b3, numOutFeatures, bool(combin), bool(avg), bool(deterministic))
         except _EXT.CapacityError:
             geo.edges()   # the list did not fit the guess (first batch of a shape): exact rebuild, then the layer
             geo.core.uses = geo.uses
-            out = _EXT.conv(geo.core, feats, w1, b1, w2, b2, w3, b3, numOutFeatures, bool(combin), bool(avg))
+            out = _EXT.conv(geo.core, feats, w1, b1, w2, b2, w3, b3, numOutFeatures, bool(combin), bool(avg), bool(deterministic))
         if geo.e < 0:
             geo.e = geo.core.e
             _remember(geo.gkey, geo.m, geo.e)

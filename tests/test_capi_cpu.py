@@ -118,3 +118,19 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert not bad.search(src), os.path.join(dp, f)
+
+
+def test_environment_switches_are_a_handful():
+    """The product package reads FOUR documented path switches, the MCCNN_DEBUG list and the two A/B build variables of
+    mccnn_amd.build -- nothing else (csrc/debug_opts.h, mccnn_amd/_env.py)."""
+    import glob
+    import re
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "mccnn_amd", "*.py")) + glob.glob(os.path.join(ROOT, "mccnn_amd", "csrc", "*")):
+        if not os.path.isfile(f):
+            continue
+        txt = open(f, errors="ignore").read()
+        names |= set(re.findall(r'(?:getenv|environ\.get|environ\[)\(?\s*"(MCCNN_[A-Z0-9_]+)"', txt))
+        names |= set("MCCNN_" + n for n in re.findall(r'_env\.flag\("([A-Z0-9_]+)"', txt) + re.findall(r'\bflag\("([A-Z0-9_]+)"\)', txt))
+    assert names <= {"MCCNN_NATIVE", "MCCNN_TORCH_EXT", "MCCNN_ROW_KERNELS", "MCCNN_GEO_PREFETCH", "MCCNN_DEBUG", "MCCNN_LIB_NAME",
+                     "MCCNN_EXTRA_FLAGS"}, sorted(names)

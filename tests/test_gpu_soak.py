@@ -32,7 +32,7 @@ def test_room_network_soak_with_changing_room_sizes(mc):
     launches on its stream). This is the run that exposed a helper thread's scratch being taken from the caching allocator's
     pool of ANOTHER stream without ordering (level sizes of a prefetched hierarchy overwritten by convolution kernels)."""
     # (also: the steps issued one at a time -- ConvolutionBuilder.hostStepsAhead_ = 0 --, random layer subsets, skipped backward passes)
-    env = dict(os.environ, SOAK_STEPS="500", SOAK_DEEP="1", SOAK_CFG="cfg4", MCCNN_HIER_PREFETCH_PMODE="0", SOAK_LAG="0",
+    env = dict(os.environ, SOAK_STEPS="500", SOAK_DEEP="1", SOAK_CFG="cfg4", MCCNN_DEBUG="hier_pmode=0", SOAK_LAG="0",
                SOAK_VARY_GRAPH="1", SOAK_SKIP_BWD="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_network.py")], env=env, capture_output=True, text=True,
                          timeout=900)
