@@ -442,6 +442,15 @@ __global__ __launch_bounds__(256) void edge_records(ConvArgs a, float4* __restri
 #endif
 // combin layers with 2..4 input features and at most this many blocks keep one plane of per-edge feature-gradient sums
 // per block (E * Fin floats each) instead of a read-modify-write of one plane
+// (Round 5, built and dropped: the per-edge sums of a wave's slice kept in LDS across the blocks -- read-modify-write by
+// the lane that owns the edge, at most 19 chunks per wave so that two workgroups of 62 KB stay resident -- and one float
+// atomic per (edge, fin) to featGrad from inside the wave's LAST block, every wave starting its round of the blocks
+// somewhere else so that the atomics spread over the whole kernel: no planes in memory, no scatter_edge_featgrad.
+// Parity-green; 3 -> 8 on the room under rocprofv3, same box: 433 + 11 us against 265 + 128 + 9 us (sweep, scatter,
+// reduction of the partial rows). Of the 168 us the sweep loses, the finer slices cost 33 (the plane form at the same
+// slicing: 297 us), dynamic LDS beyond ~20 KB per workgroup another 25-35 even when nothing touches it, and neither the
+// atomics nor the LDS updates show up in ablation builds (434 / 437 us without them): the rest is the sweep itself
+// compiled in its 18 (fin, first neuron, last block) forms at the 256-register limit.)
 #define MCCNN_DF_PLANES 4
 static inline int df_planes(int Fin, int nb) { return (Fin >= 2 && Fin <= 4 && nb <= MCCNN_DF_PLANES) ? nb : 1; }
 // Waves own equal, contiguous EDGE ranges (cpw chunks of 64 edges each): nothing in the backward pass needs
