@@ -389,7 +389,7 @@ class Workload:
                    ("factored Fin = 1 (conv_f1.hip)" if (combin and fin == 1) else "edge-streaming (conv.hip)"))
         t_s2g, _ = ev_time(lambda: M._gather_rows(fg, idx, n))
         C = int(np.prod(cells.shape[:4]))
-        # algorithmic work per launch (stated in DESIGN.md section 6)
+        # algorithmic work per launch (stated in NOTES.md section 6)
         alg = {
             "sort_points_step1": ("hbm", n * 16 + n * 8 + 4 * C, t_s1),
             "sort_points_step2": ("hbm", n * (16 + 8 + 4 * fin) + n * (16 + 4 * fin) + 8 * C, t_s2),
@@ -978,7 +978,7 @@ def compact_record(rec, details_path=None):
     if isinstance(ly, dict):
         out["layers"] = {}
         for name, ent in ly.items():
-            e = _pick(ent, ("ms_per_step", "value"))
+            e = _pick(ent, ("ms_per_step", "value", "mode", "sequential_ms_per_step"))
             if isinstance(ent.get("conv_ms"), dict):
                 e["conv_ms"] = ent["conv_ms"]
             if isinstance(ent.get("roofline"), dict):
@@ -1158,7 +1158,15 @@ def main():
     layers = None if args.no_layers else {}
     for name, w2 in others.items():
         ms, val, _ = w2.timed(max(args.steps // 2, 3), 2)
-        layers[name] = {"ms_per_step": round(ms, 4), "value": round(val, 1), "unit": "points/s", "edges_per_gpu": w2.e_local}
+        layers[name] = {"ms_per_step": round(ms, 4), "value": round(val, 1), "unit": "points/s", "edges_per_gpu": w2.e_local,
+                        "mode": "pipelined" if w2.pipeline else "sequential"}
+        if w2.pipeline:  # the same steps strictly one after the other, reported beside the chosen mode
+            w2.pipeline = False
+            ms_s, val_s, _ = w2.timed(max(args.steps // 2, 3), 2)
+            w2.pipeline = True
+            layers[name]["sequential_ms_per_step"] = round(ms_s, 4)
+            if ms_s < ms:
+                layers[name].update(ms_per_step=round(ms_s, 4), value=round(val_s, 1), mode="sequential")
 
     # ------------------------------------------------------------------ the headline region
     ms_per_step, value, m_total = wl.timed(args.steps, max(args.warmup - 1, 0))
@@ -1177,7 +1185,9 @@ def main():
             rank_stats = wl.rank_stats
     if layers is not None:
         layers[args.layer] = {"ms_per_step": round(ms_per_step, 4), "value": round(value, 1), "unit": "points/s",
-                              "edges_per_gpu": wl.e_local}
+                              "edges_per_gpu": wl.e_local, "mode": headline_mode}
+        if ms_sequential is not None:
+            layers[args.layer]["sequential_ms_per_step"] = round(ms_sequential, 4)
 
     # ------------------------------------------------------------------ per-op breakdowns and rooflines (rank 0)
     roofline = breakdown = None

@@ -9,7 +9,7 @@
 // rows are contiguous (find_neighbors.cu:255-258): lanes are edges, the sum over a centre's edges is a segmented wave
 // scan and every output row is written exactly once -- no atomics, no pre-zeroing, bit-reproducible.
 //   conv_stream      forward (and, on the transposed list, the depth-wise feature gradient): MFMA kernel MLP,
-//                    edge-balanced slices, wave-wide fused-DPP scan with carry            
+//                    edge-balanced slices, wave-wide fused-DPP scan with carry            (NOTES.md section 5)
 //   conv_bwd_mfma    backward: q-outer sweeps with the weight-gradient sums in VGPRs, deterministic partial rows
 //   conv_fwd_valu / conv_bwd_valu   fallback for nb > MCCNN_LDS_MAX_NB: scalar-loaded weights, fmaf chains, LDS tile
 //   conv_f1.hip      combin layers with ONE input feature take the factored kernels there

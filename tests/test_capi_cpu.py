@@ -134,3 +134,22 @@ def test_environment_switches_are_a_handful():
         names |= set("MCCNN_" + n for n in re.findall(r'_env\.flag\("([A-Z0-9_]+)"', txt) + re.findall(r'\bflag\("([A-Z0-9_]+)"\)', txt))
     assert names <= {"MCCNN_NATIVE", "MCCNN_TORCH_EXT", "MCCNN_ROW_KERNELS", "MCCNN_GEO_PREFETCH", "MCCNN_DEBUG", "MCCNN_LIB_NAME",
                      "MCCNN_EXTRA_FLAGS"}, sorted(names)
+
+
+def test_debug_list_parser(monkeypatch):
+    """mccnn_amd/_env.py: the four path switches and the MCCNN_DEBUG list (bare key = 1, typed by the default)."""
+    import importlib
+    monkeypatch.setenv("MCCNN_DEBUG", "small_off, plan_min_l=16 ,ecap_scale=0.5,fuse_sort=0,geo_trace")
+    monkeypatch.setenv("MCCNN_NATIVE", "0")
+    monkeypatch.delenv("MCCNN_TORCH_EXT", raising=False)
+    from mccnn_amd import _env
+    env = importlib.reload(_env)
+    try:
+        assert env.debug("small_off", 0) == 1 and env.debug("plan_min_l", 4) == 16
+        assert env.debug("ecap_scale", 1.0) == 0.5 and env.debug("fuse_sort", True) is False and env.debug("geo_trace", False) is True
+        assert env.debug("absent", 7) == 7 and env.debug("absent", "x") == "x"
+        assert env.flag("NATIVE") is False and env.flag("TORCH_EXT") is True
+    finally:
+        monkeypatch.delenv("MCCNN_DEBUG")
+        monkeypatch.delenv("MCCNN_NATIVE")
+        importlib.reload(_env)

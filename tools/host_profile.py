@@ -1,5 +1,5 @@
 """cProfile of a BASELINE.json configuration's step loop (host side): python tools/host_profile.py cfg4
-Where the Python / autograd / ctypes time of a host-bound step goes."""
+Where the Python / autograd / ctypes time of a host-bound step goes (NOTES.md section 6b)."""
 import os, sys, cProfile, pstats, torch
 sys.path.insert(0, os.getcwd())
 import bench
