@@ -56,7 +56,7 @@ LAYERS = {  # name: (Fin, Fout, combin)   -- SURVEY 8(d) layer shapes
 }
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector == f32 MFMA dense peak
-PROFILE_ROUND = "r04"    # profiles/<round>_pmc_traffic_<layer>.json supplies roofline.traffic
+PROFILE_ROUND = "r05"    # profiles/<round>_pmc_traffic_<layer>.json supplies roofline.traffic
 
 
 def log(*a):

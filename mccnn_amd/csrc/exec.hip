@@ -450,9 +450,12 @@ int mccnn_geometry_prebuild(mccnn_geometry_t* g, int what, int avg, void* ws, si
     if (e == 0) return 0;
     avg = avg ? 1 : 0;
     int rc = 0;
-    if (what & NEED_TLIST) rc = ensure_tlist(g, e, ws, ws_bytes, stream);
-    if (!rc && (what & NEED_PLAN_FWD)) rc = ensure_plan(g, 0, e, avg, ws, ws_bytes, stream);
+    // (the transposed plan of a large list builds the transposed list itself when there is none yet -- its rank pass
+    // writes the plan on the way, conv_rows.hip plan_scatter_tr -- so the plan goes first and the list call that
+    // follows finds its work done; the forward plan evaluates the edge records both plans permute)
+    if (what & NEED_PLAN_FWD) rc = ensure_plan(g, 0, e, avg, ws, ws_bytes, stream);
     if (!rc && (what & NEED_PLAN_TR)) rc = ensure_plan(g, 1, e, avg, ws, ws_bytes, stream);
+    if (!rc && (what & NEED_TLIST)) rc = ensure_tlist(g, e, ws, ws_bytes, stream);
     return rc;
 }
 

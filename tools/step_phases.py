@@ -1,0 +1,53 @@
+"""Where a pipelined step of a BASELINE configuration spends its time: host time of the phases of ConfigWorkload.step (deep
+pipeline: hierarchy two batches ahead + prefetch_step) and, from events on the main queue, the span of the convolution
+chain against the step period.   python tools/step_phases.py cfg4 [lag]"""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import torch
+import bench
+from mccnn_amd.workloads import CONFIGS
+
+torch.cuda.set_device(0)
+torch.autograd.set_multithreading_enabled(False)
+name = sys.argv[1]
+lag = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+cw = bench.ConfigWorkload(CONFIGS[name], torch.device("cuda", 0))
+assert cw.set_pipeline(True, geometry=True)
+cw.builder.hostStepsAhead_ = (lag - 1) if lag else None
+ph_t = {k: 0.0 for k in ("reset", "adopt", "request", "prefetch", "fwd", "bwd")}
+ev = []
+N = 60
+
+
+def step(rec):
+    t = [time.perf_counter()]
+    cw.builder.reset(); t.append(time.perf_counter())
+    ph = cw.ph = cw.ready_ph
+    nxt = cw.hierarchy(cw.next_ph); t.append(time.perf_counter())
+    cw.request_next(); t.append(time.perf_counter())
+    cw.builder.prefetch_step(nxt); t.append(time.perf_counter())
+    cw.ready_ph = nxt
+    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    outs = [cw.conv(ph, ci) for ci in range(len(cw.cfg.convs))]; t.append(time.perf_counter())
+    cw.grads = torch.autograd.grad(outs, cw.feats + cw.params, cw.ogs, allow_unused=True); t.append(time.perf_counter())
+    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+    if rec:
+        for k, a, b in zip(ph_t, t[:-1], t[1:]):
+            ph_t[k] += b - a
+        ev.append((e0, e1))
+
+
+for _ in range(10):
+    step(False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(N):
+    step(True)
+t_issue = time.perf_counter() - t0
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+span = sum(a.elapsed_time(b) for a, b in ev) / N
+period = ev[0][0].elapsed_time(ev[-1][0]) / (N - 1)
+print("%s lag %d: %.3f ms/step (host issue %.3f); host phases ms: %s" % (name, lag, el / N * 1e3, t_issue / N * 1e3,
+      ", ".join("%s %.3f" % (k, v / N * 1e3) for k, v in ph_t.items())))
+print("   main queue: convolution chain spans %.3f ms of a %.3f ms period (first conv launch to end of backward)" % (span, period))
