@@ -275,3 +275,39 @@ def test_backward_detects_inputs_modified_in_place(mc):
         next(iter(b.parameters())).mul_(2.0)
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         out.sum().backward()
+
+
+def test_geometries_dropped_before_their_totals_arrive(mc, oracle):
+    """A geometry destroyed right after being queued (a prefetch nobody uses, an exception path): its pinned slot must not go
+    back to the pool while the count pass can still write it -- a later geometry armed with -1 would read a stale total and
+    convolve over a truncated list (torch_ext.cpp: parked slots). Hundreds of builds on side streams and on the caller's
+    stream are dropped unread, then a fresh geometry of ANOTHER size must still report its own edge total."""
+    import torch
+    from mccnn_amd import native
+    from mccnn_amd import MCConvModule as M
+    if native._EXT is None:
+        pytest.skip("needs the torch extension")
+    clouds = []
+    for n_per, seed in ((3000, 1), (700, 2), (1500, 3)):
+        pts, bids = make_cloud(n_per, 2, seed, "clustered", False)
+        P, Bi = _t(pts), _t(bids)
+        mn, mx = M.compute_aabb(P, Bi, 2, True)
+        clouds.append((pts, bids, P, Bi, mn, mx))
+    radius = 0.2
+    nc = M._num_cells(clouds[0][4], clouds[0][5], 2, radius, True)
+    want = []
+    for pts, bids, P, Bi, mn, mx in clouds:
+        omn, omx = oracle.compute_aabb(pts, bids, 2, True)
+        k_, i_ = oracle.sort_points_step1(pts, bids, omn, omx, 2, radius, True)
+        sp, sb, _, cl = oracle.sort_points_step2(pts, bids, np.zeros((len(pts), 1), np.float32), k_, i_, omn, omx, 2, radius, True)
+        want.append(len(oracle.find_neighbors(pts, bids, sp, cl, omn, omx, radius, 2, True)[1]))
+    for rnd in range(60):
+        for ci, (pts, bids, P, Bi, mn, mx) in enumerate(clouds):
+            for side in (-1, rnd % 4):
+                g = native.build_geometry(P, Bi, P, Bi, mn, mx, 2, nc, radius, True, 0.25, True, side=side, fork=side >= 0)
+                del g   # dropped before anybody asked for its total
+        ci = rnd % 3
+        pts, bids, P, Bi, mn, mx = clouds[ci]
+        g = native.build_geometry(P, Bi, P, Bi, mn, mx, 2, nc, radius, True, 0.25, True)
+        assert g.edges() == want[ci], (rnd, ci)
+    torch.cuda.synchronize()
