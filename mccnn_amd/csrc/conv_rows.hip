@@ -43,7 +43,7 @@ struct RowPlan {
     int numRows, S;
 };
 
-#define MCCNN_PLAN_SMALL 4096  // rows and virtual rows up to here: laid out by ONE workgroup, windows left unsorted
+#define MCCNN_PLAN_SMALL 8192  // capacity of the single-workgroup layout (rows and virtual rows); plan_small_limit() is what is used
 struct PlanSizes {
     bool small;       // single-workgroup layout (plan_small)
     int L;            // longest virtual row of this plan
@@ -51,6 +51,10 @@ struct PlanSizes {
     int windows, S;   // windows of SELL_SIGMA virtual rows, slices of 64
     long long slots;  // bound on the number of slots
 };
+static int plan_small_limit() {
+    static const int v = max(1024, min(MCCNN_PLAN_SMALL, debug_int("plan_small", 4096)));
+    return v;
+}
 static PlanSizes plan_sizes(int rows, int e) {
     PlanSizes z;
     // A lane walks its virtual row serially (~1 us per edge of latency), so a list with few rows is cut finer: about
@@ -58,15 +62,24 @@ static PlanSizes plan_sizes(int rows, int e) {
     // of the usual 30 - 100 edges then stays in one piece.
     z.L = ROWS_L;
     static const int minL = debug_int("plan_min_l", 4);  // A/B switch, read once
-    if (rows <= 3072 && minL < 16) {
+    const int lim = plan_small_limit();
+    // (round 5: pieces of the small form are at most 16 edges long. Without the cap a list of 1 273 rows x 32 edges got
+    // pieces of 32 -- 192 workgroups walking 32 serial iterations: 36 us forward / 49 us backward where the same list
+    // in pieces of 16 takes 29 / 40; cfg4's convolution chain 1.455 -> 1.365 ms. A larger single-workgroup layout
+    // (plan_small=8192) with the same cap: the same times, fewer launches, 99 KB of LDS; kept at 4 096. The floor of
+    // 16 for mid-size lists below: 8 and 32 both measured slower.)
+    static const int maxL = debug_int("plan_small_max_l", 16);
+    int Ls = minL;
+    if (rows <= lim / 4 * 3 && minL < 16)
+        while (Ls < ROWS_L && rows + e / Ls > lim / 8 * 7) Ls <<= 1;
+    if (rows <= lim / 4 * 3 && minL < 16 && Ls <= maxL) {
         // the coarse levels of a hierarchy: the chip is empty, every iteration of a lane is exposed latency -- pieces as
-        // short as the single-workgroup layout (MCCNN_PLAN_SMALL virtual rows) allows
-        int L = minL;
-        while (L < ROWS_L && rows + e / L > 3584) L <<= 1;
-        z.L = L;
+        // short as the single-workgroup layout (plan_small_limit() virtual rows) allows
+        z.L = Ls;
     } else if (rows < 16384) {
+        static const int midL = debug_int("plan_mid_l", 16);
         long long want = e / 65536;
-        int L = 16;
+        int L = midL;
         while (L < want && L < ROWS_L) L <<= 1;
         z.L = L;
     }
@@ -78,7 +91,7 @@ static PlanSizes plan_sizes(int rows, int e) {
     // of it a bitonic sort whose only purpose is less padding. One workgroup does the whole layout for them, in row
     // order; unsorted, a slice holds at most 64 L slots.
     static const bool allowSmall = !debug_int("plan_small_off", 0);  // A/B switch, read once
-    z.small = allowSmall && rows <= MCCNN_PLAN_SMALL && z.vcap <= MCCNN_PLAN_SMALL;
+    z.small = allowSmall && rows <= lim && z.vcap <= lim;
     if (z.small) z.slots = (long long)z.L * (z.vcap + 64);
     return z;
 }
@@ -1138,7 +1151,7 @@ int mccnn_rowplan_bound(int rows, int e_cap, int transposed, long long* buffer_b
         const long long S = windows * (SELL_SIGMA / 64);
         long long slots = (long long)e_cap + 64LL * L * windows;
         const long long small = (long long)L * (vcap + 64);
-        if (rows <= MCCNN_PLAN_SMALL && small > slots) slots = small;
+        if (rows <= plan_small_limit() && small > slots) slots = small;
         if (slots > 0x7fffffffLL || vcap > 0x7fffffffLL) return MCCNN_E_TOOLARGE;
         size_t o = 0;
         o += plan_al((size_t)64 * S) * 2 + plan_al((size_t)S + 1) + plan_al((size_t)(rows > 0 ? rows : 1));
