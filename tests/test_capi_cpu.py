@@ -153,3 +153,27 @@ def test_debug_list_parser(monkeypatch):
         monkeypatch.delenv("MCCNN_DEBUG")
         monkeypatch.delenv("MCCNN_NATIVE")
         importlib.reload(_env)
+
+
+def test_rowplan_bound_covers_every_edge_count():
+    """mccnn_rowplan_bound(rows, e_cap): buffer and workspace sizes that hold for EVERY list of up to e_cap edges -- what a
+    caller allocates before the true total is known (plans prebuilt on helper threads). The piece length L is a step
+    function of (rows, e) with several regimes (single-workgroup form with pieces of <= 16 edges, mid-size lists, large
+    lists): checked against mccnn_rowplan_buffer / _build_workspace_bytes on random shapes. Host arithmetic only."""
+    import ctypes as C
+    import numpy as np
+    from mccnn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    offs = (C.c_longlong * 6)()
+    for _ in range(300):
+        rows = int(rng.choice([1, 7, 73, 318, 1273, 3000, 3100, 4096, 5627, 16000, 20000, 100000, 800000]))
+        e_cap = int(rows * rng.choice([0.5, 3, 8, 33, 60, 400]) + rng.integers(0, 1000))
+        for tr in (0, 1):
+            b, w = C.c_longlong(0), C.c_longlong(0)
+            assert lib.mccnn_rowplan_bound(rows, e_cap, tr, C.byref(b), C.byref(w)) == 0
+            for e in sorted(set([1, e_cap, e_cap // 2, e_cap // 7 + 1] + [int(x) for x in rng.integers(1, e_cap + 1, 6)])):
+                total, cap, srows, S = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0), C.c_int(0)
+                assert lib.mccnn_rowplan_buffer(rows, e, offs, C.byref(total), C.byref(S), C.byref(cap), C.byref(srows)) == 0
+                assert total.value <= b.value, (rows, e, e_cap, tr, total.value, b.value)
+                assert lib.mccnn_rowplan_build_workspace_bytes(rows, e, tr) <= w.value, (rows, e, e_cap, tr)
