@@ -27,11 +27,14 @@ inline const char* debug_opt(const char* key) {
     while (p < list.size()) {
         size_t q = list.find(',', p);
         if (q == std::string::npos) q = list.size();
+        const size_t next = q + 1;
+        while (p < q && list[p] == ' ') ++p;                 // (blanks around an item are ignored, as on the Python side)
+        while (q > p && list[q - 1] == ' ') --q;
         if (q - p >= kl && list.compare(p, kl, key) == 0 && (q - p == kl || list[p + kl] == '=')) {
             val = (q - p == kl) ? std::string("1") : list.substr(p + kl + 1, q - p - kl - 1);
             return val.c_str();
         }
-        p = q + 1;
+        p = next;
     }
     return nullptr;
 }

@@ -177,3 +177,20 @@ def test_rowplan_bound_covers_every_edge_count():
                 assert lib.mccnn_rowplan_buffer(rows, e, offs, C.byref(total), C.byref(S), C.byref(cap), C.byref(srows)) == 0
                 assert total.value <= b.value, (rows, e, e_cap, tr, total.value, b.value)
                 assert lib.mccnn_rowplan_build_workspace_bytes(rows, e, tr) <= w.value, (rows, e, e_cap, tr)
+
+
+def test_debug_list_parser_of_the_library(tmp_path):
+    """csrc/debug_opts.h (the C++ side of the MCCNN_DEBUG list): bare keys, values, blanks, a key that is a prefix of another."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("no g++")
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "debug_opts.h"\n#include <cstdio>\nint main() { printf("%d %d %d %d %g\\n", mccnn::debug_int("small_off", 0), '
+                   'mccnn::debug_int("plan_min_l", 4), mccnn::debug_int("absent", 7), mccnn::debug_int("plan_min", 9), '
+                   'mccnn::debug_float("ecap_scale", 1.0)); }\n')
+    exe = tmp_path / "t"
+    subprocess.check_call([cxx, "-std=c++17", "-I", os.path.join(ROOT, "mccnn_amd", "csrc"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], env=dict(os.environ, MCCNN_DEBUG="small_off, plan_min_l=16 ,ecap_scale=0.5"), capture_output=True, text=True)
+    assert out.stdout.split() == ["1", "16", "7", "9", "0.5"]
