@@ -43,7 +43,8 @@ struct RowPlan {
     int numRows, S;
 };
 
-#define MCCNN_PLAN_SMALL 8192  // capacity of the single-workgroup layout (rows and virtual rows); plan_small_limit() is what is used
+#define MCCNN_PLAN_SMALL 4096  // capacity of the single-workgroup layout (rows and virtual rows): 49 KB of LDS. (8 192, measured in
+                               // round 5: the same step times with 12 launches fewer, but 99 KB of LDS make every plan_small launch 8 -> 12 us)
 struct PlanSizes {
     bool small;       // single-workgroup layout (plan_small)
     int L;            // longest virtual row of this plan
