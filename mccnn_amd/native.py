@@ -54,6 +54,7 @@ _EDGE_RATIO = {}   # (device, radius, scaleInv) -> edges per centre of the last 
 def _slot():
     """A pinned int32 the count pass stores the edge total into (device-accessible host memory: no copy is enqueued);
     pooled per host thread."""
+    _poll_parked()
     pool = getattr(_TLS, "slots", None)
     if pool is None:
         pool = _TLS.slots = []
@@ -66,6 +67,36 @@ def _release_slot(t):
     pool = getattr(_TLS, "slots", None)
     if pool is not None and len(pool) < 64:
         pool.append(t)
+
+
+_PARKED = []   # (slot, event): words of geometries dropped before their total arrived -- the count pass may still write them
+
+
+def _park_slot(t):
+    """Keeps a pinned word alive (neither pooled nor returned to the host allocator) until everything the current stream
+    holds -- the build that writes it among it -- has retired."""
+    try:
+        ev = torch.cuda.Event()
+        ev.record()
+    except Exception:   # interpreter shutdown, no device: the word simply stays referenced
+        ev = None
+    _PARKED.append((t, ev))
+
+
+def _poll_parked():
+    if not _PARKED:
+        return
+    keep = []
+    for t, ev in _PARKED:
+        try:
+            done = int(t[0]) >= 0 or ev is None or ev.query()
+        except Exception:
+            done = False
+        if done:
+            _release_slot(t)
+        else:
+            keep.append((t, ev))
+    _PARKED[:] = keep
 
 
 def _ws(nbytes, device):
@@ -124,8 +155,14 @@ class Geometry:
                 _lib.load().mccnn_geometry_destroy(h)
             except Exception:
                 pass
-        if self.slot is not None and self.e >= 0:  # (a total that never arrived keeps its word: the kernel may still write it)
-            _release_slot(self.slot)
+        if self.slot is not None:
+            if self.e >= 0:
+                _release_slot(self.slot)
+            else:   # the total never arrived here: the count pass may still write the word (see _park_slot)
+                try:
+                    _park_slot(self.slot)
+                except Exception:
+                    pass
 
     # ------------------------------------------------------------------ sizes
     def edges(self):

@@ -285,8 +285,7 @@ def test_geometries_dropped_before_their_totals_arrive(mc, oracle):
     import torch
     from mccnn_amd import native
     from mccnn_amd import MCConvModule as M
-    if native._EXT is None:
-        pytest.skip("needs the torch extension")
+    sides = (-1, 0) if native._EXT is None else None   # (ctypes binding: every build runs on the caller's stream)
     clouds = []
     for n_per, seed in ((3000, 1), (700, 2), (1500, 3)):
         pts, bids = make_cloud(n_per, 2, seed, "clustered", False)
@@ -303,7 +302,7 @@ def test_geometries_dropped_before_their_totals_arrive(mc, oracle):
         want.append(len(oracle.find_neighbors(pts, bids, sp, cl, omn, omx, radius, 2, True)[1]))
     for rnd in range(60):
         for ci, (pts, bids, P, Bi, mn, mx) in enumerate(clouds):
-            for side in (-1, rnd % 4):
+            for side in (sides or (-1, rnd % 4)):
                 g = native.build_geometry(P, Bi, P, Bi, mn, mx, 2, nc, radius, True, 0.25, True, side=side, fork=side >= 0)
                 del g   # dropped before anybody asked for its total
         ci = rnd % 3
@@ -311,3 +310,16 @@ def test_geometries_dropped_before_their_totals_arrive(mc, oracle):
         g = native.build_geometry(P, Bi, P, Bi, mn, mx, 2, nc, radius, True, 0.25, True)
         assert g.edges() == want[ci], (rnd, ci)
     torch.cuda.synchronize()
+
+
+def test_geometries_dropped_before_their_totals_arrive_ctypes_binding():
+    """The same through the ctypes binding of the C-ABI (MCCNN_TORCH_EXT=0: mccnn_amd.native parks the pinned words itself)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MCCNN_TORCH_EXT="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_native.py"), "-m", "gpu", "-x", "-q",
+                          "-k", "test_geometries_dropped_before_their_totals_arrive and not ctypes"], env=env, capture_output=True,
+                         text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-1500:] + out.stderr[-500:]
