@@ -52,32 +52,7 @@ def _log(msg):
         print(msg)
 
 
-_RECORD_STREAMS = _env.debug("record_stream", False)
 _GEO_TRACE = _env.debug("geo_trace", False)
-
-
-def _storage_users(t):
-    """How many TensorImpls / wrappers share t's storage beyond what t itself accounts for (views made by anybody: a
-    user's slice of a cached list). A tensor that is itself a view (packed = buf[:e] inside find_neighbors) accounts for
-    its base as well. None when this torch build does not expose the count."""
-    fn = getattr(torch._C, "_storage_Use_Count", None)
-    if fn is None:
-        return None
-    try:
-        return int(fn(t.untyped_storage()._cdata)) - (1 if t._base is not None else 0)
-    except Exception:
-        return None
-
-
-def _storage_baseline():
-    """The count _storage_users() reports for a tensor nobody else shares (the probe's own wrapper included)."""
-    global _STORAGE_BASE
-    if _STORAGE_BASE is None:
-        _STORAGE_BASE = _storage_users(torch.empty(1)) or 0
-    return _STORAGE_BASE
-
-
-_STORAGE_BASE = None
 
 
 class _LazyEntry:
@@ -332,8 +307,6 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         self.resetEvent_ = None
         self.prefetchTransposed_ = {}
         self.prefetchDummy_ = None
-        self.sideTensors_ = []      # tensors of the installed prefetch (allocated on the side stream), see __retire_side_tensors__
-        self.sideRecorded_ = 0      # how many of them needed the record_stream() fallback so far (tests)
 
     # ------------------------------------------------------------------ variable store
     @property
@@ -404,7 +377,6 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                 t0 = time.perf_counter()
                 evs[-(int(k) + 1)].synchronize()
                 _M.HOST_WAIT_S[0] += time.perf_counter() - t0
-        self.__retire_side_tensors__()
         self.cacheGrids_ = {}
         self.cacheNeighs_ = {}
         self.cachePDFs_ = {}
@@ -433,10 +405,12 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
             for d in (grids, neighs, pdfs):
                 for v in d.values():
                     for t in (v if isinstance(v, tuple) else (v,)):
-                        if _RECORD_STREAMS:
-                            t.record_stream(main)
-                        else:
-                            self.sideTensors_.append(t)  # allocated on the side stream, read on this one: see below
+                        # allocated on the side stream, read on this one: the allocator may hand the block out again only
+                        # behind this stream's reads. (Rounds 2-4 dropped these tensors here themselves when reference-
+                        # count probes said the builder was their last owner -- 8 blocks x 5.5 us of main-queue time per
+                        # step saved on this fallback path, for a test that three CPython / torch internals stay as they
+                        # are. The native executor, the default path, never needed it.)
+                        t.record_stream(main)
             self.cacheGrids_, self.cacheNeighs_, self.cachePDFs_ = grids, neighs, pdfs
         if torch.cuda.is_available():
             self.resetEvent_ = torch.cuda.Event()
@@ -455,53 +429,6 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                                                   neighs[kN][0], neighs[kN][1], mn, mx, g[0].shape[0], centres.shape[0],
                                                   neighs[kN][1].shape[0], B, radius, rel, self.useAVG_)
             self.prefetchTransposed_ = {}
-
-    def __retire_side_tensors__(self):
-        """Lifetime of the tensors prefetch_geometry() allocated on the side stream and the main stream reads.
-        Tensor.record_stream() would make the allocator record one event per block on the main stream when the block is
-        freed -- 8 blocks x 5.5 us of main-queue time between the backward pass of one step and the forward pass of the
-        next (0.66 -> 0.63 ms per step on the 100k room). Instead the builder is their last owner: it drops them HERE,
-        before reset() records the event every later piece of side-stream work waits for, so whatever reuses their memory
-        (only side-stream allocations can) runs after everything the main stream had been given by now. A tensor somebody
-        else still holds at this point (an autograd graph kept alive, a user variable) may get more readers later: that
-        one falls back to record_stream()."""
-        tensors, self.sideTensors_ = self.sideTensors_, []
-        if not tensors:
-            return
-        main = torch.cuda.current_stream()
-        extra = []
-        for t in tensors:  # the transposed lists / row plans built on the side stream live (and die) with their neighbour list
-            hit = getattr(t, "_mccnn_transposed", None)
-            if hit is not None:
-                extra.extend(hit[:2])
-            for pl in (getattr(t, "_mccnn_rowplans", None) or {}).values():
-                if getattr(pl, "event", None) is not None:  # built on the side stream (prefetch_rowplan)
-                    pl.row_start = None
-                    extra.append(pl.buf)
-                    pl.buf = None
-                    # the entry stays in the list's dictionary but can never be a cache hit again: a list that outlives
-                    # this reset() (a graph kept for a later backward pass) rebuilds its plan instead of sweeping freed
-                    # memory through the stale addresses
-                    pl.key = None
-                    pl.vrow = pl.vcode = pl.slice_off = pl.vpos_row = pl.rec = pl.other = 0
-        self.cacheGrids_ = self.cacheNeighs_ = self.cachePDFs_ = None  # the cache dictionaries' references go first
-        # Is the builder the LAST owner? Exactly three counts answer that, and a build of torch that lacks one of them
-        # takes the always-correct record_stream() path: Python references to the tensor object (this frame + the
-        # probe's argument), C++ references to its TensorImpl (the Python object; a view of it holds one more), and
-        # TensorImpls over its STORAGE (views made by anybody: packed = buf[:e], a user's slice of a cached list).
-        probe = hasattr(torch.Tensor, "_use_count") and _storage_baseline() > 0
-        base = _storage_baseline()
-        while tensors:
-            t = tensors.pop()
-            if not probe or sys.getrefcount(t) > 2 or t._use_count() > 1 or (_storage_users(t) or base + 1) > base:
-                t.record_stream(main)
-                self.sideRecorded_ += 1
-            del t
-        for t in extra:
-            if not probe or t._use_count() > 1 or (_storage_users(t) or base + 1) > base:
-                t.record_stream(main)
-                self.sideRecorded_ += 1
-        del extra
 
     def prefetch_geometry(self, inPointHierarchy, inPointLevel, convRadius, outPointHierarchy=None, outPointLevel=None,
                           KDEWindow=None, relativeRadius=None, usePDF=None, transposed=False):

@@ -283,9 +283,8 @@ def _transposed_neighbors(packed, n):
         ev = getattr(packed, "_mccnn_transposed_event", None)
         if ev is not None:  # built ahead of time on another stream (prefetch_transposed): order this stream behind it
             torch.cuda.current_stream().wait_event(ev)
-            if _env.debug("record_stream", False):
-                for t in hit[:2]:
-                    t.record_stream(torch.cuda.current_stream())
+            for t in hit[:2]:   # allocated on that stream, read on this one
+                t.record_stream(torch.cuda.current_stream())
             # the event stays with the list: a later consumer on another stream has to wait for it, too (waiting for an
             # event that has fired costs nothing on the queue)
         return hit
@@ -357,6 +356,7 @@ def _row_plan(packed_obj, transposed, pts, bids, pdfs, smp, st, pk, mn, mx, n, m
     if hit is not None and hit.key == key:
         if hit.event is not None:  # built ahead of time on another stream (prefetch_rowplan): order this stream behind it
             torch.cuda.current_stream().wait_event(hit.event)
+            hit.buf.record_stream(torch.cuda.current_stream())   # ... and its memory behind this stream's sweeps
         return hit
     lib = _lib.load()
     dev = pk.device
@@ -601,9 +601,7 @@ def build_grid(inPts, inBatchIds, aabbMin, aabbMax, batchSize, cellSize, scaleIn
     cells = torch.empty((batchSize, nc, nc, nc, 2), dtype=torch.int32, device=dev)
     check(lib.mccnn_build_grid(ptr(pts), ptr(bids), ptr(mn), ptr(mx), n, batchSize, nc, ptr(idx), ptr(oP), ptr(oB), ptr(cells),
                                ptr(inv), ptr(ws), ws.numel(), stream_handle()), "build_grid")
-    # a weak reference: the grid tuple owns the permutation (a strong one here would make this cache a co-owner of a
-    # tensor the builder's side-stream bookkeeping wants to be the last owner of: record_stream() fallback on every step
-    # whose next batch has other points)
+    # a weak reference: the grid tuple owns the permutation
     _remember_order(inPts, "order_weak", weakref.ref(inv))
     return oP, oB, cells, idx, inv
 
@@ -1271,7 +1269,7 @@ class _SpatialConv(torch.autograd.Function):
         ctx.state = state
         # the builder's cached tensor OBJECT carries the transposed list (see _transposed_neighbors). A weak reference: the
         # graph object outlives its backward pass (as long as the caller keeps the output or the loss), and a strong one
-        # would make the graph a co-owner of the list for that long (ConvolutionBuilder.__retire_side_tensors__)
+        # would keep the list (and its transposed form and plans) alive for that long
         ctx.packed_ref = weakref.ref(packedNeighs if pk is packedNeighs else pk)
         ctx.attrs = (numOutFeatures, bool(combin), batchSize, float(radius), bool(scaleInv), bool(avg))
         return out

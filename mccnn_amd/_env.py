@@ -13,7 +13,7 @@ the library (csrc/debug_opts.h names the library's keys):
     MCCNN_DEBUG="key=value,key,..."      (a bare key means key=1; read once per process)
 
 Python-side keys (default): fuse_sort (1), native_prefetch (1), plan_prefetch (1), plan_prefetch_max_e (1e12),
-geo_prefetch_min (5), record_stream (0), mailbox_copy (0), count_mailbox (1), ecap_scale (1), hier_pmode (1),
+geo_prefetch_min (5), mailbox_copy (0), count_mailbox (1), ecap_scale (1), hier_pmode (1),
 rows_min_degree (16), unsorted_max_points (32768), geo_trace (0).
 (MCCNN_LIB_NAME / MCCNN_EXTRA_FLAGS belong to mccnn_amd.build: A/B builds of the library.)"""
 import os

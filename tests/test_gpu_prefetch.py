@@ -284,10 +284,9 @@ def test_pipeline_over_changing_batches(mc, protocol):
 
 
 def test_side_stream_tensor_lifetime(mc):
-    """The prefetched tensors are allocated on the side stream and read on the main one. In the plain training loop the
-    builder is their last owner and drops them inside reset() (no record_stream(), no allocator events on the main
-    queue); a tensor that somebody else still holds at that point -- here: an autograd graph that has not run its
-    backward pass yet -- falls back to record_stream()."""
+    """The prefetched tensors are allocated on the side stream and read on the main one (op-by-op protocol): their memory is
+    handed to the allocator with record_stream(), so a reader that comes late -- here: an autograd graph that runs its
+    backward pass after the next reset() -- still finds its lists intact; plain loops and changing batches first."""
     import torch
     from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
     pts, bids = make_cloud(2000, 2, 41, "uniform", True)
@@ -307,15 +306,14 @@ def test_side_stream_tensor_lifetime(mc):
     ref = conv()
     ref.backward(og)
     ref_grad = F.grad.clone()
-    for _ in range(4):                      # the plain loop: nothing needs the fallback
+    for _ in range(4):                      # the plain loop
         builder.prefetch_geometry(ph, 0, 0.15)
         builder.reset()
         F.grad = None
         out = conv()
         out.backward(og)
         assert torch.equal(out.detach(), ref.detach())
-    assert builder.sideRecorded_ == 0
-    # ... nor when the batches CHANGE (the visiting-order hint of the previous batch's points must not co-own its grid)
+    # ... and with batches that CHANGE
     pts2, bids2 = make_cloud(1500, 2, 42, "clustered", True)
     F2 = torch.from_numpy(rng.random((len(pts2), 1), dtype=np.float32)).cuda().requires_grad_(True)
     ph2 = PointHierarchy(torch.from_numpy(pts2).cuda(), F2, torch.from_numpy(bids2).cuda(), [], "PH2", 2, True)
@@ -327,14 +325,12 @@ def test_side_stream_tensor_lifetime(mc):
         Fn.grad = None
         o2 = builder.create_convolution("Conv", nxt, 0, Fn, 1, 0.15, outNumFeatures=16, multiFeatureConv=True)
         o2.backward(ogn)
-    assert builder.sideRecorded_ == 0
     builder.prefetch_geometry(ph, 0, 0.15)
     builder.reset()
     F.grad = None
     late = conv()                           # graph kept alive across the next reset(): it still owns the lists
     builder.prefetch_geometry(ph, 0, 0.15)
     builder.reset()
-    assert builder.sideRecorded_ > 0
     late.backward(og)                       # reads the retired lists AFTER the reset
     assert torch.equal(late.detach(), ref.detach())
     assert float((F.grad - ref_grad).abs().max()) <= 1e-5 * float(ref_grad.abs().max())
