@@ -1052,7 +1052,9 @@ std::atomic<int>& conv_impl_override() {
 }
 
 bool transpose_small(int e, int n) {
-    return e <= MCCNN_TR_SMALL_E && n <= MCCNN_TR_SMALL_N && (long long)e * e / n <= (4LL << 20) && small_kernels_on();
+    // (the rank phase of tr_small is quadratic in the row length: e * e / n bounds the work of the worst case -- all edges on
+    // one row -- to ~1 M compares spread over 1 024 threads, a few microseconds)
+    return e <= MCCNN_TR_SMALL_E && n <= MCCNN_TR_SMALL_N && (long long)e * e / n <= (1LL << 20) && small_kernels_on();
 }
 // The first half of a transposition (large lists), shared with the fused plan build of conv_rows.hip: row counts with
 // every edge's arrival slot, their prefix sums (start_t[n] = e). blk = [align_up(4 n) counters][scan workspace].
