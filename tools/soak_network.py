@@ -100,6 +100,7 @@ bad = torch.zeros((), dtype=torch.int64, device=dev)
 worst = torch.zeros((), dtype=torch.float32, device=dev)
 TRACE = torch.zeros((STEPS, len(cfg.convs)), dtype=torch.int64, device=dev) if os.environ.get("SOAK_TRACE") else None
 DEEP = os.environ.get("SOAK_DEEP", "0") == "1"   # hierarchy two batches ahead + ConvolutionBuilder.prefetch_step for the next
+ADOPT_FIRST = os.environ.get("SOAK_ADOPT_FIRST", "0") == "1"
 ahead = batches[order[0]].request()
 if DEEP:
     ready = batches[order[0]].hierarchy(ahead)
@@ -117,9 +118,17 @@ for s in range(STEPS):
             if s + 1 < STEPS:
                 state["nxt"] = batches[order[s + 1]].hierarchy(ahead)
                 builder.prefetch_step(state["nxt"])
-        outs, grads = step(builder, b, ready=ready, then=start_next)
-        ready = state.get("nxt")
-        ahead = batches[order[s + 2]].request() if s + 2 < STEPS else None
+        if ADOPT_FIRST:   # examples/mcclass_s.py's order: next hierarchy adopted and the one after it requested BEFORE reset()'s wait
+            if s + 1 < STEPS:
+                state["nxt"] = batches[order[s + 1]].hierarchy(ahead)
+            ahead = batches[order[s + 2]].request() if s + 2 < STEPS else None
+            outs, grads = step(builder, b, ready=ready,
+                               then=(lambda: builder.prefetch_step(state["nxt"])) if "nxt" in state else None)
+            ready = state.get("nxt")
+        else:
+            outs, grads = step(builder, b, ready=ready, then=start_next)
+            ready = state.get("nxt")
+            ahead = batches[order[s + 2]].request() if s + 2 < STEPS else None
     else:
         cur, ahead = ahead, (batches[order[s + 1]].request() if s + 1 < STEPS else None)
         outs, grads = step(builder, b, cur)

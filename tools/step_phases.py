@@ -21,10 +21,16 @@ N = 60
 
 def step(rec):
     t = [time.perf_counter()]
-    cw.builder.reset(); t.append(time.perf_counter())
-    ph = cw.ph = cw.ready_ph
-    nxt = cw.hierarchy(cw.next_ph); t.append(time.perf_counter())
-    cw.request_next(); t.append(time.perf_counter())
+    if os.environ.get("REORDER") == "1":   # A/B: adopt the next hierarchy and request the one after it BEFORE reset()'s wait
+        ph = cw.ph = cw.ready_ph
+        nxt = cw.hierarchy(cw.next_ph)
+        cw.request_next()
+        cw.builder.reset(); t.append(time.perf_counter()); t.append(time.perf_counter()); t.append(time.perf_counter())
+    else:
+        cw.builder.reset(); t.append(time.perf_counter())
+        ph = cw.ph = cw.ready_ph
+        nxt = cw.hierarchy(cw.next_ph); t.append(time.perf_counter())
+        cw.request_next(); t.append(time.perf_counter())
     cw.builder.prefetch_step(nxt); t.append(time.perf_counter())
     cw.ready_ph = nxt
     e0 = torch.cuda.Event(enable_timing=True); e0.record()
