@@ -451,6 +451,11 @@ __global__ __launch_bounds__(256) void edge_records(ConvArgs a, float4* __restri
 // slicing: 297 us), dynamic LDS beyond ~20 KB per workgroup another 25-35 even when nothing touches it, and neither the
 // atomics nor the LDS updates show up in ablation builds (434 / 437 us without them): the rest is the sweep itself
 // compiled in its 18 (fin, first neuron, last block) forms at the 256-register limit.)
+// (Round 5, second form, also dropped: the plane form's slicing with ONE read-modify-write plane and the last block adding
+// the finished sums to featGrad with returnless atomics: sweep 289 -> 434 us against 289 + 130 (scatter_edge_featgrad);
+// atomics from every block, no plane at all: 765 us. Float atomics to random rows retire at ~100 G/s on this part --
+// 13.6 M of them are 130-145 us wherever they are issued; hoisting the plane read above the MFMA chains costs 150
+// more spill instructions and 60 us.)
 #define MCCNN_DF_PLANES 4
 static inline int df_planes(int Fin, int nb) { return (Fin >= 2 && Fin <= 4 && nb <= MCCNN_DF_PLANES) ? nb : 1; }
 // Waves own equal, contiguous EDGE ranges (cpw chunks of 64 edges each): nothing in the backward pass needs
