@@ -7,6 +7,7 @@
 // mccnn_amd/build.py with g++ against the torch headers (host code only, no kernels here); mccnn_amd/native.py falls
 // back to the ctypes form of the same calls when this module is not built.
 #include <torch/extension.h>
+#include <execinfo.h>
 #include <torch/csrc/autograd/function.h>
 #include <torch/csrc/autograd/functions/utils.h>
 #include <torch/csrc/autograd/saved_variable.h>
@@ -225,21 +226,26 @@ public:
     }
     int which_ = 0;
     void push(std::function<void()> job) {
-        if (inline_jobs(which_)) {
-            job();
-            return;
-        }
-        {
+        bool queued = false;
+        if (!inline_jobs(which_)) {
             std::lock_guard<std::mutex> lk(m_);
-            if (!started_) {
-                th_ = std::thread([this] { run(); });
-                started_ = true;
+            if (!stop_) {   // (retired: the job runs on the caller's thread)
+                if (!started_) {
+                    th_ = std::thread([this] { run(); });
+                    started_ = true;
+                }
+                q_.push_back(std::move(job));
+                queued = true;
             }
-            q_.push_back(std::move(job));
         }
-        cv_.notify_one();
+        if (queued) cv_.notify_one();
+        else job();
     }
-    ~Issuer() {
+    // Runs the queued jobs to the end and joins the thread; later jobs run on the caller's thread. Called from Python's
+    // atexit (shutdown_helpers): a job -- or its destruction -- may drop the last reference to a tensor that has a Python
+    // object, which takes the GIL; on a helper thread during interpreter finalisation that attempt ends the thread with a
+    // forced unwind (std::terminate). After this no helper thread exists that could hold such a reference.
+    void retire() {
         {
             std::lock_guard<std::mutex> lk(m_);
             stop_ = true;
@@ -247,6 +253,7 @@ public:
         cv_.notify_all();
         if (started_ && th_.joinable()) th_.join();
     }
+    ~Issuer() { retire(); }
 
 private:
     void run() {
@@ -1092,6 +1099,14 @@ std::shared_ptr<HierFuture> hierarchy_prefetch(const Tensor& pts, const Tensor& 
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
     mod.doc() = "PyTorch-ROCm side of the native step executor of libmccnn_hip.so";
+    if (mccnn::debug_int("trace_terminate", 0)) {   // debugging: where std::terminate was called from
+        std::set_terminate([] {
+            void* frames[64];
+            const int n = backtrace(frames, 64);
+            backtrace_symbols_fd(frames, n, 2);
+            abort();
+        });
+    }
     static py::exception<CapacityError> cap_exc(mod, "CapacityError");
     py::register_exception_translator([](std::exception_ptr p) {
         try {
@@ -1137,5 +1152,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
         .def("result", &HierFuture::result)
         .def("done", [](HierFuture& f) { return f.done.load(std::memory_order_acquire) != 0; });
     mod.def("hierarchy_prefetch", &hierarchy_prefetch, py::call_guard<py::gil_scoped_release>());
+    mod.def("shutdown_helpers", [] { for (int k = 0; k < 3; ++k) Issuer::get(k).retire(); },
+            py::call_guard<py::gil_scoped_release>());
     mod.def("wait_ns", [] { return (long long)g_wait_ns.load(std::memory_order_relaxed); });
 }

@@ -42,6 +42,13 @@ def _load_ext():
 
 
 _EXT = _load_ext()
+if _EXT is not None:
+    # The extension's helper threads hold tensors that have Python objects; dropping the last reference to one takes the
+    # GIL, and a non-main thread that asks for it while the interpreter finalises is ended by Python with a forced unwind
+    # (std::terminate: "terminate called without an active exception" at the end of a script that stops with prefetched
+    # work in flight). Before finalisation starts the queued jobs are run to the end and the threads joined.
+    import atexit
+    atexit.register(_EXT.shutdown_helpers)
 
 E_CAPACITY = -6
 NEED_PLAN_FWD, NEED_PLAN_TR, NEED_TLIST, NEED_RECORDS = 1, 2, 4, 8

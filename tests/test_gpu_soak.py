@@ -39,3 +39,17 @@ def test_room_network_soak_with_changing_room_sizes(mc):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     m = re.search(r"forward mismatches (\d+), worst relative gradient deviation (\S+),", out.stdout)
     assert m and int(m.group(1)) == 0 and float(m.group(2)) < 1e-4, out.stdout
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
+def test_script_that_ends_with_prefetched_work_in_flight(mc, cfg):
+    """A script whose last steps start the next batch's hierarchy, geometry and row plans and never consume them: the helper
+    threads still hold tensors with Python objects when the interpreter finalises. Dropping those takes the GIL, which
+    Python answers with a forced unwind of the thread (std::terminate, a core dump after the script's last line) -- the
+    extension's helpers are drained and joined from atexit instead (native.py, Issuer::retire in csrc/torch_ext.cpp)."""
+    env = dict(os.environ, NOCONV="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_phases.py"), cfg, "1"], env=env, capture_output=True,
+                         text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, "rc %d\n" % out.returncode + out.stdout[-1500:] + out.stderr[-1500:]
+    assert "terminate called" not in out.stderr, out.stderr[-1500:]
+    assert "ms/step" in out.stdout

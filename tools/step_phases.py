@@ -17,6 +17,7 @@ cw.builder.hostStepsAhead_ = (lag - 1) if lag else None
 ph_t = {k: 0.0 for k in ("reset", "adopt", "request", "prefetch", "fwd", "bwd")}
 ev = []
 N = 60
+NOCONV = os.environ.get("NOCONV") == "1"
 
 
 def step(rec):
@@ -34,8 +35,11 @@ def step(rec):
     cw.builder.prefetch_step(nxt); t.append(time.perf_counter())
     cw.ready_ph = nxt
     e0 = torch.cuda.Event(enable_timing=True); e0.record()
-    outs = [cw.conv(ph, ci) for ci in range(len(cw.cfg.convs))]; t.append(time.perf_counter())
-    cw.grads = torch.autograd.grad(outs, cw.feats + cw.params, cw.ogs, allow_unused=True); t.append(time.perf_counter())
+    if NOCONV and rec:   # the side chains alone: hierarchy two ahead + the next batch's geometry, no layer consumes them
+        t.append(time.perf_counter()); t.append(time.perf_counter())
+    else:
+        outs = [cw.conv(ph, ci) for ci in range(len(cw.cfg.convs))]; t.append(time.perf_counter())
+        cw.grads = torch.autograd.grad(outs, cw.feats + cw.params, cw.ogs, allow_unused=True); t.append(time.perf_counter())
     e1 = torch.cuda.Event(enable_timing=True); e1.record()
     if rec:
         for k, a, b in zip(ph_t, t[:-1], t[1:]):
