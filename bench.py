@@ -518,7 +518,9 @@ class ConfigWorkload:
 
     def request_next(self):
         from mccnn_amd.MCConvBuilder import PointHierarchy
-        self.next_ph = PointHierarchy.prefetch(self.P, self.Bi, list(self.cfg.hierarchy), self.B, self.cfg.relative)
+        # after=True: the synthetic batch has been resident in HBM since before the timed region -- its hierarchy does not
+        # queue behind the convolutions the calling stream holds (a loader would pass the event of its upload stream)
+        self.next_ph = PointHierarchy.prefetch(self.P, self.Bi, list(self.cfg.hierarchy), self.B, self.cfg.relative, after=True)
         return self.next_ph is not None
 
     def set_pipeline(self, on, geometry=False):

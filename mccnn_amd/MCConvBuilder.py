@@ -132,19 +132,21 @@ class PointHierarchy(_PlainState, torch.nn.Module):
     """
 
     @staticmethod
-    def prefetch(inPoints, inBatchIds, radiusList, batchSize=32, relativeRadius=True):
+    def prefetch(inPoints, inBatchIds, radiusList, batchSize=32, relativeRadius=True, after=None):
         """Extension (no counterpart in the reference): starts the geometry of a hierarchy -- the boxes and every level's
         Poisson-disk samples, which depend on the points only -- on a stream of its own, issued by a helper thread, and
         returns a handle for `PointHierarchy(..., prefetched=handle)`. In a training loop: request the hierarchy of batch
         k + 1 right after the one of batch k has been constructed; its chain of small dependent kernels and its two
         read-backs then run under the convolutions of batch k instead of in front of those of batch k + 1, and the calling
         thread never waits for the device. The build starts behind what the calling stream holds at the moment of the call
-        (the upload of the batch). Returns None when there is nothing to run ahead (host tensors, no extension): the
-        constructor then builds inline, as without the argument."""
+        (the upload of the batch) -- or, for a loader that uploads on a stream of its own, behind the torch.cuda.Event it
+        recorded there (after=event), or at once (after=True: points and batch ids are complete); the calling stream may
+        hold a whole step of convolutions by then, which such a hierarchy no longer queues behind. Returns None when there
+        is nothing to run ahead (host tensors, no extension): the constructor then builds inline, as without the argument."""
         from . import MCConvModule as _M
         if not FUSED_HIERARCHY or not poisson_sampling.__module__.endswith("MCConvModule"):
             return None
-        fut = _M.point_hierarchy_prefetch(inPoints, inBatchIds, list(radiusList), batchSize, relativeRadius)
+        fut = _M.point_hierarchy_prefetch(inPoints, inBatchIds, list(radiusList), batchSize, relativeRadius, after)
         if fut is None:
             return None
         return _PrefetchedHierarchy(fut, inPoints, inBatchIds, radiusList, batchSize, relativeRadius)
@@ -162,6 +164,7 @@ class PointHierarchy(_PlainState, torch.nn.Module):
         super().__init__()
         ops = _Ops(ops)
         self.readyEvent_ = None
+        self.prefetchFuture_ = None
         self.points_ = [inPoints]
         self.features_ = [inFeatures]
         self.batchIds_ = [inBatchIds]
@@ -230,6 +233,8 @@ class PointHierarchy(_PlainState, torch.nn.Module):
         aabbMin, aabbMax, extent, levels = prefetched.future.result()   # (its wait is counted by the extension: wait_ns)
         if not levels:
             return False
+        # (geometry builds over this hierarchy on side streams wait for THIS, not for the calling stream: native.build_geometry)
+        self.prefetchFuture_ = prefetched.future
         self.aabbMin_, self.aabbMax_ = aabbMin, aabbMax
         if not self.relativeRadius_:
             _M._seed_num_cells(aabbMin, aabbMax, extent)
@@ -601,7 +606,8 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                 owner = g2
         k = len(self.prefetchedGeo_)
         geo = _native.build_geometry(inPts, inBids, centres, cBids, mn, mx, B, nc, convRadius, relativeRadius, KDEWindow,
-                                     usePDF, owner, side=k, fork=fork, background=True)
+                                     usePDF, owner, side=k, fork=fork, background=True,
+                                     after=(inPH.prefetchFuture_ if inPH is outPH else None))
         geo.uses = 0
         if pieces:   # row plans / transposed list the layers of the last step used: attached and issued by a helper thread
             geo.prebuild_async(pieces, self.useAVG_)
@@ -684,7 +690,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
             nc = _hip_ops._num_cells(mn, mx, B, radius, rel)
             owner = self.cacheGeoGrid_.get(keyGrid)
             geo = _native.build_geometry(inPts, inBids, centres, cBids, mn, mx, B, nc, radius, rel, window, usePDF, owner,
-                                         side=k, fork=(k == 0))
+                                         side=k, fork=(k == 0), after=ph.prefetchFuture_)
             k += 1
             geo.uses = 0
             if have and pieces and geo.e_cap <= _PLAN_PREFETCH_MAX_E:

@@ -995,12 +995,13 @@ def _torch_ext():
     return native._EXT
 
 
-def point_hierarchy_prefetch(inPts, inBatchIds, radiusList, batchSize, scaleInv):
+def point_hierarchy_prefetch(inPts, inBatchIds, radiusList, batchSize, scaleInv, after=None):
     """Boxes and level geometry of a point hierarchy (compute_aabb + point_hierarchy_levels) started on a stream of its own,
     issued by a helper thread of the PyTorch-ROCm extension (csrc/torch_ext.cpp: hierarchy_prefetch): the call returns at once
     with a future, `future.result()` -> (aabbMin, aabbMax, extent, levels) orders the calling stream behind the build. The
-    build starts behind what the calling stream holds NOW. None when the extension (or the single-launch Poisson form) is
-    not available -- the caller then builds the hierarchy inline."""
+    build starts behind what the calling stream holds NOW (after=None), at once (after=True: the inputs are complete) or
+    behind a torch.cuda.Event (after=event: the upload's stream recorded it). None when the extension (or the single-launch
+    Poisson form) is not available -- the caller then builds the hierarchy inline."""
     ext = _torch_ext()
     if ext is None or not POISSON_DATAFLOW or len(radiusList) == 0 or not getattr(inPts, "is_cuda", False):
         return None
@@ -1015,7 +1016,13 @@ def point_hierarchy_prefetch(inPts, inBatchIds, radiusList, batchSize, scaleInv)
     for radius in radiusList:
         _req(radius > 0.0, op + " expects positive radii")
     pmode = 2 if POISSON_DATAFLOW == 2 else _env.debug("hier_pmode", 1)
-    return ext.hierarchy_prefetch(pts, bids, [float(r) for r in radiusList], int(batchSize), bool(scaleInv), pmode)
+    mode, handle = 0, 0
+    if after is True:
+        mode = 1
+    elif after is not None and after is not False:
+        _req(isinstance(after, torch.cuda.Event), op + ".prefetch: `after` is None, True or a torch.cuda.Event")
+        mode, handle = 2, int(after.cuda_event)
+    return ext.hierarchy_prefetch(pts, bids, [float(r) for r in radiusList], int(batchSize), bool(scaleInv), pmode, mode, handle)
 
 
 def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batchSize, scaleInv):

@@ -12,6 +12,8 @@
 #include <torch/csrc/autograd/functions/utils.h>
 #include <torch/csrc/autograd/saved_variable.h>
 #include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
@@ -60,6 +62,10 @@ struct DevGuard {
 };
 
 void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+// a raw stream as PyTorch's allocator knows it (pool selection: HIPStreamGuard; consumers: Tensor::record_stream)
+c10::Stream as_torch_stream(void* s, int dev) {
+    return c10::hip::getStreamFromExternalMasqueradingAsCUDA((hipStream_t)s, (c10::DeviceIndex)dev).unwrap();
+}
 
 hipEvent_t take_event_fwd();
 void give_event_fwd(hipEvent_t e);
@@ -294,6 +300,12 @@ struct Geo {
     bool needs_wait = false;
     int side = -1;                 // index of the side stream the build ran on (-1: the caller's stream)
     void* alloc_stream = nullptr;  // the stream the buffers were allocated on (the caller's at build time)
+    // own_pool: `buf` and the prebuilt pieces come from the caching allocator's pool of the build's OWN side stream (a
+    // block it hands out was last used on that stream: the build needs no ordering behind the calling stream for its
+    // memory) and the build waits for the event of the prefetched hierarchy it reads instead of for everything the
+    // calling stream holds -- the next batch's geometry then starts when it is asked for, not when the device has
+    // finished the step in flight. Every stream that joins the build is made known to the allocator (record_stream).
+    bool own_pool = false;
     Tensor buf, slot;
     std::vector<Tensor> keep, attached;
     std::shared_ptr<Geo> grid_owner;
@@ -335,17 +347,26 @@ struct Geo {
     // second stage: both write the shared records. A backward pass waits for both.
     void join(void* stream, bool everything = true) {
         wait_issued();
+        bool joined = false;
         if (needs_wait && event) {
             hip_check(hipStreamWaitEvent((hipStream_t)stream, event, 0), "hipStreamWaitEvent");
             needs_wait = false;
+            joined = true;
         }
         if (plan_wait && plan_event) {
             hip_check(hipStreamWaitEvent((hipStream_t)stream, plan_event, 0), "hipStreamWaitEvent");
             plan_wait = false;
+            joined = true;
         }
         if (tr_wait && tr_event && (everything || !(have & 1))) {
             hip_check(hipStreamWaitEvent((hipStream_t)stream, tr_event, 0), "hipStreamWaitEvent");
             tr_wait = false;
+            joined = true;
+        }
+        if (joined && own_pool && stream != alloc_stream && buf.defined()) {
+            const c10::Stream consumer = as_torch_stream(stream, (int)buf.device().index());
+            buf.record_stream(consumer);
+            for (Tensor& t : attached) t.record_stream(consumer);
         }
     }
     ~Geo() {
@@ -353,6 +374,10 @@ struct Geo {
         const bool total_pending = slot.defined() && e.load(std::memory_order_relaxed) < 0 &&
                                    *reinterpret_cast<volatile int*>(slot.data_ptr()) < 0;
         hipEvent_t slot_ev = nullptr;
+        // a grid shared from a geometry on ANOTHER side stream's pool: its memory may go back to that pool right after this
+        // (the owner outlives its users), and this build's reads of it are ordered on this stream only
+        if (event && build_rc == 0 && side >= 0 && grid_owner && grid_owner->own_pool && grid_owner->side != side)
+            (void)hipStreamWaitEvent((hipStream_t)grid_owner->alloc_stream, event, 0);
         if (event) {
             // never consumed: the buffers go back to the allocator of the stream they were taken on -- order that
             // stream behind the build first, or the next owner of the memory could race with it
@@ -436,7 +461,13 @@ struct Geo {
             if (!(what & bit)) continue;
             long long bytes = 0, w = 0;
             check(mccnn_geometry_piece_bytes(h, bit, &bytes, &w), "geometry_piece_bytes");
-            Tensor t = at::empty({(int64_t)(bytes > 256 ? bytes : 256)}, like.options().dtype(at::kByte));
+            Tensor t;
+            if (own_pool) {   // (with the geometry's buffer: one pool, one stream to order the memory on)
+                const c10::hip::HIPStreamGuardMasqueradingAsCUDA own(as_torch_stream((void*)ss, (int)like.device().index()));
+                t = at::empty({(int64_t)(bytes > 256 ? bytes : 256)}, like.options().dtype(at::kByte));
+            } else {
+                t = at::empty({(int64_t)(bytes > 256 ? bytes : 256)}, like.options().dtype(at::kByte));
+            }
             check(mccnn_geometry_attach(h, bit, t.data_ptr(), (size_t)t.numel()), "geometry_attach");
             attached.push_back(std::move(t));
             have |= bit;
@@ -445,10 +476,12 @@ struct Geo {
         Tensor& ws = scratch(wsb, like, (void*)ss);
         // the side stream starts behind the calling stream (the memory just allocated may have had readers there) and,
         // being the build's own stream, behind the geometry itself
-        static thread_local hipEvent_t fork_ev = nullptr;
-        if (!fork_ev) hip_check(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming), "hipEventCreate");
-        hip_check(hipEventRecord(fork_ev, (hipStream_t)main_stream), "hipEventRecord");
-        hip_check(hipStreamWaitEvent(ss, fork_ev, 0), "hipStreamWaitEvent");
+        if (!own_pool) {
+            static thread_local hipEvent_t fork_ev = nullptr;
+            if (!fork_ev) hip_check(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipEventRecord(fork_ev, (hipStream_t)main_stream), "hipEventRecord");
+            hip_check(hipStreamWaitEvent(ss, fork_ev, 0), "hipStreamWaitEvent");
+        }
         if (event && side < 0) hip_check(hipStreamWaitEvent(ss, event, 0), "hipStreamWaitEvent");
         check(issue_pieces(what & 7, avg, ss, ws.data_ptr(), (size_t)ws.numel()), "geometry_prebuild");
     }
@@ -474,10 +507,14 @@ void check_dev(const Tensor& t, at::ScalarType dt, const char* name) {
                 ": expected a contiguous device tensor of the op's type");
 }
 
+struct HierFuture;
+// the event recorded behind an ADOPTED prefetched hierarchy (nullptr: not adopted, failed, none)
+hipEvent_t hierarchy_ready_event(const std::shared_ptr<HierFuture>& f);
+
 std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const Tensor& centres, const Tensor& cbids,
                                     const Tensor& mn, const Tensor& mx, int64_t B, int64_t nc, double radius, bool scale_inv,
                                     double window, bool use_pdf, int64_t capacity, std::shared_ptr<Geo> grid_from,
-                                    int64_t side, bool fork, bool background) {
+                                    int64_t side, bool fork, bool background, std::shared_ptr<HierFuture> after) {
     check_dev(pts, at::kFloat, "points");
     check_dev(centres, at::kFloat, "sample points");
     check_dev(bids, at::kInt, "batch ids");
@@ -493,15 +530,40 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
     g->h = mccnn_geometry_create();
     TORCH_CHECK(g->h, "mccnn_geometry_create failed");
     g->slot = take_slot();
-    g->buf = at::empty({(int64_t)bytes}, pts.options().dtype(at::kByte));
     g->keep = {pts, bids, centres, cbids, mn, mx};
     g->grid_owner = grid_from;
     g->n = n; g->m = m; g->nc = (int)nc; g->B = (int)B; g->e_cap = capacity;
     void* stream = cur_stream(pts);
     g->alloc_stream = stream;
-    if (side >= 0) {
-        // a geometry that shares another one's grid runs behind it on the same side stream
-        if (grid_from && grid_from->side >= 0 && grid_from->needs_wait) side = grid_from->side;
+    // a geometry that shares another one's grid runs behind it on the same side stream
+    if (side >= 0 && grid_from && grid_from->side >= 0 && grid_from->needs_wait) side = grid_from->side;
+    // Everything this build reads is the adopted prefetched hierarchy `after` (its points, batch ids, boxes -- and a grid
+    // that was itself built this way): the build then waits for THAT, takes its memory from its own stream's pool and
+    // starts now, not behind what the calling stream holds (Geo::own_pool).
+    static const bool own_pools = mccnn::debug_int("geo_own_pool", 1) != 0;
+    hipEvent_t ready = (side >= 0 && own_pools && Issuer::enabled()) ? hierarchy_ready_event(after) : nullptr;
+    if (ready && grid_from && !grid_from->own_pool) ready = nullptr;
+    // (a build that takes the fork path after one that did not: the caller's fork=false refers to a record that was skipped)
+    static thread_local bool fork_skipped = false;
+    if (ready && side_stream((int)side)) {
+        hipStream_t ss = side_stream((int)side);
+        if (fork) fork_skipped = true;
+        {
+            const c10::hip::HIPStreamGuardMasqueradingAsCUDA own(as_torch_stream((void*)ss, (int)pts.device().index()));
+            g->buf = at::empty({(int64_t)bytes}, pts.options().dtype(at::kByte));
+        }
+        g->own_pool = true;
+        g->alloc_stream = (void*)ss;
+        hip_check(hipStreamWaitEvent(ss, ready, 0), "hipStreamWaitEvent");
+        const int sk = (int)(((side % kSideStreams) + kSideStreams) % kSideStreams);
+        if (grid_from && grid_from->event && grid_from->side != sk) {
+            grid_from->wait_issued();
+            hip_check(hipStreamWaitEvent(ss, grid_from->event, 0), "hipStreamWaitEvent");
+        }
+        g->side = sk;
+        stream = ss;
+    } else if (side >= 0) {
+        g->buf = at::empty({(int64_t)bytes}, pts.options().dtype(at::kByte));
         hipStream_t ss = side_stream((int)side);
         if (ss) {
             // the side stream starts behind everything the calling stream held at the last fork (the point hierarchy;
@@ -512,7 +574,8 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
                 hip_check(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming), "hipEventCreate");
                 fork = true;
             }
-            if (fork) hip_check(hipEventRecord(fork_ev, (hipStream_t)stream), "hipEventRecord");
+            if (fork || fork_skipped) hip_check(hipEventRecord(fork_ev, (hipStream_t)stream), "hipEventRecord");
+            fork_skipped = false;
             hip_check(hipStreamWaitEvent(ss, fork_ev, 0), "hipStreamWaitEvent");
             // (a grid owner on another side stream -- its build has been joined by the caller's stream already, or it
             // would have pulled this build onto its own stream above: order this stream behind it without consuming the
@@ -524,8 +587,9 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
             g->side = (int)(((side % kSideStreams) + kSideStreams) % kSideStreams);
             stream = ss;
         }
-    } else if (grid_from) {
-        grid_from->join(stream);
+    } else {
+        g->buf = at::empty({(int64_t)bytes}, pts.options().dtype(at::kByte));
+        if (grid_from) grid_from->join(stream);
     }
     if (g->side >= 0 && Issuer::enabled()) {
         // the helper thread issues the launches and records the event; whoever touches the geometry waits for `issued`
@@ -599,9 +663,15 @@ void prebuild_async(std::shared_ptr<Geo> g, int what, bool avg) {
         total += (b + 255) / 256 * 256;
         if (w > wsb) wsb = w;
     }
-    Tensor block = at::empty({(int64_t)total}, g->buf.options());
-    g->attached.push_back(block);
     hipStream_t ss = side_stream(g->side);
+    Tensor block;
+    if (g->own_pool) {
+        const c10::hip::HIPStreamGuardMasqueradingAsCUDA own(as_torch_stream((void*)ss, (int)g->buf.device().index()));
+        block = at::empty({(int64_t)total}, g->buf.options());
+    } else {
+        block = at::empty({(int64_t)total}, g->buf.options());
+    }
+    g->attached.push_back(block);
     g->pieces_issued.store(0, std::memory_order_release);
     char* base = (char*)block.data_ptr();
     Tensor like = g->buf;
@@ -1042,8 +1112,15 @@ struct HierFuture {
         if (rc) throw std::runtime_error("PointHierarchy prefetch: " + what);
         const DevGuard device_guard((int)pts.device().index());
         if (!joined) {
-            hip_check(hipStreamWaitEvent((hipStream_t)cur_stream(pts), event, 0), "hipStreamWaitEvent");
+            void* consumer_stream = cur_stream(pts);
+            hip_check(hipStreamWaitEvent((hipStream_t)consumer_stream, event, 0), "hipStreamWaitEvent");
             joined = true;
+            // (allocated on the hierarchy's stream, consumed on this one from here on)
+            const c10::Stream consumer = as_torch_stream(consumer_stream, (int)pts.device().index());
+            mn.record_stream(consumer);
+            mx.record_stream(consumer);
+            for (Tensor& t : ints) t.record_stream(consumer);
+            for (Tensor& t : flts) t.record_stream(consumer);
         }
         std::vector<std::vector<Tensor>> out;
         bool ok = true;
@@ -1057,8 +1134,16 @@ struct HierFuture {
     }
 };
 
+hipEvent_t hierarchy_ready_event(const std::shared_ptr<HierFuture>& f) {
+    return (f && f->joined && f->rc == 0 && f->done.load(std::memory_order_acquire)) ? f->event : nullptr;
+}
+
+// after_mode: 0 = the build starts behind everything the calling stream holds now (where the inputs were produced);
+// 1 = the inputs are complete (uploaded and synchronised, or resident for long): the build starts at once;
+// 2 = behind `after_event` (a hipEvent_t: the upload's own stream recorded it).
 std::shared_ptr<HierFuture> hierarchy_prefetch(const Tensor& pts, const Tensor& bids, const std::vector<double>& radii,
-                                               int64_t B, bool scale_inv, int64_t pmode) {
+                                               int64_t B, bool scale_inv, int64_t pmode, int64_t after_mode,
+                                               int64_t after_event) {
     check_dev(pts, at::kFloat, "points");
     check_dev(bids, at::kInt, "batch ids");
     const DevGuard device_guard((int)pts.device().index());
@@ -1072,20 +1157,30 @@ std::shared_ptr<HierFuture> hierarchy_prefetch(const Tensor& pts, const Tensor& 
     f->B = (int)B; f->L = L; f->cap = cap; f->pmode = (int)pmode; f->scale_inv = scale_inv;
     f->ca = (cap + 63) / 64 * 64;
     auto iopt = pts.options().dtype(at::kInt);
-    f->mn = at::empty({B, 3}, pts.options());
-    f->mx = at::empty({B, 3}, pts.options());
-    f->sizes = at::empty({L + 1}, iopt);
-    for (int l = 0; l < L; ++l) {
-        f->ints.push_back(at::empty({3 * f->ca}, iopt));
-        f->flts.push_back(at::empty({3 * f->ca}, pts.options()));
-    }
     void* stream = cur_stream(pts);
-    f->alloc_stream = stream;
+    {
+        // the outputs come from the caching allocator's pool of the hierarchy's OWN stream: a block it hands out was last
+        // used on that stream, so the build needs no ordering behind the calling stream for its memory (only for its
+        // inputs, below); result() tells the allocator about the stream that consumes them (record_stream)
+        const c10::hip::HIPStreamGuardMasqueradingAsCUDA own(as_torch_stream((void*)ss, (int)pts.device().index()));
+        f->mn = at::empty({B, 3}, pts.options());
+        f->mx = at::empty({B, 3}, pts.options());
+        f->sizes = at::empty({L + 1}, iopt);
+        for (int l = 0; l < L; ++l) {
+            f->ints.push_back(at::empty({3 * f->ca}, iopt));
+            f->flts.push_back(at::empty({3 * f->ca}, pts.options()));
+        }
+    }
+    f->alloc_stream = (void*)ss;
     f->event = take_event();
-    static thread_local hipEvent_t fork_ev = nullptr;
-    if (!fork_ev) hip_check(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming), "hipEventCreate");
-    hip_check(hipEventRecord(fork_ev, (hipStream_t)stream), "hipEventRecord");
-    hip_check(hipStreamWaitEvent(ss, fork_ev, 0), "hipStreamWaitEvent");
+    if (after_mode == 2 && after_event) {
+        hip_check(hipStreamWaitEvent(ss, (hipEvent_t)(uintptr_t)after_event, 0), "hipStreamWaitEvent");
+    } else if (after_mode != 1) {
+        static thread_local hipEvent_t fork_ev = nullptr;
+        if (!fork_ev) hip_check(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming), "hipEventCreate");
+        hip_check(hipEventRecord(fork_ev, (hipStream_t)stream), "hipEventRecord");
+        hip_check(hipStreamWaitEvent(ss, fork_ev, 0), "hipStreamWaitEvent");
+    }
     if (Issuer::enabled()) {
         f->done.store(0, std::memory_order_release);
         Issuer::get(1).push([f, ss] { f->run(ss); });
@@ -1140,7 +1235,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
             py::arg("mn"), py::arg("mx"), py::arg("B"), py::arg("nc"), py::arg("radius"), py::arg("scale_inv"),
             py::arg("window"), py::arg("use_pdf"), py::arg("capacity"), py::arg("grid_from").none(true),
             py::arg("side") = -1, py::arg("fork") = false, py::arg("background") = false,
-            py::call_guard<py::gil_scoped_release>());
+            py::arg("after").none(true) = py::none(), py::call_guard<py::gil_scoped_release>());
     mod.def("sampled_features", &sampled_features, py::call_guard<py::gil_scoped_release>());
     mod.def("prebuild_async", &prebuild_async, py::arg("geometry"), py::arg("what"), py::arg("avg"),
             py::call_guard<py::gil_scoped_release>());
@@ -1151,7 +1246,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
     py::class_<HierFuture, std::shared_ptr<HierFuture>>(mod, "HierarchyFuture")
         .def("result", &HierFuture::result)
         .def("done", [](HierFuture& f) { return f.done.load(std::memory_order_acquire) != 0; });
-    mod.def("hierarchy_prefetch", &hierarchy_prefetch, py::call_guard<py::gil_scoped_release>());
+    mod.def("hierarchy_prefetch", &hierarchy_prefetch, py::arg("pts"), py::arg("bids"), py::arg("radii"), py::arg("B"),
+            py::arg("scale_inv"), py::arg("pmode"), py::arg("after_mode") = 0, py::arg("after_event") = 0,
+            py::call_guard<py::gil_scoped_release>());
     mod.def("shutdown_helpers", [] { for (int k = 0; k < 3; ++k) Issuer::get(k).retire(); },
             py::call_guard<py::gil_scoped_release>());
     mod.def("wait_ns", [] { return (long long)g_wait_ns.load(std::memory_order_relaxed); });

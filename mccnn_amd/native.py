@@ -257,13 +257,13 @@ class Geometry:
 
 
 def _build_into(g, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, capacity, grid_from,
-                side=-1, fork=False, background=False):
+                side=-1, fork=False, background=False, after=None):
     n, m = inPts.shape[0], centres.shape[0]
     if _EXT is not None:
         uses = g.core.uses if g.core is not None else 0
         g.core = _EXT.build_geometry(inPts, inBids, centres, cbids, mn, mx, B, nc, float(radius), bool(scaleInv), float(window),
                                      bool(usePDF), capacity, grid_from.core if grid_from is not None else None, side, fork,
-                                     background)
+                                     background, after)
         g.core.uses = uses
         g.buf = g.core.buf
         g.grid_owner = grid_from
@@ -300,11 +300,13 @@ def side_streams_available():
 
 
 def build_geometry(inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF, grid_from=None,
-                   side=-1, fork=False, background=False):
+                   side=-1, fork=False, background=False, after=None):
     """Enqueues grid + search + KDE of one convolution geometry; no host wait. nc: cells per axis
     (MCConvModule._num_cells). grid_from: a Geometry over the same points / radius whose grid is shared. side >= 0
     (torch extension only): the build runs on side stream `side` -- behind everything the current stream holds at the
-    first call that says fork=True -- and the first layer that uses the geometry orders its stream behind it."""
+    first call that says fork=True -- and the first layer that uses the geometry orders its stream behind it.
+    after: the future of the ADOPTED prefetched hierarchy that every input of this build belongs to; a side-stream build
+    then waits for that hierarchy only and takes its memory from its own stream's pool (torch_ext.cpp, Geo::own_pool)."""
     n, m = inPts.shape[0], centres.shape[0]
     gkey = (inPts.device.index, n, m, float(radius), int(B), bool(scaleInv))
     g = Geometry()
@@ -312,7 +314,8 @@ def build_geometry(inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleIn
     if grid_from is not None and grid_from.grid_owner is not None:
         grid_from = grid_from.grid_owner
     _build_into(g, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleInv, window, usePDF,
-                _capacity_guess(gkey, m), grid_from, side if _EXT is not None else -1, fork, background)
+                _capacity_guess(gkey, m), grid_from, side if _EXT is not None else -1, fork, background,
+                after if _EXT is not None else None)
     return g
 
 

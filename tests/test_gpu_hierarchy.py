@@ -121,14 +121,29 @@ def test_prefetched_hierarchy_equals_the_inline_one(mc, case):
     g_ref = F.grad.clone()
     (lv_r, idx_r) = _levels(ref)
     busy = torch.randn(2048, 2048, device="cuda")
+    up = torch.cuda.Stream()
     for rep in range(3):
-        h = MB.PointHierarchy.prefetch(P, Bi, radii, B, rel)
+        # what the build waits for: the calling stream (default) | nothing: the inputs are complete | an event of the
+        # stream that produced them (here: a copy of the points on a stream of its own)
+        if rep == 0:
+            after, Pin, Bin = None, P, Bi
+        elif rep == 1:
+            torch.cuda.synchronize()
+            after, Pin, Bin = True, P, Bi
+        else:
+            torch.cuda.synchronize()
+            with torch.cuda.stream(up):
+                Pin, Bin = P.clone(), Bi.clone()
+                after = torch.cuda.Event()
+                after.record()
+        h = MB.PointHierarchy.prefetch(Pin, Bin, radii, B, rel, after=after)
         assert h is not None
         h2 = MB.PointHierarchy.prefetch(P, Bi, radii, B, rel)       # a second request in flight, never adopted
         for _ in range(4):
             busy = torch.tanh(busy @ busy * 1e-3)                     # work of the calling stream the build runs under
         F.grad = None
-        ph = MB.PointHierarchy(P, F, Bi, radii, "PH", B, rel, prefetched=h)
+        torch.cuda.current_stream().wait_stream(up)
+        ph = MB.PointHierarchy(Pin, F, Bin, radii, "PH", B, rel, prefetched=h)
         del h2
         (ph.features_[-1] * torch.linspace(1, 2, 3, device="cuda")).sum().backward()
         (lv, idx) = _levels(ph)
@@ -156,4 +171,6 @@ def test_prefetched_hierarchy_equals_the_inline_one(mc, case):
     with pytest.raises(InvalidArgumentError):
         MB.PointHierarchy(P2, F, Bi, radii, "PH", B, rel, prefetched=h)
     del h
+    with pytest.raises(InvalidArgumentError):
+        MB.PointHierarchy.prefetch(P, Bi, radii, B, rel, after="now")
     torch.cuda.synchronize()

@@ -13,10 +13,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("deep", ["0", "1"], ids=["hierarchy_ahead", "hierarchy_and_geometry_ahead"])
+@pytest.mark.parametrize("deep", ["0", "1", "fork"], ids=["hierarchy_ahead", "hierarchy_and_geometry_ahead",
+                                                          "everything_forked_from_the_calling_stream"])
 def test_network_soak_with_everything_running_ahead(mc, deep):
-    """deep: the hierarchy two batches ahead and ConvolutionBuilder.prefetch_step() for the next batch's geometry and plans."""
-    env = dict(os.environ, SOAK_STEPS="400", SOAK_DEEP=deep)
+    """deep: the hierarchy two batches ahead and ConvolutionBuilder.prefetch_step() for the next batch's geometry and plans.
+    By default the prefetched hierarchy starts at once (after=True) and the geometry streams wait for the hierarchy's event,
+    with their memory from their own streams' pools; "fork": both start behind what the calling stream holds (the form
+    for inputs produced on the calling stream, and the only one up to round 4)."""
+    env = dict(os.environ, SOAK_STEPS="400", SOAK_DEEP="1" if deep == "fork" else deep)
+    if deep == "fork":
+        env.update(SOAK_HIER_AFTER="0", MCCNN_DEBUG="geo_own_pool=0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_network.py")], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

@@ -40,7 +40,8 @@ class Batch:
         return PointHierarchy(self.P, self.F0, self.Bi, list(cfg.hierarchy), "PH", self.B, cfg.relative, prefetched=prefetched)
 
     def request(self):
-        return PointHierarchy.prefetch(self.P, self.Bi, list(cfg.hierarchy), self.B, cfg.relative)
+        return PointHierarchy.prefetch(self.P, self.Bi, list(cfg.hierarchy), self.B, cfg.relative,
+                                       after=(True if os.environ.get("SOAK_HIER_AFTER", "1") == "1" else None))
 
     def rows(self, ph):
         if self.feats is None:
