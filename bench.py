@@ -591,10 +591,9 @@ class ConfigWorkload:
         from mccnn_amd import MCConvModule as _M
         l0 = self.lib.mccnn_debug_launch_count()
         w0 = _M.host_wait_seconds()
-        # the host at most `lag` steps ahead of the GPU (0 = unbounded): a GPU-bound step of hundreds of small launches on
-        # several queues runs ~5 % faster when the next step is not enqueued on top of it (cfg3 6.26 -> 5.93 ms); a step
-        # bound by the issuing thread loses from any wait (cfg2 1.40 -> 1.62) -- run_config() tries it where it can pay
-        lag = getattr(self, "lag", 0) or int(os.environ.get("MCCNN_BENCH_LAG", "0"))
+        # the host issues a step while the device is at most `lag` steps behind (0 = unbounded; run_config(): 2 for the
+        # pipelined modes)
+        lag = getattr(self, "lag", 0)
         self.builder.hostStepsAhead_ = (lag - 1) if lag else None   # (ConvolutionBuilder.reset() does the waiting)
         self.builder.__dict__.pop("stepEvents_", None)
         t0 = time.perf_counter()
@@ -767,9 +766,9 @@ def run_config(name, device, args, want_cpu):
         try:
             ref = [o.detach().clone() for o in cw.step()]
             best_issue, best_wait = seq_issue, seq_wait
-            for deep in (False, True):
-                if deep and os.environ.get("MCCNN_BENCH_DEEP", "1") == "0":
-                    break
+            # ONE pipelined form is timed: hierarchy two batches ahead + the next batch's geometry (MCCNN_BENCH_DEEP=0: the
+            # shallow form, hierarchy one batch ahead, instead)
+            for deep in ((True,) if os.environ.get("MCCNN_BENCH_DEEP", "1") != "0" else (False,)):
                 cw.set_pipeline(False)
                 torch.cuda.synchronize()
                 if not cw.set_pipeline(True, geometry=deep):
@@ -778,19 +777,20 @@ def run_config(name, device, args, want_cpu):
                 for _ in range(4):
                     same = same and all(torch.equal(a, b) for a, b in zip(cw.step(), ref))
                 if same:
-                    # ... each also with the host kept one step at a time (ConvolutionBuilder.hostStepsAhead_ = 0)
-                    for lag in ((0, 1) if os.environ.get("MCCNN_BENCH_LAG_TRY", "1") != "0" else (0,)):
-                        cw.lag = lag
-                        if lag:
-                            for _ in range(3):
-                                cw.step()
-                        ms_p, launches_p = cw.timed(steps, 5)
-                        cw.lag = 0
-                        if os.environ.get("MCCNN_BENCH_VERBOSE"):
-                            print("bench: %s %s host lag %d: %.4f ms" % (name, "deep" if deep else "pipelined", lag, ms_p), file=sys.stderr)
-                        if ms_p < ms:
-                            ms, launches, mode, lag_used = ms_p, launches_p, ("pipelined+geometry" if deep else "pipelined"), lag
-                            best_issue, best_wait = cw.host_issue_ms, cw.host_wait_ms
+                    # the host at most ONE step ahead of the device (ConvolutionBuilder.hostStepsAhead_ = 1), as a training
+                    # loop would run: bounded memory, and no slower than letting it run free (r05, tools/lag_probe.py:
+                    # cfg2 1.43 against 1.49 ms unbounded and 1.67 one step at a time, cfg3 5.90 / 6.01 / 6.10)
+                    lag = int(os.environ.get("MCCNN_BENCH_LAG", "2"))
+                    cw.lag = lag
+                    for _ in range(3):
+                        cw.step()
+                    ms_p, launches_p = cw.timed(steps, 5)
+                    cw.lag = 0
+                    if os.environ.get("MCCNN_BENCH_VERBOSE"):
+                        print("bench: %s %s host lag %d: %.4f ms" % (name, "deep" if deep else "pipelined", lag, ms_p), file=sys.stderr)
+                    if ms_p < ms:
+                        ms, launches, mode, lag_used = ms_p, launches_p, ("pipelined+geometry" if deep else "pipelined"), lag
+                        best_issue, best_wait = cw.host_issue_ms, cw.host_wait_ms
                 else:
                     print("bench: %s steps of %s do not reproduce the sequential outputs" % (
                         "pipelined+geometry" if deep else "pipelined", name), file=sys.stderr)
@@ -809,8 +809,8 @@ def run_config(name, device, args, want_cpu):
            # PDFs / row plans are started under this batch's convolutions as well (ConvolutionBuilder.prefetch_step);
            # sequential_ms_per_step: hierarchy, then convolutions, nothing carried over
            "mode": mode, "sequential_ms_per_step": round(ms_seq, 4),
-           # 1: the host waits for the end of the previous step before it issues the next (ConvolutionBuilder.hostStepsAhead_
-           # = 0); tried after the pipelined modes, kept when faster
+           # pipelined modes: the host issues a step while the device is at most this many steps behind
+           # (ConvolutionBuilder.hostStepsAhead_ + 1); 0 = sequential steps, nothing bounded
            "host_lag_steps": lag_used,
            "library_launches_per_step": round(launches, 1),
            # when this equals ms_per_step the step is bound by the HOST issuing its launches, not by the kernels
