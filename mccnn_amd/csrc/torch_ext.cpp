@@ -306,6 +306,7 @@ struct Geo {
     // calling stream holds -- the next batch's geometry then starts when it is asked for, not when the device has
     // finished the step in flight. Every stream that joins the build is made known to the allocator (record_stream).
     bool own_pool = false;
+    void* caller_stream = nullptr;  // own_pool: the stream of the thread that asked for the build (where its inputs are consumed)
     Tensor buf, slot;
     std::vector<Tensor> keep, attached;
     std::shared_ptr<Geo> grid_owner;
@@ -382,7 +383,12 @@ struct Geo {
             // never consumed: the buffers go back to the allocator of the stream they were taken on -- order that
             // stream behind the build first, or the next owner of the memory could race with it
             // (this destructor may run on the helper thread: the allocation stream is the one remembered at build time)
-            if (needs_wait && buf.defined() && build_rc == 0) (void)hipStreamWaitEvent((hipStream_t)alloc_stream, event, 0);
+            if (needs_wait && buf.defined() && build_rc == 0) {
+                (void)hipStreamWaitEvent((hipStream_t)alloc_stream, event, 0);
+                // own pool: the INPUTS (`keep`: tensors of the hierarchy, freed after this) are known to the allocator as
+                // used on the caller's stream only -- a build nobody joined has to be over before that stream moves on
+                if (own_pool && caller_stream) (void)hipStreamWaitEvent((hipStream_t)caller_stream, event, 0);
+            }
             if (total_pending && build_rc == 0) slot_ev = event;   // (the event of the build: the parked slot keeps it)
             else give_event(event);
         } else if (total_pending && build_rc == 0 && buf.defined()) {
@@ -395,11 +401,17 @@ struct Geo {
             }
         }
         if (plan_event) {
-            if (plan_wait && buf.defined()) (void)hipStreamWaitEvent((hipStream_t)alloc_stream, plan_event, 0);
+            if (plan_wait && buf.defined()) {
+                (void)hipStreamWaitEvent((hipStream_t)alloc_stream, plan_event, 0);
+                if (own_pool && caller_stream) (void)hipStreamWaitEvent((hipStream_t)caller_stream, plan_event, 0);
+            }
             give_event(plan_event);
         }
         if (tr_event) {
-            if (tr_wait && buf.defined()) (void)hipStreamWaitEvent((hipStream_t)alloc_stream, tr_event, 0);
+            if (tr_wait && buf.defined()) {
+                (void)hipStreamWaitEvent((hipStream_t)alloc_stream, tr_event, 0);
+                if (own_pool && caller_stream) (void)hipStreamWaitEvent((hipStream_t)caller_stream, tr_event, 0);
+            }
             give_event(tr_event);
         }
         if (h) mccnn_geometry_destroy(h);
@@ -553,6 +565,7 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
             g->buf = at::empty({(int64_t)bytes}, pts.options().dtype(at::kByte));
         }
         g->own_pool = true;
+        g->caller_stream = stream;
         g->alloc_stream = (void*)ss;
         hip_check(hipStreamWaitEvent(ss, ready, 0), "hipStreamWaitEvent");
         const int sk = (int)(((side % kSideStreams) + kSideStreams) % kSideStreams);
