@@ -110,6 +110,24 @@ class _PrefetchedHierarchy:
                                        "batch size or radius mode (or the tensors were modified since)")
 
 
+def _record_event(device_index=None):
+    """A torch.cuda.Event recorded on the current stream of `device_index` (default: the current device). With the index
+    spelled out torch.cuda.current_stream() skips its device look-up chain (~9 us of the ~12 an Event().record() costs;
+    a step records three)."""
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(torch.cuda.current_device() if device_index is None else device_index))
+    return ev
+
+
+_CUDA_OK = []   # torch.cuda.is_available(), asked once (reset() runs every step)
+
+
+def _cuda_ok():
+    if not _CUDA_OK:
+        _CUDA_OK.append(bool(torch.cuda.is_available()))
+    return _CUDA_OK[0]
+
+
 class _PlainState:
     """Attributes whose names end in '_' are plain state (caches, lists, tensors the class merely holds): they bypass
     torch.nn.Module.__setattr__, whose parameter / buffer / sub-module bookkeeping costs ~5 us per assignment -- a reset()
@@ -163,16 +181,10 @@ class PointHierarchy(_PlainState, torch.nn.Module):
         slice of the single-device hierarchy (mccnn_amd.dist)."""
         super().__init__()
         ops = _Ops(ops)
-        self.readyEvent_ = None
-        self.prefetchFuture_ = None
-        self.points_ = [inPoints]
-        self.features_ = [inFeatures]
-        self.batchIds_ = [inBatchIds]
-        self.sampledIndexs_ = []
-        self.radiusList_ = [0.0]
-        self.batchSize_ = batchSize
-        self.relativeRadius_ = relativeRadius
-        self.hierarchyName_ = hierarchyName
+        # (plain state, written through __dict__: a hierarchy is built every step, see _PlainState)
+        self.__dict__.update(readyEvent_=None, prefetchFuture_=None, points_=[inPoints], features_=[inFeatures],
+                             batchIds_=[inBatchIds], sampledIndexs_=[], radiusList_=[0.0], batchSize_=batchSize,
+                             relativeRadius_=relativeRadius, hierarchyName_=hierarchyName)
 
         if prefetched is not None:
             prefetched.check(inPoints, inBatchIds, radiusList, batchSize, relativeRadius)
@@ -234,8 +246,8 @@ class PointHierarchy(_PlainState, torch.nn.Module):
         if not levels:
             return False
         # (geometry builds over this hierarchy on side streams wait for THIS, not for the calling stream: native.build_geometry)
-        self.prefetchFuture_ = prefetched.future
-        self.aabbMin_, self.aabbMax_ = aabbMin, aabbMax
+        self.__dict__["prefetchFuture_"] = prefetched.future
+        self.__dict__.update(aabbMin_=aabbMin, aabbMax_=aabbMax)
         if not self.relativeRadius_:
             _M._seed_num_cells(aabbMin, aabbMax, extent)
         _log("########## Point Hierarchy: %s (Rel: %s, prefetched)" % (self.hierarchyName_, self.relativeRadius_))
@@ -253,8 +265,7 @@ class PointHierarchy(_PlainState, torch.nn.Module):
     def __mark_ready__(self):
         """Everything the hierarchy holds (points of every level, boxes) has been enqueued on the current stream."""
         if getattr(self.points_[0], "is_cuda", False):
-            self.readyEvent_ = torch.cuda.Event()
-            self.readyEvent_.record()
+            self.__dict__["readyEvent_"] = _record_event(self.points_[0].device.index)
 
 
 def _fan_avg_uniform_(t, fan_in, fan_out):
@@ -365,26 +376,22 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         prefetch_geometry() since the last reset() becomes the new cache content.
 
         hostStepsAhead_ (extension, attribute; None = unbounded): with k, reset() waits until the GPU has finished every
-        step but the last k (0: everything enqueued so far -- the steps are issued one at a time). A loop whose steps are
-        hundreds of small launches on several queues runs FASTER with 0 when the GPU is its bound: left alone, the issuing
-        thread fills the launch queue and then sits blocked inside the runtime, where it holds up the launches of the
-        helper threads that build the next batch's geometry (BASELINE cfg3: 6.30 -> 5.96 ms per step; with 1 there is no
-        gain -- two steps of ~400 launches fill the queue as well; a step bound by the issuing thread itself can lose)."""
-        k = getattr(self, "hostStepsAhead_", None)
-        if k is not None and torch.cuda.is_available():
-            evs = self.__dict__.setdefault("stepEvents_", [])
-            ev = torch.cuda.Event()
-            ev.record()                      # the end of the step that has just been issued
-            evs.append(ev)
+        step but the last k (0: everything enqueued so far -- the steps are issued one at a time). 1 is what a training
+        loop wants: memory of at most two steps in flight, and on the pipelined loop (PointHierarchy.prefetch two batches
+        ahead + prefetch_step) no slower than running free -- BASELINE cfg2 1.43 ms per step against 1.49 unbounded and
+        1.67 one at a time, cfg3 5.90 / 6.01 / 6.10, cfg4 1.81 / 1.83 / 2.04 (round 5, tools/lag_probe.py)."""
+        d = self.__dict__   # (plain state is written through __dict__ here: a dozen assignments per step, see _PlainState)
+        k = d.get("hostStepsAhead_", None)
+        if k is not None and _cuda_ok():
+            evs = d.setdefault("stepEvents_", [])
+            evs.append(_record_event())      # the end of the step that has just been issued
             del evs[:-8]
             if len(evs) > k:
                 from . import MCConvModule as _M
                 t0 = time.perf_counter()
                 evs[-(int(k) + 1)].synchronize()
                 _M.HOST_WAIT_S[0] += time.perf_counter() - t0
-        self.cacheGrids_ = {}
-        self.cacheNeighs_ = {}
-        self.cachePDFs_ = {}
+        d["cacheGrids_"], d["cacheNeighs_"], d["cachePDFs_"] = {}, {}, {}
         if self.geoSeen_:
             # the geometries the step's layers USED (built by them, prebuilt, or started a step ago by prefetch_step) and
             # the pieces they attached to each (row plans, transposed list): what the next step asks for ahead
@@ -392,12 +399,11 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
             for key, ent in self.geoSeen_.items():
                 geo = self.cacheGeo_.get(key)
                 plan.append(ent + ((geo.have & 7) if geo is not None else 0, key))
-            self.geoPlan_, self.geoSeen_ = plan, {}
-        self.cacheGeo_ = {}
-        self.cacheGeoGrid_ = {}
+            d["geoPlan_"], d["geoSeen_"] = plan, {}
+        d["cacheGeo_"], d["cacheGeoGrid_"] = {}, {}
         if self.prefetchedGeo_:
             self.__install_prefetched_geometries__()
-        pf, self.prefetched_ = self.prefetched_, None
+        pf, d["prefetched_"] = self.prefetched_, None
         if pf is not None:
             grids, neighs, pdfs, event = pf
             main = torch.cuda.current_stream()
@@ -417,9 +423,8 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                         # are. The native executor, the default path, never needed it.)
                         t.record_stream(main)
             self.cacheGrids_, self.cacheNeighs_, self.cachePDFs_ = grids, neighs, pdfs
-        if torch.cuda.is_available():
-            self.resetEvent_ = torch.cuda.Event()
-            self.resetEvent_.record()
+        if _cuda_ok():
+            d["resetEvent_"] = _record_event()
         if pf is not None:
             for kN, (kG, kP, centres, mn, mx, B, radius, rel) in self.prefetchTransposed_.items():
                 if kN in neighs and kG in grids and getattr(self.ops_, "_ops", 0) is None:

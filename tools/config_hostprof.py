@@ -16,6 +16,9 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 torch.cuda.set_device(0)
 torch.autograd.set_multithreading_enabled(False)
 cw = bench.ConfigWorkload(CONFIGS[name], torch.device("cuda", 0))
+if os.environ.get("PIPE") == "1":   # the training-loop step: hierarchy two ahead + next batch's geometry, host one step ahead
+    cw.set_pipeline(True, geometry=True)
+    cw.builder.hostStepsAhead_ = 1
 for _ in range(5):
     cw.step()
 torch.cuda.synchronize()
