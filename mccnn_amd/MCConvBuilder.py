@@ -380,10 +380,10 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         loop wants: memory of at most two steps in flight, and on the pipelined loop (PointHierarchy.prefetch two batches
         ahead + prefetch_step) no slower than running free -- BASELINE cfg2 1.43 ms per step against 1.49 unbounded and
         1.67 one at a time, cfg3 5.90 / 6.01 / 6.10, cfg4 1.81 / 1.83 / 2.04 (round 5, tools/lag_probe.py)."""
-        d = self.__dict__   # (plain state is written through __dict__ here: a dozen assignments per step, see _PlainState)
-        k = d.get("hostStepsAhead_", None)
+        state = self.__dict__   # (plain state is written through __dict__ here: a dozen assignments per step, see _PlainState)
+        k = state.get("hostStepsAhead_", None)
         if k is not None and _cuda_ok():
-            evs = d.setdefault("stepEvents_", [])
+            evs = state.setdefault("stepEvents_", [])
             evs.append(_record_event())      # the end of the step that has just been issued
             del evs[:-8]
             if len(evs) > k:
@@ -391,7 +391,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                 t0 = time.perf_counter()
                 evs[-(int(k) + 1)].synchronize()
                 _M.HOST_WAIT_S[0] += time.perf_counter() - t0
-        d["cacheGrids_"], d["cacheNeighs_"], d["cachePDFs_"] = {}, {}, {}
+        state["cacheGrids_"], state["cacheNeighs_"], state["cachePDFs_"] = {}, {}, {}
         if self.geoSeen_:
             # the geometries the step's layers USED (built by them, prebuilt, or started a step ago by prefetch_step) and
             # the pieces they attached to each (row plans, transposed list): what the next step asks for ahead
@@ -399,11 +399,11 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
             for key, ent in self.geoSeen_.items():
                 geo = self.cacheGeo_.get(key)
                 plan.append(ent + ((geo.have & 7) if geo is not None else 0, key))
-            d["geoPlan_"], d["geoSeen_"] = plan, {}
-        d["cacheGeo_"], d["cacheGeoGrid_"] = {}, {}
+            state["geoPlan_"], state["geoSeen_"] = plan, {}
+        state["cacheGeo_"], state["cacheGeoGrid_"] = {}, {}
         if self.prefetchedGeo_:
             self.__install_prefetched_geometries__()
-        pf, d["prefetched_"] = self.prefetched_, None
+        pf, state["prefetched_"] = self.prefetched_, None
         if pf is not None:
             grids, neighs, pdfs, event = pf
             main = torch.cuda.current_stream()
@@ -424,7 +424,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                         t.record_stream(main)
             self.cacheGrids_, self.cacheNeighs_, self.cachePDFs_ = grids, neighs, pdfs
         if _cuda_ok():
-            d["resetEvent_"] = _record_event()
+            state["resetEvent_"] = _record_event()
         if pf is not None:
             for kN, (kG, kP, centres, mn, mx, B, radius, rel) in self.prefetchTransposed_.items():
                 if kN in neighs and kG in grids and getattr(self.ops_, "_ops", 0) is None:
