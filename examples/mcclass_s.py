@@ -32,10 +32,12 @@ class MCClassS(torch.nn.Module):
 
     RADII = [0.1, 0.4, math.sqrt(3.0) + 0.1]
 
-    def prefetch_hierarchy(self, points, batchIds):
+    def prefetch_hierarchy(self, points, batchIds, after=None):
         """Extension: starts the point hierarchy of a batch on a stream of its own (PointHierarchy.prefetch) -- call it for
-        batch k + 1 before the forward pass of batch k and hand the result to forward(prefetched=...)."""
-        return PointHierarchy.prefetch(points, batchIds, self.RADII, self.args[1])
+        batch k + 1 before the forward pass of batch k and hand the result to forward(prefetched=...). after: what the
+        build waits for -- None: the calling stream (the batch was uploaded there), a torch.cuda.Event of the loader's
+        upload stream, or True (the batch is complete)."""
+        return PointHierarchy.prefetch(points, batchIds, self.RADII, self.args[1], after=after)
 
     def hierarchy(self, points, batchIds, features, prefetched=None):
         """The network's point hierarchy for a batch (prefetched: what prefetch_hierarchy() returned for it)."""

@@ -59,13 +59,15 @@ print("... with the next batch's hierarchy one step ahead (PointHierarchy.prefet
 # ... and two batches ahead: the next batch's hierarchy is complete when a step starts, its geometry and row plans are started
 # under this batch's layers (ConvolutionBuilder.prefetch_step through forward(nextHierarchy=...))
 ph_cur = net.hierarchy(P, Bi, F)
-fut = net.prefetch_hierarchy(P, Bi)
+AFTER = True if os.environ.get("E2E_AFTER", "1") == "1" else None   # the synthetic batch is resident: its hierarchy starts at once
+net.convBuilder.hostStepsAhead_ = 1
+fut = net.prefetch_hierarchy(P, Bi, after=AFTER)
 
 
 def deep_step():
     global ph_cur, fut
     ph_nxt = net.hierarchy(P, Bi, F, prefetched=fut)
-    fut = net.prefetch_hierarchy(P, Bi)
+    fut = net.prefetch_hierarchy(P, Bi, after=AFTER)
     logits = net(P, Bi, F, True, hierarchy=ph_cur, nextHierarchy=ph_nxt)
     loss = torch.nn.functional.cross_entropy(logits, y)
     opt.zero_grad(set_to_none=True)
