@@ -20,3 +20,6 @@ for _ in range(50):
     st, pk = M.find_neighbors(P, Bi, sP, cells, mn, mx, 0.1, B, False)
 e1.record(); torch.cuda.synchronize()
 print("find_neighbors ms %.4f  E %d" % (e0.elapsed_time(e1) / 50, pk.shape[0]))
+# order-sensitive checksum of the list (A/B runs of two fill passes must print the same value)
+w = torch.arange(1, pk.shape[0] + 1, device=pk.device, dtype=torch.int64)
+print("checksum", int(((pk[:, 0].to(torch.int64) * 31 + pk[:, 1].to(torch.int64)) * (w % 1000003)).sum()), int(st.to(torch.int64).sum()))
