@@ -455,9 +455,7 @@ def _rows_shape(combin, fin, feats, rows, e, backward=False):
         # cell-coherent order: on a large list whose gathered rows do not fit the L2s (>= 64 k points) and whose layer is
         # narrow (<= 16 blocks: little arithmetic per gathered byte) the better locality wins -- room, 64 features 0.38 /
         # 0.32 ms; cfg3 Pool_1 0.16 / 0.12, DeConv_1 0.24 / 0.21; the other way round on 41 k points (Conv_2 0.13 / 0.15)
-        # (round 5: a pooling list of long rows takes the row kernel all the same -- cfg2 Pool_1, 6 344 centres x 218 edges:
-        # 0.077 / 0.096 ms)
-        return not (fin <= 128 and feats.shape[0] >= 65536) or e >= 128 * rows
+        return not (fin <= 128 and feats.shape[0] >= 65536)
     return fin >= 256 and e / float(rows) >= ROWS_MIN_DEGREE
 
 

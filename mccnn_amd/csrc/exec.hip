@@ -141,9 +141,7 @@ bool rows_shape(bool combin, int fin, const void* feats, int rows, int n_points,
     static const int force = debug_int("rows_force", 0);  // A/B: 1 = rows wherever they apply
     if (force == 1) return true;
     if (e <= 500000) return true;
-    // (a pooling list of LONG rows -- BASELINE cfg2 Pool_1: 32 features, 6 344 centres x 218 edges over 131 k points -- takes the
-    // row kernel all the same: 0.077 against 0.096 ms, tools/rows_force_ab.py)
-    if (!backward) return !(fin <= 128 && n_points >= 65536) || (long long)e >= 128LL * rows;
+    if (!backward) return !(fin <= 128 && n_points >= 65536);
     return fin >= 256 && (float)e / (float)rows >= rows_min_degree();
 }
 
