@@ -25,6 +25,18 @@ FLAGS = [
 ]
 
 
+# Per-file flags. The edge-streaming convolution kernels (conv.hip, conv_f1.hip) are compiled WITHOUT SLP vectorisation: the
+# vectoriser pairs their accumulating FMAs into v_pk_fma_f32 (the same ~26 FMA per cycle and SIMD as v_fma_f32 on gfx950)
+# at the price of register-pairing moves and, in the 176-sum sweep of the small-Fin combin layers, spills -- the 3 -> 8
+# backward sweep runs 224 instead of 252 us without it, the Fin = 1 backward 334 instead of 338, the streaming forward 117
+# instead of 121 (round 5, tools/ktab.sh through the ctypes binding). The row kernels (conv_rows.hip) keep it: dw_bwd_rows is
+# 0.5 % faster with the packed form. Same arithmetic either way (one IEEE fma per element): results do not change.
+# (A/B: MCCNN_EXTRA_FLAGS=-fslp-vectorize comes later on the command line and switches it back on.)
+FILE_FLAGS = {
+    "conv.hip": ["-fno-slp-vectorize"],
+    "conv_f1.hip": ["-fno-slp-vectorize"],
+}
+
 TORCH_EXT = os.path.join(LIB_DIR, "_mccnn_torch.so")   # the PyTorch-ROCm extension over the C-ABI (csrc/torch_ext.cpp)
 TORCH_EXT_SRC = os.path.join(CSRC, "torch_ext.cpp")
 
@@ -105,7 +117,8 @@ def build(force=False, verbose=False):
     procs = []
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(LIB) + "." + os.path.basename(src) + ".o")
-        cmd = [hipcc] + FLAGS + os.environ.get("MCCNN_EXTRA_FLAGS", "").split() + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", src, "-o", obj]
+        per_file = FILE_FLAGS.get(os.path.basename(src), [])
+        cmd = [hipcc] + FLAGS + per_file + os.environ.get("MCCNN_EXTRA_FLAGS", "").split() + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

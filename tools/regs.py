@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mccnn_amd import build as B
 src = os.path.join(B.CSRC, sys.argv[1])
-cmd = [B._hipcc()] + B.FLAGS + sys.argv[2:] + ["-I" + os.path.join(ROOT, "include"), "-I" + B.CSRC, "-c", src, "-o", "/tmp/regs.o",
+cmd = [B._hipcc()] + B.FLAGS + B.FILE_FLAGS.get(sys.argv[1], []) + sys.argv[2:] + ["-I" + os.path.join(ROOT, "include"), "-I" + B.CSRC, "-c", src, "-o", "/tmp/regs.o",
                                  "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None

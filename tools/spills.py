@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mccnn_amd import build as B
 src = os.path.join(B.CSRC, sys.argv[1])
-cmd = [B._hipcc()] + B.FLAGS + sys.argv[3:] + ["-I" + os.path.join(ROOT, "include"), "-I" + B.CSRC, "--cuda-device-only", "-S", src, "-o", "/tmp/spills.s"]
+cmd = [B._hipcc()] + B.FLAGS + B.FILE_FLAGS.get(sys.argv[1], []) + sys.argv[3:] + ["-I" + os.path.join(ROOT, "include"), "-I" + B.CSRC, "--cuda-device-only", "-S", src, "-o", "/tmp/spills.s"]
 subprocess.run(cmd, capture_output=True, text=True)
 lines = open("/tmp/spills.s").read().split("\n")
 start = [i for i, l in enumerate(lines) if sys.argv[2] in l and l.rstrip().endswith(sys.argv[2].join(["", ""])) is not None and re.match(r"^_Z\w+:", l) and sys.argv[2] in l][0]
