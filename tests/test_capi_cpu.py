@@ -91,7 +91,7 @@ def test_register_budget_of_the_hot_kernels(lib_path, tmp_path):
         r"f1_bwd_edges": 0, r"f1_fwd_edges": 0,
         r"conv_streamILb0ELi[24]ELb1E": 0,
         r"conv_bwd_mfmaILb0ELi[24]ELb1E": 0,  # the depth-wise streaming backward (COOP)
-        r"conv_bwd_mfmaILb1ELi3ELb0E": 64,     # combin layers with 2..4 input features: 60
+        r"conv_bwd_mfmaILb1ELi3ELb0E": 40,     # combin layers with 2..4 input features: 36 since conv.hip is built without SLP (60 before)
     }
     for pat, limit in budgets.items():
         hits = {k: v for k, v in meta.items() if re.search(pat, k)}
