@@ -115,7 +115,11 @@ def load():
         raise MCCNNError(
             "libmccnn_hip.so not found at %s -- build it with `python -m mccnn_amd.build` "
             "(there is no CPU / PyTorch fallback for the MC-convolution ops)" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    # An A/B library (MCCNN_LIB_NAME) is loaded with RTLD_GLOBAL: the torch extension links libmccnn_hip.so by name, and only
+    # symbols of global scope, loaded BEFORE it, take precedence over that library's -- without this every layer that goes
+    # through the extension runs the DEFAULT library's kernels whatever MCCNN_LIB_NAME says (round 5: a dozen void A/Bs).
+    mode = C.RTLD_GLOBAL if os.environ.get("MCCNN_LIB_NAME") else C.DEFAULT_MODE
+    lib = C.CDLL(LIB_PATH, mode=mode)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
