@@ -56,7 +56,7 @@ LAYERS = {  # name: (Fin, Fout, combin)   -- SURVEY 8(d) layer shapes
 }
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector == f32 MFMA dense peak
-PROFILE_ROUND = "r05"    # profiles/<round>_pmc_traffic_<layer>.json supplies roofline.traffic
+PROFILE_ROUND = "r06"    # profiles/<round>_pmc_traffic_<layer>.json supplies roofline.traffic
 
 
 def log(*a):
@@ -263,6 +263,23 @@ class Workload:
             m_total = float(m_local)
         return elapsed / steps * 1e3, m_total * steps / elapsed, m_total
 
+    def find_neighbors_roofline(self):
+        """find_neighbors alone on THIS workload's batch (the north star's gather-bound pass): HIP-event time of the op
+        through the op surface, algorithmic bytes 16M + 12N + 8C + 4M + 8E of SURVEY 8(d) against the HBM peak."""
+        from mccnn_amd import MCConvModule as M
+        a, B, P, Bi = self.args, self.B, self.P, self.Bi
+        mn, mx = self.ph.aabbMin_, self.ph.aabbMax_
+        keys, idx = M.sort_points_step1(P, Bi, mn, mx, B, a.radius, False)
+        sP, sB, sF, cells = M.sort_points_step2(P, Bi, self.F.detach(), keys, idx, mn, mx, B, a.radius, False)
+        t_fn, (start, packed) = ev_time(lambda: M.find_neighbors(P, Bi, sP, cells, mn, mx, a.radius, B, False))
+        n, m, e = sP.shape[0], P.shape[0], packed.shape[0]
+        C = int(np.prod(cells.shape[:4]))
+        work = 16 * m + 12 * n + 8 * C + 4 * m + 8 * e
+        ach = work / (t_fn * 1e-3) / 1e9
+        return {"bound": "hbm", "ms": round(t_fn, 4), "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "rooms": B, "points": int(n), "edges": int(e),
+                "algorithmic_bytes": int(work)}
+
     def breakdown(self):
         """Per-op HIP-event times through the C-ABI on rank 0 and the roofline of the dominant op."""
         from mccnn_amd import MCConvModule as M
@@ -459,19 +476,25 @@ class Workload:
                                 "algorithmic_frac": round(alg_f * nb * e / (t_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
                                 "executed_frac": round(ex[k] / (t_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4)}
             roofline["fwd_bwd"] = both
+        # Two fields bench.py cannot measure itself (counters need rocprofv3 around the process): they are READ from the
+        # committed profile of this command (tools/prof.sh -> profiles/<round>_*), are named for what they are, and carry
+        # whether that profile was taken from the kernel sources of THIS tree (`kernel_sources_match`: sha1 of
+        # mccnn_amd/csrc/*.hip recorded by tools/prof_summary.py next to the numbers). `traffic` -- the contract's key --
+        # is the profile's number when the sources match and null otherwise.
         busy = mfma_busy_from_profile(self.layer)
         if busy is not None and a.points == 100000 and B == 1:
-            roofline["mfma_pipe_busy"] = busy
-        # HBM-side bytes per launch of the dominant kernel come from the separate rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE passes of THIS command (tools/prof.sh), committed under profiles/ -- bench.py cannot collect
-        # counters itself; null when the committed profile does not cover this workload.
+            roofline["mfma_pipe_busy_from_committed_profile"] = busy
         tfile = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PROFILE_ROUND, self.layer))
         if dom == "spatial_conv_bwd" and os.path.exists(tfile) and a.points == 100000 and B == 1:
             with open(tfile) as fh:
-                for kname, tr in json.load(fh).items():
-                    if kname.startswith(("conv_bwd_mfma", "f1_bwd_edges", "dw_bwd_rows")):
-                        roofline["traffic"] = int(tr["bytes"])
-                        roofline["traffic_source"] = "profiles/" + os.path.basename(tfile)
+                tj = json.load(fh)
+            match = tj.get("_kernel_sources_sha1") == kernel_sources_sha1()
+            for kname, tr in tj.items():
+                if kname.startswith(("conv_bwd_mfma", "f1_bwd_edges", "dw_bwd_rows")):
+                    roofline["traffic_from_committed_profile"] = {
+                        "bytes": int(tr["bytes"]), "source": "profiles/" + os.path.basename(tfile),
+                        "kernel_sources_match": bool(match), "measured_in_this_run": False}
+                    roofline["traffic"] = int(tr["bytes"]) if match else None
         # the north star's second kernel: the neighbour search against the HBM roofline (algorithmic bytes of SURVEY 8d)
         fn = breakdown.get("find_neighbors") if isinstance(breakdown, dict) else None
         if isinstance(fn, dict) and fn.get("unit") == "GB/s":
@@ -835,6 +858,20 @@ def config_cpu_leg(ent, cw, name):
         ent["cpu_baseline"] = {"error": repr(ex)}
 
 
+def kernel_sources_sha1():
+    """sha1 over mccnn_amd/csrc/*.hip and *.h (sorted by name): recorded by tools/prof_summary.py in every committed
+    profile, compared here so that a number read from a profile says whether it belongs to the kernels of this tree."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "mccnn_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def mfma_busy_from_profile(layer):
     """Matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)) of the main forward /
     backward kernels of `layer`, from the committed rocprofv3 --pmc pass of this command (tools/prof.sh); bench.py
@@ -849,7 +886,7 @@ def mfma_busy_from_profile(layer):
         return None
     out = {}
     for name, rec in ks.items():
-        if "mfma_busy" not in rec:
+        if not isinstance(rec, dict) or "mfma_busy" not in rec:
             continue
         if name.startswith(("f1_fwd_edges", "conv_stream", "dw_fwd")) and "fwd" not in out:
             out["fwd"] = {"kernel": name.split("(")[0][:60], "busy": rec["mfma_busy"]}
@@ -858,6 +895,8 @@ def mfma_busy_from_profile(layer):
     if not out:
         return None
     out["source"] = "profiles/" + os.path.basename(path)
+    out["kernel_sources_match"] = bool(ks.get("_kernel_sources_sha1") == kernel_sources_sha1())
+    out["measured_in_this_run"] = False
     return out
 
 
@@ -944,22 +983,28 @@ def compact_record(rec, details_path=None):
     cfg = rec.get("config") or {}
     out = {k: rec.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    if isinstance(rec.get("sequential"), dict):   # the strictly sequential step (SURVEY 8d's literal definition) beside `value`
+        out["sequential"] = _pick(rec["sequential"], ("ms_per_step", "value", "unit"))
     out["config"] = _pick(cfg, ("workload", "points_total", "points_per_gpu", "edges_per_gpu", "layer", "parallelism",
                                 "headline_mode", "pipelined_ms_per_step", "sequential_ms_per_step",
-                                "collective_backend", "rccl_world_size"))
+                                "collective_backend", "rccl_world_size", "collectives_warmed_before_warmup"))
     if isinstance(out["config"].get("workload"), str):
         out["config"]["workload"] = out["config"]["workload"][:300]
     rl = rec.get("roofline")
     if isinstance(rl, dict):
         r = _pick(rl, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ms", "executed_frac"))
-        busy = rl.get("mfma_pipe_busy") or {}
+        busy = rl.get("mfma_pipe_busy_from_committed_profile") or {}
         if busy:
-            r["mfma_pipe_busy"] = {d: busy[d].get("busy") for d in ("fwd", "bwd") if isinstance(busy.get(d), dict)}
+            r["mfma_pipe_busy_from_committed_profile"] = {d: busy[d].get("busy") for d in ("fwd", "bwd") if isinstance(busy.get(d), dict)}
+            r["mfma_pipe_busy_from_committed_profile"]["kernel_sources_match"] = busy.get("kernel_sources_match")
+        if isinstance(rl.get("traffic_from_committed_profile"), dict):
+            r["traffic_from_committed_profile"] = _pick(rl["traffic_from_committed_profile"], ("bytes", "source", "kernel_sources_match"))
         fb = rl.get("fwd_bwd") or {}
         if fb:
             r["fwd_bwd"] = {d: _pick(fb[d], ("ms", "algorithmic_frac")) for d in ("fwd", "bwd") if d in fb}
-        if "find_neighbors" in rl:
-            r["find_neighbors"] = rl["find_neighbors"]
+        for k in ("find_neighbors", "find_neighbors_8rooms"):
+            if isinstance(rl.get(k), dict):
+                r[k] = _pick(rl[k], ("bound", "ms", "achieved", "peak", "unit", "frac", "rooms", "edges"))
         out["roofline"] = r
     else:
         out["roofline"] = rl
@@ -1111,6 +1156,17 @@ def main():
             dist.init_process_group(backend)
         if dist.get_world_size() != world:
             raise SystemExit("bench.py: process group of %d ranks, WORLD_SIZE %d" % (dist.get_world_size(), world))
+        # Every collective KIND the steps use runs once here, before any warm-up or timed step: RCCL builds its rings /
+        # channels and loads its kernels on the first call of a (collective, dtype, op), which takes hundreds of
+        # milliseconds over xGMI -- a SCALE run must time the steady state, whatever --warmup says.
+        for op_ in (dist.ReduceOp.SUM, dist.ReduceOp.MIN, dist.ReduceOp.MAX):      # gradients; whole-batch box (dist.py)
+            w_ = torch.zeros(4096, dtype=torch.float32, device=device)
+            dist.all_reduce(w_, op=op_)
+        w64 = torch.zeros(3, dtype=torch.float64, device=device)                   # the timing reductions of timed()
+        dist.all_reduce(w64, op=dist.ReduceOp.MAX)
+        dist.all_gather([torch.zeros_like(w64) for _ in range(world)], w64)
+        dist.barrier()
+        torch.cuda.synchronize()
 
     # one process per GPU: the autograd engine's per-device worker thread only adds a thread hand-off (~0.2 ms per
     # backward() call, more than a quarter of a step here); run the backward pass on the calling thread
@@ -1216,6 +1272,11 @@ def main():
                   "mode": "pipelined" if sw.pipeline else "sequential", "rank_stats": sw.rank_stats,
                   "note": "fixed batch of %d rooms split cloud-per-GPU over %d rank(s); speed-up at N ranks = value(N) / "
                           "value(1)" % (args.strong_rooms, world)}
+        if rank == 0 and world == 1 and isinstance(roofline, dict) and not args.no_breakdown:
+            try:   # the neighbour search on the whole 8-room batch (330 MB of algorithmic bytes): the size at which HBM shows
+                roofline["find_neighbors_%drooms" % args.strong_rooms] = sw.find_neighbors_roofline()
+            except Exception as ex:
+                roofline["find_neighbors_%drooms" % args.strong_rooms] = {"error": repr(ex)[:200]}
         if wl_strong is not None:
             # (no torch.cuda.empty_cache() here: returning gigabytes to the driver idles the GPU for tens of milliseconds,
             # and the headline region below would start at the clocks of an idle chip -- 0.67 instead of 0.61 ms per step
@@ -1268,6 +1329,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if args.scaling == "strong" else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
+            # the same K steps strictly one after the other, nothing carried over or run ahead: SURVEY 8(d)'s literal
+            # definition of the metric, beside the pipelined `value` (every pipelined step still executes all of it)
+            "sequential": ({"ms_per_step": round(ms_sequential, 4), "value": round(m_total / (ms_sequential * 1e-3), 1),
+                            "unit": "points/s"} if ms_sequential is not None else
+                           {"ms_per_step": round(ms_per_step, 4), "value": round(value, 1), "unit": "points/s"}),
             "config": {"workload": "ScanNet-like non-uniform room, %d pts/room, %d room(s) on rank 0, absolute radius %g, "
                                    "KDE window %g, same-level conv %s (Fin=%d, Fout=%d, %s), avg on"
                                    % (args.points, B, args.radius, args.window, args.layer, fin, fout,
@@ -1281,7 +1347,8 @@ def main():
                        "pipelined_ms_per_step": (round(ms_pipelined, 4) if ms_pipelined is not None else None),
                        "sequential_ms_per_step": (round(ms_sequential, 4) if ms_sequential is not None else None),
                        "collective_backend": (backend if dist_on else None),
-                       "rccl_world_size": (dist.get_world_size() if dist_on else 1), "rank_stats": rank_stats},
+                       "rccl_world_size": (dist.get_world_size() if dist_on else 1),
+                       "collectives_warmed_before_warmup": bool(dist_on), "rank_stats": rank_stats},
             "roofline": roofline, "cpu_baseline": cpu, "strong": strong, "layers": layers, "configs": configs,
             "breakdown": breakdown,
         }

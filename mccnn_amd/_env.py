@@ -12,11 +12,24 @@ the library (csrc/debug_opts.h names the library's keys):
 
     MCCNN_DEBUG="key=value,key,..."      (a bare key means key=1; read once per process)
 
-Python-side keys (default): fuse_sort (1), native_prefetch (1), plan_prefetch (1), plan_prefetch_max_e (1e12),
-geo_prefetch_min (5), mailbox_copy (0), count_mailbox (1), ecap_scale (1), hier_pmode (1),
-rows_min_degree (16), unsorted_max_points (32768), geo_trace (0).
+THE table of keys is KNOWN_KEYS below -- the same table as kDebugKeys of csrc/debug_opts.h (tests/test_capi_cpu.py checks
+that they are equal and that every key any source file queries is in it); a key of MCCNN_DEBUG that is not in it is
+reported once on stderr instead of being silently ignored. Python-side keys (default): fuse_sort (1), native_prefetch (1),
+plan_prefetch (1), plan_prefetch_max_e (1e12), geo_prefetch_min (5), mailbox_copy (0), count_mailbox (1), ecap_scale (1),
+hier_pmode (1), rows_min_degree (16), unsorted_max_points (32768), geo_trace (0), nw_no_order (0), step_plan (1).
 (MCCNN_LIB_NAME / MCCNN_EXTRA_FLAGS belong to mccnn_amd.build: A/B builds of the library.)"""
 import os
+import sys
+
+KNOWN_KEYS = (
+    # library (csrc/debug_opts.h)
+    "small_off", "plan_small_off", "plan_small", "plan_small_max_l", "plan_mid_l", "plan_min_l", "rows_force",
+    "rows_min_degree", "unsorted_max_points", "force_valu", "no_f1", "f1_x4_min_e", "f1_x4_waves_per_cu", "nw_lean",
+    "nw_group", "nw_group_fill", "nw_lds_pad", "scan_bg_tiles", "issue_thread", "issue_inline", "job_delay_us",
+    "hier_trace", "geo_own_pool", "trace_terminate", "geo_small", "nw_fused",
+    # Python side
+    "fuse_sort", "native_prefetch", "plan_prefetch", "plan_prefetch_max_e", "geo_prefetch_min", "mailbox_copy",
+    "count_mailbox", "ecap_scale", "hier_pmode", "geo_trace", "nw_no_order", "step_plan")
 
 
 def _parse():
@@ -27,6 +40,8 @@ def _parse():
             continue
         k, _, v = item.partition("=")
         out[k.strip()] = v.strip() if _ else "1"
+        if k.strip() not in KNOWN_KEYS:
+            sys.stderr.write("mccnn: MCCNN_DEBUG key %r is not known (mccnn_amd/_env.py KNOWN_KEYS): ignored\n" % k.strip())
     return out
 
 

@@ -1197,8 +1197,10 @@ static int build_large(int transposed, const float* sorted_pts, const int* sorte
                        int batch_size, float radius, int scale_inv, int avg, const int* order, void* rec_edges, int rec_ready,
                        int* start_t, int* perm_t, int tlist_ready, void* plan_buffer, void* ws, size_t ws_bytes, hipStream_t s) {
     const int rows = transposed ? n : m;
-    if (!rec_edges || batch_size <= 0 || !(radius > 0.0f) || !sorted_pts || !sorted_batch_ids || !pdfs || !samples || !start_idx ||
-        !packed || !aabb_min || !aabb_max)
+    // the geometry (points, densities, samples, boxes, radius) is only read where records are EVALUATED: with records
+    // ready (rec_ready) both plans are pure permutations of them, as the non-inline path always accepted
+    if (!rec_edges || !start_idx || !packed) return MCCNN_E_BADARG;
+    if (!rec_ready && (batch_size <= 0 || !(radius > 0.0f) || !sorted_pts || !sorted_batch_ids || !pdfs || !samples || !aabb_min || !aabb_max))
         return MCCNN_E_BADARG;
     long long off[6], total, cap, srows;
     int S;
@@ -1220,7 +1222,7 @@ static int build_large(int transposed, const float* sorted_pts, const int* sorte
     ConvArgs a = {};
     a.pts = sorted_pts; a.bids = sorted_batch_ids; a.pdfs = pdfs; a.samples = samples; a.start = start_idx;
     a.packed = reinterpret_cast<const int2*>(packed); a.mn = aabb_min; a.mx = aabb_max;
-    a.n = n; a.m = m; a.e = e; a.radius = radius; a.invRadius = 1.0f / radius; a.scaleInv = scale_inv; a.avg = avg;
+    a.n = n; a.m = m; a.e = e; a.radius = radius; a.invRadius = radius > 0.0f ? 1.0f / radius : 0.0f; a.scaleInv = scale_inv; a.avg = avg;
     a.B = batch_size;
     RowPlan p = {vrow, vcode, sliceOff, vposRow, nullptr, nullptr, rows, z.S};
     const int eb = ceil_div(e, 256);

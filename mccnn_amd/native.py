@@ -77,6 +77,7 @@ def _release_slot(t):
 
 
 _PARKED = []   # (slot, event): words of geometries dropped before their total arrived -- the count pass may still write them
+_PARKED_LOCK = threading.Lock()   # Geometry.__del__ parks from any thread, and from GC runs inside _poll_parked's own loop
 
 
 def _park_slot(t):
@@ -87,23 +88,35 @@ def _park_slot(t):
         ev.record()
     except Exception:   # interpreter shutdown, no device: the word simply stays referenced
         ev = None
-    _PARKED.append((t, ev))
+    _PARKED.append((t, ev))   # (list.append is atomic; _poll_parked never overwrites the list, see there)
 
 
 def _poll_parked():
     if not _PARKED:
         return
-    keep = []
-    for t, ev in _PARKED:
-        try:
-            done = int(t[0]) >= 0 or ev is None or ev.query()
-        except Exception:
-            done = False
-        if done:
-            _release_slot(t)
-        else:
-            keep.append((t, ev))
-    _PARKED[:] = keep
+    # Take the entries present NOW out of the list in one atomic step and work on the private copy: an entry parked while
+    # this loop runs (another thread, or a GC run triggered by the allocations below calling Geometry.__del__) stays in
+    # _PARKED and is never dropped -- `_PARKED[:] = keep` used to discard it and hand a word the count pass could still
+    # write back to the host allocator. Non-blocking: a second caller simply skips its poll.
+    if not _PARKED_LOCK.acquire(False):
+        return
+    try:
+        k = len(_PARKED)
+        items = _PARKED[:k]
+        del _PARKED[:k]
+        keep = []
+        for t, ev in items:
+            try:
+                done = int(t[0]) >= 0 or ev is None or ev.query()
+            except Exception:
+                done = False
+            if done:
+                _release_slot(t)
+            else:
+                keep.append((t, ev))
+        _PARKED.extend(keep)
+    finally:
+        _PARKED_LOCK.release()
 
 
 def _ws(nbytes, device):

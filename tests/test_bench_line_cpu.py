@@ -20,8 +20,15 @@ def _full_record(n_layers=17):
           "conv_kernels": "x" * 200, "executed_frac": 0.3576,
           "fwd_bwd": {"fwd": {"ms": 0.1689, "algorithmic_frac": 0.4378, "executed_frac": 0.31},
                       "bwd": {"ms": 0.366, "algorithmic_frac": 0.5758, "executed_frac": 0.36}},
-          "mfma_pipe_busy": {"bwd": {"kernel": "f1_bwd_edges", "busy": 0.24}, "fwd": {"kernel": "f", "busy": 0.31},
-                             "source": "profiles/x.json"}, "traffic_source": "profiles/y.json"}
+          "mfma_pipe_busy_from_committed_profile": {"bwd": {"kernel": "f1_bwd_edges", "busy": 0.24}, "fwd": {"kernel": "f", "busy": 0.31},
+                                                    "source": "profiles/x.json", "kernel_sources_match": True,
+                                                    "measured_in_this_run": False},
+          "traffic_from_committed_profile": {"bytes": 1224237649, "source": "profiles/y.json", "kernel_sources_match": True,
+                                             "measured_in_this_run": False},
+          "find_neighbors": {"bound": "hbm", "ms": 0.061, "achieved": 675.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.084},
+          "find_neighbors_8rooms": {"bound": "hbm", "ms": 0.285, "achieved": 1160.0, "peak": 8000.0, "unit": "GB/s",
+                                    "frac": 0.145, "rooms": 8, "points": 800000, "edges": 36000000,
+                                    "algorithmic_bytes": 330000000}}
     layer = {"name": "Pool_0", "levels": [0, 1], "radius": 0.1, "fin": 1, "fout": 64, "fwd_ms": 0.083, "bwd_ms": 0.111,
              "roofline_fwd": dict(rl), "roofline_bwd": dict(rl), "note": "n" * 300}
     cfg = {"workload": "w" * 120, "points": 100000, "clouds": 1, "level_sizes": [100000, 5627, 1273, 318, 73],
@@ -33,6 +40,7 @@ def _full_record(n_layers=17):
         "metric": "MC-convolved points/sec (fwd+bwd), 100k-pt cloud r=0.1", "value": 172722645.0, "unit": "points/s",
         "n_gpus": 1, "steps": 100, "warmup": 10, "ms_per_step": 0.579, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "sequential": {"ms_per_step": 0.7005, "value": 142755174.9, "unit": "points/s"},
         "config": {"workload": "ScanNet-like non-uniform room " + "c" * 150, "points_total": 100000,
                    "points_per_gpu": 100000, "edges_per_gpu": 4543198, "layer": "1to64", "parallelism": "cloud-per-GPU dp1",
                    "headline_mode": "pipelined", "pipeline": "p" * 400, "pipelined_ms_per_step": 0.579,
@@ -68,6 +76,17 @@ def test_final_line_is_small_and_complete():
         assert k in out["cpu_baseline"]
     assert out["config"]["workload"] == rec["config"]["workload"] and "model" not in out["config"]
     assert out["strong"]["value"] == rec["strong"]["value"]
+    # round-5 review, item 6: (a) the strictly sequential step at top level beside `value`; (b) numbers that come from a
+    # committed profile are NAMED so and say whether the profile belongs to this tree's kernels; (c) the neighbour search
+    # against the HBM roofline on one room AND on the 8-room batch
+    assert out["sequential"] == rec["sequential"] and out["sequential"]["ms_per_step"] >= out["ms_per_step"]
+    r = out["roofline"]
+    assert "mfma_pipe_busy" not in r and "traffic_source" not in r
+    assert r["mfma_pipe_busy_from_committed_profile"] == {"fwd": 0.31, "bwd": 0.24, "kernel_sources_match": True}
+    assert r["traffic_from_committed_profile"] == {"bytes": 1224237649, "source": "profiles/y.json", "kernel_sources_match": True}
+    for k in ("find_neighbors", "find_neighbors_8rooms"):
+        assert r[k]["bound"] == "hbm" and r[k]["unit"] == "GB/s" and 0 < r[k]["frac"] < 1, k
+    assert r["find_neighbors_8rooms"]["rooms"] == 8
     assert set(out["configs"]) == {"cfg0", "cfg1", "cfg2", "cfg3", "cfg4"}
     for c in out["configs"].values():
         assert {"ms_per_step", "value", "host_issue_ms_per_step", "launches"} <= set(c)
@@ -91,6 +110,19 @@ def test_emit_record_prints_the_compact_line_last(tmp_path, capsys):
     assert len(lines) == 2 and lines[0].startswith("details: ") and len(lines[-1]) < 4096
     assert json.loads(lines[-1])["details"] == path
     assert json.load(open(path)) == rec == json.loads(lines[0][len("details: "):])
+
+
+def test_profile_numbers_are_dropped_when_the_profile_is_of_other_sources(tmp_path):
+    """bench.kernel_sources_sha1 == the hash tools/prof_summary.py records; a profile of other kernel sources does not
+    supply the contract's `traffic`."""
+    import subprocess
+    import sys
+    b = _bench()
+    sha = b.kernel_sources_sha1()
+    assert len(sha) == 40
+    ps = os.path.join(ROOT, "tools", "prof_summary.py")
+    code = "__file__ = %r; exec(open(__file__).read().split('SRC_SHA = _src_sha()')[0]); print(_src_sha())" % ps
+    assert subprocess.check_output([sys.executable, "-c", code]).decode().strip() == sha
 
 
 def test_last_committed_full_record_compacts():

@@ -194,3 +194,40 @@ def test_debug_list_parser_of_the_library(tmp_path):
     subprocess.check_call([cxx, "-std=c++17", "-I", os.path.join(ROOT, "mccnn_amd", "csrc"), str(src), "-o", str(exe)])
     out = subprocess.run([str(exe)], env=dict(os.environ, MCCNN_DEBUG="small_off, plan_min_l=16 ,ecap_scale=0.5"), capture_output=True, text=True)
     assert out.stdout.split() == ["1", "16", "7", "9", "0.5"]
+
+
+def test_debug_keys_one_table_and_unknown_keys_are_reported(tmp_path):
+    """ONE table of MCCNN_DEBUG keys: kDebugKeys (csrc/debug_opts.h) == KNOWN_KEYS (mccnn_amd/_env.py); every key that any
+    source file queries is in it; a key that is not is reported on stderr by both sides (a misspelt A/B switch used to be
+    ignored silently -- the void-A/B failure mode of round 5)."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import sys
+    from mccnn_amd import _env
+    hdr = open(os.path.join(ROOT, "mccnn_amd", "csrc", "debug_opts.h")).read()
+    body = hdr[hdr.index("#define MCCNN_DEBUG_KEYS"):hdr.index("static const char* const kDebugKeys")]
+    ckeys = re.findall(r'"([a-z0-9_]+)"', body)
+    assert ckeys == list(_env.KNOWN_KEYS) and len(set(ckeys)) == len(ckeys)
+    used = set()
+    for f in glob.glob(os.path.join(ROOT, "mccnn_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "mccnn_amd", "*.py")):
+        if os.path.isfile(f):
+            txt = open(f, errors="ignore").read()
+            used |= set(re.findall(r'debug_(?:int|float|opt)\("([a-z0-9_]+)"', txt))
+            used |= set(re.findall(r'_env\.debug\(\s*"([a-z0-9_]+)"', txt))
+    assert used <= set(ckeys), sorted(used - set(ckeys))
+    # the Python side reports an unknown key ...
+    r = subprocess.run([sys.executable, "-c", "from mccnn_amd import _env; print(_env.debug('small_off', 0))"], cwd=ROOT,
+                       env=dict(os.environ, MCCNN_DEBUG="small_off,plan_smal=8192"), capture_output=True, text=True)
+    assert r.stdout.strip() == "1" and "plan_smal" in r.stderr and "small_off" not in r.stderr
+    # ... and so does the library's parser
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("no g++")
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "debug_opts.h"\nint main() { return mccnn::debug_int("small_off", 0) + mccnn::debug_int("plan_small", 4096) == 4097 ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    subprocess.check_call([cxx, "-std=c++17", "-I", os.path.join(ROOT, "mccnn_amd", "csrc"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], env=dict(os.environ, MCCNN_DEBUG="small_off, plan_smal=8192 ,nw_lean=1"), capture_output=True, text=True)
+    assert out.returncode == 0 and out.stderr.count("not known") == 1 and "plan_smal" in out.stderr

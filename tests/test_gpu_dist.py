@@ -195,6 +195,10 @@ def test_bench_eight_ranks_sharing_the_gpu_weak_and_strong(mc):
     partition."""
     rec = _torchrun_bench(8, [])
     assert rec["n_gpus"] == 8 and rec["config"]["rccl_world_size"] == 8 and rec["scaling"] == "weak"
+    # every collective kind ran once before the first warm-up step (a SCALE run times steady state), and a rank's share
+    # of the fixed batch IS the N = 1 workload: one room per rank in both curves
+    assert rec["config"]["collectives_warmed_before_warmup"] is True
+    assert rec["strong"]["rank_stats"] is None or rec["strong"]["rank_stats"]["points"] == [20000] * 8
     assert rec["config"]["points_total"] == 8 * 20000 and rec["config"]["points_per_gpu"] == 20000
     st = rec["config"]["rank_stats"]
     assert len(st["own_ms_per_step"]) == 8 and st["points"] == [20000] * 8 and min(st["own_ms_per_step"]) > 0

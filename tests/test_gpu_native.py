@@ -323,3 +323,69 @@ def test_geometries_dropped_before_their_totals_arrive_ctypes_binding():
                           "-k", "test_geometries_dropped_before_their_totals_arrive and not ctypes"], env=env, capture_output=True,
                          text=True, timeout=600, cwd=root)
     assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-1500:] + out.stderr[-500:]
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["native", "opchain"])
+def test_use_pdf_false_against_the_oracle(mc, oracle, native):
+    """usePDF=False (utils/MCConvBuilder.py:379-391: the PDF tensor is a tensor of ones, same cache key scheme): the
+    builder's native executor (and its op-by-op path) against the IDENTICAL graph on the oracle ops -- a combin Fin = 1
+    layer, a small-Fin combin layer, a depth-wise layer, a pooling layer to another level, and a layer that asks for
+    usePDF=True on the same list (another cache entry, real densities). Lists bit-exact, outputs and all seven gradients
+    within 1e-4 norm-wise and per element."""
+    import torch
+    from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder
+    from tests.oracle_ops import OracleOps
+    pts, bids = make_cloud(1500, 2, 11, "clustered", True)
+    B = 2
+    oo = OracleOps(oracle)
+    P, Bi = _t(pts), _t(bids)
+    ph = PointHierarchy(P, torch.ones((len(pts), 1), device="cuda"), Bi, [0.15], "PH", B, True)
+    phc = PointHierarchy(torch.from_numpy(pts), torch.ones((len(pts), 1)), torch.from_numpy(bids), [0.15], "PH", B, True, ops=oo)
+    assert np.array_equal(ph.points_[1].cpu().numpy(), phc.points_[1].numpy())
+    torch.manual_seed(5)
+    cb = ConvolutionBuilder(KDEWindow=0.25, relativeRadius=True, usePDF=False, native=native)
+    cbc = ConvolutionBuilder(KDEWindow=0.25, relativeRadius=True, usePDF=False, ops=oo)
+    cb.reset()
+    cbc.reset()
+    assert bool(cb.native_) == native
+    rng = np.random.default_rng(3)
+    layers = [  # name, lin, lout, fin, fout, combin, radius, usePDF override
+        ("NP_f1", 0, 0, 1, 16, True, 0.2, None),
+        ("NP_3to8", 0, 0, 3, 8, True, 0.2, None),
+        ("NP_dw", 0, 0, 16, 16, False, 0.2, None),
+        ("NP_pool", 0, 1, 8, 8, False, 0.3, None),
+        ("WP_dw", 0, 0, 16, 16, False, 0.2, True),
+    ]
+    sizes = [int(p.shape[0]) for p in ph.points_]
+    for (name, lin, lout, fin, fout, combin, radius, up) in layers:
+        n, m = sizes[lin], sizes[lout]
+        outF = fout if combin else fin
+        f = (2 * rng.random((n, fin)) - 1).astype(np.float32)
+        og = (2 * rng.random((m, outF)) - 1).astype(np.float32)
+        F = _t(f).requires_grad_(True)
+        out = cb.create_convolution(name, ph, lin, F, fin, radius, ph, lout, combin, fout, usePDF=up)
+        names = [name + s for s in ("_weights", "_biases", "_weights2", "_biases2", "_weights3", "_biases3")]
+        gp = dict(cb.named_parameters())
+        cbc.load_state_dict({k: gp[k].detach().cpu().clone() for k in names}, strict=False)
+        Fc = torch.from_numpy(f).requires_grad_(True)
+        outc = cbc.create_convolution(name, phc, lin, Fc, fin, radius, phc, lout, combin, fout, usePDF=up)
+        cp = dict(cbc.named_parameters())
+        g_gpu = torch.autograd.grad([out], [F] + [gp[k] for k in names], [_t(og)])
+        g_cpu = torch.autograd.grad([outc], [Fc] + [cp[k] for k in names], [torch.from_numpy(og)])
+        torch.cuda.synchronize()
+        _close(out, outc, RTOL, name + ":out")
+        for nm, a, b in zip(["featGrad"] + names, g_gpu, g_cpu):
+            _close(a, b, RTOL, name + ":" + nm)
+    # two PDF cache entries over the radius-0.2 list: "...|False" (ones) and "...|True" (densities)
+    assert list(cb.cachePDFs_) == list(cbc.cachePDFs_) and list(cb.cacheNeighs_) == list(cbc.cacheNeighs_)
+    keys = [k for k in cbc.cachePDFs_ if k.endswith("|False")]
+    assert len(keys) == 2 and len(cbc.cachePDFs_) == 3
+    for k in cbc.cachePDFs_:
+        a = cb.cachePDFs_[k]
+        a = a.value() if hasattr(a, "value") else a
+        if k.endswith("|False"):
+            assert float(a.min()) == 1.0 and float(a.max()) == 1.0, k
+        _close(a.reshape(-1), cbc.cachePDFs_[k].reshape(-1), RTOL, k)
+    for k in cbc.cacheNeighs_:
+        (s0, p0), (s1, p1) = cb.cacheNeighs_[k], cbc.cacheNeighs_[k]
+        assert np.array_equal(s0.cpu().numpy(), s1.numpy()) and np.array_equal(p0.cpu().numpy(), p1.numpy()), k

@@ -13,29 +13,45 @@ ident = lambda a: a
 
 
 # ------------------------------------------------------------------ structural known answers
+# The expected values are NOT typed in here: tests/golden/reference_constants.json is written by
+# tests/golden/make_reference_constants.py, which parses them out of the reference's own sources in the build container
+# (find_neighbors.cu:282-291, poisson_sampling.cu:192-196, compute_pdf.cu:85-87, genCompileScript.py:20,
+# sort_gpu.cu:404-408 + the radii of models/*.py).
+import json
+
+with open(os.path.join(GOLD, "reference_constants.json")) as _f:
+    REFC = json.load(_f)
+
+
 def test_neighbor_offset_table(oracle):
     t = oracle.cell_offsets()
-    # find_neighbors.cu:282-291: x fastest (+1,0,-1), then y, then z
-    assert t[0].tolist() == [1, 1, 1] and t[1].tolist() == [0, 1, 1] and t[2].tolist() == [-1, 1, 1]
-    assert t[3].tolist() == [1, 0, 1] and t[9].tolist() == [1, 1, 0] and t[13].tolist() == [0, 0, 0]
-    assert t[26].tolist() == [-1, -1, -1]
+    assert t.tolist() == REFC["cell_offsets"]
     assert len({tuple(r) for r in t.tolist()}) == 27 and np.abs(t).max() == 1
+    # the closed form the HIP kernels use (common.h neigh_offset): x fastest (+1, 0, -1), then y, then z
     exp = np.array([[1 - o % 3, 1 - (o // 3) % 3, 1 - o // 9] for o in range(27)])
-    assert np.array_equal(t, exp)
+    assert np.array_equal(np.array(REFC["cell_offsets"]), exp)
 
 
 def test_poisson_phase_table(oracle):
     t = oracle.cell_offsets_pool()
-    # poisson_sampling.cu:192-196, first and last rows of the listing
-    assert t[:7].tolist() == [[1, 1, -1], [0, -1, 1], [0, 1, 1], [0, 1, 0], [0, 0, 1], [0, -1, 0], [-1, 1, -1]]
-    assert t[20:].tolist() == [[1, 0, -1], [1, -1, 0], [-1, 0, 1], [1, 1, 1], [-1, 0, -1], [-1, -1, -1], [-1, -1, 1]]
+    assert t.tolist() == REFC["cell_offsets_pool"]
     assert len({tuple(r) for r in t.tolist()}) == 27 and np.abs(t).max() == 1
 
 
-@pytest.mark.parametrize("r,nc", [(0.1, 10), (0.2, 5), (0.4, 2), (0.8, 1), (0.05, 20), (0.025, 40), (0.03, 33),
-                                  (0.15, 6), (3 ** 0.5 + 0.1, 1)])
+def test_poisson_phase_table_of_the_kernels():
+    # the table compiled into the HIP kernels (csrc/common.h kPoolOffsets, packed (dx+1) | (dy+1)<<2 | (dz+1)<<4)
+    import re
+    src = open(os.path.join(os.path.dirname(GOLD), "..", "mccnn_amd", "csrc", "common.h")).read()
+    body = src[src.index("kPoolOffsets[27]"):]
+    body = body[:body.index("};")]
+    ent = re.findall(r"(\d)\s*\|\s*\((\d)\s*<<\s*2\)\s*\|\s*\((\d)\s*<<\s*4\)", body)
+    assert len(ent) == 27
+    assert [[int(a) - 1, int(b) - 1, int(c) - 1] for a, b, c in ent] == REFC["cell_offsets_pool"]
+
+
+@pytest.mark.parametrize("r,nc", [tuple(x) for x in REFC["num_cells_known"]])
 def test_num_cells_known_answers(oracle, r, nc):
-    # numCells(scale_inv) = max(1, (int)(1.0f / r)), sort_gpu.cu:404-408 (values from SURVEY 8a)
+    # numCells(scale_inv) = max(1, (int)(1.0f / r)), sort_gpu.cu:404-408, on every radius the reference's models use
     z = np.zeros((1, 3), np.float32)
     assert oracle.num_cells(z, z + 1, 1, r, True) == nc
 
@@ -48,7 +64,26 @@ def test_num_cells_absolute(oracle):
 
 
 def test_block_size(oracle):
-    assert oracle.get_block_size() == 8  # genCompileScript.py:20
+    assert oracle.get_block_size() == REFC["block_mlp_size"]  # genCompileScript.py:20
+
+
+def test_gauss_constant(oracle):
+    # compute_pdf.cu:85-87: a centre whose only neighbour is itself has pdf = (invH * c * exp(0))^3 / 1, every product
+    # rounded to f32 as the reference does; c is the literal parsed from the reference
+    c = float(REFC["gauss_norm"])
+    assert REFC["gauss_norm_uses"] == 3
+    pts = np.array([[0.5, 0.5, 0.5]], np.float32)
+    bids = np.zeros((1, 1), np.int32)
+    mn, mx = pts.copy(), pts.copy() + 1
+    start = np.zeros((1, 1), np.int32)
+    packed = np.zeros((1, 2), np.int32)
+    for window in (0.2, 0.25):
+        pdf = oracle.compute_pdf(pts, bids, mn, mx, start, packed, window, 0.3, 1, False)
+        invH = np.float32(1) / np.float32(window)          # float invH = 1 / h
+        g = np.float32(float(invH) * (c * 1.0))            # float * (double * exp(0)) -> double, rounded on assignment
+        g = np.float32(float(g * invH) * (c * 1.0))        # (float * float) is a float product in C, then * double
+        g = np.float32(float(g * invH) * (c * 1.0))
+        assert np.asarray(pdf).reshape(-1)[0] == g
 
 
 # ------------------------------------------------------------------ NumPy float64 cross-check

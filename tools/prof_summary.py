@@ -9,6 +9,24 @@ import json
 import os
 import sys
 
+
+def _src_sha():
+    # sha1 of the kernel sources these numbers were taken from (bench.kernel_sources_sha1 computes the same): a reader of a
+    # committed profile -- and bench.py, which quotes its traffic -- can tell whether it belongs to the tree at hand
+    import glob
+    import hashlib
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mccnn_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+SRC_SHA = _src_sha()
+
 import pandas as pd
 
 out = sys.argv[1]
@@ -68,5 +86,7 @@ if rows:
             if f == f and w == w:
                 traffic[k] = {"fetch_bytes": float(f) * 1024 * 2, "write_bytes": float(w) * 1024,
                               "bytes": float(f) * 1024 * 2 + float(w) * 1024}
+    traffic["_kernel_sources_sha1"] = SRC_SHA
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+kern["_kernel_sources_sha1"] = SRC_SHA
 json.dump(kern, open(os.path.join(out, "kernels.json"), "w"), indent=1)
