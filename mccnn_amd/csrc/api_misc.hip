@@ -7,6 +7,49 @@ std::atomic<long long> g_launches{0};
 thread_local int g_background = 0;
 std::atomic<int> g_small_off{debug_int("small_off", 0) ? 1 : 0};
 std::atomic<int> g_f1_x4_min_edges{debug_int("f1_x4_min_e", 2000000)};
+
+// The head of a call chain whose first kernel itself needs zeros (histogram counters of a grid build, ...): ONE launch
+// for everything the chain wants cleared up front; every later need is met by a kernel of the chain (clear_span_dev).
+__global__ __launch_bounds__(256) void clear_spans(ClearSpan a, ClearSpan b, ClearSpan c) {
+    clear_span_dev(a);
+    clear_span_dev(b);
+    clear_span_dev(c);
+}
+// caller-owned buffers of any 4-byte-aligned size (a zero-filled scatter target, a one-word counter): 4-byte granular
+__global__ __launch_bounds__(256) void zero_words(unsigned* __restrict__ p, unsigned long long words) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < words; k += stride) p[k] = 0u;
+}
+__global__ __launch_bounds__(256) void fill_words(unsigned* __restrict__ p, unsigned long long words, unsigned v) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < words; k += stride) p[k] = v;
+}
+int launch_fill_words(void* p, size_t words, unsigned v, hipStream_t s) {
+    if (words == 0) return 0;
+    long long blocks = (long long)((words + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    fill_words<<<(int)blocks, 256, 0, s>>>(reinterpret_cast<unsigned*>(p), (unsigned long long)words, v);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+int launch_zero_words(void* p, size_t words, hipStream_t s) {
+    if (words == 0) return 0;
+    if ((((uintptr_t)p) & 15) == 0 && (words & 3) == 0) return launch_clear_spans(clear_span(p, words * 4), no_span(), no_span(), s);
+    long long blocks = (long long)((words + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    zero_words<<<(int)blocks, 256, 0, s>>>(reinterpret_cast<unsigned*>(p), (unsigned long long)words);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+int launch_clear_spans(ClearSpan a, ClearSpan b, ClearSpan c, hipStream_t s) {
+    const unsigned long long most = a.n16 > b.n16 ? (a.n16 > c.n16 ? a.n16 : c.n16) : (b.n16 > c.n16 ? b.n16 : c.n16);
+    if (most == 0) return 0;
+    long long blocks = (long long)((most + 255) / 256);
+    if (blocks > 4096) blocks = 4096;   // 16 B per thread and trip: 16 MB per sweep of the grid
+    clear_spans<<<(int)blocks, 256, 0, s>>>(a, b, c);
+    MCCNN_LAUNCHED();
+    return 0;
+}
 }
 
 extern "C" {

@@ -62,6 +62,32 @@ struct Arena {
     }
 };
 
+// ---------------------------------------------------------------------------------------
+// Clearing without launches of its own. Counters, status words of the single-pass scans, selection bytes ... have to be
+// zero when the kernel that uses them starts. A hipMemsetAsync is a launch (~4 us on both sides of the queue, 13 per
+// step of BASELINE cfg1, 44 of cfg4 in round 5); instead a kernel that runs EARLIER in the same chain clears what a later
+// one needs, grid-stride, on its way (clear_span_dev at the top of the kernel), and only the head of a call chain -- when
+// its first kernel itself needs zeros -- launches clear_spans. Spans are 16-byte granular: every arena piece is 256-byte
+// aligned and padded (Arena::take / align_up).
+struct ClearSpan {
+    void* p;
+    unsigned long long n16;  // 16-byte units
+};
+inline ClearSpan clear_span(void* p, size_t bytes) { return ClearSpan{p, (unsigned long long)((bytes + 15) / 16)}; }
+inline ClearSpan no_span() { return ClearSpan{nullptr, 0ull}; }
+__device__ __forceinline__ void clear_span_dev(const ClearSpan& s) {
+    if (s.n16 == 0) return;
+    uint4* q = reinterpret_cast<uint4*>(s.p);
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < s.n16; k += stride)
+        q[k] = make_uint4(0u, 0u, 0u, 0u);
+}
+// the head of a chain: up to three spans in one launch (defined in api_misc.hip)
+int launch_clear_spans(ClearSpan a, ClearSpan b, ClearSpan c, hipStream_t s);
+// caller-owned buffers (any 4-byte aligned address and size): a zero-filled scatter target, a one-word counter
+int launch_zero_words(void* p, size_t words, hipStream_t s);
+int launch_fill_words(void* p, size_t words, unsigned v, hipStream_t s);   // (usePDF = False: a tensor of ones)
+
 // Exclusive prefix sum of n int32 (out may alias in). If total != nullptr the grand
 // total is written there. ws must hold scan_workspace_bytes(n). Defined in scan.hip.
 // Up to 2 M elements the scan is ONE launch (decoupled look-back); its status words are the first

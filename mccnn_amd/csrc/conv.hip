@@ -884,7 +884,8 @@ __global__ __launch_bounds__(256) void gather_edge_featgrad(const int* __restric
 __global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ partials, int numWaves, int nb,
                                                         float* __restrict__ dw1, float* __restrict__ db1,
                                                         float* __restrict__ dw2, float* __restrict__ db2,
-                                                        float* __restrict__ dw3, float* __restrict__ db3) {
+                                                        float* __restrict__ dw3, float* __restrict__ db3, ClearSpan x1) {
+    clear_span_dev(x1);  // (the feature gradient the scatter pass that follows adds into: common.h)
     reduce_partials_body(blockIdx.x, partials, numWaves, nb, dw1, db1, dw2, db2, dw3, db3);
 }
 
@@ -1039,7 +1040,7 @@ int launch_edge_records(const ConvArgs& a, float4* rec, hipStream_t s) {
 
 void launch_reduce_partials(const float* partials, int rows, int nb, float* dw1, float* db1, float* dw2, float* db2,
                             float* dw3, float* db3, hipStream_t s) {
-    reduce_partials<<<ceil_div((long long)nb * 176, 16), 1024, 0, s>>>(partials, rows, nb, dw1, db1, dw2, db2, dw3, db3);
+    reduce_partials<<<ceil_div((long long)nb * 176, 16), 1024, 0, s>>>(partials, rows, nb, dw1, db1, dw2, db2, dw3, db3, no_span());
 }
 
 int conv_fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_feats, const int* sorted_batch_ids,
@@ -1067,7 +1068,10 @@ size_t transpose_count_bytes(int n) { return align_up((size_t)n * 4) + scan_work
 int transpose_count(const int2* pk, int e, int n, int* start_t, char* blk, int* slot, hipStream_t s) {
     const size_t cntBytes = align_up((size_t)n * 4);
     int* cnt = (int*)blk;
-    MCCNN_MEMSET(hipMemsetAsync(blk, 0, cntBytes + scan_status_bytes(n), s));
+    {   // the head of a transposition: row counters + the scan's status words (neighbours: one span)
+        int rc = launch_clear_spans(clear_span(blk, cntBytes + scan_status_bytes(n)), no_span(), no_span(), s);
+        if (rc) return rc;
+    }
     if (n <= MCCNN_TR_LDS_BINS && e >= 4 * n) tr_count_lds<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, n, cnt, slot);
     else tr_count<<<ceil_div(e, 256), 256, 0, s>>>(pk, e, cnt, slot);
     MCCNN_LAUNCHED();
@@ -1199,8 +1203,7 @@ static int conv_fwd_impl(const float* sorted_pts, const float* sorted_feats, con
         return 0;
     }
     if (e == 0) {
-        MCCNN_MEMSET(hipMemsetAsync(out, 0, (size_t)m * a.outF * (bf16 ? 2 : sizeof(float)), s));
-        return 0;
+        return launch_zero_words(out, (size_t)m * a.outF * (bf16 ? 2 : sizeof(float)) / 4, s);  // (bf16 rows: outF is even)
     }
     // fallback for very wide layers (nb > MCCNN_LDS_MAX_NB): VALU kernel with scalar-loaded weights
     int G = 2048 / a.outF;
@@ -1273,8 +1276,7 @@ int mccnn_transpose_neighbors(const int* packed, int e, int n, int* start_t, int
     if (e < 0 || n < 0 || !start_t) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (e == 0 || n == 0) {
-        MCCNN_MEMSET(hipMemsetAsync(start_t, 0, (size_t)(n + 1) * sizeof(int), s));
-        return 0;
+        return launch_zero_words(start_t, (size_t)n + 1, s);
     }
     if (!packed || !perm_t) return MCCNN_E_BADARG;
     if (!ws || ws_bytes < mccnn_transpose_neighbors_workspace_bytes(n, e)) return MCCNN_E_WORKSPACE;
@@ -1346,15 +1348,27 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
     const bool f1Clears = mfma && m > 0 && e > 0 && f1_shape(num_in_feats, num_out_feats, combin);
     // (... and the transposed gather of combin layers with 2..4 input features writes every row)
     const bool gatherT = mfma && combin && a.Fin >= 2 && a.Fin <= 4 && start_t && perm_t && m > 0 && e > 0;
-    if (n > 0 && !dfeatT && !f1Clears && !gatherT)
-        MCCNN_MEMSET(hipMemsetAsync(feat_grad, 0, (size_t)n * a.Fin * (bf16 ? 2 : sizeof(float)), s));
-    if (!mfma || m == 0 || e == 0) {
-        MCCNN_MEMSET(hipMemsetAsync(dw1, 0, 3 * nn * sizeof(float), s));
-        MCCNN_MEMSET(hipMemsetAsync(db1, 0, nn * sizeof(float), s));
-        MCCNN_MEMSET(hipMemsetAsync(dw2, 0, 8 * nn * sizeof(float), s));
-        MCCNN_MEMSET(hipMemsetAsync(db2, 0, nn * sizeof(float), s));
-        MCCNN_MEMSET(hipMemsetAsync(dw3, 0, 8 * nn * sizeof(float), s));
-        MCCNN_MEMSET(hipMemsetAsync(db3, 0, nn * sizeof(float), s));
+    // feat_grad of the paths that ACCUMULATE into it (float atomics of scatter_edge_featgrad, the VALU fallback): cleared
+    // by reduce_partials -- the kernel of this chain that runs before the first add -- when the rows allow 16-byte stores,
+    // by a launch of its own otherwise
+    const size_t fgBytes = (size_t)n * a.Fin * (bf16 ? 2 : sizeof(float));
+    ClearSpan fgSpan = no_span();
+    if (n > 0 && !dfeatT && !f1Clears && !gatherT) {
+        const bool scatterPath = mfma && m > 0 && e > 0 && combin && a.Fin > 1;   // sweep -> reduce_partials -> scatter
+        if (scatterPath && (((uintptr_t)feat_grad) & 15) == 0 && fgBytes % 16 == 0) {
+            fgSpan = clear_span(feat_grad, fgBytes);
+        } else {
+            int rc = launch_zero_words(feat_grad, fgBytes / 4, s);
+            if (rc) return rc;
+        }
+    }
+    if (!mfma || m == 0 || e == 0) {  // (degenerate lists and the VALU fallback: the six sums start from zero)
+        float* gp[6] = {dw1, db1, dw2, db2, dw3, db3};
+        const size_t gn[6] = {3 * nn, nn, 8 * nn, nn, 8 * nn, nn};
+        for (int k = 0; k < 6; ++k) {
+            int rc = launch_zero_words(gp[k], gn[k], s);
+            if (rc) return rc;
+        }
     }
     if (m == 0 || e == 0) return 0;
     if (!out_grad) return MCCNN_E_BADARG;
@@ -1405,7 +1419,7 @@ static int conv_bwd_impl(const float* sorted_pts, const float* sorted_feats, con
             MCCNN_LAUNCHED();
             reduce_partials<<<ceil_div((long long)nbT * 176, 16), 1024, 0, s>>>(
                 partials, rows, nbT, dw1 + (size_t)q0 * 24, db1 + (size_t)q0 * 8, dw2 + (size_t)q0 * 64, db2 + (size_t)q0 * 8,
-                dw3 + (size_t)q0 * 64, db3 + (size_t)q0 * 8);
+                dw3 + (size_t)q0 * 64, db3 + (size_t)q0 * 8, q0 == 0 ? fgSpan : no_span());
             MCCNN_LAUNCHED();
         }
         if (combin && a.Fin > 1) {  // Fin == 1: the main kernel adds each edge's finished sum itself

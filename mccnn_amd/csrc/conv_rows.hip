@@ -100,7 +100,9 @@ static PlanSizes plan_sizes(int rows, int e) {
 // ------------------------------------------------------------------------------------------------ layout
 // pieces per row position of the visiting order
 __global__ __launch_bounds__(256) void vr_count(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
-                                                int* __restrict__ vcnt, int L) {
+                                                int* __restrict__ vcnt, int L, ClearSpan x1, ClearSpan x2) {
+    clear_span_dev(x1);  // the status words of the two prefix sums that follow in this chain (common.h)
+    clear_span_dev(x2);
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= rows) return;
     int r = order ? order[p] : p;
@@ -1044,10 +1046,7 @@ int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order
                          int* slice_off, int* vpos_row, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
     if (rows < 0 || e < 0 || !slice_off) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    if (rows == 0) {
-        MCCNN_MEMSET(hipMemsetAsync(slice_off, 0, sizeof(int), s));
-        return 0;
-    }
+    if (rows == 0) return launch_zero_words(slice_off, 1, s);
     if (!row_start || !plan_vrow || !plan_vcode || !vpos_row) return MCCNN_E_BADARG;
     if (!ws || ws_bytes < mccnn_rowplan_workspace_bytes(rows, e)) return MCCNN_E_WORKSPACE;
     const PlanSizes z = plan_sizes(rows, e);
@@ -1065,15 +1064,16 @@ int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order
     void* scan1 = ar.take<char>(scan_workspace_bytes(rows));
     void* scan2 = ar.take<char>(scan_workspace_bytes(z.S));
     if (!vcnt || !vposP || !vlistRow || !sliceSlots || !scan1 || !scan2) return MCCNN_E_WORKSPACE;
-    vr_count<<<ceil_div(rows, 256), 256, 0, s>>>(row_start, rows, e, order, vcnt, z.L);
+    vr_count<<<ceil_div(rows, 256), 256, 0, s>>>(row_start, rows, e, order, vcnt, z.L, clear_span(scan1, scan_status_bytes(rows)),
+                                                  clear_span(scan2, scan_status_bytes(z.S)));
     MCCNN_LAUNCHED();
-    int rc = exclusive_scan_i32(vcnt, vposP, rows, vposP + rows, scan1, s);  // vposP[rows] = number of virtual rows
+    int rc = exclusive_scan_i32(vcnt, vposP, rows, vposP + rows, scan1, s, true);  // vposP[rows] = number of virtual rows
     if (rc) return rc;
     vr_expand<<<ceil_div(rows, 256), 256, 0, s>>>(row_start, rows, e, order, vposP, vpos_row, vlistRow, z.L);
     MCCNN_LAUNCHED();
     sell_sort<<<z.windows, 256, 0, s>>>(row_start, rows, e, vlistRow, vpos_row, vposP + rows, plan_vrow, plan_vcode, sliceSlots, z.L);
     MCCNN_LAUNCHED();
-    return exclusive_scan_i32(sliceSlots, slice_off, z.S, slice_off + z.S, scan2, s);
+    return exclusive_scan_i32(sliceSlots, slice_off, z.S, slice_off + z.S, scan2, s, true);
 }
 
 int mccnn_edge_records(const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs, const float* samples,

@@ -20,6 +20,17 @@
 
 namespace mccnn {
 std::atomic<int>& conv_impl_override();  // conv.hip (mccnn_debug_conv_impl)
+// grid.hip: the grid build as one chain of four launches, the visiting order of foreign centres as three; what each wants
+// cleared before its first kernel is a span the caller may clear together with others (one launch per geometry)
+ClearSpan grid_head_span(int n, int batch_size, int num_cells, void* ws, size_t ws_bytes);
+int build_grid_fused(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n,
+                     int batch_size, int num_cells, int* new_idx, float* out_pts, int* out_batch_ids, int* cell_indexs,
+                     int* inv_idx, void* ws, size_t ws_bytes, hipStream_t s, const int* n_dev, bool cleared, ClearSpan x1,
+                     ClearSpan x2);
+size_t visiting_order_workspace_bytes(int m, int batch_size, int num_cells);
+ClearSpan visiting_order_head_span(int m, int batch_size, int num_cells, void* ws, size_t ws_bytes);
+int visiting_order(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int m, int batch_size,
+                   int num_cells, int* order, void* ws, size_t ws_bytes, hipStream_t s, bool cleared);
 }
 
 using namespace mccnn;
@@ -84,6 +95,7 @@ struct GeoLayout {
 };
 
 size_t cells_of(int B, int nc) { return (size_t)B * nc * nc * nc; }
+constexpr int MCCNN_ORDER_MIN_M = 16384;  // foreign centres get a visiting order of their own from this many on
 
 // byte offsets of the pieces of a geometry buffer; total_bytes == 0: the grid does not fit 32-bit keys
 GeoLayout geo_layout(int n, int m, int B, int nc, int e_cap, bool with_grid) {
@@ -104,16 +116,21 @@ GeoLayout geo_layout(int n, int m, int B, int nc, int e_cap, bool with_grid) {
     L.total = o; o += 256;
     L.order = o; o += al(m1 * 4);
     size_t w = mccnn_find_neighbors_workspace_bytes(m, n);
+    // the grid build and the visiting order of foreign centres (>= MCCNN_ORDER_MIN_M of them) run before the search and
+    // are cleared by ONE launch at the head of the chain: side by side, not aliased (the search and the KDE reuse the space)
+    size_t head = 0;
     if (with_grid) {
         const size_t g = mccnn_build_grid_workspace_bytes(n, B, nc);
         if (g == 0) return L;
-        if (g > w) w = g;
+        head += al(g);
     }
-    // a visiting order for centres of another level: their destinations in this grid (sort_step1 on the centres) + keys
-    const size_t c = mccnn_sort_step1_workspace_bytes(m, B, nc);
-    if (c == 0) return L;
-    const size_t cw = c + al(m1 * 4) * 2;
-    if (cw > w) w = cw;
+    if (m >= MCCNN_ORDER_MIN_M) {
+        const size_t c = visiting_order_workspace_bytes(m, B, nc);
+        if (c == 0) return L;
+        head += al(c);
+    }
+    if (head > w) w = head;
+    if (mccnn_sort_step1_workspace_bytes(m, B, nc) == 0) return L;   // (32-bit keys)
     const size_t p = mccnn_compute_pdf_workspace_bytes(e_cap, 1);
     if (p > w) w = p;
     L.ws = o;
@@ -312,29 +329,34 @@ int mccnn_geometry_build(mccnn_geometry_t* g, const float* pts, const int* batch
     *total_host = -1;  // armed: the prefix sum of the count pass overwrites it
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    // visiting order of the centres (speed only): the grid's own order when the centres are the gridded points; for the
+    // points of another level (pooling / up-sampling: Poisson samples arrive phase by phase, all over the scene) a
+    // cell-coherent order of their own in THIS grid -- small lists are searched in ~10 us either way
+    const bool own_order = !g->same_level && m >= MCCNN_ORDER_MIN_M;
+    Arena ha(g->ws, g->ws_bytes);
+    char* gws = nullptr;
+    char* ows = nullptr;
+    const size_t gwb = with_grid ? al(mccnn_build_grid_workspace_bytes(n, batch_size, num_cells)) : 0;
+    const size_t owb = own_order ? al(visiting_order_workspace_bytes(m, batch_size, num_cells)) : 0;
+    if (with_grid && !(gws = ha.take<char>(gwb))) return MCCNN_E_WORKSPACE;
+    if (own_order && !(ows = ha.take<char>(owb))) return MCCNN_E_WORKSPACE;
+    // ONE clear at the head of the chain (histogram counters + scan status words of both counting sorts); everything
+    // later in the chain is cleared by a kernel of the chain
+    rc = launch_clear_spans(with_grid ? grid_head_span(n, batch_size, num_cells, gws, gwb) : no_span(),
+                            own_order ? visiting_order_head_span(m, batch_size, num_cells, ows, owb) : no_span(), no_span(), s);
+    if (rc) return rc;
     if (with_grid) {
-        rc = mccnn_build_grid(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, g->new_idx, g->s_pts, g->s_bids,
-                              g->cells, g->inv_idx, g->ws, g->ws_bytes, stream);
+        rc = build_grid_fused(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, g->new_idx, g->s_pts, g->s_bids, g->cells,
+                              g->inv_idx, gws, gwb, s, nullptr, true, no_span(), no_span());
         if (rc) return rc;
     }
     const mccnn_geometry* go = grid_owner(g);
-    // visiting order of the centres (speed only): the grid's own order when the centres are the gridded points; for the
-    // points of another level (pooling / up-sampling: Poisson samples arrive phase by phase, all over the scene) their
-    // destinations in THIS grid, a counting sort of the library's own -- small lists are searched in ~10 us either way
     const int* order = nullptr;
     if (g->same_level) {
         order = go->inv_idx;
-    } else if (m >= 16384) {
-        const size_t m1 = (size_t)m;
-        Arena a(g->ws, g->ws_bytes);
-        int* keys = a.take<int>(m1);
-        int* dest = a.take<int>(m1);
-        if (!keys || !dest) return MCCNN_E_WORKSPACE;
-        rc = mccnn_sort_step1(centres, centre_batch_ids, aabb_min, aabb_max, m, batch_size, num_cells, keys, dest, a.base + a.off,
-                              a.cap - a.off, stream);
-        if (rc) return rc;
+    } else if (own_order) {
         g->order = (int*)(b + L.order);
-        rc = mccnn_invert_permutation(dest, m, g->order, stream);
+        rc = visiting_order(centres, centre_batch_ids, aabb_min, aabb_max, m, batch_size, num_cells, g->order, ows, owb, s, true);
         if (rc) return rc;
         order = g->order;
     }
@@ -351,7 +373,8 @@ int mccnn_geometry_build(mccnn_geometry_t* g, const float* pts, const int* batch
                                   batch_size, window, radius, g->scale_inv, g->pdfs, g->ws, g->ws_bytes, stream);
         if (rc) return rc;
     } else {  // MCConvBuilder.py:388-390: a tensor of ones
-        MCCNN_MEMSET(hipMemsetD32Async((hipDeviceptr_t)g->pdfs, 0x3f800000, (size_t)e_capacity, s));
+        rc = launch_fill_words(g->pdfs, (size_t)e_capacity, 0x3f800000u, s);
+        if (rc) return rc;
     }
     g->built = true;
     return 0;

@@ -135,7 +135,10 @@ __global__ __launch_bounds__(256) void check_bids(const int* __restrict__ bids, 
 __global__ __launch_bounds__(256) void keys_hist(const float* __restrict__ pts, const int* __restrict__ bids,
                                                  const float* __restrict__ mn, const float* __restrict__ mx,
                                                  int n, int B, int nc, int* __restrict__ keys, int* __restrict__ cnt,
-                                                 int* __restrict__ arrival, const int* __restrict__ nDev) {
+                                                 int* __restrict__ arrival, const int* __restrict__ nDev,
+                                                 ClearSpan x1, ClearSpan x2) {
+    clear_span_dev(x1);  // what LATER kernels of the chain want zeroed (common.h)
+    clear_span_dev(x2);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (nDev) n = *nDev;  // device-side point count (hierarchy levels chained without a host read-back)
     if (i >= n) return;
@@ -157,7 +160,9 @@ __global__ __launch_bounds__(256) void keys_hist_lds(const float* __restrict__ p
                                                      const float* __restrict__ mn, const float* __restrict__ mx,
                                                      int n, int B, int nc, int C, int* __restrict__ keys,
                                                      int* __restrict__ cnt, int* __restrict__ arrival,
-                                                     const int* __restrict__ nDev) {
+                                                     const int* __restrict__ nDev, ClearSpan x1, ClearSpan x2) {
+    clear_span_dev(x1);
+    clear_span_dev(x2);
     __shared__ int bins[MCCNN_HIST_LDS_BINS];
     for (int c = threadIdx.x; c < C; c += 256) bins[c] = 0;
     __syncthreads();
@@ -213,6 +218,47 @@ __global__ __launch_bounds__(256) void rank_in_cell(const int* __restrict__ keys
     }
     for (; q < s1; ++q) r += (slot[q] < id) ? 1 : 0;
     newIdx[id] = s0 + r;
+}
+
+// rank_in_cell, move_points and cell_table in ONE launch (the grid build of the native executor and of a hierarchy level,
+// where both sort steps belong to one call): the thread of parked position p ranks its point inside the cell and moves it
+// -- point, batch id, inverse permutation -- to the final position at once; the cell table needs neither the sorted keys
+// nor a cleared table: entry c is [start[c], start[c + 1]) of the prefix sum when the cell holds a point and (0, 0) -- what
+// the reference's memset leaves, sort_gpu.cu:492 -- when it does not (save_indexs, sort_gpu.cu:225-248, writes exactly
+// these bounds). Seven launches of round 5 (memset, keys_hist, scan, park_ids, rank_in_cell, move_points, cell_table) are
+// four: keys_hist, scan, park_ids, rank_move.
+__global__ __launch_bounds__(256) void rank_move(const int* __restrict__ keys, const int* __restrict__ start,
+                                                 const int* __restrict__ slot, int n, long long numCells,
+                                                 const float* __restrict__ pts, const int* __restrict__ bids,
+                                                 int* __restrict__ newIdx, float* __restrict__ oPts, int* __restrict__ oBids,
+                                                 int* __restrict__ inv, int2* __restrict__ cells,
+                                                 const int* __restrict__ nDev, ClearSpan x1, ClearSpan x2) {
+    clear_span_dev(x1);
+    clear_span_dev(x2);
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long c = t; c < numCells; c += (long long)gridDim.x * blockDim.x) {
+        const int s0 = start[c], s1 = start[c + 1];
+        cells[c] = s1 > s0 ? make_int2(s0, s1) : make_int2(0, 0);
+    }
+    if (nDev) n = *nDev;
+    if (t >= n) return;
+    const int id = slot[t];
+    const int k = keys[id];
+    const int s0 = start[k], s1 = start[k + 1];
+    int r = 0;
+    int q = s0;
+    for (; q + 4 <= s1; q += 4) {
+        int a0 = slot[q], a1 = slot[q + 1], a2 = slot[q + 2], a3 = slot[q + 3];
+        r += (a0 < id) + (a1 < id) + (a2 < id) + (a3 < id);
+    }
+    for (; q < s1; ++q) r += (slot[q] < id) ? 1 : 0;
+    const int f = s0 + r;
+    newIdx[id] = f;
+    oPts[(size_t)f * 3] = pts[(size_t)id * 3];
+    oPts[(size_t)f * 3 + 1] = pts[(size_t)id * 3 + 1];
+    oPts[(size_t)f * 3 + 2] = pts[(size_t)id * 3 + 2];
+    oBids[f] = bids[id];
+    if (inv) inv[f] = id;
 }
 
 // ------------------------------------------------------------------ step 2
@@ -305,6 +351,67 @@ __global__ __launch_bounds__(1024) void grid_small_step1(const float* __restrict
         int r = 0;
         for (int q = s0; q < s1; ++q) r += (slot[q] < id) ? 1 : 0;
         newIdx[id] = s0 + r;
+    }
+}
+
+// Both sort steps of a small level in ONE workgroup (geometry only: the grid build of the native executor and of a
+// hierarchy level): the phases of grid_small_step1, then -- still in the same launch -- the cell table straight from the
+// prefix sum and every point moved by the thread that ranked it (see rank_move).
+__global__ __launch_bounds__(1024) void grid_small_all(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                       const float* __restrict__ mn, const float* __restrict__ mx, int n,
+                                                       int B, int nc, int C, int* __restrict__ keys, int* __restrict__ newIdx,
+                                                       int* __restrict__ cnt, int* __restrict__ start, int* __restrict__ slot,
+                                                       float* __restrict__ oPts, int* __restrict__ oBids, int* __restrict__ inv,
+                                                       int2* __restrict__ cells, const int* __restrict__ nDev, ClearSpan x1,
+                                                       ClearSpan x2) {
+    __shared__ int wsum[17];
+    clear_span_dev(x1);
+    clear_span_dev(x2);
+    const int t = threadIdx.x;
+    if (nDev) n = *nDev;
+    for (int c = t; c < C; c += 1024) cnt[c] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {  // keys_hist
+        const int b = clamp_batch(bids[i], B);
+        const float cs = max_extent(mn, mx, b) / (float)nc;
+        const int x = cell_coord(pts[(size_t)i * 3], mn[b * 3], cs, nc);
+        const int y = cell_coord(pts[(size_t)i * 3 + 1], mn[b * 3 + 1], cs, nc);
+        const int z = cell_coord(pts[(size_t)i * 3 + 2], mn[b * 3 + 2], cs, nc);
+        const int key = b * nc * nc * nc + x * nc * nc + y * nc + z;
+        keys[i] = key;
+        newIdx[i] = atomicAdd(&cnt[key], 1);  // arrival rank, replaced by the final position below
+    }
+    __syncthreads();
+    {   // start = exclusive scan of the cell counts; the cell table on the way (non-empty: [start, start + count))
+        const int per = (C + 1023) / 1024, c0 = min(C, t * per), c1 = min(C, c0 + per);
+        int sum = 0;
+        for (int c = c0; c < c1; ++c) sum += cnt[c];
+        int tot;
+        int run = block1024_excl_scan(sum, tot, wsum);
+        for (int c = c0; c < c1; ++c) {
+            const int v = cnt[c];
+            start[c] = run;
+            cells[c] = v > 0 ? make_int2(run, run + v) : make_int2(0, 0);
+            run += v;
+        }
+        if (t == 0) start[C] = tot;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) slot[start[keys[i]] + newIdx[i]] = i;  // park_ids
+    __syncthreads();
+    for (int p = t; p < n; p += 1024) {  // rank_in_cell + move_points
+        const int id = slot[p];
+        const int k = keys[id];
+        const int s0 = start[k], s1 = start[k + 1];
+        int r = 0;
+        for (int q = s0; q < s1; ++q) r += (slot[q] < id) ? 1 : 0;
+        const int f = s0 + r;
+        newIdx[id] = f;
+        oPts[(size_t)f * 3] = pts[(size_t)id * 3];
+        oPts[(size_t)f * 3 + 1] = pts[(size_t)id * 3 + 1];
+        oPts[(size_t)f * 3 + 2] = pts[(size_t)id * 3 + 2];
+        oBids[f] = bids[id];
+        if (inv) inv[f] = id;
     }
 }
 
@@ -402,7 +509,10 @@ extern "C" {
 int mccnn_check_batch_ids(const int* batch_ids, int n, int batch_size, int* bad_count_dev, mccnn_stream_t stream) {
     if (n < 0 || batch_size <= 0 || !bad_count_dev || (n > 0 && !batch_ids)) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    MCCNN_MEMSET(hipMemsetAsync(bad_count_dev, 0, sizeof(int), s));
+    {
+        int rc = launch_zero_words(bad_count_dev, 1, s);
+        if (rc) return rc;
+    }
     if (n == 0) return 0;
     check_bids<<<ceil_div(n, 256), 256, 0, s>>>(batch_ids, n, batch_size, bad_count_dev);
     MCCNN_LAUNCHED();
@@ -495,12 +605,15 @@ static int sort_step1_impl(const float* pts, const int* batch_ids, const float* 
         MCCNN_LAUNCHED();
         return 0;
     }
-    MCCNN_MEMSET(hipMemsetAsync(blk, 0, cntBytes + scan_status_bytes((int)C), s));
+    {   // the head of this chain: histogram counters and the scan's status words (neighbours: one span)
+        int rc = launch_clear_spans(clear_span(blk, cntBytes + scan_status_bytes((int)C)), no_span(), no_span(), s);
+        if (rc) return rc;
+    }
     int blocks = ceil_div(n, 256);
     if (C <= MCCNN_HIST_LDS_BINS && n >= 4 * C)  // few cells, many points per cell
-        keys_hist_lds<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, (int)C, keys, cnt, new_idx, n_dev);
+        keys_hist_lds<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, (int)C, keys, cnt, new_idx, n_dev, no_span(), no_span());
     else
-        keys_hist<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, keys, cnt, new_idx, n_dev);
+        keys_hist<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, keys, cnt, new_idx, n_dev, no_span(), no_span());
     MCCNN_LAUNCHED();
     int rc = exclusive_scan_i32(cnt, start, (int)C, start + C, scanws, s, true);
     if (rc) return rc;
@@ -538,8 +651,7 @@ static int sort_step2_impl(const float* pts, const int* batch_ids, const float* 
     if (C >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
-        MCCNN_MEMSET(hipMemsetAsync(cell_indexs, 0, (size_t)C * 2 * sizeof(int), s));  // sort_gpu.cu:492
-        return 0;
+        return launch_zero_words(cell_indexs, (size_t)C * 2, s);  // sort_gpu.cu:492
     }
     if (!pts || !batch_ids || !keys || !new_idx || !out_pts || !out_batch_ids || (num_feats > 0 && (!feats || !out_feats)))
         return MCCNN_E_BADARG;
@@ -614,23 +726,135 @@ size_t mccnn_build_grid_workspace_bytes(int n, int batch_size, int num_cells) {
     return align_up((size_t)(n > 0 ? n : 1) * 4) + (a > b ? a : b);
 }
 
-int mccnn_build_grid(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n,
+}  // extern "C"
+namespace mccnn {
+// Both sort steps of a grid build as ONE chain (geometry only), with the device-count form folded in: keys_hist -> prefix
+// sum -> park_ids -> rank_move (four launches; one workgroup and one launch for small levels). `ws` as
+// mccnn_build_grid_workspace_bytes sizes it. What has to be zero before the first kernel -- the histogram counters and the
+// status words of the single-pass scan -- is the span grid_head_span() names: the caller either had an earlier kernel of
+// ITS chain clear it (cleared = true) or this function launches the clear itself. x1 / x2: spans LATER stages of the
+// caller's chain want cleared (a hierarchy level's sampling state ...): the first kernel here clears them on its way.
+ClearSpan grid_head_span(int n, int batch_size, int num_cells, void* ws, size_t ws_bytes) {
+    const long long C = total_cells(batch_size, num_cells);
+    if (C <= 0 || C >= 0x7fffffffLL || !ws) return no_span();
+    if (n <= MCCNN_GRID_SMALL_N && C <= MCCNN_GRID_SMALL_C && small_kernels_on()) return no_span();  // clears its counters itself
+    Arena a(ws, ws_bytes);
+    if (!a.take<int>((size_t)(n > 0 ? n : 1))) return no_span();
+    const size_t cntBytes = align_up((size_t)C * 4);
+    char* blk = a.take<char>(cntBytes + scan_workspace_bytes((int)C));
+    if (!blk) return no_span();
+    return clear_span(blk, cntBytes + scan_status_bytes((int)C));
+}
+
+int build_grid_fused(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n,
                      int batch_size, int num_cells, int* new_idx, float* out_pts, int* out_batch_ids, int* cell_indexs,
-                     int* inv_idx, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
-    if (n < 0 || batch_size <= 0 || num_cells <= 0) return MCCNN_E_BADARG;
+                     int* inv_idx, void* ws, size_t ws_bytes, hipStream_t s, const int* n_dev, bool cleared, ClearSpan x1,
+                     ClearSpan x2) {
+    if (n < 0 || batch_size <= 0 || num_cells <= 0 || !aabb_min || !aabb_max || !cell_indexs) return MCCNN_E_BADARG;
+    const long long C = total_cells(batch_size, num_cells);
+    if (C >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
     const size_t need = mccnn_build_grid_workspace_bytes(n, batch_size, num_cells);
     if (need == 0) return MCCNN_E_TOOLARGE;
     if (!ws || ws_bytes < need) return MCCNN_E_WORKSPACE;
+    if (n == 0) {
+        int rc = launch_clear_spans(x1, x2, no_span(), s);
+        if (rc) return rc;
+        return launch_zero_words(cell_indexs, (size_t)C * 2, s);  // sort_gpu.cu:492
+    }
+    if (!pts || !batch_ids || !new_idx || !out_pts || !out_batch_ids) return MCCNN_E_BADARG;
     Arena a(ws, ws_bytes);
-    int* keys = a.take<int>((size_t)(n > 0 ? n : 1));
-    void* rest = a.base + a.off;
-    const size_t restBytes = ws_bytes - a.off;
-    int rc = sort_step1_impl(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, keys, new_idx, rest, restBytes,
-                             stream, nullptr);
+    int* keys = a.take<int>((size_t)n);
+    const size_t cntBytes = align_up((size_t)C * 4), scanBytes = scan_workspace_bytes((int)C);
+    char* blk = a.take<char>(cntBytes + scanBytes);
+    int* start = a.take<int>((size_t)C + 1);
+    int* slot = a.take<int>((size_t)n);
+    if (!keys || !blk || !start || !slot) return MCCNN_E_WORKSPACE;
+    int* cnt = (int*)blk;
+    void* scanws = blk + cntBytes;
+    int2* ct = reinterpret_cast<int2*>(cell_indexs);
+    if (n <= MCCNN_GRID_SMALL_N && C <= MCCNN_GRID_SMALL_C && small_kernels_on()) {
+        grid_small_all<<<1, 1024, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, (int)C, keys, new_idx, cnt,
+                                          start, slot, out_pts, out_batch_ids, inv_idx, ct, n_dev, x1, x2);
+        MCCNN_LAUNCHED();
+        return 0;
+    }
+    if (!cleared) {
+        int rc = launch_clear_spans(clear_span(blk, cntBytes + scan_status_bytes((int)C)), no_span(), no_span(), s);
+        if (rc) return rc;
+    }
+    const int blocks = ceil_div(n, 256);
+    if (C <= MCCNN_HIST_LDS_BINS && n >= 4 * C)  // few cells, many points per cell
+        keys_hist_lds<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, (int)C, keys, cnt, new_idx, n_dev, x1, x2);
+    else
+        keys_hist<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, keys, cnt, new_idx, n_dev, x1, x2);
+    MCCNN_LAUNCHED();
+    int rc = exclusive_scan_i32(cnt, start, (int)C, start + C, scanws, s, true);
     if (rc) return rc;
-    // geometry only (no feature rows): the device-count form of step 2 accepts that; its count is the host's here
-    return sort_step2_impl(pts, batch_ids, nullptr, keys, new_idx, n, 0, batch_size, num_cells, out_pts, out_batch_ids,
-                           nullptr, cell_indexs, inv_idx, rest, restBytes, stream, nullptr, true);
+    park_ids<<<blocks, 256, 0, s>>>(keys, start, new_idx, n, slot, n_dev);
+    MCCNN_LAUNCHED();
+    rank_move<<<blocks, 256, 0, s>>>(keys, start, slot, n, C, pts, batch_ids, new_idx, out_pts, out_batch_ids, inv_idx, ct, n_dev,
+                                     no_span(), no_span());
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+// A cell-coherent VISITING ORDER of points that are not the gridded ones (the centres of another level: Poisson samples
+// arrive phase by phase, all over the scene): position -> point id, points of one cell consecutive. Speed only -- no result
+// depends on the order inside a cell, so the arrival order of the histogram's atomics is kept (keys_hist, prefix sum,
+// park_ids: three launches; the stable sort of mccnn_sort_step1 + an inversion were six). ws as
+// mccnn_sort_step1_workspace_bytes(m) + m ints of keys + m ints of arrival ranks; `order` [m].
+size_t visiting_order_workspace_bytes(int m, int batch_size, int num_cells) {
+    const size_t c = mccnn_sort_step1_workspace_bytes(m, batch_size, num_cells);
+    return c == 0 ? 0 : c + 2 * align_up((size_t)(m > 0 ? m : 1) * 4);
+}
+ClearSpan visiting_order_head_span(int m, int batch_size, int num_cells, void* ws, size_t ws_bytes) {
+    const long long C = total_cells(batch_size, num_cells);
+    if (C <= 0 || C >= 0x7fffffffLL || !ws) return no_span();
+    Arena a(ws, ws_bytes);
+    if (!a.take<int>((size_t)(m > 0 ? m : 1)) || !a.take<int>((size_t)(m > 0 ? m : 1))) return no_span();
+    const size_t cntBytes = align_up((size_t)C * 4);
+    char* blk = a.take<char>(cntBytes + scan_workspace_bytes((int)C));
+    if (!blk) return no_span();
+    return clear_span(blk, cntBytes + scan_status_bytes((int)C));
+}
+int visiting_order(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int m, int batch_size,
+                   int num_cells, int* order, void* ws, size_t ws_bytes, hipStream_t s, bool cleared) {
+    if (m <= 0 || !order) return MCCNN_E_BADARG;
+    const long long C = total_cells(batch_size, num_cells);
+    if (C >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
+    if (!ws || ws_bytes < visiting_order_workspace_bytes(m, batch_size, num_cells)) return MCCNN_E_WORKSPACE;
+    Arena a(ws, ws_bytes);
+    int* keys = a.take<int>((size_t)m);
+    int* arrival = a.take<int>((size_t)m);
+    const size_t cntBytes = align_up((size_t)C * 4), scanBytes = scan_workspace_bytes((int)C);
+    char* blk = a.take<char>(cntBytes + scanBytes);
+    int* start = a.take<int>((size_t)C + 1);
+    if (!keys || !arrival || !blk || !start) return MCCNN_E_WORKSPACE;
+    int* cnt = (int*)blk;
+    if (!cleared) {
+        int rc = launch_clear_spans(clear_span(blk, cntBytes + scan_status_bytes((int)C)), no_span(), no_span(), s);
+        if (rc) return rc;
+    }
+    const int blocks = ceil_div(m, 256);
+    if (C <= MCCNN_HIST_LDS_BINS && m >= 4 * C)
+        keys_hist_lds<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, m, batch_size, num_cells, (int)C, keys, cnt, arrival, nullptr, no_span(), no_span());
+    else
+        keys_hist<<<blocks, 256, 0, s>>>(pts, batch_ids, aabb_min, aabb_max, m, batch_size, num_cells, keys, cnt, arrival, nullptr, no_span(), no_span());
+    MCCNN_LAUNCHED();
+    int rc = exclusive_scan_i32(cnt, start, (int)C, start + C, blk + cntBytes, s, true);
+    if (rc) return rc;
+    park_ids<<<blocks, 256, 0, s>>>(keys, start, arrival, m, order, nullptr);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+}  // namespace mccnn
+extern "C" {
+
+int mccnn_build_grid(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n,
+                     int batch_size, int num_cells, int* new_idx, float* out_pts, int* out_batch_ids, int* cell_indexs,
+                     int* inv_idx, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    return build_grid_fused(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, new_idx, out_pts, out_batch_ids,
+                            cell_indexs, inv_idx, ws, ws_bytes, (hipStream_t)stream, nullptr, false, no_span(), no_span());
 }
 
 int mccnn_permute_gather(const float* in, const int* idx, int n_idx, int num_feats, float* out,
@@ -647,7 +871,10 @@ int mccnn_permute_scatter(const float* in, const int* idx, int n_idx, int num_fe
     hipStream_t s = (hipStream_t)stream;
     if (zero_fill && n_out > 0) {
         if (!out) return MCCNN_E_BADARG;
-        MCCNN_MEMSET(hipMemsetAsync(out, 0, (size_t)n_out * num_feats * sizeof(float), s));
+        // (scatter into zeros -- GetSampledFeaturesGrad, poisson_sampling.cu:158-172 after its cudaMemset: the zero fill is
+        // part of the op; rows no index points at stay zero)
+        int rc = launch_zero_words(out, (size_t)n_out * num_feats, s);
+        if (rc) return rc;
     }
     if (n_idx == 0) return 0;
     if (!in || !idx || !out) return MCCNN_E_BADARG;

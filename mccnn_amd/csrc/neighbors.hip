@@ -845,9 +845,9 @@ static int find_neighbors_count_impl(const float* centres, const int* centre_bat
     if (m < 0 || n < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (m == 0) {
-        MCCNN_MEMSET(hipMemsetAsync(total_dev, 0, sizeof(int), s));
-        if (total_host) MCCNN_MEMSET(hipMemsetAsync(total_host, 0, sizeof(int), s));
-        return 0;
+        int rc = launch_zero_words(total_dev, 1, s);
+        if (!rc && total_host) rc = launch_zero_words(total_host, 1, s);   // (a pinned word the device can write)
+        return rc;
     }
     if (!centres || !centre_batch_ids || !cell_indexs || !aabb_min || !aabb_max || !start_idx || (n > 0 && !sorted_pts))
         return MCCNN_E_BADARG;

@@ -422,9 +422,12 @@ __global__ __launch_bounds__(256) void poisson_emit(const float* __restrict__ pt
     }
 }
 
-int sort_step2_dn_inv(const float* pts, const int* batch_ids, const int* keys, const int* new_idx, int n_cap,
-                      const int* n_dev, int batch_size, int num_cells, float* out_pts, int* out_batch_ids,
-                      int* cell_indexs, int* inv_idx, void* ws, size_t ws_bytes, mccnn_stream_t stream);  // grid.hip
+// grid.hip: both sort steps as one chain of four launches (device-count form included)
+ClearSpan grid_head_span(int n, int batch_size, int num_cells, void* ws, size_t ws_bytes);
+int build_grid_fused(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int n,
+                     int batch_size, int num_cells, int* new_idx, float* out_pts, int* out_batch_ids, int* cell_indexs,
+                     int* inv_idx, void* ws, size_t ws_bytes, hipStream_t s, const int* n_dev, bool cleared, ClearSpan x1,
+                     ClearSpan x2);
 
 static long long poisson_slots(int B, int nc) {
     PoissonDims d = poisson_dims(nc);
@@ -452,7 +455,24 @@ size_t mccnn_poisson_sampling_workspace_bytes(int n, int batch_size, int num_cel
 static int poisson_count_impl(const float* sorted_pts, const int* sorted_batch_ids, int n, const int* cell_indexs,
                               const float* aabb_min, const float* aabb_max, int batch_size, int num_cells, float radius,
                               int scale_inv, int mode, int* total_dev, void* ws, size_t ws_bytes, mccnn_stream_t stream,
-                              const int** fail_out);
+                              const int** fail_out, bool cleared = false);
+
+// what the sampling wants zeroed before its first kernel: selection bytes, slot counters + scan status words and (dataflow
+// forms) the per-cell flags, failure flag and phase counters -- neighbours in the arena, ONE span (the bytes in between are
+// scratch). A caller whose chain runs a kernel before the sampling has THAT kernel clear it (mccnn_hierarchy_level).
+static ClearSpan poisson_clear_span(int n, int batch_size, int num_cells, int mode, void* ws, size_t ws_bytes) {
+    const long long S = poisson_slots(batch_size, num_cells);
+    if (n <= 0 || S >= 0x7fffffffLL || !ws || ws_bytes < mccnn_poisson_sampling_workspace_bytes(n, batch_size, num_cells)) return no_span();
+    Arena a(ws, ws_bytes);
+    unsigned char* sel = a.take<unsigned char>((size_t)n);
+    const size_t slotBytes = align_up((size_t)S * 4);
+    char* blk = a.take<char>(slotBytes + scan_workspace_bytes((int)S));
+    const size_t C = (size_t)batch_size * num_cells * num_cells * num_cells;
+    int* flags = a.take<int>(C + 1 + 32);
+    if (!sel || !blk || !flags) return no_span();
+    if (mode == 1 || mode == 2) return clear_span(sel, (size_t)((char*)(flags + C + 1 + 32) - (char*)sel));
+    return clear_span(sel, (size_t)((blk + slotBytes + scan_status_bytes((int)S)) - (char*)sel));
+}
 
 int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batch_ids, int n, const int* cell_indexs,
                                  const float* aabb_min, const float* aabb_max, int batch_size, int num_cells,
@@ -467,15 +487,12 @@ int mccnn_poisson_sampling_count(const float* sorted_pts, const int* sorted_batc
 static int poisson_count_impl(const float* sorted_pts, const int* sorted_batch_ids, int n, const int* cell_indexs,
                               const float* aabb_min, const float* aabb_max, int batch_size, int num_cells, float radius,
                               int scale_inv, int mode, int* total_dev, void* ws, size_t ws_bytes, mccnn_stream_t stream,
-                              const int** fail_out) {
+                              const int** fail_out, bool cleared) {
     (void)sorted_batch_ids;
     if (fail_out) *fail_out = nullptr;
     if (n < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    if (n == 0) {
-        MCCNN_MEMSET(hipMemsetAsync(total_dev, 0, sizeof(int), s));
-        return 0;
-    }
+    if (n == 0) return launch_zero_words(total_dev, 1, s);
     if (!sorted_pts || !cell_indexs || !aabb_min || !aabb_max) return MCCNN_E_BADARG;
     long long S = poisson_slots(batch_size, num_cells);
     if (S >= 0x7fffffffLL) return MCCNN_E_TOOLARGE;
@@ -493,12 +510,9 @@ static int poisson_count_impl(const float* sorted_pts, const int* sorted_batch_i
     if (!sel || !blk || !flags || !plist) return MCCNN_E_WORKSPACE;
     int* slots = (int*)blk;
     void* scanws = blk + slotBytes;
-    // selection bytes, slot counters + scan status words and (dataflow forms) the per-cell flags are neighbours in the
-    // arena: ONE memset clears them all (three launches before; the bytes in between are scratch)
-    if (mode == 1 || mode == 2) {
-        MCCNN_MEMSET(hipMemsetAsync(sel, 0, (size_t)((char*)(flags + C + 1 + 32) - (char*)sel), s));
-    } else {
-        MCCNN_MEMSET(hipMemsetAsync(sel, 0, (size_t)((blk + slotBytes + scan_status_bytes((int)S)) - (char*)sel), s));
+    if (!cleared) {  // the head of a bare sampling call (op surface); a hierarchy level's first kernel clears it on its way
+        int rc = launch_clear_spans(poisson_clear_span(n, batch_size, num_cells, mode, ws, ws_bytes), no_span(), no_span(), s);
+        if (rc) return rc;
     }
     long long threads = perPhase;
     if (mode == 1 || mode == 2) {
@@ -595,18 +609,25 @@ int mccnn_hierarchy_level(const float* pts, const int* batch_ids, const float* a
     char* wp = a.take<char>(bp);
     char* wt = a.take<char>(bt);
     if (!keys || !w1 || !w2 || !wp || !wt) return MCCNN_E_WORKSPACE;
-    int rc = mccnn_sort_step1_dn(pts, batch_ids, aabb_min, aabb_max, n_cap, n_dev, batch_size, num_cells, keys, new_idx, w1, b1, stream);
-    if (rc) return rc;
-    // three launches less per level than the op chain: the second sort step leaves the inverse permutation (in the
-    // transform's own scratch), and the emit kernel of the sampling writes the transformed indices (transform_indexs:
-    // inv[sampled index]) and turns a timed-out wait into *s_dev = -1 -- no invert / map / flag kernels of their own
+    // One chain per level: [head clear] keys_hist -> prefix sum -> park_ids -> rank_move -> poisson_compact -> sampling ->
+    // prefix sum -> emit = 8 launches + the head (round 5: 13 with three memsets). The grid build's first kernel clears what
+    // the sampling wants zeroed; the last one leaves the inverse permutation (in the transform's own scratch), and the emit
+    // kernel writes the transformed indices (transform_indexs: inv[sampled index]) and turns a timed-out wait into
+    // *s_dev = -1 -- no invert / map / flag kernels of their own.
+    (void)keys; (void)w2;
+    hipStream_t s = (hipStream_t)stream;
+    char* gw = reinterpret_cast<char*>(keys);   // keys | step-1 scratch (| step-2 scratch, unused): the layout build_grid_fused expects
+    const size_t gwb = (size_t)(wp - gw);
     int* inv = reinterpret_cast<int*>(wt);
-    rc = sort_step2_dn_inv(pts, batch_ids, keys, new_idx, n_cap, n_dev, batch_size, num_cells, sorted_pts, sorted_batch_ids,
-                           cell_indexs, inv, w2, b2, stream);
+    const ClearSpan ps = poisson_clear_span(n_cap, batch_size, num_cells, mode, wp, bp);
+    int rc = launch_clear_spans(grid_head_span(n_cap, batch_size, num_cells, gw, gwb), no_span(), no_span(), s);
+    if (rc) return rc;
+    rc = build_grid_fused(pts, batch_ids, aabb_min, aabb_max, n_cap, batch_size, num_cells, new_idx, sorted_pts, sorted_batch_ids,
+                          cell_indexs, inv, gw, gwb, s, n_dev, true, ps, no_span());
     if (rc) return rc;
     const int* fail = nullptr;
     rc = poisson_count_impl(sorted_pts, sorted_batch_ids, n_cap, cell_indexs, aabb_min, aabb_max, batch_size, num_cells, radius,
-                            scale_inv, mode, s_dev, wp, bp, stream, &fail);
+                            scale_inv, mode, s_dev, wp, bp, stream, &fail, ps.n16 != 0);
     if (rc) return rc;
     return poisson_fill_impl(sorted_pts, n_cap, cell_indexs, batch_size, num_cells, n_cap, out_pts, out_batch_ids, out_indexs,
                              wp, bp, stream, inv, transformed_indexs, fail, s_dev);

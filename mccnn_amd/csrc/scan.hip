@@ -173,9 +173,9 @@ size_t scan_workspace_bytes(int n) {
 
 int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t s, bool status_zeroed, int* total2) {
     if (n <= 0) {
-        if (total) MCCNN_MEMSET(hipMemsetAsync(total, 0, sizeof(int), s));
-        if (total2) MCCNN_MEMSET(hipMemsetAsync(total2, 0, sizeof(int), s));
-        return 0;
+        int rc = total ? launch_zero_words(total, 1, s) : 0;
+        if (!rc && total2) rc = launch_zero_words(total2, 1, s);
+        return rc;
     }
     int tiles = ceil_div(n, SCAN_TILE);
     if (tiles == 1) {
@@ -190,7 +190,10 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
     static const int bgTiles = debug_int("scan_bg_tiles", 8);
     if (g_background && bgTiles > 0 && tiles >= bgTiles) sb = 0;
     if (sb) {  // single pass; the status words sit at the start of the workspace
-        if (!status_zeroed) MCCNN_MEMSET(hipMemsetAsync(ws, 0, sb, s));
+        if (!status_zeroed) {  // (every caller inside the library has an earlier kernel of its chain clear the words)
+            int rc = launch_clear_spans(clear_span(ws, sb), no_span(), no_span(), s);
+            if (rc) return rc;
+        }
         scan_chained<<<tiles, SCAN_THREADS, 0, s>>>(in, out, n, (unsigned long long*)ws, total, total2);
         MCCNN_LAUNCHED();
         return 0;
