@@ -31,6 +31,11 @@ size_t visiting_order_workspace_bytes(int m, int batch_size, int num_cells);
 ClearSpan visiting_order_head_span(int m, int batch_size, int num_cells, void* ws, size_t ws_bytes);
 int visiting_order(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int m, int batch_size,
                    int num_cells, int* order, void* ws, size_t ws_bytes, hipStream_t s, bool cleared);
+// neighbors.hip: count + (scan) + fill; lists of few centres scan their counts inside the fill pass
+int find_neighbors_chain(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts, int n,
+                         const int* cell_indexs, const float* aabb_min, const float* aabb_max, int batch_size, int num_cells,
+                         float radius, int scale_inv, const int* centre_order, int* start_idx, int e_capacity, int* packed,
+                         int* total_dev, int* total_host, void* ws, size_t ws_bytes, mccnn_stream_t stream);
 }
 
 using namespace mccnn;
@@ -360,13 +365,9 @@ int mccnn_geometry_build(mccnn_geometry_t* g, const float* pts, const int* batch
         if (rc) return rc;
         order = g->order;
     }
-    rc = mccnn_find_neighbors_count2(centres, centre_batch_ids, m, go->s_pts, n, go->cells, aabb_min, aabb_max, batch_size,
-                                     num_cells, radius, g->scale_inv, order, g->start, g->total_dev, total_host, g->ws,
-                                     g->ws_bytes, stream);
-    if (rc) return rc;
-    rc = mccnn_find_neighbors_fill(centres, centre_batch_ids, m, go->s_pts, n, go->cells, aabb_min, aabb_max, batch_size,
-                                   num_cells, radius, g->scale_inv, order, g->start, e_capacity, g->packed, g->ws, g->ws_bytes,
-                                   stream);
+    rc = find_neighbors_chain(centres, centre_batch_ids, m, go->s_pts, n, go->cells, aabb_min, aabb_max, batch_size, num_cells,
+                              radius, g->scale_inv, order, g->start, e_capacity, g->packed, g->total_dev, total_host, g->ws,
+                              g->ws_bytes, stream);
     if (rc) return rc;
     if (use_pdf) {
         rc = mccnn_compute_pdf_dn(go->s_pts, go->s_bids, g->start, m, g->packed, e_capacity, g->total_dev, aabb_min, aabb_max,

@@ -115,6 +115,91 @@ __global__ __launch_bounds__(256) void aabb_finalize(const unsigned* __restrict_
     }
 }
 
+// The whole op in ONE launch for up to MCCNN_AABB_ONE_N points (a network step computes one box per batch: init, reduce and
+// finalize as three launches were 12-15 us of a chain that is a few microseconds of work): one workgroup of 1024 threads,
+// running minima / maxima per cloud in LDS (order-preserving integers, wave pre-reduction as in aabb_reduce), then the
+// finalize step. Same values (min / max are exact and order-free). Larger batches keep the three launches: one workgroup
+// walks its points at one memory latency per trip.
+#define MCCNN_AABB_ONE_N 32768
+#define MCCNN_AABB_ONE_B 1024
+__global__ __launch_bounds__(1024) void aabb_one(const float* __restrict__ pts, const int* __restrict__ bids, int n, int B,
+                                                 int scaleInv, float* __restrict__ mn, float* __restrict__ mx) {
+    __shared__ unsigned enc[6 * MCCNN_AABB_ONE_B];
+    __shared__ unsigned g[6];
+    const int t = threadIdx.x;
+    for (int k = t; k < 3 * B; k += 1024) {
+        enc[k] = f2ord(FLT_MAX);
+        enc[3 * B + k] = f2ord(-FLT_MAX);
+    }
+    if (t < 3) g[t] = 0xffffffffu;
+    if (t >= 3 && t < 6) g[t] = 0u;
+    __syncthreads();
+    for (int i00 = 0; i00 < n; i00 += 4096) {
+      // four trips' loads in flight at once
+      int bb[4];
+      float xx[4], yy[4], zz[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+          const int i = i00 + u * 1024 + t;
+          const bool a = i < n;
+          bb[u] = a ? bids[i] : -1;
+          xx[u] = a ? pts[(size_t)i * 3] : 0.f;
+          yy[u] = a ? pts[(size_t)i * 3 + 1] : 0.f;
+          zz[u] = a ? pts[(size_t)i * 3 + 2] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i00 + u * 1024 + t;
+        const bool act = i < n;
+        const int b = bb[u];
+        const float x = xx[u], y = yy[u], z = zz[u];
+        if (i00 + u * 1024 >= n) break;
+        const int b0 = __shfl(b, 0, 64);
+        const bool uniform = __all(b == b0 || !act) && (__shfl(act ? 1 : 0, 0, 64) != 0) && b0 >= 0 && b0 < B;
+        if (uniform) {   // clouds are stored contiguously: one LDS atomic per wave and coordinate
+            float mnx = act ? x : FLT_MAX, mny = act ? y : FLT_MAX, mnz = act ? z : FLT_MAX;
+            float mxx = act ? x : -FLT_MAX, mxy = act ? y : -FLT_MAX, mxz = act ? z : -FLT_MAX;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                mnx = fminf(mnx, __shfl_xor(mnx, d, 64));
+                mny = fminf(mny, __shfl_xor(mny, d, 64));
+                mnz = fminf(mnz, __shfl_xor(mnz, d, 64));
+                mxx = fmaxf(mxx, __shfl_xor(mxx, d, 64));
+                mxy = fmaxf(mxy, __shfl_xor(mxy, d, 64));
+                mxz = fmaxf(mxz, __shfl_xor(mxz, d, 64));
+            }
+            if (lane_id() == 0) {
+                atomicMin(&enc[b0 * 3], f2ord(mnx)); atomicMin(&enc[b0 * 3 + 1], f2ord(mny)); atomicMin(&enc[b0 * 3 + 2], f2ord(mnz));
+                atomicMax(&enc[3 * B + b0 * 3], f2ord(mxx)); atomicMax(&enc[3 * B + b0 * 3 + 1], f2ord(mxy));
+                atomicMax(&enc[3 * B + b0 * 3 + 2], f2ord(mxz));
+            }
+        } else if (act && b >= 0 && b < B) {
+            atomicMin(&enc[b * 3], f2ord(x)); atomicMin(&enc[b * 3 + 1], f2ord(y)); atomicMin(&enc[b * 3 + 2], f2ord(z));
+            atomicMax(&enc[3 * B + b * 3], f2ord(x)); atomicMax(&enc[3 * B + b * 3 + 1], f2ord(y));
+            atomicMax(&enc[3 * B + b * 3 + 2], f2ord(z));
+        }
+      }
+    }
+    __syncthreads();
+    if (scaleInv) {
+        for (int k = t; k < 3 * B; k += 1024) {
+            mn[k] = ord2f(enc[k]);
+            mx[k] = ord2f(enc[3 * B + k]);
+        }
+        return;
+    }
+    // scale_inv == 0: every row gets the whole-batch box (aabb_gpu.cu:104-114)
+    for (int k = t; k < 3 * B; k += 1024) {
+        atomicMin(&g[k % 3], enc[k]);
+        atomicMax(&g[3 + k % 3], enc[3 * B + k]);
+    }
+    __syncthreads();
+    for (int k = t; k < 3 * B; k += 1024) {
+        mn[k] = ord2f(g[k % 3]);
+        mx[k] = ord2f(g[3 + k % 3]);
+    }
+}
+
 __global__ void num_cells_dev(const float* __restrict__ mn, const float* __restrict__ mx, float cellSize,
                               int* __restrict__ out) {
     // determine_cell_size, sort_gpu.cu:374-391 (batch 0 only)
@@ -528,6 +613,11 @@ int mccnn_compute_aabb(const float* pts, const int* batch_ids, int n, int batch_
     if (!aabb_min || !aabb_max || batch_size <= 0 || n < 0 || (n > 0 && (!pts || !batch_ids))) return MCCNN_E_BADARG;
     if (!ws || ws_bytes < mccnn_compute_aabb_workspace_bytes(batch_size)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    if (n <= MCCNN_AABB_ONE_N && batch_size <= MCCNN_AABB_ONE_B && small_kernels_on()) {
+        aabb_one<<<1, 1024, 0, s>>>(pts, batch_ids, n, batch_size, scale_inv, aabb_min, aabb_max);
+        MCCNN_LAUNCHED();
+        return 0;
+    }
     unsigned* enc = (unsigned*)ws;
     aabb_init<<<ceil_div(3 * batch_size, 256), 256, 0, s>>>(enc, batch_size);
     MCCNN_LAUNCHED();

@@ -64,6 +64,7 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 #ifndef MCCNN_NW_ROUNDS
 #define MCCNN_NW_ROUNDS 8
 #endif
+#define MCCNN_NW_SCAN_M 2048   // lists of up to this many centres: the prefix sum of the counts rides in the fill pass
 
 // (xcd_contiguous: common.h)
 // MODE 0 = count: hits per centre, and the ballot of every 64-candidate round is saved (`masks`).
@@ -82,14 +83,52 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                                                     int* __restrict__ cnt, unsigned long long* __restrict__ masks,
                                                     const int* __restrict__ startIdx, int* __restrict__ packed,
                                                     int capacity, unsigned long long* __restrict__ zeroWords, int numZero,
-                                                    int G /* centres per wave, 1 .. 32 */, float Tabs) {
+                                                    int G /* centres per wave, 1 .. 32 */, float Tabs,
+                                                    const int* __restrict__ scanCnt, int* __restrict__ startOut,
+                                                    int* __restrict__ totalDev, int* __restrict__ totalHost) {
     constexpr bool FILL = MODE == 1;
     // the status words of the prefix sum that follows the count pass (scan.hip): cleared here, no launch of their own
     if (!FILL && blockIdx.x == 0)
         for (int k = threadIdx.x; k < numZero; k += blockDim.x) zeroWords[k] = 0ull;
     __shared__ float4 win[4][MCCNN_NW_CAP];
     __shared__ int2 ctab[4][32];
+    extern __shared__ int scanLds[];   // [m] exclusive prefix of the counts (scan mode of the fill pass only)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (FILL && scanCnt) {
+        // Lists of at most MCCNN_NW_SCAN_M centres (the coarse levels of a hierarchy): the prefix sum between the two passes
+        // is one tile -- every workgroup of the fill pass computes it for itself in LDS (8 KB of counts, a block scan)
+        // instead of waiting for a launch of its own; workgroup 0 also writes startIdx and the edge total (device word and
+        // the caller's pinned word).
+        __shared__ int wtot[4];
+        constexpr int PER = MCCNN_NW_SCAN_M / 256;
+        int v[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = threadIdx.x * PER + k;
+            v[k] = idx < m ? scanCnt[idx] : 0;
+            sum += v[k];
+        }
+        const int incl = wave_incl_scan(sum);
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int run = incl - sum;
+        for (int w = 0; w < wave; ++w) run += wtot[w];
+        const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = threadIdx.x * PER + k;
+            if (idx < m) {
+                scanLds[idx] = run;
+                if (blockIdx.x == 0) startOut[idx] = run;
+            }
+            run += v[k];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            *totalDev = total;
+            if (totalHost) *totalHost = total;
+        }
+        __syncthreads();
+    }
     const int g0 = (xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave) * G;
     if (g0 >= m) return;
     float4* lw = win[wave];
@@ -101,7 +140,7 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
     CentreCtx c = centre_ctx(centres, cb, mn, mx, i, B, nc, radius, scaleInv, Tabs);
     const int key = own ? ((c.b * nc + c.x) * nc + c.y) * nc + c.z : -1;
     int count = 0;                                   // hits of this lane's centre so far
-    const int base = (FILL && own) ? startIdx[i] : 0;
+    const int base = (FILL && own) ? (scanCnt ? scanLds[i] : startIdx[i]) : 0;
     unsigned todo = (unsigned)(__ballot(own) & ((1ull << G) - 1));
     const int2* ct = reinterpret_cast<const int2*>(cells);
     int2* out = reinterpret_cast<int2*>(packed);
@@ -818,7 +857,8 @@ static bool neigh_ws(void* ws, size_t ws_bytes, int m, int n, NeighWs& w) {
 static int find_neighbors_count_impl(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
                                int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max,
                                int batch_size, int num_cells, float radius, int scale_inv, const int* centre_order,
-                               int* start_idx, int* total_dev, int* total_host, void* ws, size_t ws_bytes, mccnn_stream_t stream);
+                               int* start_idx, int* total_dev, int* total_host, void* ws, size_t ws_bytes, mccnn_stream_t stream,
+                               bool skip_scan = false);
 
 int mccnn_find_neighbors_count(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
                                int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max,
@@ -841,7 +881,8 @@ int mccnn_find_neighbors_count2(const float* centres, const int* centre_batch_id
 static int find_neighbors_count_impl(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
                                int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max,
                                int batch_size, int num_cells, float radius, int scale_inv, const int* centre_order,
-                               int* start_idx, int* total_dev, int* total_host, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+                               int* start_idx, int* total_dev, int* total_host, void* ws, size_t ws_bytes, mccnn_stream_t stream,
+                               bool skip_scan) {
     if (m < 0 || n < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f) || !total_dev) return MCCNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (m == 0) {
@@ -860,25 +901,28 @@ static int find_neighbors_count_impl(const float* centres, const int* centre_bat
     if (neigh_lean())
         neigh_window<0, true><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs,
                                                      aabb_min, aabb_max, batch_size, num_cells, radius, scale_inv, centre_order,
-                                                     w.cnt, w.masks, nullptr, nullptr, 0, zw, nz, G, Tabs);
+                                                     w.cnt, w.masks, nullptr, nullptr, 0, zw, nz, G, Tabs, nullptr, nullptr, nullptr, nullptr);
     else
         neigh_window<0, false><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs,
                                                      aabb_min, aabb_max, batch_size, num_cells, radius, scale_inv, centre_order,
-                                                     w.cnt, w.masks, nullptr, nullptr, 0, zw, nz, G, Tabs);
+                                                     w.cnt, w.masks, nullptr, nullptr, 0, zw, nz, G, Tabs, nullptr, nullptr, nullptr, nullptr);
     MCCNN_LAUNCHED();
+    if (skip_scan) return 0;   // (the fill pass that follows in the same chain scans the counts itself: find_neighbors_fill_impl)
     int rc = exclusive_scan_i32(w.cnt, start_idx, m, total_dev, w.scanws, s, true, total_host);
     if (rc) return rc;
     return 0;
 }
 
-int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
+static int find_neighbors_fill_impl(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
                               int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max,
                               int batch_size, int num_cells, float radius, int scale_inv, const int* centre_order,
                               const int* start_idx, int e, int* packed, void* ws, size_t ws_bytes,
-                              mccnn_stream_t stream) {
+                              mccnn_stream_t stream, int* scan_start_out, int* scan_total_dev, int* scan_total_host) {
     if (m < 0 || n < 0 || e < 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.0f)) return MCCNN_E_BADARG;
+    const bool scan = scan_start_out != nullptr;   // the counts of a skip_scan count pass are still in `ws`: scanned here
+    if (scan && (m > MCCNN_NW_SCAN_M || !scan_total_dev)) return MCCNN_E_BADARG;
     if (m == 0 || e == 0) return 0;
-    if (!centres || !centre_batch_ids || !sorted_pts || !cell_indexs || !aabb_min || !aabb_max || !start_idx || !packed)
+    if (!centres || !centre_batch_ids || !sorted_pts || !cell_indexs || !aabb_min || !aabb_max || (!scan && !start_idx) || !packed)
         return MCCNN_E_BADARG;
     NeighWs w;
     if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
@@ -890,17 +934,53 @@ int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids,
     if (G == 16) G = MCCNN_NW_G;
     if (forcedFill >= 1 && forcedFill <= 32) G = forcedFill;
     const float Tabs = scale_inv ? 0.0f : sqrt_threshold_host(radius);
+    size_t dyn = neigh_lds_pad();
+    if (scan && dyn < (size_t)m * sizeof(int)) dyn = (size_t)m * sizeof(int);
+    const int* scanCnt = scan ? w.cnt : nullptr;
     if (neigh_lean())
-        neigh_window<1, true><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs,
+        neigh_window<1, true><<<ceil_div(m, 4 * G), 256, dyn, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs,
                                                      aabb_min, aabb_max, batch_size, num_cells, radius, scale_inv, centre_order,
-                                                     nullptr, w.masks, start_idx, packed, e, nullptr, 0, G, Tabs);
+                                                     nullptr, w.masks, start_idx, packed, e, nullptr, 0, G, Tabs, scanCnt, scan_start_out,
+                                                     scan_total_dev, scan_total_host);
     else
-        neigh_window<1, false><<<ceil_div(m, 4 * G), 256, neigh_lds_pad(), s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs,
+        neigh_window<1, false><<<ceil_div(m, 4 * G), 256, dyn, s>>>(centres, centre_batch_ids, m, sorted_pts, cell_indexs,
                                                      aabb_min, aabb_max, batch_size, num_cells, radius, scale_inv, centre_order,
-                                                     nullptr, w.masks, start_idx, packed, e, nullptr, 0, G, Tabs);
+                                                     nullptr, w.masks, start_idx, packed, e, nullptr, 0, G, Tabs, scanCnt, scan_start_out,
+                                                     scan_total_dev, scan_total_host);
     MCCNN_LAUNCHED();
     return 0;
 }
+
+int mccnn_find_neighbors_fill(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
+                              int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max,
+                              int batch_size, int num_cells, float radius, int scale_inv, const int* centre_order,
+                              const int* start_idx, int e, int* packed, void* ws, size_t ws_bytes,
+                              mccnn_stream_t stream) {
+    return find_neighbors_fill_impl(centres, centre_batch_ids, m, sorted_pts, n, cell_indexs, aabb_min, aabb_max, batch_size,
+                                    num_cells, radius, scale_inv, centre_order, start_idx, e, packed, ws, ws_bytes, stream, nullptr,
+                                    nullptr, nullptr);
+}
+
+}  // extern "C"
+namespace mccnn {
+// Both passes of a search back to back (the native executor's geometry chain). Lists of at most MCCNN_NW_SCAN_M centres:
+// count -> fill, the prefix sum of the counts rides in the fill pass (two launches); larger ones: count -> scan -> fill.
+int find_neighbors_chain(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts, int n,
+                         const int* cell_indexs, const float* aabb_min, const float* aabb_max, int batch_size, int num_cells,
+                         float radius, int scale_inv, const int* centre_order, int* start_idx, int e_capacity, int* packed,
+                         int* total_dev, int* total_host, void* ws, size_t ws_bytes, mccnn_stream_t stream) {
+    static const bool fusedScan = debug_int("nw_fused", 1) != 0;   // A/B switch, read once
+    const bool small = fusedScan && m > 0 && m <= MCCNN_NW_SCAN_M && e_capacity > 0 && n > 0;
+    int rc = find_neighbors_count_impl(centres, centre_batch_ids, m, sorted_pts, n, cell_indexs, aabb_min, aabb_max, batch_size,
+                                       num_cells, radius, scale_inv, centre_order, start_idx, total_dev, total_host, ws, ws_bytes,
+                                       stream, small);
+    if (rc) return rc;
+    return find_neighbors_fill_impl(centres, centre_batch_ids, m, sorted_pts, n, cell_indexs, aabb_min, aabb_max, batch_size,
+                                    num_cells, radius, scale_inv, centre_order, start_idx, e_capacity, packed, ws, ws_bytes, stream,
+                                    small ? start_idx : nullptr, small ? total_dev : nullptr, small ? total_host : nullptr);
+}
+}  // namespace mccnn
+extern "C" {
 
 int mccnn_invert_permutation(const int* new_idx, int n, int* inv, mccnn_stream_t stream) {
     if (n < 0) return MCCNN_E_BADARG;
