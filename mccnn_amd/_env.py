@@ -16,7 +16,7 @@ THE table of keys is KNOWN_KEYS below -- the same table as kDebugKeys of csrc/de
 that they are equal and that every key any source file queries is in it); a key of MCCNN_DEBUG that is not in it is
 reported once on stderr instead of being silently ignored. Python-side keys (default): fuse_sort (1), native_prefetch (1),
 plan_prefetch (1), plan_prefetch_max_e (1e12), geo_prefetch_min (5), mailbox_copy (0), count_mailbox (1), ecap_scale (1),
-hier_pmode (1), rows_min_degree (16), unsorted_max_points (32768), geo_trace (0), nw_no_order (0), step_plan (1).
+hier_pmode (1), rows_min_degree (16), unsorted_max_points (32768), geo_trace (0), nw_no_order (0).
 (MCCNN_LIB_NAME / MCCNN_EXTRA_FLAGS belong to mccnn_amd.build: A/B builds of the library.)"""
 import os
 import sys
@@ -26,10 +26,10 @@ KNOWN_KEYS = (
     "small_off", "plan_small_off", "plan_small", "plan_small_max_l", "plan_mid_l", "plan_min_l", "rows_force",
     "rows_min_degree", "unsorted_max_points", "force_valu", "no_f1", "f1_x4_min_e", "f1_x4_waves_per_cu", "nw_lean",
     "nw_group", "nw_group_fill", "nw_lds_pad", "scan_bg_tiles", "issue_thread", "issue_inline", "job_delay_us",
-    "hier_trace", "geo_own_pool", "trace_terminate", "geo_small", "nw_fused",
+    "hier_trace", "geo_own_pool", "trace_terminate", "nw_fused",
     # Python side
     "fuse_sort", "native_prefetch", "plan_prefetch", "plan_prefetch_max_e", "geo_prefetch_min", "mailbox_copy",
-    "count_mailbox", "ecap_scale", "hier_pmode", "geo_trace", "nw_no_order", "step_plan")
+    "count_mailbox", "ecap_scale", "hier_pmode", "geo_trace", "nw_no_order")
 
 
 def _parse():

@@ -16,6 +16,7 @@
 // edge, padded with zero records (1/(pdf K) = 0 zeroes every term a padding lane feeds). Loads are perfectly coalesced;
 // padding is ~4 % on the 100k-point room at sigma = 1024 (31 % unsorted).
 #include "conv_mfma.h"
+#include "chain.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -123,6 +124,50 @@ __global__ __launch_bounds__(256) void vr_expand(const int* __restrict__ rowStar
     vposRow[r] = v0;
     for (int k = 0; k < vc; ++k) vlistRow[v0 + k] = r;
 }
+// vr_expand with the prefix sum of the pieces inside (single pass, decoupled look-back: chain.h) -- the launch between
+// vr_count and vr_expand is gone. Tile = 2048 consecutive row positions of the visiting order; status words (tiles + the
+// ticket) cleared by vr_count, which runs before. vTotal receives the number of virtual rows (sell_sort reads it).
+__global__ __launch_bounds__(SCAN_THREADS) void vr_scan_expand(const int* __restrict__ rowStart, int rows, int e,
+                                                               const int* __restrict__ order, const int* __restrict__ vcnt,
+                                                               unsigned long long* status, int* __restrict__ vposRow,
+                                                               int* __restrict__ vlistRow, int* __restrict__ vTotal) {
+    __shared__ int lds[4];
+    __shared__ int sOff;
+    __shared__ int sTile;
+    if (threadIdx.x == 0)
+        sTile = (int)__hip_atomic_fetch_add(status + gridDim.x, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int tile = sTile;
+    const int base = tile * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < rows) ? vcnt[base + k] : 0;
+        s += v[k];
+    }
+    int tot;
+    const int ex = block_excl_scan(s, tot, lds);
+    if (threadIdx.x < 64) {
+        const int excl = chain_lookback(status, tile, tot, (int)threadIdx.x);
+        if (threadIdx.x == 0) sOff = excl;
+    }
+    __syncthreads();
+    int run = ex + sOff;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int p = base + k;
+        if (p < rows) {
+            int r = order ? order[p] : p;
+            r = max(0, min(r, rows - 1));
+            vposRow[r] = run;
+            for (int j = 0; j < v[k]; ++j) vlistRow[run + j] = r;
+        }
+        run += v[k];
+    }
+    if (tile == (int)gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *vTotal = run;
+}
+
 // The whole layout of a small list in one workgroup of 1024 threads (rows, virtual rows <= MCCNN_PLAN_SMALL): pieces per
 // row and their prefix sum (4 row positions per thread), then one thread per VIRTUAL row -- its row found by a binary
 // search over the rows' first virtual-row ids -- so that a list of 73 rows with 150 pieces each is expanded by 1024
@@ -244,10 +289,14 @@ __device__ __forceinline__ void sell_radix_pass(const unsigned* __restrict__ src
     __syncthreads();
 }
 
+// The slices' first slots (sliceOff = exclusive prefix of the slice lengths, sliceOff[S] = total) come out of the same
+// launch: the windows are chained by a decoupled look-back over their slot totals (chain.h; windows taken from a ticket;
+// status words cleared by vr_count at the head of the layout) -- no prefix-sum launch behind the sort.
 __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStart, int rows, int e,
                                                  const int* __restrict__ vlistRow, const int* __restrict__ vposRow,
                                                  const int* __restrict__ vTotal, int* __restrict__ vrow,
-                                                 int* __restrict__ vcode, int* __restrict__ sliceSlots, int L) {
+                                                 int* __restrict__ vcode, int* __restrict__ sliceOff, int L,
+                                                 unsigned long long* status) {
     __shared__ unsigned key[SELL_SIGMA];
     __shared__ unsigned key2[SELL_SIGMA];
     __shared__ int rowOf[SELL_SIGMA];
@@ -255,8 +304,13 @@ __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStar
     __shared__ int cutOf[SELL_SIGMA];
     __shared__ int cnt[256];
     __shared__ int wsum[5];
+    __shared__ int sWin, sBase, sLen[SELL_SIGMA / 64];
+    if (threadIdx.x == 0)
+        sWin = (int)__hip_atomic_fetch_add(status + gridDim.x, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int win = sWin;
     const int V = *vTotal;
-    const int w0 = blockIdx.x * SELL_SIGMA;
+    const int w0 = win * SELL_SIGMA;
     for (int k = threadIdx.x; k < SELL_SIGMA; k += 256) {
         const int v = w0 + k;
         int r = -1, len = 0, cut = 0;
@@ -285,7 +339,23 @@ __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStar
         int d = lenOf[kk];
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) d = max(d, __shfl_xor(d, s, 64));
-        if (lane == 0) sliceSlots[slice] = d * 64;
+        if (lane == 0) sLen[g] = d * 64;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane2 = threadIdx.x;
+        int tot = 0;
+#pragma unroll
+        for (int g = 0; g < SELL_SIGMA / 64; ++g) tot += sLen[g];
+        const int excl = chain_lookback(status, win, tot, lane2);
+        if (lane2 == 0) sBase = excl;
+    }
+    __syncthreads();
+    if (threadIdx.x < SELL_SIGMA / 64) {
+        int run = sBase;
+        for (int g = 0; g < (int)threadIdx.x; ++g) run += sLen[g];
+        sliceOff[w0 / 64 + threadIdx.x] = run;
+        if (win == (int)gridDim.x - 1 && threadIdx.x == SELL_SIGMA / 64 - 1) sliceOff[w0 / 64 + SELL_SIGMA / 64] = run + sLen[threadIdx.x];
     }
 }
 
@@ -1035,11 +1105,18 @@ int mccnn_rowplan_sizes(int rows, int e, int* num_slices, long long* slot_capaci
     return 0;
 }
 
+// status words of the pieces' chain (vr_scan_expand): one per tile of 2 048 row positions + the ticket; never less than
+// what a stand-alone prefix sum over the rows would take (the bound of earlier rounds)
+static size_t layout_scan1_bytes(int rows) {
+    const size_t chain = align_up(((size_t)ceil_div(rows > 0 ? rows : 1, 2048) + 1) * 8) + 256;
+    const size_t scan = scan_workspace_bytes(rows > 0 ? rows : 1);
+    return chain > scan ? chain : scan;
+}
 size_t mccnn_rowplan_workspace_bytes(int rows, int e) {
     if (rows <= 0) return 256;
     const PlanSizes z = plan_sizes(rows, e);
     return align_up((size_t)(rows + 1) * sizeof(int)) * 2 + align_up((size_t)z.vcap * sizeof(int)) +
-           align_up((size_t)z.S * sizeof(int)) + scan_workspace_bytes(rows) + scan_workspace_bytes(z.S) + 512;
+           align_up((size_t)z.S * sizeof(int)) + layout_scan1_bytes(rows) + scan_workspace_bytes(z.S) + 512;
 }
 
 int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order, int* plan_vrow, int* plan_vcode,
@@ -1061,19 +1138,25 @@ int mccnn_rowplan_layout(const int* row_start, int rows, int e, const int* order
     int* vposP = ar.take<int>((size_t)rows + 1);
     int* vlistRow = ar.take<int>((size_t)z.vcap);
     int* sliceSlots = ar.take<int>((size_t)z.S);
-    void* scan1 = ar.take<char>(scan_workspace_bytes(rows));
+    void* scan1 = ar.take<char>(layout_scan1_bytes(rows));
     void* scan2 = ar.take<char>(scan_workspace_bytes(z.S));
     if (!vcnt || !vposP || !vlistRow || !sliceSlots || !scan1 || !scan2) return MCCNN_E_WORKSPACE;
-    vr_count<<<ceil_div(rows, 256), 256, 0, s>>>(row_start, rows, e, order, vcnt, z.L, clear_span(scan1, scan_status_bytes(rows)),
-                                                  clear_span(scan2, scan_status_bytes(z.S)));
+    // Three launches (round 5: six with a memset): vr_count (+ the status words of both chains), vr_scan_expand (prefix sum
+    // of the pieces + expansion), sell_sort (+ the slices' offsets). The status areas are the scan workspaces' first bytes:
+    // tiles + 1 words for the pieces' chain (2 048 positions per tile), windows + 1 for the slices' chain.
+    const int tiles = ceil_div(rows, SCAN_TILE);
+    if ((size_t)(tiles + 1) * 8 > layout_scan1_bytes(rows) || (size_t)(z.windows + 1) * 8 > align_up((size_t)z.S * 4)) return MCCNN_E_WORKSPACE;
+    unsigned long long* st1 = reinterpret_cast<unsigned long long*>(scan1);
+    // (the slices' chain needs windows + 1 words: S / 16 + 1 -- they fit the unused slice-length array + its scan workspace)
+    unsigned long long* st2 = reinterpret_cast<unsigned long long*>(sliceSlots);
+    vr_count<<<ceil_div(rows, 256), 256, 0, s>>>(row_start, rows, e, order, vcnt, z.L, clear_span(st1, (size_t)(tiles + 1) * 8),
+                                                  clear_span(st2, (size_t)(z.windows + 1) * 8));
     MCCNN_LAUNCHED();
-    int rc = exclusive_scan_i32(vcnt, vposP, rows, vposP + rows, scan1, s, true);  // vposP[rows] = number of virtual rows
-    if (rc) return rc;
-    vr_expand<<<ceil_div(rows, 256), 256, 0, s>>>(row_start, rows, e, order, vposP, vpos_row, vlistRow, z.L);
+    vr_scan_expand<<<tiles, SCAN_THREADS, 0, s>>>(row_start, rows, e, order, vcnt, st1, vpos_row, vlistRow, vposP + rows);
     MCCNN_LAUNCHED();
-    sell_sort<<<z.windows, 256, 0, s>>>(row_start, rows, e, vlistRow, vpos_row, vposP + rows, plan_vrow, plan_vcode, sliceSlots, z.L);
+    sell_sort<<<z.windows, 256, 0, s>>>(row_start, rows, e, vlistRow, vpos_row, vposP + rows, plan_vrow, plan_vcode, slice_off, z.L, st2);
     MCCNN_LAUNCHED();
-    return exclusive_scan_i32(sliceSlots, slice_off, z.S, slice_off + z.S, scan2, s, true);
+    return 0;
 }
 
 int mccnn_edge_records(const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs, const float* samples,
@@ -1159,7 +1242,7 @@ int mccnn_rowplan_bound(int rows, int e_cap, int transposed, long long* buffer_b
         o += plan_al((size_t)(slots > 0 ? slots : 1)) + plan_al((size_t)(slots > 0 ? slots : 1) * 4);
         if (o * 4 > buf) buf = o * 4;
         const size_t w = align_up((size_t)(rows + 1) * sizeof(int)) * 2 + align_up((size_t)vcap * sizeof(int)) +
-                         align_up((size_t)S * sizeof(int)) + scan_workspace_bytes(rows > 0 ? rows : 1) + scan_workspace_bytes((int)S) + 512 +
+                         align_up((size_t)S * sizeof(int)) + layout_scan1_bytes(rows) + scan_workspace_bytes((int)S) + 512 +
                          align_up((size_t)vcap * sizeof(int2));
         if (w > ws) ws = w;
     }

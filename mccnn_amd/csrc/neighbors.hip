@@ -64,7 +64,7 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 #ifndef MCCNN_NW_ROUNDS
 #define MCCNN_NW_ROUNDS 8
 #endif
-#define MCCNN_NW_SCAN_M 2048   // lists of up to this many centres: the prefix sum of the counts rides in the fill pass
+#define MCCNN_NW_SCAN_M 4096   // lists of up to this many centres: the prefix sum of the counts rides in the fill pass (16 KB of LDS)
 
 // (xcd_contiguous: common.h)
 // MODE 0 = count: hits per centre, and the ballot of every 64-candidate round is saved (`masks`).
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (FILL && scanCnt) {
         // Lists of at most MCCNN_NW_SCAN_M centres (the coarse levels of a hierarchy): the prefix sum between the two passes
-        // is one tile -- every workgroup of the fill pass computes it for itself in LDS (8 KB of counts, a block scan)
+        // is two tiles at most -- every workgroup of the fill pass computes it for itself in LDS (16 KB of counts, a block scan)
         // instead of waiting for a launch of its own; workgroup 0 also writes startIdx and the edge total (device word and
         // the caller's pinned word).
         __shared__ int wtot[4];

@@ -2,31 +2,9 @@
 // workgroup, recursion over the per-tile sums. Replaces the reference's two hand-rolled
 // 3-level Hillis-Steele scans (sort_gpu.cu:87-146, find_neighbors.cu:122-176), which cap
 // the input at 512^3 / 256^3 elements.
-#include "common.h"
+#include "chain.h"
 
 namespace mccnn {
-
-constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048
-
-// Block-wide exclusive scan of one value per thread; returns exclusive prefix, total via ref.
-__device__ __forceinline__ int block_excl_scan(int v, int& total, int* lds /*>=4 ints*/) {
-    int incl = wave_incl_scan(v);
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 63) lds[wave] = incl;
-    __syncthreads();
-    int woff = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
-        int s = lds[w];
-        if (w < wave) woff += s;
-        tot += s;
-    }
-    __syncthreads();
-    total = tot;
-    return woff + incl - v;
-}
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const int* __restrict__ in, int n,
                                                                int* __restrict__ sums) {
@@ -113,34 +91,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained(const int* in, int*
     int tot;
     const int ex = block_excl_scan(s, tot, lds);
     if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        int excl = 0;
-        if (tile == 0) {
-            if (lane == 0) __hip_atomic_store(status, (2ull << 62) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (lane == 0) __hip_atomic_store(status + tile, (1ull << 62) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int hi = tile - 1;  // look back over tiles hi, hi - 1, ... (lane l reads tile hi - l)
-            while (true) {
-                const int p = hi - lane;
-                unsigned long long w = 0;
-                bool ready;
-                do {  // every word of the window has to be published before the window can be summed
-                    w = (p >= 0) ? __hip_atomic_load(status + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
-                    ready = __all((w >> 62) != 0);
-                    if (!ready) __builtin_amdgcn_s_sleep(2);
-                } while (!ready);
-                const unsigned long long pref = __ballot((w >> 62) == 2);      // lanes holding an inclusive prefix
-                const int first = (int)__builtin_ctzll(pref ? pref : 1ull << 63);
-                int val = (pref == 0 || lane <= first) ? (int)(unsigned)w : 0;    // aggregates up to and incl. the prefix
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
-                excl += val;
-                if (pref) break;
-                hi -= 64;
-            }
-            if (lane == 0) __hip_atomic_store(status + tile, (2ull << 62) | (unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) sOff = excl;
+        const int excl = chain_lookback(status, tile, tot, (int)threadIdx.x);   // chain.h
+        if (threadIdx.x == 0) sOff = excl;
     }
     __syncthreads();
     int run = ex + sOff;
