@@ -614,6 +614,7 @@ class ConfigWorkload:
         from mccnn_amd import MCConvModule as _M
         l0 = self.lib.mccnn_debug_launch_count()
         w0 = _M.host_wait_seconds()
+        lw0 = _M.HOST_LAG_WAIT_S[0]
         # the host issues a step while the device is at most `lag` steps behind (0 = unbounded; run_config(): 2 for the
         # pipelined modes)
         lag = getattr(self, "lag", 0)
@@ -624,6 +625,7 @@ class ConfigWorkload:
             self.step()
         t_issue = time.perf_counter() - t0   # the host has enqueued the last launch (edge-count waits included)
         waits = _M.host_wait_seconds() - w0
+        lag_waits = _M.HOST_LAG_WAIT_S[0] - lw0
         self.builder.hostStepsAhead_ = None
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -631,6 +633,9 @@ class ConfigWorkload:
         self.host_issue_ms = t_issue / steps * 1e3
         # ... of which the host WAITED for sizes computed on the device (edge totals, sample counts): the rest is its own work
         self.host_wait_ms = waits / steps * 1e3
+        # ... split: waiting for the DEVICE to catch up (the host is held at most `lag` steps ahead: the step is bound by
+        # the GPU when this is large) and waiting for device-side SIZES (edge totals, level sizes)
+        self.host_lag_wait_ms = lag_waits / steps * 1e3
         return el / steps * 1e3, launches
 
     def per_layer(self, iters=5):
@@ -788,7 +793,7 @@ def run_config(name, device, args, want_cpu):
         # every convolution are bit-identical to the sequential step's and the steps are not slower
         try:
             ref = [o.detach().clone() for o in cw.step()]
-            best_issue, best_wait = seq_issue, seq_wait
+            best_issue, best_wait, best_lag = seq_issue, seq_wait, 0.0
             # ONE pipelined form is timed: hierarchy two batches ahead + the next batch's geometry (MCCNN_BENCH_DEEP=0: the
             # shallow form, hierarchy one batch ahead, instead)
             for deep in ((True,) if os.environ.get("MCCNN_BENCH_DEEP", "1") != "0" else (False,)):
@@ -813,14 +818,14 @@ def run_config(name, device, args, want_cpu):
                         print("bench: %s %s host lag %d: %.4f ms" % (name, "deep" if deep else "pipelined", lag, ms_p), file=sys.stderr)
                     if ms_p < ms:
                         ms, launches, mode, lag_used = ms_p, launches_p, ("pipelined+geometry" if deep else "pipelined"), lag
-                        best_issue, best_wait = cw.host_issue_ms, cw.host_wait_ms
+                        best_issue, best_wait, best_lag = cw.host_issue_ms, cw.host_wait_ms, cw.host_lag_wait_ms
                 else:
                     print("bench: %s steps of %s do not reproduce the sequential outputs" % (
                         "pipelined+geometry" if deep else "pipelined", name), file=sys.stderr)
-            cw.host_issue_ms, cw.host_wait_ms = best_issue, best_wait
+            cw.host_issue_ms, cw.host_wait_ms, cw.host_lag_wait_ms = best_issue, best_wait, best_lag
         except Exception as ex:  # the sequential numbers stand
             print("bench: pipelined %s steps failed: %r" % (name, ex), file=sys.stderr)
-            cw.host_issue_ms, cw.host_wait_ms = seq_issue, seq_wait
+            cw.host_issue_ms, cw.host_wait_ms, cw.host_lag_wait_ms = seq_issue, seq_wait, 0.0
         cw.set_pipeline(False)
         torch.cuda.synchronize()
     n = int(cw.P.shape[0])
@@ -839,7 +844,16 @@ def run_config(name, device, args, want_cpu):
            # when this equals ms_per_step the step is bound by the HOST issuing its launches, not by the kernels
            "host_issue_ms_per_step": round(cw.host_issue_ms, 4),
            # the host's OWN work per step: issue time minus the time it sat waiting for device-side sizes
-           "host_busy_ms_per_step": round(cw.host_issue_ms - cw.host_wait_ms, 4), "hierarchy_ms": round(t_h, 4),
+           "host_busy_ms_per_step": round(cw.host_issue_ms - cw.host_wait_ms, 4),
+           # the waits, split: held back by the lag bound (= the GPU is the bound) / waiting for device-side sizes
+           "host_lag_wait_ms_per_step": round(getattr(cw, "host_lag_wait_ms", 0.0), 4),
+           "host_size_wait_ms_per_step": round(cw.host_wait_ms - getattr(cw, "host_lag_wait_ms", 0.0), 4),
+           # who bounds the step: the host's own work against what is left of the step
+           "bound_by": ("host" if (cw.host_issue_ms - cw.host_wait_ms) >= 0.85 * ms else "gpu"),
+           # the prefetched hierarchy of the pipelined modes starts at once (after=True: the synthetic batch is resident in
+           # HBM before the timed region); a loader that uploads per step would pass the event of its upload stream
+           "hierarchy_start": ("after=True (batch resident in HBM)" if mode != "sequential" else "inline"),
+           "hierarchy_ms": round(t_h, 4),
            "conv_fwd_bwd_ms_cached_geometry": round(sum(l["fwd_ms"] + l["bwd_ms"] for l in layers), 4),
            "layers": layers}
     if want_cpu == "later":   # main(): every configuration's GPU steps first, the 128-thread CPU legs after all of them
@@ -1037,7 +1051,8 @@ def compact_record(rec, details_path=None):
         out["configs"] = {}
         for name, ent in cf.items():
             e = _pick(ent, ("ms_per_step", "value", "mode", "host_lag_steps", "sequential_ms_per_step", "host_issue_ms_per_step",
-                            "host_busy_ms_per_step", "library_launches_per_step", "points", "convolutions"))
+                            "host_busy_ms_per_step", "host_lag_wait_ms_per_step", "bound_by", "library_launches_per_step", "points",
+                            "convolutions"))
             if "library_launches_per_step" in e:
                 e["launches"] = e.pop("library_launches_per_step")
             if isinstance(ent.get("cpu_baseline"), dict) and "value" in ent["cpu_baseline"]:

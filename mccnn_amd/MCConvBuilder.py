@@ -390,7 +390,9 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                 from . import MCConvModule as _M
                 t0 = time.perf_counter()
                 evs[-(int(k) + 1)].synchronize()
-                _M.HOST_WAIT_S[0] += time.perf_counter() - t0
+                dt = time.perf_counter() - t0
+                _M.HOST_WAIT_S[0] += dt
+                _M.HOST_LAG_WAIT_S[0] += dt
         state["cacheGrids_"], state["cacheNeighs_"], state["cachePDFs_"] = {}, {}, {}
         if self.geoSeen_:
             # the geometries the step's layers USED (built by them, prebuilt, or started a step ago by prefetch_step) and

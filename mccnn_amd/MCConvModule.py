@@ -206,6 +206,7 @@ _MAILBOX_YIELD_S = 0.25   # ... then polling that hands the GIL to other threads
 #: seconds this process has spent WAITING for sizes computed on the device (edge totals through the mailbox, the sample
 #: counts of a hierarchy); diagnostics only (bench.py: host work per step = issue time - waits)
 HOST_WAIT_S = [0.0]   # ... measured by this module (the op-by-op paths)
+HOST_LAG_WAIT_S = [0.0]   # the part of HOST_WAIT_S spent in ConvolutionBuilder.reset() holding the host k steps behind the device
 
 
 def host_wait_seconds():

@@ -368,6 +368,10 @@ struct Geo {
             const c10::Stream consumer = as_torch_stream(stream, (int)buf.device().index());
             buf.record_stream(consumer);
             for (Tensor& t : attached) t.record_stream(consumer);
+            // (the inputs the library borrowed pointers of: a consumer on a stream other than the one that made the geometry
+            // reads through them too -- the grid's sorted copies are ours, the centres are the caller's)
+            if (stream != caller_stream)
+                for (Tensor& t : keep) if (t.defined()) t.record_stream(consumer);
         }
     }
     ~Geo() {
@@ -522,6 +526,8 @@ void check_dev(const Tensor& t, at::ScalarType dt, const char* name) {
 struct HierFuture;
 // the event recorded behind an ADOPTED prefetched hierarchy (nullptr: not adopted, failed, none)
 hipEvent_t hierarchy_ready_event(const std::shared_ptr<HierFuture>& f);
+// whether `t` lives in the memory of that hierarchy (its input points / batch ids, boxes, level rows)
+bool hierarchy_owns(const std::shared_ptr<HierFuture>& f, const Tensor& t);
 
 std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const Tensor& centres, const Tensor& cbids,
                                     const Tensor& mn, const Tensor& mx, int64_t B, int64_t nc, double radius, bool scale_inv,
@@ -555,6 +561,11 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
     static const bool own_pools = mccnn::debug_int("geo_own_pool", 1) != 0;
     hipEvent_t ready = (side >= 0 && own_pools && Issuer::enabled()) ? hierarchy_ready_event(after) : nullptr;
     if (ready && grid_from && !grid_from->own_pool) ready = nullptr;
+    // ... and only then: an input that is NOT the hierarchy's own memory (a re-made-contiguous copy of a level, a tensor
+    // the caller produced on its stream) is ordered by the calling stream alone -- such a build forks behind it like any other
+    if (ready)
+        for (const Tensor* t : {&pts, &bids, &centres, &cbids, &mn, &mx})
+            if (!hierarchy_owns(after, *t)) { ready = nullptr; break; }
     // (a build that takes the fork path after one that did not: the caller's fork=false refers to a record that was skipped)
     static thread_local bool fork_skipped = false;
     if (ready && side_stream((int)side)) {
@@ -1149,6 +1160,19 @@ struct HierFuture {
 
 hipEvent_t hierarchy_ready_event(const std::shared_ptr<HierFuture>& f) {
     return (f && f->joined && f->rc == 0 && f->done.load(std::memory_order_acquire)) ? f->event : nullptr;
+}
+bool hierarchy_owns(const std::shared_ptr<HierFuture>& f, const Tensor& t) {
+    if (!f || !t.defined() || !t.is_cuda()) return false;
+    const char* p = static_cast<const char*>(t.data_ptr());
+    auto inside = [p](const Tensor& o) {
+        if (!o.defined() || !o.is_cuda()) return false;
+        const char* b = static_cast<const char*>(o.data_ptr());
+        return p >= b && p < b + o.nbytes();
+    };
+    if (inside(f->pts) || inside(f->bids) || inside(f->mn) || inside(f->mx)) return true;
+    for (const Tensor& o : f->ints) if (inside(o)) return true;
+    for (const Tensor& o : f->flts) if (inside(o)) return true;
+    return false;
 }
 
 // after_mode: 0 = the build starts behind everything the calling stream holds now (where the inputs were produced);

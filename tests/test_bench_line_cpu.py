@@ -34,6 +34,9 @@ def _full_record(n_layers=17):
     cfg = {"workload": "w" * 120, "points": 100000, "clouds": 1, "level_sizes": [100000, 5627, 1273, 318, 73],
            "convolutions": n_layers, "steps": 30, "ms_per_step": 4.9454, "value": 20220717.2, "unit": "points/s",
            "library_launches_per_step": 394.0, "host_issue_ms_per_step": 4.9373, "hierarchy_ms": 0.661,
+           "mode": "pipelined+geometry", "host_lag_steps": 2, "sequential_ms_per_step": 6.8912, "host_busy_ms_per_step": 1.7421,
+           "host_lag_wait_ms_per_step": 2.9811, "host_size_wait_ms_per_step": 0.2141, "bound_by": "gpu",
+           "hierarchy_start": "after=True (batch resident in HBM)",
            "layers": [dict(layer) for _ in range(n_layers)],
            "cpu_baseline": {"value": 10437.1, "unit": "points/s", "cores": 128, "kind": "port", "sample": "s" * 300}}
     return {
@@ -89,7 +92,8 @@ def test_final_line_is_small_and_complete():
     assert r["find_neighbors_8rooms"]["rooms"] == 8
     assert set(out["configs"]) == {"cfg0", "cfg1", "cfg2", "cfg3", "cfg4"}
     for c in out["configs"].values():
-        assert {"ms_per_step", "value", "host_issue_ms_per_step", "launches"} <= set(c)
+        assert {"ms_per_step", "value", "host_issue_ms_per_step", "launches", "host_busy_ms_per_step", "host_lag_wait_ms_per_step",
+                "bound_by"} <= set(c)
 
 
 def test_final_line_survives_errors_and_missing_objects():
