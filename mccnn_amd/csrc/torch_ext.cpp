@@ -753,6 +753,19 @@ void prepare(Geo& g, const Tensor& feats, const Layer& L, int backward, int flag
     }
 }
 
+// host-time census of the layer calls (debug_times(): ns and calls per section; cheap enough to stay compiled in)
+enum { T_FWD = 0, T_FWD_LIB, T_FWD_ALLOC, T_BWD, T_BWD_LIB, T_BWD_ALLOC, T_BWD_VIEWS, T_BWD_JOIN, T_N };
+std::atomic<long long> g_t_ns[T_N], g_t_calls[T_N];
+struct Tick {
+    int k;
+    std::chrono::steady_clock::time_point t0;
+    explicit Tick(int k_) : k(k_), t0(std::chrono::steady_clock::now()) {}
+    ~Tick() {
+        g_t_ns[k].fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+        g_t_calls[k].fetch_add(1, std::memory_order_relaxed);
+    }
+};
+
 struct ConvBackward : public torch::autograd::Node {
     std::shared_ptr<Geo> geo;
     // the seven inputs, held as plain tensors with the version each had in the forward pass (they are INPUTS of this node,
@@ -764,6 +777,7 @@ struct ConvBackward : public torch::autograd::Node {
     Layer L;
 
     torch::autograd::variable_list apply(torch::autograd::variable_list&& grads) override {
+        const Tick tick_all(T_BWD);
         TORCH_CHECK(geo && feats_.defined(), "MC convolution: backward through a graph whose buffers have been freed (retain_graph=True?)");
         const DevGuard device_guard((int)geo->buf.device().index());
         const Tensor &feats = feats_, &w1 = w1_, &b1 = b1_, &w2 = w2_, &b2 = b2_, &w3 = w3_, &b3 = b3_;
@@ -783,17 +797,24 @@ struct ConvBackward : public torch::autograd::Node {
         // layers with 2..4 input features is gathered through it in a fixed order (bit-reproducible) instead of added
         // with float atomics; a bare single call keeps the atomics (the list would cost more than they do)
         if (geo->uses > 1) flags |= 2;
-        geo->join(cur_stream(feats), true);
+        { const Tick tj(T_BWD_JOIN); geo->join(cur_stream(feats), true); }
         long long wsb = 0, svb = 0;
         prepare(*geo, feats, L, 1, flags, wsb, svb);
-        Tensor fg = at::empty_like(feats);
+        Tensor fg;
+        Tensor gflat;
         // the six MLP gradients: consecutive slices of ONE buffer in the order the builder creates the variables (a
         // data-parallel step all-reduces that buffer as it is, dist.GradBucket)
         const int64_t n1 = w1.numel(), n2 = b1.numel(), n3 = w2.numel(), n4 = b2.numel(), n5 = w3.numel(), n6 = b3.numel();
-        Tensor gflat = at::empty({n1 + n2 + n3 + n4 + n5 + n6}, w1.options());
+        {
+            const Tick ta(T_BWD_ALLOC);
+            fg = at::empty_like(feats);
+            gflat = at::empty({n1 + n2 + n3 + n4 + n5 + n6}, w1.options());
+        }
         float* base = gflat.data_ptr<float>();
         void* st = cur_stream(feats);
         Tensor& ws = scratch((size_t)wsb, feats, st);
+        {
+        const Tick tl(T_BWD_LIB);
         check(mccnn_conv_backward(geo->h, feats.data_ptr(), saved.defined() ? saved.data_ptr() : nullptr,
                                   saved.defined() ? (size_t)saved.numel() : 0, og.data_ptr(), L.fin, L.fout, L.combin, L.avg,
                                   L.bf16, flags, w1.data_ptr<float>(), b1.data_ptr<float>(), w2.data_ptr<float>(),
@@ -801,6 +822,8 @@ struct ConvBackward : public torch::autograd::Node {
                                   base + n1, base + n1 + n2, base + n1 + n2 + n3, base + n1 + n2 + n3 + n4,
                                   base + n1 + n2 + n3 + n4 + n5, ws.data_ptr(), (size_t)ws.numel(), st),
               "conv_backward");
+        }
+        const Tick tv(T_BWD_VIEWS);
         int64_t o = 0;
         auto piece = [&](int64_t cnt, const Tensor& like) {
             Tensor t = gflat.as_strided(like.sizes(), like.strides(), o);   // (contiguous variables: checked in conv())
@@ -842,16 +865,21 @@ Tensor conv(std::shared_ptr<Geo> geo, const Tensor& feats, const Tensor& w1, con
     // through the transposed list instead of adding them with float atomics)
     L.flags = (need_grad ? 1 : 0) | (deterministic ? 2 : 0);
     Tensor out, saved;
+    const Tick tick_all(T_FWD);
     {
         at::AutoDispatchBelowADInplaceOrView guard;
         geo->join(cur_stream(feats), geo->pre_avg != L.avg);
         if (geo->grid_owner) geo->grid_owner->join(cur_stream(feats));
         long long wsb = 0, svb = 0;
         prepare(*geo, feats, L, 0, L.flags, wsb, svb);
-        out = at::empty({geo->m, combin ? fout : (int64_t)L.fin}, feats.options());
-        if (svb > 0) saved = at::empty({(int64_t)svb}, feats.options().dtype(at::kByte));
+        {
+            const Tick ta(T_FWD_ALLOC);
+            out = at::empty({geo->m, combin ? fout : (int64_t)L.fin}, feats.options());
+            if (svb > 0) saved = at::empty({(int64_t)svb}, feats.options().dtype(at::kByte));
+        }
         void* st = cur_stream(feats);
         Tensor& ws = scratch((size_t)wsb, feats, st);
+        const Tick tl(T_FWD_LIB);
         check(mccnn_conv_forward(geo->h, feats.data_ptr(), L.fin, L.fout, L.combin, L.avg, L.bf16, L.flags, w1.data_ptr<float>(),
                                  b1.data_ptr<float>(), w2.data_ptr<float>(), b2.data_ptr<float>(), w3.data_ptr<float>(),
                                  b3.data_ptr<float>(), out.data_ptr(), saved.defined() ? saved.data_ptr() : nullptr,
@@ -1289,4 +1317,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
     mod.def("shutdown_helpers", [] { for (int k = 0; k < 3; ++k) Issuer::get(k).retire(); },
             py::call_guard<py::gil_scoped_release>());
     mod.def("wait_ns", [] { return (long long)g_wait_ns.load(std::memory_order_relaxed); });
+    mod.def("debug_times", [](bool reset) {
+        static const char* names[T_N] = {"fwd", "fwd_lib", "fwd_alloc", "bwd", "bwd_lib", "bwd_alloc", "bwd_views", "bwd_join"};
+        py::dict d;
+        for (int k = 0; k < T_N; ++k) {
+            d[names[k]] = py::make_tuple((long long)g_t_ns[k].load(), (long long)g_t_calls[k].load());
+            if (reset) { g_t_ns[k].store(0); g_t_calls[k].store(0); }
+        }
+        return d;
+    }, py::arg("reset") = false);
 }

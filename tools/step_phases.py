@@ -60,4 +60,11 @@ span = sum(a.elapsed_time(b) for a, b in ev) / N
 period = ev[0][0].elapsed_time(ev[-1][0]) / (N - 1)
 print("%s lag %d: %.3f ms/step (host issue %.3f); host phases ms: %s" % (name, lag, el / N * 1e3, t_issue / N * 1e3,
       ", ".join("%s %.3f" % (k, v / N * 1e3) for k, v in ph_t.items())))
+try:
+    from mccnn_amd import native as _nat
+    if _nat._EXT is not None:
+        dt = _nat._EXT.debug_times(False)
+        print("   extension, us per call: " + ", ".join("%s %.1f (x%d/step)" % (k, v[0] / max(v[1], 1) / 1e3, round(v[1] / (N + 10))) for k, v in dt.items()))
+except Exception as ex:
+    print("   (no extension census: %r)" % (ex,))
 print("   main queue: convolution chain spans %.3f ms of a %.3f ms period (first conv launch to end of backward)" % (span, period))
