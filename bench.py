@@ -543,7 +543,10 @@ class ConfigWorkload:
         from mccnn_amd.MCConvBuilder import PointHierarchy
         # after=True: the synthetic batch has been resident in HBM since before the timed region -- its hierarchy does not
         # queue behind the convolutions the calling stream holds (a loader would pass the event of its upload stream)
-        self.next_ph = PointHierarchy.prefetch(self.P, self.Bi, list(self.cfg.hierarchy), self.B, self.cfg.relative, after=True)
+        # (features=: the input feature rows of the batch travel with it -- every level's rows are gathered on the
+        # hierarchy's stream instead of by one launch per level on this thread at adoption)
+        self.next_ph = PointHierarchy.prefetch(self.P, self.Bi, list(self.cfg.hierarchy), self.B, self.cfg.relative, after=True,
+                                               features=(None if os.environ.get("MCCNN_BENCH_NO_FEATURE_PREFETCH") else self.F0))
         return self.next_ph is not None
 
     def set_pipeline(self, on, geometry=False):

@@ -89,8 +89,11 @@ _PLAN_PREFETCH_MAX_E = _env.debug("plan_prefetch_max_e", 10 ** 12)
 class _PrefetchedHierarchy:
     """Handle of PointHierarchy.prefetch(): the future of the extension and what it was requested for."""
 
-    def __init__(self, future, points, batchIds, radiusList, batchSize, relativeRadius):
+    def __init__(self, future, points, batchIds, radiusList, batchSize, relativeRadius, features=None):
         self.future, self.points, self.batchIds = future, points, batchIds
+        # (feature rows handed to prefetch(): the levels' rows were gathered with the hierarchy when these are still the
+        # same tensor, unmodified)
+        self.features, self.featuresVersion = features, (features._version if features is not None else None)
         self.radiusList, self.batchSize, self.relativeRadius = [float(r) for r in radiusList], int(batchSize), bool(relativeRadius)
         self.version = (points._version, batchIds._version)
 
@@ -150,7 +153,7 @@ class PointHierarchy(_PlainState, torch.nn.Module):
     """
 
     @staticmethod
-    def prefetch(inPoints, inBatchIds, radiusList, batchSize=32, relativeRadius=True, after=None):
+    def prefetch(inPoints, inBatchIds, radiusList, batchSize=32, relativeRadius=True, after=None, features=None):
         """Extension (no counterpart in the reference): starts the geometry of a hierarchy -- the boxes and every level's
         Poisson-disk samples, which depend on the points only -- on a stream of its own, issued by a helper thread, and
         returns a handle for `PointHierarchy(..., prefetched=handle)`. In a training loop: request the hierarchy of batch
@@ -160,14 +163,18 @@ class PointHierarchy(_PlainState, torch.nn.Module):
         (the upload of the batch) -- or, for a loader that uploads on a stream of its own, behind the torch.cuda.Event it
         recorded there (after=event), or at once (after=True: points and batch ids are complete); the calling stream may
         hold a whole step of convolutions by then, which such a hierarchy no longer queues behind. Returns None when there
-        is nothing to run ahead (host tensors, no extension): the constructor then builds inline, as without the argument."""
+        is nothing to run ahead (host tensors, no extension): the constructor then builds inline, as without the argument.
+        features (optional): the feature rows the constructor will be given for level 0. Rows that carry no gradient (a
+        network's input features) are then gathered for every level together with the hierarchy, on its stream, instead of
+        by one launch per level on the calling thread when the hierarchy is adopted; the constructor uses them when it is
+        handed the very same, unmodified tensor, and gathers as usual otherwise."""
         from . import MCConvModule as _M
         if not FUSED_HIERARCHY or not poisson_sampling.__module__.endswith("MCConvModule"):
             return None
-        fut = _M.point_hierarchy_prefetch(inPoints, inBatchIds, list(radiusList), batchSize, relativeRadius, after)
+        fut = _M.point_hierarchy_prefetch(inPoints, inBatchIds, list(radiusList), batchSize, relativeRadius, after, features)
         if fut is None:
             return None
-        return _PrefetchedHierarchy(fut, inPoints, inBatchIds, radiusList, batchSize, relativeRadius)
+        return _PrefetchedHierarchy(fut, inPoints, inBatchIds, radiusList, batchSize, relativeRadius, features)
 
     def __init__(self, inPoints, inFeatures, inBatchIds, radiusList, hierarchyName="Point_Hierarchy", batchSize=32,
                  relativeRadius=True, aabbReduceGroup=None, ops=None, prefetched=None):
@@ -252,8 +259,18 @@ class PointHierarchy(_PlainState, torch.nn.Module):
             _M._seed_num_cells(aabbMin, aabbMax, extent)
         _log("########## Point Hierarchy: %s (Rel: %s, prefetched)" % (self.hierarchyName_, self.relativeRadius_))
         currFeatures = inFeatures
-        for (sampledPts, sampledBatchsIds, _sortedIdx, transformedIndexs), currRadius in zip(levels, prefetched.radiusList):
-            currFeatures = ops.get_sampled_features(transformedIndexs, currFeatures)
+        # the levels' feature rows came with the hierarchy when prefetch() was handed this very tensor (no gradient, unmodified)
+        pf = prefetched.features
+        gathered = (pf is not None and inFeatures is not None and not getattr(inFeatures, "requires_grad", True)
+                    and (inFeatures is pf or (inFeatures.data_ptr() == pf.data_ptr() and inFeatures.shape == pf.shape
+                                              and inFeatures.dtype == pf.dtype))
+                    and pf._version == prefetched.featuresVersion)
+        for lvl, currRadius in zip(levels, prefetched.radiusList):
+            sampledPts, sampledBatchsIds, _sortedIdx, transformedIndexs = lvl[:4]
+            if gathered and len(lvl) > 4:
+                currFeatures = lvl[4]
+            else:
+                currFeatures = ops.get_sampled_features(transformedIndexs, currFeatures)
             self.points_.append(sampledPts)
             self.batchIds_.append(sampledBatchsIds)
             self.features_.append(currFeatures)

@@ -996,7 +996,7 @@ def _torch_ext():
     return native._EXT
 
 
-def point_hierarchy_prefetch(inPts, inBatchIds, radiusList, batchSize, scaleInv, after=None):
+def point_hierarchy_prefetch(inPts, inBatchIds, radiusList, batchSize, scaleInv, after=None, features=None):
     """Boxes and level geometry of a point hierarchy (compute_aabb + point_hierarchy_levels) started on a stream of its own,
     issued by a helper thread of the PyTorch-ROCm extension (csrc/torch_ext.cpp: hierarchy_prefetch): the call returns at once
     with a future, `future.result()` -> (aabbMin, aabbMax, extent, levels) orders the calling stream behind the build. The
@@ -1023,7 +1023,11 @@ def point_hierarchy_prefetch(inPts, inBatchIds, radiusList, batchSize, scaleInv,
     elif after is not None and after is not False:
         _req(isinstance(after, torch.cuda.Event), op + ".prefetch: `after` is None, True or a torch.cuda.Event")
         mode, handle = 2, int(after.cuda_event)
-    return ext.hierarchy_prefetch(pts, bids, [float(r) for r in radiusList], int(batchSize), bool(scaleInv), pmode, mode, handle)
+    # features (optional): level 0's input feature rows -- rows without a gradient are gathered for every level on the
+    # hierarchy's own stream (the extension decides: short contiguous f32 / bf16 rows); the levels then carry a 5th tensor
+    feats = features if (features is not None and getattr(features, "is_cuda", False) and not features.requires_grad) else None
+    return ext.hierarchy_prefetch(pts, bids, [float(r) for r in radiusList], int(batchSize), bool(scaleInv), pmode, mode, handle,
+                                  feats)
 
 
 def point_hierarchy_levels(inPts, inBatchIds, aabbMin, aabbMax, radiusList, batchSize, scaleInv):

@@ -1049,6 +1049,11 @@ hipStream_t hier_stream() {
 struct HierFuture {
     Tensor pts, bids, mn, mx, sizes;
     std::vector<Tensor> ints, flts;  // per level: sampled batch ids | sampled indexs | transformed indexs   and   sampled points
+    // optional: the input feature rows of level 0 (no gradient, short rows) -- every level's rows are then gathered HERE,
+    // on the hierarchy's stream, once the level sizes are known (GetSampledFeatures, MCConvBuilder.py:112-116), instead
+    // of by one launch per level on the calling thread when the hierarchy is adopted
+    Tensor feats;
+    std::vector<Tensor> lfeats;      // per level: [ca x F] rows
     std::vector<double> radii;
     std::vector<int> ncs, hs;
     int B = 0, L = 0, cap = 0, pmode = 1;
@@ -1134,9 +1139,21 @@ struct HierFuture {
             if (!host.defined() || host.numel() < L + 1)
                 host = at::empty({L + 65}, at::TensorOptions().dtype(at::kInt).pinned_memory(true));
             hip_check(hipMemcpyAsync(host.data_ptr(), sz, (size_t)(L + 1) * sizeof(int), hipMemcpyDeviceToHost, ss), "hipMemcpyAsync");
-            hip_check(hipEventRecord(event, ss), "hipEventRecord");
+            if (!feats.defined()) hip_check(hipEventRecord(event, ss), "hipEventRecord");
             hip_check(hipStreamSynchronize(ss), "hipStreamSynchronize");
             hs.assign(host.data_ptr<int>(), host.data_ptr<int>() + L + 1);
+            if (feats.defined()) {
+                bool ok = true;
+                for (int l = 1; l <= L; ++l) ok = ok && hs[l] >= 0;
+                const int words = (int)(feats.size(1) * (int64_t)feats.element_size() / 4);
+                const float* src = (const float*)feats.data_ptr();
+                for (int l = 0; ok && l < L; ++l) {   // rows of level l + 1 = rows of level l at transformedIndexs
+                    check(mccnn_permute_gather(src, ints[l].data_ptr<int>() + 2 * ca, hs[l + 1], words,
+                                               (float*)lfeats[l].data_ptr(), (void*)ss), "permute_gather");
+                    src = (const float*)lfeats[l].data_ptr();
+                }
+                hip_check(hipEventRecord(event, ss), "hipEventRecord");
+            }
             if (mccnn::debug_int("hier_trace", 0)) {
                 std::string line = "hier job: cap " + std::to_string(cap) + " extent " + std::to_string(extent) + " nc";
                 for (int l = 0; l < L; ++l) line += " " + std::to_string(ncs[l]);
@@ -1173,6 +1190,7 @@ struct HierFuture {
             mx.record_stream(consumer);
             for (Tensor& t : ints) t.record_stream(consumer);
             for (Tensor& t : flts) t.record_stream(consumer);
+            for (Tensor& t : lfeats) t.record_stream(consumer);
         }
         std::vector<std::vector<Tensor>> out;
         bool ok = true;
@@ -1181,6 +1199,10 @@ struct HierFuture {
             const int64_t sN = hs[l + 1];
             out.push_back({flts[l].narrow(0, 0, 3 * sN).view({sN, 3}), ints[l].narrow(0, 0, sN).view({sN, 1}),
                            ints[l].narrow(0, ca, sN), ints[l].narrow(0, 2 * ca, sN)});
+            if (feats.defined()) {   // 5th entry: the level's feature rows
+                const int64_t F = feats.size(1);
+                out.back().push_back(lfeats[l].narrow(0, 0, sN * F).view({sN, F}));
+            }
         }
         return py::make_tuple(mn, mx, extent, out);
     }
@@ -1200,6 +1222,7 @@ bool hierarchy_owns(const std::shared_ptr<HierFuture>& f, const Tensor& t) {
     if (inside(f->pts) || inside(f->bids) || inside(f->mn) || inside(f->mx)) return true;
     for (const Tensor& o : f->ints) if (inside(o)) return true;
     for (const Tensor& o : f->flts) if (inside(o)) return true;
+    for (const Tensor& o : f->lfeats) if (inside(o)) return true;
     return false;
 }
 
@@ -1208,7 +1231,7 @@ bool hierarchy_owns(const std::shared_ptr<HierFuture>& f, const Tensor& t) {
 // 2 = behind `after_event` (a hipEvent_t: the upload's own stream recorded it).
 std::shared_ptr<HierFuture> hierarchy_prefetch(const Tensor& pts, const Tensor& bids, const std::vector<double>& radii,
                                                int64_t B, bool scale_inv, int64_t pmode, int64_t after_mode,
-                                               int64_t after_event) {
+                                               int64_t after_event, const c10::optional<Tensor>& feats) {
     check_dev(pts, at::kFloat, "points");
     check_dev(bids, at::kInt, "batch ids");
     const DevGuard device_guard((int)pts.device().index());
@@ -1234,6 +1257,18 @@ std::shared_ptr<HierFuture> hierarchy_prefetch(const Tensor& pts, const Tensor& 
         for (int l = 0; l < L; ++l) {
             f->ints.push_back(at::empty({3 * f->ca}, iopt));
             f->flts.push_back(at::empty({3 * f->ca}, pts.options()));
+        }
+        if (feats.has_value() && feats->defined()) {
+            const Tensor& ft = *feats;
+            // short rows without a gradient only (the input features of a network: ones, normals, colours): the level
+            // buffers are sized by the capacity
+            const int64_t row_bytes = ft.dim() == 2 ? ft.size(1) * (int64_t)ft.element_size() : 0;
+            if (ft.is_cuda() && ft.device() == pts.device() && ft.dim() == 2 && ft.size(0) == cap && ft.is_contiguous() &&
+                !ft.requires_grad() && row_bytes > 0 && row_bytes <= 256 && row_bytes % 4 == 0 &&
+                (ft.scalar_type() == at::kFloat || ft.scalar_type() == at::kBFloat16)) {
+                f->feats = ft;
+                for (int l = 0; l < L; ++l) f->lfeats.push_back(at::empty({f->ca * ft.size(1)}, ft.options()));
+            }
         }
     }
     f->alloc_stream = (void*)ss;
@@ -1313,7 +1348,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
         .def("done", [](HierFuture& f) { return f.done.load(std::memory_order_acquire) != 0; });
     mod.def("hierarchy_prefetch", &hierarchy_prefetch, py::arg("pts"), py::arg("bids"), py::arg("radii"), py::arg("B"),
             py::arg("scale_inv"), py::arg("pmode"), py::arg("after_mode") = 0, py::arg("after_event") = 0,
-            py::call_guard<py::gil_scoped_release>());
+            py::arg("feats") = py::none(), py::call_guard<py::gil_scoped_release>());
     mod.def("shutdown_helpers", [] { for (int k = 0; k < 3; ++k) Issuer::get(k).retire(); },
             py::call_guard<py::gil_scoped_release>());
     mod.def("wait_ns", [] { return (long long)g_wait_ns.load(std::memory_order_relaxed); });

@@ -174,3 +174,58 @@ def test_prefetched_hierarchy_equals_the_inline_one(mc, case):
     with pytest.raises(InvalidArgumentError):
         MB.PointHierarchy.prefetch(P, Bi, radii, B, rel, after="now")
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_prefetched_hierarchy_gathers_the_feature_rows(mc, dtype):
+    """PointHierarchy.prefetch(..., features=F): the feature rows of every level (GetSampledFeatures,
+    MCConvBuilder.py:112-116) are gathered with the hierarchy on its own stream. The constructor takes them when it is
+    handed the very same, unmodified tensor without a gradient -- bit-identical to the inline gathers -- and gathers
+    itself (differentiably) when the rows carry a gradient, are another tensor, or were modified in between."""
+    import torch
+    import mccnn_amd.MCConvBuilder as MB
+    from mccnn_amd import native
+    if not native.side_streams_available():
+        pytest.skip("PointHierarchy.prefetch() needs the torch extension")
+    pts, bids = make_cloud(2500, 4, 9, "clustered", True)
+    B, radii = 4, [0.1, 0.3, 0.9]
+    P, Bi = torch.from_numpy(pts).cuda(), torch.from_numpy(bids).cuda()
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    F = torch.from_numpy(np.random.default_rng(4).random((len(pts), 6), dtype=np.float32)).cuda().to(td)
+    ref = MB.PointHierarchy(P, F, Bi, radii, "PH", B, True)
+    launches = mc._lib.load().mccnn_debug_launch_count
+
+    def same(ph):
+        assert len(ph.features_) == len(ref.features_) == 4
+        for a, b in zip(ph.points_ + ph.batchIds_ + ph.features_ + ph.sampledIndexs_,
+                        ref.points_ + ref.batchIds_ + ref.features_ + ref.sampledIndexs_):
+            assert a.dtype == b.dtype and torch.equal(a, b)
+
+    # 1. the very tensor: no gather launch on the calling thread at adoption
+    h = MB.PointHierarchy.prefetch(P, Bi, radii, B, True, features=F)
+    assert h is not None
+    h.future.result()                      # (the helper thread is done: whatever is launched below is the constructor's)
+    l0 = launches()
+    ph = MB.PointHierarchy(P, F, Bi, radii, "PH", B, True, prefetched=h)
+    assert launches() == l0
+    torch.cuda.synchronize()
+    same(ph)
+    # 2. rows with a gradient: gathered by the constructor, and the gradient flows through every level
+    Fg = F.float().clone().requires_grad_(True)
+    h = MB.PointHierarchy.prefetch(P, Bi, radii, B, True, features=Fg)
+    ph = MB.PointHierarchy(P, Fg, Bi, radii, "PH", B, True, prefetched=h)
+    assert ph.features_[3].requires_grad
+    ph.features_[3].sum().backward()
+    assert float(Fg.grad.sum()) == ph.features_[3].numel()
+    # 3. another tensor / a tensor modified since the request: gathered by the constructor from what it is handed
+    h = MB.PointHierarchy.prefetch(P, Bi, radii, B, True, features=F)
+    F2 = (F.float() * 2).to(td)
+    ph = MB.PointHierarchy(P, F2, Bi, radii, "PH", B, True, prefetched=h)
+    assert torch.equal(ph.features_[1].float(), ref.features_[1].float() * 2)
+    Fm = F.clone()
+    h = MB.PointHierarchy.prefetch(P, Bi, radii, B, True, features=Fm)
+    h.future.result()
+    Fm.mul_(0)
+    ph = MB.PointHierarchy(P, Fm, Bi, radii, "PH", B, True, prefetched=h)
+    torch.cuda.synchronize()
+    assert float(ph.features_[2].float().abs().sum()) == 0.0
