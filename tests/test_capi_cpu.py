@@ -231,3 +231,15 @@ def test_debug_keys_one_table_and_unknown_keys_are_reported(tmp_path):
     subprocess.check_call([cxx, "-std=c++17", "-I", os.path.join(ROOT, "mccnn_amd", "csrc"), str(src), "-o", str(exe)])
     out = subprocess.run([str(exe)], env=dict(os.environ, MCCNN_DEBUG="small_off, plan_smal=8192 ,nw_lean=1"), capture_output=True, text=True)
     assert out.returncode == 0 and out.stderr.count("not known") == 1 and "plan_smal" in out.stderr
+
+
+def test_library_issues_no_memsets():
+    """Round 6: clears ride on kernels of the chain they belong to (csrc/common.h ClearSpan) -- a hipMemsetAsync is a launch
+    of its own (13-61 `fillBufferAligned` per step of the BASELINE configurations in round 5). None may come back."""
+    import glob
+    import re
+    bad = re.compile(r"\bhipMemset\w*\s*\(")
+    for f in sorted(glob.glob(os.path.join(ROOT, "mccnn_amd", "csrc", "*"))):
+        if os.path.isfile(f):
+            src = re.sub(r"//[^\n]*", "", open(f, errors="ignore").read())
+            assert not bad.search(src), f

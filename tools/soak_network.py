@@ -33,15 +33,20 @@ class Batch:
         c = cfg._replace(clouds=clouds, points=points, seed=seed)
         p, b, self.B = config_points(c)
         self.P, self.Bi = torch.from_numpy(p).to(dev), torch.from_numpy(b).to(dev)
-        self.F0 = torch.ones((len(p), 1), device=dev)
+        # input feature rows that differ from point to point: the level rows gathered WITH a prefetched hierarchy
+        # (PointHierarchy.prefetch(features=), SOAK_FEATS=0 switches it off) are compared with the inline gathers below
+        gF = torch.Generator(device="cpu").manual_seed(seed)
+        self.F0 = torch.rand((len(p), 3), generator=gF).to(dev)
         self.feats = self.ogs = None
+        self.ref_level_feats = None
 
     def hierarchy(self, prefetched=None):
         return PointHierarchy(self.P, self.F0, self.Bi, list(cfg.hierarchy), "PH", self.B, cfg.relative, prefetched=prefetched)
 
     def request(self):
         return PointHierarchy.prefetch(self.P, self.Bi, list(cfg.hierarchy), self.B, cfg.relative,
-                                       after=(True if os.environ.get("SOAK_HIER_AFTER", "1") == "1" else None))
+                                       after=(True if os.environ.get("SOAK_HIER_AFTER", "1") == "1" else None),
+                                       features=(self.F0 if os.environ.get("SOAK_FEATS", "1") == "1" else None))
 
     def rows(self, ph):
         if self.feats is None:
@@ -61,6 +66,12 @@ def step(builder, batch, prefetched=None, ready=None, then=None):
         then()
     ph = ready if ready is not None else batch.hierarchy(prefetched)
     batch.rows(ph)
+    if batch.ref_level_feats is None:     # (the reference pass: built inline, nothing prefetched)
+        batch.ref_level_feats = [f.detach().clone() for f in ph.features_]
+    else:
+        global feat_bad
+        for f, r in zip(ph.features_, batch.ref_level_feats):
+            feat_bad += (f.detach() != r).sum()
     use = list(range(len(cfg.convs)))
     if VARY_GRAPH and vrng.random() < 0.4:      # a step whose graph differs: some layers missing, the rest in another order
         use = [ci for ci in use if vrng.random() < 0.7]
@@ -77,6 +88,7 @@ def step(builder, batch, prefetched=None, ready=None, then=None):
     return outs, grads
 
 
+feat_bad = torch.zeros((), dtype=torch.int64, device=dev)
 if cfg.cloud_kind == "room":
     SHAPES = ((1, 100000, 20180601), (1, 60000, 7), (2, 40000, 11), (1, 80000, 19), (1, 30000, 23))
 else:
@@ -166,7 +178,7 @@ if TRACE is not None:
             int(TRACE[st_, ci])))
 dt = time.perf_counter() - t0
 print("soak_network%s: %d steps in %.1f s (%.2f ms/step), forward mismatches %d, worst relative gradient deviation %.2e, "
-      "memory now %.0f MB (start %.0f), peak %.0f MB" % (" (deep)" if DEEP else "", STEPS, dt, dt / STEPS * 1e3, int(bad.item()), float(worst.item()),
-                                                        torch.cuda.memory_allocated() / 1e6, m0 / 1e6,
-                                                        torch.cuda.max_memory_allocated() / 1e6))
-assert int(bad.item()) == 0 and float(worst.item()) < 1e-4
+      "memory now %.0f MB (start %.0f), peak %.0f MB; level feature rows: %d mismatches" % (
+          " (deep)" if DEEP else "", STEPS, dt, dt / STEPS * 1e3, int(bad.item()), float(worst.item()),
+          torch.cuda.memory_allocated() / 1e6, m0 / 1e6, torch.cuda.max_memory_allocated() / 1e6, int(feat_bad.item())))
+assert int(bad.item()) == 0 and float(worst.item()) < 1e-4 and int(feat_bad.item()) == 0
