@@ -389,3 +389,80 @@ def test_use_pdf_false_against_the_oracle(mc, oracle, native):
     for k in cbc.cacheNeighs_:
         (s0, p0), (s1, p1) = cb.cacheNeighs_[k], cbc.cacheNeighs_[k]
         assert np.array_equal(s0.cpu().numpy(), s1.numpy()) and np.array_equal(p0.cpu().numpy(), p1.numpy()), k
+
+
+@pytest.mark.parametrize("n_per,B,radius,relative,empty", [
+    (2048, 1, 0.11, True, False),      # exactly the single-workgroup limit (grid_small_all)
+    (2049, 1, 0.11, True, False),      # one past it: keys_hist / scan / park_ids / rank_move
+    (700, 5, 0.3, True, True),         # clouds WITHOUT points in the batch (their cells stay (0, 0)); few cells, LDS histogram
+    (4096, 1, 0.05, True, False),      # 8 000 cells, 4 096 centres: the in-fill prefix sum at its limit
+    (4097, 1, 0.05, True, False),      # ... and one past it (stand-alone scan)
+    (1500, 3, 0.07, False, False),     # absolute radius, whole-batch box
+    (33000, 1, 0.02, True, False),     # aabb in three launches, 125 000 cells (multi-tile chained scan over the cells)
+])
+def test_fused_grid_and_search_chain_equals_the_ops(mc, oracle, n_per, B, radius, relative, empty):
+    """Round 6's launch chain -- grid build as keys_hist / scan / park_ids / rank_move (cell table read off the prefix sum) or
+    one workgroup, the visiting order, count -> (scan ->) fill, aabb in one launch -- through the native executor's geometry
+    against the op-by-op surface AND the oracle: sorted points, batch ids, cell table, permutation, startIdx, packed: bit-exact."""
+    import torch
+    from mccnn_amd import native
+    pts, bids = make_cloud(n_per, B, 21, "clustered", True)
+    if empty:
+        keep = (bids[:, 0] != 1) & (bids[:, 0] != 3)      # clouds 1 and 3 have no points
+        pts, bids = np.ascontiguousarray(pts[keep]), np.ascontiguousarray(bids[keep])
+    if not relative:
+        pts = pts * 2.0
+    P, Bi = _t(pts), _t(bids)
+    mn, mx = mc.compute_aabb(P, Bi, B, relative)
+    omn, omx = oracle.compute_aabb(pts, bids, B, relative)
+    assert np.array_equal(mn.cpu().numpy(), omn) and np.array_equal(mx.cpu().numpy(), omx)
+    # the op surface
+    keys, idx = mc.sort_points_step1(P, Bi, mn, mx, B, radius, relative)
+    sP, sB, _sF, cells = mc.sort_points_step2(P, Bi, torch.ones((len(pts), 1), device="cuda"), keys, idx, mn, mx, B, radius, relative)
+    st, pk = mc.find_neighbors(P, Bi, sP, cells, mn, mx, radius, B, relative)
+    # the native geometry (one library call)
+    nc = mc._num_cells(mn, mx, B, radius, relative)
+    geo = native.build_geometry(P, Bi, P, Bi, mn, mx, B, nc, radius, relative, 0.25, True)
+    gP, gB, gC, gI, gInv = geo.grid()
+    gst, gpk = geo.neighbors()
+    torch.cuda.synchronize()
+    assert torch.equal(gP, sP) and torch.equal(gB.reshape(-1), sB.reshape(-1)) and torch.equal(gC, cells) and torch.equal(gI, idx)
+    assert torch.equal(gInv[idx.long()].cpu(), torch.arange(len(pts), dtype=torch.int32))
+    assert torch.equal(gst.reshape(-1), st.reshape(-1)) and torch.equal(gpk, pk)
+    # ... and the oracle
+    ok_, oi_ = oracle.sort_points_step1(pts, bids, omn, omx, B, radius, relative)
+    osP, osB, _f, ocl = oracle.sort_points_step2(pts, bids, np.zeros((len(pts), 1), np.float32), ok_, oi_, omn, omx, B, radius, relative)
+    ost, opk = oracle.find_neighbors(pts, bids, osP, ocl, omn, omx, radius, B, relative)
+    assert np.array_equal(gI.cpu().numpy(), oi_) and np.array_equal(gC.cpu().numpy().reshape(-1), ocl.reshape(-1))
+    assert np.array_equal(gst.cpu().numpy().reshape(-1), ost.reshape(-1)) and np.array_equal(gpk.cpu().numpy(), opk)
+    if empty:
+        c = gC.cpu().numpy()
+        assert not c[1].any() and not c[3].any()
+
+
+def test_foreign_centres_get_a_visiting_order_without_changing_the_list(mc):
+    """Centres that are not the gridded points (>= 16 384 of them: pooling / up-sampling lists) are searched in a
+    cell-coherent order of their own -- keys_hist / scan / park_ids, arrival order inside a cell (round 6: no stable sort).
+    The order is speed only: startIdx / packed equal the op surface's, whatever the arrival order was (two builds)."""
+    import torch
+    from mccnn_amd import native
+    pts, bids = make_cloud(9000, 4, 33, "clustered", True)
+    B, radius = 4, 0.08
+    rng = np.random.default_rng(8)
+    pick = np.sort(rng.choice(len(pts), 20000, replace=False))   # (clouds stay contiguous)
+    cen = np.ascontiguousarray(pts[pick] + rng.normal(0, 1e-3, (len(pick), 3)).astype(np.float32))
+    cb = np.ascontiguousarray(bids[pick])
+    perm = np.concatenate([rng.permutation(np.nonzero(cb[:, 0] == b)[0]) for b in range(B)])   # scattered inside each cloud
+    cen, cb = np.ascontiguousarray(cen[perm]), np.ascontiguousarray(cb[perm])
+    P, Bi, Cn, Cb = _t(pts), _t(bids), _t(cen), _t(cb)
+    mn, mx = mc.compute_aabb(P, Bi, B, True)
+    keys, idx = mc.sort_points_step1(P, Bi, mn, mx, B, radius, True)
+    sP, sB, _sF, cells = mc.sort_points_step2(P, Bi, torch.ones((len(pts), 1), device="cuda"), keys, idx, mn, mx, B, radius, True)
+    st, pk = mc.find_neighbors(Cn, Cb, sP, cells, mn, mx, radius, B, True)
+    nc = mc._num_cells(mn, mx, B, radius, True)
+    for _ in range(2):
+        geo = native.build_geometry(P, Bi, Cn, Cb, mn, mx, B, nc, radius, True, 0.25, True)
+        gst, gpk = geo.neighbors()
+        torch.cuda.synchronize()
+        assert torch.equal(gst.reshape(-1), st.reshape(-1)) and torch.equal(gpk, pk)
+    assert pk.shape[0] > 0
