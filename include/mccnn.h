@@ -448,6 +448,24 @@ int mccnn_geometry_build(mccnn_geometry_t* g, const float* pts, const int* batch
                          int batch_size, int num_cells, float radius, int scale_inv, float window, int use_pdf,
                          int e_capacity, const mccnn_geometry_t* grid_from, void* buffer, size_t buffer_bytes,
                          int* total_host, mccnn_stream_t stream);
+
+/* Several geometries of a network step in ONE call (extension): one launch per kernel KIND over all of them -- head clear,
+ * keys + histogram, prefix sums of the cell counters, park, rank + move + cell tables, count pass, prefix sums of the counts,
+ * fill pass, KDE: nine launches whatever `count` is (per geometry the chain of mccnn_geometry_build is nine as well) -- with
+ * results identical to mccnn_geometry_build bit for bit. A request that shares the grid of another request names that
+ * request's geometry in grid_from and comes AFTER it. */
+typedef struct mccnn_geometry_request {
+    mccnn_geometry_t* geometry;
+    const float* pts; const int* batch_ids; int n;
+    const float* centres; const int* centre_batch_ids; int m;
+    const float* aabb_min; const float* aabb_max;
+    int batch_size, num_cells;
+    float radius; int scale_inv; float window; int use_pdf; int e_capacity;
+    const mccnn_geometry_t* grid_from;
+    void* buffer; size_t buffer_bytes;
+    int* total_host;
+} mccnn_geometry_request;
+int mccnn_geometry_build_batch(const mccnn_geometry_request* requests, int count, mccnn_stream_t stream);
 /* E, or -1 while the count pass has not retired (wait_us: 0 = look once, < 0 = wait, > 0 = wait at most that long). */
 int mccnn_geometry_edges(mccnn_geometry_t* g, int wait_us);
 /* out[0..7]: device addresses of sortPts [n,3], sortBatchs [n], cellIndexs [B,nc,nc,nc,2], index_new_pos [n], its

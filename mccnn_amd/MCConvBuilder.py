@@ -650,6 +650,16 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         started = 0
         name, levels = pointHierarchy.hierarchyName_, len(pointHierarchy.points_)
         pieces = _env.debug("plan_prefetch", True)
+        from . import native as _native
+        _native.begin_batch()   # the step's geometries go out together: one launch per kernel kind over all of them
+        try:
+            started = self.__prefetch_step_entries__(pointHierarchy, name, levels, pieces)
+        finally:
+            _native.end_batch()
+        return started
+
+    def __prefetch_step_entries__(self, pointHierarchy, name, levels, pieces):
+        started = 0
         for ent in self.geoPlan_:
             hname, inLevel, outLevel, radius, window, rel, usePDF, have = ent[:8]
             if hname != name or inLevel >= levels or outLevel >= levels:

@@ -14,7 +14,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, os.environ.get("MCCNN_LIB_NAME", "libmccnn_hip.so"))  # override only for A/B experiments
 SOURCES = ["api_misc.hip", "scan.hip", "grid.hip", "neighbors.hip", "poisson.hip", "conv.hip", "conv_f1.hip", "conv_rows.hip", "exec.hip"]
-HEADERS = ["common.h", "chain.h", "conv_mfma.h", "debug_opts.h"]
+HEADERS = ["common.h", "chain.h", "batch.h", "conv_mfma.h", "debug_opts.h"]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # bit-exact geometry: no FMA contraction, correctly rounded f32 divide / sqrt (see csrc/common.h)

@@ -41,6 +41,20 @@ int launch_zero_words(void* p, size_t words, hipStream_t s) {
     MCCNN_LAUNCHED();
     return 0;
 }
+// ... of a whole batch of geometries (mccnn_geometry_build_batch): every span in one launch
+__global__ __launch_bounds__(256) void clear_spans_batch(SpanBatch sb) {
+    for (int k = 0; k < sb.count; ++k) clear_span_dev(sb.sp[k]);
+}
+int launch_clear_batch(const SpanBatch& sb, hipStream_t s) {
+    unsigned long long most = 0;
+    for (int k = 0; k < sb.count; ++k) most = sb.sp[k].n16 > most ? sb.sp[k].n16 : most;
+    if (most == 0) return 0;
+    long long blocks = (long long)((most + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    clear_spans_batch<<<(int)blocks, 256, 0, s>>>(sb);
+    MCCNN_LAUNCHED();
+    return 0;
+}
 int launch_clear_spans(ClearSpan a, ClearSpan b, ClearSpan c, hipStream_t s) {
     const unsigned long long most = a.n16 > b.n16 ? (a.n16 > c.n16 ? a.n16 : c.n16) : (b.n16 > c.n16 ? b.n16 : c.n16);
     if (most == 0) return 0;

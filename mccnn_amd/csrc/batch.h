@@ -1,0 +1,54 @@
+// Batch form of a step's geometries (exec.hip: mccnn_geometry_build_batch): ONE launch per kernel kind over up to
+// MCCNN_BATCH_MAX geometries. The per-geometry arguments of every kind travel by value in the kernel arguments (BatchBlocks,
+// ScanBatch, SpanBatch: common.h); kernels and item builders live next to their single forms (grid.hip, neighbors.hip, scan.hip).
+#pragma once
+#include "common.h"
+
+namespace mccnn {
+
+// one counting sort: the grid build of a geometry, or the visiting order of its foreign centres (newIdx == nullptr)
+struct GridItem {
+    const float* pts; const int* bids; const float* mn; const float* mx;
+    int* keys; int* cnt; int* arrival; int* start; int* slot;
+    int* newIdx; float* oPts; int* oBids; int* inv; int2* cells;
+    int n, B, nc, C, ldsHist;
+};
+struct GridBatch { GridItem it[MCCNN_BATCH_MAX]; };
+
+// one neighbour search (count pass / fill pass)
+struct NeighItem {
+    const float* centres; const int* cb; const float* pts; const int* cells; const float* mn; const float* mx; const int* order;
+    int* cnt; unsigned long long* masks; int* startIdx; int* packed; unsigned long long* zeroWords;
+    int m, B, nc, scaleInv, capacity, G, numZero;
+    float radius, Tabs;
+};
+struct NeighBatch { NeighItem it[MCCNN_BATCH_MAX]; };
+
+// one kernel-density estimate
+struct PdfItem {
+    const float* pts; const int* bids; const int2* packed; const int* startIdx; const float* mn; const float* mx; float* pdfs;
+    const int* eDev;
+    int m, e, B, scaleInv, rowsPerWave;
+    float window, radius;
+};
+struct PdfBatch { PdfItem it[MCCNN_BATCH_MAX]; };
+
+bool grid_batch_eligible(int n, int batch_size, int num_cells);
+int grid_batch_item(GridItem& g, ScanItem& sc, ClearSpan& head, const float* pts, const int* batch_ids, const float* aabb_min,
+                    const float* aabb_max, int n, int batch_size, int num_cells, int* new_idx, float* out_pts,
+                    int* out_batch_ids, int* cell_indexs, int* inv_idx, void* ws, size_t ws_bytes);
+int order_batch_item(GridItem& g, ScanItem& sc, ClearSpan& head, const float* pts, const int* batch_ids, const float* aabb_min,
+                     const float* aabb_max, int m, int batch_size, int num_cells, int* order, void* ws, size_t ws_bytes);
+int launch_grid_batch_phase(const GridBatch& gb, int count, int phase, hipStream_t s);   // 0 keys + histogram, 1 park, 2 rank + move + cells
+bool neigh_batch_eligible(int m, int n);
+int neigh_batch_item(NeighItem& it, ScanItem& sc, const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
+                     int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max, int batch_size, int num_cells,
+                     float radius, int scale_inv, const int* order, int* start_idx, int e_capacity, int* packed, int* total_dev,
+                     int* total_host, void* ws, size_t ws_bytes);
+int launch_neigh_batch(const NeighBatch& nbt, int count, int mode, hipStream_t s);        // 0 count, 1 fill
+void pdf_batch_item(PdfItem& it, const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx, int m, const int* packed,
+                    int e_capacity, const int* e_dev, const float* aabb_min, const float* aabb_max, int batch_size, float window,
+                    float radius, int scale_inv, float* pdfs);
+int launch_pdf_batch(const PdfBatch& pb, int count, hipStream_t s);
+
+}  // namespace mccnn

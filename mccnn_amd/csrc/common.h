@@ -88,6 +88,37 @@ int launch_clear_spans(ClearSpan a, ClearSpan b, ClearSpan c, hipStream_t s);
 int launch_zero_words(void* p, size_t words, hipStream_t s);
 int launch_fill_words(void* p, size_t words, unsigned v, hipStream_t s);   // (usePDF = False: a tensor of ones)
 
+// ---------------------------------------------------------------------------------------
+// One launch per kernel KIND over all geometries of a step (exec.hip: mccnn_geometry_build_batch). The per-geometry
+// arguments of a kind travel BY VALUE in the kernel arguments (<= MCCNN_BATCH_MAX items, < 4 KB), a workgroup finds its
+// item from the prefix of the items' workgroup counts.
+#define MCCNN_BATCH_MAX 16
+struct BatchBlocks {
+    int first[MCCNN_BATCH_MAX + 1];   // first[k] = first workgroup of item k, first[count] = grid size
+    int count;
+};
+__device__ __forceinline__ int batch_item(const BatchBlocks& b, int blk, int& local, int& blocks) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < MCCNN_BATCH_MAX; ++i) k += (i < b.count && blk >= b.first[i]) ? 1 : 0;
+    local = blk - b.first[k];
+    blocks = b.first[k + 1] - b.first[k];
+    return k;
+}
+// generic single-pass prefix sum item (scan.hip: scan_chained_batch)
+struct ScanItem {
+    const int* in;
+    int* out;
+    unsigned long long* status;   // tiles + 1 words, zero on entry (the head clear of the batch)
+    int* total;
+    int* total2;
+    int n, tiles;
+};
+struct ScanBatch { ScanItem it[MCCNN_BATCH_MAX]; };
+int launch_scan_batch(const ScanBatch& sb, int count, hipStream_t s);   // scan.hip
+struct SpanBatch { ClearSpan sp[3 * MCCNN_BATCH_MAX]; int count; };
+int launch_clear_batch(const SpanBatch& sb, hipStream_t s);             // api_misc.hip
+
 // Exclusive prefix sum of n int32 (out may alias in). If total != nullptr the grand
 // total is written there. ws must hold scan_workspace_bytes(n). Defined in scan.hip.
 // Up to 2 M elements the scan is ONE launch (decoupled look-back); its status words are the first

@@ -10,7 +10,7 @@
 // No kernels live here: every launch goes through the op-level entry points of this library (mccnn.h), so the results are
 // those of the op-by-op chain bit for bit. The library still allocates no device memory: buffers come from the caller,
 // sized by the *_bytes queries.
-#include "common.h"
+#include "batch.h"
 
 #include <chrono>
 #include <cstdlib>
@@ -71,7 +71,7 @@ struct mccnn_geometry {
     size_t bytes = 0;
     float* s_pts = nullptr;
     int *s_bids = nullptr, *cells = nullptr, *new_idx = nullptr, *inv_idx = nullptr;
-    int *start = nullptr, *packed = nullptr, *total_dev = nullptr, *order = nullptr;
+    int *start = nullptr, *packed = nullptr, *total_dev = nullptr, *order = nullptr, *order_buf = nullptr;
     float* pdfs = nullptr;
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -299,16 +299,20 @@ size_t mccnn_geometry_bytes(int n, int m, int batch_size, int num_cells, int e_c
     return geo_layout(n, m, batch_size, num_cells, e_capacity, with_grid != 0).total_bytes;
 }
 
-int mccnn_geometry_build(mccnn_geometry_t* g, const float* pts, const int* batch_ids, int n, const float* centres,
-                         const int* centre_batch_ids, int m, const float* aabb_min, const float* aabb_max, int batch_size,
-                         int num_cells, float radius, int scale_inv, float window, int use_pdf, int e_capacity,
-                         const mccnn_geometry_t* grid_from, void* buffer, size_t buffer_bytes, int* total_host,
-                         mccnn_stream_t stream) {
+}  // extern "C"
+namespace {
+// Argument checks + the struct of a geometry over the caller's buffer (nothing is launched). `in_batch`: the grid owner may
+// be a geometry set up earlier in the same batch (not built yet).
+int geometry_setup(mccnn_geometry_t* g, const float* pts, const int* batch_ids, int n, const float* centres,
+                   const int* centre_batch_ids, int m, const float* aabb_min, const float* aabb_max, int batch_size, int num_cells,
+                   float radius, int scale_inv, float window, int use_pdf, int e_capacity, const mccnn_geometry_t* grid_from,
+                   void* buffer, size_t buffer_bytes, int* total_host, bool in_batch) {
     if (!g || !pts || !batch_ids || !centres || !centre_batch_ids || !aabb_min || !aabb_max || !buffer || !total_host)
         return MCCNN_E_BADARG;
     if (n <= 0 || m <= 0 || batch_size <= 0 || num_cells <= 0 || !(radius > 0.f) || e_capacity <= 0) return MCCNN_E_BADARG;
     if (use_pdf && !(window > 0.f)) return MCCNN_E_BADARG;
-    if (grid_from && (grid_from->n != n || grid_from->nc != num_cells || grid_from->B != batch_size || !grid_owner(grid_from)->built))
+    if (grid_from && (grid_from->n != n || grid_from->nc != num_cells || grid_from->B != batch_size ||
+                      !(grid_owner(grid_from)->built || (in_batch && grid_owner(grid_from)->s_pts))))
         return MCCNN_E_BADARG;
     const bool with_grid = grid_from == nullptr;
     const GeoLayout L = geo_layout(n, m, batch_size, num_cells, e_capacity, with_grid);
@@ -329,56 +333,195 @@ int mccnn_geometry_build(mccnn_geometry_t* g, const float* pts, const int* batch
     }
     g->start = (int*)(b + L.start); g->packed = (int*)(b + L.packed); g->pdfs = (float*)(b + L.pdfs);
     g->total_dev = (int*)(b + L.total);
+    g->order_buf = (int*)(b + L.order);
     g->ws = b + L.ws; g->ws_bytes = L.ws_bytes;
     g->e_cap = e_capacity; g->e = -1; g->total_host = total_host;
     *total_host = -1;  // armed: the prefix sum of the count pass overwrites it
-    hipStream_t s = (hipStream_t)stream;
-    int rc;
+    return 0;
+}
+
+// the two workspaces that are alive side by side at the head of a geometry's chain: grid build | visiting order
+struct HeadWs { char* gws; size_t gwb; char* ows; size_t owb; bool with_grid, own_order; };
+int head_ws(const mccnn_geometry_t* g, HeadWs& h) {
+    h.with_grid = g->grid_of == nullptr;
     // visiting order of the centres (speed only): the grid's own order when the centres are the gridded points; for the
     // points of another level (pooling / up-sampling: Poisson samples arrive phase by phase, all over the scene) a
     // cell-coherent order of their own in THIS grid -- small lists are searched in ~10 us either way
-    const bool own_order = !g->same_level && m >= MCCNN_ORDER_MIN_M;
+    h.own_order = !g->same_level && g->m >= MCCNN_ORDER_MIN_M;
     Arena ha(g->ws, g->ws_bytes);
-    char* gws = nullptr;
-    char* ows = nullptr;
-    const size_t gwb = with_grid ? al(mccnn_build_grid_workspace_bytes(n, batch_size, num_cells)) : 0;
-    const size_t owb = own_order ? al(visiting_order_workspace_bytes(m, batch_size, num_cells)) : 0;
-    if (with_grid && !(gws = ha.take<char>(gwb))) return MCCNN_E_WORKSPACE;
-    if (own_order && !(ows = ha.take<char>(owb))) return MCCNN_E_WORKSPACE;
+    h.gws = h.ows = nullptr;
+    h.gwb = h.with_grid ? al(mccnn_build_grid_workspace_bytes(g->n, g->B, g->nc)) : 0;
+    h.owb = h.own_order ? al(visiting_order_workspace_bytes(g->m, g->B, g->nc)) : 0;
+    if (h.with_grid && !(h.gws = ha.take<char>(h.gwb))) return MCCNN_E_WORKSPACE;
+    if (h.own_order && !(h.ows = ha.take<char>(h.owb))) return MCCNN_E_WORKSPACE;
+    return 0;
+}
+
+// the chain of ONE geometry: [head clear] grid build (4 launches) [visiting order (3)] count (scan) fill KDE
+int geometry_issue_single(mccnn_geometry_t* g, mccnn_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int n = g->n, m = g->m, batch_size = g->B, num_cells = g->nc;
+    HeadWs h;
+    int rc = head_ws(g, h);
+    if (rc) return rc;
     // ONE clear at the head of the chain (histogram counters + scan status words of both counting sorts); everything
     // later in the chain is cleared by a kernel of the chain
-    rc = launch_clear_spans(with_grid ? grid_head_span(n, batch_size, num_cells, gws, gwb) : no_span(),
-                            own_order ? visiting_order_head_span(m, batch_size, num_cells, ows, owb) : no_span(), no_span(), s);
+    rc = launch_clear_spans(h.with_grid ? grid_head_span(n, batch_size, num_cells, h.gws, h.gwb) : no_span(),
+                            h.own_order ? visiting_order_head_span(m, batch_size, num_cells, h.ows, h.owb) : no_span(), no_span(), s);
     if (rc) return rc;
-    if (with_grid) {
-        rc = build_grid_fused(pts, batch_ids, aabb_min, aabb_max, n, batch_size, num_cells, g->new_idx, g->s_pts, g->s_bids, g->cells,
-                              g->inv_idx, gws, gwb, s, nullptr, true, no_span(), no_span());
+    if (h.with_grid) {
+        rc = build_grid_fused(g->pts, g->bids, g->mn, g->mx, n, batch_size, num_cells, g->new_idx, g->s_pts, g->s_bids, g->cells,
+                              g->inv_idx, h.gws, h.gwb, s, nullptr, true, no_span(), no_span());
         if (rc) return rc;
     }
     const mccnn_geometry* go = grid_owner(g);
     const int* order = nullptr;
     if (g->same_level) {
         order = go->inv_idx;
-    } else if (own_order) {
-        g->order = (int*)(b + L.order);
-        rc = visiting_order(centres, centre_batch_ids, aabb_min, aabb_max, m, batch_size, num_cells, g->order, ows, owb, s, true);
+    } else if (h.own_order) {
+        g->order = g->order_buf;
+        rc = visiting_order(g->centres, g->cbids, g->mn, g->mx, m, batch_size, num_cells, g->order, h.ows, h.owb, s, true);
         if (rc) return rc;
         order = g->order;
     }
-    rc = find_neighbors_chain(centres, centre_batch_ids, m, go->s_pts, n, go->cells, aabb_min, aabb_max, batch_size, num_cells,
-                              radius, g->scale_inv, order, g->start, e_capacity, g->packed, g->total_dev, total_host, g->ws,
-                              g->ws_bytes, stream);
+    rc = find_neighbors_chain(g->centres, g->cbids, m, go->s_pts, n, go->cells, g->mn, g->mx, batch_size, num_cells, g->radius,
+                              g->scale_inv, order, g->start, g->e_cap, g->packed, g->total_dev, const_cast<int*>((volatile int*)g->total_host),
+                              g->ws, g->ws_bytes, stream);
     if (rc) return rc;
-    if (use_pdf) {
-        rc = mccnn_compute_pdf_dn(go->s_pts, go->s_bids, g->start, m, g->packed, e_capacity, g->total_dev, aabb_min, aabb_max,
-                                  batch_size, window, radius, g->scale_inv, g->pdfs, g->ws, g->ws_bytes, stream);
+    if (g->use_pdf) {
+        rc = mccnn_compute_pdf_dn(go->s_pts, go->s_bids, g->start, m, g->packed, g->e_cap, g->total_dev, g->mn, g->mx, batch_size,
+                                  g->window, g->radius, g->scale_inv, g->pdfs, g->ws, g->ws_bytes, stream);
         if (rc) return rc;
     } else {  // MCConvBuilder.py:388-390: a tensor of ones
-        rc = launch_fill_words(g->pdfs, (size_t)e_capacity, 0x3f800000u, s);
+        rc = launch_fill_words(g->pdfs, (size_t)g->e_cap, 0x3f800000u, s);
         if (rc) return rc;
     }
     g->built = true;
     return 0;
+}
+
+// ONE launch per kernel kind over a chunk of <= MCCNN_BATCH_MAX geometries (and <= MCCNN_BATCH_MAX counting sorts): head
+// clear, keys + histogram, prefix sums of the cell counters, park, rank + move + cell tables, count pass, prefix sums of
+// the counts, fill pass, KDE -- nine launches whatever the number of geometries (a step of BASELINE cfg4 has fourteen).
+int geometry_issue_chunk(mccnn_geometry_t* const* gs, int count, mccnn_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    GridBatch gridB;
+    ScanBatch scanG, scanN;
+    NeighBatch neighB;
+    PdfBatch pdfB;
+    SpanBatch spans;
+    spans.count = 0;
+    int nGrid = 0, nPdf = 0;
+    int rc;
+    for (int k = 0; k < count; ++k) {
+        mccnn_geometry_t* g = gs[k];
+        HeadWs h;
+        rc = head_ws(g, h);
+        if (rc) return rc;
+        if (h.with_grid) {
+            ClearSpan head;
+            rc = grid_batch_item(gridB.it[nGrid], scanG.it[nGrid], head, g->pts, g->bids, g->mn, g->mx, g->n, g->B, g->nc, g->new_idx,
+                                 g->s_pts, g->s_bids, g->cells, g->inv_idx, h.gws, h.gwb);
+            if (rc) return rc;
+            spans.sp[spans.count++] = head;
+            ++nGrid;
+        }
+        if (h.own_order) {
+            ClearSpan head;
+            g->order = g->order_buf;
+            rc = order_batch_item(gridB.it[nGrid], scanG.it[nGrid], head, g->centres, g->cbids, g->mn, g->mx, g->m, g->B, g->nc, g->order,
+                                  h.ows, h.owb);
+            if (rc) return rc;
+            spans.sp[spans.count++] = head;
+            ++nGrid;
+        }
+    }
+    rc = launch_clear_batch(spans, s);
+    if (rc) return rc;
+    if (nGrid) {
+        if ((rc = launch_grid_batch_phase(gridB, nGrid, 0, s))) return rc;
+        if ((rc = launch_scan_batch(scanG, nGrid, s))) return rc;
+        if ((rc = launch_grid_batch_phase(gridB, nGrid, 1, s))) return rc;
+        if ((rc = launch_grid_batch_phase(gridB, nGrid, 2, s))) return rc;
+    }
+    for (int k = 0; k < count; ++k) {
+        mccnn_geometry_t* g = gs[k];
+        const mccnn_geometry* go = grid_owner(g);
+        const int* order = g->same_level ? go->inv_idx : g->order;
+        rc = neigh_batch_item(neighB.it[k], scanN.it[k], g->centres, g->cbids, g->m, go->s_pts, g->n, go->cells, g->mn, g->mx, g->B, g->nc,
+                              g->radius, g->scale_inv, order, g->start, g->e_cap, g->packed, g->total_dev,
+                              const_cast<int*>((volatile int*)g->total_host), g->ws, g->ws_bytes);
+        if (rc) return rc;
+        if (g->use_pdf)
+            pdf_batch_item(pdfB.it[nPdf++], go->s_pts, go->s_bids, g->start, g->m, g->packed, g->e_cap, g->total_dev, g->mn, g->mx, g->B,
+                           g->window, g->radius, g->scale_inv, g->pdfs);
+    }
+    if ((rc = launch_neigh_batch(neighB, count, 0, s))) return rc;
+    if ((rc = launch_scan_batch(scanN, count, s))) return rc;
+    if ((rc = launch_neigh_batch(neighB, count, 1, s))) return rc;
+    if (nPdf && (rc = launch_pdf_batch(pdfB, nPdf, s))) return rc;
+    for (int k = 0; k < count; ++k) {
+        mccnn_geometry_t* g = gs[k];
+        if (!g->use_pdf) {  // MCConvBuilder.py:388-390: a tensor of ones
+            rc = launch_fill_words(g->pdfs, (size_t)g->e_cap, 0x3f800000u, s);
+            if (rc) return rc;
+        }
+        g->built = true;
+    }
+    return 0;
+}
+}  // namespace
+extern "C" {
+
+int mccnn_geometry_build(mccnn_geometry_t* g, const float* pts, const int* batch_ids, int n, const float* centres,
+                         const int* centre_batch_ids, int m, const float* aabb_min, const float* aabb_max, int batch_size,
+                         int num_cells, float radius, int scale_inv, float window, int use_pdf, int e_capacity,
+                         const mccnn_geometry_t* grid_from, void* buffer, size_t buffer_bytes, int* total_host,
+                         mccnn_stream_t stream) {
+    int rc = geometry_setup(g, pts, batch_ids, n, centres, centre_batch_ids, m, aabb_min, aabb_max, batch_size, num_cells, radius,
+                            scale_inv, window, use_pdf, e_capacity, grid_from, buffer, buffer_bytes, total_host, false);
+    if (rc) return rc;
+    return geometry_issue_single(g, stream);
+}
+
+// Several geometries of a step at once (a grid owner BEFORE the geometries that share its grid): one launch per kernel
+// kind over chunks of the requests; a geometry too large for the batch form (> 2 M cells or centres) takes its own chain.
+int mccnn_geometry_build_batch(const mccnn_geometry_request* req, int count, mccnn_stream_t stream) {
+    if (!req || count < 0) return MCCNN_E_BADARG;
+    for (int k = 0; k < count; ++k) {
+        const mccnn_geometry_request& r = req[k];
+        int rc = geometry_setup(r.geometry, r.pts, r.batch_ids, r.n, r.centres, r.centre_batch_ids, r.m, r.aabb_min, r.aabb_max,
+                                r.batch_size, r.num_cells, r.radius, r.scale_inv, r.window, r.use_pdf, r.e_capacity, r.grid_from,
+                                r.buffer, r.buffer_bytes, r.total_host, true);
+        if (rc) return rc;
+    }
+    mccnn_geometry_t* chunk[MCCNN_BATCH_MAX];
+    int nc = 0, sorts = 0;
+    auto flush = [&]() -> int {
+        int rc = nc ? geometry_issue_chunk(chunk, nc, stream) : 0;
+        nc = 0; sorts = 0;
+        return rc;
+    };
+    for (int k = 0; k < count; ++k) {
+        mccnn_geometry_t* g = req[k].geometry;
+        const bool with_grid = g->grid_of == nullptr, own_order = !g->same_level && g->m >= MCCNN_ORDER_MIN_M;
+        const bool ok = grid_batch_eligible(with_grid ? g->n : 1, g->B, g->nc) && (!own_order || grid_batch_eligible(g->m, g->B, g->nc)) &&
+                        neigh_batch_eligible(g->m, g->n);
+        if (!ok) {   // its own chain -- behind the chunk in flight (it may share a grid set up there), and before what follows
+            int rc = flush();
+            if (!rc) rc = geometry_issue_single(g, stream);
+            if (rc) return rc;
+            continue;
+        }
+        const int need = (with_grid ? 1 : 0) + (own_order ? 1 : 0);
+        if (nc == MCCNN_BATCH_MAX || sorts + need > MCCNN_BATCH_MAX) {
+            int rc = flush();
+            if (rc) return rc;
+        }
+        chunk[nc++] = g;
+        sorts += need;
+    }
+    return flush();
 }
 
 long long mccnn_debug_wait_ns(void) { return g_wait_ns.load(std::memory_order_relaxed); }

@@ -1,6 +1,6 @@
 // Bounding boxes, grid-hash keys, stable counting sort into cells, cell table, row
 // permutations. Replaces tf_ops/aabb_gpu.cu and tf_ops/sort_gpu.cu.
-#include "common.h"
+#include "batch.h"
 
 namespace mccnn {
 
@@ -217,14 +217,11 @@ __global__ __launch_bounds__(256) void check_bids(const int* __restrict__ bids, 
 // calc_key + update_counters fused (sort_gpu.cu:35-80). arrival[i] = rank in atomic arrival
 // order; it is only used to park point ids in their cell segment, the final order is fixed
 // by rank_in_cell below.
-__global__ __launch_bounds__(256) void keys_hist(const float* __restrict__ pts, const int* __restrict__ bids,
-                                                 const float* __restrict__ mn, const float* __restrict__ mx,
-                                                 int n, int B, int nc, int* __restrict__ keys, int* __restrict__ cnt,
-                                                 int* __restrict__ arrival, const int* __restrict__ nDev,
-                                                 ClearSpan x1, ClearSpan x2) {
-    clear_span_dev(x1);  // what LATER kernels of the chain want zeroed (common.h)
-    clear_span_dev(x2);
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void keys_hist_body(int blk, const float* __restrict__ pts, const int* __restrict__ bids,
+                                               const float* __restrict__ mn, const float* __restrict__ mx, int n, int B, int nc,
+                                               int* __restrict__ keys, int* __restrict__ cnt, int* __restrict__ arrival,
+                                               const int* __restrict__ nDev) {
+    int i = blk * 256 + threadIdx.x;
     if (nDev) n = *nDev;  // device-side point count (hierarchy levels chained without a host read-back)
     if (i >= n) return;
     int b = clamp_batch(bids[i], B);
@@ -236,22 +233,27 @@ __global__ __launch_bounds__(256) void keys_hist(const float* __restrict__ pts, 
     keys[i] = key;
     arrival[i] = atomicAdd(&cnt[key], 1);
 }
+__global__ __launch_bounds__(256) void keys_hist(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                 const float* __restrict__ mn, const float* __restrict__ mx,
+                                                 int n, int B, int nc, int* __restrict__ keys, int* __restrict__ cnt,
+                                                 int* __restrict__ arrival, const int* __restrict__ nDev,
+                                                 ClearSpan x1, ClearSpan x2) {
+    clear_span_dev(x1);  // what LATER kernels of the chain want zeroed (common.h)
+    clear_span_dev(x2);
+    keys_hist_body((int)blockIdx.x, pts, bids, mn, mx, n, B, nc, keys, cnt, arrival, nDev);
+}
 
 // The same for grids of FEW cells (a classification network's coarse convolutions put a whole cloud into one to 27
 // cells): thousands of returning atomics on a few dozen addresses serialise at the L2 (5 277 points in 32 cells: 34 us).
 // Ranks inside the workgroup come from LDS counters, one global atomic per (workgroup, occupied cell) fetches the base.
 #define MCCNN_HIST_LDS_BINS 1024
-__global__ __launch_bounds__(256) void keys_hist_lds(const float* __restrict__ pts, const int* __restrict__ bids,
-                                                     const float* __restrict__ mn, const float* __restrict__ mx,
-                                                     int n, int B, int nc, int C, int* __restrict__ keys,
-                                                     int* __restrict__ cnt, int* __restrict__ arrival,
-                                                     const int* __restrict__ nDev, ClearSpan x1, ClearSpan x2) {
-    clear_span_dev(x1);
-    clear_span_dev(x2);
-    __shared__ int bins[MCCNN_HIST_LDS_BINS];
+__device__ __forceinline__ void keys_hist_lds_body(int blk, const float* __restrict__ pts, const int* __restrict__ bids,
+                                                   const float* __restrict__ mn, const float* __restrict__ mx, int n, int B, int nc,
+                                                   int C, int* __restrict__ keys, int* __restrict__ cnt, int* __restrict__ arrival,
+                                                   const int* __restrict__ nDev, int* __restrict__ bins /* LDS, MCCNN_HIST_LDS_BINS */) {
     for (int c = threadIdx.x; c < C; c += 256) bins[c] = 0;
     __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blk * 256 + threadIdx.x;
     if (nDev) n = *nDev;
     int key = -1, local = 0;
     if (i < n) {
@@ -271,6 +273,16 @@ __global__ __launch_bounds__(256) void keys_hist_lds(const float* __restrict__ p
     }
     __syncthreads();
     if (i < n) arrival[i] = bins[key] + local;
+}
+__global__ __launch_bounds__(256) void keys_hist_lds(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                     const float* __restrict__ mn, const float* __restrict__ mx,
+                                                     int n, int B, int nc, int C, int* __restrict__ keys,
+                                                     int* __restrict__ cnt, int* __restrict__ arrival,
+                                                     const int* __restrict__ nDev, ClearSpan x1, ClearSpan x2) {
+    clear_span_dev(x1);
+    clear_span_dev(x2);
+    __shared__ int bins[MCCNN_HIST_LDS_BINS];
+    keys_hist_lds_body((int)blockIdx.x, pts, bids, mn, mx, n, B, nc, C, keys, cnt, arrival, nDev, bins);
 }
 
 __global__ __launch_bounds__(256) void park_ids(const int* __restrict__ keys, const int* __restrict__ start,
@@ -312,16 +324,13 @@ __global__ __launch_bounds__(256) void rank_in_cell(const int* __restrict__ keys
 // the reference's memset leaves, sort_gpu.cu:492 -- when it does not (save_indexs, sort_gpu.cu:225-248, writes exactly
 // these bounds). Seven launches of round 5 (memset, keys_hist, scan, park_ids, rank_in_cell, move_points, cell_table) are
 // four: keys_hist, scan, park_ids, rank_move.
-__global__ __launch_bounds__(256) void rank_move(const int* __restrict__ keys, const int* __restrict__ start,
-                                                 const int* __restrict__ slot, int n, long long numCells,
-                                                 const float* __restrict__ pts, const int* __restrict__ bids,
-                                                 int* __restrict__ newIdx, float* __restrict__ oPts, int* __restrict__ oBids,
-                                                 int* __restrict__ inv, int2* __restrict__ cells,
-                                                 const int* __restrict__ nDev, ClearSpan x1, ClearSpan x2) {
-    clear_span_dev(x1);
-    clear_span_dev(x2);
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (long long c = t; c < numCells; c += (long long)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void rank_move_body(int blk, int nblk, const int* __restrict__ keys, const int* __restrict__ start,
+                                               const int* __restrict__ slot, int n, long long numCells,
+                                               const float* __restrict__ pts, const int* __restrict__ bids,
+                                               int* __restrict__ newIdx, float* __restrict__ oPts, int* __restrict__ oBids,
+                                               int* __restrict__ inv, int2* __restrict__ cells, const int* __restrict__ nDev) {
+    const long long t = (long long)blk * 256 + threadIdx.x;
+    for (long long c = t; c < numCells; c += (long long)nblk * 256) {
         const int s0 = start[c], s1 = start[c + 1];
         cells[c] = s1 > s0 ? make_int2(s0, s1) : make_int2(0, 0);
     }
@@ -344,6 +353,39 @@ __global__ __launch_bounds__(256) void rank_move(const int* __restrict__ keys, c
     oPts[(size_t)f * 3 + 2] = pts[(size_t)id * 3 + 2];
     oBids[f] = bids[id];
     if (inv) inv[f] = id;
+}
+__global__ __launch_bounds__(256) void rank_move(const int* __restrict__ keys, const int* __restrict__ start,
+                                                 const int* __restrict__ slot, int n, long long numCells,
+                                                 const float* __restrict__ pts, const int* __restrict__ bids,
+                                                 int* __restrict__ newIdx, float* __restrict__ oPts, int* __restrict__ oBids,
+                                                 int* __restrict__ inv, int2* __restrict__ cells,
+                                                 const int* __restrict__ nDev, ClearSpan x1, ClearSpan x2) {
+    clear_span_dev(x1);
+    clear_span_dev(x2);
+    rank_move_body((int)blockIdx.x, (int)gridDim.x, keys, start, slot, n, numCells, pts, bids, newIdx, oPts, oBids, inv, cells, nDev);
+}
+
+// ------------------------------------------------------------------ one launch per phase over a BATCH of counting sorts
+// (mccnn_geometry_build_batch, exec.hip): item = the grid build of one geometry, or the visiting order of one geometry's
+// foreign centres (newIdx == nullptr: no rank / move phase). The prefix sums of the items' cell counters are one launch of
+// scan.hip's batch form in between.
+__global__ __launch_bounds__(256) void grid_keys_batch(GridBatch gb, BatchBlocks bb) {
+    __shared__ int bins[MCCNN_HIST_LDS_BINS];
+    int local, blocks;
+    const GridItem& g = gb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    if (g.ldsHist) keys_hist_lds_body(local, g.pts, g.bids, g.mn, g.mx, g.n, g.B, g.nc, g.C, g.keys, g.cnt, g.arrival, nullptr, bins);
+    else keys_hist_body(local, g.pts, g.bids, g.mn, g.mx, g.n, g.B, g.nc, g.keys, g.cnt, g.arrival, nullptr);
+}
+__global__ __launch_bounds__(256) void grid_park_batch(GridBatch gb, BatchBlocks bb) {
+    int local, blocks;
+    const GridItem& g = gb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    const int i = local * 256 + threadIdx.x;
+    if (i < g.n) g.slot[g.start[g.keys[i]] + g.arrival[i]] = i;
+}
+__global__ __launch_bounds__(256) void grid_rank_move_batch(GridBatch gb, BatchBlocks bb) {
+    int local, blocks;
+    const GridItem& g = gb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    rank_move_body(local, blocks, g.keys, g.start, g.slot, g.n, g.C, g.pts, g.bids, g.newIdx, g.oPts, g.oBids, g.inv, g.cells, nullptr);
 }
 
 // ------------------------------------------------------------------ step 2
@@ -884,6 +926,77 @@ int build_grid_fused(const float* pts, const int* batch_ids, const float* aabb_m
     MCCNN_LAUNCHED();
     rank_move<<<blocks, 256, 0, s>>>(keys, start, slot, n, C, pts, batch_ids, new_idx, out_pts, out_batch_ids, inv_idx, ct, n_dev,
                                      no_span(), no_span());
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
+// ---- host side of the batch form: one item per counting sort, the same workspace layouts as the single calls above
+bool grid_batch_eligible(int n, int batch_size, int num_cells) {
+    const long long C = total_cells(batch_size, num_cells);
+    return n > 0 && C > 0 && C <= 2048LL * 1024;   // (tiles of the cell counters' chained prefix sum)
+}
+// a grid build (ws: mccnn_build_grid_workspace_bytes)
+int grid_batch_item(GridItem& g, ScanItem& sc, ClearSpan& head, const float* pts, const int* batch_ids, const float* aabb_min,
+                    const float* aabb_max, int n, int batch_size, int num_cells, int* new_idx, float* out_pts,
+                    int* out_batch_ids, int* cell_indexs, int* inv_idx, void* ws, size_t ws_bytes) {
+    const long long C = total_cells(batch_size, num_cells);
+    if (!grid_batch_eligible(n, batch_size, num_cells)) return MCCNN_E_TOOLARGE;
+    if (!ws || ws_bytes < mccnn_build_grid_workspace_bytes(n, batch_size, num_cells)) return MCCNN_E_WORKSPACE;
+    Arena a(ws, ws_bytes);
+    int* keys = a.take<int>((size_t)n);
+    const size_t cntBytes = align_up((size_t)C * 4), scanBytes = scan_workspace_bytes((int)C);
+    char* blk = a.take<char>(cntBytes + scanBytes);
+    int* start = a.take<int>((size_t)C + 1);
+    int* slot = a.take<int>((size_t)n);
+    if (!keys || !blk || !start || !slot) return MCCNN_E_WORKSPACE;
+    const int tiles = ceil_div(C, 2048);
+    g = GridItem{pts, batch_ids, aabb_min, aabb_max, keys, (int*)blk, new_idx /* arrival ranks, then the final positions */, start, slot,
+                 new_idx, out_pts, out_batch_ids, inv_idx, reinterpret_cast<int2*>(cell_indexs), n, batch_size, num_cells, (int)C,
+                 (C <= MCCNN_HIST_LDS_BINS && n >= 4 * C) ? 1 : 0};
+    sc = ScanItem{(const int*)blk, start, reinterpret_cast<unsigned long long*>(blk + cntBytes), start + C, nullptr, (int)C, tiles};
+    head = clear_span(blk, cntBytes + align_up((size_t)(tiles + 1) * 8));
+    return 0;
+}
+// a visiting order (ws: visiting_order_workspace_bytes)
+size_t visiting_order_workspace_bytes(int m, int batch_size, int num_cells);
+int order_batch_item(GridItem& g, ScanItem& sc, ClearSpan& head, const float* pts, const int* batch_ids, const float* aabb_min,
+                     const float* aabb_max, int m, int batch_size, int num_cells, int* order, void* ws, size_t ws_bytes) {
+    const long long C = total_cells(batch_size, num_cells);
+    if (!grid_batch_eligible(m, batch_size, num_cells)) return MCCNN_E_TOOLARGE;
+    if (!ws || ws_bytes < visiting_order_workspace_bytes(m, batch_size, num_cells)) return MCCNN_E_WORKSPACE;
+    Arena a(ws, ws_bytes);
+    int* keys = a.take<int>((size_t)m);
+    int* arrival = a.take<int>((size_t)m);
+    const size_t cntBytes = align_up((size_t)C * 4), scanBytes = scan_workspace_bytes((int)C);
+    char* blk = a.take<char>(cntBytes + scanBytes);
+    int* start = a.take<int>((size_t)C + 1);
+    if (!keys || !arrival || !blk || !start) return MCCNN_E_WORKSPACE;
+    const int tiles = ceil_div(C, 2048);
+    g = GridItem{pts, batch_ids, aabb_min, aabb_max, keys, (int*)blk, arrival, start, order, nullptr, nullptr, nullptr, nullptr, nullptr,
+                 m, batch_size, num_cells, (int)C, (C <= MCCNN_HIST_LDS_BINS && m >= 4 * C) ? 1 : 0};
+    sc = ScanItem{(const int*)blk, start, reinterpret_cast<unsigned long long*>(blk + cntBytes), start + C, nullptr, (int)C, tiles};
+    head = clear_span(blk, cntBytes + align_up((size_t)(tiles + 1) * 8));
+    return 0;
+}
+static BatchBlocks grid_blocks(const GridBatch& gb, int count, bool rankOnly) {
+    BatchBlocks bb;
+    bb.count = count;
+    int run = 0;
+    for (int k = 0; k < count; ++k) {
+        bb.first[k] = run;
+        if (!rankOnly || gb.it[k].newIdx) run += ceil_div(gb.it[k].n, 256);
+    }
+    for (int k = count; k <= MCCNN_BATCH_MAX; ++k) bb.first[k] = run;
+    return bb;
+}
+// phase 0: keys + histogram; phase 1 (after the prefix sums): park; phase 2: rank + move + cell table (grid builds only)
+int launch_grid_batch_phase(const GridBatch& gb, int count, int phase, hipStream_t s) {
+    const BatchBlocks bb = grid_blocks(gb, count, phase == 2);
+    const int grid = bb.first[count];
+    if (grid == 0) return 0;
+    if (phase == 0) grid_keys_batch<<<grid, 256, 0, s>>>(gb, bb);
+    else if (phase == 1) grid_park_batch<<<grid, 256, 0, s>>>(gb, bb);
+    else grid_rank_move_batch<<<grid, 256, 0, s>>>(gb, bb);
     MCCNN_LAUNCHED();
     return 0;
 }

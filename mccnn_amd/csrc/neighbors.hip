@@ -1,6 +1,6 @@
 // Fixed-radius neighbour search over the 27-cell window and the per-edge kernel density
 // estimate. Replaces tf_ops/find_neighbors.cu and tf_ops/compute_pdf.cu.
-#include "common.h"
+#include "batch.h"
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
@@ -75,8 +75,9 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 // and stores them with ONE instruction per (centre, segment). Faster alone (count pass on the room 35 -> 26 us), but its
 // denser LDS-read / VALU bursts cost the convolution kernels it runs beside more than the search saves (pipelined step
 // 0.640 -> 0.672 ms): background launches (mccnn_background_launches) keep the plain loop.
+// (the kernel's body: workgroup `blk` of `nblk` -- the single launch, and one geometry's share of a batch launch)
 template <int MODE, bool LEAN>
-__global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ centres, const int* __restrict__ cb, int m,
+__device__ __forceinline__ void neigh_window_body(const int blk, const int nblk, const float* __restrict__ centres, const int* __restrict__ cb, int m,
                                                     const float* __restrict__ pts, const int* __restrict__ cells,
                                                     const float* __restrict__ mn, const float* __restrict__ mx, int B, int nc,
                                                     float radius, int scaleInv, const int* __restrict__ order,
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
                                                     int* __restrict__ totalDev, int* __restrict__ totalHost) {
     constexpr bool FILL = MODE == 1;
     // the status words of the prefix sum that follows the count pass (scan.hip): cleared here, no launch of their own
-    if (!FILL && blockIdx.x == 0)
+    if (!FILL && blk == 0)
         for (int k = threadIdx.x; k < numZero; k += blockDim.x) zeroWords[k] = 0ull;
     __shared__ float4 win[4][MCCNN_NW_CAP];
     __shared__ int2 ctab[4][32];
@@ -119,17 +120,17 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
             const int idx = threadIdx.x * PER + k;
             if (idx < m) {
                 scanLds[idx] = run;
-                if (blockIdx.x == 0) startOut[idx] = run;
+                if (blk == 0) startOut[idx] = run;
             }
             run += v[k];
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (blk == 0 && threadIdx.x == 0) {
             *totalDev = total;
             if (totalHost) *totalHost = total;
         }
         __syncthreads();
     }
-    const int g0 = (xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave) * G;
+    const int g0 = (xcd_contiguous(blk, nblk) * 4 + wave) * G;
     if (g0 >= m) return;
     float4* lw = win[wave];
     int2* tab = ctab[wave];
@@ -373,6 +374,32 @@ __global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ ce
     if (!FILL && own) cnt[i] = count;
 }
 
+template <int MODE, bool LEAN>
+__global__ __launch_bounds__(256) void neigh_window(const float* __restrict__ centres, const int* __restrict__ cb, int m,
+                                                    const float* __restrict__ pts, const int* __restrict__ cells,
+                                                    const float* __restrict__ mn, const float* __restrict__ mx, int B, int nc,
+                                                    float radius, int scaleInv, const int* __restrict__ order,
+                                                    int* __restrict__ cnt, unsigned long long* __restrict__ masks,
+                                                    const int* __restrict__ startIdx, int* __restrict__ packed,
+                                                    int capacity, unsigned long long* __restrict__ zeroWords, int numZero,
+                                                    int G /* centres per wave, 1 .. 32 */, float Tabs,
+                                                    const int* __restrict__ scanCnt, int* __restrict__ startOut,
+                                                    int* __restrict__ totalDev, int* __restrict__ totalHost) {
+    neigh_window_body<MODE, LEAN>((int)blockIdx.x, (int)gridDim.x, centres, cb, m, pts, cells, mn, mx, B, nc, radius, scaleInv, order, cnt,
+                                  masks, startIdx, packed, capacity, zeroWords, numZero, G, Tabs, scanCnt, startOut, totalDev, totalHost);
+}
+
+// One launch for the count (or the fill) pass of a BATCH of searches (mccnn_geometry_build_batch): the plain loop of the
+// background launches, the prefix sum of the counts a launch of its own in between (scan.hip's batch form).
+template <int MODE>
+__global__ __launch_bounds__(256) void neigh_window_batch(NeighBatch nbt, BatchBlocks bb) {
+    int local, blocks;
+    const NeighItem& g = nbt.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    neigh_window_body<MODE, false>(local, blocks, g.centres, g.cb, g.m, g.pts, g.cells, g.mn, g.mx, g.B, g.nc, g.radius, g.scaleInv, g.order,
+                                   g.cnt, g.masks, g.startIdx, g.packed, g.capacity, g.zeroWords, g.numZero, g.G, g.Tabs, nullptr, nullptr,
+                                   nullptr, nullptr);
+}
+
 __global__ __launch_bounds__(256) void invert_perm_k(const int* __restrict__ newIdx, int n, int* __restrict__ inv) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) inv[newIdx[i]] = i;
@@ -565,7 +592,7 @@ __device__ __forceinline__ void pdf_row_long(const float* __restrict__ pts, cons
 
 struct PdfLongRow { int rowStart, k; float s, scale; };
 template <int WAVES>  // 4: lists of many rows (4 rows per wave); 16: lists of few rows (one row per wave)
-__global__ __launch_bounds__(WAVES * 64) void pdf_rows_mfma(const float* __restrict__ pts, const int* __restrict__ bids,
+__device__ __forceinline__ void pdf_rows_mfma_body(const int blk, const float* __restrict__ pts, const int* __restrict__ bids,
                                                      const int2* __restrict__ packed, const int* __restrict__ startIdx,
                                                      int m, int e, const float* __restrict__ mn,
                                                      const float* __restrict__ mx, int B, float window, float radius,
@@ -579,7 +606,7 @@ __global__ __launch_bounds__(WAVES * 64) void pdf_rows_mfma(const float* __restr
     for (int t = threadIdx.x; t < WAVES * MCCNN_PDF_ROWS; t += WAVES * 64) longRows[t].k = 0;
     if (threadIdx.x == 0) anyLong = 0;
     __syncthreads();
-    const int r0 = (blockIdx.x * WAVES + wave) * rowsPerWave;
+    const int r0 = (blk * WAVES + wave) * rowsPerWave;
     float* __restrict__ P = planes[wave];
     const int c = lane >> 4, mm = lane & 15;
     const float bscale = (c == 3) ? 1.0f : -2.0f;
@@ -784,6 +811,25 @@ __global__ __launch_bounds__(WAVES * 64) void pdf_rows_mfma(const float* __restr
     }
 }
 
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void pdf_rows_mfma(const float* __restrict__ pts, const int* __restrict__ bids,
+                                                     const int2* __restrict__ packed, const int* __restrict__ startIdx,
+                                                     int m, int e, const float* __restrict__ mn,
+                                                     const float* __restrict__ mx, int B, float window, float radius,
+                                                     int scaleInv, float* __restrict__ pdfs,
+                                                     const int* __restrict__ eDev, int rowsPerWave) {
+    pdf_rows_mfma_body<WAVES>((int)blockIdx.x, pts, bids, packed, startIdx, m, e, mn, mx, B, window, radius, scaleInv, pdfs, eDev, rowsPerWave);
+}
+
+// One launch for the KDE of a BATCH of lists (mccnn_geometry_build_batch): 16 waves per workgroup for every list (the
+// pooled planes of long rows), rows per wave by the list's size.
+__global__ __launch_bounds__(1024) void pdf_rows_mfma_batch(PdfBatch pb, BatchBlocks bb) {
+    int local, blocks;
+    const PdfItem& g = pb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    pdf_rows_mfma_body<16>(local, g.pts, g.bids, g.packed, g.startIdx, g.m, g.e, g.mn, g.mx, g.B, g.window, g.radius, g.scaleInv, g.pdfs,
+                           g.eDev, g.rowsPerWave);
+}
+
 }  // namespace mccnn
 
 using namespace mccnn;
@@ -978,6 +1024,58 @@ int find_neighbors_chain(const float* centres, const int* centre_batch_ids, int 
     return find_neighbors_fill_impl(centres, centre_batch_ids, m, sorted_pts, n, cell_indexs, aabb_min, aabb_max, batch_size,
                                     num_cells, radius, scale_inv, centre_order, start_idx, e_capacity, packed, ws, ws_bytes, stream,
                                     small ? start_idx : nullptr, small ? total_dev : nullptr, small ? total_host : nullptr);
+}
+}  // namespace mccnn
+extern "C" {
+
+}  // extern "C"
+namespace mccnn {
+// ---- host side of the batch form (mccnn_geometry_build_batch): one item per search / KDE, the workspace layout of the
+// single calls (neigh_ws); background settings (plain loop, centres per wave by the list's size)
+bool neigh_batch_eligible(int m, int n) { return m > 0 && n > 0 && (long long)m <= 2048LL * 1024; }
+int neigh_batch_item(NeighItem& it, ScanItem& sc, const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts,
+                     int n, const int* cell_indexs, const float* aabb_min, const float* aabb_max, int batch_size, int num_cells,
+                     float radius, int scale_inv, const int* order, int* start_idx, int e_capacity, int* packed, int* total_dev,
+                     int* total_host, void* ws, size_t ws_bytes) {
+    if (!neigh_batch_eligible(m, n)) return MCCNN_E_TOOLARGE;
+    NeighWs w;
+    if (!neigh_ws(ws, ws_bytes, m, n, w)) return MCCNN_E_WORKSPACE;
+    const int tiles = ceil_div(m, 2048);
+    const int G = m >= 32768 ? MCCNN_NW_G : (m >= 16384 ? 4 : (m >= 8192 ? 2 : 1));   // (neigh_group of background launches)
+    it = NeighItem{centres, centre_batch_ids, sorted_pts, cell_indexs, aabb_min, aabb_max, order, w.cnt, w.masks, start_idx, packed,
+                   reinterpret_cast<unsigned long long*>(w.scanws), m, batch_size, num_cells, scale_inv, e_capacity, G, tiles + 1,
+                   radius, scale_inv ? 0.0f : sqrt_threshold_host(radius)};
+    sc = ScanItem{w.cnt, start_idx, reinterpret_cast<unsigned long long*>(w.scanws), total_dev, total_host, m, tiles};
+    return 0;
+}
+int launch_neigh_batch(const NeighBatch& nbt, int count, int mode, hipStream_t s) {
+    BatchBlocks bb;
+    bb.count = count;
+    int run = 0;
+    for (int k = 0; k < count; ++k) { bb.first[k] = run; run += ceil_div(nbt.it[k].m, 4 * nbt.it[k].G); }
+    for (int k = count; k <= MCCNN_BATCH_MAX; ++k) bb.first[k] = run;
+    if (run == 0) return 0;
+    if (mode == 0) neigh_window_batch<0><<<run, 256, 24000, s>>>(nbt, bb);   // (the LDS pad of background launches: neigh_lds_pad)
+    else neigh_window_batch<1><<<run, 256, 24000, s>>>(nbt, bb);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+void pdf_batch_item(PdfItem& it, const float* sorted_pts, const int* sorted_batch_ids, const int* start_idx, int m, const int* packed,
+                    int e_capacity, const int* e_dev, const float* aabb_min, const float* aabb_max, int batch_size, float window,
+                    float radius, int scale_inv, float* pdfs) {
+    it = PdfItem{sorted_pts, sorted_batch_ids, reinterpret_cast<const int2*>(packed), start_idx, aabb_min, aabb_max, pdfs, e_dev,
+                 m, e_capacity, batch_size, scale_inv, m >= 16384 ? MCCNN_PDF_ROWS : 1, window, radius};
+}
+int launch_pdf_batch(const PdfBatch& pb, int count, hipStream_t s) {
+    BatchBlocks bb;
+    bb.count = count;
+    int run = 0;
+    for (int k = 0; k < count; ++k) { bb.first[k] = run; run += ceil_div(pb.it[k].m, 16 * pb.it[k].rowsPerWave); }
+    for (int k = count; k <= MCCNN_BATCH_MAX; ++k) bb.first[k] = run;
+    if (run == 0) return 0;
+    pdf_rows_mfma_batch<<<run, 1024, 0, s>>>(pb, bb);
+    MCCNN_LAUNCHED();
+    return 0;
 }
 }  // namespace mccnn
 extern "C" {

@@ -107,6 +107,57 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained(const int* in, int*
     }
 }
 
+// The same for up to MCCNN_BATCH_MAX independent arrays in ONE launch (one geometry each): an item's tiles are chained
+// among themselves only (own status words, own ticket behind them).
+__global__ __launch_bounds__(SCAN_THREADS) void scan_chained_batch(ScanBatch sb, BatchBlocks bb) {
+    __shared__ int lds[4];
+    __shared__ int sOff;
+    __shared__ int sTile;
+    int local, blocks;
+    const ScanItem& it = sb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    if (threadIdx.x == 0)
+        sTile = (int)__hip_atomic_fetch_add(it.status + blocks, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int tile = sTile;
+    const int n = it.n;
+    const long long base = (long long)tile * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? it.in[base + k] : 0;
+        s += v[k];
+    }
+    int tot;
+    const int ex = block_excl_scan(s, tot, lds);
+    if (threadIdx.x < 64) {
+        const int excl = chain_lookback(it.status, tile, tot, (int)threadIdx.x);
+        if (threadIdx.x == 0) sOff = excl;
+    }
+    __syncthreads();
+    int run = ex + sOff;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) it.out[base + k] = run;
+        run += v[k];
+    }
+    if (tile == blocks - 1 && threadIdx.x == SCAN_THREADS - 1) {
+        if (it.total) *it.total = run;
+        if (it.total2) *it.total2 = run;
+    }
+}
+int launch_scan_batch(const ScanBatch& sb, int count, hipStream_t s) {
+    BatchBlocks bb;
+    bb.count = count;
+    int run = 0;
+    for (int k = 0; k < count; ++k) { bb.first[k] = run; run += sb.it[k].tiles; }
+    for (int k = count; k <= MCCNN_BATCH_MAX; ++k) bb.first[k] = run;
+    if (run == 0) return 0;
+    scan_chained_batch<<<run, SCAN_THREADS, 0, s>>>(sb, bb);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
 size_t scan_status_bytes(int n) {
     const long long tiles = ((long long)n + SCAN_TILE - 1) / SCAN_TILE;
     // one status word per tile + the ticket counter

@@ -432,6 +432,7 @@ struct Geo {
     bool tr_wait = false;
     int pre_avg = -1;                  // the `avg` the prebuilt plans were made for
     int have = 0;                      // pieces attached so far (mask)
+    int plan_side = -1;                // batch builds: the side stream this geometry's row plans / transposed list go to (spread over all of them)
 
     // The attached pieces of `what` (1 | 2 | 4) on stream ss, forward stage first; one event per stage.
     int issue_pieces(int what, bool avg, hipStream_t ss, void* ws, size_t wsb) {
@@ -529,6 +530,60 @@ hipEvent_t hierarchy_ready_event(const std::shared_ptr<HierFuture>& f);
 // whether `t` lives in the memory of that hierarchy (its input points / batch ids, boxes, level rows)
 bool hierarchy_owns(const std::shared_ptr<HierFuture>& f, const Tensor& t);
 
+// ---- geometries of a step issued as ONE batch (mccnn_geometry_build_batch: one launch per kernel kind over all of them).
+// Between begin_geometry_batch() and end_geometry_batch() every build_geometry() call that would go to a side stream is
+// only RECORDED (its buffers allocated, its Geo returned); end_geometry_batch() hands the whole list to the helper thread,
+// which issues them on ONE side stream and records every geometry's event behind the batch.
+struct BatchEntry {
+    std::shared_ptr<Geo> g, grid_from;
+    mccnn_geometry_request req;
+};
+struct GeoBatch {
+    bool active = false;
+    int side = -1;
+    bool background = false;
+    std::vector<BatchEntry> entries;
+};
+thread_local GeoBatch t_geo_batch;
+void begin_geometry_batch() {
+    static const bool on = mccnn::debug_int("geo_batch", 1) != 0;   // A/B switch: 0 = every geometry its own chain
+    t_geo_batch.active = on && Issuer::enabled();
+    t_geo_batch.side = -1;
+    t_geo_batch.entries.clear();
+}
+void end_geometry_batch() {
+    GeoBatch& b = t_geo_batch;
+    b.active = false;
+    if (b.entries.empty()) return;
+    auto entries = std::make_shared<std::vector<BatchEntry>>(std::move(b.entries));
+    b.entries.clear();
+    hipStream_t stream = side_stream(b.side);
+    const bool background = b.background;
+    const int dev = (int)(*entries)[0].g->buf.device().index();
+    Issuer::get().push([entries, stream, background, dev] {
+        enter_device(dev);
+        std::vector<mccnn_geometry_request> reqs;
+        reqs.reserve(entries->size());
+        for (BatchEntry& e : *entries) {
+            // a grid owner outside this batch has to be issued; one inside it is set up by the same library call
+            bool inside = false;
+            if (e.grid_from)
+                for (BatchEntry& o : *entries) inside = inside || (o.g.get() == e.grid_from.get());
+            if (e.grid_from && !inside) e.grid_from->wait_issued_nothrow();
+            reqs.push_back(e.req);
+        }
+        const int prev = background ? mccnn_background_launches(1) : 0;
+        int rc = mccnn_geometry_build_batch(reqs.data(), (int)reqs.size(), (void*)stream);
+        if (background) mccnn_background_launches(prev);
+        for (BatchEntry& e : *entries) {
+            int r = rc;
+            if (r == 0 && hipEventRecord(e.g->event, stream) != hipSuccess) r = (int)hipErrorUnknown;
+            e.g->build_rc = r;
+            e.g->issued.store(1, std::memory_order_release);
+        }
+    });
+}
+
 std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const Tensor& centres, const Tensor& cbids,
                                     const Tensor& mn, const Tensor& mx, int64_t B, int64_t nc, double radius, bool scale_inv,
                                     double window, bool use_pdf, int64_t capacity, std::shared_ptr<Geo> grid_from,
@@ -555,6 +610,13 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
     g->alloc_stream = stream;
     // a geometry that shares another one's grid runs behind it on the same side stream
     if (side >= 0 && grid_from && grid_from->side >= 0 && grid_from->needs_wait) side = grid_from->side;
+    // ... and the geometries of a batch all run on the side stream of the first one
+    const bool batched = side >= 0 && t_geo_batch.active;
+    const int asked_side = side >= 0 ? (int)(((side % kSideStreams) + kSideStreams) % kSideStreams) : -1;
+    if (batched) {
+        if (t_geo_batch.side < 0) { t_geo_batch.side = (int)(((side % kSideStreams) + kSideStreams) % kSideStreams); t_geo_batch.background = background; }
+        side = t_geo_batch.side;
+    }
     // Everything this build reads is the adopted prefetched hierarchy `after` (its points, batch ids, boxes -- and a grid
     // that was itself built this way): the build then waits for THAT, takes its memory from its own stream's pool and
     // starts now, not behind what the calling stream holds (Geo::own_pool).
@@ -631,6 +693,16 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
         const int iB = (int)B, inc = (int)nc, icap = (int)capacity, isi = scale_inv ? 1 : 0, ipdf = use_pdf ? 1 : 0;
         const float fr = (float)radius, fw = (float)window;
         const int dev = (int)pts.device().index();
+        if (batched && stream == (void*)side_stream(t_geo_batch.side)) {   // recorded: end_geometry_batch() issues the list
+            BatchEntry e;
+            e.g = g;
+            e.grid_from = grid_from;
+            e.req = mccnn_geometry_request{g->h, p0, p1, n, p2, p3, m, p4, p5, iB, inc, fr, isi, fw, ipdf, icap,
+                                           grid_from ? grid_from->h : nullptr, bufp, bytes, slotp};
+            t_geo_batch.entries.push_back(std::move(e));
+            g->plan_side = asked_side;   // the pieces built ahead keep the spread over the side streams the builds gave up
+            return g;
+        }
         Issuer::get().push([g, grid_from, p0, p1, p2, p3, p4, p5, bufp, slotp, n, m, iB, inc, icap, isi, ipdf, fr, fw, bytes, stream, background, dev] {
             enter_device(dev);
             if (grid_from) grid_from->wait_issued_nothrow();
@@ -687,7 +759,8 @@ void prebuild_async(std::shared_ptr<Geo> g, int what, bool avg) {
         total += (b + 255) / 256 * 256;
         if (w > wsb) wsb = w;
     }
-    hipStream_t ss = side_stream(g->side);
+    const bool other = g->plan_side >= 0 && g->plan_side != g->side;   // (a batch build: pieces on another side stream, behind the build's event)
+    hipStream_t ss = side_stream(other ? g->plan_side : g->side);
     Tensor block;
     if (g->own_pool) {
         const c10::hip::HIPStreamGuardMasqueradingAsCUDA own(as_torch_stream((void*)ss, (int)g->buf.device().index()));
@@ -699,9 +772,10 @@ void prebuild_async(std::shared_ptr<Geo> g, int what, bool avg) {
     g->pieces_issued.store(0, std::memory_order_release);
     char* base = (char*)block.data_ptr();
     Tensor like = g->buf;
-    Issuer::get(2).push([g, what, avg, base, off, len, wsb, ss, like]() mutable {
+    Issuer::get(2).push([g, what, avg, base, off, len, wsb, ss, like, other]() mutable {
         enter_device((int)like.device().index());
         g->wait_build_issued_nothrow();
+        if (g->build_rc == 0 && other && g->event && hipStreamWaitEvent(ss, g->event, 0) != hipSuccess) g->build_rc = (int)hipErrorUnknown;
         if (g->build_rc == 0) {
             const int prev = mccnn_debug_wait_accounting(0);
             const int E = mccnn_geometry_edges(g->h, -1);
@@ -1337,6 +1411,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
             py::arg("side") = -1, py::arg("fork") = false, py::arg("background") = false,
             py::arg("after").none(true) = py::none(), py::call_guard<py::gil_scoped_release>());
     mod.def("sampled_features", &sampled_features, py::call_guard<py::gil_scoped_release>());
+    mod.def("begin_geometry_batch", &begin_geometry_batch);
+    mod.def("end_geometry_batch", &end_geometry_batch, py::call_guard<py::gil_scoped_release>());
     mod.def("prebuild_async", &prebuild_async, py::arg("geometry"), py::arg("what"), py::arg("avg"),
             py::call_guard<py::gil_scoped_release>());
     mod.def("conv", &conv, py::arg("geometry"), py::arg("feats"), py::arg("w1"), py::arg("b1"), py::arg("w2"), py::arg("b2"),

@@ -307,6 +307,18 @@ def _build_into(g, inPts, inBids, centres, cbids, mn, mx, B, nc, radius, scaleIn
                                    g.slot.data_ptr(), stream_handle()), "geometry_build")
 
 
+def begin_batch():
+    """Geometries requested until end_batch() that go to a side stream are issued as ONE batch -- one launch per kernel kind
+    over all of them (mccnn_geometry_build_batch) -- on one side stream (torch extension only; otherwise a no-op)."""
+    if _EXT is not None:
+        _EXT.begin_geometry_batch()
+
+
+def end_batch():
+    if _EXT is not None:
+        _EXT.end_geometry_batch()
+
+
 def side_streams_available():
     """Geometry builds on side streams need the torch extension (events and streams live on its side)."""
     return _EXT is not None

@@ -466,3 +466,91 @@ def test_foreign_centres_get_a_visiting_order_without_changing_the_list(mc):
         torch.cuda.synchronize()
         assert torch.equal(gst.reshape(-1), st.reshape(-1)) and torch.equal(gpk, pk)
     assert pk.shape[0] > 0
+
+
+def test_batched_geometries_equal_the_single_chains(mc):
+    """mccnn_geometry_build_batch (one launch per kernel kind over all geometries of a step; what prefetch_step issues) against
+    mccnn_geometry_build of every geometry on its own: grids, cell tables, lists, PDFs bit-identical -- own grids, a shared
+    grid (owner earlier in the batch), foreign centres with a visiting order of their own, a tiny and a large list, a list
+    without densities. Also: 18 requests (two chunks)."""
+    import ctypes as C
+    import torch
+    from mccnn_amd import _lib
+    from mccnn_amd._lib import ptr, check
+    lib = _lib.load()
+    pts, bids = make_cloud(6000, 4, 41, "clustered", True)
+    B = 4
+    P, Bi = _t(pts), _t(bids)
+    rng = np.random.default_rng(2)
+    pick = np.sort(rng.choice(len(pts), 17000, replace=False))
+    Cn, Cb = _t(np.ascontiguousarray(pts[pick])), _t(np.ascontiguousarray(bids[pick]))
+    small = np.sort(rng.choice(len(pts), 300, replace=False))
+    Sn, Sb = _t(np.ascontiguousarray(pts[small])), _t(np.ascontiguousarray(bids[small]))
+    mn, mx = mc.compute_aabb(P, Bi, B, True)
+
+    class Req(C.Structure):
+        _fields_ = [("geometry", C.c_void_p), ("pts", C.c_void_p), ("batch_ids", C.c_void_p), ("n", C.c_int),
+                    ("centres", C.c_void_p), ("centre_batch_ids", C.c_void_p), ("m", C.c_int), ("aabb_min", C.c_void_p),
+                    ("aabb_max", C.c_void_p), ("batch_size", C.c_int), ("num_cells", C.c_int), ("radius", C.c_float),
+                    ("scale_inv", C.c_int), ("window", C.c_float), ("use_pdf", C.c_int), ("e_capacity", C.c_int),
+                    ("grid_from", C.c_void_p), ("buffer", C.c_void_p), ("buffer_bytes", C.c_size_t), ("total_host", C.c_void_p)]
+
+    lib.mccnn_geometry_create.restype = C.c_void_p
+    specs = [  # (points, ids, centres, ids, radius, use_pdf, grid owner index or None)
+        (P, Bi, P, Bi, 0.08, 1, None),      # same level, own grid
+        (P, Bi, Cn, Cb, 0.08, 1, 0),        # foreign centres (>= 16 384: visiting order), grid shared with request 0
+        (P, Bi, Sn, Sb, 0.2, 1, None),      # few centres, own grid
+        (Sn, Sb, Sn, Sb, 0.5, 0, None),     # tiny level, no densities
+        (Cn, Cb, P, Bi, 0.05, 1, None),     # own grid over the centre set, the points as foreign centres
+    ]
+    specs = specs + [specs[2]] * 13         # 18 requests: more than one chunk
+    def build(batched):
+        outs, keep = [], []
+        handles = [lib.mccnn_geometry_create() for _ in specs]
+        reqs = (Req * len(specs))()
+        slots = torch.empty(len(specs), dtype=torch.int32).pin_memory()
+        for k, (p, b, c, cb, r, up, owner) in enumerate(specs):
+            n, m = p.shape[0], c.shape[0]
+            nc = mc._num_cells(mn, mx, B, r, True)
+            cap = 900 * m
+            nbytes = lib.mccnn_geometry_bytes(n, m, B, nc, cap, 0 if owner is not None else 1)
+            buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            keep.append(buf)
+            reqs[k] = Req(handles[k], ptr(p), ptr(b), n, ptr(c), ptr(cb), m, ptr(mn), ptr(mx), B, nc, r, 1, 0.25, up, cap,
+                          handles[owner] if owner is not None else None, buf.data_ptr(), nbytes, slots.data_ptr() + 4 * k)
+        st = torch.cuda.current_stream().cuda_stream
+        if batched:
+            check(lib.mccnn_geometry_build_batch(C.byref(reqs), len(specs), C.c_void_p(st)), "geometry_build_batch")
+        else:
+            for k, q in enumerate(reqs):
+                check(lib.mccnn_geometry_build(C.c_void_p(q.geometry), C.c_void_p(q.pts), C.c_void_p(q.batch_ids), q.n, C.c_void_p(q.centres),
+                                               C.c_void_p(q.centre_batch_ids), q.m, C.c_void_p(q.aabb_min), C.c_void_p(q.aabb_max), q.batch_size,
+                                               q.num_cells, C.c_float(q.radius), q.scale_inv, C.c_float(q.window), q.use_pdf, q.e_capacity,
+                                               C.c_void_p(q.grid_from) if q.grid_from else None, C.c_void_p(q.buffer), q.buffer_bytes,
+                                               C.c_void_p(q.total_host), C.c_void_p(st)), "geometry_build")
+        torch.cuda.synchronize()
+        info = (C.c_longlong * 16)()
+        for k, (p, b, c, cb, r, up, owner) in enumerate(specs):
+            e = int(slots[k])
+            assert 0 < e <= reqs[k].e_capacity, (k, e)
+            check(lib.mccnn_geometry_info(C.c_void_p(handles[k]), info), "geometry_info")
+            n, m, nc = p.shape[0], c.shape[0], reqs[k].num_cells
+            def view(addr, count, dt):
+                for t in keep:   # (the grid arrays of a geometry that shares a grid lie in the owner's buffer)
+                    off = addr - t.data_ptr()
+                    if 0 <= off < t.numel():
+                        nb = count * torch.empty(0, dtype=dt).element_size()
+                        return t[off:off + nb].view(dt).cpu()
+                raise AssertionError("address outside the buffers")
+            outs.append((e, view(info[0], n * 3, torch.float32), view(info[2], B * nc ** 3 * 2, torch.int32), view(info[3], n, torch.int32),
+                         view(info[5], m, torch.int32), view(info[6], e * 2, torch.int32), view(info[7], e, torch.float32)))
+        for h in handles:
+            lib.mccnn_geometry_destroy(C.c_void_p(h))
+        return outs
+    lib.mccnn_geometry_build.argtypes = None
+    a, b_ = build(False), build(True)
+    for k, (x, y) in enumerate(zip(a, b_)):
+        assert x[0] == y[0], k
+        for t0, t1 in zip(x[1:], y[1:]):
+            assert torch.equal(t0, t1), k
+    assert a[3][6].min() == 1.0 and a[3][6].max() == 1.0   # usePDF = 0: ones
