@@ -487,6 +487,14 @@ int mccnn_geometry_piece_bytes(mccnn_geometry_t* g, int what, long long* bytes, 
  * attaches and prebuilds them once E has arrived). */
 int mccnn_geometry_piece_bound(int n, int m, int e_cap, int what, long long* bytes, long long* ws_bytes);
 int mccnn_geometry_prebuild(mccnn_geometry_t* g, int what, int avg, void* ws, size_t ws_bytes, mccnn_stream_t stream);
+
+/* The pieces of several geometries at once (extension): what[k] = mask of the pieces of geoms[k] (their buffers attached with
+ * mccnn_geometry_attach). The small plans / lists -- single-workgroup transposition and layout, records evaluated inline -- go
+ * out as one launch per kernel kind over all of them; the rest builds as mccnn_geometry_prebuild does, behind them. Results
+ * identical to mccnn_geometry_prebuild per geometry. Waits for the edge totals. */
+size_t mccnn_geometry_prebuild_batch_ws_bytes(mccnn_geometry_t* const* geoms, const int* what, int count);
+int mccnn_geometry_prebuild_batch(mccnn_geometry_t* const* geoms, const int* what, int count, int avg, void* ws, size_t ws_bytes,
+                                  mccnn_stream_t stream);
 /* One layer over a geometry: SpatialConv / SpatialConvGrad INCLUDING sort_features / its gradient
  * (MCConvModuleSrc:35-45,70-81). feats [n, num_in_feats] and feat_grad are rows of the UNSORTED points (f32, or bf16
  * with bf16 != 0: depth-wise layers, num_in_feats % 8 == 0); out [m, combin ? num_out_feats : num_in_feats].

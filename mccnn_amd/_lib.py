@@ -40,6 +40,8 @@ SIGNATURES = {
     "mccnn_hierarchy_level_workspace_bytes": (_sz, [_i, _i, _i]),
     "mccnn_hierarchy_level": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _f, _i, _i] + [_vp] * 9 + [_vp, _sz, _vp]),
     "mccnn_geometry_build_batch": (_i, [_vp, _i, _vp]),
+    "mccnn_geometry_prebuild_batch_ws_bytes": (_sz, [_vp, _vp, _i]),
+    "mccnn_geometry_prebuild_batch": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
     "mccnn_build_grid_workspace_bytes": (_sz, [_i, _i, _i]),
     "mccnn_build_grid": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mccnn_transform_indexs_dn": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),

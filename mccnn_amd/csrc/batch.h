@@ -33,6 +33,35 @@ struct PdfItem {
 };
 struct PdfBatch { PdfItem it[MCCNN_BATCH_MAX]; };
 
+// ---- small row plans of a step (mccnn_geometry_prebuild_batch): transposition, layout and fill of every small list as one
+// launch each. (12 items per launch: the fill's item carries the geometry an inline record is evaluated from.)
+#define MCCNN_PLAN_BATCH_MAX 12
+struct TrSmallItem { const int2* packed; int* cnt; int* slot; int* tmp; int* startT; int* permT; int e, n; };
+struct TrSmallBatch { TrSmallItem it[MCCNN_BATCH_MAX]; };
+struct PlanSmallItem { const int* rowStart; const int* order; int* vrow; int* vcode; int* sliceOff; int* vposRow; int rows, e, L, S; };
+struct PlanSmallBatch { PlanSmallItem it[MCCNN_BATCH_MAX]; };
+struct SellFillItem {
+    // the list and its geometry (records are evaluated inline: conv_mfma.h edge_record)
+    const float* pts; const int* bids; const float* pdfs; const float* samples; const int* start; const int2* packed;
+    const float* mn; const float* mx;
+    const int* rowStart; const int* permT;
+    // the plan
+    const int* vrow; const int* vcode; const int* sliceOff; const int* vposRow; float4* rec; int* oth;
+    long long cap;
+    int n, m, e, B, scaleInv, avg, rows, S, L, chunks;
+    float radius;
+};
+struct SellFillBatch { SellFillItem it[MCCNN_PLAN_BATCH_MAX]; };
+// the transposition of a list too long for one workgroup: count -> prefix sum (scan.hip's batch form) -> fill -> rank
+struct TrChainItem { const int2* packed; int* cnt; int* slot; int* tmp; int* startT; int* permT; int e, n, lds; };
+struct TrChainBatch { TrChainItem it[MCCNN_BATCH_MAX]; };
+int tr_chain_item(TrChainItem& t, ScanItem& sc, ClearSpan& head, const int* packed, int e, int n, int* start_t, int* perm_t, void* ws,
+                  size_t ws_bytes);                                                                 // conv.hip (ws: mccnn_transpose_neighbors_workspace_bytes)
+int launch_tr_chain_batch(const TrChainBatch& tb, int count, int phase, hipStream_t s);            // 0 count, 1 fill, 2 rank
+int launch_tr_small_batch(const TrSmallBatch& tb, int count, hipStream_t s);                       // conv.hip
+int launch_plan_small_batch(const PlanSmallBatch& pb, int count, hipStream_t s);                   // conv_rows.hip
+int launch_sell_fill_batch(const SellFillBatch& fb, int count, int transposed, hipStream_t s);     // conv_rows.hip
+
 bool grid_batch_eligible(int n, int batch_size, int num_cells);
 int grid_batch_item(GridItem& g, ScanItem& sc, ClearSpan& head, const float* pts, const int* batch_ids, const float* aabb_min,
                     const float* aabb_max, int n, int batch_size, int num_cells, int* new_idx, float* out_pts,

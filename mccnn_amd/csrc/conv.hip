@@ -14,6 +14,7 @@
 //   conv_fwd_valu / conv_bwd_valu   fallback for nb > MCCNN_LDS_MAX_NB: scalar-loaded weights, fmaf chains, LDS tile
 //   conv_f1.hip      combin layers with ONE input feature take the factored kernels there
 #include "conv_mfma.h"
+#include "batch.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -795,14 +796,92 @@ __global__ __launch_bounds__(256) void tr_rank(const int2* __restrict__ packed, 
     permT[s0 + r] = v;
 }
 
+// ---- the three kernels above over a BATCH of lists (mccnn_geometry_prebuild_batch): one launch per phase
+__global__ __launch_bounds__(256) void tr_count_batch(TrChainBatch tb, BatchBlocks bb) {
+    __shared__ int bins[MCCNN_TR_LDS_BINS];
+    int local, blocks;
+    const TrChainItem& c = tb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    const int t = local * 256 + threadIdx.x;
+    if (!c.lds) {
+        if (t < c.e) c.slot[t] = atomicAdd(&c.cnt[c.packed[t].x], 1);
+        return;
+    }
+    for (int j = threadIdx.x; j < c.n; j += 256) bins[j] = 0;
+    __syncthreads();
+    int j = -1, loc = 0;
+    if (t < c.e) {
+        j = c.packed[t].x;
+        loc = atomicAdd(&bins[j], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < c.n; k += 256) {
+        const int v = bins[k];
+        if (v) bins[k] = atomicAdd(&c.cnt[k], v);
+    }
+    __syncthreads();
+    if (t < c.e) c.slot[t] = bins[j] + loc;
+}
+__global__ __launch_bounds__(256) void tr_fill_batch(TrChainBatch tb, BatchBlocks bb) {
+    int local, blocks;
+    const TrChainItem& c = tb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    const int t = xcd_contiguous(local, blocks) * 256 + threadIdx.x;
+    if (t < c.e) c.tmp[c.startT[c.packed[t].x] + c.slot[t]] = t;
+}
+__global__ __launch_bounds__(256) void tr_rank_batch(TrChainBatch tb, BatchBlocks bb) {
+    int local, blocks;
+    const TrChainItem& c = tb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    const int p = xcd_contiguous(local, blocks) * 256 + threadIdx.x;
+    if (p >= c.e) return;
+    const int v = c.tmp[p];
+    const int j = c.packed[v].x;
+    const int s0 = c.startT[j], s1 = c.startT[j + 1];
+    int r = 0;
+    int q = s0;
+    for (; q + 4 <= s1; q += 4) {
+        int a0 = c.tmp[q], a1 = c.tmp[q + 1], a2 = c.tmp[q + 2], a3 = c.tmp[q + 3];
+        r += (a0 < v) + (a1 < v) + (a2 < v) + (a3 < v);
+    }
+    for (; q < s1; ++q) r += (c.tmp[q] < v) ? 1 : 0;
+    c.permT[s0 + r] = v;
+}
+int tr_chain_item(TrChainItem& t, ScanItem& sc, ClearSpan& head, const int* packed, int e, int n, int* start_t, int* perm_t, void* ws,
+                  size_t ws_bytes) {
+    if (e <= 0 || n <= 0 || (long long)n > 2048LL * 1024 || !start_t || !perm_t) return MCCNN_E_BADARG;
+    if (!ws || ws_bytes < mccnn_transpose_neighbors_workspace_bytes(n, e)) return MCCNN_E_WORKSPACE;
+    Arena ar(ws, ws_bytes);
+    const size_t cntBytes = align_up((size_t)n * 4);
+    char* blk = ar.take<char>(cntBytes + scan_workspace_bytes(n));
+    int* slot = ar.take<int>((size_t)e);
+    int* tmp = ar.take<int>((size_t)e);
+    if (!blk || !slot || !tmp) return MCCNN_E_WORKSPACE;
+    const int tiles = ceil_div(n, 2048);
+    t = TrChainItem{reinterpret_cast<const int2*>(packed), (int*)blk, slot, tmp, start_t, perm_t, e, n,
+                    (n <= MCCNN_TR_LDS_BINS && e >= 4 * n) ? 1 : 0};
+    sc = ScanItem{(const int*)blk, start_t, reinterpret_cast<unsigned long long*>(blk + cntBytes), start_t + n, nullptr, n, tiles};
+    head = clear_span(blk, cntBytes + align_up((size_t)(tiles + 1) * 8));
+    return 0;
+}
+int launch_tr_chain_batch(const TrChainBatch& tb, int count, int phase, hipStream_t s) {
+    BatchBlocks bb;
+    bb.count = count;
+    int run = 0;
+    for (int k = 0; k < count; ++k) { bb.first[k] = run; run += ceil_div(tb.it[k].e, 256); }
+    for (int k = count; k <= MCCNN_BATCH_MAX; ++k) bb.first[k] = run;
+    if (run == 0) return 0;
+    if (phase == 0) tr_count_batch<<<run, 256, 0, s>>>(tb, bb);
+    else if (phase == 1) tr_fill_batch<<<run, 256, 0, s>>>(tb, bb);
+    else tr_rank_batch<<<run, 256, 0, s>>>(tb, bb);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+
 // The whole transposition of a SMALL list in one workgroup of 1024 threads (memset, tr_count, scan, tr_fill, tr_rank: five
 // launches for a few microseconds of work on the coarse levels of a hierarchy; the host pays ~6 us to issue each).
 #define MCCNN_TR_SMALL_E 8192
 #define MCCNN_TR_SMALL_N 8192
-__global__ __launch_bounds__(1024) void tr_small(const int2* __restrict__ packed, int e, int n, int* __restrict__ cnt,
-                                                 int* __restrict__ slot, int* __restrict__ tmp, int* __restrict__ startT,
-                                                 int* __restrict__ permT) {
-    __shared__ int wsum[17];
+__device__ __forceinline__ void tr_small_body(const int2* __restrict__ packed, int e, int n, int* __restrict__ cnt,
+                                              int* __restrict__ slot, int* __restrict__ tmp, int* __restrict__ startT,
+                                              int* __restrict__ permT, int* wsum /* LDS, 17 */) {
     const int t = threadIdx.x;
     for (int j = t; j < n; j += 1024) cnt[j] = 0;
     __syncthreads();
@@ -828,6 +907,24 @@ __global__ __launch_bounds__(1024) void tr_small(const int2* __restrict__ packed
         for (int q = s0; q < s1; ++q) r += (tmp[q] < v) ? 1 : 0;
         permT[s0 + r] = v;
     }
+}
+__global__ __launch_bounds__(1024) void tr_small(const int2* __restrict__ packed, int e, int n, int* __restrict__ cnt,
+                                                 int* __restrict__ slot, int* __restrict__ tmp, int* __restrict__ startT,
+                                                 int* __restrict__ permT) {
+    __shared__ int wsum[17];
+    tr_small_body(packed, e, n, cnt, slot, tmp, startT, permT, wsum);
+}
+// ... of a BATCH of small lists (mccnn_geometry_prebuild_batch): one workgroup per list, one launch
+__global__ __launch_bounds__(1024) void tr_small_batch(TrSmallBatch tb) {
+    __shared__ int wsum[17];
+    const TrSmallItem& t = tb.it[blockIdx.x];
+    tr_small_body(t.packed, t.e, t.n, t.cnt, t.slot, t.tmp, t.startT, t.permT, wsum);
+}
+int launch_tr_small_batch(const TrSmallBatch& tb, int count, hipStream_t s) {
+    if (count <= 0) return 0;
+    tr_small_batch<<<count, 1024, 0, s>>>(tb);
+    MCCNN_LAUNCHED();
+    return 0;
 }
 
 // combin layers: featGrad[j, f] += dfE[e, f] (one atomic per edge and input feature)

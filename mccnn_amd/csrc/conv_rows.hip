@@ -17,6 +17,7 @@
 // padding is ~4 % on the 100k-point room at sigma = 1024 (31 % unsorted).
 #include "conv_mfma.h"
 #include "chain.h"
+#include "batch.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -173,9 +174,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void vr_scan_expand(const int* __rest
 // search over the rows' first virtual-row ids -- so that a list of 73 rows with 150 pieces each is expanded by 1024
 // threads, not by 73 (the per-row loop of the first version took 52 us on such a list); slice lengths by one wave per
 // slice, offsets by a serial pass over <= 65 slices. No sort: the slices keep the visiting order.
-__global__ __launch_bounds__(1024) void plan_small(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
-                                                   int L, int S, int* __restrict__ vrow, int* __restrict__ vcode,
-                                                   int* __restrict__ sliceOff, int* __restrict__ vposRow) {
+__device__ __forceinline__ void plan_small_body(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
+                                                int L, int S, int* __restrict__ vrow, int* __restrict__ vcode,
+                                                int* __restrict__ sliceOff, int* __restrict__ vposRow) {
     __shared__ int posV0[MCCNN_PLAN_SMALL + 1];  // row position -> first virtual row id (exclusive prefix of the pieces)
     __shared__ int posRow[MCCNN_PLAN_SMALL];     // row position -> row id
     __shared__ int lens[MCCNN_PLAN_SMALL + 64];  // virtual row -> length
@@ -242,6 +243,16 @@ __global__ __launch_bounds__(1024) void plan_small(const int* __restrict__ rowSt
         for (int sl = 0; sl < S; ++sl) { sliceOff[sl] = run; run += slen[sl]; }
         sliceOff[S] = run;
     }
+}
+__global__ __launch_bounds__(1024) void plan_small(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
+                                                   int L, int S, int* __restrict__ vrow, int* __restrict__ vcode,
+                                                   int* __restrict__ sliceOff, int* __restrict__ vposRow) {
+    plan_small_body(rowStart, rows, e, order, L, S, vrow, vcode, sliceOff, vposRow);
+}
+// ... of a BATCH of small lists: one workgroup per plan, one launch
+__global__ __launch_bounds__(1024) void plan_small_batch(PlanSmallBatch pb) {
+    const PlanSmallItem& t = pb.it[blockIdx.x];
+    plan_small_body(t.rowStart, t.rows, t.e, t.order, t.L, t.S, t.vrow, t.vcode, t.sliceOff, t.vposRow);
 }
 
 // One workgroup per window of SELL_SIGMA virtual rows: a STABLE sort by descending length (ties keep the visiting order) ->
@@ -375,15 +386,14 @@ __device__ __forceinline__ int fresh_lane() {
 // INL: the records are computed here from the geometry instead of permuted from the edge-order array -- small lists, where
 // the extra launch and buffer of mccnn_edge_records cost more than evaluating every record twice (once per plan).
 template <bool TR, bool INL>
-__global__ __launch_bounds__(256) void sell_fill(const float4* __restrict__ recE, const int2* __restrict__ packed, int e,
-                                                 const int* __restrict__ rowStart, int rows, const int* __restrict__ permT,
-                                                 RowPlan p, long long cap, float4* __restrict__ rec, int* __restrict__ oth,
-                                                 int L, ConvArgs a) {
+__device__ __forceinline__ void sell_fill_body(const int slice, const int by, const float4* __restrict__ recE, const int2* __restrict__ packed, int e,
+                                               const int* __restrict__ rowStart, int rows, const int* __restrict__ permT,
+                                               const RowPlan& p, long long cap, float4* __restrict__ rec, int* __restrict__ oth,
+                                               int L, const ConvArgs& a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slice = blockIdx.x;
     const int off = p.sliceOff[slice];
     const int len = (p.sliceOff[slice + 1] - off) >> 6;
-    const int it0 = blockIdx.y * MCCNN_FILL_CHUNK + wave * (MCCNN_FILL_CHUNK / 4);
+    const int it0 = by * MCCNN_FILL_CHUNK + wave * (MCCNN_FILL_CHUNK / 4);
     if (it0 >= len || (long long)off + (long long)len * 64 > cap) return;  // (the bound of plan_sizes makes the latter impossible)
     const int r = p.vrow[slice * 64 + lane];
     int base = 0, deg = 0;
@@ -419,6 +429,24 @@ __global__ __launch_bounds__(256) void sell_fill(const float4* __restrict__ recE
             oth[slot] = real ? (TR ? pr[k].y : pr[k].x) : pad;
         }
     }
+}
+template <bool TR, bool INL>
+__global__ __launch_bounds__(256) void sell_fill(const float4* __restrict__ recE, const int2* __restrict__ packed, int e,
+                                                 const int* __restrict__ rowStart, int rows, const int* __restrict__ permT,
+                                                 RowPlan p, long long cap, float4* __restrict__ rec, int* __restrict__ oth,
+                                                 int L, ConvArgs a) {
+    sell_fill_body<TR, INL>((int)blockIdx.x, (int)blockIdx.y, recE, packed, e, rowStart, rows, permT, p, cap, rec, oth, L, a);
+}
+// ... of a BATCH of small plans (records evaluated inline): one launch for all forward plans, one for all transposed ones
+template <bool TR>
+__global__ __launch_bounds__(256) void sell_fill_batch(SellFillBatch fb, BatchBlocks bb) {
+    int local, blocks;
+    const SellFillItem& t = fb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    ConvArgs a = {};
+    a.pts = t.pts; a.bids = t.bids; a.pdfs = t.pdfs; a.samples = t.samples; a.start = t.start; a.packed = t.packed; a.mn = t.mn; a.mx = t.mx;
+    a.n = t.n; a.m = t.m; a.e = t.e; a.radius = t.radius; a.invRadius = 1.0f / t.radius; a.scaleInv = t.scaleInv; a.avg = t.avg; a.B = t.B;
+    const RowPlan p = {t.vrow, t.vcode, t.sliceOff, t.vposRow, nullptr, nullptr, t.rows, t.S};
+    sell_fill_body<TR, true>(local % t.S, local / t.S, nullptr, t.packed, t.e, t.rowStart, t.rows, t.permT, p, t.cap, t.rec, t.oth, t.L, a);
 }
 
 // ------------------------------------------------------------------------------------------------ scatter fill (transposed plan)
@@ -1068,6 +1096,74 @@ int conv_fill_args(ConvArgs& a, const float* sorted_pts, const float* sorted_fea
                    const float* aabb_min, const float* aabb_max, const float* w1, const float* b1, const float* w2,
                    const float* b2, const float* w3, const float* b3, int n, int m, int e, int Fin, int Fout, int combin,
                    int batch_size, float radius, int scale_inv, int avg);
+
+// (the same rule as plan_inline_records below)
+static bool plan_inline_records_fwd(int rows, int e) { return plan_sizes(rows, e).small && e <= 262144; }
+int launch_plan_small_batch(const PlanSmallBatch& pb, int count, hipStream_t s) {
+    if (count <= 0) return 0;
+    plan_small_batch<<<count, 1024, 0, s>>>(pb);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+int launch_sell_fill_batch(const SellFillBatch& fb, int count, int transposed, hipStream_t s) {
+    BatchBlocks bb;
+    bb.count = count;
+    int run = 0;
+    for (int k = 0; k < count; ++k) { bb.first[k] = run; run += fb.it[k].S * fb.it[k].chunks; }
+    for (int k = count; k <= MCCNN_BATCH_MAX; ++k) bb.first[k] = run;
+    if (run == 0) return 0;
+    if (transposed) sell_fill_batch<true><<<run, 256, 0, s>>>(fb, bb);
+    else sell_fill_batch<false><<<run, 256, 0, s>>>(fb, bb);
+    MCCNN_LAUNCHED();
+    return 0;
+}
+// whether the plan of (rows, e) -- transposed over n points when `transposed` -- is one of the small ones the batch form takes:
+// single-workgroup layout, records evaluated inline, single-workgroup transposition
+bool transpose_small(int e, int n);
+bool plan_batchable(int rows, int e, int transposed) {
+    if (rows <= 0 || e <= 0) return false;
+    const PlanSizes z = plan_sizes(rows, e);
+    (void)transposed;   // (the transposition of a list too long for one workgroup is a batch chain of its own: conv.hip tr_chain_item)
+    return z.small && plan_inline_records_fwd(rows, e);
+}
+// the items of one small plan into the three batches; `tws`: cnt [n] | slot [e] | tmp [e] of the transposition (transposed only)
+size_t plan_batch_tr_ws_bytes(int n, int e) { return align_up((size_t)(n > 0 ? n : 1) * 4) + 2 * align_up((size_t)(e > 0 ? e : 1) * 4); }
+int plan_batch_items(int transposed, const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs, const float* samples,
+                     const int* start_idx, const int* packed, const float* aabb_min, const float* aabb_max, int n, int m, int e,
+                     int batch_size, float radius, int scale_inv, int avg, const int* order, int* start_t, int* perm_t,
+                     int tlist_ready, void* plan_buffer, void* tws, size_t tws_bytes, TrSmallItem* tr /* may stay unused */,
+                     bool* use_tr, PlanSmallItem& lay, SellFillItem& fill) {
+    const int rows = transposed ? n : m;
+    if (!plan_batchable(rows, e, transposed)) return MCCNN_E_BADARG;
+    long long off[6], total, cap, srows;
+    int S;
+    int rc = mccnn_rowplan_buffer(rows, e, off, &total, &S, &cap, &srows);
+    if (rc) return rc;
+    char* base = reinterpret_cast<char*>(plan_buffer);
+    int* vrow = reinterpret_cast<int*>(base + off[0]);
+    int* vcode = reinterpret_cast<int*>(base + off[1]);
+    int* sliceOff = reinterpret_cast<int*>(base + off[2]);
+    int* vposRow = reinterpret_cast<int*>(base + off[3]);
+    int* other = reinterpret_cast<int*>(base + off[4]);
+    float4* rec = reinterpret_cast<float4*>(base + off[5]);
+    const PlanSizes z = plan_sizes(rows, e);
+    *use_tr = false;
+    if (transposed && !tlist_ready && tr) {   // (tr == nullptr: the caller transposes the list by a chain of its own, ahead of the layout)
+        if (!tws || tws_bytes < plan_batch_tr_ws_bytes(n, e) || !start_t || !perm_t) return MCCNN_E_WORKSPACE;
+        char* w = reinterpret_cast<char*>(tws);
+        int* cnt = reinterpret_cast<int*>(w);
+        int* slot = reinterpret_cast<int*>(w + align_up((size_t)n * 4));
+        int* tmp = reinterpret_cast<int*>(w + align_up((size_t)n * 4) + align_up((size_t)e * 4));
+        *tr = TrSmallItem{reinterpret_cast<const int2*>(packed), cnt, slot, tmp, start_t, perm_t, e, n};
+        *use_tr = true;
+    }
+    const int* rowStart = transposed ? start_t : start_idx;
+    lay = PlanSmallItem{rowStart, transposed ? nullptr : order, vrow, vcode, sliceOff, vposRow, rows, e, z.L, z.S};
+    fill = SellFillItem{sorted_pts, sorted_batch_ids, pdfs, samples, start_idx, reinterpret_cast<const int2*>(packed), aabb_min, aabb_max,
+                        rowStart, transposed ? perm_t : nullptr, vrow, vcode, sliceOff, vposRow, rec, other, z.slots,
+                        n, m, e, batch_size, scale_inv, avg, rows, z.S, z.L, ceil_div(z.L, MCCNN_FILL_CHUNK), radius};
+    return 0;
+}
 
 static int bwd_rows_spw(int S, int nb, int rows, int e) {
     // workgroups are dispatched as slots free up: >= ~12 rounds of the 2048 resident waves keep the tail below one

@@ -32,6 +32,15 @@ ClearSpan visiting_order_head_span(int m, int batch_size, int num_cells, void* w
 int visiting_order(const float* pts, const int* batch_ids, const float* aabb_min, const float* aabb_max, int m, int batch_size,
                    int num_cells, int* order, void* ws, size_t ws_bytes, hipStream_t s, bool cleared);
 // neighbors.hip: count + (scan) + fill; lists of few centres scan their counts inside the fill pass
+// conv_rows.hip: small row plans as batch items
+bool plan_batchable(int rows, int e, int transposed);
+size_t plan_batch_tr_ws_bytes(int n, int e);
+int plan_batch_items(int transposed, const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs, const float* samples,
+                     const int* start_idx, const int* packed, const float* aabb_min, const float* aabb_max, int n, int m, int e,
+                     int batch_size, float radius, int scale_inv, int avg, const int* order, int* start_t, int* perm_t,
+                     int tlist_ready, void* plan_buffer, void* tws, size_t tws_bytes, TrSmallItem* tr, bool* use_tr,
+                     PlanSmallItem& lay, SellFillItem& fill);
+bool transpose_small(int e, int n);
 int find_neighbors_chain(const float* centres, const int* centre_batch_ids, int m, const float* sorted_pts, int n,
                          const int* cell_indexs, const float* aabb_min, const float* aabb_max, int batch_size, int num_cells,
                          float radius, int scale_inv, const int* centre_order, int* start_idx, int e_capacity, int* packed,
@@ -624,6 +633,161 @@ int mccnn_geometry_prebuild(mccnn_geometry_t* g, int what, int avg, void* ws, si
     if (!rc && (what & NEED_PLAN_TR)) rc = ensure_plan(g, 1, e, avg, ws, ws_bytes, stream);
     if (!rc && (what & NEED_TLIST)) rc = ensure_tlist(g, e, ws, ws_bytes, stream);
     return rc;
+}
+
+// The pieces of SEVERAL geometries at once (the row plans / transposed lists a step's layers will ask for, built ahead): the
+// small ones -- single-workgroup transposition, single-workgroup layout, records evaluated inline: most plans of a network's
+// coarse levels -- go out as one launch per kernel kind over all of them (tr_small, plan_small, sell_fill forward, sell_fill
+// transposed: four launches where a step of BASELINE cfg4 had ~40); everything else takes its own chain behind them.
+// ws: mccnn_geometry_prebuild_batch_ws_bytes. Waits for the edge totals.
+size_t mccnn_geometry_prebuild_batch_ws_bytes(mccnn_geometry_t* const* geoms, const int* what, int count) {
+    if (!geoms || !what || count < 0) return 0;
+    size_t single = 256, trs = 0;
+    for (int k = 0; k < count; ++k) {
+        mccnn_geometry_t* g = geoms[k];
+        if (!g || !g->built) return 0;
+        const int e = wait_edges(g, -1);
+        if (e <= 0 || e > g->e_cap) continue;
+        for (int bit = 1; bit <= 4; bit <<= 1) {
+            if (!(what[k] & bit)) continue;
+            long long b = 0, w = 0;
+            if (mccnn_geometry_piece_bytes(g, bit, &b, &w) == 0 && (size_t)w > single) single = (size_t)w;
+        }
+        if ((what[k] & 6) && !g->tl_built)
+            trs += transpose_small(e, g->n) ? al(plan_batch_tr_ws_bytes(g->n, e)) : al(mccnn_transpose_neighbors_workspace_bytes(g->n, e));
+    }
+    return al(single) + trs + 512;
+}
+
+int mccnn_geometry_prebuild_batch(mccnn_geometry_t* const* geoms, const int* what, int count, int avg, void* ws, size_t ws_bytes,
+                                  mccnn_stream_t stream) {
+    if (!geoms || !what || count < 0 || !ws) return MCCNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    avg = avg ? 1 : 0;
+    Arena ar(ws, ws_bytes);
+    // the region the individual builds share (one after the other, stream-ordered) comes first
+    size_t single = 256;
+    for (int k = 0; k < count; ++k) {
+        mccnn_geometry_t* g = geoms[k];
+        if (!g || !g->built) return MCCNN_E_BADARG;
+        const int e = wait_edges(g, -1);
+        if (e < 0) return MCCNN_E_BADARG;
+        if (e == 0 || e > g->e_cap) continue;
+        for (int bit = 1; bit <= 4; bit <<= 1) {
+            if (!(what[k] & bit)) continue;
+            long long b = 0, w = 0;
+            if (mccnn_geometry_piece_bytes(g, bit, &b, &w) == 0 && (size_t)w > single) single = (size_t)w;
+        }
+    }
+    char* sws = ar.take<char>(al(single));
+    if (!sws) return MCCNN_E_WORKSPACE;
+    TrSmallBatch trB;
+    TrChainBatch chB;
+    ScanBatch chScan;
+    SpanBatch chSpans;
+    chSpans.count = 0;
+    PlanSmallBatch layB;
+    SellFillBatch fwdB, trfB;
+    int nTr = 0, nCh = 0, nLay = 0, nFwd = 0, nTrf = 0;
+    auto flush = [&]() -> int {
+        int rc = 0;
+        if (nCh) {   // transpositions too long for one workgroup: head clear, count, prefix sums, fill, rank -- one launch each
+            rc = launch_clear_batch(chSpans, s);
+            if (!rc) rc = launch_tr_chain_batch(chB, nCh, 0, s);
+            if (!rc) rc = launch_scan_batch(chScan, nCh, s);
+            if (!rc) rc = launch_tr_chain_batch(chB, nCh, 1, s);
+            if (!rc) rc = launch_tr_chain_batch(chB, nCh, 2, s);
+        }
+        if (!rc) rc = launch_tr_small_batch(trB, nTr, s);
+        if (!rc) rc = launch_plan_small_batch(layB, nLay, s);
+        if (!rc) rc = launch_sell_fill_batch(fwdB, nFwd, 0, s);
+        if (!rc) rc = launch_sell_fill_batch(trfB, nTrf, 1, s);
+        nTr = nCh = nLay = nFwd = nTrf = 0;
+        chSpans.count = 0;
+        return rc;
+    };
+    // the transposed list of g, by the batch: single-workgroup form or chain item; false = not possible here
+    auto batch_tlist = [&](mccnn_geometry_t* g, int e) -> int {
+        if (transpose_small(e, g->n)) {
+            char* w = ar.take<char>(al(plan_batch_tr_ws_bytes(g->n, e)));
+            if (!w) return MCCNN_E_WORKSPACE;
+            trB.it[nTr++] = TrSmallItem{reinterpret_cast<const int2*>(g->packed), reinterpret_cast<int*>(w),
+                                        reinterpret_cast<int*>(w + al((size_t)g->n * 4)),
+                                        reinterpret_cast<int*>(w + al((size_t)g->n * 4) + al((size_t)e * 4)), tl_start(g), tl_perm(g), e, g->n};
+            return 0;
+        }
+        const size_t wb = al(mccnn_transpose_neighbors_workspace_bytes(g->n, e));
+        char* w = ar.take<char>(wb);
+        if (!w) return MCCNN_E_WORKSPACE;
+        ClearSpan head;
+        int rc = tr_chain_item(chB.it[nCh], chScan.it[nCh], head, g->packed, e, g->n, tl_start(g), tl_perm(g), w, wb);
+        if (rc) return rc;
+        chSpans.sp[chSpans.count++] = head;
+        ++nCh;
+        return 0;
+    };
+    struct Later { mccnn_geometry_t* g; int what; };
+    Later later[256];
+    int nLater = 0;
+    for (int k = 0; k < count; ++k) {
+        mccnn_geometry_t* g = geoms[k];
+        const int e = g->e;
+        if (e <= 0 || e > g->e_cap) continue;   // (an overflowing list is rebuilt by its first layer: nothing to build ahead)
+        const mccnn_geometry* go = grid_owner(g);
+        int rest = what[k] & 7;
+        if (nLay + 2 > MCCNN_PLAN_BATCH_MAX || nTr + 1 > MCCNN_PLAN_BATCH_MAX || nCh + 1 > MCCNN_PLAN_BATCH_MAX) {
+            int rc = flush();
+            if (rc) return rc;
+        }
+        const bool tl_room = g->tl_buf && g->tl_bytes >= tlist_bytes(g->n, e) && (long long)g->n <= 2048LL * 1024;
+        // the transposed list: on its own (a combin layer's deterministic feature gradient) or under a small transposed plan
+        const bool tr_plan_small = (rest & 2) && plan_batchable(g->n, e, 1) && !(g->plan[1].built && g->plan[1].avg == avg);
+        if (((rest & 4) || tr_plan_small) && !g->tl_built && tl_room && (!(rest & 2) || tr_plan_small)) {
+            int rc = batch_tlist(g, e);
+            if (rc) return rc;
+            g->tl_built = true;
+        }
+        if (g->tl_built) rest &= ~4;
+        for (int tr = 0; tr < 2; ++tr) {
+            const int bit = tr ? 2 : 1;
+            if (!(rest & bit)) continue;
+            Plan& p = g->plan[tr];
+            if (p.built && p.avg == avg) { rest &= ~bit; continue; }
+            const int rows = tr ? g->n : g->m;
+            if (!plan_batchable(rows, e, tr)) continue;
+            if (plan_prepare(g, tr, e)) continue;
+            if (!p.buf || p.bytes < (size_t)p.total) continue;
+            if (tr && (!g->tl_buf || g->tl_bytes < tlist_bytes(g->n, e))) continue;
+            if (tr && !g->tl_built) continue;   // (no room for the list: the individual chain below reports it)
+            const int* order = tr ? nullptr : (g->same_level ? go->inv_idx : (g->order ? g->order : nullptr));
+            bool use_tr = false;
+            SellFillItem& fi = tr ? trfB.it[nTrf] : fwdB.it[nFwd];
+            int rc = plan_batch_items(tr, go->s_pts, go->s_bids, g->pdfs, g->centres, g->start, g->packed, g->mn, g->mx, g->n, g->m, e, g->B,
+                                      g->radius, g->scale_inv, avg, order, tr ? tl_start(g) : nullptr, tr ? tl_perm(g) : nullptr,
+                                      1 /* the list: transposed above, ahead of every layout of this flush */, p.buf, nullptr, 0, nullptr,
+                                      &use_tr, layB.it[nLay], fi);
+            if (rc) continue;   // (left to the individual chain below)
+            ++nLay;
+            if (tr) ++nTrf; else ++nFwd;
+            if (tr) g->tl_built = true;
+            p.built = true;
+            p.avg = avg;
+            rest &= ~bit;
+            if (tr) rest &= ~4;
+        }
+        if (rest && nLater < 256) later[nLater++] = Later{g, rest};
+    }
+    int rc = flush();
+    if (rc) return rc;
+    for (int k = 0; k < nLater; ++k) {   // the large ones (and what did not fit): their own chains, one after the other
+        mccnn_geometry_t* g = later[k].g;
+        const int e = g->e, w = later[k].what;
+        if (w & NEED_PLAN_FWD) rc = ensure_plan(g, 0, e, avg, sws, al(single), stream);
+        if (!rc && (w & NEED_PLAN_TR)) rc = ensure_plan(g, 1, e, avg, sws, al(single), stream);
+        if (!rc && (w & NEED_TLIST)) rc = ensure_tlist(g, e, sws, al(single), stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // What one mccnn_conv_forward / _backward call of this layer shape needs from the caller: which pieces the geometry does

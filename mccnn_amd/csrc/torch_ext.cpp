@@ -538,11 +538,19 @@ struct BatchEntry {
     std::shared_ptr<Geo> g, grid_from;
     mccnn_geometry_request req;
 };
+struct PieceEntry {   // row plans / transposed list of a batched geometry whose list is small: built as a batch as well
+    std::shared_ptr<Geo> g;
+    int what;
+    bool avg;
+    char* base;
+    long long off[4], len[4];
+};
 struct GeoBatch {
     bool active = false;
     int side = -1;
     bool background = false;
     std::vector<BatchEntry> entries;
+    std::vector<PieceEntry> pieces;
 };
 thread_local GeoBatch t_geo_batch;
 void begin_geometry_batch() {
@@ -550,6 +558,7 @@ void begin_geometry_batch() {
     t_geo_batch.active = on && Issuer::enabled();
     t_geo_batch.side = -1;
     t_geo_batch.entries.clear();
+    t_geo_batch.pieces.clear();
 }
 void end_geometry_batch() {
     GeoBatch& b = t_geo_batch;
@@ -581,6 +590,66 @@ void end_geometry_batch() {
             e.g->build_rc = r;
             e.g->issued.store(1, std::memory_order_release);
         }
+    });
+    if (b.pieces.empty()) return;
+    // ... and the pieces of the small lists among them: ONE job, one launch per kernel kind (mccnn_geometry_prebuild_batch)
+    auto pieces = std::make_shared<std::vector<PieceEntry>>(std::move(b.pieces));
+    b.pieces.clear();
+    const int pside = (*pieces)[0].g->plan_side;
+    Issuer::get(2).push([pieces, pside, dev]() mutable {
+        enter_device(dev);
+        hipStream_t ss = side_stream(pside);
+        std::vector<mccnn_geometry_t*> hs;
+        std::vector<int> whats;
+        std::vector<PieceEntry*> live;
+        bool avg = (*pieces)[0].avg;
+        hipEvent_t last = nullptr;
+        for (PieceEntry& pe : *pieces) {
+            Geo& g = *pe.g;
+            g.wait_build_issued_nothrow();
+            if (g.build_rc != 0) continue;
+            const int prev = mccnn_debug_wait_accounting(0);
+            const int E = mccnn_geometry_edges(g.h, -1);
+            mccnn_debug_wait_accounting(prev);
+            if (E >= 0) g.e.store(E, std::memory_order_relaxed);
+            if (E <= 0 || E > g.e_cap) continue;
+            int rc = 0;
+            for (int k = 0; k < 4 && !rc; ++k)
+                if (pe.what & (1 << k)) rc = mccnn_geometry_attach(g.h, 1 << k, pe.base + pe.off[k], (size_t)pe.len[k]);
+            if (rc) continue;   // (left unbuilt: the layer that needs a piece builds it, and reports)
+            g.have |= pe.what;
+            hs.push_back(g.h);
+            whats.push_back(pe.what & 7);
+            live.push_back(&pe);
+            if (g.event) last = g.event;
+        }
+        int rc = 0;
+        if (!hs.empty()) {
+            // behind the builds (one stream, events recorded in order: the last one covers them all)
+            if (last && hipStreamWaitEvent(ss, last, 0) != hipSuccess) rc = (int)hipErrorUnknown;
+            if (!rc) {
+                try {
+                    const size_t wsb = mccnn_geometry_prebuild_batch_ws_bytes(hs.data(), whats.data(), (int)hs.size());
+                    Tensor& ws = scratch(wsb, live[0]->g->buf, (void*)ss);
+                    rc = mccnn_geometry_prebuild_batch(hs.data(), whats.data(), (int)hs.size(), avg ? 1 : 0, ws.data_ptr(), (size_t)ws.numel(), (void*)ss);
+                } catch (const std::exception&) {
+                    rc = (int)hipErrorUnknown;
+                }
+            }
+            for (PieceEntry* pe : live) {
+                Geo& g = *pe->g;
+                if (!rc && (pe->what & 1)) {
+                    if (!g.plan_event) g.plan_event = take_event();
+                    if (hipEventRecord(g.plan_event, ss) == hipSuccess) g.plan_wait = true;
+                }
+                if (!rc && (pe->what & 6)) {
+                    if (!g.tr_event) g.tr_event = take_event();
+                    if (hipEventRecord(g.tr_event, ss) == hipSuccess) g.tr_wait = true;
+                }
+                g.pre_avg = avg ? 1 : 0;
+            }
+        }
+        for (PieceEntry& pe : *pieces) pe.g->pieces_issued.store(1, std::memory_order_release);
     });
 }
 
@@ -759,6 +828,10 @@ void prebuild_async(std::shared_ptr<Geo> g, int what, bool avg) {
         total += (b + 255) / 256 * 256;
         if (w > wsb) wsb = w;
     }
+    // a batched geometry with a small list: its pieces join the batch too, on ONE side stream (the next one after the builds')
+    const bool small_batch = t_geo_batch.active && t_geo_batch.side >= 0 && g->plan_side >= 0 &&
+                             mccnn_rowplan_inline_records(g->m, (int)g->e_cap) && mccnn_rowplan_inline_records(g->n, (int)g->e_cap);
+    if (small_batch) g->plan_side = (t_geo_batch.side + 1) % kSideStreams;
     const bool other = g->plan_side >= 0 && g->plan_side != g->side;   // (a batch build: pieces on another side stream, behind the build's event)
     hipStream_t ss = side_stream(other ? g->plan_side : g->side);
     Tensor block;
@@ -772,6 +845,13 @@ void prebuild_async(std::shared_ptr<Geo> g, int what, bool avg) {
     g->pieces_issued.store(0, std::memory_order_release);
     char* base = (char*)block.data_ptr();
     Tensor like = g->buf;
+    if (small_batch) {
+        PieceEntry pe;
+        pe.g = g; pe.what = what; pe.avg = avg; pe.base = base;
+        for (int k = 0; k < 4; ++k) { pe.off[k] = off[k]; pe.len[k] = len[k]; }
+        t_geo_batch.pieces.push_back(std::move(pe));
+        return;
+    }
     Issuer::get(2).push([g, what, avg, base, off, len, wsb, ss, like, other]() mutable {
         enter_device((int)like.device().index());
         g->wait_build_issued_nothrow();

@@ -554,3 +554,116 @@ def test_batched_geometries_equal_the_single_chains(mc):
         for t0, t1 in zip(x[1:], y[1:]):
             assert torch.equal(t0, t1), k
     assert a[3][6].min() == 1.0 and a[3][6].max() == 1.0   # usePDF = 0: ones
+
+
+@pytest.mark.gpu
+def test_batched_pieces_equal_the_single_chains(mc):
+    """mccnn_geometry_prebuild_batch (the row plans and transposed lists of a step's small lists: one launch per kernel kind
+    -- transposition chain or single-workgroup transposition, layout, slot fill) against mccnn_geometry_prebuild of every
+    geometry on its own: the attached buffers are byte-identical. Lists: tiny (single-workgroup transposition), small plan
+    over a list whose transposition is a chain, a large one (own chain behind the batch), a list without densities; masks
+    1|2|4, 2 alone, 4 alone, 1 alone; both `avg` flags; 14 geometries (two flushes)."""
+    import ctypes as C
+    import torch
+    from mccnn_amd import _lib
+    from mccnn_amd._lib import ptr, check
+    lib = _lib.load()
+    lib.mccnn_geometry_create.restype = C.c_void_p
+    lib.mccnn_geometry_build.argtypes = None
+    lib.mccnn_geometry_prebuild_batch_ws_bytes.restype = C.c_size_t
+    pts, bids = make_cloud(5000, 3, 43, "clustered", True)
+    B = 3
+    P, Bi = _t(pts), _t(bids)
+    rng = np.random.default_rng(5)
+    def sub(k):
+        pick = np.sort(rng.choice(len(pts), k, replace=False))
+        return _t(np.ascontiguousarray(pts[pick])), _t(np.ascontiguousarray(bids[pick]))
+    Mn, Mb = sub(2500)
+    Sn, Sb = sub(400)
+    Tn, Tb = sub(60)
+    mn, mx = mc.compute_aabb(P, Bi, B, True)
+    specs = [  # (points, ids, centres, ids, radius, use_pdf, mask)
+        (Tn, Tb, Tn, Tb, 0.6, 1, 7),      # tiny: tr_small
+        (Mn, Mb, Sn, Sb, 0.25, 1, 7),     # 2 500 rows transposed, list of ~100 k edges: chain transposition under a small plan
+        (Mn, Mb, Mn, Mb, 0.12, 1, 7),     # same level
+        (P, Bi, P, Bi, 0.12, 1, 7),       # large: own chains
+        (Sn, Sb, Sn, Sb, 0.4, 0, 7),      # no densities
+        (Mn, Mb, Sn, Sb, 0.25, 1, 2),     # transposed plan alone (the list comes with it)
+        (Mn, Mb, Sn, Sb, 0.25, 1, 4),     # list alone
+        (Mn, Mb, Sn, Sb, 0.25, 1, 1),     # forward plan alone
+        (Sn, Sb, Tn, Tb, 0.5, 1, 6),
+    ]
+    specs = specs + [specs[1], specs[0], specs[2], specs[8], specs[4]]
+    st = torch.cuda.current_stream().cuda_stream
+
+    def build(batched, avg):
+        keep, handles, pieces, sizes = [], [], [], []
+        slots = torch.empty(len(specs), dtype=torch.int32).pin_memory()
+        for k, (p, b, c, cb, r, up, mask) in enumerate(specs):
+            n, m = p.shape[0], c.shape[0]
+            nc = mc._num_cells(mn, mx, B, r, True)
+            cap = min(900 * m, 4_000_000)
+            nbytes = lib.mccnn_geometry_bytes(n, m, B, nc, cap, 1)
+            buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            h = lib.mccnn_geometry_create()
+            keep.append(buf)
+            handles.append(h)
+            vp = lambda t: C.c_void_p(t.data_ptr())
+            check(lib.mccnn_geometry_build(C.c_void_p(h), vp(p), vp(b), n, vp(c), vp(cb), m, vp(mn), vp(mx), B, nc, C.c_float(r), 1,
+                                           C.c_float(0.25), up, cap, None, C.c_void_p(buf.data_ptr()), C.c_size_t(nbytes),
+                                           C.c_void_p(slots.data_ptr() + 4 * k), C.c_void_p(st)), "geometry_build")
+        torch.cuda.synchronize()
+        wsmax = 256
+        for k, (p, b, c, cb, r, up, mask) in enumerate(specs):
+            e = int(slots[k])
+            assert 0 < e <= min(900 * c.shape[0], 4_000_000), (k, e)
+            sizes.append(e)
+            mine = {}
+            for bit in (1, 2, 4, 8):
+                if not ((mask | 8) & bit):
+                    continue
+                nb, wb = C.c_longlong(0), C.c_longlong(0)
+                check(lib.mccnn_geometry_piece_bytes(C.c_void_p(handles[k]), bit, C.byref(nb), C.byref(wb)), "piece_bytes")
+                wsmax = max(wsmax, wb.value)
+                if bit == 2 and not (mask & 4):   # a transposed plan needs the list
+                    nl = C.c_longlong(0)
+                    check(lib.mccnn_geometry_piece_bytes(C.c_void_p(handles[k]), 4, C.byref(nl), C.byref(wb)), "piece_bytes")
+                    wsmax = max(wsmax, wb.value)
+                    t = torch.zeros(max(nl.value, 256), dtype=torch.uint8, device="cuda")
+                    check(lib.mccnn_geometry_attach(C.c_void_p(handles[k]), 4, C.c_void_p(t.data_ptr()), C.c_size_t(t.numel())), "attach")
+                    mine[4] = t
+                if nb.value <= 0:
+                    continue
+                t = torch.zeros(nb.value, dtype=torch.uint8, device="cuda")
+                check(lib.mccnn_geometry_attach(C.c_void_p(handles[k]), bit, C.c_void_p(t.data_ptr()), C.c_size_t(nb.value)), "attach")
+                mine[bit] = t
+            pieces.append(mine)
+        if batched:
+            hs = (C.c_void_p * len(specs))(*handles)
+            wh = (C.c_int * len(specs))(*[s[6] for s in specs])
+            wsb = lib.mccnn_geometry_prebuild_batch_ws_bytes(hs, wh, len(specs))
+            assert wsb > 0
+            ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+            check(lib.mccnn_geometry_prebuild_batch(hs, wh, len(specs), avg, C.c_void_p(ws.data_ptr()), C.c_size_t(wsb), C.c_void_p(st)),
+                  "geometry_prebuild_batch")
+        else:
+            ws = torch.empty(wsmax, dtype=torch.uint8, device="cuda")
+            for k, s in enumerate(specs):
+                check(lib.mccnn_geometry_prebuild(C.c_void_p(handles[k]), s[6], avg, C.c_void_p(ws.data_ptr()), C.c_size_t(wsmax),
+                                                  C.c_void_p(st)), "geometry_prebuild")
+        torch.cuda.synchronize()
+        out = [{bit: t.cpu() for bit, t in mine.items() if bit != 8} for mine in pieces]
+        for h in handles:
+            lib.mccnn_geometry_destroy(C.c_void_p(h))
+        return sizes, out
+
+    for avg in (0, 1):
+        (ea, a), (eb, b_) = build(False, avg), build(True, avg)
+        assert ea == eb
+        chain = 0
+        for k, (x, y) in enumerate(zip(a, b_)):
+            assert x.keys() == y.keys()
+            for bit in x:
+                assert torch.equal(x[bit], y[bit]), (avg, k, bit, ea[k])
+                assert x[bit].any(), (k, bit)
+        assert ea[0] <= 4096 and ea[1] > 16384 and ea[3] > 262144, ea   # the three regimes were met
