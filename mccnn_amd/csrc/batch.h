@@ -53,11 +53,39 @@ struct SellFillItem {
 };
 struct SellFillBatch { SellFillItem it[MCCNN_PLAN_BATCH_MAX]; };
 // the transposition of a list too long for one workgroup: count -> prefix sum (scan.hip's batch form) -> fill -> rank
-struct TrChainItem { const int2* packed; int* cnt; int* slot; int* tmp; int* startT; int* permT; int e, n, lds; };
+struct TrChainItem { const int2* packed; int* cnt; int* slot; int* tmp; int* startT; int* permT; int e, n, lds, norank /* ranked by the plan's scatter */; };
 struct TrChainBatch { TrChainItem it[MCCNN_BATCH_MAX]; };
 int tr_chain_item(TrChainItem& t, ScanItem& sc, ClearSpan& head, const int* packed, int e, int n, int* start_t, int* perm_t, void* ws,
                   size_t ws_bytes);                                                                 // conv.hip (ws: mccnn_transpose_neighbors_workspace_bytes)
 int launch_tr_chain_batch(const TrChainBatch& tb, int count, int phase, hipStream_t s);            // 0 count, 1 fill, 2 rank
+// a LARGE row plan (every plan plan_small does not lay out): layout (vr_count -> vr_scan_expand -> sell_sort), then the
+// forward plan's tile fill or the transposed plan's bases + scatter (conv_rows.hip build_large has the single-plan chain)
+#define MCCNN_LARGE_BATCH_MAX 8
+struct LargeItem {
+    const int* rowStart; const int* order;
+    int* vcnt; unsigned long long* st1; unsigned long long* st2; int* vlistRow; int* vTotal;
+    int* vrow; int* vcode; int* sliceOff; int* vposRow; int* oth; float4* rec;
+    long long cap;
+    const float* pts; const int* bids; const float* pdfs; const float* samples; const int* start; const int2* packed;
+    const float* mn; const float* mx;
+    float4* recE;                                    // per-edge records in edge order (evaluated here when `eval`)
+    int2* vinfo; const int* startT; const int* tmp; int* permT;   // transposed plans
+    int rows, e, n, m, B, L, S, windows, tiles, scaleInv, avg;
+    int tr, eval /* 0 records ready, 1 evaluate (fwd: in the fill; tr: a pass of its own) */, rank /* tr: the list is ranked in the scatter */;
+    float radius;
+};
+struct LargeBatch { LargeItem it[MCCNN_LARGE_BATCH_MAX]; };
+bool plan_large_batchable(int rows, int e, int n, int transposed, int tlist_ready);                 // conv_rows.hip
+size_t plan_large_ws_bytes(int rows, int e, int n, int transposed, int tlist_ready);
+// -> item + (transposed, list not ready) the chain item of its transposition (*use_chain) + the spans its head has to clear
+int plan_large_item(int transposed, const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs, const float* samples,
+                    const int* start_idx, const int* packed, const float* aabb_min, const float* aabb_max, int n, int m, int e,
+                    int batch_size, float radius, int scale_inv, int avg, const int* order, void* rec_edges, int rec_ready, int* start_t,
+                    int* perm_t, int tlist_ready, void* plan_buffer, void* ws, size_t ws_bytes, LargeItem& it, TrChainItem* tc,
+                    ScanItem* sc, bool* use_chain, SpanBatch& spans);
+enum { LARGE_VR_COUNT = 0, LARGE_VR_SCAN, LARGE_SELL_SORT, LARGE_BASES, LARGE_RECORDS, LARGE_FILL, LARGE_SCATTER };
+int launch_plan_large_batch(const LargeBatch& lb, int count, int phase, hipStream_t s);
+
 int launch_tr_small_batch(const TrSmallBatch& tb, int count, hipStream_t s);                       // conv.hip
 int launch_plan_small_batch(const PlanSmallBatch& pb, int count, hipStream_t s);                   // conv_rows.hip
 int launch_sell_fill_batch(const SellFillBatch& fb, int count, int transposed, hipStream_t s);     // conv_rows.hip

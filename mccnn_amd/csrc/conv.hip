@@ -856,7 +856,7 @@ int tr_chain_item(TrChainItem& t, ScanItem& sc, ClearSpan& head, const int* pack
     if (!blk || !slot || !tmp) return MCCNN_E_WORKSPACE;
     const int tiles = ceil_div(n, 2048);
     t = TrChainItem{reinterpret_cast<const int2*>(packed), (int*)blk, slot, tmp, start_t, perm_t, e, n,
-                    (n <= MCCNN_TR_LDS_BINS && e >= 4 * n) ? 1 : 0};
+                    (n <= MCCNN_TR_LDS_BINS && e >= 4 * n) ? 1 : 0, 0};
     sc = ScanItem{(const int*)blk, start_t, reinterpret_cast<unsigned long long*>(blk + cntBytes), start_t + n, nullptr, n, tiles};
     head = clear_span(blk, cntBytes + align_up((size_t)(tiles + 1) * 8));
     return 0;
@@ -865,7 +865,7 @@ int launch_tr_chain_batch(const TrChainBatch& tb, int count, int phase, hipStrea
     BatchBlocks bb;
     bb.count = count;
     int run = 0;
-    for (int k = 0; k < count; ++k) { bb.first[k] = run; run += ceil_div(tb.it[k].e, 256); }
+    for (int k = 0; k < count; ++k) { bb.first[k] = run; run += (phase == 2 && tb.it[k].norank) ? 0 : ceil_div(tb.it[k].e, 256); }
     for (int k = count; k <= MCCNN_BATCH_MAX; ++k) bb.first[k] = run;
     if (run == 0) return 0;
     if (phase == 0) tr_count_batch<<<run, 256, 0, s>>>(tb, bb);

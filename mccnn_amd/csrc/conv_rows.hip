@@ -101,16 +101,25 @@ static PlanSizes plan_sizes(int rows, int e) {
 
 // ------------------------------------------------------------------------------------------------ layout
 // pieces per row position of the visiting order
-__global__ __launch_bounds__(256) void vr_count(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
-                                                int* __restrict__ vcnt, int L, ClearSpan x1, ClearSpan x2) {
-    clear_span_dev(x1);  // the status words of the two prefix sums that follow in this chain (common.h)
-    clear_span_dev(x2);
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void vr_count_body(int p, const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
+                                              int* __restrict__ vcnt, int L) {
     if (p >= rows) return;
     int r = order ? order[p] : p;
     r = max(0, min(r, rows - 1));
     const int deg = ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
     vcnt[p] = max(1, (deg + L - 1) / L);
+}
+__global__ __launch_bounds__(256) void vr_count(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
+                                                int* __restrict__ vcnt, int L, ClearSpan x1, ClearSpan x2) {
+    clear_span_dev(x1);  // the status words of the two prefix sums that follow in this chain (common.h)
+    clear_span_dev(x2);
+    vr_count_body(blockIdx.x * blockDim.x + threadIdx.x, rowStart, rows, e, order, vcnt, L);
+}
+// (batch form: the status words are cleared by the head launch of the batch)
+__global__ __launch_bounds__(256) void vr_count_batch(LargeBatch lb, BatchBlocks bb) {
+    int local, blocks;
+    const LargeItem& t = lb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    vr_count_body(local * 256 + (int)threadIdx.x, t.rowStart, t.rows, t.e, t.order, t.vcnt, t.L);
 }
 // virtual row id -> row; row -> its first virtual row id
 __global__ __launch_bounds__(256) void vr_expand(const int* __restrict__ rowStart, int rows, int e, const int* __restrict__ order,
@@ -128,15 +137,15 @@ __global__ __launch_bounds__(256) void vr_expand(const int* __restrict__ rowStar
 // vr_expand with the prefix sum of the pieces inside (single pass, decoupled look-back: chain.h) -- the launch between
 // vr_count and vr_expand is gone. Tile = 2048 consecutive row positions of the visiting order; status words (tiles + the
 // ticket) cleared by vr_count, which runs before. vTotal receives the number of virtual rows (sell_sort reads it).
-__global__ __launch_bounds__(SCAN_THREADS) void vr_scan_expand(const int* __restrict__ rowStart, int rows, int e,
-                                                               const int* __restrict__ order, const int* __restrict__ vcnt,
-                                                               unsigned long long* status, int* __restrict__ vposRow,
-                                                               int* __restrict__ vlistRow, int* __restrict__ vTotal) {
+__device__ __forceinline__ void vr_scan_expand_body(const int nblk, const int* __restrict__ rowStart, int rows, int e,
+                                                    const int* __restrict__ order, const int* __restrict__ vcnt,
+                                                    unsigned long long* status, int* __restrict__ vposRow,
+                                                    int* __restrict__ vlistRow, int* __restrict__ vTotal) {
     __shared__ int lds[4];
     __shared__ int sOff;
     __shared__ int sTile;
     if (threadIdx.x == 0)
-        sTile = (int)__hip_atomic_fetch_add(status + gridDim.x, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sTile = (int)__hip_atomic_fetch_add(status + nblk, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int tile = sTile;
     const int base = tile * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
@@ -166,7 +175,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void vr_scan_expand(const int* __rest
         }
         run += v[k];
     }
-    if (tile == (int)gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *vTotal = run;
+    if (tile == nblk - 1 && threadIdx.x == SCAN_THREADS - 1) *vTotal = run;
+}
+__global__ __launch_bounds__(SCAN_THREADS) void vr_scan_expand(const int* __restrict__ rowStart, int rows, int e,
+                                                               const int* __restrict__ order, const int* __restrict__ vcnt,
+                                                               unsigned long long* status, int* __restrict__ vposRow,
+                                                               int* __restrict__ vlistRow, int* __restrict__ vTotal) {
+    vr_scan_expand_body((int)gridDim.x, rowStart, rows, e, order, vcnt, status, vposRow, vlistRow, vTotal);
+}
+__global__ __launch_bounds__(SCAN_THREADS) void vr_scan_expand_batch(LargeBatch lb, BatchBlocks bb) {
+    int local, blocks;
+    const LargeItem& t = lb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    vr_scan_expand_body(blocks, t.rowStart, t.rows, t.e, t.order, t.vcnt, t.st1, t.vposRow, t.vlistRow, t.vTotal);
 }
 
 // The whole layout of a small list in one workgroup of 1024 threads (rows, virtual rows <= MCCNN_PLAN_SMALL): pieces per
@@ -303,11 +323,11 @@ __device__ __forceinline__ void sell_radix_pass(const unsigned* __restrict__ src
 // The slices' first slots (sliceOff = exclusive prefix of the slice lengths, sliceOff[S] = total) come out of the same
 // launch: the windows are chained by a decoupled look-back over their slot totals (chain.h; windows taken from a ticket;
 // status words cleared by vr_count at the head of the layout) -- no prefix-sum launch behind the sort.
-__global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStart, int rows, int e,
-                                                 const int* __restrict__ vlistRow, const int* __restrict__ vposRow,
-                                                 const int* __restrict__ vTotal, int* __restrict__ vrow,
-                                                 int* __restrict__ vcode, int* __restrict__ sliceOff, int L,
-                                                 unsigned long long* status) {
+__device__ __forceinline__ void sell_sort_body(const int nblk, const int* __restrict__ rowStart, int rows, int e,
+                                               const int* __restrict__ vlistRow, const int* __restrict__ vposRow,
+                                               const int* __restrict__ vTotal, int* __restrict__ vrow,
+                                               int* __restrict__ vcode, int* __restrict__ sliceOff, int L,
+                                               unsigned long long* status) {
     __shared__ unsigned key[SELL_SIGMA];
     __shared__ unsigned key2[SELL_SIGMA];
     __shared__ int rowOf[SELL_SIGMA];
@@ -317,7 +337,7 @@ __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStar
     __shared__ int wsum[5];
     __shared__ int sWin, sBase, sLen[SELL_SIGMA / 64];
     if (threadIdx.x == 0)
-        sWin = (int)__hip_atomic_fetch_add(status + gridDim.x, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sWin = (int)__hip_atomic_fetch_add(status + nblk, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int win = sWin;
     const int V = *vTotal;
@@ -366,8 +386,20 @@ __global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStar
         int run = sBase;
         for (int g = 0; g < (int)threadIdx.x; ++g) run += sLen[g];
         sliceOff[w0 / 64 + threadIdx.x] = run;
-        if (win == (int)gridDim.x - 1 && threadIdx.x == SELL_SIGMA / 64 - 1) sliceOff[w0 / 64 + SELL_SIGMA / 64] = run + sLen[threadIdx.x];
+        if (win == nblk - 1 && threadIdx.x == SELL_SIGMA / 64 - 1) sliceOff[w0 / 64 + SELL_SIGMA / 64] = run + sLen[threadIdx.x];
     }
+}
+__global__ __launch_bounds__(256) void sell_sort(const int* __restrict__ rowStart, int rows, int e,
+                                                 const int* __restrict__ vlistRow, const int* __restrict__ vposRow,
+                                                 const int* __restrict__ vTotal, int* __restrict__ vrow,
+                                                 int* __restrict__ vcode, int* __restrict__ sliceOff, int L,
+                                                 unsigned long long* status) {
+    sell_sort_body((int)gridDim.x, rowStart, rows, e, vlistRow, vposRow, vTotal, vrow, vcode, sliceOff, L, status);
+}
+__global__ __launch_bounds__(256) void sell_sort_batch(LargeBatch lb, BatchBlocks bb) {
+    int local, blocks;
+    const LargeItem& t = lb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    sell_sort_body(blocks, t.rowStart, t.rows, t.e, t.vlistRow, t.vposRow, t.vTotal, t.vrow, t.vcode, t.sliceOff, t.L, t.st2);
 }
 
 // The records of a slice in (iteration, lane) order: a pure PERMUTATION of the per-edge records (delta, 1 / (pdf K)) that
@@ -470,9 +502,8 @@ __global__ __launch_bounds__(256) void sell_fill_batch(SellFillBatch fb, BatchBl
 __device__ __forceinline__ int row_len(const int* __restrict__ rowStart, int rows, int e, int r) {
     return ((r + 1 < rows) ? rowStart[r + 1] : e) - rowStart[r];
 }
-__global__ __launch_bounds__(256) void plan_bases(RowPlan p, const int* __restrict__ rowStart, int rows, int e, int L, long long cap,
-                                                  int2* __restrict__ vinfo, float4* __restrict__ rec, int* __restrict__ oth) {
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void plan_bases_body(const int pos, const RowPlan& p, const int* __restrict__ rowStart, int rows, int e, int L,
+                                                long long cap, int2* __restrict__ vinfo, float4* __restrict__ rec, int* __restrict__ oth) {
     if (pos >= p.S * 64) return;
     const int slice = pos >> 6, lane = pos & 63;
     const int off = p.sliceOff[slice];
@@ -494,6 +525,16 @@ __global__ __launch_bounds__(256) void plan_bases(RowPlan p, const int* __restri
         }
     }
 }
+__global__ __launch_bounds__(256) void plan_bases(RowPlan p, const int* __restrict__ rowStart, int rows, int e, int L, long long cap,
+                                                  int2* __restrict__ vinfo, float4* __restrict__ rec, int* __restrict__ oth) {
+    plan_bases_body(blockIdx.x * blockDim.x + threadIdx.x, p, rowStart, rows, e, L, cap, vinfo, rec, oth);
+}
+__global__ __launch_bounds__(256) void plan_bases_batch(LargeBatch lb, BatchBlocks bb) {
+    int local, blocks;
+    const LargeItem& t = lb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    const RowPlan p = {t.vrow, t.vcode, t.sliceOff, t.vposRow, nullptr, nullptr, t.rows, t.S};
+    plan_bases_body(local * 256 + (int)threadIdx.x, p, t.rowStart, t.rows, t.e, t.L, t.cap, t.vinfo, t.rec, t.oth);
+}
 // the slot of edge #r of row `row` (deg edges), and the padding behind the row's last edge
 __device__ __forceinline__ void plan_put(int row, int r, int deg, int L, const int* __restrict__ vposRow,
                                          const int2* __restrict__ vinfo, float4* __restrict__ rec, int* __restrict__ oth,
@@ -514,12 +555,11 @@ __device__ __forceinline__ void plan_put(int row, int r, int deg, int L, const i
     }
 }
 template <bool RANK>
-__global__ __launch_bounds__(256) void plan_scatter_tr(const float4* __restrict__ recE, const int2* __restrict__ packed, int e, int n,
-                                                       const int* __restrict__ startT, const int* __restrict__ tmp,
-                                                       int* __restrict__ permT, const int* __restrict__ vposRow,
-                                                       const int2* __restrict__ vinfo, int L, float4* __restrict__ rec,
-                                                       int* __restrict__ oth) {
-    const int p = xcd_contiguous(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void plan_scatter_tr_body(const int p, const float4* __restrict__ recE, const int2* __restrict__ packed, int e, int n,
+                                                     const int* __restrict__ startT, const int* __restrict__ tmp,
+                                                     int* __restrict__ permT, const int* __restrict__ vposRow,
+                                                     const int2* __restrict__ vinfo, int L, float4* __restrict__ rec,
+                                                     int* __restrict__ oth) {
     if (p >= e) return;
     const int v = RANK ? tmp[p] : permT[p];
     const int2 pr = packed[v];
@@ -538,6 +578,22 @@ __global__ __launch_bounds__(256) void plan_scatter_tr(const float4* __restrict_
     }
     plan_put(j, r, s1 - s0, L, vposRow, vinfo, rec, oth, recE[v], pr.y);
 }
+template <bool RANK>
+__global__ __launch_bounds__(256) void plan_scatter_tr(const float4* __restrict__ recE, const int2* __restrict__ packed, int e, int n,
+                                                       const int* __restrict__ startT, const int* __restrict__ tmp,
+                                                       int* __restrict__ permT, const int* __restrict__ vposRow,
+                                                       const int2* __restrict__ vinfo, int L, float4* __restrict__ rec,
+                                                       int* __restrict__ oth) {
+    plan_scatter_tr_body<RANK>(xcd_contiguous(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x, recE, packed, e, n, startT, tmp, permT,
+                               vposRow, vinfo, L, rec, oth);
+}
+__global__ __launch_bounds__(256) void plan_scatter_tr_batch(LargeBatch lb, BatchBlocks bb) {
+    int local, blocks;
+    const LargeItem& t = lb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    const int p = xcd_contiguous(local, blocks) * 256 + (int)threadIdx.x;
+    if (t.rank) plan_scatter_tr_body<true>(p, t.recE, t.packed, t.e, t.n, t.startT, t.tmp, t.permT, t.vposRow, t.vinfo, t.L, t.rec, t.oth);
+    else plan_scatter_tr_body<false>(p, t.recE, t.packed, t.e, t.n, t.startT, nullptr, t.permT, t.vposRow, t.vinfo, t.L, t.rec, t.oth);
+}
 
 // ------------------------------------------------------------------------------------------------ tile fill (forward plan)
 // The permutation of sell_fill with BOTH sides coalesced: a workgroup owns (slice, 16 iterations) as in sell_fill, but reads the
@@ -547,15 +603,13 @@ __global__ __launch_bounds__(256) void plan_scatter_tr(const float4* __restrict_
 // LDS tile [it][row] with a row stride of 65 float4: the 8 lanes one ds_write_b128 group serves hold 8 iterations of a
 // row = 8 x 4 distinct banks.
 template <bool EVAL>
-__global__ __launch_bounds__(256) void plan_fill_tiles(ConvArgs a, const float4* __restrict__ recIn, float4* __restrict__ recOut,
-                                                       const int* __restrict__ rowStart, int rows, RowPlan p, long long cap, float4* __restrict__ rec, int* __restrict__ oth,
-                                                       int L) {
-    __shared__ float4 tRec[MCCNN_FILL_CHUNK][65];
-    __shared__ int tOth[MCCNN_FILL_CHUNK][65];
+__device__ __forceinline__ void plan_fill_tiles_body(const int lin, const ConvArgs& a, const float4* __restrict__ recIn, float4* __restrict__ recOut,
+                                                     const int* __restrict__ rowStart, int rows, const RowPlan& p, long long cap,
+                                                     float4* __restrict__ rec, int* __restrict__ oth, int L,
+                                                     float4 (*tRec)[65], int (*tOth)[65]) {
     // workgroups in XCD-contiguous order, the chunks of a slice side by side: the slices of a window -- rows of one region of
     // space, whose gathered lines they share -- stay on one XCD
     const int chunks = (L + MCCNN_FILL_CHUNK - 1) / MCCNN_FILL_CHUNK;
-    const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
     const int slice = lin / chunks;
     if (slice >= p.S) return;
     const int off = p.sliceOff[slice];
@@ -607,6 +661,41 @@ __global__ __launch_bounds__(256) void plan_fill_tiles(ConvArgs a, const float4*
             oth[slot] = tOth[il][lane];
         }
     }
+}
+template <bool EVAL>
+__global__ __launch_bounds__(256) void plan_fill_tiles(ConvArgs a, const float4* __restrict__ recIn, float4* __restrict__ recOut,
+                                                       const int* __restrict__ rowStart, int rows, RowPlan p, long long cap, float4* __restrict__ rec, int* __restrict__ oth,
+                                                       int L) {
+    __shared__ float4 tRec[MCCNN_FILL_CHUNK][65];
+    __shared__ int tOth[MCCNN_FILL_CHUNK][65];
+    plan_fill_tiles_body<EVAL>(xcd_contiguous(blockIdx.x, gridDim.x), a, recIn, recOut, rowStart, rows, p, cap, rec, oth, L, tRec, tOth);
+}
+__device__ __forceinline__ ConvArgs large_conv_args(const LargeItem& t) {
+    ConvArgs a = {};
+    a.pts = t.pts; a.bids = t.bids; a.pdfs = t.pdfs; a.samples = t.samples; a.start = t.start; a.packed = t.packed; a.mn = t.mn; a.mx = t.mx;
+    a.n = t.n; a.m = t.m; a.e = t.e; a.radius = t.radius; a.invRadius = t.radius > 0.0f ? 1.0f / t.radius : 0.0f; a.scaleInv = t.scaleInv;
+    a.avg = t.avg; a.B = t.B;
+    return a;
+}
+__global__ __launch_bounds__(256) void plan_fill_tiles_batch(LargeBatch lb, BatchBlocks bb) {
+    __shared__ float4 tRec[MCCNN_FILL_CHUNK][65];
+    __shared__ int tOth[MCCNN_FILL_CHUNK][65];
+    int local, blocks;
+    const LargeItem& t = lb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    const ConvArgs a = large_conv_args(t);
+    const RowPlan p = {t.vrow, t.vcode, t.sliceOff, t.vposRow, nullptr, nullptr, t.rows, t.S};
+    const int lin = xcd_contiguous(local, blocks);
+    if (t.eval) plan_fill_tiles_body<true>(lin, a, nullptr, t.recE, t.rowStart, t.rows, p, t.cap, t.rec, t.oth, t.L, tRec, tOth);
+    else plan_fill_tiles_body<false>(lin, a, t.recE, nullptr, t.rowStart, t.rows, p, t.cap, t.rec, t.oth, t.L, tRec, tOth);
+}
+// the per-edge records of the transposed plans of a batch whose forward plan did not leave them (conv.hip edge_records)
+__global__ __launch_bounds__(256) void edge_records_batch(LargeBatch lb, BatchBlocks bb) {
+    int local, blocks;
+    const LargeItem& t = lb.it[batch_item(bb, (int)blockIdx.x, local, blocks)];
+    const int k = local * 256 + (int)threadIdx.x;
+    if (k >= t.e) return;
+    const ConvArgs a = large_conv_args(t);
+    t.recE[k] = edge_record(a, k);
 }
 
 // The pieces of cut rows left their sums in scratch rows (one per virtual row id, `cols` 32-bit words wide -- f32 rows,
@@ -1447,6 +1536,122 @@ static int build_large(int transposed, const float* sorted_pts, const int* sorte
     MCCNN_LAUNCHED();
     return 0;
 }
+
+// ---- the same chain for a BATCH of large plans: items + one launch per phase (exec.hip mccnn_geometry_prebuild_batch)
+namespace mccnn {
+bool plan_large_batchable(int rows, int e, int n, int transposed, int tlist_ready) {
+    if (rows <= 0 || e <= 0) return false;
+    const PlanSizes z = plan_sizes(rows, e);
+    if (z.small || z.slots > 0x7fffffffLL || z.vcap > 0x7fffffffLL) return false;
+    // (a list short enough for the single-workgroup transposition under a large plan: left to the single chain)
+    if (transposed && !tlist_ready && (transpose_small(e, n) || (long long)n > 2048LL * 1024)) return false;
+    return true;
+}
+size_t plan_large_ws_bytes(int rows, int e, int n, int transposed, int tlist_ready) {
+    const PlanSizes z = plan_sizes(rows, e);
+    size_t b = align_up(mccnn_rowplan_workspace_bytes(rows, e)) + align_up((size_t)z.vcap * sizeof(int2));
+    if (transposed && !tlist_ready) b += align_up(mccnn_transpose_neighbors_workspace_bytes(n, e));
+    return b + 256;
+}
+int plan_large_item(int transposed, const float* sorted_pts, const int* sorted_batch_ids, const float* pdfs, const float* samples,
+                    const int* start_idx, const int* packed, const float* aabb_min, const float* aabb_max, int n, int m, int e,
+                    int batch_size, float radius, int scale_inv, int avg, const int* order, void* rec_edges, int rec_ready, int* start_t,
+                    int* perm_t, int tlist_ready, void* plan_buffer, void* ws, size_t ws_bytes, LargeItem& it, TrChainItem* tc,
+                    ScanItem* sc, bool* use_chain, SpanBatch& spans) {
+    const int rows = transposed ? n : m;
+    *use_chain = false;
+    if (!plan_large_batchable(rows, e, n, transposed, tlist_ready)) return MCCNN_E_BADARG;
+    if (!rec_edges || !start_idx || !packed || !plan_buffer) return MCCNN_E_BADARG;
+    if (!rec_ready && (batch_size <= 0 || !(radius > 0.0f) || !sorted_pts || !sorted_batch_ids || !pdfs || !samples || !aabb_min || !aabb_max))
+        return MCCNN_E_BADARG;
+    if (transposed && (!start_t || !perm_t)) return MCCNN_E_BADARG;
+    if (!ws || ws_bytes < plan_large_ws_bytes(rows, e, n, transposed, tlist_ready)) return MCCNN_E_WORKSPACE;
+    if (spans.count + 3 > (int)(sizeof(spans.sp) / sizeof(spans.sp[0]))) return MCCNN_E_WORKSPACE;
+    long long off[6], total, cap, srows;
+    int S;
+    int rc = mccnn_rowplan_buffer(rows, e, off, &total, &S, &cap, &srows);
+    if (rc) return rc;
+    const PlanSizes z = plan_sizes(rows, e);
+    char* base = reinterpret_cast<char*>(plan_buffer);
+    Arena ar(ws, ws_bytes);
+    // the layout's workspace, cut as mccnn_rowplan_layout cuts it
+    int* vcnt = ar.take<int>((size_t)rows + 1);
+    int* vposP = ar.take<int>((size_t)rows + 1);
+    int* vlistRow = ar.take<int>((size_t)z.vcap);
+    int* sliceSlots = ar.take<int>((size_t)z.S);
+    void* scan1 = ar.take<char>(layout_scan1_bytes(rows));
+    int2* vinfo = ar.take<int2>((size_t)z.vcap);
+    if (!vcnt || !vposP || !vlistRow || !sliceSlots || !scan1 || !vinfo) return MCCNN_E_WORKSPACE;
+    const int tiles = ceil_div(rows, SCAN_TILE);
+    if ((size_t)(tiles + 1) * 8 > layout_scan1_bytes(rows) || (size_t)(z.windows + 1) * 8 > align_up((size_t)z.S * 4)) return MCCNN_E_WORKSPACE;
+    it = LargeItem{};
+    it.rowStart = transposed ? start_t : start_idx;
+    it.order = transposed ? nullptr : order;
+    it.vcnt = vcnt; it.st1 = reinterpret_cast<unsigned long long*>(scan1); it.st2 = reinterpret_cast<unsigned long long*>(sliceSlots);
+    it.vlistRow = vlistRow; it.vTotal = vposP + rows;
+    it.vrow = reinterpret_cast<int*>(base + off[0]); it.vcode = reinterpret_cast<int*>(base + off[1]);
+    it.sliceOff = reinterpret_cast<int*>(base + off[2]); it.vposRow = reinterpret_cast<int*>(base + off[3]);
+    it.oth = reinterpret_cast<int*>(base + off[4]); it.rec = reinterpret_cast<float4*>(base + off[5]);
+    it.cap = z.slots;
+    it.pts = sorted_pts; it.bids = sorted_batch_ids; it.pdfs = pdfs; it.samples = samples; it.start = start_idx;
+    it.packed = reinterpret_cast<const int2*>(packed); it.mn = aabb_min; it.mx = aabb_max;
+    it.recE = reinterpret_cast<float4*>(rec_edges);
+    it.vinfo = vinfo; it.startT = start_t; it.tmp = nullptr; it.permT = perm_t;
+    it.rows = rows; it.e = e; it.n = n; it.m = m; it.B = batch_size; it.L = z.L; it.S = z.S; it.windows = z.windows; it.tiles = tiles;
+    it.scaleInv = scale_inv; it.avg = avg; it.tr = transposed ? 1 : 0; it.eval = rec_ready ? 0 : 1; it.rank = 0;
+    it.radius = radius;
+    spans.sp[spans.count++] = clear_span(it.st1, (size_t)(tiles + 1) * 8);
+    spans.sp[spans.count++] = clear_span(it.st2, (size_t)(z.windows + 1) * 8);
+    if (transposed && !tlist_ready) {   // the transposition is part of the build: count -> scan -> [layout] -> fill -> rank in the scatter
+        const size_t wb = mccnn_transpose_neighbors_workspace_bytes(n, e);
+        char* tws = ar.take<char>(wb);
+        if (!tws || !tc || !sc) return MCCNN_E_WORKSPACE;
+        ClearSpan head;
+        rc = tr_chain_item(*tc, *sc, head, packed, e, n, start_t, perm_t, tws, wb);
+        if (rc) return rc;
+        tc->norank = 1;
+        spans.sp[spans.count++] = head;
+        it.tmp = tc->tmp;
+        it.rank = 1;
+        *use_chain = true;
+    }
+    return 0;
+}
+int launch_plan_large_batch(const LargeBatch& lb, int count, int phase, hipStream_t s) {
+    BatchBlocks bb;
+    bb.count = count;
+    int run = 0;
+    for (int k = 0; k < count; ++k) {
+        const LargeItem& t = lb.it[k];
+        bb.first[k] = run;
+        int blocks = 0;
+        switch (phase) {
+            case LARGE_VR_COUNT: blocks = ceil_div(t.rows, 256); break;
+            case LARGE_VR_SCAN: blocks = t.tiles; break;
+            case LARGE_SELL_SORT: blocks = t.windows; break;
+            case LARGE_BASES: blocks = t.tr ? (int)ceil_div((long long)t.S * 64, 256) : 0; break;
+            case LARGE_RECORDS: blocks = (t.tr && t.eval) ? ceil_div(t.e, 256) : 0; break;
+            case LARGE_FILL: blocks = t.tr ? 0 : t.S * ceil_div(t.L, MCCNN_FILL_CHUNK); break;
+            case LARGE_SCATTER: blocks = t.tr ? ceil_div(t.e, 256) : 0; break;
+        }
+        run += blocks;
+    }
+    for (int k = count; k <= MCCNN_BATCH_MAX; ++k) bb.first[k] = run;
+    if (run == 0) return 0;
+    switch (phase) {
+        case LARGE_VR_COUNT: vr_count_batch<<<run, 256, 0, s>>>(lb, bb); break;
+        case LARGE_VR_SCAN: vr_scan_expand_batch<<<run, SCAN_THREADS, 0, s>>>(lb, bb); break;
+        case LARGE_SELL_SORT: sell_sort_batch<<<run, 256, 0, s>>>(lb, bb); break;
+        case LARGE_BASES: plan_bases_batch<<<run, 256, 0, s>>>(lb, bb); break;
+        case LARGE_RECORDS: edge_records_batch<<<run, 256, 0, s>>>(lb, bb); break;
+        case LARGE_FILL: plan_fill_tiles_batch<<<run, 256, 0, s>>>(lb, bb); break;
+        case LARGE_SCATTER: plan_scatter_tr_batch<<<run, 256, 0, s>>>(lb, bb); break;
+        default: return MCCNN_E_BADARG;
+    }
+    MCCNN_LAUNCHED();
+    return 0;
+}
+}  // namespace mccnn
 
 extern "C" {
 

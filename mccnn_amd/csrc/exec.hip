@@ -655,6 +655,9 @@ size_t mccnn_geometry_prebuild_batch_ws_bytes(mccnn_geometry_t* const* geoms, co
         }
         if ((what[k] & 6) && !g->tl_built)
             trs += transpose_small(e, g->n) ? al(plan_batch_tr_ws_bytes(g->n, e)) : al(mccnn_transpose_neighbors_workspace_bytes(g->n, e));
+        for (int tr = 0; tr < 2; ++tr)
+            if ((what[k] & (tr ? 2 : 1)) && plan_large_batchable(tr ? g->n : g->m, e, g->n, tr, 0))
+                trs += al(plan_large_ws_bytes(tr ? g->n : g->m, e, g->n, tr, 0));
     }
     return al(single) + trs + 512;
 }
@@ -688,12 +691,13 @@ int mccnn_geometry_prebuild_batch(mccnn_geometry_t* const* geoms, const int* wha
     chSpans.count = 0;
     PlanSmallBatch layB;
     SellFillBatch fwdB, trfB;
-    int nTr = 0, nCh = 0, nLay = 0, nFwd = 0, nTrf = 0;
+    LargeBatch lgB;
+    int nTr = 0, nCh = 0, nLay = 0, nFwd = 0, nTrf = 0, nLg = 0;
     auto flush = [&]() -> int {
         int rc = 0;
-        if (nCh) {   // transpositions too long for one workgroup: head clear, count, prefix sums, fill, rank -- one launch each
-            rc = launch_clear_batch(chSpans, s);
-            if (!rc) rc = launch_tr_chain_batch(chB, nCh, 0, s);
+        if (chSpans.count) rc = launch_clear_batch(chSpans, s);   // the head of the batch: status words and row counters of every chain in it
+        if (!rc && nCh) {   // transpositions too long for one workgroup: count, prefix sums, fill, rank -- one launch each
+            rc = launch_tr_chain_batch(chB, nCh, 0, s);
             if (!rc) rc = launch_scan_batch(chScan, nCh, s);
             if (!rc) rc = launch_tr_chain_batch(chB, nCh, 1, s);
             if (!rc) rc = launch_tr_chain_batch(chB, nCh, 2, s);
@@ -702,7 +706,9 @@ int mccnn_geometry_prebuild_batch(mccnn_geometry_t* const* geoms, const int* wha
         if (!rc) rc = launch_plan_small_batch(layB, nLay, s);
         if (!rc) rc = launch_sell_fill_batch(fwdB, nFwd, 0, s);
         if (!rc) rc = launch_sell_fill_batch(trfB, nTrf, 1, s);
-        nTr = nCh = nLay = nFwd = nTrf = 0;
+        // the large plans: layout, then tile fill (forward) / bases + records + scatter (transposed)
+        for (int ph = LARGE_VR_COUNT; ph <= LARGE_SCATTER && !rc && nLg; ++ph) rc = launch_plan_large_batch(lgB, nLg, ph, s);
+        nTr = nCh = nLay = nFwd = nTrf = nLg = 0;
         chSpans.count = 0;
         return rc;
     };
@@ -769,6 +775,42 @@ int mccnn_geometry_prebuild_batch(mccnn_geometry_t* const* geoms, const int* wha
             if (rc) continue;   // (left to the individual chain below)
             ++nLay;
             if (tr) ++nTrf; else ++nFwd;
+            if (tr) g->tl_built = true;
+            p.built = true;
+            p.avg = avg;
+            rest &= ~bit;
+            if (tr) rest &= ~4;
+        }
+        // the large plans of the batch (records in the geometry's own array: evaluated by the forward plan's fill, or by a
+        // pass of the batch when the transposed plan comes alone)
+        for (int tr = 0; tr < 2; ++tr) {
+            const int bit = tr ? 2 : 1;
+            if (!(rest & bit)) continue;
+            Plan& p = g->plan[tr];
+            const int rows = tr ? g->n : g->m;
+            if (!plan_large_batchable(rows, e, g->n, tr, g->tl_built ? 1 : 0)) continue;
+            if (plan_prepare(g, tr, e)) continue;
+            if (!p.buf || p.bytes < (size_t)p.total) continue;
+            if (!g->rec_buf || g->rec_bytes < (size_t)e * 16) continue;
+            if (tr && (!g->tl_buf || g->tl_bytes < tlist_bytes(g->n, e))) continue;
+            if (nLg + 1 > MCCNN_LARGE_BATCH_MAX || nCh + 1 > MCCNN_PLAN_BATCH_MAX || chSpans.count + 3 > 3 * MCCNN_BATCH_MAX) {
+                int rc = flush();
+                if (rc) return rc;
+            }
+            const size_t wb = al(plan_large_ws_bytes(rows, e, g->n, tr, g->tl_built ? 1 : 0));
+            char* w = ar.take<char>(wb);
+            if (!w) continue;   // (left to the individual chain below, on the shared region)
+            const int* order = tr ? nullptr : (g->same_level ? go->inv_idx : (g->order ? g->order : nullptr));
+            bool use_chain = false;
+            const int spans0 = chSpans.count;
+            int rc = plan_large_item(tr, go->s_pts, go->s_bids, g->pdfs, g->centres, g->start, g->packed, g->mn, g->mx, g->n, g->m, e, g->B,
+                                     g->radius, g->scale_inv, avg, order, g->rec_buf, g->rec_avg == avg ? 1 : 0, tr ? tl_start(g) : nullptr,
+                                     tr ? tl_perm(g) : nullptr, g->tl_built ? 1 : 0, p.buf, w, wb, lgB.it[nLg], &chB.it[nCh], &chScan.it[nCh],
+                                     &use_chain, chSpans);
+            if (rc) { chSpans.count = spans0; continue; }
+            ++nLg;
+            if (use_chain) ++nCh;
+            g->rec_avg = avg;
             if (tr) g->tl_built = true;
             p.built = true;
             p.avg = avg;

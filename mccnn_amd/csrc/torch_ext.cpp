@@ -830,8 +830,9 @@ void prebuild_async(std::shared_ptr<Geo> g, int what, bool avg) {
     }
     // a batched geometry with a small plan (either direction; the other one follows on the same stream): its pieces join the
     // batch too, on ONE side stream (the next one after the builds')
+    static const int batch_all = mccnn::debug_int("plan_batch_all", 1);   // A/B: 0 = only geometries with a small plan join the batch
     const bool small_batch = t_geo_batch.active && t_geo_batch.side >= 0 && g->plan_side >= 0 &&
-                             (mccnn_rowplan_inline_records(g->m, (int)g->e_cap) || mccnn_rowplan_inline_records(g->n, (int)g->e_cap));
+                             (batch_all || mccnn_rowplan_inline_records(g->m, (int)g->e_cap) || mccnn_rowplan_inline_records(g->n, (int)g->e_cap));
     if (small_batch) g->plan_side = (t_geo_batch.side + 1) % kSideStreams;
     const bool other = g->plan_side >= 0 && g->plan_side != g->side;   // (a batch build: pieces on another side stream, behind the build's event)
     hipStream_t ss = side_stream(other ? g->plan_side : g->side);
