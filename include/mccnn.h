@@ -489,9 +489,10 @@ int mccnn_geometry_piece_bound(int n, int m, int e_cap, int what, long long* byt
 int mccnn_geometry_prebuild(mccnn_geometry_t* g, int what, int avg, void* ws, size_t ws_bytes, mccnn_stream_t stream);
 
 /* The pieces of several geometries at once (extension): what[k] = mask of the pieces of geoms[k] (their buffers attached with
- * mccnn_geometry_attach). The small plans / lists -- single-workgroup transposition and layout, records evaluated inline -- go
- * out as one launch per kernel kind over all of them; the rest builds as mccnn_geometry_prebuild does, behind them. Results
- * identical to mccnn_geometry_prebuild per geometry. Waits for the edge totals. */
+ * mccnn_geometry_attach). One launch per kernel kind over all of them, in flushes of <= 12 small plans (single-workgroup
+ * layout, records evaluated inline) and <= 8 large ones (layout, tile fill / bases + records + scatter), their transpositions
+ * as batched chains; what a flush cannot take builds as mccnn_geometry_prebuild does, behind them. Results identical to
+ * mccnn_geometry_prebuild per geometry (tests/test_gpu_native.py). Waits for the edge totals. */
 size_t mccnn_geometry_prebuild_batch_ws_bytes(mccnn_geometry_t* const* geoms, const int* what, int count);
 int mccnn_geometry_prebuild_batch(mccnn_geometry_t* const* geoms, const int* what, int count, int avg, void* ws, size_t ws_bytes,
                                   mccnn_stream_t stream);

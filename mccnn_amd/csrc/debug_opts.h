@@ -16,7 +16,8 @@
 // rows_min_degree (16) unsorted_max_points (32768) force_valu (0) no_f1 (0) f1_x4_min_e (2000000) f1_x4_waves_per_cu (0)
 // nw_lean (-1) nw_group (0) nw_group_fill (0) nw_lds_pad (-1) scan_bg_tiles (8) issue_thread (1) issue_inline (0)
 // job_delay_us (0) hier_trace (0) geo_own_pool (1) trace_terminate (0) nw_fused (1: lists of <= 2048 centres scan their
-// counts inside the fill pass) geo_batch (1: the geometries prefetch_step starts go out as ONE batch, one launch per kernel kind).
+// counts inside the fill pass) geo_batch (1: the geometries prefetch_step starts go out as ONE batch, one launch per kernel kind)
+// plan_batch_all (1: the pieces of all of them as one batch as well; 0 = only geometries with a small plan).
 #pragma once
 #include <cstdio>
 #include <cstdlib>
