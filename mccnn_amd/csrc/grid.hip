@@ -119,8 +119,10 @@ __global__ __launch_bounds__(256) void aabb_finalize(const unsigned* __restrict_
 // finalize as three launches were 12-15 us of a chain that is a few microseconds of work): one workgroup of 1024 threads,
 // running minima / maxima per cloud in LDS (order-preserving integers, wave pre-reduction as in aabb_reduce), then the
 // finalize step. Same values (min / max are exact and order-free). Larger batches keep the three launches: one workgroup
-// walks its points at one memory latency per trip.
-#define MCCNN_AABB_ONE_N 32768
+// walks its points at one memory latency per trip (32 768 points: 68 us in the pipelined cfg1 step against ~20 for the three
+// launches, and the hierarchy's chain is what bounds that step: 0.44 -> 0.41 ms with the limit at 8 192; cfg0, 4 096 points,
+// keeps the single launch: 0.151 against 0.158 ms. MCCNN_DEBUG=aabb_one_max=N moves the limit down for an A/B).
+#define MCCNN_AABB_ONE_N 8192
 #define MCCNN_AABB_ONE_B 1024
 __global__ __launch_bounds__(1024) void aabb_one(const float* __restrict__ pts, const int* __restrict__ bids, int n, int B,
                                                  int scaleInv, float* __restrict__ mn, float* __restrict__ mx) {
@@ -655,7 +657,8 @@ int mccnn_compute_aabb(const float* pts, const int* batch_ids, int n, int batch_
     if (!aabb_min || !aabb_max || batch_size <= 0 || n < 0 || (n > 0 && (!pts || !batch_ids))) return MCCNN_E_BADARG;
     if (!ws || ws_bytes < mccnn_compute_aabb_workspace_bytes(batch_size)) return MCCNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    if (n <= MCCNN_AABB_ONE_N && batch_size <= MCCNN_AABB_ONE_B && small_kernels_on()) {
+    static const int oneMax = debug_int("aabb_one_max", MCCNN_AABB_ONE_N);   // A/B switch, read once
+    if (n <= oneMax && n <= MCCNN_AABB_ONE_N && batch_size <= MCCNN_AABB_ONE_B && small_kernels_on()) {
         aabb_one<<<1, 1024, 0, s>>>(pts, batch_ids, n, batch_size, scale_inv, aabb_min, aabb_max);
         MCCNN_LAUNCHED();
         return 0;

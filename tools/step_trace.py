@@ -17,7 +17,7 @@ df["n"] = df.Kernel_Name.str.replace("void mccnn::", "").str.replace("mccnn::", 
 # otherwise the rarest kernel; the step = [marker[-back-1], marker[-back])
 cnt = df.n.value_counts()
 marker = None
-for cand in ("aabb_reduce", "aabb_points", "aabb_all"):
+for cand in ("aabb_reduce", "aabb_one", "aabb_points", "aabb_all"):
     if cand in cnt.index:
         marker = cand
         break
