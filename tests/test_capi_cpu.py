@@ -243,3 +243,16 @@ def test_library_issues_no_memsets():
         if os.path.isfile(f):
             src = re.sub(r"//[^\n]*", "", open(f, errors="ignore").read())
             assert not bad.search(src), f
+
+
+def test_library_has_no_unresolved_symbols_of_its_own(lib_path):
+    """A shared-library link does not report undefined symbols: a function declared in a header (csrc/batch.h) and defined
+    with another linkage only fails when the library is LOADED -- on the GPU box. Every undefined dynamic symbol of the
+    library in the package's namespace (mccnn::, mccnn_*) is such a mistake."""
+    import shutil
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    if not os.path.exists(nm) and not shutil.which(nm):
+        pytest.skip("no nm")
+    out = subprocess.run([nm, "-D", "--undefined-only", lib_path], capture_output=True, text=True, check=True).stdout
+    own = [l.split()[-1] for l in out.splitlines() if l.split() and (l.split()[0] == "U") and ("mccnn" in l.split()[-1])]
+    assert not own, own
