@@ -667,3 +667,56 @@ def test_batched_pieces_equal_the_single_chains(mc):
                 assert torch.equal(x[bit], y[bit]), (avg, k, bit, ea[k])
                 assert x[bit].any(), (k, bit)
         assert ea[0] <= 4096 and ea[1] > 16384 and ea[3] > 262144, ea   # the three regimes were met
+
+
+@pytest.mark.gpu
+def test_batch_entries_error_behaviour(mc):
+    """Error codes of the two batch entries, as the single entries give them: no requests is not an error, a null array is
+    MCCNN_E_BADARG, a request with a too small buffer fails as mccnn_geometry_build does and NOTHING of the batch is
+    launched (every request is checked before the first launch); prebuild_batch with an unbuilt geometry: BADARG."""
+    import ctypes as C
+    import torch
+    from mccnn_amd import _lib
+    lib = _lib.load()
+    lib.mccnn_geometry_create.restype = C.c_void_p
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.mccnn_geometry_build_batch(None, 0, st) != 0                   # MCCNN_E_BADARG
+
+    class Req(C.Structure):
+        _fields_ = [("geometry", C.c_void_p), ("pts", C.c_void_p), ("batch_ids", C.c_void_p), ("n", C.c_int),
+                    ("centres", C.c_void_p), ("centre_batch_ids", C.c_void_p), ("m", C.c_int), ("aabb_min", C.c_void_p),
+                    ("aabb_max", C.c_void_p), ("batch_size", C.c_int), ("num_cells", C.c_int), ("radius", C.c_float),
+                    ("scale_inv", C.c_int), ("window", C.c_float), ("use_pdf", C.c_int), ("e_capacity", C.c_int),
+                    ("grid_from", C.c_void_p), ("buffer", C.c_void_p), ("buffer_bytes", C.c_size_t), ("total_host", C.c_void_p)]
+    reqs = (Req * 2)()
+    assert lib.mccnn_geometry_build_batch(C.byref(reqs), 0, st) == 0          # nothing to do
+    pts, bids = make_cloud(2000, 2, 3, "uniform", True)
+    P, Bi = _t(pts), _t(bids)
+    mn, mx = mc.compute_aabb(P, Bi, 2, True)
+    nc = mc._num_cells(mn, mx, 2, 0.1, True)
+    n = P.shape[0]
+    cap = 64 * n
+    nbytes = lib.mccnn_geometry_bytes(n, n, 2, nc, cap, 1)
+    bufs = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    slots = torch.zeros(2, dtype=torch.int32).pin_memory()
+    hs = [lib.mccnn_geometry_create() for _ in range(2)]
+    for k in range(2):
+        reqs[k] = Req(hs[k], P.data_ptr(), Bi.data_ptr(), n, P.data_ptr(), Bi.data_ptr(), n, mn.data_ptr(), mx.data_ptr(), 2, nc, 0.1, 1,
+                      0.25, 1, cap, None, bufs[k].data_ptr(), nbytes if k == 0 else 1024, slots.data_ptr() + 4 * k)
+    l0 = lib.mccnn_debug_launch_count()
+    rc = lib.mccnn_geometry_build_batch(C.byref(reqs), 2, st)
+    assert rc != 0 and lib.mccnn_debug_launch_count() == l0                   # second request's buffer too small: nothing launched
+    # prebuild of geometries that were never built
+    arr = (C.c_void_p * 2)(*hs)
+    what = (C.c_int * 2)(7, 7)
+    ws = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    lib.mccnn_geometry_prebuild_batch_ws_bytes.restype = C.c_size_t
+    assert lib.mccnn_geometry_prebuild_batch_ws_bytes(arr, what, 2) == 0
+    assert lib.mccnn_geometry_prebuild_batch(arr, what, 2, 0, C.c_void_p(ws.data_ptr()), C.c_size_t(4096), st) != 0
+    # ... and the repaired batch builds
+    reqs[1].buffer_bytes = nbytes
+    assert lib.mccnn_geometry_build_batch(C.byref(reqs), 2, st) == 0
+    torch.cuda.synchronize()
+    assert int(slots[0]) == int(slots[1]) > 0
+    for h in hs:
+        lib.mccnn_geometry_destroy(C.c_void_p(h))
