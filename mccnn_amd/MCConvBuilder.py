@@ -18,6 +18,28 @@ import torch
 
 from . import _env
 
+
+# `from . import x` inside a function is ~1 us per execution (importlib's _handle_fromlist): 60-70 of them per step of a
+# 17-layer graph. The two modules are imported once, on first use (not at import time: they load the libraries).
+_NATIVE = None
+_HIPOPS = None
+
+
+def _native_mod():
+    global _NATIVE
+    if _NATIVE is None:
+        from . import native
+        _NATIVE = native
+    return _NATIVE
+
+
+def _hip_ops_mod():
+    global _HIPOPS
+    if _HIPOPS is None:
+        from . import MCConvModule
+        _HIPOPS = MCConvModule
+    return _HIPOPS
+
 from .MCConvModule import (compute_aabb, sort_points_step1, sort_points_step2, sort_features, sort_features_back,
                            compute_pdf, poisson_sampling, get_sampled_features, spatial_conv, get_block_size,
                            transform_indexs, find_neighbors)
@@ -168,7 +190,7 @@ class PointHierarchy(_PlainState, torch.nn.Module):
         network's input features) are then gathered for every level together with the hierarchy, on its stream, instead of
         by one launch per level on the calling thread when the hierarchy is adopted; the constructor uses them when it is
         handed the very same, unmodified tensor, and gathers as usual otherwise."""
-        from . import MCConvModule as _M
+        _M = _hip_ops_mod()
         if not FUSED_HIERARCHY or not poisson_sampling.__module__.endswith("MCConvModule"):
             return None
         fut = _M.point_hierarchy_prefetch(inPoints, inBatchIds, list(radiusList), batchSize, relativeRadius, after, features)
@@ -207,7 +229,7 @@ class PointHierarchy(_PlainState, torch.nn.Module):
 
         if FUSED_HIERARCHY and ops._ops is None and len(radiusList) > 0 and getattr(inPoints, "is_cuda", False) \
                 and poisson_sampling.__module__.endswith("MCConvModule"):
-            from . import MCConvModule as _M
+            _M = _hip_ops_mod()
             fused = _M.point_hierarchy_levels(inPoints, inBatchIds, aabbMin, aabbMax, list(radiusList), batchSize,
                                               self.relativeRadius_)
             if fused is not None:
@@ -248,7 +270,7 @@ class PointHierarchy(_PlainState, torch.nn.Module):
     def __adopt_prefetched__(self, prefetched, inFeatures, ops):
         """The levels a helper thread built ahead (PointHierarchy.prefetch): the current stream is ordered behind them, the
         feature rows of every level are gathered now. False when the single-launch Poisson form gave up somewhere."""
-        from . import MCConvModule as _M
+        _M = _hip_ops_mod()
         aabbMin, aabbMax, extent, levels = prefetched.future.result()   # (its wait is counted by the extension: wait_ns)
         if not levels:
             return False
@@ -381,11 +403,22 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
     # ------------------------------------------------------------------ caches
     def __compute_dic_keys__(self, inPointHierarchy, outPointHierarchy, inPointLevel, outPointLevel, convRadius,
                              KDEWindow, relativeRadius, usePDF):
-        # MCConvBuilder.py:203-238
+        # MCConvBuilder.py:203-238 (the strings depend on names and numbers only: memoised -- six str() of floats per call)
+        memo = self.__dict__.setdefault("_keyMemo", {})
+        k = (inPointHierarchy.hierarchyName_, outPointHierarchy.hierarchyName_, inPointLevel, outPointLevel, convRadius, KDEWindow,
+             relativeRadius, usePDF)
+        try:
+            hit = memo.get(k)
+        except TypeError:   # (an unhashable argument: a tensor radius)
+            hit, k = None, None
+        if hit is not None:
+            return hit
         keyGrid = inPointHierarchy.hierarchyName_ + '|' + str(inPointLevel) + '|' + str(convRadius) + '|' + \
             str(relativeRadius)
         keyNeighs = keyGrid + '|' + outPointHierarchy.hierarchyName_ + '|' + str(outPointLevel)
         keyPDF = keyNeighs + '|' + str(KDEWindow) + '|' + str(usePDF)
+        if k is not None and len(memo) < 4096:
+            memo[k] = (keyGrid, keyNeighs, keyPDF)
         return keyGrid, keyNeighs, keyPDF
 
     def reset(self):
@@ -404,7 +437,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
             evs.append(_record_event())      # the end of the step that has just been issued
             del evs[:-8]
             if len(evs) > k:
-                from . import MCConvModule as _M
+                _M = _hip_ops_mod()
                 t0 = time.perf_counter()
                 evs[-(int(k) + 1)].synchronize()
                 dt = time.perf_counter() - t0
@@ -447,7 +480,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         if pf is not None:
             for kN, (kG, kP, centres, mn, mx, B, radius, rel) in self.prefetchTransposed_.items():
                 if kN in neighs and kG in grids and getattr(self.ops_, "_ops", 0) is None:
-                    from . import MCConvModule as _hip_ops
+                    _hip_ops = _hip_ops_mod()
                     self.sideStream_.wait_event(self.resetEvent_)
                     g = grids[kG]
                     _hip_ops.prefetch_transposed(neighs[kN][1], g[0].shape[0], self.sideStream_)
@@ -528,7 +561,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                              currRelativeRadius, currKDEWindow, currUsePDF, outPH, outLevel, transposed):
         with torch.cuda.stream(side):
             if keyGrid not in grids and self.fuseSort_ and getattr(self.ops_, "_ops", 0) is None and not pts.requires_grad:
-                from . import MCConvModule as _hip_ops
+                _hip_ops = _hip_ops_mod()
                 grids[keyGrid] = _hip_ops.build_grid(pts, bids, mn, mx, B, convRadius, currRelativeRadius)
             if keyGrid not in grids:
                 keys, indexs = self.ops_.sort_points_step1(pts, bids, mn, mx, B, convRadius, currRelativeRadius)
@@ -541,7 +574,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
             g = grids[keyGrid]
             deferred = None
             if getattr(self.ops_, "_ops", 0) is None:  # the HIP op surface (not a checker handed in through `ops=`)
-                from . import MCConvModule as _hip_ops
+                _hip_ops = _hip_ops_mod()
                 deferred = _hip_ops.find_neighbors_pdf_deferred
             if keyNeighs not in neighs and keyPDF not in pdfs and currUsePDF and deferred is not None:
                 # search + KDE without a host wait (list sizes from the last total of this shape; None on the first call)
@@ -604,8 +637,8 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         batch's convolutions, call prefetch_geometry() BEFORE they are launched (right after reset()); called after them
         it is still correct, the build then simply waits for them. Returns False when this call has to take the op-by-op
         prefetch (no torch extension, points with a gradient, ...)."""
-        from . import native as _native
-        from . import MCConvModule as _hip_ops
+        _native = _native_mod()
+        _hip_ops = _hip_ops_mod()
         if not (self.native_ and self.fuseSort_ and getattr(self.ops_, "_ops", 0) is None and _native.side_streams_available()
                 and int(_hip_ops.PDF_MODE) == 1 and self.prefetched_ is None
                 and _env.debug("native_prefetch", True)):
@@ -624,15 +657,15 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
             return True
         mn, mx, B = inPH.aabbMin_, inPH.aabbMax_, inPH.batchSize_
         nc = _hip_ops._num_cells(mn, mx, B, convRadius, relativeRadius)
-        owner = None
-        for (g2, kG2, _kN2, _u2, _t2) in self.prefetchedGeo_.values():
-            if kG2 == keyGrid and g2.grid_owner is None:
-                owner = g2
+        owners = self.__dict__.setdefault("prefetchedGridOwner_", {})   # keyGrid -> the parked geometry that owns that grid
+        owner = owners.get(keyGrid)
         k = len(self.prefetchedGeo_)
         geo = _native.build_geometry(inPts, inBids, centres, cBids, mn, mx, B, nc, convRadius, relativeRadius, KDEWindow,
                                      usePDF, owner, side=k, fork=fork, background=True,
                                      after=(inPH.prefetchFuture_ if inPH is outPH else None))
         geo.uses = 0
+        if owner is None:
+            owners[keyGrid] = geo
         if pieces:   # row plans / transposed list the layers of the last step used: attached and issued by a helper thread
             geo.prebuild_async(pieces, self.useAVG_)
         self.prefetchedGeo_[keyPDF] = (geo, keyGrid, keyNeighs, usePDF, want)
@@ -650,7 +683,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         started = 0
         name, levels = pointHierarchy.hierarchyName_, len(pointHierarchy.points_)
         pieces = _env.debug("plan_prefetch", True)
-        from . import native as _native
+        _native = _native_mod()
         _native.begin_batch()   # the step's geometries go out together: one launch per kernel kind over all of them
         try:
             started = self.__prefetch_step_entries__(pointHierarchy, name, levels, pieces)
@@ -677,8 +710,9 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         """reset(): the geometries prefetch_geometry() built since the last reset() become the cache content; for those
         asked for with transposed=True the transposed list and the transposed row plan of the depth-wise backward pass are
         started on their side stream now (their edge totals arrived long ago), under the forward passes to come."""
-        from . import native as _native
+        _native = _native_mod()
         parked, self.prefetchedGeo_ = self.prefetchedGeo_, {}
+        self.__dict__["prefetchedGridOwner_"] = {}
         for keyPDF, (geo, keyGrid, keyNeighs, usePDF, transposed) in parked.items():
             geo.unverified = True   # (checked against the hierarchy's tensors at its first use)
             self.cacheGeo_[keyPDF] = geo
@@ -696,8 +730,8 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         """Learned prefetch: every geometry the previous step built over a hierarchy of this name, issued now -- before the
         first layer of this step -- on side streams. A step whose graph differs simply builds what is missing when it is
         asked for; a geometry nobody asks for is dropped at the next reset()."""
-        from . import native as _native
-        from . import MCConvModule as _hip_ops
+        _native = _native_mod()
+        _hip_ops = _hip_ops_mod()
         plan, name = self.geoPlan_, ph.hierarchyName_
         levels = len(ph.points_)
         mn, mx, B = ph.aabbMin_, ph.aabbMax_, ph.batchSize_
@@ -748,8 +782,8 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         is ONE library call (no host wait), the layer one call per direction with the feature sort inside. Returns None
         when this call has to take the op-by-op path: a cache entry of that path exists already (prefetch_geometry), the
         level is empty, or the features are not rows the library reads in place."""
-        from . import native as _native
-        from . import MCConvModule as _hip_ops
+        _native = _native_mod()
+        _hip_ops = _hip_ops_mod()
         # (a step with a handful of geometries gains nothing: the hops between the streams cost what the overlap saves --
         # measured: BASELINE cfg1, three lists, 0.93 -> 0.97 ms; cfg2, seven, 2.59 -> 2.18)
         if (not self.cacheGeo_ and self.geoPrefetch_ and len(self.geoPlan_) >= _GEO_PREFETCH_MIN and inPH is outPH and self.prefetched_ is None
@@ -904,7 +938,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                 currGridTuple = self.cacheGrids_[keyGrid]
                 self._trace("sort_features", keyGrid)
             else:
-                from . import MCConvModule as _hip_ops
+                _hip_ops = _hip_ops_mod()
                 currGridTuple = _hip_ops.build_grid(inPts, inPointHierarchy.batchIds_[inPointLevel],
                                                      inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_,
                                                      inPointHierarchy.batchSize_, convRadius, currRelativeRadius)
@@ -934,7 +968,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
         if fused and currUsePDF and keyNeighs not in self.cacheNeighs_ and keyPDF not in self.cachePDFs_:
             # search + KDE enqueued back to back (list sizes from the last total of this shape), ONE wait for the edge
             # count at the end instead of a wait between the two ops; None on the first call of a shape
-            from . import MCConvModule as _hip_ops
+            _hip_ops = _hip_ops_mod()
             h = _hip_ops.find_neighbors_pdf_deferred(
                 currOutPointHierarchy.points_[currOutPointLevel], currOutPointHierarchy.batchIds_[currOutPointLevel],
                 currGridTuple[0], currGridTuple[1], currGridTuple[2], inPointHierarchy.aabbMin_, inPointHierarchy.aabbMax_,
@@ -981,7 +1015,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
             weights2, weights3 = weights2v.reshape(blockSize, nn), weights3v.reshape(blockSize, nn)
             biases2, biases3 = biases2v.reshape(nn), biases3v.reshape(nn)
         if sortIndex is not None:
-            from . import MCConvModule as _hip_ops
+            _hip_ops = _hip_ops_mod()
             # (the variables in their stored shapes: the op reinterprets them itself, see _SpatialConv.forward)
             return _hip_ops.spatial_conv(currGridTuple[0], sortFeatures, currGridTuple[1], currPDFs,
                                 currOutPointHierarchy.points_[currOutPointLevel], currNeighTuple[0], currNeighTuple[1],
