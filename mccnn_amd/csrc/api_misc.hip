@@ -69,7 +69,7 @@ int launch_clear_spans(ClearSpan a, ClearSpan b, ClearSpan c, hipStream_t s) {
 extern "C" {
 
 int mccnn_block_size(void) { return MCCNN_MLP; }
-int mccnn_abi_version(void) { return 9; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn; 5: row plans, aabb_extent; 6: rowplan_build, build_grid; 7: feat_index of the row kernels, hierarchy_level, find_neighbors_count2; 8: background_launches, debug_f1_x4_min_edges; 9: native step executor (mccnn_geometry_*, mccnn_conv_*)
+int mccnn_abi_version(void) { return 10; }  // 2: optional forward state of spatial_conv; 3: bf16 rows, device-side counts; 4: compute_pdf_dn; 5: row plans, aabb_extent; 6: rowplan_build, build_grid; 7: feat_index of the row kernels, hierarchy_level, find_neighbors_count2; 8: background_launches, debug_f1_x4_min_edges; 9: native step executor (mccnn_geometry_*, mccnn_conv_*); 10: mccnn_geometry_build_batch, mccnn_geometry_prebuild_batch
 const char* mccnn_arch(void) { return "gfx950"; }
 int mccnn_background_launches(int on) { const int prev = mccnn::g_background; mccnn::g_background = on ? 1 : 0; return prev; }
 int mccnn_debug_f1_x4_min_edges(int edges) { return mccnn::g_f1_x4_min_edges.exchange(edges < 0 ? 0 : edges); }
