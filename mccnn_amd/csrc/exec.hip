@@ -635,10 +635,19 @@ int mccnn_geometry_prebuild(mccnn_geometry_t* g, int what, int avg, void* ws, si
     return rc;
 }
 
-// The pieces of SEVERAL geometries at once (the row plans / transposed lists a step's layers will ask for, built ahead): the
-// small ones -- single-workgroup transposition, single-workgroup layout, records evaluated inline: most plans of a network's
-// coarse levels -- go out as one launch per kernel kind over all of them (tr_small, plan_small, sell_fill forward, sell_fill
-// transposed: four launches where a step of BASELINE cfg4 had ~40); everything else takes its own chain behind them.
+// The pieces of SEVERAL geometries at once (the row plans / transposed lists a step's layers will ask for, built ahead), one
+// launch per kernel KIND per flush:
+//   head clear (status words, row counters of every chain of the flush)
+//   transposition chains of lists too long for one workgroup: tr_count, scan, tr_fill, tr_rank (a large transposed plan's
+//     chain is ranked by its scatter instead)                                  | tr_small: single-workgroup transpositions
+//   small plans (single-workgroup layout, records evaluated inline): plan_small, sell_fill forward, sell_fill transposed
+//   large plans: vr_count, vr_scan_expand, sell_sort, plan_bases (transposed), edge_records (transposed plans whose forward
+//     plan did not leave the records), plan_fill_tiles (forward; evaluates the records), plan_scatter_tr (transposed)
+// A flush holds <= MCCNN_PLAN_BATCH_MAX small plans / chains and <= MCCNN_LARGE_BATCH_MAX large plans (the items travel in
+// the kernel arguments); what no flush can take (a small layout over > 262 144 edges, a list beyond the chained scan, a
+// geometry without room for a piece) builds as mccnn_geometry_prebuild does, behind the flushes, on the shared region at the
+// head of `ws`. Launch errors aside, the flags of a geometry (plan built, list built, records evaluated) are set when its
+// items are QUEUED: later items of the same call rely on them (a transposed plan on the list queued before it).
 // ws: mccnn_geometry_prebuild_batch_ws_bytes. Waits for the edge totals.
 size_t mccnn_geometry_prebuild_batch_ws_bytes(mccnn_geometry_t* const* geoms, const int* what, int count) {
     if (!geoms || !what || count < 0) return 0;
