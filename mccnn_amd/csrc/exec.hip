@@ -702,21 +702,39 @@ int mccnn_geometry_prebuild_batch(mccnn_geometry_t* const* geoms, const int* wha
     SellFillBatch fwdB, trfB;
     LargeBatch lgB;
     int nTr = 0, nCh = 0, nLay = 0, nFwd = 0, nTrf = 0, nLg = 0;
+    static const int dbgSync = debug_int("plan_batch_sync", 0);   // debugging: a synchronisation and a line per launch
+    auto mark = [&](const char* what, int k) {
+        if (!dbgSync) return;
+        const hipError_t e = hipStreamSynchronize(s);
+        fprintf(stderr, "mccnn batch: %s %d -> %d\n", what, k, (int)e);
+    };
     auto flush = [&]() -> int {
         int rc = 0;
+        if (dbgSync) fprintf(stderr, "mccnn batch: flush nCh %d nTr %d nLay %d nFwd %d nTrf %d nLg %d spans %d\n", nCh, nTr, nLay, nFwd, nTrf, nLg, chSpans.count);
         if (chSpans.count) rc = launch_clear_batch(chSpans, s);   // the head of the batch: status words and row counters of every chain in it
+        mark("clear", 0);
         if (!rc && nCh) {   // transpositions too long for one workgroup: count, prefix sums, fill, rank -- one launch each
             rc = launch_tr_chain_batch(chB, nCh, 0, s);
+            mark("tr_count", 0);
             if (!rc) rc = launch_scan_batch(chScan, nCh, s);
+            mark("tr_scan", 0);
             if (!rc) rc = launch_tr_chain_batch(chB, nCh, 1, s);
+            mark("tr_fill", 0);
             if (!rc) rc = launch_tr_chain_batch(chB, nCh, 2, s);
+            mark("tr_rank", 0);
         }
         if (!rc) rc = launch_tr_small_batch(trB, nTr, s);
+        mark("tr_small", 0);
         if (!rc) rc = launch_plan_small_batch(layB, nLay, s);
+        mark("plan_small", 0);
         if (!rc) rc = launch_sell_fill_batch(fwdB, nFwd, 0, s);
         if (!rc) rc = launch_sell_fill_batch(trfB, nTrf, 1, s);
+        mark("sell_fill", 0);
         // the large plans: layout, then tile fill (forward) / bases + records + scatter (transposed)
-        for (int ph = LARGE_VR_COUNT; ph <= LARGE_SCATTER && !rc && nLg; ++ph) rc = launch_plan_large_batch(lgB, nLg, ph, s);
+        for (int ph = LARGE_VR_COUNT; ph <= LARGE_SCATTER && !rc && nLg; ++ph) {
+            rc = launch_plan_large_batch(lgB, nLg, ph, s);
+            mark("large", ph);
+        }
         nTr = nCh = nLay = nFwd = nTrf = nLg = 0;
         chSpans.count = 0;
         return rc;
@@ -797,6 +815,8 @@ int mccnn_geometry_prebuild_batch(mccnn_geometry_t* const* geoms, const int* wha
             if (!(rest & bit)) continue;
             Plan& p = g->plan[tr];
             const int rows = tr ? g->n : g->m;
+            static const int largeOn = debug_int("plan_large_batch", 1);   // A/B: 0 = large plans take their own chains
+            if (!largeOn) continue;
             if (!plan_large_batchable(rows, e, g->n, tr, g->tl_built ? 1 : 0)) continue;
             if (plan_prepare(g, tr, e)) continue;
             if (!p.buf || p.bytes < (size_t)p.total) continue;

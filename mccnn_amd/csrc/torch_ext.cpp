@@ -307,6 +307,11 @@ struct Geo {
     // finished the step in flight. Every stream that joins the build is made known to the allocator (record_stream).
     bool own_pool = false;
     void* caller_stream = nullptr;  // own_pool: the stream of the thread that asked for the build (where its inputs are consumed)
+    // (... which is a NULL handle when that thread runs on the device's default stream -- the usual case: `has_caller`, not the
+    // handle, says whether it is set. Round 6: the waits below were skipped for exactly that stream, and a loop that prefetched
+    // geometry it never consumed let the next hierarchy overwrite level tensors that builds / plan kernels were still reading.)
+    bool has_caller = false;
+    static bool caller_waits() { static const bool on = mccnn::debug_int("caller_join_off", 0) == 0; return on; }   // (fault injection: the round-6 bug back)
     Tensor buf, slot;
     std::vector<Tensor> keep, attached;
     std::shared_ptr<Geo> grid_owner;
@@ -391,7 +396,7 @@ struct Geo {
                 (void)hipStreamWaitEvent((hipStream_t)alloc_stream, event, 0);
                 // own pool: the INPUTS (`keep`: tensors of the hierarchy, freed after this) are known to the allocator as
                 // used on the caller's stream only -- a build nobody joined has to be over before that stream moves on
-                if (own_pool && caller_stream) (void)hipStreamWaitEvent((hipStream_t)caller_stream, event, 0);
+                if (own_pool && has_caller && caller_waits()) (void)hipStreamWaitEvent((hipStream_t)caller_stream, event, 0);
             }
             if (total_pending && build_rc == 0) slot_ev = event;   // (the event of the build: the parked slot keeps it)
             else give_event(event);
@@ -407,14 +412,14 @@ struct Geo {
         if (plan_event) {
             if (plan_wait && buf.defined()) {
                 (void)hipStreamWaitEvent((hipStream_t)alloc_stream, plan_event, 0);
-                if (own_pool && caller_stream) (void)hipStreamWaitEvent((hipStream_t)caller_stream, plan_event, 0);
+                if (own_pool && has_caller && caller_waits()) (void)hipStreamWaitEvent((hipStream_t)caller_stream, plan_event, 0);
             }
             give_event(plan_event);
         }
         if (tr_event) {
             if (tr_wait && buf.defined()) {
                 (void)hipStreamWaitEvent((hipStream_t)alloc_stream, tr_event, 0);
-                if (own_pool && caller_stream) (void)hipStreamWaitEvent((hipStream_t)caller_stream, tr_event, 0);
+                if (own_pool && has_caller && caller_waits()) (void)hipStreamWaitEvent((hipStream_t)caller_stream, tr_event, 0);
             }
             give_event(tr_event);
         }
@@ -636,13 +641,16 @@ void end_geometry_batch() {
                     rc = (int)hipErrorUnknown;
                 }
             }
+            if (rc) fprintf(stderr, "mccnn: batch of row plans / transposed lists: error %d (the layers build what is missing)\n", rc);
+            // (events also after an error: part of the batch may have been launched, and whoever frees a geometry's memory
+            // orders its stream behind them -- Geo::~Geo)
             for (PieceEntry* pe : live) {
                 Geo& g = *pe->g;
-                if (!rc && (pe->what & 1)) {
+                if (pe->what & 1) {
                     if (!g.plan_event) g.plan_event = take_event();
                     if (hipEventRecord(g.plan_event, ss) == hipSuccess) g.plan_wait = true;
                 }
-                if (!rc && (pe->what & 6)) {
+                if (pe->what & 6) {
                     if (!g.tr_event) g.tr_event = take_event();
                     if (hipEventRecord(g.tr_event, ss) == hipSuccess) g.tr_wait = true;
                 }
@@ -708,6 +716,7 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
         }
         g->own_pool = true;
         g->caller_stream = stream;
+        g->has_caller = true;
         g->alloc_stream = (void*)ss;
         hip_check(hipStreamWaitEvent(ss, ready, 0), "hipStreamWaitEvent");
         const int sk = (int)(((side % kSideStreams) + kSideStreams) % kSideStreams);
@@ -1298,6 +1307,11 @@ struct HierFuture {
             if (!feats.defined()) hip_check(hipEventRecord(event, ss), "hipEventRecord");
             hip_check(hipStreamSynchronize(ss), "hipStreamSynchronize");
             hs.assign(host.data_ptr<int>(), host.data_ptr<int>() + L + 1);
+            for (int l = 1; l <= L; ++l)
+                if (hs[l] < 0) {   // (rare and worth knowing: a wait of the single-launch Poisson kernel timed out under load)
+                    fprintf(stderr, "mccnn: prefetched hierarchy: level %d gave up (size %d); the caller builds it op by op\n", l, hs[l]);
+                    break;
+                }
             if (feats.defined()) {
                 bool ok = true;
                 for (int l = 1; l <= L; ++l) ok = ok && hs[l] >= 0;

@@ -20,7 +20,13 @@ N = 60
 NOCONV = os.environ.get("NOCONV") == "1"
 
 
+HOLD = []   # (debugging, HOLD_GEOS=n: the geometries of the last n steps are kept alive -- is a fault tied to their release?)
+
+
 def step(rec):
+    if os.environ.get("HOLD_GEOS"):
+        HOLD.append(list(cw.builder.cacheGeo_.values()) + [v[0] for v in cw.builder.prefetchedGeo_.values()])
+        del HOLD[:-int(os.environ["HOLD_GEOS"])]
     t = [time.perf_counter()]
     if os.environ.get("REORDER") == "1":   # A/B: adopt the next hierarchy and request the one after it BEFORE reset()'s wait
         ph = cw.ph = cw.ready_ph
