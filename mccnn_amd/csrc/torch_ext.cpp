@@ -292,6 +292,10 @@ private:
 
 void count_wait(std::chrono::steady_clock::time_point t0);
 
+// how often a geometry nobody joined ordered its CALLER's stream behind its kernels when it died (debug_counters(): the
+// regression check of NOTES round-6 item 6c -- zero would mean the waits are being skipped again)
+std::atomic<long long> g_caller_orderings{0};
+
 struct Geo {
     mccnn_geometry_t* h = nullptr;
     std::atomic<int> issued{1};    // 0 while the helper thread has not issued this geometry's build yet
@@ -311,6 +315,11 @@ struct Geo {
     // handle, says whether it is set. Round 6: the waits below were skipped for exactly that stream, and a loop that prefetched
     // geometry it never consumed let the next hierarchy overwrite level tensors that builds / plan kernels were still reading.)
     bool has_caller = false;
+    void order_caller_behind(hipEvent_t ev) {
+        if (!(own_pool && has_caller && caller_waits())) return;
+        g_caller_orderings.fetch_add(1, std::memory_order_relaxed);
+        (void)hipStreamWaitEvent((hipStream_t)caller_stream, ev, 0);
+    }
     static bool caller_waits() { static const bool on = mccnn::debug_int("caller_join_off", 0) == 0; return on; }   // (fault injection: the round-6 bug back)
     Tensor buf, slot;
     std::vector<Tensor> keep, attached;
@@ -396,7 +405,7 @@ struct Geo {
                 (void)hipStreamWaitEvent((hipStream_t)alloc_stream, event, 0);
                 // own pool: the INPUTS (`keep`: tensors of the hierarchy, freed after this) are known to the allocator as
                 // used on the caller's stream only -- a build nobody joined has to be over before that stream moves on
-                if (own_pool && has_caller && caller_waits()) (void)hipStreamWaitEvent((hipStream_t)caller_stream, event, 0);
+                order_caller_behind(event);
             }
             if (total_pending && build_rc == 0) slot_ev = event;   // (the event of the build: the parked slot keeps it)
             else give_event(event);
@@ -412,14 +421,14 @@ struct Geo {
         if (plan_event) {
             if (plan_wait && buf.defined()) {
                 (void)hipStreamWaitEvent((hipStream_t)alloc_stream, plan_event, 0);
-                if (own_pool && has_caller && caller_waits()) (void)hipStreamWaitEvent((hipStream_t)caller_stream, plan_event, 0);
+                order_caller_behind(plan_event);
             }
             give_event(plan_event);
         }
         if (tr_event) {
             if (tr_wait && buf.defined()) {
                 (void)hipStreamWaitEvent((hipStream_t)alloc_stream, tr_event, 0);
-                if (own_pool && has_caller && caller_waits()) (void)hipStreamWaitEvent((hipStream_t)caller_stream, tr_event, 0);
+                order_caller_behind(tr_event);
             }
             give_event(tr_event);
         }
@@ -1524,6 +1533,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
     mod.def("shutdown_helpers", [] { for (int k = 0; k < 3; ++k) Issuer::get(k).retire(); },
             py::call_guard<py::gil_scoped_release>());
     mod.def("wait_ns", [] { return (long long)g_wait_ns.load(std::memory_order_relaxed); });
+    mod.def("debug_counters", [] {
+        py::dict d;
+        d["caller_orderings"] = (long long)g_caller_orderings.load(std::memory_order_relaxed);
+        return d;
+    });
     mod.def("debug_times", [](bool reset) {
         static const char* names[T_N] = {"fwd", "fwd_lib", "fwd_alloc", "bwd", "bwd_lib", "bwd_alloc", "bwd_views", "bwd_join"};
         py::dict d;

@@ -59,3 +59,44 @@ def test_script_that_ends_with_prefetched_work_in_flight(mc, cfg):
     assert out.returncode == 0, "rc %d\n" % out.returncode + out.stdout[-1500:] + out.stderr[-1500:]
     assert "terminate called" not in out.stderr, out.stderr[-1500:]
     assert "ms/step" in out.stdout
+
+
+def test_geometry_dropped_unconsumed_orders_the_default_stream(mc):
+    """Round 6, NOTES item 6c: a prefetched geometry nobody consumes borrows its hierarchy's level tensors; when it dies it has
+    to order the CALLER's stream -- the only consumer the allocator knows for them -- behind its build / plan kernels first. The
+    handle of the device's default stream is a null pointer and used to be taken for "no caller" (GPU memory faults in a
+    prefetch-and-drop loop). Deterministic check: a few prefetch-and-drop steps on the default stream must have enqueued such
+    orderings (the extension counts them)."""
+    code = r"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+import bench
+from mccnn_amd import native
+from mccnn_amd.workloads import CONFIGS
+torch.cuda.set_device(0)
+torch.autograd.set_multithreading_enabled(False)
+cw = bench.ConfigWorkload(CONFIGS["cfg2"], torch.device("cuda", 0))
+assert cw.set_pipeline(True, geometry=True)
+for _ in range(8):
+    cw.step()                      # (the builder learns the step's geometries and pieces)
+torch.cuda.synchronize()
+c0 = native._EXT.debug_counters()["caller_orderings"]
+assert torch.cuda.current_stream().cuda_stream == 0   # the default stream: a null handle
+for _ in range(6):                 # prefetch and drop: reset, adopt, request, prefetch_step -- no layer
+    cw.builder.reset()
+    cw.ph = cw.ready_ph
+    nxt = cw.hierarchy(cw.next_ph)
+    cw.request_next()
+    cw.builder.prefetch_step(nxt)
+    cw.ready_ph = nxt
+cw.builder.reset(); cw.builder.reset()
+torch.cuda.synchronize()
+import gc; gc.collect()
+c1 = native._EXT.debug_counters()["caller_orderings"]
+print("caller orderings", c1 - c0)
+assert c1 - c0 >= 6, (c0, c1)
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "caller orderings" in out.stdout
