@@ -16,7 +16,7 @@ from mccnn_amd.MCConvBuilder import PointHierarchy, ConvolutionBuilder  # noqa: 
 from mccnn_amd.workloads import CONFIGS, config_points  # noqa: E402
 
 torch.cuda.set_device(0)
-torch.autograd.set_multithreading_enabled(False)
+torch.autograd.set_multithreading_enabled(os.environ.get("AUTOGRAD_MT", "0") == "1")   # (AUTOGRAD_MT=1: the backward passes on the engine's device thread)
 STEPS = int(os.environ.get("SOAK_STEPS", "2000"))
 cfg = CONFIGS[os.environ.get("SOAK_CFG", "cfg2")]   # cfg4: absolute radii (box extent read back per hierarchy), 17 layers
 dev = torch.device("cuda", 0)

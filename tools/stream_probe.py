@@ -7,7 +7,7 @@ import torch
 import bench
 from mccnn_amd.workloads import CONFIGS
 torch.cuda.set_device(0)
-torch.autograd.set_multithreading_enabled(False)
+torch.autograd.set_multithreading_enabled(os.environ.get("AUTOGRAD_MT", "0") == "1")   # (AUTOGRAD_MT=1: the engine's device thread runs the backward passes)
 name = sys.argv[1]
 cw = bench.ConfigWorkload(CONFIGS[name], torch.device("cuda", 0))
 # reference: sequential step on the default stream
