@@ -544,6 +544,10 @@ def compute_aabb(inPts, inBatchIds, batchSize, scaleInv=True):
     lib = _lib.load()
     if CHECK_BATCH_IDS and check_batch_ids(bids, batchSize):
         check(-2, op)  # MCCNN_E_BATCHID
+    ext = _torch_ext()
+    if ext is not None and pts.is_cuda and bids.dim() in (1, 2):   # one C++ call (the op every hierarchy of a step starts with)
+        mn, mx = ext.compute_aabb(pts, bids.view(-1), int(batchSize), bool(scaleInv))
+        return mn, mx
     mn = torch.empty((batchSize, 3), dtype=torch.float32, device=pts.device)
     mx = torch.empty_like(mn)
     ws = _ws(lib.mccnn_compute_aabb_workspace_bytes(batchSize), pts.device)

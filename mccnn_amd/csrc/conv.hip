@@ -1347,7 +1347,12 @@ int mccnn_spatial_conv_fwd_bf16(const float* sorted_pts, const void* sorted_feat
 #ifndef MCCNN_BWD_WAVES
 #define MCCNN_BWD_WAVES 2048    // 256 CUs x 4 SIMDs x 2 resident waves
 #endif
-#define MCCNN_BWD_MIN_CHUNKS 8  // amortises the per-(wave, block) reduction of the 176 partial sums
+// chunks per wave at least: amortises the per-(wave, block) reduction of the 176 partial sums. 8 until round 6 -- which left a
+// short list on a tenth of the chip: BASELINE cfg0 (4 096 points, ~100 k edges, nb = 3) ran 200 waves of 24 sweeps each,
+// conv_bwd_mfma 46.0 us; with 2 (800 waves of 6 sweeps) 25.0 us, reduce_partials 4.8 us either way (rocprofv3, same box;
+// 1 measures the same as 2). Lists of >= 16 k chunks (1 M edges) are partitioned by MCCNN_BWD_WAVES as before.
+// MCCNN_DEBUG=bwd_min_chunks=N: A/B.
+#define MCCNN_BWD_MIN_CHUNKS 2
 
 // Larger inputs get R equal rounds of resident-many waves with <= 32-chunk slices (see f1_bwd_partition): the slices in
 // flight have to stay inside the Infinity Cache, the q-outer sweep re-reads them nb times.
@@ -1358,7 +1363,8 @@ static void bwd_partition(int e, int& cpw, int& waves) {
         const long long rounds = (cpw + 31) / 32;
         cpw = (int)((chunks + (long long)MCCNN_BWD_WAVES * rounds - 1) / ((long long)MCCNN_BWD_WAVES * rounds));
     }
-    if (cpw < MCCNN_BWD_MIN_CHUNKS) cpw = MCCNN_BWD_MIN_CHUNKS;
+    static const int minChunks = debug_int("bwd_min_chunks", MCCNN_BWD_MIN_CHUNKS);   // A/B switch, read once
+    if (cpw < minChunks) cpw = minChunks < 1 ? 1 : minChunks;
     waves = (int)((chunks + cpw - 1) / cpw);
     if (waves < 1) waves = 1;
 }

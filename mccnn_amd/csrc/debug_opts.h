@@ -19,7 +19,8 @@
 // counts inside the fill pass) geo_batch (1: the geometries prefetch_step starts go out as ONE batch, one launch per kernel kind)
 // plan_batch_all (1: the pieces of all of them as one batch as well; 0 = only geometries with a small plan)
 // aabb_one_max (8192: compute_aabb in one launch up to this many points) plan_large_batch (1: large plans join the batch)
-// plan_batch_sync (0: debugging -- a synchronisation and a stderr line per launch of the plan batch) caller_join_off (0: fault
+// plan_batch_sync (0: debugging -- a synchronisation and a stderr line per launch of the plan batch) bwd_min_chunks (2: 64-edge chunks per wave
+// of conv_bwd_mfma at least) caller_join_off (0: fault
 // injection -- a geometry nobody joined does not order the caller's stream behind its events: the round-6 lifetime bug).
 #pragma once
 #include <cstdio>
@@ -33,7 +34,7 @@ namespace mccnn {
     "small_off", "plan_small_off", "plan_small", "plan_small_max_l", "plan_mid_l", "plan_min_l", "rows_force",            \
     "rows_min_degree", "unsorted_max_points", "force_valu", "no_f1", "f1_x4_min_e", "f1_x4_waves_per_cu", "nw_lean",      \
     "nw_group", "nw_group_fill", "nw_lds_pad", "scan_bg_tiles", "issue_thread", "issue_inline", "job_delay_us",           \
-    "hier_trace", "geo_own_pool", "trace_terminate", "nw_fused", "geo_batch", "plan_batch_all", "aabb_one_max", "plan_large_batch", "plan_batch_sync", "caller_join_off",            \
+    "hier_trace", "geo_own_pool", "trace_terminate", "nw_fused", "geo_batch", "plan_batch_all", "aabb_one_max", "plan_large_batch", "plan_batch_sync", "caller_join_off", "bwd_min_chunks",            \
     /* Python side (mccnn_amd/_env.py) */                                                                                \
     "fuse_sort", "native_prefetch", "plan_prefetch", "plan_prefetch_max_e", "geo_prefetch_min", "mailbox_copy",           \
     "count_mailbox", "ecap_scale", "hier_pmode", "geo_trace", "nw_no_order"

@@ -1076,6 +1076,22 @@ Tensor conv(std::shared_ptr<Geo> geo, const Tensor& feats, const Tensor& w1, con
     return out;
 }
 
+// ComputeAabb through the extension (aabb_gpu.cc:22-86): the op a hierarchy without a prefetch request starts with, every
+// step -- one C++ call instead of the ctypes op (two allocations, a workspace look-up, ten argument conversions).
+std::vector<Tensor> compute_aabb(const Tensor& pts, const Tensor& bids, int64_t B, bool scale_inv) {
+    check_dev(pts, at::kFloat, "points");
+    check_dev(bids, at::kInt, "batch ids");
+    TORCH_CHECK(B > 0, "ComputeAabbOp expects a positive batch size");
+    const DevGuard device_guard((int)pts.device().index());
+    Tensor mn = at::empty({B, 3}, pts.options()), mx = at::empty({B, 3}, pts.options());
+    void* st = cur_stream(pts);
+    Tensor& ws = scratch(mccnn_compute_aabb_workspace_bytes((int)B), pts, st);
+    check(mccnn_compute_aabb(pts.data_ptr<float>(), bids.data_ptr<int>(), (int)pts.size(0), (int)B, scale_inv ? 1 : 0, mn.data_ptr<float>(),
+                             mx.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(), st),
+          "compute_aabb");
+    return {mn, mx};
+}
+
 std::atomic<long long> g_wait_ns{0};  // host time spent waiting for the level sizes (diagnostics: wait_ns())
 void count_wait(std::chrono::steady_clock::time_point t0) {
     if (t_helper_thread) return;   // (only the calling side's waits: a helper thread waiting is the point of having it)
@@ -1523,6 +1539,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
     mod.def("conv", &conv, py::arg("geometry"), py::arg("feats"), py::arg("w1"), py::arg("b1"), py::arg("w2"), py::arg("b2"),
             py::arg("w3"), py::arg("b3"), py::arg("fout"), py::arg("combin"), py::arg("avg"), py::arg("deterministic") = false,
             py::call_guard<py::gil_scoped_release>());
+    mod.def("compute_aabb", &compute_aabb);
     mod.def("hierarchy_levels", &hierarchy_levels, py::call_guard<py::gil_scoped_release>());
     py::class_<HierFuture, std::shared_ptr<HierFuture>>(mod, "HierarchyFuture")
         .def("result", &HierFuture::result)
