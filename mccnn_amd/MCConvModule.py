@@ -534,6 +534,9 @@ def _seed_num_cells(aabbMin, aabbMax, extent):
 
 
 # ---------------------------------------------------------------------------------------------
+_AABB_EXT = _env.debug("aabb_ext", True)   # A/B: 0 = the ctypes op
+
+
 def compute_aabb(inPts, inBatchIds, batchSize, scaleInv=True):
     """ComputeAabb (MCConvModuleSrc:20, aabb_gpu.cc:22-86). Non differentiable."""
     op = "ComputeAabbOp"
@@ -545,7 +548,7 @@ def compute_aabb(inPts, inBatchIds, batchSize, scaleInv=True):
     if CHECK_BATCH_IDS and check_batch_ids(bids, batchSize):
         check(-2, op)  # MCCNN_E_BATCHID
     ext = _torch_ext()
-    if ext is not None and pts.is_cuda and bids.dim() in (1, 2):   # one C++ call (the op every hierarchy of a step starts with)
+    if ext is not None and _AABB_EXT and pts.is_cuda and bids.dim() in (1, 2):   # one C++ call (the op every hierarchy of a step starts with)
         mn, mx = ext.compute_aabb(pts, bids.view(-1), int(batchSize), bool(scaleInv))
         return mn, mx
     mn = torch.empty((batchSize, 3), dtype=torch.float32, device=pts.device)

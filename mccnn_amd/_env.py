@@ -29,7 +29,7 @@ KNOWN_KEYS = (
     "hier_trace", "geo_own_pool", "trace_terminate", "nw_fused", "geo_batch", "plan_batch_all", "aabb_one_max", "plan_large_batch", "plan_batch_sync", "caller_join_off", "bwd_min_chunks",
     # Python side
     "fuse_sort", "native_prefetch", "plan_prefetch", "plan_prefetch_max_e", "geo_prefetch_min", "mailbox_copy",
-    "count_mailbox", "ecap_scale", "hier_pmode", "geo_trace", "nw_no_order")
+    "count_mailbox", "ecap_scale", "hier_pmode", "geo_trace", "nw_no_order", "aabb_ext")
 
 
 def _parse():

@@ -37,7 +37,7 @@ namespace mccnn {
     "hier_trace", "geo_own_pool", "trace_terminate", "nw_fused", "geo_batch", "plan_batch_all", "aabb_one_max", "plan_large_batch", "plan_batch_sync", "caller_join_off", "bwd_min_chunks",            \
     /* Python side (mccnn_amd/_env.py) */                                                                                \
     "fuse_sort", "native_prefetch", "plan_prefetch", "plan_prefetch_max_e", "geo_prefetch_min", "mailbox_copy",           \
-    "count_mailbox", "ecap_scale", "hier_pmode", "geo_trace", "nw_no_order"
+    "count_mailbox", "ecap_scale", "hier_pmode", "geo_trace", "nw_no_order", "aabb_ext"
 static const char* const kDebugKeys[] = {MCCNN_DEBUG_KEYS};
 
 // Parses MCCNN_DEBUG once; items whose key is not in kDebugKeys are reported on stderr (once per process and library).
