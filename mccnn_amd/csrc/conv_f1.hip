@@ -764,7 +764,10 @@ static void f1_bwd_partition(int e, int& cpw, int& waves) {
         const long long rounds = (cpw + 31) / 32;
         cpw = (int)((chunks + resident * rounds - 1) / (resident * rounds));
     }
-    if (cpw < 8) cpw = 8;  // amortises the per-(wave, block) reduction
+    // (at least 2 chunks per wave -- 8 until round 6, which ran a short list on a fraction of the chip: conv.hip MCCNN_BWD_MIN_CHUNKS;
+    // the same A/B key)
+    static const int minChunks = debug_int("bwd_min_chunks", 2);
+    if (cpw < minChunks) cpw = minChunks < 1 ? 1 : minChunks;
     waves = (int)((chunks + cpw - 1) / cpw);
     if (waves < 1) waves = 1;
 }
