@@ -34,7 +34,7 @@ namespace mccnn {
     "small_off", "plan_small_off", "plan_small", "plan_small_max_l", "plan_mid_l", "plan_min_l", "rows_force",            \
     "rows_min_degree", "unsorted_max_points", "force_valu", "no_f1", "f1_x4_min_e", "f1_x4_waves_per_cu", "nw_lean",      \
     "nw_group", "nw_group_fill", "nw_lds_pad", "scan_bg_tiles", "issue_thread", "issue_inline", "job_delay_us",           \
-    "hier_trace", "geo_own_pool", "trace_terminate", "nw_fused", "geo_batch", "plan_batch_all", "aabb_one_max", "plan_large_batch", "plan_batch_sync", "caller_join_off", "bwd_min_chunks",            \
+    "hier_trace", "geo_own_pool", "trace_terminate", "nw_fused", "geo_batch", "plan_batch_all", "aabb_one_max", "plan_large_batch", "plan_batch_sync", "caller_join_off", "bwd_min_chunks", "geo_arena",            \
     /* Python side (mccnn_amd/_env.py) */                                                                                \
     "fuse_sort", "native_prefetch", "plan_prefetch", "plan_prefetch_max_e", "geo_prefetch_min", "mailbox_copy",           \
     "count_mailbox", "ecap_scale", "hier_pmode", "geo_trace", "nw_no_order", "aabb_ext"

@@ -565,18 +565,47 @@ struct GeoBatch {
     bool background = false;
     std::vector<BatchEntry> entries;
     std::vector<PieceEntry> pieces;
+    // The buffers of a batch's geometries ([0]) and of their pieces ([1]) are views of ONE allocation each, sized by what the
+    // last batch took: a block that carries record_stream() costs its consumer's QUEUE an event record when it is freed
+    // (~3-5 us of queue time), and a step's geometries are all joined by the layers' stream and all die in one reset() --
+    // 28 blocks per step of BASELINE cfg4 were 0.14 ms of the queue that bounds the step; two blocks are two records.
+    Tensor arena[2];
+    int64_t arena_off[2] = {0, 0}, taken[2] = {0, 0};
 };
 thread_local GeoBatch t_geo_batch;
+thread_local int64_t t_arena_want[2] = {0, 0};   // bytes the last batch of this thread took from each arena (0: none yet)
+// `bytes` of the batch's arena `k` (allocated on first use under the caller's stream guard), or an undefined tensor: the
+// caller then allocates a block of its own (first batch, a batch larger than the last one, batches switched off)
+Tensor arena_take(int k, int64_t bytes, const Tensor& like) {
+    static const bool on = mccnn::debug_int("geo_arena", 1) != 0;   // A/B switch
+    GeoBatch& b = t_geo_batch;
+    const int64_t need = (bytes + 255) / 256 * 256;
+    b.taken[k] += need;
+    if (!on || !b.active || t_arena_want[k] <= 0) return Tensor();
+    if (!b.arena[k].defined()) {
+        b.arena[k] = at::empty({t_arena_want[k] + t_arena_want[k] / 16 + 4096}, like.options().dtype(at::kByte));
+        b.arena_off[k] = 0;
+    }
+    if (b.arena_off[k] + need > b.arena[k].numel()) return Tensor();
+    Tensor t = b.arena[k].narrow(0, b.arena_off[k], bytes);
+    b.arena_off[k] += need;
+    return t;
+}
 void begin_geometry_batch() {
     static const bool on = mccnn::debug_int("geo_batch", 1) != 0;   // A/B switch: 0 = every geometry its own chain
     t_geo_batch.active = on && Issuer::enabled();
     t_geo_batch.side = -1;
     t_geo_batch.entries.clear();
     t_geo_batch.pieces.clear();
+    for (int k = 0; k < 2; ++k) { t_geo_batch.arena[k] = Tensor(); t_geo_batch.arena_off[k] = t_geo_batch.taken[k] = 0; }
 }
 void end_geometry_batch() {
     GeoBatch& b = t_geo_batch;
     b.active = false;
+    for (int k = 0; k < 2; ++k) {   // (the views keep the arenas alive; the next batch is sized by this one)
+        if (b.taken[k] > 0) t_arena_want[k] = b.taken[k];
+        b.arena[k] = Tensor();
+    }
     if (b.entries.empty()) return;
     auto entries = std::make_shared<std::vector<BatchEntry>>(std::move(b.entries));
     b.entries.clear();
@@ -721,7 +750,8 @@ std::shared_ptr<Geo> build_geometry(const Tensor& pts, const Tensor& bids, const
         if (fork) fork_skipped = true;
         {
             const c10::hip::HIPStreamGuardMasqueradingAsCUDA own(as_torch_stream((void*)ss, (int)pts.device().index()));
-            g->buf = at::empty({(int64_t)bytes}, pts.options().dtype(at::kByte));
+            if (batched) g->buf = arena_take(0, (int64_t)bytes, pts);
+            if (!g->buf.defined()) g->buf = at::empty({(int64_t)bytes}, pts.options().dtype(at::kByte));
         }
         g->own_pool = true;
         g->caller_stream = stream;
@@ -857,7 +887,8 @@ void prebuild_async(std::shared_ptr<Geo> g, int what, bool avg) {
     Tensor block;
     if (g->own_pool) {
         const c10::hip::HIPStreamGuardMasqueradingAsCUDA own(as_torch_stream((void*)ss, (int)g->buf.device().index()));
-        block = at::empty({(int64_t)total}, g->buf.options());
+        if (small_batch) block = arena_take(1, (int64_t)total, g->buf);
+        if (!block.defined()) block = at::empty({(int64_t)total}, g->buf.options());
     } else {
         block = at::empty({(int64_t)total}, g->buf.options());
     }
@@ -1238,6 +1269,7 @@ hipStream_t hier_stream() {
 
 struct HierFuture {
     Tensor pts, bids, mn, mx, sizes;
+    Tensor block;                    // prefetched hierarchies: the ONE allocation mn .. lfeats are views of
     std::vector<Tensor> ints, flts;  // per level: sampled batch ids | sampled indexs | transformed indexs   and   sampled points
     // optional: the input feature rows of level 0 (no gradient, short rows) -- every level's rows are then gathered HERE,
     // on the hierarchy's stream, once the level sizes are known (GetSampledFeatures, MCConvBuilder.py:112-116), instead
@@ -1381,11 +1413,15 @@ struct HierFuture {
             joined = true;
             // (allocated on the hierarchy's stream, consumed on this one from here on)
             const c10::Stream consumer = as_torch_stream(consumer_stream, (int)pts.device().index());
-            mn.record_stream(consumer);
-            mx.record_stream(consumer);
-            for (Tensor& t : ints) t.record_stream(consumer);
-            for (Tensor& t : flts) t.record_stream(consumer);
-            for (Tensor& t : lfeats) t.record_stream(consumer);
+            if (block.defined()) {
+                block.record_stream(consumer);   // (every output is a view of it)
+            } else {
+                mn.record_stream(consumer);
+                mx.record_stream(consumer);
+                for (Tensor& t : ints) t.record_stream(consumer);
+                for (Tensor& t : flts) t.record_stream(consumer);
+                for (Tensor& t : lfeats) t.record_stream(consumer);
+            }
         }
         std::vector<std::vector<Tensor>> out;
         bool ok = true;
@@ -1446,24 +1482,38 @@ std::shared_ptr<HierFuture> hierarchy_prefetch(const Tensor& pts, const Tensor& 
         // used on that stream, so the build needs no ordering behind the calling stream for its memory (only for its
         // inputs, below); result() tells the allocator about the stream that consumes them (record_stream)
         const c10::hip::HIPStreamGuardMasqueradingAsCUDA own(as_torch_stream((void*)ss, (int)pts.device().index()));
-        f->mn = at::empty({B, 3}, pts.options());
-        f->mx = at::empty({B, 3}, pts.options());
-        f->sizes = at::empty({L + 1}, iopt);
-        for (int l = 0; l < L; ++l) {
-            f->ints.push_back(at::empty({3 * f->ca}, iopt));
-            f->flts.push_back(at::empty({3 * f->ca}, pts.options()));
-        }
+        bool with_feats = false;
         if (feats.has_value() && feats->defined()) {
             const Tensor& ft = *feats;
             // short rows without a gradient only (the input features of a network: ones, normals, colours): the level
             // buffers are sized by the capacity
             const int64_t row_bytes = ft.dim() == 2 ? ft.size(1) * (int64_t)ft.element_size() : 0;
-            if (ft.is_cuda() && ft.device() == pts.device() && ft.dim() == 2 && ft.size(0) == cap && ft.is_contiguous() &&
-                !ft.requires_grad() && row_bytes > 0 && row_bytes <= 256 && row_bytes % 4 == 0 &&
-                (ft.scalar_type() == at::kFloat || ft.scalar_type() == at::kBFloat16)) {
-                f->feats = ft;
-                for (int l = 0; l < L; ++l) f->lfeats.push_back(at::empty({f->ca * ft.size(1)}, ft.options()));
-            }
+            with_feats = ft.is_cuda() && ft.device() == pts.device() && ft.dim() == 2 && ft.size(0) == cap && ft.is_contiguous() &&
+                         !ft.requires_grad() && row_bytes > 0 && row_bytes <= 256 && row_bytes % 4 == 0 &&
+                         (ft.scalar_type() == at::kFloat || ft.scalar_type() == at::kBFloat16);
+            if (with_feats) f->feats = ft;
+        }
+        // ONE block for everything the hierarchy hands out (boxes, level sizes, every level's rows): a block that carries
+        // record_stream() costs its consumer's QUEUE an event record when it is freed (~3-5 us of queue time each; a dozen
+        // blocks per hierarchy were 0.08 ms of the calling queue per step of BASELINE cfg4) -- one block, one record
+        auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+        const int64_t bBox = al(B * 3 * 4), bSz = al((L + 1) * 4), bLvl = al(3 * f->ca * 4);
+        const int64_t bFt = with_feats ? al(f->ca * f->feats.size(1) * (int64_t)f->feats.element_size()) : 0;
+        f->block = at::empty({2 * bBox + bSz + L * (2 * bLvl + bFt)}, pts.options().dtype(at::kByte));
+        int64_t off = 0;
+        auto piece = [&](int64_t bytes, int64_t used, at::ScalarType dt) {
+            Tensor t = f->block.narrow(0, off, used).view(dt);
+            off += bytes;
+            return t;
+        };
+        f->mn = piece(bBox, B * 3 * 4, at::kFloat).view({B, 3});
+        f->mx = piece(bBox, B * 3 * 4, at::kFloat).view({B, 3});
+        f->sizes = piece(bSz, (L + 1) * 4, at::kInt);
+        for (int l = 0; l < L; ++l) {
+            f->ints.push_back(piece(bLvl, 3 * f->ca * 4, at::kInt));
+            f->flts.push_back(piece(bLvl, 3 * f->ca * 4, at::kFloat));
+            if (with_feats)
+                f->lfeats.push_back(piece(bFt, f->ca * f->feats.size(1) * (int64_t)f->feats.element_size(), f->feats.scalar_type()));
         }
     }
     f->alloc_stream = (void*)ss;

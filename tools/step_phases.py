@@ -20,6 +20,7 @@ N = 60
 NOCONV = os.environ.get("NOCONV") == "1"
 
 
+GQ = []     # main-queue events: start of reset() / after reset() / after the hierarchy's adoption
 HOLD = []   # (debugging, HOLD_GEOS=n: the geometries of the last n steps are kept alive -- is a fault tied to their release?)
 
 
@@ -34,10 +35,15 @@ def step(rec):
         cw.request_next()
         cw.builder.reset(); t.append(time.perf_counter()); t.append(time.perf_counter()); t.append(time.perf_counter())
     else:
+        gA = torch.cuda.Event(enable_timing=True); gA.record()
         cw.builder.reset(); t.append(time.perf_counter())
+        gB = torch.cuda.Event(enable_timing=True); gB.record()
         ph = cw.ph = cw.ready_ph
         nxt = cw.hierarchy(cw.next_ph); t.append(time.perf_counter())
+        gC = torch.cuda.Event(enable_timing=True); gC.record()
         cw.request_next(); t.append(time.perf_counter())
+        if rec:
+            GQ.append((gA, gB, gC))
     cw.builder.prefetch_step(nxt); t.append(time.perf_counter())
     cw.ready_ph = nxt
     e0 = torch.cuda.Event(enable_timing=True); e0.record()
@@ -53,6 +59,10 @@ def step(rec):
         ev.append((e0, e1))
 
 
+if os.environ.get("MAIN_STREAM") == "1":   # A/B: the loop on a stream of its own instead of the device's default (null) stream
+    _s = torch.cuda.Stream()
+    _ctx = torch.cuda.stream(_s)
+    _ctx.__enter__()
 for _ in range(10):
     step(False)
 torch.cuda.synchronize()
@@ -63,6 +73,11 @@ t_issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 span = sum(a.elapsed_time(b) for a, b in ev) / N
+if GQ and len(GQ) == len(ev):   # where the main QUEUE spends the time between two convolution chains (event records and waits
+    k = len(ev) - 1             # cost queue time too: a freed block that carries record_stream() is an event record)
+    gaps = [sum(ev[i][1].elapsed_time(GQ[i + 1][0]) for i in range(k)) / k, sum(g[0].elapsed_time(g[1]) for g in GQ) / len(GQ),
+            sum(g[1].elapsed_time(g[2]) for g in GQ) / len(GQ), sum(GQ[i][2].elapsed_time(ev[i][0]) for i in range(len(ev))) / len(ev)]
+    print("   main queue between two chains, ms: end of backward -> reset() %.3f, across reset() %.3f, across the adoption %.3f, request + prefetch_step -> first layer %.3f" % tuple(gaps))
 period = ev[0][0].elapsed_time(ev[-1][0]) / (N - 1)
 print("%s lag %d: %.3f ms/step (host issue %.3f); host phases ms: %s" % (name, lag, el / N * 1e3, t_issue / N * 1e3,
       ", ".join("%s %.3f" % (k, v / N * 1e3) for k, v in ph_t.items())))
