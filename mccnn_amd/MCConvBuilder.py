@@ -144,6 +144,12 @@ def _record_event(device_index=None):
     return ev
 
 
+# The op-by-op prefetch (prefetch_geometry() without the native executor) orders its side stream behind two events: the one a
+# PointHierarchy records when its last level is enqueued and the one of the last reset(). An event record is ~5 us of host time and
+# ~4 us of the calling QUEUE's -- two or three per step of a loop that never takes that path (the native executor forks its side
+# streams itself). They are recorded from the first op-by-op prefetch on; that first call waits for the calling stream instead.
+_SIDE_EVENTS = [False]
+
 _CUDA_OK = []   # torch.cuda.is_available(), asked once (reset() runs every step)
 
 
@@ -303,7 +309,7 @@ class PointHierarchy(_PlainState, torch.nn.Module):
 
     def __mark_ready__(self):
         """Everything the hierarchy holds (points of every level, boxes) has been enqueued on the current stream."""
-        if getattr(self.points_[0], "is_cuda", False):
+        if _SIDE_EVENTS[0] and getattr(self.points_[0], "is_cuda", False):
             self.__dict__["readyEvent_"] = _record_event(self.points_[0].device.index)
 
 
@@ -475,8 +481,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                         # are. The native executor, the default path, never needed it.)
                         t.record_stream(main)
             self.cacheGrids_, self.cacheNeighs_, self.cachePDFs_ = grids, neighs, pdfs
-        if _cuda_ok():
-            state["resetEvent_"] = _record_event()
+        state["resetEvent_"] = _record_event() if (_SIDE_EVENTS[0] and _cuda_ok()) else None
         if pf is not None:
             for kN, (kG, kP, centres, mn, mx, B, radius, rel) in self.prefetchTransposed_.items():
                 if kN in neighs and kG in grids and getattr(self.ops_, "_ops", 0) is None:
@@ -527,6 +532,7 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
             return
         if self.sideStream_ is None:
             self.sideStream_ = torch.cuda.Stream(device=pts.device)
+        _SIDE_EVENTS[0] = True   # (hierarchies and reset()s record their events from here on)
         pf = self.prefetched_
         grids, neighs, pdfs = (pf[0], pf[1], pf[2]) if pf is not None else ({}, {}, {})
         side = self.sideStream_
@@ -543,8 +549,11 @@ class ConvolutionBuilder(_PlainState, torch.nn.Module):
                 waited = True
                 break
             side.wait_event(ev)
-        if not waited and self.resetEvent_ is not None:
-            side.wait_event(self.resetEvent_)  # memory retired at the last reset() is reused only behind it
+        if not waited:   # memory retired at the last reset() is reused only behind it
+            if self.resetEvent_ is not None:
+                side.wait_event(self.resetEvent_)
+            else:
+                side.wait_stream(torch.cuda.current_stream())
         bg = None
         if getattr(self.ops_, "_ops", 0) is None:  # the HIP surface: this thread's launches are background work for a while
             from . import _lib as _mclib
